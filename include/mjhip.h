@@ -1,0 +1,257 @@
+/* mjhip.h — C ABI of the MI355X-native many-environment rigid-body stepper.
+ *
+ * This is the drop-in boundary for the hot path of HoangGiang93/mujoco_sim: the
+ * reference has no plugin interface; its boundary IS the handful of MuJoCo C
+ * calls made by the step driver plus the raw mjModel/mjData fields the wrapper
+ * dereferences.  Every entry point below names the reference
+ * call site (file:line under /root/reference) it replaces.
+ *
+ * Conventions
+ *   - plain C linkage, plain pointers and sizes, no exceptions across the ABI
+ *   - return 0 on success, negative mjh_error on failure; text in mjh_last_error()
+ *   - host I/O is double (mjtNum / ros_control handles are double,
+ *     include/mujoco_sim/mj_hw_interface.h:58-65); device arithmetic is fp32
+ *   - one stepping thread per engine (the reference serialises on `mtx`,
+ *     src/mj_main.cpp:82,112)
+ *   - "env" = one independent copy of the simulated world (the reference has
+ *     exactly one: the globals `m`,`d`, include/mujoco_sim/mj_model.h:29-30)
+ */
+#ifndef MJHIP_H_
+#define MJHIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ enums */
+
+enum mjh_error {
+  MJH_OK = 0,
+  MJH_ERR_ARG = -1,        /* bad argument / index out of range            */
+  MJH_ERR_NO_DEVICE = -2,  /* no HIP device / HIP runtime failure          */
+  MJH_ERR_CAPACITY = -3,   /* model exceeds what the kernels support       */
+  MJH_ERR_STATE = -4,      /* call sequence violation (step2 before step1) */
+  MJH_ERR_UNSUPPORTED = -5 /* feature not implemented                      */
+};
+
+/* joint types: values follow MuJoCo's mjtJoint so that jnt_type tables read by
+ * the wrapper (mj_sim.cpp:503-513, mj_ros.cpp:2164-2194) keep their meaning */
+enum mjh_joint { MJH_JNT_FREE = 0, MJH_JNT_BALL = 1, MJH_JNT_SLIDE = 2, MJH_JNT_HINGE = 3 };
+
+/* geom types: values follow mjtGeom (read by mj_ros.cpp:1968-2094) */
+enum mjh_geom {
+  MJH_GEOM_PLANE = 0, MJH_GEOM_HFIELD = 1, MJH_GEOM_SPHERE = 2, MJH_GEOM_CAPSULE = 3,
+  MJH_GEOM_ELLIPSOID = 4, MJH_GEOM_CYLINDER = 5, MJH_GEOM_BOX = 6, MJH_GEOM_MESH = 7
+};
+
+enum mjh_eq { MJH_EQ_CONNECT = 0, MJH_EQ_WELD = 1, MJH_EQ_JOINT = 2 };
+
+/* constraint row types (order of assembly: equality, friction loss, limit, contact) */
+enum mjh_cnstr {
+  MJH_CNSTR_EQUALITY = 0, MJH_CNSTR_FRICTION_DOF = 1, MJH_CNSTR_LIMIT_JOINT = 3,
+  MJH_CNSTR_CONTACT_FRICTIONLESS = 5, MJH_CNSTR_CONTACT_PYRAMIDAL = 6
+};
+
+/* disable-flag bits (subset of mjtDisableBit that this path honours) */
+enum mjh_disable {
+  MJH_DSBL_CONSTRAINT = 1 << 0, MJH_DSBL_EQUALITY = 1 << 1, MJH_DSBL_FRICTIONLOSS = 1 << 2,
+  MJH_DSBL_LIMIT = 1 << 3, MJH_DSBL_CONTACT = 1 << 4, MJH_DSBL_PASSIVE = 1 << 5,
+  MJH_DSBL_GRAVITY = 1 << 6, MJH_DSBL_WARMSTART = 1 << 8, MJH_DSBL_FILTERPARENT = 1 << 9,
+  MJH_DSBL_REFSAFE = 1 << 11, MJH_DSBL_EULERDAMP = 1 << 13
+};
+
+/* per-env parameter tables that may override the shared model (S24 draws box
+ * half-extents per env) */
+enum mjh_env_param {
+  MJH_EP_GEOM_SIZE = 0,       /* 3*ngeom  */
+  MJH_EP_GEOM_RBOUND = 1,     /* ngeom    */
+  MJH_EP_BODY_MASS = 2,       /* nbody    */
+  MJH_EP_BODY_INERTIA = 3,    /* 3*nbody  */
+  MJH_EP_BODY_INVWEIGHT0 = 4, /* 2*nbody  */
+  MJH_EP_DOF_INVWEIGHT0 = 5,  /* nv       */
+  MJH_EP_COUNT = 6
+};
+
+/* ------------------------------------------------------------ model (IR) */
+
+typedef struct mjh_option {
+  double timestep;          /* model/world/empty.xml:2 -> 0.005                */
+  double gravity[3];
+  int iterations;           /* main solver sweeps (MuJoCo default 100)         */
+  double tolerance;         /* scaled-improvement threshold (default 1e-8)     */
+  double impratio;          /* default 1                                       */
+  int noslip_iterations;    /* model/ontology/scene.xml:2-3 (not implemented)  */
+  int disableflags;         /* mjh_disable bits                                */
+} mjh_option;
+
+/* Compiled, topology-sorted model: the subset of mjModel this path reads
+ * (SURVEY.md §8-b B1 lists the fields the wrapper itself touches).  All arrays
+ * are owned by the model object; bodies are sorted parents-first, body 0 is
+ * the world. */
+typedef struct mjh_model {
+  /* sizes */
+  int nq, nv, nbody, njnt, ngeom, neq, npair, nM, ntree, nexclude;
+  int maxcon;  /* contact capacity per env (contacts beyond it are dropped + flagged) */
+  int maxefc;  /* constraint-row capacity per env                                     */
+  mjh_option opt;
+  double meaninertia; /* stat.meaninertia: mean diag(M(qpos0)) — scales solver tolerance */
+
+  /* bodies */
+  int *body_parentid, *body_rootid, *body_weldid, *body_jntadr, *body_jntnum;
+  int *body_dofadr, *body_dofnum, *body_treeid, *body_level, *body_geomadr, *body_geomnum;
+  double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia;
+  double *body_gravcomp, *body_invweight0; /* [2*nbody] translational, rotational */
+  /* joints */
+  int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
+  double *jnt_pos, *jnt_axis, *jnt_stiffness, *jnt_range, *jnt_margin;
+  double *jnt_solref, *jnt_solimp; /* [2*njnt], [5*njnt] limit parameters */
+  double *qpos0, *qpos_spring;
+  /* dofs */
+  int *dof_bodyid, *dof_jntid, *dof_parentid, *dof_Madr, *dof_treeid;
+  double *dof_armature, *dof_damping, *dof_frictionloss, *dof_invweight0;
+  double *dof_solref, *dof_solimp; /* friction-loss parameters */
+  /* trees (a tree = a child of the world with all its descendants; contiguous dofs) */
+  int *tree_dofadr, *tree_dofnum, *tree_bodyid;
+  /* geoms */
+  int *geom_type, *geom_bodyid, *geom_condim, *geom_contype, *geom_conaffinity, *geom_priority;
+  double *geom_pos, *geom_quat, *geom_size, *geom_rbound, *geom_friction;
+  double *geom_solmix, *geom_solref, *geom_solimp, *geom_margin, *geom_gap;
+  /* static candidate pair list: geom1 < geom2 by (type, then id) ordering rule of
+   * the narrow phase; filters (same/weld body, parent-child, contype/conaffinity,
+   * <exclude>) applied at compile time */
+  int *pair_geom1, *pair_geom2;
+  /* equality constraints */
+  int *eq_type, *eq_obj1id, *eq_obj2id, *eq_active;
+  double *eq_data, *eq_solref, *eq_solimp; /* [11*neq], [2*neq], [5*neq] */
+  /* name tables: resolved ONCE on the host (the reference calls mj_name2id per
+   * joint per step: mj_hw_interface.cpp:64,79; mj_sim.cpp:1060,1083-1146) */
+  char **body_names, **jnt_names, **geom_names;
+} mjh_model;
+
+/* ------------------------------------------------- model builder (host) */
+/* Replaces the model-ingest boundary mj_loadXML (include/mujoco_sim/mj_util.h:190)
+ * for programmatic scenes; an MJCF-subset loader is SURVEY.md §8-f F1. */
+typedef struct mjh_builder mjh_builder;
+
+mjh_builder* mjh_builder_create(void);
+void mjh_builder_destroy(mjh_builder*);
+void mjh_builder_set_option(mjh_builder*, const mjh_option*);
+void mjh_builder_get_option(const mjh_builder*, mjh_option*);
+void mjh_builder_set_capacity(mjh_builder*, int maxcon, int maxefc);
+/* returns body id (>0) ; parent 0 = world.  mass<=0 -> inertia inferred from geoms (density 1000) */
+int mjh_builder_add_body(mjh_builder*, const char* name, int parent, const double pos[3],
+                         const double quat[4], double gravcomp);
+int mjh_builder_set_inertial(mjh_builder*, int body, double mass, const double ipos[3],
+                             const double iquat[4], const double diaginertia[3]);
+/* range==NULL -> unlimited */
+int mjh_builder_add_joint(mjh_builder*, const char* name, int body, int type, const double pos[3],
+                          const double axis[3], const double range[2], double damping,
+                          double stiffness, double armature, double frictionloss, double ref);
+int mjh_builder_add_geom(mjh_builder*, const char* name, int body, int type, const double size[3],
+                         const double pos[3], const double quat[4], const double friction[3],
+                         int condim, int contype, int conaffinity, double density);
+int mjh_builder_add_exclude(mjh_builder*, int body1, int body2);
+int mjh_builder_add_eq_joint(mjh_builder*, int joint1, int joint2, const double polycoef[5]);
+/* compile: derives inertias, qpos0, invweight0, meaninertia, rbound, pair list */
+mjh_model* mjh_builder_compile(mjh_builder*);
+void mjh_model_destroy(mjh_model*);
+int mjh_name2id(const mjh_model*, int objtype /*0 body,1 joint,2 geom*/, const char* name);
+const char* mjh_id2name(const mjh_model*, int objtype, int id);
+
+/* ------------------------------------------------------ scene builders */
+/* SURVEY.md §8-d configs, as programmatic models.  `seed_base+env` seeds PCG32. */
+mjh_model* mjh_scene_s24(void); /* 4 free boxes in a walled pen on the empty.xml floor  */
+/* per-env S24 randomisation: fills qpos0[nenv*nq] and the per-env parameter tables
+ * (each out pointer may be NULL).  Box half-extents U[0.05,0.125]^3.             */
+int mjh_scene_s24_randomize(const mjh_model*, int env0, int nenv, unsigned seed_base,
+                            double* qpos, double* geom_size, double* geom_rbound,
+                            double* body_mass, double* body_inertia,
+                            double* body_invweight0, double* dof_invweight0);
+mjh_model* mjh_scene_pendulum(void);          /* model/test/pendulum.xml restated (C1/C5) */
+mjh_model* mjh_scene_arm7(int gravcomp);      /* 7-hinge Panda-like chain with limits (C3) */
+mjh_model* mjh_scene_boxpile(int nbox);       /* nbox free boxes over the floor (C2 family) */
+
+/* --------------------------------------------------------------- engine */
+typedef struct mjh_engine mjh_engine;
+
+/* Create an engine for `nenv` environments on HIP device `device`.
+ * Replaces mj_makeData (mj_sim.cpp:816,835; mj_ros.cpp:571) + init_malloc
+ * (mj_sim.cpp:563-571: ddq/dq/tau buffers).  `stream` is a hipStream_t (may be
+ * NULL for the default stream); all kernels are launched on it. */
+int mjh_create(const mjh_model* model, int nenv, int device, void* stream, mjh_engine** out);
+void mjh_destroy(mjh_engine*); /* mj_deleteData/mj_deleteModel, mj_main.cpp:232-233 */
+
+/* mj_step1 (mj_main.cpp:83): position + velocity stages, then the control
+ * callback MjSim::controller (mj_sim.cpp:1055-1077) as a built-in device stage. */
+int mjh_step1(mjh_engine*);
+/* mj_step2 (mj_main.cpp:108) then MjSim::set_odom_vels (mj_main.cpp:110). */
+int mjh_step2(mjh_engine*);
+/* n fused steps: step1 -> [inverse if with_inverse] -> step2, one launch per step
+ * window; with_inverse reproduces the per-step mj_inverse of MjHWInterface::read
+ * (mj_hw_interface.cpp:61). */
+int mjh_step(mjh_engine*, int nsteps, int with_inverse);
+/* mj_inverse (mj_hw_interface.cpp:61): fills qfrc_inverse. */
+int mjh_inverse(mjh_engine*);
+/* mj_forward (mj_ros.cpp:608,1421). */
+int mjh_forward(mjh_engine*);
+/* mj_mulM (mj_sim.cpp:1057): res = M(q)*vec for envs [env0, env0+n); host doubles [n*nv]. */
+int mjh_mulM(mjh_engine*, int env0, int n, const double* vec, double* res);
+int mjh_synchronize(mjh_engine*);
+
+/* MjHWInterface::write (mj_hw_interface.cpp:73-91): ddq = effort command
+ * (interpreted as desired acceleration), dq = velocity command; [n*nv] each,
+ * either may be NULL.  Consumed (and zeroed, mj_sim.cpp:1075-1076) by the next step1. */
+int mjh_set_cmd(mjh_engine*, int env0, int n, const double* ddq, const double* dq);
+/* which dofs are "controlled" (MjSim::controlled_joints, mj_sim.cpp:1058-1063): mask[nv] */
+int mjh_set_controlled_dofs(mjh_engine*, const int* mask);
+/* MjSim::set_odom_vels (mj_sim.cpp:1079-1153): dof ids of the 6 odom joints of one
+ * robot (-1 = absent) and the commanded twist per env [n*6] */
+int mjh_set_odom_dofs(mjh_engine*, const int lin_dof[3], const int ang_dof[3],
+                      const int ang_qpos[3]);
+int mjh_set_odom_vel(mjh_engine*, int env0, int n, const double* twist);
+
+/* MjHWInterface::read (mj_hw_interface.cpp:62-70) */
+int mjh_get_joint_state(mjh_engine*, int env0, int n, double* qpos, double* qvel,
+                        double* qfrc_inverse);
+/* d->xpos / d->xquat readers (mj_ros.cpp:2100-2147) */
+int mjh_get_body_state(mjh_engine*, int env0, int n, double* xpos, double* xquat);
+/* d->geom_xpos / geom_xmat readers (mj_ros.cpp:1968-2094) */
+int mjh_get_geom_state(mjh_engine*, int env0, int n, double* geom_xpos, double* geom_xmat);
+/* full state: time, qpos, qvel, qacc_warmstart (add_old_state, mj_sim.cpp:465-558) */
+int mjh_get_state(mjh_engine*, int env0, int n, double* time, double* qpos, double* qvel,
+                  double* qacc_warmstart);
+int mjh_set_state(mjh_engine*, int env0, int n, const double* time, const double* qpos,
+                  const double* qvel, const double* qacc_warmstart);
+/* other per-env vectors by name: "qacc","qfrc_bias","qfrc_applied","qfrc_passive",
+ * "qfrc_constraint","qfrc_inverse","qacc_smooth","energy"(2) */
+int mjh_get_field(mjh_engine*, const char* name, int env0, int n, double* out);
+/* per-env solver statistics: ncon, nefc, solver iterations, flags (bit0 contact overflow,
+ * bit1 row overflow, bit2 NaN reset) — int[n*4] */
+int mjh_get_stats(mjh_engine*, int env0, int n, int* out);
+/* contacts of ONE env (debug/parity): dist[maxcon], pos[3*maxcon], frame[9*maxcon], geom[2*maxcon]; returns ncon or <0 */
+int mjh_get_contacts(mjh_engine*, int env, double* dist, double* pos, double* frame, int* geom);
+
+/* per-env model parameters (enum mjh_env_param) */
+int mjh_set_env_param(mjh_engine*, int which, int env0, int n, const double* values);
+/* MjRos::reset_robot (mj_ros.cpp:569-609): back to qpos0 (or the per-env initial
+ * qpos set by mjh_set_initial_qpos), zero qvel/qacc/warmstart/time */
+int mjh_set_initial_qpos(mjh_engine*, int env0, int n, const double* qpos);
+int mjh_reset(mjh_engine*, const int* env_ids, int n);
+
+/* zero-copy export for the single ROS state topic: packs time(1)+qpos(nq)+qvel(nv)
+ * fp32 per env into a caller-provided DEVICE buffer [nenv*(1+nq+nv)] on the engine's
+ * stream (feeds the RCCL all-gather). */
+int mjh_export_state_device(mjh_engine*, void* d_out);
+int mjh_state_stride(const mjh_engine*);
+
+/* introspection */
+int mjh_nenv(const mjh_engine*);
+const mjh_model* mjh_engine_model(const mjh_engine*);
+int mjh_lds_bytes(const mjh_engine*);  /* dynamic LDS per env (= per workgroup) */
+const char* mjh_last_error(void);
+const char* mjh_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MJHIP_H_ */

@@ -1,0 +1,71 @@
+// dev_types.h — device-side model / state / LDS-layout descriptors shared by the
+// host API (engine.hip) and the stepping kernel (step_kernel.h).
+#pragma once
+
+// ---- device model: every table lives in one int buffer and one float buffer ----
+#define MJH_INT_TABLES(X)                                                                          \
+  X(body_parentid) X(body_rootid) X(body_jntadr) X(body_jntnum) X(body_dofadr) X(body_dofnum)      \
+  X(body_level) X(body_subtreesize) X(body_treeid) X(body_lastdof) X(jnt_type) X(jnt_qposadr)      \
+  X(jnt_dofadr) X(jnt_bodyid) X(jnt_limited) X(dof_bodyid) X(dof_jntid) X(dof_parentid)            \
+  X(dof_Madr) X(dof_treeid) X(tree_dofadr) X(tree_dofnum) X(geom_type) X(geom_bodyid)              \
+  X(geom_condim) X(pair_geom1) X(pair_geom2) X(pair_stageadr) X(eq_obj1id) X(eq_obj2id)            \
+  X(eq_active) X(fl_dof) X(gc_body) X(controlled) X(odom)
+
+#define MJH_FLT_TABLES(X)                                                                          \
+  X(body_pos) X(body_quat) X(body_ipos) X(body_iquat) X(body_mass) X(body_inertia)                 \
+  X(body_gravcomp) X(body_invweight0) X(jnt_pos) X(jnt_axis) X(jnt_stiffness) X(jnt_range)         \
+  X(jnt_margin) X(jnt_solref) X(jnt_solimp) X(qpos0) X(qpos_spring) X(dof_armature)                \
+  X(dof_damping) X(dof_frictionloss) X(dof_invweight0) X(dof_solref) X(dof_solimp) X(geom_pos)     \
+  X(geom_quat) X(geom_size) X(geom_rbound) X(geom_friction) X(geom_solmix) X(geom_solref)          \
+  X(geom_solimp) X(geom_margin) X(geom_gap) X(eq_data) X(eq_solref) X(eq_solimp)
+
+struct DModel {
+  const int* I;
+  const float* F;
+#define X(n) int o_##n;
+  MJH_INT_TABLES(X)
+  MJH_FLT_TABLES(X)
+#undef X
+  int nq, nv, nbody, njnt, ngeom, neq, npair, nM, ntree, maxcon, maxefc;
+  int nqp, nvp;        // padded row strides of the per-env state arrays (floats)
+  int maxlevel, nfl, ngc, rowW, nstage, has_damping, has_limits;
+  int iterations, disableflags;
+  float timestep, gravity[3], tolerance, impratio, meaninertia;
+};
+
+// per-env state in HBM (fp32, env-major rows)
+struct DState {
+  float *qpos, *qvel, *qacc, *qacc_ws, *qvel_ref, *qfrc_applied, *ddq, *dq, *qfrc_inverse, *time;
+  float *initial_qpos, *odom_vel;
+  int* stats;  // [nenv*4]: ncon, nefc, solver iterations, flags
+  // optional exports (may be null)
+  float *x_xpos, *x_xquat, *x_gpos, *x_gmat;
+  float *x_bias, *x_passive, *x_smooth, *x_constraint, *x_energy;
+  float *x_contacts;  // [n * maxcon * 17]
+  float *x_vec, *x_res;  // mulM in/out [n*nvp]
+  // per-env model parameter tables (null -> shared model)
+  const float *p_geom_size, *p_geom_rbound, *p_body_mass, *p_body_inertia, *p_body_invweight0, *p_dof_invweight0;
+};
+
+// LDS layout (float offsets into the dynamic shared array)
+#define MJH_LDS_ARRAYS(X)                                                                          \
+  X(qpos) X(qvel) X(qvref) X(ws) X(qacc) X(smooth) X(asmooth) X(passive) X(bias) X(applied)        \
+  X(tmpv) X(tmpv2) X(xpos) X(xquat) X(xmat) X(xipos) X(ximat) X(com) X(cinert) X(crb) X(cvel)      \
+  X(cacc) X(cfrc) X(cfrcsub) X(xanchor) X(xaxis) X(cdof) X(cdofdot) X(qM) X(qLD) X(qLDinv)          \
+  X(gpos) X(gmat) X(con) X(rowi) X(rowf) X(J) X(B)
+
+struct Lay {
+#define X(n) int n;
+  MJH_LDS_ARRAYS(X)
+#undef X
+  int total;  // floats
+};
+
+// kernel phases
+enum { PH_STEP1 = 1, PH_INV = 2, PH_STEP2 = 4, PH_NOINT = 8, PH_FKONLY = 16, PH_MULM = 32, PH_RESET = 64 };
+// export flags
+enum { XF_BODY = 1, XF_GEOM = 2, XF_CON = 4, XF_FORCE = 8 };
+
+#define CON_STRIDE 17  // dist, pos3, frame9, g1, g2, dim, includemargin
+#define ROWF_STRIDE 8  // KI, Bc, R, ARinv, aref, f, lo, hi
+#define ROWI_STRIDE 4  // type, id, sub(k*2+neg), trees packed (t1 | t2<<16, 0xffff = none)

@@ -1,0 +1,457 @@
+// engine.hip — host side of the C ABI (include/mjhip.h): device model upload, per-env state in
+// HBM (env-major fp32 rows padded to 128 B), kernel launches on the caller's HIP stream, and
+// double<->float marshalling for the mjData-style getters/setters the reference's ROS layer uses.
+// gfx950 only; there is no CPU fallback — every entry point fails loudly without a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mjhip.h"
+#include "step_kernel.h"
+
+void mjh_set_error(const std::string& s);  // model_builder.cpp
+
+#define HIPCHK(call)                                                                             \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      mjh_set_error(std::string(#call) + ": " + hipGetErrorString(e_));                          \
+      return MJH_ERR_NO_DEVICE;                                                                  \
+    }                                                                                            \
+  } while (0)
+
+struct mjh_engine {
+  const mjh_model* model = nullptr;
+  int nenv = 0, device = 0;
+  hipStream_t stream = nullptr;
+  DModel M{};
+  DState S{};
+  Lay L{};
+  int lds_bytes = 0;
+  int* dI = nullptr; float* dF = nullptr;
+  std::vector<int> hI;  // host copy of the int tables (controlled / odom are patched in place)
+  int o_controlled = 0, o_odom = 0;
+  std::vector<void*> allocs;
+  float* scratch = nullptr; size_t scratch_floats = 0;  // export staging
+  float* p_tables[MJH_EP_COUNT] = {nullptr};
+  bool step1_done = false;
+};
+
+static int pad32(int n) { return ((n + 31) / 32) * 32; }
+
+template <class T> static int dev_alloc(mjh_engine* e, T** p, size_t n, bool zero = true) {
+  void* q = nullptr;
+  HIPCHK(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+  if (zero) HIPCHK(hipMemsetAsync(q, 0, std::max<size_t>(n, 1) * sizeof(T), e->stream));
+  e->allocs.push_back(q);
+  *p = (T*)q;
+  return MJH_OK;
+}
+
+static int ensure_scratch(mjh_engine* e, size_t floats) {
+  if (floats <= e->scratch_floats) return MJH_OK;
+  if (e->scratch) { HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipFree(e->scratch)); }
+  HIPCHK(hipMalloc((void**)&e->scratch, floats * sizeof(float)));
+  e->scratch_floats = floats;
+  return MJH_OK;
+}
+
+static int launch(mjh_engine* e, int env0, int n, int nsteps, int ph, int xflags) {
+  if (n <= 0) return MJH_OK;
+  hipLaunchKernelGGL(mjh_step_kernel, dim3(n), dim3(64), (size_t)e->lds_bytes, e->stream, e->M, e->S, e->L, env0, nsteps, ph, xflags);
+  HIPCHK(hipGetLastError());
+  return MJH_OK;
+}
+
+static int pair_cap(int t1, int t2) {
+  if (t1 > t2) std::swap(t1, t2);
+  if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_BOX) return 4;
+  if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_CAPSULE) return 2;
+  if (t1 == MJH_GEOM_BOX && t2 == MJH_GEOM_BOX) return 8;
+  return 1;
+}
+
+extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream, mjh_engine** out) {
+  if (!m || nenv <= 0 || !out) { mjh_set_error("mjh_create: bad argument"); return MJH_ERR_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    mjh_set_error("mjh_create: no HIP device visible (this engine has no CPU fallback)");
+    return MJH_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) { mjh_set_error("mjh_create: bad device index"); return MJH_ERR_ARG; }
+  if (m->nv > 64) { mjh_set_error("mjh_create: nv > 64 not supported yet (PGS maps one dof per lane)"); return MJH_ERR_CAPACITY; }
+  if (m->maxefc > 256) { mjh_set_error("mjh_create: maxefc > 256 not supported yet"); return MJH_ERR_CAPACITY; }
+  HIPCHK(hipSetDevice(device));
+  mjh_engine* e = new mjh_engine();
+  e->model = m; e->nenv = nenv; e->device = device; e->stream = (hipStream_t)stream;
+
+  // ---- derived integer tables
+  const int nb = m->nbody, nv = m->nv, nj = m->njnt, ng = m->ngeom;
+  std::vector<int> subtreesize(nb, 1), lastdof(nb, -1), stageadr(m->npair, 0), fl_dof, gc_body, controlled(std::max(nv, 1), 0), odom(10, -1);
+  odom[9] = 0;
+  for (int b = nb - 1; b > 0; b--) subtreesize[m->body_parentid[b]] += subtreesize[b];
+  for (int b = 1; b < nb; b++) lastdof[b] = m->body_dofnum[b] ? m->body_dofadr[b] + m->body_dofnum[b] - 1 : lastdof[m->body_parentid[b]];
+  int nstage = 0, maxlevel = 0, rowW = 1;
+  for (int b = 0; b < nb; b++) maxlevel = std::max(maxlevel, m->body_level[b]);
+  auto treenum = [&](int b) { int t = m->body_treeid[b]; return t >= 0 ? m->tree_dofnum[t] : 0; };
+  for (int i = 0; i < m->npair; i++) {
+    int g1 = m->pair_geom1[i], g2 = m->pair_geom2[i];
+    stageadr[i] = nstage; nstage += pair_cap(m->geom_type[g1], m->geom_type[g2]);
+    int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
+    int w = treenum(b1) + ((m->body_treeid[b1] != m->body_treeid[b2]) ? treenum(b2) : 0);
+    rowW = std::max(rowW, w);
+  }
+  for (int t = 0; t < m->ntree; t++) rowW = std::max(rowW, m->tree_dofnum[t]);
+  for (int q = 0; q < m->neq; q++) {
+    int j1 = m->eq_obj1id[q], j2 = m->eq_obj2id[q];
+    int t1 = m->dof_treeid[m->jnt_dofadr[j1]], w = m->tree_dofnum[t1];
+    if (j2 >= 0) { int t2 = m->dof_treeid[m->jnt_dofadr[j2]]; if (t2 != t1) w += m->tree_dofnum[t2]; }
+    rowW = std::max(rowW, w);
+  }
+  rowW = ((rowW + 3) / 4) * 4;
+  bool has_damping = false, has_limits = false;
+  for (int d = 0; d < nv; d++) { if (m->dof_frictionloss[d] > 0) fl_dof.push_back(d); if (m->dof_damping[d] > 0) has_damping = true; }
+  for (int j = 0; j < nj; j++) if (m->jnt_limited[j]) has_limits = true;
+  for (int b = 1; b < nb; b++) if (m->body_gravcomp[b] != 0) gc_body.push_back(b);
+
+  // ---- pack tables
+  std::vector<int> I; std::vector<float> F;
+  DModel& M = e->M;
+  auto addI = [&](const int* p, size_t n) { int o = (int)I.size(); I.insert(I.end(), p, p + n); while (I.size() % 4) I.push_back(0); return o; };
+  auto addF = [&](const double* p, size_t n) { int o = (int)F.size(); for (size_t i = 0; i < n; i++) F.push_back((float)p[i]); while (F.size() % 4) F.push_back(0); return o; };
+#define PI(name, n) M.o_##name = addI(m->name, (size_t)(n))
+#define PF(name, n) M.o_##name = addF(m->name, (size_t)(n))
+  PI(body_parentid, nb); PI(body_rootid, nb); PI(body_jntadr, nb); PI(body_jntnum, nb); PI(body_dofadr, nb); PI(body_dofnum, nb);
+  PI(body_level, nb); M.o_body_subtreesize = addI(subtreesize.data(), nb); PI(body_treeid, nb); M.o_body_lastdof = addI(lastdof.data(), nb);
+  PI(jnt_type, nj); PI(jnt_qposadr, nj); PI(jnt_dofadr, nj); PI(jnt_bodyid, nj); PI(jnt_limited, nj);
+  PI(dof_bodyid, nv); PI(dof_jntid, nv); PI(dof_parentid, nv); PI(dof_Madr, nv); PI(dof_treeid, nv);
+  PI(tree_dofadr, m->ntree); PI(tree_dofnum, m->ntree);
+  PI(geom_type, ng); PI(geom_bodyid, ng); PI(geom_condim, ng);
+  PI(pair_geom1, m->npair); PI(pair_geom2, m->npair); M.o_pair_stageadr = addI(stageadr.data(), m->npair);
+  PI(eq_obj1id, m->neq); PI(eq_obj2id, m->neq); PI(eq_active, m->neq);
+  M.o_fl_dof = addI(fl_dof.data(), fl_dof.size()); M.o_gc_body = addI(gc_body.data(), gc_body.size());
+  M.o_controlled = e->o_controlled = addI(controlled.data(), controlled.size());
+  M.o_odom = e->o_odom = addI(odom.data(), odom.size());
+  PF(body_pos, 3*nb); PF(body_quat, 4*nb); PF(body_ipos, 3*nb); PF(body_iquat, 4*nb); PF(body_mass, nb); PF(body_inertia, 3*nb);
+  PF(body_gravcomp, nb); PF(body_invweight0, 2*nb);
+  PF(jnt_pos, 3*nj); PF(jnt_axis, 3*nj); PF(jnt_stiffness, nj); PF(jnt_range, 2*nj); PF(jnt_margin, nj); PF(jnt_solref, 2*nj); PF(jnt_solimp, 5*nj);
+  PF(qpos0, m->nq); PF(qpos_spring, m->nq);
+  PF(dof_armature, nv); PF(dof_damping, nv); PF(dof_frictionloss, nv); PF(dof_invweight0, nv); PF(dof_solref, 2*nv); PF(dof_solimp, 5*nv);
+  PF(geom_pos, 3*ng); PF(geom_quat, 4*ng); PF(geom_size, 3*ng); PF(geom_rbound, ng); PF(geom_friction, 3*ng); PF(geom_solmix, ng);
+  PF(geom_solref, 2*ng); PF(geom_solimp, 5*ng); PF(geom_margin, ng); PF(geom_gap, ng);
+  PF(eq_data, 11*m->neq); PF(eq_solref, 2*m->neq); PF(eq_solimp, 5*m->neq);
+#undef PI
+#undef PF
+  M.nq = m->nq; M.nv = nv; M.nbody = nb; M.njnt = nj; M.ngeom = ng; M.neq = m->neq; M.npair = m->npair; M.nM = m->nM; M.ntree = m->ntree;
+  M.maxcon = std::max(m->maxcon, 1); M.maxefc = std::max(m->maxefc, 1);
+  M.nqp = pad32(m->nq); M.nvp = pad32(std::max(nv, 1));
+  M.maxlevel = maxlevel; M.nfl = (int)fl_dof.size(); M.ngc = (int)gc_body.size(); M.rowW = rowW; M.nstage = nstage;
+  M.has_damping = has_damping; M.has_limits = has_limits;
+  M.iterations = m->opt.iterations; M.disableflags = m->opt.disableflags;
+  M.timestep = (float)m->opt.timestep; for (int k = 0; k < 3; k++) M.gravity[k] = (float)m->opt.gravity[k];
+  M.tolerance = (float)m->opt.tolerance; M.impratio = (float)m->opt.impratio; M.meaninertia = (float)m->meaninertia;
+  e->hI = I;
+  if (dev_alloc(e, &e->dI, I.size(), false) || dev_alloc(e, &e->dF, F.size(), false)) { delete e; return MJH_ERR_NO_DEVICE; }
+  HIPCHK(hipMemcpyAsync(e->dI, I.data(), I.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->dF, F.data(), F.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  M.I = e->dI; M.F = e->dF;
+
+  // ---- LDS layout (float offsets, 16-byte aligned)
+  {
+    Lay& L = e->L; int off = 0;
+    auto put = [&](int n) { int o = off; off += ((std::max(n, 1) + 3) / 4) * 4; return o; };
+    const int rows = M.maxefc + 1;
+    int jsz = rows * rowW;
+    if (2 * jsz < nstage * RAW_STRIDE) jsz = (nstage * RAW_STRIDE + 1) / 2;
+    L.qpos = put(m->nq);
+    L.qvel = put(nv); L.qvref = put(nv); L.ws = put(nv); L.qacc = put(nv); L.smooth = put(nv); L.asmooth = put(nv); L.passive = put(nv);
+    L.bias = put(nv); L.applied = put(nv); L.tmpv = put(nv); L.tmpv2 = put(nv);
+    L.xpos = put(3*nb); L.xquat = put(4*nb); L.xmat = put(9*nb); L.xipos = put(3*nb); L.ximat = put(9*nb); L.com = put(3*nb);
+    L.cinert = put(10*nb); L.crb = put(10*nb); L.cvel = put(6*nb); L.cacc = put(6*nb); L.cfrc = put(6*nb); L.cfrcsub = put(6*nb);
+    L.xanchor = put(3*nj); L.xaxis = put(3*nj); L.cdof = put(6*nv); L.cdofdot = put(6*nv);
+    L.qM = put(m->nM); L.qLD = put(m->nM); L.qLDinv = put(nv);
+    L.gpos = put(3*ng); L.gmat = put(9*ng);
+    L.con = put(M.maxcon * CON_STRIDE); L.rowi = put(rows * ROWI_STRIDE); L.rowf = put(rows * ROWF_STRIDE);
+    L.J = put(jsz); L.B = put(jsz);
+    L.total = off;
+    e->lds_bytes = off * (int)sizeof(float);
+  }
+  if (e->lds_bytes > 160 * 1024) {
+    mjh_set_error("mjh_create: per-env working set exceeds the 160 KiB LDS of one CU (" + std::to_string(e->lds_bytes) + " B)");
+    mjh_destroy(e); return MJH_ERR_CAPACITY;
+  }
+  HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+
+  // ---- per-env state
+  DState& S = e->S;
+  const size_t nq_all = (size_t)nenv * M.nqp, nv_all = (size_t)nenv * M.nvp;
+  int rc = 0;
+  rc |= dev_alloc(e, &S.qpos, nq_all); rc |= dev_alloc(e, &S.initial_qpos, nq_all);
+  rc |= dev_alloc(e, &S.qvel, nv_all); rc |= dev_alloc(e, &S.qacc, nv_all); rc |= dev_alloc(e, &S.qacc_ws, nv_all);
+  rc |= dev_alloc(e, &S.qvel_ref, nv_all); rc |= dev_alloc(e, &S.qfrc_applied, nv_all); rc |= dev_alloc(e, &S.ddq, nv_all);
+  rc |= dev_alloc(e, &S.dq, nv_all); rc |= dev_alloc(e, &S.qfrc_inverse, nv_all);
+  rc |= dev_alloc(e, &S.time, (size_t)nenv); rc |= dev_alloc(e, &S.odom_vel, (size_t)nenv * 6); rc |= dev_alloc(e, &S.stats, (size_t)nenv * 4);
+  rc |= dev_alloc(e, &S.x_bias, nv_all); rc |= dev_alloc(e, &S.x_passive, nv_all); rc |= dev_alloc(e, &S.x_smooth, nv_all);
+  rc |= dev_alloc(e, &S.x_constraint, nv_all); rc |= dev_alloc(e, &S.x_energy, (size_t)nenv * 2);
+  if (rc) { mjh_destroy(e); return MJH_ERR_NO_DEVICE; }
+  // initial state = qpos0 for every env
+  {
+    std::vector<float> q0(nq_all, 0.0f);
+    for (int en = 0; en < nenv; en++) for (int i = 0; i < m->nq; i++) q0[(size_t)en * M.nqp + i] = (float)m->qpos0[i];
+    HIPCHK(hipMemcpyAsync(S.qpos, q0.data(), nq_all * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(S.initial_qpos, q0.data(), nq_all * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  *out = e;
+  return MJH_OK;
+}
+
+extern "C" void mjh_destroy(mjh_engine* e) {
+  if (!e) return;
+  (void)hipStreamSynchronize(e->stream);
+  for (void* p : e->allocs) (void)hipFree(p);
+  if (e->scratch) (void)hipFree(e->scratch);
+  delete e;
+}
+
+#define ENG(e) if (!(e)) { mjh_set_error("null engine"); return MJH_ERR_ARG; }
+#define RANGE(e, env0, n) if ((env0) < 0 || (n) < 0 || (env0) + (n) > (e)->nenv) { mjh_set_error("env range out of bounds"); return MJH_ERR_ARG; }
+
+extern "C" int mjh_step1(mjh_engine* e) { ENG(e); e->step1_done = true; return launch(e, 0, e->nenv, 1, PH_STEP1, XF_FORCE); }
+extern "C" int mjh_inverse(mjh_engine* e) { ENG(e); return launch(e, 0, e->nenv, 1, PH_INV, XF_FORCE); }
+extern "C" int mjh_step2(mjh_engine* e) {
+  ENG(e);
+  if (!e->step1_done) { mjh_set_error("mjh_step2 called before mjh_step1"); return MJH_ERR_STATE; }
+  e->step1_done = false;
+  return launch(e, 0, e->nenv, 1, PH_STEP2, XF_FORCE);
+}
+extern "C" int mjh_forward(mjh_engine* e) { ENG(e); return launch(e, 0, e->nenv, 1, PH_STEP1 | PH_NOINT, XF_FORCE); }
+extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
+  ENG(e);
+  if (nsteps <= 0) return MJH_OK;
+  return launch(e, 0, e->nenv, nsteps, PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0), 0);
+}
+extern "C" int mjh_synchronize(mjh_engine* e) { ENG(e); HIPCHK(hipStreamSynchronize(e->stream)); return MJH_OK; }
+
+// ---- host <-> device marshalling helpers (double on the host side, padded fp32 rows on the device)
+static int put_rows(mjh_engine* e, float* dst, int stride, int width, int env0, int n, const double* src) {
+  if (!src || n == 0) return MJH_OK;
+  std::vector<float> tmp((size_t)n * stride, 0.0f);
+  for (int i = 0; i < n; i++) for (int k = 0; k < width; k++) tmp[(size_t)i * stride + k] = (float)src[(size_t)i * width + k];
+  HIPCHK(hipMemcpyAsync(dst + (size_t)env0 * stride, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return MJH_OK;
+}
+static int get_rows(mjh_engine* e, const float* src, int stride, int width, int env0, int n, double* dst) {
+  if (!dst || n == 0) return MJH_OK;
+  std::vector<float> tmp((size_t)n * stride);
+  HIPCHK(hipMemcpyAsync(tmp.data(), src + (size_t)env0 * stride, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (int i = 0; i < n; i++) for (int k = 0; k < width; k++) dst[(size_t)i * width + k] = (double)tmp[(size_t)i * stride + k];
+  return MJH_OK;
+}
+
+extern "C" int mjh_set_cmd(mjh_engine* e, int env0, int n, const double* ddq, const double* dq) {
+  ENG(e); RANGE(e, env0, n);
+  int rc = put_rows(e, e->S.ddq, e->M.nvp, e->M.nv, env0, n, ddq);
+  if (rc) return rc;
+  return put_rows(e, e->S.dq, e->M.nvp, e->M.nv, env0, n, dq);
+}
+
+static int patch_int_table(mjh_engine* e, int off, const int* vals, int n) {
+  for (int i = 0; i < n; i++) e->hI[off + i] = vals[i];
+  HIPCHK(hipMemcpyAsync(e->dI + off, e->hI.data() + off, n * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return MJH_OK;
+}
+extern "C" int mjh_set_controlled_dofs(mjh_engine* e, const int* mask) {
+  ENG(e); if (!mask) return MJH_ERR_ARG;
+  return patch_int_table(e, e->o_controlled, mask, e->M.nv);
+}
+extern "C" int mjh_set_odom_dofs(mjh_engine* e, const int lin[3], const int ang[3], const int angq[3]) {
+  ENG(e);
+  int t[10];
+  for (int k = 0; k < 3; k++) { t[k] = lin ? lin[k] : -1; t[3+k] = ang ? ang[k] : -1; t[6+k] = angq ? angq[k] : -1; }
+  t[9] = 0; for (int k = 0; k < 6; k++) if (t[k] >= 0) t[9] = 1;
+  return patch_int_table(e, e->o_odom, t, 10);
+}
+extern "C" int mjh_set_odom_vel(mjh_engine* e, int env0, int n, const double* twist) {
+  ENG(e); RANGE(e, env0, n);
+  return put_rows(e, e->S.odom_vel, 6, 6, env0, n, twist);
+}
+
+extern "C" int mjh_get_joint_state(mjh_engine* e, int env0, int n, double* qpos, double* qvel, double* qfrc_inverse) {
+  ENG(e); RANGE(e, env0, n);
+  int rc = get_rows(e, e->S.qpos, e->M.nqp, e->M.nq, env0, n, qpos);
+  if (!rc) rc = get_rows(e, e->S.qvel, e->M.nvp, e->M.nv, env0, n, qvel);
+  if (!rc) rc = get_rows(e, e->S.qfrc_inverse, e->M.nvp, e->M.nv, env0, n, qfrc_inverse);
+  return rc;
+}
+
+// position-stage recompute for a range of envs with export pointers set
+static int fk_export(mjh_engine* e, int env0, int n, double* a, int wa, double* b, int wb, bool geoms) {
+  const size_t fa = (size_t)n * wa, fb = (size_t)n * wb;
+  int rc = ensure_scratch(e, fa + fb);
+  if (rc) return rc;
+  DState saved = e->S;
+  if (geoms) { e->S.x_gpos = e->scratch; e->S.x_gmat = e->scratch + fa; } else { e->S.x_xpos = e->scratch; e->S.x_xquat = e->scratch + fa; }
+  rc = launch(e, env0, n, 1, PH_FKONLY, geoms ? XF_GEOM : XF_BODY);
+  e->S = saved;
+  if (rc) return rc;
+  if (!rc) rc = get_rows(e, e->scratch, wa, wa, 0, n, a);
+  if (!rc) rc = get_rows(e, e->scratch + fa, wb, wb, 0, n, b);
+  return rc;
+}
+extern "C" int mjh_get_body_state(mjh_engine* e, int env0, int n, double* xpos, double* xquat) {
+  ENG(e); RANGE(e, env0, n);
+  return fk_export(e, env0, n, xpos, 3 * e->M.nbody, xquat, 4 * e->M.nbody, false);
+}
+extern "C" int mjh_get_geom_state(mjh_engine* e, int env0, int n, double* gpos, double* gmat) {
+  ENG(e); RANGE(e, env0, n);
+  return fk_export(e, env0, n, gpos, 3 * e->M.ngeom, gmat, 9 * e->M.ngeom, true);
+}
+
+extern "C" int mjh_get_state(mjh_engine* e, int env0, int n, double* time, double* qpos, double* qvel, double* ws) {
+  ENG(e); RANGE(e, env0, n);
+  int rc = get_rows(e, e->S.time, 1, 1, env0, n, time);
+  if (!rc) rc = get_rows(e, e->S.qpos, e->M.nqp, e->M.nq, env0, n, qpos);
+  if (!rc) rc = get_rows(e, e->S.qvel, e->M.nvp, e->M.nv, env0, n, qvel);
+  if (!rc) rc = get_rows(e, e->S.qacc_ws, e->M.nvp, e->M.nv, env0, n, ws);
+  return rc;
+}
+extern "C" int mjh_set_state(mjh_engine* e, int env0, int n, const double* time, const double* qpos, const double* qvel, const double* ws) {
+  ENG(e); RANGE(e, env0, n);
+  int rc = put_rows(e, e->S.time, 1, 1, env0, n, time);
+  if (!rc) rc = put_rows(e, e->S.qpos, e->M.nqp, e->M.nq, env0, n, qpos);
+  if (!rc) rc = put_rows(e, e->S.qvel, e->M.nvp, e->M.nv, env0, n, qvel);
+  if (!rc) rc = put_rows(e, e->S.qacc_ws, e->M.nvp, e->M.nv, env0, n, ws);
+  return rc;
+}
+
+extern "C" int mjh_get_field(mjh_engine* e, const char* name, int env0, int n, double* out) {
+  ENG(e); RANGE(e, env0, n);
+  if (!name) return MJH_ERR_ARG;
+  const std::string s(name);
+  const int nvp = e->M.nvp, nv = e->M.nv;
+  if (s == "qacc") return get_rows(e, e->S.qacc, nvp, nv, env0, n, out);
+  if (s == "qfrc_bias") return get_rows(e, e->S.x_bias, nvp, nv, env0, n, out);
+  if (s == "qfrc_passive") return get_rows(e, e->S.x_passive, nvp, nv, env0, n, out);
+  if (s == "qacc_smooth") return get_rows(e, e->S.x_smooth, nvp, nv, env0, n, out);
+  if (s == "qfrc_constraint") return get_rows(e, e->S.x_constraint, nvp, nv, env0, n, out);
+  if (s == "qfrc_applied") return get_rows(e, e->S.qfrc_applied, nvp, nv, env0, n, out);
+  if (s == "qfrc_inverse") return get_rows(e, e->S.qfrc_inverse, nvp, nv, env0, n, out);
+  if (s == "qacc_warmstart") return get_rows(e, e->S.qacc_ws, nvp, nv, env0, n, out);
+  if (s == "energy") return get_rows(e, e->S.x_energy, 2, 2, env0, n, out);
+  mjh_set_error("mjh_get_field: unknown field " + s);
+  return MJH_ERR_ARG;
+}
+
+extern "C" int mjh_get_stats(mjh_engine* e, int env0, int n, int* out) {
+  ENG(e); RANGE(e, env0, n);
+  HIPCHK(hipMemcpyAsync(out, e->S.stats + (size_t)env0 * 4, (size_t)n * 4 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return MJH_OK;
+}
+
+extern "C" int mjh_get_contacts(mjh_engine* e, int env, double* dist, double* pos, double* frame, int* geom) {
+  ENG(e); RANGE(e, env, 1);
+  const int mc = e->M.maxcon;
+  int rc = ensure_scratch(e, (size_t)mc * CON_STRIDE);
+  if (rc) return rc;
+  // snapshot the rows the kernel would overwrite, run the position stage only, restore
+  DState saved = e->S;
+  e->S.x_contacts = e->scratch;
+  // PH_STEP1 without state change is not available; use a dedicated read-only pass: phases = 0 runs
+  // position stage + velocity stage on qvel_ref and stores the same state back.
+  rc = launch(e, env, 1, 1, 0, XF_CON);
+  e->S = saved;
+  if (rc) return rc;
+  std::vector<float> tmp((size_t)mc * CON_STRIDE);
+  int st[4];
+  HIPCHK(hipMemcpyAsync(tmp.data(), e->scratch, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(st, e->S.stats + (size_t)env * 4, sizeof st, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const int ncon = st[0];
+  for (int c = 0; c < ncon; c++) {
+    const float* r = tmp.data() + (size_t)c * CON_STRIDE;
+    if (dist) dist[c] = r[0];
+    if (pos) for (int k = 0; k < 3; k++) pos[3*c+k] = r[1+k];
+    if (frame) for (int k = 0; k < 9; k++) frame[9*c+k] = r[4+k];
+    if (geom) { int g1, g2; std::memcpy(&g1, r + 13, 4); std::memcpy(&g2, r + 14, 4); geom[2*c] = g1; geom[2*c+1] = g2; }
+  }
+  return ncon;
+}
+
+extern "C" int mjh_mulM(mjh_engine* e, int env0, int n, const double* vec, double* res) {
+  ENG(e); RANGE(e, env0, n);
+  if (!vec || !res) return MJH_ERR_ARG;
+  const int nvp = e->M.nvp;
+  int rc = ensure_scratch(e, (size_t)2 * n * nvp);
+  if (rc) return rc;
+  rc = put_rows(e, e->scratch, nvp, e->M.nv, 0, n, vec);
+  if (rc) return rc;
+  DState saved = e->S;
+  e->S.x_vec = e->scratch; e->S.x_res = e->scratch + (size_t)n * nvp;
+  rc = launch(e, env0, n, 1, PH_MULM, 0);
+  e->S = saved;
+  if (rc) return rc;
+  return get_rows(e, e->scratch + (size_t)n * nvp, nvp, e->M.nv, 0, n, res);
+}
+
+extern "C" int mjh_set_env_param(mjh_engine* e, int which, int env0, int n, const double* values) {
+  ENG(e); RANGE(e, env0, n);
+  if (which < 0 || which >= MJH_EP_COUNT || !values) return MJH_ERR_ARG;
+  const mjh_model* m = e->model;
+  const int widths[MJH_EP_COUNT] = {3 * m->ngeom, m->ngeom, m->nbody, 3 * m->nbody, 2 * m->nbody, m->nv};
+  const double* defaults[MJH_EP_COUNT] = {m->geom_size, m->geom_rbound, m->body_mass, m->body_inertia, m->body_invweight0, m->dof_invweight0};
+  const int w = widths[which];
+  if (!e->p_tables[which]) {
+    float* p = nullptr;
+    int rc = dev_alloc(e, &p, (size_t)e->nenv * w, false);
+    if (rc) return rc;
+    std::vector<float> init((size_t)e->nenv * w);
+    for (int en = 0; en < e->nenv; en++) for (int k = 0; k < w; k++) init[(size_t)en * w + k] = (float)defaults[which][k];
+    HIPCHK(hipMemcpyAsync(p, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->p_tables[which] = p;
+    const float** slots[MJH_EP_COUNT] = {&e->S.p_geom_size, &e->S.p_geom_rbound, &e->S.p_body_mass, &e->S.p_body_inertia, &e->S.p_body_invweight0, &e->S.p_dof_invweight0};
+    *slots[which] = p;
+  }
+  return put_rows(e, e->p_tables[which], w, w, env0, n, values);
+}
+
+extern "C" int mjh_set_initial_qpos(mjh_engine* e, int env0, int n, const double* qpos) {
+  ENG(e); RANGE(e, env0, n);
+  return put_rows(e, e->S.initial_qpos, e->M.nqp, e->M.nq, env0, n, qpos);
+}
+
+extern "C" int mjh_reset(mjh_engine* e, const int* env_ids, int n) {
+  ENG(e);
+  if (!env_ids) return launch(e, 0, e->nenv, 1, PH_RESET, 0);
+  for (int i = 0; i < n; i++) {
+    if (env_ids[i] < 0 || env_ids[i] >= e->nenv) { mjh_set_error("mjh_reset: env id out of range"); return MJH_ERR_ARG; }
+    int rc = launch(e, env_ids[i], 1, 1, PH_RESET, 0);
+    if (rc) return rc;
+  }
+  return MJH_OK;
+}
+
+extern "C" int mjh_state_stride(const mjh_engine* e) { return e ? 1 + e->M.nq + e->M.nv : 0; }
+extern "C" int mjh_export_state_device(mjh_engine* e, void* d_out) {
+  ENG(e); if (!d_out) return MJH_ERR_ARG;
+  const size_t total = (size_t)e->nenv * (1 + e->M.nq + e->M.nv);
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(mjh_export_kernel, dim3(blocks), dim3(256), 0, e->stream, e->S, (float*)d_out, e->nenv, e->M.nq, e->M.nv, e->M.nqp, e->M.nvp);
+  HIPCHK(hipGetLastError());
+  return MJH_OK;
+}
+
+extern "C" int mjh_nenv(const mjh_engine* e) { return e ? e->nenv : 0; }
+extern "C" const mjh_model* mjh_engine_model(const mjh_engine* e) { return e ? e->model : nullptr; }
+extern "C" int mjh_lds_bytes(const mjh_engine* e) { return e ? e->lds_bytes : 0; }
+extern "C" const char* mjh_version(void) { return "mjhip 0.1 (gfx950)"; }

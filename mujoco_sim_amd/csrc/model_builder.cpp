@@ -1,0 +1,643 @@
+// model_builder.cpp — host-side model compiler for the mjhip engine.
+//
+// Replaces, for programmatic scenes, the model-ingest boundary of the reference
+// (mj_loadXML at include/mujoco_sim/mj_util.h:190, called from
+// MjSim::load_tmp_model, src/mujoco_sim/mj_sim.cpp:804-845).  It produces the
+// flat, topology-sorted mjh_model the device engine and the test oracle both read.
+// Derived constants (inertia from geoms at density 1000, qpos0, invweight0,
+// meaninertia, bounding radii, the static candidate pair list) are computed here
+// in fp64 with a Jacobian-based mass matrix — deliberately a different formulation
+// from the CRBA used on the device, so the two cross-check each other in tests.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../../include/mjhip.h"
+#include "hmath.h"
+
+namespace {
+
+struct BBody {
+  std::string name; int parent; double pos[3], quat[4]; double gravcomp;
+  bool explicit_inertial = false; double mass = 0, ipos[3] = {0,0,0}, iquat[4] = {1,0,0,0}, inertia[3] = {0,0,0};
+};
+struct BJoint {
+  std::string name; int body, type; double pos[3], axis[3]; bool limited; double range[2];
+  double damping, stiffness, armature, frictionloss, ref;
+};
+struct BGeom {
+  std::string name; int body, type; double size[3], pos[3], quat[4], friction[3];
+  int condim, contype, conaffinity; double density;
+};
+struct BEq { int j1, j2; double poly[5]; };
+
+}  // namespace
+
+struct mjh_builder {
+  mjh_option opt;
+  int maxcon = 0, maxefc = 0;
+  std::vector<BBody> bodies;
+  std::vector<BJoint> joints;
+  std::vector<BGeom> geoms;
+  std::vector<std::pair<int,int>> excludes;
+  std::vector<BEq> eqs;
+};
+
+static thread_local std::string g_err;
+extern "C" const char* mjh_last_error(void) { return g_err.c_str(); }
+void mjh_set_error(const std::string& s) { g_err = s; }
+
+static void default_option(mjh_option* o) {
+  o->timestep = 0.002; o->gravity[0] = 0; o->gravity[1] = 0; o->gravity[2] = -9.81;
+  o->iterations = 100; o->tolerance = 1e-8; o->impratio = 1; o->noslip_iterations = 0; o->disableflags = 0;
+}
+
+extern "C" mjh_builder* mjh_builder_create(void) {
+  mjh_builder* b = new mjh_builder();
+  default_option(&b->opt);
+  BBody w; w.name = "world"; w.parent = -1; w.pos[0] = w.pos[1] = w.pos[2] = 0;
+  w.quat[0] = 1; w.quat[1] = w.quat[2] = w.quat[3] = 0; w.gravcomp = 0; w.explicit_inertial = true;
+  b->bodies.push_back(w);
+  return b;
+}
+extern "C" void mjh_builder_destroy(mjh_builder* b) { delete b; }
+extern "C" void mjh_builder_set_option(mjh_builder* b, const mjh_option* o) { b->opt = *o; }
+extern "C" void mjh_builder_get_option(const mjh_builder* b, mjh_option* o) { *o = b->opt; }
+extern "C" void mjh_builder_set_capacity(mjh_builder* b, int maxcon, int maxefc) { b->maxcon = maxcon; b->maxefc = maxefc; }
+
+extern "C" int mjh_builder_add_body(mjh_builder* b, const char* name, int parent, const double pos[3],
+                                    const double quat[4], double gravcomp) {
+  if (parent < 0 || parent >= (int)b->bodies.size()) { g_err = "add_body: bad parent"; return MJH_ERR_ARG; }
+  BBody x; x.name = name ? name : ""; x.parent = parent;
+  for (int i = 0; i < 3; i++) x.pos[i] = pos ? pos[i] : 0;
+  if (quat) { for (int i = 0; i < 4; i++) x.quat[i] = quat[i]; hm::normalize4(x.quat); }
+  else { x.quat[0] = 1; x.quat[1] = x.quat[2] = x.quat[3] = 0; }
+  x.gravcomp = gravcomp;
+  b->bodies.push_back(x);
+  return (int)b->bodies.size() - 1;
+}
+
+extern "C" int mjh_builder_set_inertial(mjh_builder* b, int body, double mass, const double ipos[3],
+                                        const double iquat[4], const double diaginertia[3]) {
+  if (body <= 0 || body >= (int)b->bodies.size()) { g_err = "set_inertial: bad body"; return MJH_ERR_ARG; }
+  BBody& x = b->bodies[body];
+  x.explicit_inertial = true; x.mass = mass;
+  for (int i = 0; i < 3; i++) { x.ipos[i] = ipos ? ipos[i] : 0; x.inertia[i] = diaginertia[i]; }
+  if (iquat) { for (int i = 0; i < 4; i++) x.iquat[i] = iquat[i]; hm::normalize4(x.iquat); }
+  return MJH_OK;
+}
+
+extern "C" int mjh_builder_add_joint(mjh_builder* b, const char* name, int body, int type, const double pos[3],
+                                     const double axis[3], const double range[2], double damping,
+                                     double stiffness, double armature, double frictionloss, double ref) {
+  if (body <= 0 || body >= (int)b->bodies.size()) { g_err = "add_joint: bad body"; return MJH_ERR_ARG; }
+  if (type < 0 || type > 3) { g_err = "add_joint: bad type"; return MJH_ERR_ARG; }
+  BJoint j; j.name = name ? name : ""; j.body = body; j.type = type;
+  for (int i = 0; i < 3; i++) { j.pos[i] = pos ? pos[i] : 0; j.axis[i] = axis ? axis[i] : (i == 2 ? 1 : 0); }
+  hm::normalize3(j.axis);
+  j.limited = range != nullptr; j.range[0] = range ? range[0] : 0; j.range[1] = range ? range[1] : 0;
+  j.damping = damping; j.stiffness = stiffness; j.armature = armature; j.frictionloss = frictionloss; j.ref = ref;
+  b->joints.push_back(j);
+  return (int)b->joints.size() - 1;
+}
+
+extern "C" int mjh_builder_add_geom(mjh_builder* b, const char* name, int body, int type, const double size[3],
+                                    const double pos[3], const double quat[4], const double friction[3],
+                                    int condim, int contype, int conaffinity, double density) {
+  if (body < 0 || body >= (int)b->bodies.size()) { g_err = "add_geom: bad body"; return MJH_ERR_ARG; }
+  BGeom g; g.name = name ? name : ""; g.body = body; g.type = type;
+  for (int i = 0; i < 3; i++) { g.size[i] = size ? size[i] : 0; g.pos[i] = pos ? pos[i] : 0; }
+  if (quat) { for (int i = 0; i < 4; i++) g.quat[i] = quat[i]; hm::normalize4(g.quat); }
+  else { g.quat[0] = 1; g.quat[1] = g.quat[2] = g.quat[3] = 0; }
+  // MuJoCo defaults: friction 1 0.005 0.0001, condim 3, contype/conaffinity 1, density 1000
+  g.friction[0] = friction ? friction[0] : 1.0; g.friction[1] = friction ? friction[1] : 0.005;
+  g.friction[2] = friction ? friction[2] : 0.0001;
+  g.condim = condim > 0 ? condim : 3; g.contype = contype >= 0 ? contype : 1;
+  g.conaffinity = conaffinity >= 0 ? conaffinity : 1; g.density = density > 0 ? density : 1000.0;
+  b->geoms.push_back(g);
+  return (int)b->geoms.size() - 1;
+}
+
+extern "C" int mjh_builder_add_exclude(mjh_builder* b, int b1, int b2) { b->excludes.push_back({b1, b2}); return MJH_OK; }
+extern "C" int mjh_builder_add_eq_joint(mjh_builder* b, int j1, int j2, const double poly[5]) {
+  BEq e; e.j1 = j1; e.j2 = j2; for (int i = 0; i < 5; i++) e.poly[i] = poly[i];
+  b->eqs.push_back(e); return (int)b->eqs.size() - 1;
+}
+
+// ---- geom mass properties (density * volume; inertia about geom centre, geom frame)
+static bool geom_massprops(const BGeom& g, double* mass, double I[3]) {
+  const double pi = 3.14159265358979323846;
+  const double* s = g.size;
+  switch (g.type) {
+    case MJH_GEOM_SPHERE: {
+      double m = g.density * 4.0 / 3.0 * pi * s[0]*s[0]*s[0];
+      *mass = m; I[0] = I[1] = I[2] = 0.4 * m * s[0]*s[0]; return true; }
+    case MJH_GEOM_BOX: {
+      double m = g.density * 8 * s[0]*s[1]*s[2];
+      *mass = m;
+      I[0] = m / 3.0 * (s[1]*s[1] + s[2]*s[2]); I[1] = m / 3.0 * (s[0]*s[0] + s[2]*s[2]);
+      I[2] = m / 3.0 * (s[0]*s[0] + s[1]*s[1]); return true; }
+    case MJH_GEOM_CYLINDER: {
+      double r = s[0], h = s[1];  // half-height
+      double m = g.density * pi * r*r * 2*h;
+      *mass = m; I[0] = I[1] = m * (3*r*r + 4*h*h) / 12.0; I[2] = 0.5 * m * r*r; return true; }
+    case MJH_GEOM_CAPSULE: {
+      double r = s[0], h = s[1];
+      double mc = g.density * pi * r*r * 2*h;            // cylinder part
+      double ms = g.density * 4.0 / 3.0 * pi * r*r*r;     // two hemispheres = one sphere
+      *mass = mc + ms;
+      double Izz = 0.5 * mc * r*r + 0.4 * ms * r*r;
+      double Ixx = mc * (3*r*r + 4*h*h) / 12.0 + ms * (0.4*r*r + h*h + 0.75*r*h);
+      I[0] = I[1] = Ixx; I[2] = Izz; return true; }
+    default: return false;  // plane etc: no mass
+  }
+}
+
+static double geom_rbound(int type, const double* s) {
+  switch (type) {
+    case MJH_GEOM_SPHERE: return s[0];
+    case MJH_GEOM_CAPSULE: return s[0] + s[1];
+    case MJH_GEOM_CYLINDER: return std::sqrt(s[0]*s[0] + s[1]*s[1]);
+    case MJH_GEOM_BOX: return std::sqrt(s[0]*s[0] + s[1]*s[1] + s[2]*s[2]);
+    default: return 0;  // plane: unbounded, handled by the pair routine
+  }
+}
+extern "C" double mjh_geom_rbound(int type, const double* size) { return geom_rbound(type, size); }
+
+// which geom-type pairs have a narrow-phase routine (types ordered t1<=t2)
+static bool pair_supported(int t1, int t2) {
+  if (t1 > t2) std::swap(t1, t2);
+  auto is = [](int t, int a) { return t == a; };
+  if (is(t1, MJH_GEOM_PLANE))
+    return t2 == MJH_GEOM_SPHERE || t2 == MJH_GEOM_CAPSULE || t2 == MJH_GEOM_BOX || t2 == MJH_GEOM_CYLINDER;
+  if (is(t1, MJH_GEOM_SPHERE)) return t2 == MJH_GEOM_SPHERE || t2 == MJH_GEOM_CAPSULE || t2 == MJH_GEOM_BOX;
+  if (is(t1, MJH_GEOM_CAPSULE)) return t2 == MJH_GEOM_CAPSULE || t2 == MJH_GEOM_BOX;
+  if (is(t1, MJH_GEOM_BOX)) return t2 == MJH_GEOM_BOX;
+  return false;
+}
+static int pair_maxcon(int t1, int t2) {
+  if (t1 > t2) std::swap(t1, t2);
+  if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_BOX) return 4;
+  if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_CAPSULE) return 2;
+  if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_CYLINDER) return 3;
+  if (t1 == MJH_GEOM_BOX && t2 == MJH_GEOM_BOX) return 8;
+  if (t1 == MJH_GEOM_CAPSULE && t2 == MJH_GEOM_BOX) return 2;
+  return 1;
+}
+
+template <class T> static T* dup(const std::vector<T>& v) {
+  T* p = (T*)std::calloc(v.size() + 1, sizeof(T));
+  std::copy(v.begin(), v.end(), p);
+  return p;
+}
+static char** dupnames(const std::vector<std::string>& v) {
+  char** p = (char**)std::calloc(v.size() + 1, sizeof(char*));
+  for (size_t i = 0; i < v.size(); i++) {
+    p[i] = (char*)std::malloc(v[i].size() + 1);
+    std::memcpy(p[i], v[i].c_str(), v[i].size() + 1);
+  }
+  return p;
+}
+
+extern "C" mjh_model* mjh_builder_compile(mjh_builder* B) {
+  const int nb0 = (int)B->bodies.size();
+  // ---- depth-first body order (children of a body in insertion order): trees get contiguous dofs
+  std::vector<std::vector<int>> children(nb0);
+  for (int i = 1; i < nb0; i++) children[B->bodies[i].parent].push_back(i);
+  std::vector<int> order, stack;
+  stack.push_back(0);
+  while (!stack.empty()) {
+    int b = stack.back(); stack.pop_back(); order.push_back(b);
+    for (int k = (int)children[b].size() - 1; k >= 0; k--) stack.push_back(children[b][k]);
+  }
+  std::vector<int> newid(nb0);
+  for (int i = 0; i < nb0; i++) newid[order[i]] = i;
+  const int nbody = nb0;
+
+  std::vector<int> body_parentid(nbody), body_rootid(nbody), body_weldid(nbody), body_jntadr(nbody), body_jntnum(nbody),
+      body_dofadr(nbody), body_dofnum(nbody), body_treeid(nbody), body_level(nbody), body_geomadr(nbody), body_geomnum(nbody);
+  std::vector<double> body_pos(3*nbody), body_quat(4*nbody), body_ipos(3*nbody), body_iquat(4*nbody), body_mass(nbody),
+      body_inertia(3*nbody), body_gravcomp(nbody), body_invweight0(2*nbody);
+  std::vector<std::string> body_names(nbody);
+
+  // joints / geoms grouped by (new) body id, insertion order preserved
+  std::vector<int> jorder, gorder;
+  for (int nbid = 0; nbid < nbody; nbid++) {
+    int ob = order[nbid];
+    for (int j = 0; j < (int)B->joints.size(); j++) if (B->joints[j].body == ob) jorder.push_back(j);
+    for (int g = 0; g < (int)B->geoms.size(); g++) if (B->geoms[g].body == ob) gorder.push_back(g);
+  }
+  const int njnt = (int)jorder.size(), ngeom = (int)gorder.size();
+  std::vector<int> jnewid(B->joints.size());
+  for (int j = 0; j < njnt; j++) jnewid[jorder[j]] = j;
+
+  std::vector<int> jnt_type(njnt), jnt_qposadr(njnt), jnt_dofadr(njnt), jnt_bodyid(njnt), jnt_limited(njnt);
+  std::vector<double> jnt_pos(3*njnt), jnt_axis(3*njnt), jnt_stiffness(njnt), jnt_range(2*njnt), jnt_margin(njnt),
+      jnt_solref(2*njnt), jnt_solimp(5*njnt);
+  std::vector<std::string> jnt_names(njnt);
+  int nq = 0, nv = 0;
+  static const int QN[4] = {7, 4, 1, 1}, VN[4] = {6, 3, 1, 1};
+  for (int j = 0; j < njnt; j++) {
+    const BJoint& J = B->joints[jorder[j]];
+    jnt_type[j] = J.type; jnt_qposadr[j] = nq; jnt_dofadr[j] = nv; jnt_bodyid[j] = newid[J.body];
+    jnt_limited[j] = J.limited ? 1 : 0;
+    for (int k = 0; k < 3; k++) { jnt_pos[3*j+k] = J.pos[k]; jnt_axis[3*j+k] = J.axis[k]; }
+    jnt_stiffness[j] = J.stiffness; jnt_range[2*j] = J.range[0]; jnt_range[2*j+1] = J.range[1]; jnt_margin[j] = 0;
+    jnt_solref[2*j] = 0.02; jnt_solref[2*j+1] = 1;
+    const double si[5] = {0.9, 0.95, 0.001, 0.5, 2};
+    for (int k = 0; k < 5; k++) jnt_solimp[5*j+k] = si[k];
+    jnt_names[j] = J.name;
+    nq += QN[J.type]; nv += VN[J.type];
+  }
+
+  std::vector<double> qpos0(nq), qpos_spring(nq);
+  std::vector<int> dof_bodyid(nv), dof_jntid(nv), dof_parentid(nv), dof_Madr(nv), dof_treeid(nv);
+  std::vector<double> dof_armature(nv), dof_damping(nv), dof_frictionloss(nv), dof_invweight0(nv), dof_solref(2*nv), dof_solimp(5*nv);
+
+  // bodies
+  {
+    int jcur = 0, gcur = 0;
+    for (int i = 0; i < nbody; i++) {
+      const BBody& X = B->bodies[order[i]];
+      body_names[i] = X.name;
+      body_parentid[i] = i == 0 ? 0 : newid[X.parent];
+      body_level[i] = i == 0 ? 0 : body_level[body_parentid[i]] + 1;
+      for (int k = 0; k < 3; k++) body_pos[3*i+k] = X.pos[k];
+      for (int k = 0; k < 4; k++) body_quat[4*i+k] = X.quat[k];
+      body_gravcomp[i] = X.gravcomp;
+      body_jntadr[i] = jcur; int cnt = 0;
+      while (jcur < njnt && jnt_bodyid[jcur] == i) { jcur++; cnt++; }
+      body_jntnum[i] = cnt; if (!cnt) body_jntadr[i] = -1;
+      body_dofadr[i] = cnt ? jnt_dofadr[body_jntadr[i]] : -1;
+      int dn = 0; for (int j = 0; j < cnt; j++) dn += VN[jnt_type[body_jntadr[i]+j]];
+      body_dofnum[i] = dn;
+      body_geomadr[i] = gcur; int gc = 0;
+      while (gcur < ngeom && newid[B->geoms[gorder[gcur]].body] == i) { gcur++; gc++; }
+      body_geomnum[i] = gc; if (!gc) body_geomadr[i] = -1;
+      body_weldid[i] = (i == 0) ? 0 : (cnt ? i : body_weldid[body_parentid[i]]);
+      body_rootid[i] = (i == 0) ? 0 : (body_parentid[i] == 0 ? i : body_rootid[body_parentid[i]]);
+    }
+  }
+  // free joint sanity: must be the only joint of a child of the world
+  for (int j = 0; j < njnt; j++) if (jnt_type[j] == MJH_JNT_FREE) {
+    int b = jnt_bodyid[j];
+    if (body_parentid[b] != 0 || body_jntnum[b] != 1) { g_err = "free joint must be the only joint of a top-level body"; return nullptr; }
+  }
+
+  // geoms
+  std::vector<int> geom_type(ngeom), geom_bodyid(ngeom), geom_condim(ngeom), geom_contype(ngeom), geom_conaffinity(ngeom), geom_priority(ngeom);
+  std::vector<double> geom_pos(3*ngeom), geom_quat(4*ngeom), geom_size(3*ngeom), geom_rb(ngeom), geom_friction(3*ngeom),
+      geom_solmix(ngeom), geom_solref(2*ngeom), geom_solimp(5*ngeom), geom_margin(ngeom), geom_gap(ngeom);
+  std::vector<std::string> geom_names(ngeom);
+  for (int g = 0; g < ngeom; g++) {
+    const BGeom& G = B->geoms[gorder[g]];
+    geom_names[g] = G.name; geom_type[g] = G.type; geom_bodyid[g] = newid[G.body];
+    geom_condim[g] = G.condim; geom_contype[g] = G.contype; geom_conaffinity[g] = G.conaffinity; geom_priority[g] = 0;
+    for (int k = 0; k < 3; k++) { geom_pos[3*g+k] = G.pos[k]; geom_size[3*g+k] = G.size[k]; geom_friction[3*g+k] = G.friction[k]; }
+    for (int k = 0; k < 4; k++) geom_quat[4*g+k] = G.quat[k];
+    geom_rb[g] = geom_rbound(G.type, G.size);
+    geom_solmix[g] = 1; geom_solref[2*g] = 0.02; geom_solref[2*g+1] = 1;
+    const double si[5] = {0.9, 0.95, 0.001, 0.5, 2};
+    for (int k = 0; k < 5; k++) geom_solimp[5*g+k] = si[k];
+    geom_margin[g] = 0; geom_gap[g] = 0;
+  }
+
+  // ---- inertial properties from geoms where not given explicitly
+  for (int i = 1; i < nbody; i++) {
+    const BBody& X = B->bodies[order[i]];
+    if (X.explicit_inertial) {
+      body_mass[i] = X.mass;
+      for (int k = 0; k < 3; k++) { body_ipos[3*i+k] = X.ipos[k]; body_inertia[3*i+k] = X.inertia[k]; }
+      for (int k = 0; k < 4; k++) body_iquat[4*i+k] = X.iquat[k];
+      continue;
+    }
+    double M = 0, com[3] = {0,0,0};
+    for (int g = 0; g < ngeom; g++) if (geom_bodyid[g] == i) {
+      double m, I[3]; if (!geom_massprops(B->geoms[gorder[g]], &m, I)) continue;
+      M += m; for (int k = 0; k < 3; k++) com[k] += m * geom_pos[3*g+k];
+    }
+    if (M <= 0) {  // massless (e.g. a frame body): leave zero; dynamics will need armature
+      body_mass[i] = 0; body_iquat[4*i] = 1; continue;
+    }
+    for (int k = 0; k < 3; k++) com[k] /= M;
+    double It[9] = {0};
+    for (int g = 0; g < ngeom; g++) if (geom_bodyid[g] == i) {
+      double m, I[3]; if (!geom_massprops(B->geoms[gorder[g]], &m, I)) continue;
+      double R[9]; hm::quat2mat(R, &geom_quat[4*g]);
+      // R diag(I) R^T + m (|d|^2 1 - d d^T)
+      double d[3] = {geom_pos[3*g] - com[0], geom_pos[3*g+1] - com[1], geom_pos[3*g+2] - com[2]};
+      for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) {
+        double v = 0; for (int k = 0; k < 3; k++) v += R[3*r+k] * I[k] * R[3*c+k];
+        v += m * ((r == c ? hm::dot3(d, d) : 0) - d[r]*d[c]);
+        It[3*r+c] += v;
+      }
+    }
+    body_mass[i] = M;
+    for (int k = 0; k < 3; k++) body_ipos[3*i+k] = com[k];
+    bool diag = std::fabs(It[1]) + std::fabs(It[2]) + std::fabs(It[5]) < 1e-14 * (It[0] + It[4] + It[8]);
+    if (diag) {
+      body_inertia[3*i] = It[0]; body_inertia[3*i+1] = It[4]; body_inertia[3*i+2] = It[8];
+      body_iquat[4*i] = 1; body_iquat[4*i+1] = body_iquat[4*i+2] = body_iquat[4*i+3] = 0;
+    } else {
+      double e[3], V[9]; hm::eig3(It, e, V);
+      // make V a proper rotation
+      double c0[3] = {V[0], V[3], V[6]}, c1[3] = {V[1], V[4], V[7]}, c2[3];
+      hm::cross(c2, c0, c1);
+      double Rm[9] = {c0[0], c1[0], c2[0], c0[1], c1[1], c2[1], c0[2], c1[2], c2[2]};
+      hm::mat2quat(&body_iquat[4*i], Rm);
+      for (int k = 0; k < 3; k++) body_inertia[3*i+k] = e[k];
+    }
+  }
+  body_iquat[0] = 1;
+
+  // ---- dofs
+  for (int j = 0; j < njnt; j++) {
+    const BJoint& J = B->joints[jorder[j]];
+    int b = jnt_bodyid[j];
+    for (int k = 0; k < VN[J.type]; k++) {
+      int d = jnt_dofadr[j] + k;
+      dof_bodyid[d] = b; dof_jntid[d] = j;
+      dof_armature[d] = J.armature; dof_damping[d] = J.damping; dof_frictionloss[d] = J.frictionloss;
+      dof_solref[2*d] = 0.02; dof_solref[2*d+1] = 1;
+      const double si[5] = {0.9, 0.95, 0.001, 0.5, 2};
+      for (int q = 0; q < 5; q++) dof_solimp[5*d+q] = si[q];
+      if (d > body_dofadr[b]) dof_parentid[d] = d - 1;
+      else {
+        int p = body_parentid[b];
+        while (p > 0 && body_dofnum[p] == 0) p = body_parentid[p];
+        dof_parentid[d] = (p > 0) ? body_dofadr[p] + body_dofnum[p] - 1 : -1;
+      }
+    }
+    // qpos0
+    int qa = jnt_qposadr[j];
+    if (J.type == MJH_JNT_FREE) {
+      for (int k = 0; k < 3; k++) qpos0[qa+k] = body_pos[3*b+k];
+      for (int k = 0; k < 4; k++) qpos0[qa+3+k] = body_quat[4*b+k];
+    } else if (J.type == MJH_JNT_BALL) {
+      qpos0[qa] = 1; qpos0[qa+1] = qpos0[qa+2] = qpos0[qa+3] = 0;
+    } else qpos0[qa] = J.ref;
+    for (int k = 0; k < QN[J.type]; k++) qpos_spring[qa+k] = qpos0[qa+k];
+  }
+  int nM = 0;
+  for (int d = 0; d < nv; d++) {
+    dof_Madr[d] = nM;
+    int p = d; while (p >= 0) { nM++; p = dof_parentid[p]; }
+  }
+  // trees
+  std::vector<int> tree_dofadr, tree_dofnum, tree_bodyid;
+  for (int i = 0; i < nbody; i++) body_treeid[i] = -1;
+  for (int i = 1; i < nbody; i++) {
+    if (body_parentid[i] == 0) {
+      // count dofs in subtree (contiguous thanks to DFS order)
+      int first = -1, cnt = 0, last = i;
+      for (int k = i; k < nbody; k++) {
+        if (k > i && body_rootid[k] != i) break;
+        last = k;
+        if (body_dofnum[k]) { if (first < 0) first = body_dofadr[k]; cnt += body_dofnum[k]; }
+      }
+      if (cnt) {
+        int t = (int)tree_dofadr.size();
+        tree_dofadr.push_back(first); tree_dofnum.push_back(cnt); tree_bodyid.push_back(i);
+        for (int k = i; k <= last; k++) body_treeid[k] = t;
+      }
+    }
+  }
+  for (int d = 0; d < nv; d++) dof_treeid[d] = body_treeid[dof_bodyid[d]];
+  const int ntree = (int)tree_dofadr.size();
+
+  // ---- reference configuration kinematics + Jacobian-based mass matrix (fp64, dense)
+  std::vector<double> xpos(3*nbody), xquat(4*nbody), xmat(9*nbody), xipos(3*nbody), ximat(9*nbody);
+  xquat[0] = 1; hm::quat2mat(&xmat[0], &xquat[0]); hm::quat2mat(&ximat[0], &xquat[0]);
+  for (int i = 1; i < nbody; i++) {
+    int p = body_parentid[i];
+    double t[3]; hm::rotvec(t, &xmat[9*p], &body_pos[3*i]);
+    for (int k = 0; k < 3; k++) xpos[3*i+k] = xpos[3*p+k] + t[k];
+    hm::mulquat(&xquat[4*i], &xquat[4*p], &body_quat[4*i]);
+    hm::normalize4(&xquat[4*i]);
+    hm::quat2mat(&xmat[9*i], &xquat[4*i]);
+    hm::rotvec(t, &xmat[9*i], &body_ipos[3*i]);
+    for (int k = 0; k < 3; k++) xipos[3*i+k] = xpos[3*i+k] + t[k];
+    double qi[4]; hm::mulquat(qi, &xquat[4*i], &body_iquat[4*i]); hm::quat2mat(&ximat[9*i], qi);
+  }
+  // world-frame Jacobian columns of a point attached to body b: jp[3*nv], jr[3*nv] (row-major 3 x nv)
+  auto jac = [&](int b, const double* point, std::vector<double>& jp, std::vector<double>& jr) {
+    std::fill(jp.begin(), jp.end(), 0.0); std::fill(jr.begin(), jr.end(), 0.0);
+    while (b > 0) {
+      for (int j = body_jntadr[b]; j >= 0 && j < body_jntadr[b] + body_jntnum[b]; j++) {
+        int da = jnt_dofadr[j];
+        double anchor[3], t[3];
+        hm::rotvec(t, &xmat[9*b], &jnt_pos[3*j]);
+        for (int k = 0; k < 3; k++) anchor[k] = xpos[3*b+k] + t[k];
+        double r[3] = {point[0] - anchor[0], point[1] - anchor[1], point[2] - anchor[2]};
+        if (jnt_type[j] == MJH_JNT_FREE) {
+          for (int k = 0; k < 3; k++) jp[k*nv + da + k] = 1;
+          da += 3;
+        }
+        if (jnt_type[j] == MJH_JNT_FREE || jnt_type[j] == MJH_JNT_BALL) {
+          for (int a = 0; a < 3; a++) {
+            double ax[3] = {xmat[9*b + a], xmat[9*b + 3 + a], xmat[9*b + 6 + a]};
+            double c[3]; hm::cross(c, ax, r);
+            for (int k = 0; k < 3; k++) { jr[k*nv + da + a] = ax[k]; jp[k*nv + da + a] = c[k]; }
+          }
+        } else {
+          double ax[3]; hm::rotvec(ax, &xmat[9*b], &jnt_axis[3*j]);
+          if (jnt_type[j] == MJH_JNT_HINGE) {
+            double c[3]; hm::cross(c, ax, r);
+            for (int k = 0; k < 3; k++) { jr[k*nv + da] = ax[k]; jp[k*nv + da] = c[k]; }
+          } else for (int k = 0; k < 3; k++) jp[k*nv + da] = ax[k];
+        }
+      }
+      b = body_parentid[b];
+    }
+  };
+  std::vector<double> Mq((size_t)nv * nv, 0.0), jp(3*(size_t)nv), jr(3*(size_t)nv);
+  for (int b = 1; b < nbody; b++) {
+    if (body_mass[b] <= 0 && body_inertia[3*b] <= 0) continue;
+    jac(b, &xipos[3*b], jp, jr);
+    // world inertia
+    double Iw[9];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) {
+      double v = 0; for (int k = 0; k < 3; k++) v += ximat[9*b + 3*r + k] * body_inertia[3*b + k] * ximat[9*b + 3*c + k];
+      Iw[3*r+c] = v;
+    }
+    // support = dofs of this body's chain: only nonzero columns matter
+    std::vector<int> sup;
+    for (int d = 0; d < nv; d++) {
+      bool nz = false; for (int k = 0; k < 3; k++) if (jp[k*nv+d] != 0 || jr[k*nv+d] != 0) nz = true;
+      if (nz) sup.push_back(d);
+    }
+    for (int a : sup) for (int c : sup) {
+      double v = 0;
+      for (int k = 0; k < 3; k++) v += body_mass[b] * jp[k*nv+a] * jp[k*nv+c];
+      for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) v += jr[r*nv+a] * Iw[3*r+k] * jr[k*nv+c];
+      Mq[(size_t)a*nv + c] += v;
+    }
+  }
+  for (int d = 0; d < nv; d++) Mq[(size_t)d*nv + d] += dof_armature[d];
+  double meaninertia = 0;
+  for (int d = 0; d < nv; d++) meaninertia += Mq[(size_t)d*nv + d];
+  meaninertia = nv ? meaninertia / nv : 1.0;
+  if (meaninertia < 1e-15) meaninertia = 1e-15;
+  // dense Cholesky M = L L^T (trees are independent blocks but dense is fine on the host)
+  std::vector<double> L(Mq);
+  bool spd = true;
+  for (int c = 0; c < nv && spd; c++) {
+    double s = L[(size_t)c*nv + c];
+    for (int k = 0; k < c; k++) s -= L[(size_t)c*nv + k] * L[(size_t)c*nv + k];
+    if (s <= 1e-300) { spd = false; break; }
+    double dd = std::sqrt(s); L[(size_t)c*nv + c] = dd;
+    for (int r = c + 1; r < nv; r++) {
+      double t = L[(size_t)r*nv + c];
+      if (t == 0) { bool any = false; for (int k = 0; k < c; k++) if (L[(size_t)r*nv+k] != 0 && L[(size_t)c*nv+k] != 0) { any = true; break; } if (!any) continue; }
+      for (int k = 0; k < c; k++) t -= L[(size_t)r*nv + k] * L[(size_t)c*nv + k];
+      L[(size_t)r*nv + c] = t / dd;
+    }
+  }
+  if (!spd) { g_err = "mass matrix at qpos0 is not positive definite (massless body without armature?)"; return nullptr; }
+  auto solveM = [&](std::vector<double>& x) {  // in-place M^{-1} x
+    for (int r = 0; r < nv; r++) { double s = x[r]; for (int k = 0; k < r; k++) s -= L[(size_t)r*nv+k] * x[k]; x[r] = s / L[(size_t)r*nv+r]; }
+    for (int r = nv - 1; r >= 0; r--) { double s = x[r]; for (int k = r + 1; k < nv; k++) s -= L[(size_t)k*nv+r] * x[k]; x[r] = s / L[(size_t)r*nv+r]; }
+  };
+  // dof_invweight0: diag(M^-1), averaged within ball / free-translational / free-rotational triples
+  {
+    std::vector<double> dinv(nv), e(nv);
+    for (int d = 0; d < nv; d++) { std::fill(e.begin(), e.end(), 0.0); e[d] = 1; solveM(e); dinv[d] = e[d]; }
+    for (int j = 0; j < njnt; j++) {
+      int da = jnt_dofadr[j];
+      if (jnt_type[j] == MJH_JNT_FREE) {
+        double a = (dinv[da] + dinv[da+1] + dinv[da+2]) / 3, r = (dinv[da+3] + dinv[da+4] + dinv[da+5]) / 3;
+        for (int k = 0; k < 3; k++) { dof_invweight0[da+k] = a; dof_invweight0[da+3+k] = r; }
+      } else if (jnt_type[j] == MJH_JNT_BALL) {
+        double a = (dinv[da] + dinv[da+1] + dinv[da+2]) / 3;
+        for (int k = 0; k < 3; k++) dof_invweight0[da+k] = a;
+      } else dof_invweight0[da] = dinv[da];
+    }
+  }
+  // body_invweight0: (1/3) trace(Jp M^-1 Jp^T), (1/3) trace(Jr M^-1 Jr^T) at the body COM
+  for (int b = 1; b < nbody; b++) {
+    if (body_weldid[b] == 0) { body_invweight0[2*b] = body_invweight0[2*b+1] = 0; continue; }
+    jac(b, &xipos[3*b], jp, jr);
+    double tr = 0, rr = 0;
+    std::vector<double> x(nv);
+    for (int k = 0; k < 3; k++) {
+      for (int d = 0; d < nv; d++) x[d] = jp[k*nv+d];
+      solveM(x); for (int d = 0; d < nv; d++) tr += jp[k*nv+d] * x[d];
+      for (int d = 0; d < nv; d++) x[d] = jr[k*nv+d];
+      solveM(x); for (int d = 0; d < nv; d++) rr += jr[k*nv+d] * x[d];
+    }
+    body_invweight0[2*b] = tr / 3; body_invweight0[2*b+1] = rr / 3;
+  }
+
+  // ---- static candidate pair list
+  struct P { int b1, b2, g1, g2; };
+  std::vector<P> pairs;
+  auto excluded = [&](int b1, int b2) {
+    for (auto& e : B->excludes) { int x = newid[e.first], y = newid[e.second]; if ((x == b1 && y == b2) || (x == b2 && y == b1)) return true; }
+    return false;
+  };
+  const bool filterparent = !(B->opt.disableflags & MJH_DSBL_FILTERPARENT);
+  for (int g1 = 0; g1 < ngeom; g1++) for (int g2 = g1 + 1; g2 < ngeom; g2++) {
+    int b1 = geom_bodyid[g1], b2 = geom_bodyid[g2];
+    int w1 = body_weldid[b1], w2 = body_weldid[b2];
+    if (w1 == w2) continue;  // same body / welded together / both static
+    int wp1 = body_weldid[body_parentid[w1]], wp2 = body_weldid[body_parentid[w2]];
+    if (filterparent && w1 != 0 && w2 != 0 && (w1 == wp2 || w2 == wp1)) continue;
+    if (!((geom_contype[g1] & geom_conaffinity[g2]) || (geom_contype[g2] & geom_conaffinity[g1]))) continue;
+    if (excluded(b1, b2)) continue;
+    if (!pair_supported(geom_type[g1], geom_type[g2])) continue;
+    P p; p.b1 = std::min(b1, b2); p.b2 = std::max(b1, b2);
+    if (geom_type[g1] <= geom_type[g2]) { p.g1 = g1; p.g2 = g2; } else { p.g1 = g2; p.g2 = g1; }
+    pairs.push_back(p);
+  }
+  std::stable_sort(pairs.begin(), pairs.end(), [](const P& a, const P& b) {
+    if (a.b1 != b.b1) return a.b1 < b.b1; if (a.b2 != b.b2) return a.b2 < b.b2; return false; });
+  const int npair = (int)pairs.size();
+  std::vector<int> pair_geom1(npair), pair_geom2(npair);
+  int capcon = 0, caprow = 0;
+  for (int i = 0; i < npair; i++) {
+    pair_geom1[i] = pairs[i].g1; pair_geom2[i] = pairs[i].g2;
+    int mc = pair_maxcon(geom_type[pairs[i].g1], geom_type[pairs[i].g2]);
+    int dim = std::max(geom_condim[pairs[i].g1], geom_condim[pairs[i].g2]);
+    capcon += mc; caprow += mc * (dim == 1 ? 1 : 2 * (dim - 1));
+  }
+  // equality
+  const int neq = (int)B->eqs.size();
+  std::vector<int> eq_type(neq), eq_obj1id(neq), eq_obj2id(neq), eq_active(neq);
+  std::vector<double> eq_data(11*neq), eq_solref(2*neq), eq_solimp(5*neq);
+  for (int e = 0; e < neq; e++) {
+    eq_type[e] = MJH_EQ_JOINT; eq_obj1id[e] = jnewid[B->eqs[e].j1]; eq_obj2id[e] = B->eqs[e].j2 >= 0 ? jnewid[B->eqs[e].j2] : -1;
+    eq_active[e] = 1;
+    for (int k = 0; k < 5; k++) eq_data[11*e+k] = B->eqs[e].poly[k];
+    eq_solref[2*e] = 0.02; eq_solref[2*e+1] = 1;
+    const double si[5] = {0.9, 0.95, 0.001, 0.5, 2};
+    for (int k = 0; k < 5; k++) eq_solimp[5*e+k] = si[k];
+  }
+  int nlimit = 0, nfl = 0;
+  for (int j = 0; j < njnt; j++) if (jnt_limited[j]) nlimit++;
+  for (int d = 0; d < nv; d++) if (dof_frictionloss[d] > 0) nfl++;
+
+  mjh_model* m = (mjh_model*)std::calloc(1, sizeof(mjh_model));
+  m->nq = nq; m->nv = nv; m->nbody = nbody; m->njnt = njnt; m->ngeom = ngeom; m->neq = neq; m->npair = npair;
+  m->nM = nM; m->ntree = ntree; m->nexclude = (int)B->excludes.size();
+  m->maxcon = B->maxcon > 0 ? B->maxcon : capcon;
+  m->maxefc = B->maxefc > 0 ? B->maxefc : (caprow + neq + nlimit + nfl);
+  if (B->maxcon > 0 && B->maxefc <= 0) {
+    // rows for the capped contact count at the worst-case dim present in the pair list
+    int maxrows_per_con = 1;
+    for (int i = 0; i < npair; i++) { int dim = std::max(geom_condim[pair_geom1[i]], geom_condim[pair_geom2[i]]); maxrows_per_con = std::max(maxrows_per_con, dim == 1 ? 1 : 2*(dim-1)); }
+    m->maxefc = std::min(caprow, B->maxcon * maxrows_per_con) + neq + nlimit + nfl;
+  }
+  m->opt = B->opt; m->meaninertia = meaninertia;
+#define SETI(f) m->f = dup(f)
+  SETI(body_parentid); SETI(body_rootid); SETI(body_weldid); SETI(body_jntadr); SETI(body_jntnum); SETI(body_dofadr);
+  SETI(body_dofnum); SETI(body_treeid); SETI(body_level); SETI(body_geomadr); SETI(body_geomnum);
+  SETI(body_pos); SETI(body_quat); SETI(body_ipos); SETI(body_iquat); SETI(body_mass); SETI(body_inertia);
+  SETI(body_gravcomp); SETI(body_invweight0);
+  SETI(jnt_type); SETI(jnt_qposadr); SETI(jnt_dofadr); SETI(jnt_bodyid); SETI(jnt_limited); SETI(jnt_pos); SETI(jnt_axis);
+  SETI(jnt_stiffness); SETI(jnt_range); SETI(jnt_margin); SETI(jnt_solref); SETI(jnt_solimp); SETI(qpos0); SETI(qpos_spring);
+  SETI(dof_bodyid); SETI(dof_jntid); SETI(dof_parentid); SETI(dof_Madr); SETI(dof_treeid); SETI(dof_armature); SETI(dof_damping);
+  SETI(dof_frictionloss); SETI(dof_invweight0); SETI(dof_solref); SETI(dof_solimp);
+  SETI(tree_dofadr); SETI(tree_dofnum); SETI(tree_bodyid);
+  SETI(geom_type); SETI(geom_bodyid); SETI(geom_condim); SETI(geom_contype); SETI(geom_conaffinity); SETI(geom_priority);
+  SETI(geom_pos); SETI(geom_quat); SETI(geom_size); m->geom_rbound = dup(geom_rb); SETI(geom_friction); SETI(geom_solmix);
+  SETI(geom_solref); SETI(geom_solimp); SETI(geom_margin); SETI(geom_gap);
+  SETI(pair_geom1); SETI(pair_geom2);
+  SETI(eq_type); SETI(eq_obj1id); SETI(eq_obj2id); SETI(eq_active); SETI(eq_data); SETI(eq_solref); SETI(eq_solimp);
+#undef SETI
+  m->body_names = dupnames(body_names); m->jnt_names = dupnames(jnt_names); m->geom_names = dupnames(geom_names);
+  return m;
+}
+
+extern "C" void mjh_model_destroy(mjh_model* m) {
+  if (!m) return;
+  void* ptrs[] = {m->body_parentid, m->body_rootid, m->body_weldid, m->body_jntadr, m->body_jntnum, m->body_dofadr, m->body_dofnum,
+    m->body_treeid, m->body_level, m->body_geomadr, m->body_geomnum, m->body_pos, m->body_quat, m->body_ipos, m->body_iquat,
+    m->body_mass, m->body_inertia, m->body_gravcomp, m->body_invweight0, m->jnt_type, m->jnt_qposadr, m->jnt_dofadr, m->jnt_bodyid,
+    m->jnt_limited, m->jnt_pos, m->jnt_axis, m->jnt_stiffness, m->jnt_range, m->jnt_margin, m->jnt_solref, m->jnt_solimp, m->qpos0,
+    m->qpos_spring, m->dof_bodyid, m->dof_jntid, m->dof_parentid, m->dof_Madr, m->dof_treeid, m->dof_armature, m->dof_damping,
+    m->dof_frictionloss, m->dof_invweight0, m->dof_solref, m->dof_solimp, m->tree_dofadr, m->tree_dofnum, m->tree_bodyid,
+    m->geom_type, m->geom_bodyid, m->geom_condim, m->geom_contype, m->geom_conaffinity, m->geom_priority, m->geom_pos, m->geom_quat,
+    m->geom_size, m->geom_rbound, m->geom_friction, m->geom_solmix, m->geom_solref, m->geom_solimp, m->geom_margin, m->geom_gap,
+    m->pair_geom1, m->pair_geom2, m->eq_type, m->eq_obj1id, m->eq_obj2id, m->eq_active, m->eq_data, m->eq_solref, m->eq_solimp};
+  for (void* p : ptrs) std::free(p);
+  auto freen = [](char** n, int c) { if (!n) return; for (int i = 0; i < c; i++) std::free(n[i]); std::free(n); };
+  freen(m->body_names, m->nbody); freen(m->jnt_names, m->njnt); freen(m->geom_names, m->ngeom);
+  std::free(m);
+}
+
+extern "C" int mjh_name2id(const mjh_model* m, int objtype, const char* name) {
+  if (!m || !name) return -1;
+  char** t = objtype == 0 ? m->body_names : objtype == 1 ? m->jnt_names : m->geom_names;
+  int n = objtype == 0 ? m->nbody : objtype == 1 ? m->njnt : m->ngeom;
+  for (int i = 0; i < n; i++) if (t[i] && std::strcmp(t[i], name) == 0) return i;
+  return -1;
+}
+extern "C" const char* mjh_id2name(const mjh_model* m, int objtype, int id) {
+  if (!m) return nullptr;
+  char** t = objtype == 0 ? m->body_names : objtype == 1 ? m->jnt_names : m->geom_names;
+  int n = objtype == 0 ? m->nbody : objtype == 1 ? m->njnt : m->ngeom;
+  if (id < 0 || id >= n) return nullptr;
+  return t[id];
+}

@@ -1,0 +1,951 @@
+// step_kernel.h — the many-environment stepping kernel: one 64-lane wavefront per environment,
+// the whole mj_step1 -> [mj_inverse] -> mj_step2 pipeline of the reference loop
+// (/root/reference/src/mj_main.cpp:82-112) fused in a single launch with every per-env
+// intermediate (body frames, spatial quantities, mass matrix, contacts, constraint rows) in LDS.
+// HBM traffic per env-step is the state row only.
+//
+// Stage map (reference call site -> block below):
+//   mj_step1 (mj_main.cpp:83)  FK, COM/cdof, CRBA, L'DL, collision, constraint rows, velocity stage
+//   MjSim::controller (mj_sim.cpp:1055-1077)            "controller"
+//   mj_inverse (mj_hw_interface.cpp:61)                  "inverse"
+//   mj_step2 (mj_main.cpp:108)  smooth acceleration, PGS, implicit-damping Euler
+//   MjSim::set_odom_vels (mj_sim.cpp:1079-1153)          "odom"
+#pragma once
+#include "dev_collide.h"
+#include "dev_types.h"
+
+#define WSYNC() __syncthreads()
+#define MINIMP 0.0001f
+#define MAXIMP 0.9999f
+
+DEV float get_impedance(const float* si, float pos, float margin) {
+  float s0 = fminf(MAXIMP, fmaxf(MINIMP, si[0])), s1 = fminf(MAXIMP, fmaxf(MINIMP, si[1]));
+  float s2 = fmaxf(0.0f, si[2]), s3 = fminf(MAXIMP, fmaxf(MINIMP, si[3])), s4 = fmaxf(1.0f, si[4]);
+  if (s0 == s1 || s2 <= MJ_MINVAL) return 0.5f * (s0 + s1);
+  float x = fabsf((pos - margin) / s2);
+  if (x >= 1) return s1;
+  if (x <= 0) return s0;
+  float y;
+  if (s4 == 1) y = x;
+  else if (x <= s3) y = powf(x, s4) / powf(s3, s4 - 1);
+  else y = 1 - powf(1 - x, s4) / powf(1 - s3, s4 - 1);
+  return s0 + y * (s1 - s0);
+}
+
+// in-place x <- M^-1 x over one tree's contiguous dof range, x addressed by absolute dof index
+DEV void solve_tree(float* x, const float* qLD, const float* qLDinv, const int* dof_parentid, const int* dof_Madr, int adr, int num) {
+  for (int k = adr + num - 1; k >= adr; k--) {
+    float xk = x[k];
+    if (xk == 0) continue;
+    int a = dof_Madr[k] + 1;
+    for (int i = dof_parentid[k]; i >= 0; i = dof_parentid[i]) x[i] -= qLD[a++] * xk;
+  }
+  for (int k = adr; k < adr + num; k++) x[k] *= qLDinv[k];
+  for (int k = adr; k < adr + num; k++) {
+    int a = dof_Madr[k] + 1; float xk = x[k];
+    for (int i = dof_parentid[k]; i >= 0; i = dof_parentid[i]) xk -= qLD[a++] * x[i];
+    x[k] = xk;
+  }
+}
+DEV void factor_tree(float* qLD, float* qLDinv, const int* dof_parentid, const int* dof_Madr, int adr, int num) {
+  for (int k = adr + num - 1; k >= adr; k--) {
+    int Mkk_a = dof_Madr[k], Mki = Mkk_a + 1;
+    float Mkk = qLD[Mkk_a];
+    float inv = 1.0f / Mkk;
+    for (int i = dof_parentid[k]; i >= 0; i = dof_parentid[i]) {
+      float tmp = qLD[Mki] * inv;
+      int cnt = 0, ai = dof_Madr[i];
+      for (int j = i; j >= 0; j = dof_parentid[j]) { qLD[ai + cnt] -= tmp * qLD[Mki + cnt]; cnt++; }
+      qLD[Mki] = tmp;
+      Mki++;
+    }
+    qLDinv[k] = inv;
+  }
+}
+
+// row header: hd[0] = type | sub << 8, hd[1] = id, hd[2] = a1 | n1 << 16, hd[3] = a2 | n2 << 16
+// where (a1,n1) ++ (a2,n2) are the contiguous dof ranges of the (up to two) kinematic trees the row touches
+#define ROW_TREES(hd2, hd3) const int a1 = (hd2) & 0xffff, n1 = (hd2) >> 16, a2 = (hd3) & 0xffff, n2 = (hd3) >> 16
+// offset of dof d inside the compact storage of a row spanning trees (a1,n1) ++ (a2,n2); -1 if outside
+DEV int row_off(int d, int a1, int n1, int a2, int n2) {
+  unsigned r1 = (unsigned)(d - a1), r2 = (unsigned)(d - a2);
+  return r1 < (unsigned)n1 ? (int)r1 : (r2 < (unsigned)n2 ? n1 + (int)r2 : -1);
+}
+
+__global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DState S, const Lay L, int env0, int nsteps, int ph, int xflags) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x;
+  const int env = env0 + blockIdx.x;
+  const int nq = M.nq, nv = M.nv, nbody = M.nbody, njnt = M.njnt, ngeom = M.ngeom;
+
+#define IT(n) const int* n = M.I + M.o_##n;
+  MJH_INT_TABLES(IT)
+#undef IT
+#define FT(n) const float* n = M.F + M.o_##n;
+  MJH_FLT_TABLES(FT)
+#undef FT
+  // per-env parameter overrides
+  if (S.p_geom_size) geom_size = S.p_geom_size + (size_t)env * 3 * ngeom;
+  if (S.p_geom_rbound) geom_rbound = S.p_geom_rbound + (size_t)env * ngeom;
+  if (S.p_body_mass) body_mass = S.p_body_mass + (size_t)env * nbody;
+  if (S.p_body_inertia) body_inertia = S.p_body_inertia + (size_t)env * 3 * nbody;
+  if (S.p_body_invweight0) body_invweight0 = S.p_body_invweight0 + (size_t)env * 2 * nbody;
+  if (S.p_dof_invweight0) dof_invweight0 = S.p_dof_invweight0 + (size_t)env * nv;
+
+#define LA(n) float* s_##n = lds + L.n;
+  MJH_LDS_ARRAYS(LA)
+#undef LA
+  int* s_rowi_i = (int*)s_rowi;
+  float* s_stage = s_J;  // raw-contact staging aliases the (not yet built) row storage
+
+  const size_t qrow = (size_t)env * M.nqp, vrow = (size_t)env * M.nvp;
+  const float h = M.timestep;
+  const float grav[3] = {(M.disableflags & MJH_DSBL_GRAVITY) ? 0.0f : M.gravity[0], (M.disableflags & MJH_DSBL_GRAVITY) ? 0.0f : M.gravity[1],
+                         (M.disableflags & MJH_DSBL_GRAVITY) ? 0.0f : M.gravity[2]};
+
+  // ------------------------------------------------------------------ load state
+  if (ph & PH_RESET) {
+    for (int i = lane; i < nq; i += 64) S.qpos[qrow + i] = S.initial_qpos[qrow + i];
+    for (int i = lane; i < nv; i += 64) { S.qvel[vrow+i] = 0; S.qacc[vrow+i] = 0; S.qacc_ws[vrow+i] = 0; S.qvel_ref[vrow+i] = 0; S.qfrc_applied[vrow+i] = 0; S.ddq[vrow+i] = 0; S.dq[vrow+i] = 0; }
+    if (lane == 0) { S.time[env] = 0; S.stats[4*env] = 0; S.stats[4*env+1] = 0; S.stats[4*env+2] = 0; S.stats[4*env+3] = 0; }
+    return;
+  }
+  for (int i = lane; i < nq; i += 64) s_qpos[i] = S.qpos[qrow + i];
+  for (int i = lane; i < nv; i += 64) {
+    s_qvel[i] = S.qvel[vrow + i]; s_ws[i] = S.qacc_ws[vrow + i]; s_qacc[i] = S.qacc[vrow + i];
+    s_qvref[i] = S.qvel_ref[vrow + i]; s_applied[i] = S.qfrc_applied[vrow + i];
+  }
+  float time = S.time[env];
+  int flags = 0, ncon = 0, nefc = 0, niter = 0;
+  WSYNC();
+
+  for (int step = 0; step < nsteps; step++) {
+    // ---- bad-state check (mj_checkPos / mj_checkVel): reset this env
+    {
+      bool badv = false;
+      for (int i = lane; i < nq; i += 64) { float x = s_qpos[i]; badv |= !(x == x) || fabsf(x) > MJ_MAXVAL; }
+      for (int i = lane; i < nv; i += 64) { float x = s_qvel[i], y = s_qacc[i]; badv |= !(x == x) || fabsf(x) > MJ_MAXVAL || !(y == y) || fabsf(y) > MJ_MAXVAL; }
+      if (wave_any(badv)) {
+        for (int i = lane; i < nq; i += 64) s_qpos[i] = S.initial_qpos[qrow + i];
+        for (int i = lane; i < nv; i += 64) { s_qvel[i] = 0; s_qacc[i] = 0; s_ws[i] = 0; s_applied[i] = 0; }
+        flags |= 4;
+        WSYNC();
+      }
+    }
+    // ================================================================ position stage
+    // ---- FK (mj_kinematics)
+    if (lane == 0) {
+      s_xpos[0] = s_xpos[1] = s_xpos[2] = 0; s_xquat[0] = 1; s_xquat[1] = s_xquat[2] = s_xquat[3] = 0;
+      for (int k = 0; k < 9; k++) { s_xmat[k] = (k % 4 == 0) ? 1.0f : 0.0f; s_ximat[k] = s_xmat[k]; }
+      s_xipos[0] = s_xipos[1] = s_xipos[2] = 0;
+    }
+    WSYNC();
+    for (int lev = 1; lev <= M.maxlevel; lev++) {
+      for (int b = lane; b < nbody; b += 64) {
+        if (body_level[b] != lev) continue;
+        float xpos[3], xquat[4], mat[9];
+        const int jn = body_jntnum[b], ja = body_jntadr[b];
+        if (jn == 1 && jnt_type[ja] == MJH_JNT_FREE) {
+          const int qa = jnt_qposadr[ja];
+          xpos[0] = s_qpos[qa]; xpos[1] = s_qpos[qa+1]; xpos[2] = s_qpos[qa+2];
+          xquat[0] = s_qpos[qa+3]; xquat[1] = s_qpos[qa+4]; xquat[2] = s_qpos[qa+5]; xquat[3] = s_qpos[qa+6];
+          normalize4(xquat);
+          s_qpos[qa+3] = xquat[0]; s_qpos[qa+4] = xquat[1]; s_qpos[qa+5] = xquat[2]; s_qpos[qa+6] = xquat[3];
+          s_xanchor[3*ja] = xpos[0]; s_xanchor[3*ja+1] = xpos[1]; s_xanchor[3*ja+2] = xpos[2];
+          s_xaxis[3*ja] = 0; s_xaxis[3*ja+1] = 0; s_xaxis[3*ja+2] = 1;
+        } else {
+          const int p = body_parentid[b];
+          float t[3]; rotvec(t, s_xmat + 9*p, body_pos + 3*b);
+          xpos[0] = s_xpos[3*p] + t[0]; xpos[1] = s_xpos[3*p+1] + t[1]; xpos[2] = s_xpos[3*p+2] + t[2];
+          mulquat(xquat, s_xquat + 4*p, body_quat + 4*b);
+          for (int j = ja; j < ja + jn; j++) {
+            const int qa = jnt_qposadr[j], jt = jnt_type[j];
+            float vec[3], anchor[3], axis[3];
+            quat2mat(mat, xquat);
+            rotvec(vec, mat, jnt_pos + 3*j);
+            anchor[0] = xpos[0] + vec[0]; anchor[1] = xpos[1] + vec[1]; anchor[2] = xpos[2] + vec[2];
+            rotvec(axis, mat, jnt_axis + 3*j);
+            if (jt == MJH_JNT_SLIDE) {
+              float dq = s_qpos[qa] - qpos0[qa];
+              xpos[0] += axis[0]*dq; xpos[1] += axis[1]*dq; xpos[2] += axis[2]*dq;
+            } else if (jt == MJH_JNT_BALL || jt == MJH_JNT_HINGE) {
+              float ql[4], r[4];
+              if (jt == MJH_JNT_BALL) {
+                ql[0] = s_qpos[qa]; ql[1] = s_qpos[qa+1]; ql[2] = s_qpos[qa+2]; ql[3] = s_qpos[qa+3];
+                normalize4(ql);
+                s_qpos[qa] = ql[0]; s_qpos[qa+1] = ql[1]; s_qpos[qa+2] = ql[2]; s_qpos[qa+3] = ql[3];
+              } else axisangle2quat(ql, jnt_axis + 3*j, s_qpos[qa] - qpos0[qa]);
+              mulquat(r, xquat, ql);
+              xquat[0] = r[0]; xquat[1] = r[1]; xquat[2] = r[2]; xquat[3] = r[3];
+              quat2mat(mat, xquat); rotvec(vec, mat, jnt_pos + 3*j);
+              xpos[0] = anchor[0] - vec[0]; xpos[1] = anchor[1] - vec[1]; xpos[2] = anchor[2] - vec[2];
+            }
+            s_xanchor[3*j] = anchor[0]; s_xanchor[3*j+1] = anchor[1]; s_xanchor[3*j+2] = anchor[2];
+            s_xaxis[3*j] = axis[0]; s_xaxis[3*j+1] = axis[1]; s_xaxis[3*j+2] = axis[2];
+          }
+        }
+        normalize4(xquat);
+        quat2mat(mat, xquat);
+        float t[3], qi[4], imat[9];
+        rotvec(t, mat, body_ipos + 3*b);
+        mulquat(qi, xquat, body_iquat + 4*b); quat2mat(imat, qi);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { s_xpos[3*b+k] = xpos[k]; s_xipos[3*b+k] = xpos[k] + t[k]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) s_xquat[4*b+k] = xquat[k];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { s_xmat[9*b+k] = mat[k]; s_ximat[9*b+k] = imat[k]; }
+      }
+      WSYNC();
+    }
+    for (int g = lane; g < ngeom; g += 64) {
+      const int b = geom_bodyid[g];
+      float t[3], q[4], mat[9];
+      rotvec(t, s_xmat + 9*b, geom_pos + 3*g);
+      mulquat(q, s_xquat + 4*b, geom_quat + 4*g); quat2mat(mat, q);
+#pragma unroll
+      for (int k = 0; k < 3; k++) s_gpos[3*g+k] = s_xpos[3*b+k] + t[k];
+#pragma unroll
+      for (int k = 0; k < 9; k++) s_gmat[9*g+k] = mat[k];
+    }
+    if (xflags & (XF_BODY | XF_GEOM)) {
+      WSYNC();
+      const size_t e = blockIdx.x;
+      if (S.x_xpos) for (int i = lane; i < 3*nbody; i += 64) S.x_xpos[e*3*nbody + i] = s_xpos[i];
+      if (S.x_xquat) for (int i = lane; i < 4*nbody; i += 64) S.x_xquat[e*4*nbody + i] = s_xquat[i];
+      if (S.x_gpos) for (int i = lane; i < 3*ngeom; i += 64) S.x_gpos[e*3*ngeom + i] = s_gpos[i];
+      if (S.x_gmat) for (int i = lane; i < 9*ngeom; i += 64) S.x_gmat[e*9*ngeom + i] = s_gmat[i];
+    }
+    if (ph & PH_FKONLY) break;
+
+    // ---- subtree COM of every tree root, COM-based inertias, motion axes (mj_comPos)
+    for (int r = lane; r < nbody; r += 64) {
+      if (r == 0 || body_parentid[r] != 0) continue;
+      float sm = 0, c[3] = {0, 0, 0};
+      for (int b = r; b < r + body_subtreesize[r]; b++) {
+        float m = body_mass[b]; sm += m;
+        c[0] += m * s_xipos[3*b]; c[1] += m * s_xipos[3*b+1]; c[2] += m * s_xipos[3*b+2];
+      }
+      if (sm < MJ_MINVAL) { c[0] = s_xipos[3*r]; c[1] = s_xipos[3*r+1]; c[2] = s_xipos[3*r+2]; }
+      else { float inv = 1.0f / sm; c[0] *= inv; c[1] *= inv; c[2] *= inv; }
+      s_com[3*r] = c[0]; s_com[3*r+1] = c[1]; s_com[3*r+2] = c[2];
+    }
+    WSYNC();
+    for (int b = lane; b < nbody; b += 64) {
+      float ci[10];
+      if (b == 0) { for (int k = 0; k < 10; k++) ci[k] = 0; }
+      else {
+        const float* com = s_com + 3*body_rootid[b];
+        float off[3] = {s_xipos[3*b] - com[0], s_xipos[3*b+1] - com[1], s_xipos[3*b+2] - com[2]};
+        inert_com(ci, body_inertia + 3*b, s_ximat + 9*b, off, body_mass[b]);
+      }
+#pragma unroll
+      for (int k = 0; k < 10; k++) s_cinert[10*b+k] = ci[k];
+    }
+    for (int d = lane; d < nv; d += 64) {
+      const int j = dof_jntid[d], b = dof_bodyid[d], jt = jnt_type[j];
+      int k = d - jnt_dofadr[j];
+      const float* com = s_com + 3*body_rootid[b];
+      float off[3] = {com[0] - s_xanchor[3*j], com[1] - s_xanchor[3*j+1], com[2] - s_xanchor[3*j+2]};
+      float cd[6];
+      if (jt == MJH_JNT_FREE && k < 3) { cd[0] = cd[1] = cd[2] = 0; cd[3] = (k == 0); cd[4] = (k == 1); cd[5] = (k == 2); }
+      else if (jt == MJH_JNT_FREE || jt == MJH_JNT_BALL) {
+        if (jt == MJH_JNT_FREE) k -= 3;
+        float ax[3] = {s_xmat[9*b + k], s_xmat[9*b + 3 + k], s_xmat[9*b + 6 + k]};
+        cd[0] = ax[0]; cd[1] = ax[1]; cd[2] = ax[2]; cross3(cd + 3, ax, off);
+      } else if (jt == MJH_JNT_SLIDE) { cd[0] = cd[1] = cd[2] = 0; cd[3] = s_xaxis[3*j]; cd[4] = s_xaxis[3*j+1]; cd[5] = s_xaxis[3*j+2]; }
+      else { float ax[3] = {s_xaxis[3*j], s_xaxis[3*j+1], s_xaxis[3*j+2]}; cd[0] = ax[0]; cd[1] = ax[1]; cd[2] = ax[2]; cross3(cd + 3, ax, off); }
+#pragma unroll
+      for (int q = 0; q < 6; q++) s_cdof[6*d+q] = cd[q];
+    }
+    WSYNC();
+    // ---- CRBA (mj_crb): composite inertia = sum over the body's (contiguous) subtree
+    for (int b = lane; b < nbody; b += 64) {
+      float acc[10];
+#pragma unroll
+      for (int k = 0; k < 10; k++) acc[k] = 0;
+      if (b > 0) for (int c = b; c < b + body_subtreesize[b]; c++)
+#pragma unroll
+        for (int k = 0; k < 10; k++) acc[k] += s_cinert[10*c+k];
+#pragma unroll
+      for (int k = 0; k < 10; k++) s_crb[10*b+k] = acc[k];
+    }
+    WSYNC();
+    for (int i = lane; i < nv; i += 64) {
+      float buf[6], cd[6];
+#pragma unroll
+      for (int q = 0; q < 6; q++) cd[q] = s_cdof[6*i+q];
+      mul_inert_vec(buf, s_crb + 10*dof_bodyid[i], cd);
+      int adr = dof_Madr[i];
+      for (int j = i; j >= 0; j = dof_parentid[j]) {
+        float v = 0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) v += s_cdof[6*j+q] * buf[q];
+        if (j == i) v += dof_armature[i];
+        s_qM[adr] = v; s_qLD[adr] = v; adr++;
+      }
+    }
+    WSYNC();
+    if (ph & PH_MULM) {  // mj_mulM (mj_sim.cpp:1057) for the host API
+      for (int i = lane; i < nv; i += 64) { s_tmpv[i] = S.x_vec[(size_t)blockIdx.x * M.nvp + i]; s_tmpv2[i] = 0; }
+      WSYNC();
+      for (int i = lane; i < nv; i += 64) {
+        int adr = dof_Madr[i]; float vi = s_tmpv[i], acc = s_qM[adr] * vi; int k = 1;
+        for (int j = dof_parentid[i]; j >= 0; j = dof_parentid[j]) { float mij = s_qM[adr + k]; acc += mij * s_tmpv[j]; atomicAdd(&s_tmpv2[j], mij * vi); k++; }
+        atomicAdd(&s_tmpv2[i], acc);
+      }
+      WSYNC();
+      for (int i = lane; i < nv; i += 64) S.x_res[(size_t)blockIdx.x * M.nvp + i] = s_tmpv2[i];
+      break;
+    }
+    // ---- L'DL factorisation (mj_factorM): one lane per kinematic tree
+    for (int t = lane; t < M.ntree; t += 64) factor_tree(s_qLD, s_qLDinv, dof_parentid, dof_Madr, tree_dofadr[t], tree_dofnum[t]);
+    WSYNC();
+
+    // ---- collision (mj_collision): lanes = candidate geom pairs of the static pair list
+    ncon = 0;
+    if (!(M.disableflags & (MJH_DSBL_CONTACT | MJH_DSBL_CONSTRAINT))) {
+      int conbase = 0;
+      for (int base = 0; base < M.npair; base += 64) {
+        const int ip = base + lane;
+        int n = 0, g1 = 0, g2 = 0; float margin = 0, gap = 0;
+        float* st = s_stage;
+        if (ip < M.npair) {
+          g1 = pair_geom1[ip]; g2 = pair_geom2[ip];
+          st = s_stage + pair_stageadr[ip] * RAW_STRIDE;
+          const int t1 = geom_type[g1], t2 = geom_type[g2];
+          margin = fmaxf(geom_margin[g1], geom_margin[g2]); gap = fmaxf(geom_gap[g1], geom_gap[g2]);
+          float p1[3], p2[3], m1[9], m2[9], z1[3], z2[3];
+#pragma unroll
+          for (int k = 0; k < 3; k++) { p1[k] = s_gpos[3*g1+k]; p2[k] = s_gpos[3*g2+k]; z1[k] = geom_size[3*g1+k]; z2[k] = geom_size[3*g2+k]; }
+#pragma unroll
+          for (int k = 0; k < 9; k++) { m1[k] = s_gmat[9*g1+k]; m2[k] = s_gmat[9*g2+k]; }
+          bool cull;
+          float tt[3] = {p2[0]-p1[0], p2[1]-p1[1], p2[2]-p1[2]};
+          if (t1 == MJH_GEOM_PLANE) { float nn[3] = {m1[2], m1[5], m1[8]}; cull = dot3(tt, nn) > geom_rbound[g2] + margin; }
+          else { float bound = geom_rbound[g1] + geom_rbound[g2] + margin; cull = dot3(tt, tt) > bound * bound; }
+          if (!cull) {
+            if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_BOX) n = c_plane_box(p1, m1, p2, m2, z2, margin, st);
+            else if (t1 == MJH_GEOM_BOX && t2 == MJH_GEOM_BOX) n = c_box_box(p1, m1, z1, p2, m2, z2, margin, st);
+            else if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_SPHERE) n = c_plane_sphere(p1, m1, p2, z2[0], margin, st, 0);
+            else if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_CAPSULE) n = c_plane_capsule(p1, m1, p2, m2, z2, margin, st);
+            else if (t1 == MJH_GEOM_SPHERE && t2 == MJH_GEOM_SPHERE) n = c_sphere_sphere(p1, z1[0], p2, z2[0], margin, st);
+            else if (t1 == MJH_GEOM_SPHERE && t2 == MJH_GEOM_CAPSULE) n = c_sphere_capsule(p1, z1[0], p2, m2, z2, margin, st);
+            else if (t1 == MJH_GEOM_CAPSULE && t2 == MJH_GEOM_CAPSULE) n = c_capsule_capsule(p1, m1, z1, p2, m2, z2, margin, st);
+            else if (t1 == MJH_GEOM_SPHERE && t2 == MJH_GEOM_BOX) n = c_sphere_box(p1, z1[0], p2, m2, z2, margin, st);
+          }
+        }
+        const int incl = wave_incl_scan_i(n, lane);
+        const int total = __shfl(incl, 63);
+        const int first = conbase + incl - n;
+        for (int q = 0; q < n; q++) {
+          const int idx = first + q;
+          if (idx >= M.maxcon) break;
+          const float* r = st + q * RAW_STRIDE;
+          float fr[9]; fr[0] = r[4]; fr[1] = r[5]; fr[2] = r[6];
+          make_frame(fr);
+          float* c = s_con + idx * CON_STRIDE;
+          c[0] = r[0]; c[1] = r[1]; c[2] = r[2]; c[3] = r[3];
+#pragma unroll
+          for (int k = 0; k < 9; k++) c[4+k] = fr[k];
+          c[13] = __int_as_float(g1); c[14] = __int_as_float(g2);
+          c[15] = __int_as_float(max(geom_condim[g1], geom_condim[g2])); c[16] = margin - gap;
+        }
+        conbase += total;
+      }
+      if (conbase > M.maxcon) { flags |= 1; conbase = M.maxcon; }
+      ncon = conbase;
+    }
+    WSYNC();
+    if ((xflags & XF_CON) && S.x_contacts) {
+      float* o = S.x_contacts + (size_t)blockIdx.x * M.maxcon * CON_STRIDE;
+      for (int i = lane; i < ncon * CON_STRIDE; i += 64) o[i] = s_con[i];
+      WSYNC();
+    }
+
+    // ---- constraint rows (mj_makeConstraint + mj_makeImpedance): header pass, then lanes = rows
+    nefc = 0;
+    if (!(M.disableflags & MJH_DSBL_CONSTRAINT)) {
+      // equality rows (static count), friction-loss rows (static count)
+      int nstatic = 0;
+      if (!(M.disableflags & MJH_DSBL_EQUALITY)) {
+        for (int e = 0; e < M.neq; e++) if (eq_active[e]) {
+          if (lane == 0) { int* hd = s_rowi_i + nstatic * ROWI_STRIDE; hd[0] = MJH_CNSTR_EQUALITY; hd[1] = e; }
+          nstatic++;
+        }
+      }
+      if (!(M.disableflags & MJH_DSBL_FRICTIONLOSS)) {
+        for (int f = lane; f < M.nfl; f += 64) { int* hd = s_rowi_i + (nstatic + f) * ROWI_STRIDE; hd[0] = MJH_CNSTR_FRICTION_DOF; hd[1] = fl_dof[f]; }
+        nstatic += M.nfl;
+      }
+      nefc = nstatic;
+      if (M.has_limits && !(M.disableflags & MJH_DSBL_LIMIT)) {
+        for (int base = 0; base < njnt; base += 64) {
+          const int j = base + lane; int lo = 0, hi = 0;
+          if (j < njnt && jnt_limited[j] && (jnt_type[j] == MJH_JNT_HINGE || jnt_type[j] == MJH_JNT_SLIDE)) {
+            float val = s_qpos[jnt_qposadr[j]], mg = jnt_margin[j];
+            lo = (val - jnt_range[2*j]) < mg; hi = (jnt_range[2*j+1] - val) < mg;
+          }
+          const int n = lo + hi, incl = wave_incl_scan_i(n, lane);
+          int r = nefc + incl - n;
+          if (lo && r < M.maxefc) { int* hd = s_rowi_i + r * ROWI_STRIDE; hd[0] = MJH_CNSTR_LIMIT_JOINT; hd[1] = j; r++; }
+          if (hi && r < M.maxefc) { int* hd = s_rowi_i + r * ROWI_STRIDE; hd[0] = MJH_CNSTR_LIMIT_JOINT | (1 << 8); hd[1] = j; }
+          nefc += __shfl(incl, 63);
+        }
+        if (nefc > M.maxefc) { nefc = M.maxefc; flags |= 2; }
+      }
+      // contact rows: a contact whose rows do not fit drops it and every later contact (oracle rule)
+      bool stop = false;
+      for (int base = 0; base < ncon && !stop; base += 64) {
+        const int ic = base + lane; int n = 0, dim = 0;
+        if (ic < ncon) {
+          const float* c = s_con + ic * CON_STRIDE;
+          dim = __float_as_int(c[15]);
+          n = (c[0] >= c[16]) ? 0 : (dim == 1 ? 1 : 2 * (dim - 1));
+        }
+        const int incl = wave_incl_scan_i(n, lane);
+        const int r0 = nefc + incl - n;
+        const unsigned long long over = __ballot(n > 0 && r0 + n > M.maxefc);
+        const int firstover = over ? __ffsll((long long)over) - 1 : 64;
+        if (n > 0 && lane < firstover) {
+          for (int q = 0; q < n; q++) {
+            int* hd = s_rowi_i + (r0 + q) * ROWI_STRIDE;
+            hd[0] = (dim == 1 ? MJH_CNSTR_CONTACT_FRICTIONLESS : MJH_CNSTR_CONTACT_PYRAMIDAL) | (q << 8); hd[1] = ic;
+          }
+        }
+        if (over) { flags |= 2; stop = true; nefc = __shfl(r0, firstover); }
+        else nefc += __shfl(incl, 63);
+      }
+    }
+    WSYNC();
+    // rows: Jacobian (compact over the trees it touches), impedance, regulariser, reference gains
+    for (int r = lane; r < nefc; r += 64) {
+      int* hd = s_rowi_i + r * ROWI_STRIDE;
+      const int type = hd[0] & 0xff, id = hd[1], sub = hd[0] >> 8;
+      float* J = s_J + r * M.rowW; float* rf = s_rowf + r * ROWF_STRIDE;
+      for (int k = 0; k < M.rowW; k++) J[k] = 0;
+      float pos = 0, margin = 0, diagA = 0, lo = 0, hi = 3.0e38f, rscale = -1;
+      const float *solref, *solimp;
+      int t1 = -1, t2 = -1;
+      if (type == MJH_CNSTR_EQUALITY) {
+        const int j1 = eq_obj1id[id], j2 = eq_obj2id[id];
+        const float* dat = eq_data + 11*id;
+        const int d1 = jnt_dofadr[j1];
+        float pos1 = s_qpos[jnt_qposadr[j1]] - qpos0[jnt_qposadr[j1]];
+        t1 = dof_treeid[d1];
+        J[d1 - tree_dofadr[t1]] = 1; diagA = dof_invweight0[d1];
+        if (j2 >= 0) {
+          const int d2 = jnt_dofadr[j2];
+          float p2 = s_qpos[jnt_qposadr[j2]] - qpos0[jnt_qposadr[j2]];
+          pos = pos1 - (dat[0] + p2*(dat[1] + p2*(dat[2] + p2*(dat[3] + p2*dat[4]))));
+          float deriv = dat[1] + p2*(2*dat[2] + p2*(3*dat[3] + p2*4*dat[4]));
+          int tt = dof_treeid[d2];
+          if (tt == t1) J[d2 - tree_dofadr[t1]] += -deriv;
+          else { t2 = tt; J[tree_dofnum[t1] + d2 - tree_dofadr[t2]] = -deriv; }
+          diagA += dof_invweight0[d2];
+        } else pos = pos1 - dat[0];
+        solref = eq_solref + 2*id; solimp = eq_solimp + 5*id; lo = -3.0e38f;
+      } else if (type == MJH_CNSTR_FRICTION_DOF) {
+        t1 = dof_treeid[id]; J[id - tree_dofadr[t1]] = 1; diagA = dof_invweight0[id];
+        solref = dof_solref + 2*id; solimp = dof_solimp + 5*id; lo = -dof_frictionloss[id]; hi = dof_frictionloss[id];
+      } else if (type == MJH_CNSTR_LIMIT_JOINT) {
+        const int d = jnt_dofadr[id]; float val = s_qpos[jnt_qposadr[id]];
+        t1 = dof_treeid[d];
+        if (sub == 0) { pos = val - jnt_range[2*id]; J[d - tree_dofadr[t1]] = 1; } else { pos = jnt_range[2*id+1] - val; J[d - tree_dofadr[t1]] = -1; }
+        margin = jnt_margin[id]; diagA = dof_invweight0[d];
+        solref = jnt_solref + 2*id; solimp = jnt_solimp + 5*id;
+      } else {
+        const float* c = s_con + id * CON_STRIDE;
+        const int g1 = __float_as_int(c[13]), g2 = __float_as_int(c[14]), dim = __float_as_int(c[15]);
+        const int b1 = geom_bodyid[g1], b2 = geom_bodyid[g2];
+        pos = c[0]; margin = c[16];
+        // contact parameters (mj_contactParam): max friction, solmix-weighted solref/solimp
+        float f0 = fmaxf(geom_friction[3*g1], geom_friction[3*g2]), f1 = fmaxf(geom_friction[3*g1+1], geom_friction[3*g2+1]),
+              f2 = fmaxf(geom_friction[3*g1+2], geom_friction[3*g2+2]);
+        const int k = (type == MJH_CNSTR_CONTACT_FRICTIONLESS) ? 0 : 1 + (sub >> 1);  // pyramid edge direction index 1..dim-1
+        const float sgn = (sub & 1) ? -1.0f : 1.0f;
+        const float mu = (k == 0) ? 0.0f : (k <= 2 ? f0 : (k == 3 ? f1 : f2));
+        const float tran = body_invweight0[2*b1] + body_invweight0[2*b2], rot = body_invweight0[2*b1+1] + body_invweight0[2*b2+1];
+        (void)dim;
+        if (k == 0) diagA = tran;
+        else { diagA = tran + f0*f0*tran; float mu0 = f0 * rsqrtf(M.impratio); rscale = 2 * mu0 * mu0; }  // Rpy = 2 mu^2 R(first row)
+        t1 = body_treeid[b1]; t2 = body_treeid[b2];
+        if (t1 < 0) { t1 = t2; t2 = -1; }
+        if (t2 == t1) t2 = -1;
+        const float* n = c + 4; const float* tk = c + 4 + 3 * (k <= 2 ? k : k - 3);
+        // Jacobian difference (body2 - body1) projected on (normal + sgn*mu*direction_k)
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+          const int b = side ? b2 : b1; const float ss = side ? 1.0f : -1.0f;
+          int i = body_lastdof[b];
+          if (i < 0) continue;
+          const float* com = s_com + 3*body_rootid[b];
+          const float off[3] = {c[1] - com[0], c[2] - com[1], c[3] - com[2]};
+          const int tr = dof_treeid[i];
+          const int o = (tr == t1) ? -tree_dofadr[t1] : tree_dofnum[t1] - tree_dofadr[t2];
+          for (; i >= 0; i = dof_parentid[i]) {
+            const float* cd = s_cdof + 6*i;
+            float cr[3]; cross3(cr, cd, off);
+            float jp[3] = {cd[3] + cr[0], cd[4] + cr[1], cd[5] + cr[2]};
+            float v = dot3(n, jp);
+            if (k >= 1 && k <= 2) v += sgn * mu * dot3(tk, jp);
+            else if (k >= 3) v += sgn * mu * dot3(tk, cd);
+            J[o + i] += ss * v;
+          }
+        }
+        {
+          const float a = geom_solmix[g1], bq = geom_solmix[g2];
+          float mix = (a >= MJ_MINVAL && bq >= MJ_MINVAL) ? a / (a + bq) : ((a < MJ_MINVAL && bq < MJ_MINVAL) ? 0.5f : (a < MJ_MINVAL ? 0.0f : 1.0f));
+          float* sr = s_tmpv;  // unused here; parameters are mixed into registers below
+          (void)sr;
+          float srm[2] = {mix*geom_solref[2*g1] + (1-mix)*geom_solref[2*g2], mix*geom_solref[2*g1+1] + (1-mix)*geom_solref[2*g2+1]};
+          float sim[5];
+#pragma unroll
+          for (int q = 0; q < 5; q++) sim[q] = mix*geom_solimp[5*g1+q] + (1-mix)*geom_solimp[5*g2+q];
+          // finish this row here (parameters live in registers)
+          float imp = get_impedance(sim, pos, margin);
+          float R = fmaxf(MJ_MINVAL, (1 - imp) * diagA / imp);
+          if (rscale > 0) R = fmaxf(MJ_MINVAL, rscale * R);
+          float sr0 = srm[0], sr1 = srm[1], dmax = fminf(MAXIMP, fmaxf(MINIMP, sim[1])), K, Bc;
+          if (sr0 > 0) {
+            if (!(M.disableflags & MJH_DSBL_REFSAFE)) sr0 = fmaxf(sr0, 2 * h);
+            K = 1 / fmaxf(MJ_MINVAL, dmax*dmax * sr0*sr0 * sr1*sr1); Bc = 2 / fmaxf(MJ_MINVAL, dmax * sr0);
+          } else { K = -sr0 / fmaxf(MJ_MINVAL, dmax*dmax); Bc = -sr1 / fmaxf(MJ_MINVAL, dmax); }
+          rf[0] = K * imp * (pos - margin); rf[1] = Bc; rf[2] = R; rf[6] = lo; rf[7] = hi;
+          hd[2] = tree_dofadr[t1] | (tree_dofnum[t1] << 16); hd[3] = t2 >= 0 ? (tree_dofadr[t2] | (tree_dofnum[t2] << 16)) : 0;
+          continue;
+        }
+      }
+      float imp = get_impedance(solimp, pos, margin);
+      float R = fmaxf(MJ_MINVAL, (1 - imp) * diagA / imp);
+      float sr0 = solref[0], sr1 = solref[1], dmax = fminf(MAXIMP, fmaxf(MINIMP, solimp[1])), K, Bc;
+      if (sr0 > 0) {
+        if (!(M.disableflags & MJH_DSBL_REFSAFE)) sr0 = fmaxf(sr0, 2 * h);
+        K = 1 / fmaxf(MJ_MINVAL, dmax*dmax * sr0*sr0 * sr1*sr1); Bc = 2 / fmaxf(MJ_MINVAL, dmax * sr0);
+      } else { K = -sr0 / fmaxf(MJ_MINVAL, dmax*dmax); Bc = -sr1 / fmaxf(MJ_MINVAL, dmax); }
+      if (type == MJH_CNSTR_FRICTION_DOF) K = 0;
+      rf[0] = K * imp * (pos - margin); rf[1] = Bc; rf[2] = R; rf[6] = lo; rf[7] = hi;
+      hd[2] = tree_dofadr[t1] | (tree_dofnum[t1] << 16); hd[3] = t2 >= 0 ? (tree_dofadr[t2] | (tree_dofnum[t2] << 16)) : 0;
+    }
+    WSYNC();
+    // B = M^-1 J^T per row (mj_projectConstraint without the dense AR), ARinv = 1/(J.B + R)
+    for (int r = lane; r < nefc; r += 64) {
+      const int* hd = s_rowi_i + r * ROWI_STRIDE;
+      ROW_TREES(hd[2], hd[3]);
+      const float* J = s_J + r * M.rowW; float* B = s_B + r * M.rowW; float* rf = s_rowf + r * ROWF_STRIDE;
+      int wdt = n1;
+      for (int k = 0; k < n1; k++) B[k] = J[k];
+      solve_tree(B - a1, s_qLD, s_qLDinv, dof_parentid, dof_Madr, a1, n1);
+      if (n2 > 0) {
+        for (int k = 0; k < n2; k++) B[n1 + k] = J[n1 + k];
+        solve_tree(B + n1 - a2, s_qLD, s_qLDinv, dof_parentid, dof_Madr, a2, n2);
+        wdt += n2;
+      }
+      float d = rf[2];
+      for (int k = 0; k < wdt; k++) d += J[k] * B[k];
+      rf[3] = 1.0f / d;
+    }
+    WSYNC();
+
+    // ================================================================ velocity stage (lambda: used by step1, inverse, step2-alone)
+    auto vel_levels = [&](const float* qv, const float* qa, float* out) {
+      // mj_comVel + mj_rne forward/backward; qa != null adds cdof*qacc (flg_acc)
+      if (lane == 0) { for (int k = 0; k < 6; k++) { s_cvel[k] = 0; s_cacc[k] = (k >= 3) ? -grav[k-3] : 0.0f; s_cfrc[k] = 0; } }
+      WSYNC();
+      for (int lev = 1; lev <= M.maxlevel; lev++) {
+        for (int b = lane; b < nbody; b += 64) {
+          if (body_level[b] != lev) continue;
+          const int p = body_parentid[b];
+          float cv[6], ca[6];
+#pragma unroll
+          for (int q = 0; q < 6; q++) { cv[q] = s_cvel[6*p+q]; ca[q] = s_cacc[6*p+q]; }
+          int bda = body_dofadr[b];
+          for (int j = 0; j < body_jntnum[b]; j++) {
+            const int jt = jnt_type[body_jntadr[b] + j];
+            if (jt == MJH_JNT_FREE) {
+              for (int k = 0; k < 3; k++) {
+#pragma unroll
+                for (int q = 0; q < 6; q++) { s_cdofdot[6*(bda+k)+q] = 0; cv[q] += s_cdof[6*(bda+k)+q] * qv[bda+k]; }
+              }
+              bda += 3;
+            }
+            const int nd = (jt == MJH_JNT_FREE || jt == MJH_JNT_BALL) ? 3 : 1;
+            float cvn[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) cvn[q] = cv[q];
+            for (int k = 0; k < nd; k++) {
+              float cd[6], cdd[6];
+#pragma unroll
+              for (int q = 0; q < 6; q++) cd[q] = s_cdof[6*(bda+k)+q];
+              cross_motion(cdd, cv, cd);
+              const float v = qv[bda+k];
+#pragma unroll
+              for (int q = 0; q < 6; q++) { s_cdofdot[6*(bda+k)+q] = cdd[q]; cvn[q] += cd[q] * v; }
+            }
+#pragma unroll
+            for (int q = 0; q < 6; q++) cv[q] = cvn[q];
+            bda += nd;
+          }
+          for (int d = body_dofadr[b]; d < body_dofadr[b] + body_dofnum[b]; d++) {
+            const float v = qv[d], a = qa ? qa[d] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 6; q++) ca[q] += s_cdofdot[6*d+q] * v + s_cdof[6*d+q] * a;
+          }
+          float ci[10], f[6], t[6], t1[6];
+#pragma unroll
+          for (int k = 0; k < 10; k++) ci[k] = s_cinert[10*b+k];
+          mul_inert_vec(f, ci, ca); mul_inert_vec(t, ci, cv); cross_force(t1, cv, t);
+#pragma unroll
+          for (int q = 0; q < 6; q++) { s_cvel[6*b+q] = cv[q]; s_cacc[6*b+q] = ca[q]; s_cfrc[6*b+q] = f[q] + t1[q]; }
+        }
+        WSYNC();
+      }
+      for (int b = lane; b < nbody; b += 64) {
+        float acc[6] = {0, 0, 0, 0, 0, 0};
+        if (b > 0) for (int c = b; c < b + body_subtreesize[b]; c++)
+#pragma unroll
+          for (int q = 0; q < 6; q++) acc[q] += s_cfrc[6*c+q];
+#pragma unroll
+        for (int q = 0; q < 6; q++) s_cfrcsub[6*b+q] = acc[q];
+      }
+      WSYNC();
+      for (int d = lane; d < nv; d += 64) {
+        float v = 0; const float* f = s_cfrcsub + 6*dof_bodyid[d];
+#pragma unroll
+        for (int q = 0; q < 6; q++) v += s_cdof[6*d+q] * f[q];
+        out[d] = v;
+      }
+      WSYNC();
+    };
+    auto vel_stage = [&](const float* qv) {
+      vel_levels(qv, nullptr, s_bias);
+      // mj_passive: springs, dampers, gravity compensation (gravcomp: mj_sim.cpp:301-310)
+      for (int d = lane; d < nv; d += 64) {
+        float v = 0;
+        if (!(M.disableflags & MJH_DSBL_PASSIVE)) {
+          const int j = dof_jntid[d], jt = jnt_type[j];
+          if ((jt == MJH_JNT_HINGE || jt == MJH_JNT_SLIDE) && jnt_stiffness[j] != 0) v -= jnt_stiffness[j] * (s_qpos[jnt_qposadr[j]] - qpos_spring[jnt_qposadr[j]]);
+          v -= dof_damping[d] * qv[d];
+          const int bd = dof_bodyid[d];
+          for (int g = 0; g < M.ngc; g++) {
+            const int b = gc_body[g];
+            if (b < bd || b >= bd + body_subtreesize[bd]) continue;
+            const float* com = s_com + 3*body_rootid[b];
+            const float off[3] = {s_xipos[3*b] - com[0], s_xipos[3*b+1] - com[1], s_xipos[3*b+2] - com[2]};
+            const float* cd = s_cdof + 6*d;
+            float cr[3]; cross3(cr, cd, off);
+            const float sc = -body_mass[b] * body_gravcomp[b];
+            v += sc * ((cd[3] + cr[0]) * grav[0] + (cd[4] + cr[1]) * grav[1] + (cd[5] + cr[2]) * grav[2]);
+          }
+        }
+        s_passive[d] = v;
+      }
+      // mj_referenceConstraint: aref = -B (J qvel) - K imp (pos - margin)
+      for (int r = lane; r < nefc; r += 64) {
+        const int* hd = s_rowi_i + r * ROWI_STRIDE;
+        ROW_TREES(hd[2], hd[3]);
+        const float* J = s_J + r * M.rowW; float* rf = s_rowf + r * ROWF_STRIDE;
+        float vel = 0;
+        for (int k = 0; k < n1; k++) vel += J[k] * qv[a1 + k];
+        for (int k = 0; k < n2; k++) vel += J[n1 + k] * qv[a2 + k];
+        rf[4] = -rf[1] * vel - rf[0];
+      }
+      WSYNC();
+    };
+
+    if (ph & PH_STEP1) {
+      vel_stage(s_qvel);
+      if ((xflags & XF_FORCE) && S.x_energy) {  // mj_energyPos / mj_energyVel
+        float pe = 0, ke = 0;
+        for (int b = lane; b < nbody; b += 64) if (b > 0) {
+          pe -= body_mass[b] * (grav[0]*s_xipos[3*b] + grav[1]*s_xipos[3*b+1] + grav[2]*s_xipos[3*b+2]);
+          float t[6]; mul_inert_vec(t, s_cinert + 10*b, s_cvel + 6*b);
+          for (int q = 0; q < 6; q++) ke += 0.5f * t[q] * s_cvel[6*b+q];
+        }
+        pe = wave_sum<4>(pe); ke = wave_sum<4>(ke);
+        if (lane == 0) { S.x_energy[2*blockIdx.x] = pe; S.x_energy[2*blockIdx.x+1] = ke; }
+      }
+      // ---- controller (MjSim::controller, mj_sim.cpp:1055-1077)
+      bool anydd = false, anydq = false;
+      for (int d = lane; d < nv; d += 64) {
+        float a = (step == 0) ? S.ddq[vrow + d] : 0.0f, v = (step == 0) ? S.dq[vrow + d] : 0.0f;
+        s_tmpv[d] = a; s_tmpv2[d] = v; anydd |= a != 0; anydq |= fabsf(v) > MJ_MINVAL;
+        s_applied[d] = 0; s_qvref[d] = s_qvel[d];
+      }
+      anydd = wave_any(anydd); anydq = wave_any(anydq);
+      WSYNC();
+      if (anydd) {  // tau = M ddq (mj_mulM, :1057)
+        for (int i = lane; i < nv; i += 64) {
+          int adr = dof_Madr[i]; float vi = s_tmpv[i], acc = s_qM[adr] * vi; int k = 1;
+          for (int j = dof_parentid[i]; j >= 0; j = dof_parentid[j]) { float mij = s_qM[adr + k]; acc += mij * s_tmpv[j]; atomicAdd(&s_applied[j], mij * vi); k++; }
+          atomicAdd(&s_applied[i], acc);
+        }
+        WSYNC();
+      }
+      for (int d = lane; d < nv; d += 64) {
+        if (controlled[d]) s_applied[d] += s_bias[d];            // :1058-1063
+        if (fabsf(s_tmpv2[d]) > MJ_MINVAL) s_qvel[d] = s_tmpv2[d];  // :1067-1073 velocity override
+        if (step == 0 && (anydd || anydq)) { S.ddq[vrow + d] = 0; S.dq[vrow + d] = 0; }  // :1075-1076
+      }
+      WSYNC();
+      if ((ph & PH_INV) && anydq) { vel_stage(s_qvel); for (int d = lane; d < nv; d += 64) s_qvref[d] = s_qvel[d]; WSYNC(); }
+    } else {
+      // split API: re-create the velocity-stage quantities the previous call left behind
+      if (ph & PH_INV) { for (int d = lane; d < nv; d += 64) s_qvref[d] = s_qvel[d]; WSYNC(); }
+      vel_stage(s_qvref);
+    }
+    if ((xflags & XF_FORCE) && (ph & (PH_STEP1 | PH_INV))) {
+      const size_t e = (size_t)blockIdx.x * M.nvp;
+      for (int d = lane; d < nv; d += 64) { if (S.x_bias) S.x_bias[e + d] = s_bias[d]; if (S.x_passive) S.x_passive[e + d] = s_passive[d]; }
+    }
+
+    // ================================================================ inverse (mj_inverse, mj_hw_interface.cpp:61)
+    if (ph & PH_INV) {
+      // analytic constraint force at the current qacc (mj_constraintUpdate), qc = J^T f
+      for (int r = lane; r < nefc; r += 64) {
+        const int* hd = s_rowi_i + r * ROWI_STRIDE;
+        ROW_TREES(hd[2], hd[3]);
+        const float* J = s_J + r * M.rowW; float* rf = s_rowf + r * ROWF_STRIDE;
+        float jar = -rf[4];
+        for (int k = 0; k < n1; k++) jar += J[k] * s_qacc[a1 + k];
+        for (int k = 0; k < n2; k++) jar += J[n1 + k] * s_qacc[a2 + k];
+        const float D = 1.0f / rf[2], R = rf[2];
+        float f;
+        if ((hd[0] & 0xff) == MJH_CNSTR_EQUALITY) f = -D * jar;
+        else if ((hd[0] & 0xff) == MJH_CNSTR_FRICTION_DOF) { float fl = rf[7]; f = (jar <= -R*fl) ? fl : ((jar >= R*fl) ? -fl : -D * jar); }
+        else f = jar < 0 ? -D * jar : 0.0f;
+        rf[5] = f;
+      }
+      WSYNC();
+      for (int d = lane; d < nv; d += 64) {
+        float acc = 0;
+        for (int r = 0; r < nefc; r++) {
+          const int* hd = s_rowi_i + r * ROWI_STRIDE;
+          ROW_TREES(hd[2], hd[3]);
+          const int o = row_off(d, a1, n1, a2, n2);
+          if (o >= 0) acc += s_J[r * M.rowW + o] * s_rowf[r * ROWF_STRIDE + 5];
+        }
+        s_tmpv2[d] = acc;
+      }
+      WSYNC();
+      vel_levels(s_qvel, s_qacc, s_tmpv);  // RNE with acceleration
+      for (int d = lane; d < nv; d += 64) S.qfrc_inverse[vrow + d] = s_tmpv[d] + dof_armature[d] * s_qacc[d] - s_passive[d] - s_tmpv2[d];
+    }
+
+    // ================================================================ step2 (mj_step2, mj_main.cpp:108)
+    if (ph & (PH_STEP2 | PH_NOINT)) {
+      // ---- smooth acceleration (mj_fwdAcceleration)
+      for (int d = lane; d < nv; d += 64) { float f = s_passive[d] - s_bias[d] + s_applied[d]; s_smooth[d] = f; s_asmooth[d] = f; }
+      WSYNC();
+      for (int t = lane; t < M.ntree; t += 64) solve_tree(s_asmooth, s_qLD, s_qLDinv, dof_parentid, dof_Madr, tree_dofadr[t], tree_dofnum[t]);
+      WSYNC();
+      niter = 0;
+      if (nefc == 0) {
+        for (int d = lane; d < nv; d += 64) { s_qacc[d] = s_asmooth[d]; s_ws[d] = s_asmooth[d]; s_tmpv2[d] = 0; }
+        WSYNC();
+      } else {
+        // ---- warm start (mj_fwdConstraint): forces implied by qacc_warmstart, kept if dual cost < 0
+        const bool warm = !(M.disableflags & MJH_DSBL_WARMSTART);
+        for (int r = lane; r < nefc; r += 64) {
+          float* rf = s_rowf + r * ROWF_STRIDE; float f = 0;
+          if (warm) {
+            const int* hd = s_rowi_i + r * ROWI_STRIDE;
+            ROW_TREES(hd[2], hd[3]);
+            const float* J = s_J + r * M.rowW;
+            float jar = -rf[4];
+            for (int k = 0; k < n1; k++) jar += J[k] * s_ws[a1 + k];
+            for (int k = 0; k < n2; k++) jar += J[n1 + k] * s_ws[a2 + k];
+            const float D = 1.0f / rf[2], R = rf[2];
+            if ((hd[0] & 0xff) == MJH_CNSTR_EQUALITY) f = -D * jar;
+            else if ((hd[0] & 0xff) == MJH_CNSTR_FRICTION_DOF) { float fl = rf[7]; f = (jar <= -R*fl) ? fl : ((jar >= R*fl) ? -fl : -D * jar); }
+            else f = jar < 0 ? -D * jar : 0.0f;
+          }
+          rf[5] = f;
+        }
+        WSYNC();
+        // da = sum_i B_i f_i  (lanes = dofs)
+        for (int d = lane; d < nv; d += 64) {
+          float acc = 0;
+          if (warm) for (int r = 0; r < nefc; r++) {
+            const int* hd = s_rowi_i + r * ROWI_STRIDE;
+            ROW_TREES(hd[2], hd[3]);
+            const int o = row_off(d, a1, n1, a2, n2);
+            if (o >= 0) acc += s_B[r * M.rowW + o] * s_rowf[r * ROWF_STRIDE + 5];
+          }
+          s_tmpv[d] = acc;
+        }
+        WSYNC();
+        if (warm) {
+          float cost = 0;
+          for (int r = lane; r < nefc; r += 64) {
+            const int* hd = s_rowi_i + r * ROWI_STRIDE;
+            ROW_TREES(hd[2], hd[3]);
+            const float* J = s_J + r * M.rowW; const float* rf = s_rowf + r * ROWF_STRIDE;
+            float jda = 0, b = -rf[4];
+            for (int k = 0; k < n1; k++) { jda += J[k] * s_tmpv[a1 + k]; b += J[k] * s_asmooth[a1 + k]; }
+            for (int k = 0; k < n2; k++) { jda += J[n1 + k] * s_tmpv[a2 + k]; b += J[n1 + k] * s_asmooth[a2 + k]; }
+            const float f = rf[5];
+            cost += f * (0.5f * (jda + rf[2] * f) + b);
+          }
+          cost = wave_sum<4>(cost);
+          if (cost > 0) {
+            for (int r = lane; r < nefc; r += 64) s_rowf[r * ROWF_STRIDE + 5] = 0;
+            for (int d = lane; d < nv; d += 64) s_tmpv[d] = 0;
+          }
+          WSYNC();
+        }
+        // ---- PGS (mj_solPGS) in matrix-free form: lanes = dofs, running acceleration a in registers.
+        //      row i:  res = J_i.a - aref_i + R_i f_i ;  f_i <- clamp(f_i - res/AR_ii) ;  a += B_i * delta
+        // TODO(perf, next round): nv > 64 needs several dofs per lane
+        const int d0 = lane;
+        float a = (d0 < nv) ? s_asmooth[d0] + s_tmpv[d0] : 0.0f;
+        const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
+        const int rowW = M.rowW;
+        // forces live in registers: lane l holds f of rows l, 64+l, 128+l, 192+l (maxefc <= 256);
+        // nothing is stored to LDS inside the sweep, so next-row operands can be fetched early
+        float fr[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) fr[c] = (64*c + lane < nefc) ? s_rowf[(64*c + lane) * ROWF_STRIDE + 5] : 0.0f;
+        struct RowOp { float Jd, Bd, aref, R, ARinv, lo, hi; };
+        auto fetch = [&](int r) {
+          RowOp op;
+          const int4 hd = *(const int4*)(s_rowi_i + r * ROWI_STRIDE);
+          const float4 ra = *(const float4*)(s_rowf + r * ROWF_STRIDE);      // KI, Bc, R, ARinv
+          const float4 rb = *(const float4*)(s_rowf + r * ROWF_STRIDE + 4);  // aref, f, lo, hi
+          ROW_TREES(hd.z, hd.w);
+          const int o = row_off(d0, a1, n1, a2, n2);
+          op.Jd = 0; op.Bd = 0;
+          if (o >= 0) { op.Jd = s_J[r * rowW + o]; op.Bd = s_B[r * rowW + o]; }
+          op.aref = rb.x; op.R = ra.z; op.ARinv = ra.w; op.lo = rb.z; op.hi = rb.w;
+          return op;
+        };
+        for (int it = 0; it < M.iterations; it++) {
+          float improvement = 0;
+          RowOp cur = fetch(0);
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            if (64*c >= nefc) break;
+            const int nr = min(64, nefc - 64*c);
+            float fc = fr[c];
+            for (int rr = 0; rr < nr; rr++) {
+              const int r = 64*c + rr;
+              const RowOp nxt = fetch(r + 1 < nefc ? r + 1 : 0);
+              float s = cur.Jd * a;
+              s = (nv <= 16) ? wave_sum<1>(s) : ((nv <= 32) ? wave_sum<2>(s) : wave_sum<4>(s));
+              const float fold = readlane_f(fc, rr);
+              const float res = s - cur.aref + cur.R * fold;
+              float f = fminf(cur.hi, fmaxf(cur.lo, fold - res * cur.ARinv));
+              float delta = f - fold;
+              const float change = 0.5f * delta * delta / cur.ARinv + delta * res;
+              if (change > 1e-10f) { f = fold; delta = 0; } else improvement -= change;
+              a += cur.Bd * delta;
+              fc = (lane == rr) ? f : fc;
+              cur = nxt;
+            }
+            fr[c] = fc;
+          }
+          niter = it + 1;
+          if (improvement * scale < M.tolerance) break;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) if (64*c + lane < nefc) s_rowf[(64*c + lane) * ROWF_STRIDE + 5] = fr[c];
+        WSYNC();
+        if (d0 < nv) { s_qacc[d0] = a; s_ws[d0] = a; }
+        WSYNC();
+        // qfrc_constraint = J^T f (only needed by the implicit-damping integrator and for export)
+        if (M.has_damping || (xflags & XF_FORCE)) {
+          for (int d = lane; d < nv; d += 64) {
+            float acc = 0;
+            for (int r = 0; r < nefc; r++) {
+              const int* hd = s_rowi_i + r * ROWI_STRIDE;
+              ROW_TREES(hd[2], hd[3]);
+              const int o = row_off(d, a1, n1, a2, n2);
+              if (o >= 0) acc += s_J[r * M.rowW + o] * s_rowf[r * ROWF_STRIDE + 5];
+            }
+            s_tmpv2[d] = acc;
+          }
+          WSYNC();
+        }
+      }
+      if (xflags & XF_FORCE) {
+        const size_t e = (size_t)blockIdx.x * M.nvp;
+        for (int d = lane; d < nv; d += 64) { if (S.x_smooth) S.x_smooth[e + d] = s_asmooth[d]; if (S.x_constraint) S.x_constraint[e + d] = s_tmpv2[d]; }
+      }
+      if (ph & PH_STEP2) {
+        // ---- mj_checkAcc
+        bool badv = false;
+        for (int i = lane; i < nv; i += 64) { float y = s_qacc[i]; badv |= !(y == y) || fabsf(y) > MJ_MAXVAL; }
+        if (wave_any(badv)) {
+          for (int i = lane; i < nq; i += 64) s_qpos[i] = S.initial_qpos[qrow + i];
+          for (int i = lane; i < nv; i += 64) { s_qvel[i] = 0; s_qacc[i] = 0; s_ws[i] = 0; s_applied[i] = 0; s_tmpv2[i] = 0; s_smooth[i] = 0; }
+          flags |= 4;
+          WSYNC();
+        }
+        // ---- semi-implicit Euler with implicit joint damping (mj_Euler)
+        float* qint = s_qacc;
+        if (M.has_damping && !(M.disableflags & MJH_DSBL_EULERDAMP)) {
+          for (int i = lane; i < M.nM; i += 64) s_qLD[i] = s_qM[i];
+          for (int d = lane; d < nv; d += 64) s_tmpv[d] = s_smooth[d] + s_tmpv2[d];
+          WSYNC();
+          for (int d = lane; d < nv; d += 64) s_qLD[dof_Madr[d]] += h * dof_damping[d];
+          WSYNC();
+          for (int t = lane; t < M.ntree; t += 64) {
+            factor_tree(s_qLD, s_qLDinv, dof_parentid, dof_Madr, tree_dofadr[t], tree_dofnum[t]);
+            solve_tree(s_tmpv, s_qLD, s_qLDinv, dof_parentid, dof_Madr, tree_dofadr[t], tree_dofnum[t]);
+          }
+          WSYNC();
+          qint = s_tmpv;
+        }
+        for (int d = lane; d < nv; d += 64) s_qvel[d] += h * qint[d];
+        WSYNC();
+        for (int j = lane; j < njnt; j += 64) {
+          const int qa = jnt_qposadr[j], da = jnt_dofadr[j], jt = jnt_type[j];
+          if (jt == MJH_JNT_FREE) {
+            s_qpos[qa] += h * s_qvel[da]; s_qpos[qa+1] += h * s_qvel[da+1]; s_qpos[qa+2] += h * s_qvel[da+2];
+            float q[4] = {s_qpos[qa+3], s_qpos[qa+4], s_qpos[qa+5], s_qpos[qa+6]}, w[3] = {s_qvel[da+3], s_qvel[da+4], s_qvel[da+5]};
+            quat_integrate(q, w, h);
+            s_qpos[qa+3] = q[0]; s_qpos[qa+4] = q[1]; s_qpos[qa+5] = q[2]; s_qpos[qa+6] = q[3];
+          } else if (jt == MJH_JNT_BALL) {
+            float q[4] = {s_qpos[qa], s_qpos[qa+1], s_qpos[qa+2], s_qpos[qa+3]}, w[3] = {s_qvel[da], s_qvel[da+1], s_qvel[da+2]};
+            quat_integrate(q, w, h);
+            s_qpos[qa] = q[0]; s_qpos[qa+1] = q[1]; s_qpos[qa+2] = q[2]; s_qpos[qa+3] = q[3];
+          } else s_qpos[qa] += h * s_qvel[da];
+        }
+        time += h;
+        WSYNC();
+        // ---- odom velocities (MjSim::set_odom_vels, mj_sim.cpp:1079-1153)
+        if (lane == 0 && odom[9]) {
+          const float* v = S.odom_vel + (size_t)env * 6;
+          const float ax = odom[6] >= 0 ? s_qpos[odom[6]] : 0.0f, ay = odom[7] >= 0 ? s_qpos[odom[7]] : 0.0f, az = odom[8] >= 0 ? s_qpos[odom[8]] : 0.0f;
+          const float sx = sinf(ax), cx = cosf(ax), sy = sinf(ay), cy = cosf(ay), sz = sinf(az), cz = cosf(az);
+          if (odom[0] >= 0) s_qvel[odom[0]] = v[0]*cy*cz + v[1]*(sx*sy*cz - cx*sz) + v[2]*(cx*sy*cz + sx*sz);
+          if (odom[1] >= 0) s_qvel[odom[1]] = v[0]*cy*sz + v[1]*(sx*sy*sz + cx*cz) + v[2]*(cx*sy*sz - sx*cz);
+          if (odom[2] >= 0) s_qvel[odom[2]] = -v[0]*sy + v[1]*sx*cy + v[2]*cx*cy;
+          for (int k = 0; k < 3; k++) if (odom[3+k] >= 0) s_qvel[odom[3+k]] = v[3+k];
+        }
+        WSYNC();
+      }
+    }
+  }  // steps
+
+  if (ph & (PH_FKONLY | PH_MULM)) return;
+  // ------------------------------------------------------------------ store state
+  for (int i = lane; i < nq; i += 64) S.qpos[qrow + i] = s_qpos[i];
+  for (int i = lane; i < nv; i += 64) {
+    S.qvel[vrow + i] = s_qvel[i]; S.qacc_ws[vrow + i] = s_ws[i]; S.qacc[vrow + i] = s_qacc[i];
+    S.qvel_ref[vrow + i] = s_qvref[i]; S.qfrc_applied[vrow + i] = s_applied[i];
+  }
+  if (lane == 0) {
+    S.time[env] = time;
+    S.stats[4*env] = ncon; S.stats[4*env+1] = nefc; S.stats[4*env+2] = niter; S.stats[4*env+3] |= flags;
+  }
+}
+
+// pack time + qpos + qvel per env into one contiguous fp32 buffer (feeds the RCCL all-gather)
+__global__ void mjh_export_kernel(const DState S, float* out, int nenv, int nq, int nv, int nqp, int nvp) {
+  const int stride = 1 + nq + nv;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)nenv * stride; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = (int)(i / stride), k = (int)(i % stride);
+    out[i] = (k == 0) ? S.time[e] : (k <= nq ? S.qpos[(size_t)e * nqp + k - 1] : S.qvel[(size_t)e * nvp + k - 1 - nq]);
+  }
+}

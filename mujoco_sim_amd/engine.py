@@ -1,0 +1,209 @@
+"""Thin Python mirror of the C ABI: a `Model` (compiled scene) and an `Engine`
+(nenv environments on one HIP device).  Names follow the reference's step loop
+(src/mj_main.cpp:76-113): step1 / inverse / step2 / forward, set_cmd == MjHWInterface::write,
+get_joint_state == MjHWInterface::read.  All compute happens in libmjhip.so."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class MjhError(RuntimeError):
+    pass
+
+
+def _chk(lib, rc, what):
+    if rc is not None and rc < 0:
+        raise MjhError(f"{what} failed ({rc}): {lib.mjh_last_error().decode()}")
+    return rc
+
+
+class Model:
+    """Owns an mjh_model*."""
+
+    def __init__(self, ptr, lib=None):
+        self.lib = lib or capi.load()
+        if not ptr:
+            raise MjhError("model build failed: " + self.lib.mjh_last_error().decode())
+        self.ptr = ptr
+        self.c = ptr.contents
+
+    def __getattr__(self, name):
+        c = self.__dict__.get("c")
+        if c is not None and name in capi._INT_SIZES + ["meaninertia", "opt"]:
+            return getattr(c, name)
+        raise AttributeError(name)
+
+    def array(self, name):
+        return self.c.array(name)
+
+    def name2id(self, objtype, name):
+        return self.lib.mjh_name2id(self.ptr, objtype, name.encode())
+
+    def s24_randomize(self, env0, nenv, seed_base=0x5EED0000):
+        """Per-env S24 tables: dict of float64 arrays."""
+        c = self.c
+        out = dict(
+            qpos=np.zeros((nenv, c.nq)), geom_size=np.zeros((nenv, 3 * c.ngeom)), geom_rbound=np.zeros((nenv, c.ngeom)),
+            body_mass=np.zeros((nenv, c.nbody)), body_inertia=np.zeros((nenv, 3 * c.nbody)),
+            body_invweight0=np.zeros((nenv, 2 * c.nbody)), dof_invweight0=np.zeros((nenv, c.nv)))
+        rc = self.lib.mjh_scene_s24_randomize(self.ptr, env0, nenv, seed_base, *[capi.dptr(out[k]) for k in
+                                              ["qpos", "geom_size", "geom_rbound", "body_mass", "body_inertia",
+                                               "body_invweight0", "dof_invweight0"]])
+        _chk(self.lib, rc, "mjh_scene_s24_randomize")
+        return out
+
+
+def scene(name, *args):
+    lib = capi.load()
+    fn = {"s24": lib.mjh_scene_s24, "pendulum": lib.mjh_scene_pendulum, "arm7": lib.mjh_scene_arm7,
+          "boxpile": lib.mjh_scene_boxpile}[name]
+    return Model(fn(*args), lib)
+
+
+EP = dict(geom_size=0, geom_rbound=1, body_mass=2, body_inertia=3, body_invweight0=4, dof_invweight0=5)
+
+
+class Engine:
+    def __init__(self, model, nenv, device=0, stream=None):
+        self.lib = model.lib
+        self.model = model
+        self.nenv = nenv
+        h = C.c_void_p()
+        _chk(self.lib, self.lib.mjh_create(model.ptr, nenv, device, C.c_void_p(stream or 0), C.byref(h)), "mjh_create")
+        self.h = h
+        self.nq, self.nv, self.nbody, self.ngeom = model.nq, model.nv, model.nbody, model.ngeom
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mjh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- stepping (mj_main.cpp:83-110)
+    def step1(self): _chk(self.lib, self.lib.mjh_step1(self.h), "mjh_step1")
+    def step2(self): _chk(self.lib, self.lib.mjh_step2(self.h), "mjh_step2")
+    def inverse(self): _chk(self.lib, self.lib.mjh_inverse(self.h), "mjh_inverse")
+    def forward(self): _chk(self.lib, self.lib.mjh_forward(self.h), "mjh_forward")
+    def step(self, n=1, with_inverse=False): _chk(self.lib, self.lib.mjh_step(self.h, n, int(with_inverse)), "mjh_step")
+    def synchronize(self): _chk(self.lib, self.lib.mjh_synchronize(self.h), "mjh_synchronize")
+
+    # ---- commands (mj_hw_interface.cpp:73-91)
+    def set_cmd(self, ddq=None, dq=None, env0=0):
+        a = None if ddq is None else np.ascontiguousarray(ddq, dtype=np.float64).reshape(-1, self.nv)
+        b = None if dq is None else np.ascontiguousarray(dq, dtype=np.float64).reshape(-1, self.nv)
+        n = (a if a is not None else b).shape[0]
+        _chk(self.lib, self.lib.mjh_set_cmd(self.h, env0, n, capi.dptr(a), capi.dptr(b)), "mjh_set_cmd")
+
+    def set_controlled_dofs(self, mask):
+        m = np.ascontiguousarray(mask, dtype=np.int32)
+        _chk(self.lib, self.lib.mjh_set_controlled_dofs(self.h, capi.iptr(m)), "mjh_set_controlled_dofs")
+
+    def set_odom(self, lin, ang, angq):
+        a, b, c = (np.ascontiguousarray(x, dtype=np.int32) for x in (lin, ang, angq))
+        _chk(self.lib, self.lib.mjh_set_odom_dofs(self.h, capi.iptr(a), capi.iptr(b), capi.iptr(c)), "mjh_set_odom_dofs")
+
+    def set_odom_vel(self, twist, env0=0):
+        t = np.ascontiguousarray(twist, dtype=np.float64).reshape(-1, 6)
+        _chk(self.lib, self.lib.mjh_set_odom_vel(self.h, env0, t.shape[0], capi.dptr(t)), "mjh_set_odom_vel")
+
+    # ---- state
+    def get_state(self, env0=0, n=None):
+        n = self.nenv - env0 if n is None else n
+        t = np.zeros(n); q = np.zeros((n, self.nq)); v = np.zeros((n, self.nv)); w = np.zeros((n, self.nv))
+        _chk(self.lib, self.lib.mjh_get_state(self.h, env0, n, capi.dptr(t), capi.dptr(q), capi.dptr(v), capi.dptr(w)), "mjh_get_state")
+        return t, q, v, w
+
+    def set_state(self, qpos=None, qvel=None, time=None, warmstart=None, env0=0):
+        arrs = [None if x is None else np.ascontiguousarray(x, dtype=np.float64) for x in (time, qpos, qvel, warmstart)]
+        n = next(a for a in arrs if a is not None)
+        n = n.shape[0] if n.ndim > 1 or arrs[0] is n else 1
+        if qpos is not None:
+            n = arrs[1].reshape(-1, self.nq).shape[0]
+        elif qvel is not None:
+            n = arrs[2].reshape(-1, self.nv).shape[0]
+        _chk(self.lib, self.lib.mjh_set_state(self.h, env0, n, *[capi.dptr(a) for a in arrs]), "mjh_set_state")
+
+    def get_joint_state(self, env0=0, n=None):
+        n = self.nenv - env0 if n is None else n
+        q = np.zeros((n, self.nq)); v = np.zeros((n, self.nv)); f = np.zeros((n, self.nv))
+        _chk(self.lib, self.lib.mjh_get_joint_state(self.h, env0, n, capi.dptr(q), capi.dptr(v), capi.dptr(f)), "mjh_get_joint_state")
+        return q, v, f
+
+    def get_body_state(self, env0=0, n=None):
+        n = self.nenv - env0 if n is None else n
+        p = np.zeros((n, self.nbody, 3)); q = np.zeros((n, self.nbody, 4))
+        _chk(self.lib, self.lib.mjh_get_body_state(self.h, env0, n, capi.dptr(p), capi.dptr(q)), "mjh_get_body_state")
+        return p, q
+
+    def get_geom_state(self, env0=0, n=None):
+        n = self.nenv - env0 if n is None else n
+        p = np.zeros((n, self.ngeom, 3)); m = np.zeros((n, self.ngeom, 9))
+        _chk(self.lib, self.lib.mjh_get_geom_state(self.h, env0, n, capi.dptr(p), capi.dptr(m)), "mjh_get_geom_state")
+        return p, m
+
+    def get_field(self, name, env0=0, n=None):
+        n = self.nenv - env0 if n is None else n
+        w = 2 if name == "energy" else self.nv
+        out = np.zeros((n, w))
+        _chk(self.lib, self.lib.mjh_get_field(self.h, name.encode(), env0, n, capi.dptr(out)), "mjh_get_field")
+        return out
+
+    def get_stats(self, env0=0, n=None):
+        n = self.nenv - env0 if n is None else n
+        out = np.zeros((n, 4), dtype=np.int32)
+        _chk(self.lib, self.lib.mjh_get_stats(self.h, env0, n, capi.iptr(out)), "mjh_get_stats")
+        return out
+
+    def get_contacts(self, env):
+        mc = self.model.maxcon
+        dist = np.zeros(mc); pos = np.zeros((mc, 3)); fr = np.zeros((mc, 9)); g = np.zeros((mc, 2), dtype=np.int32)
+        n = _chk(self.lib, self.lib.mjh_get_contacts(self.h, env, capi.dptr(dist), capi.dptr(pos), capi.dptr(fr), capi.iptr(g)), "mjh_get_contacts")
+        return dict(dist=dist[:n], pos=pos[:n], frame=fr[:n], geom=g[:n])
+
+    def mulM(self, vec, env0=0):
+        v = np.ascontiguousarray(vec, dtype=np.float64).reshape(-1, self.nv); r = np.zeros_like(v)
+        _chk(self.lib, self.lib.mjh_mulM(self.h, env0, v.shape[0], capi.dptr(v), capi.dptr(r)), "mjh_mulM")
+        return r
+
+    def set_env_param(self, name, values, env0=0):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        v = v.reshape(v.shape[0], -1)
+        _chk(self.lib, self.lib.mjh_set_env_param(self.h, EP[name], env0, v.shape[0], capi.dptr(v)), "mjh_set_env_param")
+
+    def set_initial_qpos(self, qpos, env0=0):
+        q = np.ascontiguousarray(qpos, dtype=np.float64).reshape(-1, self.nq)
+        _chk(self.lib, self.lib.mjh_set_initial_qpos(self.h, env0, q.shape[0], capi.dptr(q)), "mjh_set_initial_qpos")
+
+    def reset(self, env_ids=None):
+        if env_ids is None:
+            _chk(self.lib, self.lib.mjh_reset(self.h, None, 0), "mjh_reset")
+        else:
+            ids = np.ascontiguousarray(env_ids, dtype=np.int32)
+            _chk(self.lib, self.lib.mjh_reset(self.h, capi.iptr(ids), ids.shape[0]), "mjh_reset")
+
+    def export_state_device(self, device_ptr):
+        _chk(self.lib, self.lib.mjh_export_state_device(self.h, C.c_void_p(device_ptr)), "mjh_export_state_device")
+
+    @property
+    def state_stride(self):
+        return self.lib.mjh_state_stride(self.h)
+
+    @property
+    def lds_bytes(self):
+        return self.lib.mjh_lds_bytes(self.h)
+
+    def load_s24(self, seed_base=0x5EED0000, env_offset=0):
+        """Apply the per-env S24 randomisation (sizes, masses, initial poses) and reset."""
+        t = self.model.s24_randomize(env_offset, self.nenv, seed_base)
+        for k in ["geom_size", "geom_rbound", "body_mass", "body_inertia", "body_invweight0", "dof_invweight0"]:
+            self.set_env_param(k, t[k])
+        self.set_initial_qpos(t["qpos"])
+        self.reset()
+        return t
