@@ -62,7 +62,9 @@ static int ensure_scratch(mjh_engine* e, size_t floats) {
 
 static int launch(mjh_engine* e, int env0, int n, int nsteps, int ph, int xflags) {
   if (n <= 0) return MJH_OK;
-  hipLaunchKernelGGL(mjh_step_kernel, dim3(n), dim3(64), (size_t)e->lds_bytes, e->stream, e->M, e->S, e->L, env0, nsteps, ph, xflags);
+  if (e->M.nv <= 16) hipLaunchKernelGGL(mjh_step_kernel<1>, dim3(n), dim3(64), (size_t)e->lds_bytes, e->stream, e->M, e->S, e->L, env0, nsteps, ph, xflags);
+  else if (e->M.nv <= 32) hipLaunchKernelGGL(mjh_step_kernel<2>, dim3(n), dim3(64), (size_t)e->lds_bytes, e->stream, e->M, e->S, e->L, env0, nsteps, ph, xflags);
+  else hipLaunchKernelGGL(mjh_step_kernel<4>, dim3(n), dim3(64), (size_t)e->lds_bytes, e->stream, e->M, e->S, e->L, env0, nsteps, ph, xflags);
   HIPCHK(hipGetLastError());
   return MJH_OK;
 }
@@ -185,7 +187,9 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     mjh_set_error("mjh_create: per-env working set exceeds the 160 KiB LDS of one CU (" + std::to_string(e->lds_bytes) + " B)");
     mjh_destroy(e); return MJH_ERR_CAPACITY;
   }
-  HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+  HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+  HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+  HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
 
   // ---- per-env state
   DState& S = e->S;

@@ -72,6 +72,7 @@ DEV int row_off(int d, int a1, int n1, int a2, int n2) {
   return r1 < (unsigned)n1 ? (int)r1 : (r2 < (unsigned)n2 ? n1 + (int)r2 : -1);
 }
 
+template <int NROW>
 __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DState S, const Lay L, int env0, int nsteps, int ph, int xflags) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x;
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
         conbase += total;
       }
       if (conbase > M.maxcon) { flags |= 1; conbase = M.maxcon; }
-      ncon = conbase;
+      ncon = __builtin_amdgcn_readfirstlane(conbase);
     }
     WSYNC();
     if ((xflags & XF_CON) && S.x_contacts) {
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
         else nefc += __shfl(incl, 63);
       }
     }
+    nefc = __builtin_amdgcn_readfirstlane(nefc);
     WSYNC();
     // rows: Jacobian (compact over the trees it touches), impedance, regulariser, reference gains
     for (int r = lane; r < nefc; r += 64) {
@@ -761,6 +763,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
             else f = jar < 0 ? -D * jar : 0.0f;
           }
           rf[5] = f;
+          rf[0] = 1.0f / rf[3];  // AR_ii: KI is dead once aref is known (rows are rebuilt every step)
         }
         WSYNC();
         // da = sum_i B_i f_i  (lanes = dofs)
@@ -806,7 +809,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
         float fr[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) fr[c] = (64*c + lane < nefc) ? s_rowf[(64*c + lane) * ROWF_STRIDE + 5] : 0.0f;
-        struct RowOp { float Jd, Bd, aref, R, ARinv, lo, hi; };
+        struct RowOp { float Jd, Bd, aref, R, AR, ARinv, lo, hi; };
         auto fetch = [&](int r) {
           RowOp op;
           const int4 hd = *(const int4*)(s_rowi_i + r * ROWI_STRIDE);
@@ -814,9 +817,10 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
           const float4 rb = *(const float4*)(s_rowf + r * ROWF_STRIDE + 4);  // aref, f, lo, hi
           ROW_TREES(hd.z, hd.w);
           const int o = row_off(d0, a1, n1, a2, n2);
-          op.Jd = 0; op.Bd = 0;
-          if (o >= 0) { op.Jd = s_J[r * rowW + o]; op.Bd = s_B[r * rowW + o]; }
-          op.aref = rb.x; op.R = ra.z; op.ARinv = ra.w; op.lo = rb.z; op.hi = rb.w;
+          const int oc = r * rowW + max(o, 0);
+          const float jv = s_J[oc], bv = s_B[oc];
+          op.Jd = o >= 0 ? jv : 0.0f; op.Bd = o >= 0 ? bv : 0.0f;
+          op.aref = rb.x; op.R = ra.z; op.AR = ra.x; op.ARinv = ra.w; op.lo = rb.z; op.hi = rb.w;
           return op;
         };
         for (int it = 0; it < M.iterations; it++) {
@@ -831,12 +835,12 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
               const int r = 64*c + rr;
               const RowOp nxt = fetch(r + 1 < nefc ? r + 1 : 0);
               float s = cur.Jd * a;
-              s = (nv <= 16) ? wave_sum<1>(s) : ((nv <= 32) ? wave_sum<2>(s) : wave_sum<4>(s));
+              s = wave_sum<NROW>(s);
               const float fold = readlane_f(fc, rr);
               const float res = s - cur.aref + cur.R * fold;
               float f = fminf(cur.hi, fmaxf(cur.lo, fold - res * cur.ARinv));
               float delta = f - fold;
-              const float change = 0.5f * delta * delta / cur.ARinv + delta * res;
+              const float change = delta * (0.5f * delta * cur.AR + res);
               if (change > 1e-10f) { f = fold; delta = 0; } else improvement -= change;
               a += cur.Bd * delta;
               fc = (lane == rr) ? f : fc;

@@ -1109,7 +1109,11 @@ void orc_step(orc_data* d, int nsteps, int with_inverse) {
   }
 }
 
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+/* CPU baseline driver: envs split over OpenMP threads, private orc_data per env, shared read-only model */
 void orc_step_many(orc_data** ds, int nenv, int nsteps, int with_inverse) {
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
   for (int e = 0; e < nenv; e++) orc_step(ds[e], nsteps, with_inverse);
 }
 

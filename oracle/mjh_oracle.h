@@ -106,6 +106,7 @@ int orc_get_contact(orc_data* d, int k, double* dist, double* pos, double* frame
 
 /* multi-env convenience for the CPU baseline: steps `nenv` independent datas */
 void orc_step_many(orc_data** ds, int nenv, int nsteps, int with_inverse);
+void orc_set_threads(int n);
 
 #ifdef __cplusplus
 }

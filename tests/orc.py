@@ -36,6 +36,7 @@ def lib():
         L.orc_get_contact.argtypes = [vp, C.c_int, dp, dp, dp, ip, ip]
         L.orc_box_box.restype = C.c_int; L.orc_box_box.argtypes = [dp] * 6 + [C.c_double] + [dp] * 3
         L.orc_step_many.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int]
+        L.orc_set_threads.argtypes = [C.c_int]
         _lib = L
     return _lib
 
