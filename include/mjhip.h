@@ -244,6 +244,9 @@ int mjh_reset(mjh_engine*, const int* env_ids, int n);
 int mjh_export_state_device(mjh_engine*, void* d_out);
 int mjh_state_stride(const mjh_engine*);
 
+/* debug: mean shader-clock ticks from kernel start to each of the 16 stage boundaries of one fused step */
+int mjh_debug_stage_cycles(mjh_engine*, int with_inverse, double* out16);
+
 /* introspection */
 int mjh_nenv(const mjh_engine*);
 const mjh_model* mjh_engine_model(const mjh_engine*);

@@ -136,6 +136,7 @@ SYMBOLS = [
     ("mjh_reset", C.c_int, [_vp, c_int_p, C.c_int]),
     ("mjh_export_state_device", C.c_int, [_vp, _vp]),
     ("mjh_state_stride", C.c_int, [_vp]),
+    ("mjh_debug_stage_cycles", C.c_int, [_vp, C.c_int, c_double_p]),
     ("mjh_nenv", C.c_int, [_vp]),
     ("mjh_engine_model", Model_p, [_vp]),
     ("mjh_lds_bytes", C.c_int, [_vp]),

@@ -43,6 +43,7 @@ struct DState {
   float *x_bias, *x_passive, *x_smooth, *x_constraint, *x_energy;
   float *x_contacts;  // [n * maxcon * 17]
   float *x_vec, *x_res;  // mulM in/out [n*nvp]
+  long long* x_prof;     // [n*16] s_memtime stamps at stage boundaries (debug)
   // per-env model parameter tables (null -> shared model)
   const float *p_geom_size, *p_geom_rbound, *p_body_mass, *p_body_inertia, *p_body_invweight0, *p_dof_invweight0;
 };
@@ -64,7 +65,7 @@ struct Lay {
 // kernel phases
 enum { PH_STEP1 = 1, PH_INV = 2, PH_STEP2 = 4, PH_NOINT = 8, PH_FKONLY = 16, PH_MULM = 32, PH_RESET = 64 };
 // export flags
-enum { XF_BODY = 1, XF_GEOM = 2, XF_CON = 4, XF_FORCE = 8 };
+enum { XF_BODY = 1, XF_GEOM = 2, XF_CON = 4, XF_FORCE = 8, XF_PROF = 16 };
 
 #define CON_STRIDE 17  // dist, pos3, frame9, g1, g2, dim, includemargin
 #define ROWF_STRIDE 8  // KI, Bc, R, ARinv, aref, f, lo, hi

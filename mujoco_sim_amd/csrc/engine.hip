@@ -455,6 +455,27 @@ extern "C" int mjh_export_state_device(mjh_engine* e, void* d_out) {
   return MJH_OK;
 }
 
+// debug: one fused step over all envs with s_memtime stamps at the 16 stage boundaries of the kernel;
+// out[16] = mean over envs of (stamp[k] - stamp[0]) in shader-clock ticks
+extern "C" int mjh_debug_stage_cycles(mjh_engine* e, int with_inverse, double* out) {
+  ENG(e);
+  long long* buf = nullptr;
+  HIPCHK(hipMalloc((void**)&buf, (size_t)e->nenv * 16 * sizeof(long long)));
+  HIPCHK(hipMemsetAsync(buf, 0, (size_t)e->nenv * 16 * sizeof(long long), e->stream));
+  DState saved = e->S;
+  e->S.x_prof = buf;
+  int rc = launch(e, 0, e->nenv, 1, PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0), XF_PROF);
+  e->S = saved;
+  std::vector<long long> h((size_t)e->nenv * 16);
+  if (!rc) { HIPCHK(hipMemcpyAsync(h.data(), buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }
+  (void)hipFree(buf);
+  if (rc) return rc;
+  for (int k = 0; k < 16; k++) out[k] = 0;
+  for (int en = 0; en < e->nenv; en++) for (int k = 0; k < 16; k++) { long long v = h[(size_t)en*16+k]; out[k] += v ? (double)(v - h[(size_t)en*16]) : 0.0; }
+  for (int k = 0; k < 16; k++) out[k] /= e->nenv;
+  return MJH_OK;
+}
+
 extern "C" int mjh_nenv(const mjh_engine* e) { return e ? e->nenv : 0; }
 extern "C" const mjh_model* mjh_engine_model(const mjh_engine* e) { return e ? e->model : nullptr; }
 extern "C" int mjh_lds_bytes(const mjh_engine* e) { return e ? e->lds_bytes : 0; }

@@ -15,6 +15,7 @@
 #include "dev_types.h"
 
 #define WSYNC() __syncthreads()
+#define PROF(k) do { if ((xflags & XF_PROF) && lane == 0) S.x_prof[(size_t)blockIdx.x * 16 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #define MINIMP 0.0001f
 #define MAXIMP 0.9999f
 
@@ -118,7 +119,9 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
   }
   float time = S.time[env];
   int flags = 0, ncon = 0, nefc = 0, niter = 0;
+  PROF(0);
   WSYNC();
+  PROF(1);
 
   for (int step = 0; step < nsteps; step++) {
     // ---- bad-state check (mj_checkPos / mj_checkVel): reset this env
@@ -218,6 +221,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
       if (S.x_gmat) for (int i = lane; i < 9*ngeom; i += 64) S.x_gmat[e*9*ngeom + i] = s_gmat[i];
     }
     if (ph & PH_FKONLY) break;
+    PROF(2);
 
     // ---- subtree COM of every tree root, COM-based inertias, motion axes (mj_comPos)
     for (int r = lane; r < nbody; r += 64) {
@@ -299,10 +303,12 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
       for (int i = lane; i < nv; i += 64) S.x_res[(size_t)blockIdx.x * M.nvp + i] = s_tmpv2[i];
       break;
     }
+    PROF(3);
     // ---- L'DL factorisation (mj_factorM): one lane per kinematic tree
     for (int t = lane; t < M.ntree; t += 64) factor_tree(s_qLD, s_qLDinv, dof_parentid, dof_Madr, tree_dofadr[t], tree_dofnum[t]);
     WSYNC();
 
+    PROF(4);
     // ---- collision (mj_collision): lanes = candidate geom pairs of the static pair list
     ncon = 0;
     if (!(M.disableflags & (MJH_DSBL_CONTACT | MJH_DSBL_CONSTRAINT))) {
@@ -364,6 +370,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
       WSYNC();
     }
 
+    PROF(5);
     // ---- constraint rows (mj_makeConstraint + mj_makeImpedance): header pass, then lanes = rows
     nefc = 0;
     if (!(M.disableflags & MJH_DSBL_CONSTRAINT)) {
@@ -420,6 +427,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
     }
     nefc = __builtin_amdgcn_readfirstlane(nefc);
     WSYNC();
+    PROF(6);
     // rows: Jacobian (compact over the trees it touches), impedance, regulariser, reference gains
     for (int r = lane; r < nefc; r += 64) {
       int* hd = s_rowi_i + r * ROWI_STRIDE;
@@ -530,6 +538,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
       hd[2] = tree_dofadr[t1] | (tree_dofnum[t1] << 16); hd[3] = t2 >= 0 ? (tree_dofadr[t2] | (tree_dofnum[t2] << 16)) : 0;
     }
     WSYNC();
+    PROF(7);
     // B = M^-1 J^T per row (mj_projectConstraint without the dense AR), ARinv = 1/(J.B + R)
     for (int r = lane; r < nefc; r += 64) {
       const int* hd = s_rowi_i + r * ROWI_STRIDE;
@@ -549,6 +558,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
     }
     WSYNC();
 
+    PROF(8);
     // ================================================================ velocity stage (lambda: used by step1, inverse, step2-alone)
     auto vel_levels = [&](const float* qv, const float* qa, float* out) {
       // mj_comVel + mj_rne forward/backward; qa != null adds cdof*qacc (flg_acc)
@@ -657,6 +667,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
 
     if (ph & PH_STEP1) {
       vel_stage(s_qvel);
+      PROF(9);
       if ((xflags & XF_FORCE) && S.x_energy) {  // mj_energyPos / mj_energyVel
         float pe = 0, ke = 0;
         for (int b = lane; b < nbody; b += 64) if (b > 0) {
@@ -734,6 +745,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
       for (int d = lane; d < nv; d += 64) S.qfrc_inverse[vrow + d] = s_tmpv[d] + dof_armature[d] * s_qacc[d] - s_passive[d] - s_tmpv2[d];
     }
 
+    PROF(10);
     // ================================================================ step2 (mj_step2, mj_main.cpp:108)
     if (ph & (PH_STEP2 | PH_NOINT)) {
       // ---- smooth acceleration (mj_fwdAcceleration)
@@ -742,6 +754,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
       for (int t = lane; t < M.ntree; t += 64) solve_tree(s_asmooth, s_qLD, s_qLDinv, dof_parentid, dof_Madr, tree_dofadr[t], tree_dofnum[t]);
       WSYNC();
       niter = 0;
+      PROF(11);
       if (nefc == 0) {
         for (int d = lane; d < nv; d += 64) { s_qacc[d] = s_asmooth[d]; s_ws[d] = s_asmooth[d]; s_tmpv2[d] = 0; }
         WSYNC();
@@ -797,6 +810,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
           }
           WSYNC();
         }
+        PROF(12);
         // ---- PGS (mj_solPGS) in matrix-free form: lanes = dofs, running acceleration a in registers.
         //      row i:  res = J_i.a - aref_i + R_i f_i ;  f_i <- clamp(f_i - res/AR_ii) ;  a += B_i * delta
         // TODO(perf, next round): nv > 64 needs several dofs per lane
@@ -853,6 +867,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
         }
 #pragma unroll
         for (int c = 0; c < 4; c++) if (64*c + lane < nefc) s_rowf[(64*c + lane) * ROWF_STRIDE + 5] = fr[c];
+        PROF(13);
         WSYNC();
         if (d0 < nv) { s_qacc[d0] = a; s_ws[d0] = a; }
         WSYNC();
@@ -932,6 +947,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
     }
   }  // steps
 
+  PROF(14);
   if (ph & (PH_FKONLY | PH_MULM)) return;
   // ------------------------------------------------------------------ store state
   for (int i = lane; i < nq; i += 64) S.qpos[qrow + i] = s_qpos[i];
@@ -943,6 +959,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
     S.time[env] = time;
     S.stats[4*env] = ncon; S.stats[4*env+1] = nefc; S.stats[4*env+2] = niter; S.stats[4*env+3] |= flags;
   }
+  PROF(15);
 }
 
 // pack time + qpos + qvel per env into one contiguous fp32 buffer (feeds the RCCL all-gather)

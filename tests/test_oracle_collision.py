@@ -1,0 +1,164 @@
+"""Narrow-phase known answers for the oracle's primitives (CPU).  The box-box routine is this
+project's own definition (15-axis SAT + reference/incident-face manifold), shared by the HIP path;
+MuJoCo's mjc_BoxBox point selection is not reproducible without the library."""
+import ctypes as C
+
+import numpy as np
+
+import mujoco_sim_amd as ms
+import orc
+from helpers import D, free_body_model, set_opt
+
+
+def box_box(p1, R1, s1, p2, R2, s2, margin=0.0):
+    L = orc.lib()
+    a = lambda x: np.ascontiguousarray(x, dtype=np.float64)
+    p1, R1, s1, p2, R2, s2 = map(a, (p1, R1, s1, p2, R2, s2))
+    dist = np.zeros(8); pos = np.zeros(24); n = np.zeros(3)
+    P = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+    k = L.orc_box_box(P(p1), P(R1.reshape(-1)), P(s1), P(p2), P(R2.reshape(-1)), P(s2), margin, P(dist), P(pos), P(n))
+    return k, dist[:k], pos.reshape(8, 3)[:k], n
+
+
+def rotz(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+
+
+def rot(axis, a):
+    axis = np.asarray(axis, float) / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+
+
+def test_box_box_separated_and_touching():
+    I = np.eye(3)
+    k, *_ = box_box([0, 0, 0], I, [1, 1, 1], [2.5, 0, 0], I, [1, 1, 1])
+    assert k == 0
+    k, dist, pos, n = box_box([0, 0, 0], I, [1, 1, 1], [0, 0, 1.9], I, [0.5, 0.5, 1])
+    assert k >= 4 and np.allclose(dist, -0.1) and np.allclose(n, [0, 0, 1])
+    assert np.allclose(pos[:, 2], 0.95)                       # midway between the two faces
+    assert np.abs(pos[:, :2]).max() <= 0.5 + 1e-12            # manifold = the smaller face
+    corners = {(round(x, 6), round(y, 6)) for x, y, _ in pos}
+    assert {(0.5, 0.5), (-0.5, 0.5), (-0.5, -0.5), (0.5, -0.5)} <= corners
+
+
+def test_box_box_rotated_face_manifold_has_up_to_eight_points():
+    I = np.eye(3)
+    k, dist, pos, n = box_box([0, 0, 0], I, [1, 1, 1], [0, 0, 1.95], rotz(np.pi / 4), [1, 1, 1])
+    assert k == 8 and np.allclose(n, [0, 0, 1]) and np.allclose(dist, -0.05)
+    # octagon = intersection of the square with its 45-degree copy: every point on both boundaries
+    r = np.abs(pos[:, :2])
+    assert np.allclose(np.maximum(r[:, 0], r[:, 1]), 1.0, atol=1e-9)
+    assert len({tuple(np.round(p, 6)) for p in pos}) == 8
+
+
+def test_box_box_normal_points_from_first_to_second_whichever_is_reference():
+    I = np.eye(3)
+    big, small = [1, 1, 1], [0.2, 0.2, 0.2]
+    for p1, s1, p2, s2 in (([0, 0, 0], big, [0, 0, 1.15], small), ([0, 0, 1.15], small, [0, 0, 0], big)):
+        k, dist, pos, n = box_box(p1, I, s1, p2, I, s2)
+        d = np.asarray(p2, float) - np.asarray(p1, float)
+        assert k >= 4 and n @ d > 0 and np.allclose(dist, -0.05)
+
+
+def test_box_box_edge_edge_single_point():
+    # two long thin boxes crossing like a plus sign, one rotated about x so that an edge points down
+    RA = rot([1, 0, 0], np.pi / 4)                       # long along x, rolled 45 deg: top/bottom are edges
+    RB = rotz(np.pi / 2) @ rot([1, 0, 0], np.pi / 4)     # same, long axis turned to y
+    s = [1.0, 0.1, 0.1]
+    half_diag = 0.1 * np.sqrt(2)
+    k, dist, pos, n = box_box([0, 0, 0], RA, s, [0, 0, 2 * half_diag - 0.01], RB, s)
+    assert k == 1 and abs(dist[0] + 0.01) < 1e-9
+    assert np.allclose(n, [0, 0, 1], atol=1e-9) and np.allclose(pos[0], [0, 0, half_diag - 0.005], atol=1e-9)
+
+
+def test_box_box_symmetry_under_rigid_motion():
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        R1, R2 = rot(rng.normal(size=3), rng.uniform(0, 3)), rot(rng.normal(size=3), rng.uniform(0, 3))
+        s1, s2 = rng.uniform(0.05, 0.125, 3), rng.uniform(0.05, 0.125, 3)
+        p2 = rng.normal(size=3) * 0.12
+        k, dist, pos, n = box_box([0, 0, 0], R1, s1, p2, R2, s2)
+        if k == 0:
+            continue
+        T, t = rot(rng.normal(size=3), rng.uniform(0, 3)), rng.normal(size=3)
+        k2, dist2, pos2, n2 = box_box(t, T @ R1, s1, T @ p2 + t, T @ R2, s2)
+        assert k2 == k
+        np.testing.assert_allclose(dist2, dist, atol=1e-9)
+        np.testing.assert_allclose(pos2, pos @ T.T + t, atol=1e-9)
+        np.testing.assert_allclose(n2, T @ n, atol=1e-9)
+        assert abs(np.linalg.norm(n) - 1) < 1e-12 and (dist <= 0).all()
+
+
+def _contacts_of(lib, build):
+    b = lib.mjh_builder_create()
+    set_opt(lib, b, timestep=0.005)
+    lib.mjh_builder_add_geom(b, b"floor", 0, 0, D(0, 0, 0.05), None, None, None, -1, -1, -1, -1)
+    build(b)
+    m = ms.Model(lib.mjh_builder_compile(b), lib)
+    lib.mjh_builder_destroy(b)
+    d = orc.OrcData(m.ptr)
+    d.call("kinematics"); d.call("collision")
+    return m, d, d.contacts()
+
+
+def _free(lib, b, name, gtype, size, pos, quat=None):
+    bd = lib.mjh_builder_add_body(b, name, 0, D(*pos), D(*quat) if quat else None, 0.0)
+    lib.mjh_builder_add_joint(b, None, bd, 0, None, None, None, 0, 0, 0, 0, 0)
+    lib.mjh_builder_add_geom(b, None, bd, gtype, D(*size), None, None, None, -1, -1, -1, -1)
+    return bd
+
+
+def test_plane_primitives(lib):
+    m, d, c = _contacts_of(lib, lambda b: _free(lib, b, b"s", 2, (0.1, 0, 0), (0, 0, 0.08)))
+    assert len(c) == 1 and abs(c[0]["dist"] + 0.02) < 1e-12 and np.allclose(c[0]["pos"], [0, 0, -0.01])
+    assert np.allclose(c[0]["frame"][:3], [0, 0, 1]) and c[0]["geom"] == (0, 1)
+    # capsule lying on its side: two end contacts
+    q = [np.cos(np.pi / 4), 0, np.sin(np.pi / 4), 0]
+    m, d, c = _contacts_of(lib, lambda b: _free(lib, b, b"c", 3, (0.05, 0.2, 0), (0, 0, 0.04), q))
+    assert len(c) == 2 and np.allclose([x["dist"] for x in c], -0.01)
+    assert sorted(round(x["pos"][0], 6) for x in c) == [-0.2, 0.2]
+    # box tilted on an edge: two corner contacts; flat: four
+    m, d, c = _contacts_of(lib, lambda b: _free(lib, b, b"b", 6, (0.1, 0.1, 0.1), (0, 0, 0.095)))
+    assert len(c) == 4 and np.allclose([x["dist"] for x in c], -0.005)
+    q = [np.cos(np.pi / 8), np.sin(np.pi / 8), 0, 0]
+    m, d, c = _contacts_of(lib, lambda b: _free(lib, b, b"b", 6, (0.1, 0.1, 0.1), (0, 0, 0.1 * np.sqrt(2) - 0.003), q))
+    assert len(c) == 2 and np.allclose([x["dist"] for x in c], -0.003, atol=1e-9)
+
+
+def test_sphere_pairs_and_frames(lib):
+    def build(b):
+        _free(lib, b, b"a", 2, (0.1, 0, 0), (0, 0, 1.0))
+        _free(lib, b, b"b", 2, (0.15, 0, 0), (0.2, 0, 1.0))
+        _free(lib, b, b"c", 6, (0.1, 0.1, 0.1), (0, 0.18, 1.0))
+    m, d, c = _contacts_of(lib, build)
+    pairs = {x["geom"]: x for x in c}
+    ss = pairs[(1, 2)]
+    assert abs(ss["dist"] + 0.05) < 1e-12 and np.allclose(ss["frame"][:3], [1, 0, 0]) and np.allclose(ss["pos"], [0.075, 0, 1.0])
+    F = ss["frame"].reshape(3, 3)
+    assert np.allclose(F @ F.T, np.eye(3), atol=1e-12) and np.linalg.det(F) > 0
+    sb = pairs[(1, 3)]          # sphere (type 2) is geom1, box geom2: normal from sphere towards the box
+    assert abs(sb["dist"] + 0.02) < 1e-12 and np.allclose(sb["frame"][:3], [0, 1, 0])
+
+
+def test_contact_parameter_mixing_and_rows(lib):
+    """floor (condim 4, friction 2/.05/.01) x default geom -> condim 4, friction max, 6 pyramid rows"""
+    m = ms.scene("s24")
+    d = orc.OrcData(m.ptr)
+    q = m.array("qpos0").copy(); q[2] = 0.085
+    d.set_qpos(q); d.call("fwd_position")
+    cons = d.contacts()
+    floor = [c for c in cons if c["geom"][0] == 0]
+    assert len(floor) == 4 and all(c["dim"] == 4 for c in floor)
+    assert d.i("nefc") >= 24
+    t = d.ifield("efc_type")
+    assert (t[:24] == 6).all()
+    # pyramid rows: J_n +- mu J_t ; row pairs differ by 2 mu J_t, sums give 2 J_n
+    J = d.f("efc_J").reshape(d.i("nefc"), m.nv)
+    Jn = 0.5 * (J[0] + J[1])
+    np.testing.assert_allclose(0.5 * (J[2] + J[3]), Jn, atol=1e-12)
+    assert abs(Jn[2] - 1.0) < 1e-12                    # normal row lifts the box along +z
+    np.testing.assert_allclose(np.abs(0.5 * (J[0] - J[1]))[:3].max(), 2.0, atol=1e-12)   # mu1 = 2 on a unit tangent
+    R = d.f("efc_R")
+    assert np.allclose(R[:6], R[0]) and R[0] > 0
