@@ -1,0 +1,69 @@
+"""Summarise rocprofv3 rocpd (.db) outputs of tools/profile_gpu.sh into profiles/<tag>_*.{md,csv}.
+usage: python tools/summarize_prof.py <tag> [timed_launches]"""
+import glob, json, os, sqlite3, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+timed = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+lines = [f"# rocprofv3 summary `{tag}` — `python bench.py --steps {timed} --warmup 400 --no-cpu-baseline` (S24, 4096 envs, 1 MI355X)", ""]
+
+def db(path):
+    f = glob.glob(os.path.join(src, path, "*.db"))
+    return sqlite3.connect(f[0]) if f else None
+
+con = db("trace")
+kern_avg_us = None
+if con:
+    lines += ["## `rocprofv3 --kernel-trace --stats` (all launches, incl. the 400 warm-up/settle steps)", "",
+              "| kernel | calls | total (us) | average (us) | % |", "|---|---|---|---|---|"]
+    csv = ["name,calls,total_us,average_us,percentage"]
+    for r in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+        lines.append(f"| `{r[0]}` | {r[1]} | {r[2]:.1f} | {r[3]:.2f} | {r[4]:.3f} |")
+        csv.append(",".join(['"%s"' % r[0]] + [str(x) for x in r[1:]]))
+    open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w").write("\n".join(csv) + "\n")
+    rows = con.execute("select k.start, k.end, k.vgpr_count, k.accum_vgpr_count, k.sgpr_count, k.lds_size, k.scratch_size from kernels k where k.name like '%mjh_step_kernel%' order by k.start").fetchall()
+    if rows:
+        last = rows[-timed:]
+        kern_avg_us = sum((e - s) for s, e, *_ in last) / len(last) / 1e3
+        lines += ["", f"Average duration of `mjh_step_kernel` over the LAST {len(last)} launches (the timed region of bench.py): **{kern_avg_us:.1f} us**",
+                  f"(dispatch resources: VGPR {rows[-1][2]}, AGPR {rows[-1][3]}, SGPR {rows[-1][4]}, LDS {rows[-1][5]} B/workgroup, scratch {rows[-1][6]} B/lane)", ""]
+tot = {}
+for sub, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    con = db(sub)
+    if not con:
+        continue
+    rows = con.execute("select value from counters_collection where kernel_name like '%mjh_step_kernel%' and counter_name=? order by start", (name,)).fetchall()
+    if rows:
+        last = [r[0] for r in rows[-timed:]]
+        tot[name] = sum(last) / len(last)
+if tot:
+    f, w = tot.get("FETCH_SIZE", 0.0), tot.get("WRITE_SIZE", 0.0)
+    lines += ["## HBM traffic (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, separate passes; units of 1 KiB; last %d launches)" % timed, "",
+              f"- FETCH_SIZE = {f:.1f} KiB/launch, WRITE_SIZE = {w:.1f} KiB/launch",
+              f"- raw (FETCH+WRITE)*1024 = {(f + w) * 1024 / 1e6:.2f} MB/launch; with the gfx950 x2 read correction for wide coalesced reads (MI355X_MICROARCH.md §HBM): {(2 * f + w) * 1024 / 1e6:.2f} MB/launch",
+              f"- algorithmic bytes = 800 B/env-step x 4096 envs = 3.28 MB/launch", ""]
+    json.dump({"tag": tag, "fetch_kib": f, "write_kib": w, "bytes_per_launch": (2 * f + w) * 1024,
+               "note": "rocprofv3 PMC, FETCH_SIZE doubled per MI355X_MICROARCH.md (upper bound for 4 B/lane rows), WRITE_SIZE raw"},
+              open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+con = db("pmc_sq")
+if con:
+    lines += ["## SQ counters (per launch, averages over the last %d launches)" % timed, "", "| counter | value | per wave |", "|---|---|---|"]
+    names = [r[0] for r in con.execute("select distinct counter_name from counters_collection")]
+    for n in sorted(names):
+        rows = con.execute("select value from counters_collection where kernel_name like '%mjh_step_kernel%' and counter_name=? order by start", (n,)).fetchall()
+        last = [r[0] for r in rows[-timed:]]
+        if last:
+            v = sum(last) / len(last)
+            lines.append(f"| {n} | {v:.4g} | {v / 4096:.4g} |")
+    lines.append("")
+for jf in ("bench_trace.json",):
+    p = os.path.join(src, jf)
+    if os.path.exists(p):
+        txt = open(p).read().strip().splitlines()
+        if txt:
+            lines += ["## bench.py line of the traced run", "", "```", txt[-1], "```", ""]
+open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines))
+print("\n".join(lines))
