@@ -109,6 +109,21 @@ template <int NROW> DEV float wave_sum(float v) {
   MJH_DPP_ADD(v, 0x143, 0xc, false);  // row_bcast:31 into rows 2,3
   return readlane_f(v, 63);
 }
+// N simultaneous sums over lanes [0,16*NROW): the DPP steps of the N chains are issued interleaved so
+// that each chain's two wait states are filled by the others (results broadcast, uniform)
+#define MJH_DPP_STEP4(v, N, ctrl, rm, bc) do { MJH_DPP_ADD(v[0], ctrl, rm, bc); if (N > 1) MJH_DPP_ADD(v[1], ctrl, rm, bc); \
+    if (N > 2) MJH_DPP_ADD(v[2], ctrl, rm, bc); if (N > 3) MJH_DPP_ADD(v[3], ctrl, rm, bc); } while (0)
+template <int NROW, int N> DEV void wave_sum4(float* v) {
+  MJH_DPP_STEP4(v, N, 0x111, 0xf, true);
+  MJH_DPP_STEP4(v, N, 0x112, 0xf, true);
+  MJH_DPP_STEP4(v, N, 0x114, 0xf, true);
+  MJH_DPP_STEP4(v, N, 0x118, 0xf, true);
+  if (NROW >= 2) MJH_DPP_STEP4(v, N, 0x142, 0xa, false);
+  if (NROW >= 4) MJH_DPP_STEP4(v, N, 0x143, 0xc, false);
+  const int src = NROW == 1 ? 15 : (NROW == 2 ? 31 : 63);
+#pragma unroll
+  for (int j = 0; j < N; j++) v[j] = readlane_f(v[j], src);
+}
 DEV int wave_incl_scan_i(int v, int lane) {
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o); if (lane >= o) v += t; }

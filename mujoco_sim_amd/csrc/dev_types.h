@@ -28,7 +28,7 @@ struct DModel {
 #undef X
   int nq, nv, nbody, njnt, ngeom, neq, npair, nM, ntree, maxcon, maxefc;
   int nqp, nvp;        // padded row strides of the per-env state arrays (floats)
-  int maxlevel, nfl, ngc, rowW, nstage, has_damping, has_limits;
+  int maxlevel, nfl, ngc, rowW, nstage, has_damping, has_limits, diagM, maxblk, maxbrow;
   int iterations, disableflags;
   float timestep, gravity[3], tolerance, impratio, meaninertia;
 };
@@ -53,7 +53,8 @@ struct DState {
   X(qpos) X(qvel) X(qvref) X(ws) X(qacc) X(smooth) X(asmooth) X(passive) X(bias) X(applied)        \
   X(tmpv) X(tmpv2) X(xpos) X(xquat) X(xmat) X(xipos) X(ximat) X(com) X(cinert) X(crb) X(cvel)      \
   X(cacc) X(cfrc) X(cfrcsub) X(xanchor) X(xaxis) X(cdof) X(cdofdot) X(qM) X(qLD) X(qLDinv)          \
-  X(gpos) X(gmat) X(con) X(rowi) X(rowf) X(J) X(B)
+  X(gpos) X(gmat) X(con) X(blki) X(blkf) X(bv) X(phi) X(J) X(B) X(dofpar) X(dofMadr)               \
+  X(p_gsize) X(p_rbound) X(p_mass) X(p_inertia) X(p_binv) X(p_dinv)
 
 struct Lay {
 #define X(n) int n;
@@ -68,5 +69,14 @@ enum { PH_STEP1 = 1, PH_INV = 2, PH_STEP2 = 4, PH_NOINT = 8, PH_FKONLY = 16, PH_
 enum { XF_BODY = 1, XF_GEOM = 2, XF_CON = 4, XF_FORCE = 8, XF_PROF = 16 };
 
 #define CON_STRIDE 17  // dist, pos3, frame9, g1, g2, dim, includemargin
-#define ROWF_STRIDE 8  // KI, Bc, R, ARinv, aref, f, lo, hi
-#define ROWI_STRIDE 4  // type, id, sub(k*2+neg), trees packed (t1 | t2<<16, 0xffff = none)
+// constraint blocks: header int4 + 32 floats per block
+//   hd.x = kind | nrows<<4 | nbase<<8 | clamp<<12 | jadr<<16 ; hd.y = id | rtype<<24 | side<<28 ; hd.z = a1 | n1<<16 ; hd.w = a2 | n2<<16
+//   floats: [0..3] R, frictionloss, mu_tangent, mu_torsion ; [4..9] aref per row ; [10..15] force per row ;
+//           [16..31] A_c = J_base M^-1 J_base^T (upper triangle; slots (1,0),(2,0) carry KI and Bc until the solve)
+#define BLKI_STRIDE 4
+#define BLKF_STRIDE 32
+#define BF_AREF 4
+#define BF_F 10
+#define BF_A 16
+enum { BK_SINGLE = 0, BK_PYR3 = 3, BK_PYR4 = 4 };
+enum { RT_EQ = 0, RT_FL = 1, RT_LIMIT = 2, RT_CONTACT = 3 };

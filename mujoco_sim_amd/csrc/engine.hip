@@ -62,9 +62,11 @@ static int ensure_scratch(mjh_engine* e, size_t floats) {
 
 static int launch(mjh_engine* e, int env0, int n, int nsteps, int ph, int xflags) {
   if (n <= 0) return MJH_OK;
-  if (e->M.nv <= 16) hipLaunchKernelGGL(mjh_step_kernel<1>, dim3(n), dim3(64), (size_t)e->lds_bytes, e->stream, e->M, e->S, e->L, env0, nsteps, ph, xflags);
-  else if (e->M.nv <= 32) hipLaunchKernelGGL(mjh_step_kernel<2>, dim3(n), dim3(64), (size_t)e->lds_bytes, e->stream, e->M, e->S, e->L, env0, nsteps, ph, xflags);
-  else hipLaunchKernelGGL(mjh_step_kernel<4>, dim3(n), dim3(64), (size_t)e->lds_bytes, e->stream, e->M, e->S, e->L, env0, nsteps, ph, xflags);
+#define MJH_LAUNCH(NR, DG) hipLaunchKernelGGL((mjh_step_kernel<NR, DG>), dim3(n), dim3(64), (size_t)e->lds_bytes, e->stream, e->M, e->S, e->L, env0, nsteps, ph, xflags)
+  const int nr = e->M.nv <= 16 ? 1 : (e->M.nv <= 32 ? 2 : 4);
+  if (e->M.diagM) { if (nr == 1) MJH_LAUNCH(1, true); else if (nr == 2) MJH_LAUNCH(2, true); else MJH_LAUNCH(4, true); }
+  else { if (nr == 1) MJH_LAUNCH(1, false); else if (nr == 2) MJH_LAUNCH(2, false); else MJH_LAUNCH(4, false); }
+#undef MJH_LAUNCH
   HIPCHK(hipGetLastError());
   return MJH_OK;
 }
@@ -86,7 +88,8 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   }
   if (device < 0 || device >= ndev) { mjh_set_error("mjh_create: bad device index"); return MJH_ERR_ARG; }
   if (m->nv > 64) { mjh_set_error("mjh_create: nv > 64 not supported yet (PGS maps one dof per lane)"); return MJH_ERR_CAPACITY; }
-  if (m->maxefc > 256) { mjh_set_error("mjh_create: maxefc > 256 not supported yet"); return MJH_ERR_CAPACITY; }
+  for (int g = 0; g < m->ngeom; g++) if (m->geom_condim[g] != 1 && m->geom_condim[g] != 3 && m->geom_condim[g] != 4) {
+    mjh_set_error("mjh_create: condim must be 1, 3 or 4 (rolling friction, condim 6, is not implemented)"); return MJH_ERR_UNSUPPORTED; }
   HIPCHK(hipSetDevice(device));
   mjh_engine* e = new mjh_engine();
   e->model = m; e->nenv = nenv; e->device = device; e->stream = (hipStream_t)stream;
@@ -115,6 +118,13 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     rowW = std::max(rowW, w);
   }
   rowW = ((rowW + 3) / 4) * 4;
+  // every tree a single free body about its own COM with principal axes = body axes  =>  M is diagonal
+  bool diagM = m->ntree > 0;
+  for (int t = 0; t < m->ntree && diagM; t++) {
+    const int b = m->tree_bodyid[t];
+    diagM = m->tree_dofnum[t] == 6 && m->body_jntnum[b] == 1 && m->jnt_type[m->body_jntadr[b]] == MJH_JNT_FREE && subtreesize[b] == 1 &&
+            m->body_ipos[3*b] == 0 && m->body_ipos[3*b+1] == 0 && m->body_ipos[3*b+2] == 0 && m->body_iquat[4*b] == 1;
+  }
   bool has_damping = false, has_limits = false;
   for (int d = 0; d < nv; d++) { if (m->dof_frictionloss[d] > 0) fl_dof.push_back(d); if (m->dof_damping[d] > 0) has_damping = true; }
   for (int j = 0; j < nj; j++) if (m->jnt_limited[j]) has_limits = true;
@@ -152,7 +162,12 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   M.maxcon = std::max(m->maxcon, 1); M.maxefc = std::max(m->maxefc, 1);
   M.nqp = pad32(m->nq); M.nvp = pad32(std::max(nv, 1));
   M.maxlevel = maxlevel; M.nfl = (int)fl_dof.size(); M.ngc = (int)gc_body.size(); M.rowW = rowW; M.nstage = nstage;
-  M.has_damping = has_damping; M.has_limits = has_limits;
+  M.has_damping = has_damping; M.has_limits = has_limits; M.diagM = diagM;
+  {
+    int nlim = 0; for (int j = 0; j < nj; j++) if (m->jnt_limited[j]) nlim++;
+    const int nfix = m->neq + (int)fl_dof.size() + 2 * nlim;
+    M.maxblk = nfix + M.maxcon; M.maxbrow = nfix + 4 * M.maxcon;
+  }
   M.iterations = m->opt.iterations; M.disableflags = m->opt.disableflags;
   M.timestep = (float)m->opt.timestep; for (int k = 0; k < 3; k++) M.gravity[k] = (float)m->opt.gravity[k];
   M.tolerance = (float)m->opt.tolerance; M.impratio = (float)m->opt.impratio; M.meaninertia = (float)m->meaninertia;
@@ -167,9 +182,10 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   {
     Lay& L = e->L; int off = 0;
     auto put = [&](int n) { int o = off; off += ((std::max(n, 1) + 3) / 4) * 4; return o; };
-    const int rows = M.maxefc + 1;
-    int jsz = rows * rowW;
-    if (2 * jsz < nstage * RAW_STRIDE) jsz = (nstage * RAW_STRIDE + 1) / 2;
+    const int nblkcap = M.maxblk + 2;
+    int jsz = nblkcap * rowW * 4;
+    const int need = nstage * RAW_STRIDE;            // raw-contact staging aliases J (+B)
+    if ((diagM ? 1 : 2) * jsz < need) jsz = diagM ? need : (need + 1) / 2;
     L.qpos = put(m->nq);
     L.qvel = put(nv); L.qvref = put(nv); L.ws = put(nv); L.qacc = put(nv); L.smooth = put(nv); L.asmooth = put(nv); L.passive = put(nv);
     L.bias = put(nv); L.applied = put(nv); L.tmpv = put(nv); L.tmpv2 = put(nv);
@@ -178,8 +194,11 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     L.xanchor = put(3*nj); L.xaxis = put(3*nj); L.cdof = put(6*nv); L.cdofdot = put(6*nv);
     L.qM = put(m->nM); L.qLD = put(m->nM); L.qLDinv = put(nv);
     L.gpos = put(3*ng); L.gmat = put(9*ng);
-    L.con = put(M.maxcon * CON_STRIDE); L.rowi = put(rows * ROWI_STRIDE); L.rowf = put(rows * ROWF_STRIDE);
-    L.J = put(jsz); L.B = put(jsz);
+    L.dofpar = put(nv); L.dofMadr = put(nv);
+    L.p_gsize = put(3*ng); L.p_rbound = put(ng); L.p_mass = put(nb); L.p_inertia = put(3*nb); L.p_binv = put(2*nb); L.p_dinv = put(nv);
+    L.con = put(M.maxcon * CON_STRIDE); L.blki = put(nblkcap * BLKI_STRIDE); L.blkf = put(nblkcap * BLKF_STRIDE);
+    L.bv = put(nblkcap * 4); L.phi = put(nblkcap * 4);
+    L.J = put(jsz); L.B = diagM ? L.J : put(jsz);
     L.total = off;
     e->lds_bytes = off * (int)sizeof(float);
   }
@@ -187,9 +206,9 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     mjh_set_error("mjh_create: per-env working set exceeds the 160 KiB LDS of one CU (" + std::to_string(e->lds_bytes) + " B)");
     mjh_destroy(e); return MJH_ERR_CAPACITY;
   }
-  HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
-  HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
-  HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+#define MJH_ATTR(NR, DG) HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<NR, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes))
+  MJH_ATTR(1, true); MJH_ATTR(2, true); MJH_ATTR(4, true); MJH_ATTR(1, false); MJH_ATTR(2, false); MJH_ATTR(4, false);
+#undef MJH_ATTR
 
   // ---- per-env state
   DState& S = e->S;

@@ -34,18 +34,19 @@ DEV float get_impedance(const float* si, float pos, float margin) {
 }
 
 // in-place x <- M^-1 x over one tree's contiguous dof range, x addressed by absolute dof index
+template <int STRIDE = 1>
 DEV void solve_tree(float* x, const float* qLD, const float* qLDinv, const int* dof_parentid, const int* dof_Madr, int adr, int num) {
   for (int k = adr + num - 1; k >= adr; k--) {
-    float xk = x[k];
+    float xk = x[k * STRIDE];
     if (xk == 0) continue;
     int a = dof_Madr[k] + 1;
-    for (int i = dof_parentid[k]; i >= 0; i = dof_parentid[i]) x[i] -= qLD[a++] * xk;
+    for (int i = dof_parentid[k]; i >= 0; i = dof_parentid[i]) x[i * STRIDE] -= qLD[a++] * xk;
   }
-  for (int k = adr; k < adr + num; k++) x[k] *= qLDinv[k];
+  for (int k = adr; k < adr + num; k++) x[k * STRIDE] *= qLDinv[k];
   for (int k = adr; k < adr + num; k++) {
-    int a = dof_Madr[k] + 1; float xk = x[k];
-    for (int i = dof_parentid[k]; i >= 0; i = dof_parentid[i]) xk -= qLD[a++] * x[i];
-    x[k] = xk;
+    int a = dof_Madr[k] + 1; float xk = x[k * STRIDE];
+    for (int i = dof_parentid[k]; i >= 0; i = dof_parentid[i]) xk -= qLD[a++] * x[i * STRIDE];
+    x[k * STRIDE] = xk;
   }
 }
 DEV void factor_tree(float* qLD, float* qLDinv, const int* dof_parentid, const int* dof_Madr, int adr, int num) {
@@ -73,7 +74,40 @@ DEV int row_off(int d, int a1, int n1, int a2, int n2) {
   return r1 < (unsigned)n1 ? (int)r1 : (r2 < (unsigned)n2 ? n1 + (int)r2 : -1);
 }
 
-template <int NROW>
+
+// A_c is stored as its upper triangle in a 4x4 row-major array
+#define A_SYM(A, i, j) ((i) <= (j) ? (A)[4*(i)+(j)] : (A)[4*(j)+(i)])
+// One pyramidal contact block of the PGS sweep: NB base rows (normal, tangents[, torsion]), NR = 2(NB-1) rows
+//   row r = J_n + c_r J_k,  k = 1 + r/2,  c_r = +-mu_k.   Everything after the NB reductions is wave-uniform.
+template <int NB, int NR, int NROW>
+DEV void pgs_pyramid(const float* P, const float* aref, float* f, const float* A, const float* Jd, const float* Bd, float& a, float& improvement) {
+  float u[4] = {Jd[0] * a, Jd[1] * a, Jd[2] * a, NB > 3 ? Jd[3] * a : 0.0f}, dphi[NB];
+  wave_sum4<NROW, NB>(u);
+#pragma unroll
+  for (int j = 0; j < NB; j++) dphi[j] = 0;
+  const float R = P[0];
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    const int k = 1 + (r >> 1);
+    const float c = ((r & 1) ? -1.0f : 1.0f) * (k < 3 ? P[2] : P[3]);
+    const float AR = A[0] + c * (2.0f * A[k] + c * A[4*k + k]) + R;
+    const float ARinv = __builtin_amdgcn_rcpf(AR);
+    const float fold = f[r];
+    const float res = u[0] + c * u[k] - aref[r] + R * fold;
+    float fn = fmaxf(0.0f, fold - res * ARinv);
+    float delta = fn - fold;
+    const float change = delta * (0.5f * delta * AR + res);
+    if (change > 1e-10f) { fn = fold; delta = 0; } else improvement -= change;
+#pragma unroll
+    for (int j = 0; j < NB; j++) u[j] += (A_SYM(A, j, 0) + c * A_SYM(A, j, k)) * delta;
+    dphi[0] += delta; dphi[k] += c * delta;
+    f[r] = fn;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; j++) a += Bd[j] * dphi[j];
+}
+
+template <int NROW, bool DIAGM>
 __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DState S, const Lay L, int env0, int nsteps, int ph, int xflags) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x;
@@ -86,19 +120,12 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
 #define FT(n) const float* n = M.F + M.o_##n;
   MJH_FLT_TABLES(FT)
 #undef FT
-  // per-env parameter overrides
-  if (S.p_geom_size) geom_size = S.p_geom_size + (size_t)env * 3 * ngeom;
-  if (S.p_geom_rbound) geom_rbound = S.p_geom_rbound + (size_t)env * ngeom;
-  if (S.p_body_mass) body_mass = S.p_body_mass + (size_t)env * nbody;
-  if (S.p_body_inertia) body_inertia = S.p_body_inertia + (size_t)env * 3 * nbody;
-  if (S.p_body_invweight0) body_invweight0 = S.p_body_invweight0 + (size_t)env * 2 * nbody;
-  if (S.p_dof_invweight0) dof_invweight0 = S.p_dof_invweight0 + (size_t)env * nv;
-
 #define LA(n) float* s_##n = lds + L.n;
   MJH_LDS_ARRAYS(LA)
 #undef LA
-  int* s_rowi_i = (int*)s_rowi;
-  float* s_stage = s_J;  // raw-contact staging aliases the (not yet built) row storage
+  int* s_blki_i = (int*)s_blki; int* s_dofpar_i = (int*)s_dofpar; int* s_dofMadr_i = (int*)s_dofMadr;
+  float* s_stage = s_J;  // raw-contact staging aliases the (not yet built) base-row storage
+  const int rowW = M.rowW;
 
   const size_t qrow = (size_t)env * M.nqp, vrow = (size_t)env * M.nvp;
   const float h = M.timestep;
@@ -117,6 +144,16 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
     s_qvel[i] = S.qvel[vrow + i]; s_ws[i] = S.qacc_ws[vrow + i]; s_qacc[i] = S.qacc[vrow + i];
     s_qvref[i] = S.qvel_ref[vrow + i]; s_applied[i] = S.qfrc_applied[vrow + i];
   }
+  // hot chain-walk tables and the (possibly per-env) model parameters go to LDS once per launch
+  for (int i = lane; i < nv; i += 64) {
+    s_dofpar_i[i] = dof_parentid[i]; s_dofMadr_i[i] = dof_Madr[i];
+    s_p_dinv[i] = S.p_dof_invweight0 ? S.p_dof_invweight0[(size_t)env * nv + i] : dof_invweight0[i];
+  }
+  for (int i = lane; i < 3 * ngeom; i += 64) s_p_gsize[i] = S.p_geom_size ? S.p_geom_size[(size_t)env * 3 * ngeom + i] : geom_size[i];
+  for (int i = lane; i < ngeom; i += 64) s_p_rbound[i] = S.p_geom_rbound ? S.p_geom_rbound[(size_t)env * ngeom + i] : geom_rbound[i];
+  for (int i = lane; i < nbody; i += 64) s_p_mass[i] = S.p_body_mass ? S.p_body_mass[(size_t)env * nbody + i] : body_mass[i];
+  for (int i = lane; i < 3 * nbody; i += 64) s_p_inertia[i] = S.p_body_inertia ? S.p_body_inertia[(size_t)env * 3 * nbody + i] : body_inertia[i];
+  for (int i = lane; i < 2 * nbody; i += 64) s_p_binv[i] = S.p_body_invweight0 ? S.p_body_invweight0[(size_t)env * 2 * nbody + i] : body_invweight0[i];
   float time = S.time[env];
   int flags = 0, ncon = 0, nefc = 0, niter = 0;
   PROF(0);
@@ -228,7 +265,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
       if (r == 0 || body_parentid[r] != 0) continue;
       float sm = 0, c[3] = {0, 0, 0};
       for (int b = r; b < r + body_subtreesize[r]; b++) {
-        float m = body_mass[b]; sm += m;
+        float m = s_p_mass[b]; sm += m;
         c[0] += m * s_xipos[3*b]; c[1] += m * s_xipos[3*b+1]; c[2] += m * s_xipos[3*b+2];
       }
       if (sm < MJ_MINVAL) { c[0] = s_xipos[3*r]; c[1] = s_xipos[3*r+1]; c[2] = s_xipos[3*r+2]; }
@@ -242,7 +279,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
       else {
         const float* com = s_com + 3*body_rootid[b];
         float off[3] = {s_xipos[3*b] - com[0], s_xipos[3*b+1] - com[1], s_xipos[3*b+2] - com[2]};
-        inert_com(ci, body_inertia + 3*b, s_ximat + 9*b, off, body_mass[b]);
+        inert_com(ci, s_p_inertia + 3*b, s_ximat + 9*b, off, s_p_mass[b]);
       }
 #pragma unroll
       for (int k = 0; k < 10; k++) s_cinert[10*b+k] = ci[k];
@@ -281,8 +318,8 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
 #pragma unroll
       for (int q = 0; q < 6; q++) cd[q] = s_cdof[6*i+q];
       mul_inert_vec(buf, s_crb + 10*dof_bodyid[i], cd);
-      int adr = dof_Madr[i];
-      for (int j = i; j >= 0; j = dof_parentid[j]) {
+      int adr = s_dofMadr_i[i];
+      for (int j = i; j >= 0; j = s_dofpar_i[j]) {
         float v = 0;
 #pragma unroll
         for (int q = 0; q < 6; q++) v += s_cdof[6*j+q] * buf[q];
@@ -295,8 +332,8 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
       for (int i = lane; i < nv; i += 64) { s_tmpv[i] = S.x_vec[(size_t)blockIdx.x * M.nvp + i]; s_tmpv2[i] = 0; }
       WSYNC();
       for (int i = lane; i < nv; i += 64) {
-        int adr = dof_Madr[i]; float vi = s_tmpv[i], acc = s_qM[adr] * vi; int k = 1;
-        for (int j = dof_parentid[i]; j >= 0; j = dof_parentid[j]) { float mij = s_qM[adr + k]; acc += mij * s_tmpv[j]; atomicAdd(&s_tmpv2[j], mij * vi); k++; }
+        int adr = s_dofMadr_i[i]; float vi = s_tmpv[i], acc = s_qM[adr] * vi; int k = 1;
+        for (int j = s_dofpar_i[i]; j >= 0; j = s_dofpar_i[j]) { float mij = s_qM[adr + k]; acc += mij * s_tmpv[j]; atomicAdd(&s_tmpv2[j], mij * vi); k++; }
         atomicAdd(&s_tmpv2[i], acc);
       }
       WSYNC();
@@ -305,7 +342,8 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
     }
     PROF(3);
     // ---- L'DL factorisation (mj_factorM): one lane per kinematic tree
-    for (int t = lane; t < M.ntree; t += 64) factor_tree(s_qLD, s_qLDinv, dof_parentid, dof_Madr, tree_dofadr[t], tree_dofnum[t]);
+    if (DIAGM) { for (int d = lane; d < nv; d += 64) s_qLDinv[d] = 1.0f / s_qM[s_dofMadr_i[d]]; }   // every tree: M is diagonal (single free body about its COM)
+    else for (int t = lane; t < M.ntree; t += 64) factor_tree(s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t]);
     WSYNC();
 
     PROF(4);
@@ -324,13 +362,13 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
           margin = fmaxf(geom_margin[g1], geom_margin[g2]); gap = fmaxf(geom_gap[g1], geom_gap[g2]);
           float p1[3], p2[3], m1[9], m2[9], z1[3], z2[3];
 #pragma unroll
-          for (int k = 0; k < 3; k++) { p1[k] = s_gpos[3*g1+k]; p2[k] = s_gpos[3*g2+k]; z1[k] = geom_size[3*g1+k]; z2[k] = geom_size[3*g2+k]; }
+          for (int k = 0; k < 3; k++) { p1[k] = s_gpos[3*g1+k]; p2[k] = s_gpos[3*g2+k]; z1[k] = s_p_gsize[3*g1+k]; z2[k] = s_p_gsize[3*g2+k]; }
 #pragma unroll
           for (int k = 0; k < 9; k++) { m1[k] = s_gmat[9*g1+k]; m2[k] = s_gmat[9*g2+k]; }
           bool cull;
           float tt[3] = {p2[0]-p1[0], p2[1]-p1[1], p2[2]-p1[2]};
-          if (t1 == MJH_GEOM_PLANE) { float nn[3] = {m1[2], m1[5], m1[8]}; cull = dot3(tt, nn) > geom_rbound[g2] + margin; }
-          else { float bound = geom_rbound[g1] + geom_rbound[g2] + margin; cull = dot3(tt, tt) > bound * bound; }
+          if (t1 == MJH_GEOM_PLANE) { float nn[3] = {m1[2], m1[5], m1[8]}; cull = dot3(tt, nn) > s_p_rbound[g2] + margin; }
+          else { float bound = s_p_rbound[g1] + s_p_rbound[g2] + margin; cull = dot3(tt, tt) > bound * bound; }
           if (!cull) {
             if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_BOX) n = c_plane_box(p1, m1, p2, m2, z2, margin, st);
             else if (t1 == MJH_GEOM_BOX && t2 == MJH_GEOM_BOX) n = c_box_box(p1, m1, z1, p2, m2, z2, margin, st);
@@ -371,22 +409,22 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
     }
 
     PROF(5);
-    // ---- constraint rows (mj_makeConstraint + mj_makeImpedance): header pass, then lanes = rows
+    // ---- constraint blocks (mj_makeConstraint + mj_makeImpedance).  A block = the rows that share base
+    //      Jacobians: 1 row (equality / friction loss / limit / frictionless contact) or the 2(dim-1)
+    //      pyramid rows of a contact, which are all  J_n +- mu_k J_k  over nbase = dim base rows.
     nefc = 0;
+    int nblk = 0, nbrow = 0;
     if (!(M.disableflags & MJH_DSBL_CONSTRAINT)) {
-      // equality rows (static count), friction-loss rows (static count)
-      int nstatic = 0;
-      if (!(M.disableflags & MJH_DSBL_EQUALITY)) {
-        for (int e = 0; e < M.neq; e++) if (eq_active[e]) {
-          if (lane == 0) { int* hd = s_rowi_i + nstatic * ROWI_STRIDE; hd[0] = MJH_CNSTR_EQUALITY; hd[1] = e; }
-          nstatic++;
-        }
-      }
+      auto put_block = [&](int b, int kind, int nrows, int nb, int clamp, int, int id, int rtype, int side) {
+        int* hd = s_blki_i + b * BLKI_STRIDE;
+        hd[0] = kind | (nrows << 4) | (nb << 8) | (clamp << 12); hd[1] = id | (rtype << 24) | (side << 28);
+      };
+      if (!(M.disableflags & MJH_DSBL_EQUALITY))
+        for (int e = 0; e < M.neq; e++) if (eq_active[e]) { if (lane == 0) put_block(nblk, BK_SINGLE, 1, 1, 0, nbrow, e, RT_EQ, 0); nblk++; nbrow++; nefc++; }
       if (!(M.disableflags & MJH_DSBL_FRICTIONLOSS)) {
-        for (int f = lane; f < M.nfl; f += 64) { int* hd = s_rowi_i + (nstatic + f) * ROWI_STRIDE; hd[0] = MJH_CNSTR_FRICTION_DOF; hd[1] = fl_dof[f]; }
-        nstatic += M.nfl;
+        for (int f = lane; f < M.nfl; f += 64) put_block(nblk + f, BK_SINGLE, 1, 1, 2, nbrow + f, fl_dof[f], RT_FL, 0);
+        nblk += M.nfl; nbrow += M.nfl; nefc += M.nfl;
       }
-      nefc = nstatic;
       if (M.has_limits && !(M.disableflags & MJH_DSBL_LIMIT)) {
         for (int base = 0; base < njnt; base += 64) {
           const int j = base + lane; int lo = 0, hi = 0;
@@ -395,171 +433,267 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
             lo = (val - jnt_range[2*j]) < mg; hi = (jnt_range[2*j+1] - val) < mg;
           }
           const int n = lo + hi, incl = wave_incl_scan_i(n, lane);
-          int r = nefc + incl - n;
-          if (lo && r < M.maxefc) { int* hd = s_rowi_i + r * ROWI_STRIDE; hd[0] = MJH_CNSTR_LIMIT_JOINT; hd[1] = j; r++; }
-          if (hi && r < M.maxefc) { int* hd = s_rowi_i + r * ROWI_STRIDE; hd[0] = MJH_CNSTR_LIMIT_JOINT | (1 << 8); hd[1] = j; }
-          nefc += __shfl(incl, 63);
+          int r = incl - n;
+          if (lo) { put_block(nblk + r, BK_SINGLE, 1, 1, 1, nbrow + r, j, RT_LIMIT, 0); r++; }
+          if (hi) put_block(nblk + r, BK_SINGLE, 1, 1, 1, nbrow + r, j, RT_LIMIT, 1);
+          const int tot = __shfl(incl, 63);
+          nblk += tot; nbrow += tot; nefc += tot;
         }
-        if (nefc > M.maxefc) { nefc = M.maxefc; flags |= 2; }
       }
-      // contact rows: a contact whose rows do not fit drops it and every later contact (oracle rule)
+      // contacts: a contact whose rows do not fit drops it and every later contact (oracle rule)
       bool stop = false;
       for (int base = 0; base < ncon && !stop; base += 64) {
-        const int ic = base + lane; int n = 0, dim = 0;
+        const int ic = base + lane; int nr = 0, nb = 0, dim = 0;
         if (ic < ncon) {
           const float* c = s_con + ic * CON_STRIDE;
           dim = __float_as_int(c[15]);
-          n = (c[0] >= c[16]) ? 0 : (dim == 1 ? 1 : 2 * (dim - 1));
+          if (c[0] < c[16]) { nr = dim == 1 ? 1 : 2 * (dim - 1); nb = dim == 1 ? 1 : (dim == 3 ? 3 : 4); }
         }
-        const int incl = wave_incl_scan_i(n, lane);
-        const int r0 = nefc + incl - n;
-        const unsigned long long over = __ballot(n > 0 && r0 + n > M.maxefc);
+        const int inc = nr > 0;
+        const int sr = wave_incl_scan_i(nr, lane), sb = wave_incl_scan_i(nb, lane), sc = wave_incl_scan_i(inc, lane);
+        const unsigned long long over = __ballot(inc && nefc + sr > M.maxefc);
         const int firstover = over ? __ffsll((long long)over) - 1 : 64;
-        if (n > 0 && lane < firstover) {
-          for (int q = 0; q < n; q++) {
-            int* hd = s_rowi_i + (r0 + q) * ROWI_STRIDE;
-            hd[0] = (dim == 1 ? MJH_CNSTR_CONTACT_FRICTIONLESS : MJH_CNSTR_CONTACT_PYRAMIDAL) | (q << 8); hd[1] = ic;
-          }
-        }
-        if (over) { flags |= 2; stop = true; nefc = __shfl(r0, firstover); }
-        else nefc += __shfl(incl, 63);
+        if (inc && lane < firstover)
+          put_block(nblk + sc - 1, dim == 1 ? BK_SINGLE : (dim == 3 ? BK_PYR3 : BK_PYR4), nr, nb, 1, nbrow + sb - nb, ic, RT_CONTACT, 0);
+        int last = 63;
+        if (over) { flags |= 2; stop = true; last = firstover - 1; }
+        if (last >= 0) { nefc += __shfl(sr, last); nbrow += __shfl(sb, last); nblk += __shfl(sc, last); }
       }
     }
-    nefc = __builtin_amdgcn_readfirstlane(nefc);
+    nefc = __builtin_amdgcn_readfirstlane(nefc); nblk = __builtin_amdgcn_readfirstlane(nblk); nbrow = __builtin_amdgcn_readfirstlane(nbrow);
     WSYNC();
     PROF(6);
-    // rows: Jacobian (compact over the trees it touches), impedance, regulariser, reference gains
-    for (int r = lane; r < nefc; r += 64) {
-      int* hd = s_rowi_i + r * ROWI_STRIDE;
-      const int type = hd[0] & 0xff, id = hd[1], sub = hd[0] >> 8;
-      float* J = s_J + r * M.rowW; float* rf = s_rowf + r * ROWF_STRIDE;
-      for (int k = 0; k < M.rowW; k++) J[k] = 0;
-      float pos = 0, margin = 0, diagA = 0, lo = 0, hi = 3.0e38f, rscale = -1;
-      const float *solref, *solimp;
+    // ---- base Jacobian rows: lanes = (block, base) tasks.  Storage is interleaved per block, J[b][k][4]
+    //      (k = compact dof index over the up-to-two trees the block touches), so that the solver reads
+    //      the 4 base entries of one dof with a single ds_read_b128.
+    for (int t = lane; t < 4 * nblk; t += 64) {
+      const int b = t >> 2, jb = t & 3;
+      int* hd = s_blki_i + b * BLKI_STRIDE;
+      const int nb = (hd[0] >> 8) & 15;
+      float* J = s_J + b * rowW * 4 + jb;
+      for (int k = 0; k < rowW; k++) J[4*k] = 0;
+      if (jb >= nb) continue;
+      const int id = hd[1] & 0xffffff, rtype = (hd[1] >> 24) & 15, side = (hd[1] >> 28) & 1;
       int t1 = -1, t2 = -1;
-      if (type == MJH_CNSTR_EQUALITY) {
+      if (rtype == RT_EQ) {
         const int j1 = eq_obj1id[id], j2 = eq_obj2id[id];
         const float* dat = eq_data + 11*id;
         const int d1 = jnt_dofadr[j1];
-        float pos1 = s_qpos[jnt_qposadr[j1]] - qpos0[jnt_qposadr[j1]];
         t1 = dof_treeid[d1];
-        J[d1 - tree_dofadr[t1]] = 1; diagA = dof_invweight0[d1];
+        J[4*(d1 - tree_dofadr[t1])] = 1;
         if (j2 >= 0) {
           const int d2 = jnt_dofadr[j2];
-          float p2 = s_qpos[jnt_qposadr[j2]] - qpos0[jnt_qposadr[j2]];
+          const float p2 = s_qpos[jnt_qposadr[j2]] - qpos0[jnt_qposadr[j2]];
+          const float deriv = dat[1] + p2*(2*dat[2] + p2*(3*dat[3] + p2*4*dat[4]));
+          const int tt = dof_treeid[d2];
+          if (tt == t1) J[4*(d2 - tree_dofadr[t1])] += -deriv;
+          else { t2 = tt; J[4*(tree_dofnum[t1] + d2 - tree_dofadr[t2])] = -deriv; }
+        }
+      } else if (rtype == RT_FL) { t1 = dof_treeid[id]; J[4*(id - tree_dofadr[t1])] = 1; }
+      else if (rtype == RT_LIMIT) { const int d = jnt_dofadr[id]; t1 = dof_treeid[d]; J[4*(d - tree_dofadr[t1])] = side ? -1.0f : 1.0f; }
+      else {
+        const float* c = s_con + id * CON_STRIDE;
+        const int g1 = __float_as_int(c[13]), g2 = __float_as_int(c[14]);
+        const int b1 = geom_bodyid[g1], b2 = geom_bodyid[g2];
+        t1 = body_treeid[b1]; t2 = body_treeid[b2];
+        if (t1 < 0) { t1 = t2; t2 = -1; }
+        if (t2 == t1) t2 = -1;
+        const float* dir = c + 4 + 3 * (jb < 3 ? jb : 0);   // base 0..2: translation along n,t1,t2 ; base 3: rotation about n
+#pragma unroll
+        for (int sd = 0; sd < 2; sd++) {
+          const int bd = sd ? b2 : b1; const float ss = sd ? 1.0f : -1.0f;
+          int i = body_lastdof[bd];
+          if (i < 0) continue;
+          const float* com = s_com + 3*body_rootid[bd];
+          const float off[3] = {c[1] - com[0], c[2] - com[1], c[3] - com[2]};
+          const int tr = dof_treeid[i];
+          const int o = (tr == t1) ? -tree_dofadr[t1] : tree_dofnum[t1] - tree_dofadr[t2];
+          for (; i >= 0; i = s_dofpar_i[i]) {
+            const float* cd = s_cdof + 6*i;
+            float v;
+            if (jb < 3) { float cr[3]; cross3(cr, cd, off); const float jp[3] = {cd[3] + cr[0], cd[4] + cr[1], cd[5] + cr[2]}; v = dot3(dir, jp); }
+            else v = dot3(dir, cd);
+            J[4*(o + i)] += ss * v;
+          }
+        }
+      }
+      if (jb == 0) { hd[2] = tree_dofadr[t1] | (tree_dofnum[t1] << 16); hd[3] = t2 >= 0 ? (tree_dofadr[t2] | (tree_dofnum[t2] << 16)) : 0; }
+    }
+    // ---- block parameters: impedance, regulariser R, reference gains (lanes = blocks)
+    for (int b = lane; b < nblk; b += 64) {
+      const int* hd = s_blki_i + b * BLKI_STRIDE;
+      const int id = hd[1] & 0xffffff, rtype = (hd[1] >> 24) & 15, side = (hd[1] >> 28) & 1;
+      float* bf = s_blkf + b * BLKF_STRIDE;
+      float pos = 0, margin = 0, diagA = 0, fl = 0, mu1 = 0, mu3 = 0, rscale = -1, sr[2], si[5];
+      if (rtype == RT_EQ) {
+        const int j1 = eq_obj1id[id], j2 = eq_obj2id[id];
+        const float* dat = eq_data + 11*id;
+        const float pos1 = s_qpos[jnt_qposadr[j1]] - qpos0[jnt_qposadr[j1]];
+        diagA = s_p_dinv[jnt_dofadr[j1]];
+        if (j2 >= 0) {
+          const float p2 = s_qpos[jnt_qposadr[j2]] - qpos0[jnt_qposadr[j2]];
           pos = pos1 - (dat[0] + p2*(dat[1] + p2*(dat[2] + p2*(dat[3] + p2*dat[4]))));
-          float deriv = dat[1] + p2*(2*dat[2] + p2*(3*dat[3] + p2*4*dat[4]));
-          int tt = dof_treeid[d2];
-          if (tt == t1) J[d2 - tree_dofadr[t1]] += -deriv;
-          else { t2 = tt; J[tree_dofnum[t1] + d2 - tree_dofadr[t2]] = -deriv; }
-          diagA += dof_invweight0[d2];
+          diagA += s_p_dinv[jnt_dofadr[j2]];
         } else pos = pos1 - dat[0];
-        solref = eq_solref + 2*id; solimp = eq_solimp + 5*id; lo = -3.0e38f;
-      } else if (type == MJH_CNSTR_FRICTION_DOF) {
-        t1 = dof_treeid[id]; J[id - tree_dofadr[t1]] = 1; diagA = dof_invweight0[id];
-        solref = dof_solref + 2*id; solimp = dof_solimp + 5*id; lo = -dof_frictionloss[id]; hi = dof_frictionloss[id];
-      } else if (type == MJH_CNSTR_LIMIT_JOINT) {
-        const int d = jnt_dofadr[id]; float val = s_qpos[jnt_qposadr[id]];
-        t1 = dof_treeid[d];
-        if (sub == 0) { pos = val - jnt_range[2*id]; J[d - tree_dofadr[t1]] = 1; } else { pos = jnt_range[2*id+1] - val; J[d - tree_dofadr[t1]] = -1; }
-        margin = jnt_margin[id]; diagA = dof_invweight0[d];
-        solref = jnt_solref + 2*id; solimp = jnt_solimp + 5*id;
+        sr[0] = eq_solref[2*id]; sr[1] = eq_solref[2*id+1];
+#pragma unroll
+        for (int q = 0; q < 5; q++) si[q] = eq_solimp[5*id+q];
+      } else if (rtype == RT_FL) {
+        diagA = s_p_dinv[id]; fl = dof_frictionloss[id];
+        sr[0] = dof_solref[2*id]; sr[1] = dof_solref[2*id+1];
+#pragma unroll
+        for (int q = 0; q < 5; q++) si[q] = dof_solimp[5*id+q];
+      } else if (rtype == RT_LIMIT) {
+        const float val = s_qpos[jnt_qposadr[id]];
+        pos = side ? jnt_range[2*id+1] - val : val - jnt_range[2*id];
+        margin = jnt_margin[id]; diagA = s_p_dinv[jnt_dofadr[id]];
+        sr[0] = jnt_solref[2*id]; sr[1] = jnt_solref[2*id+1];
+#pragma unroll
+        for (int q = 0; q < 5; q++) si[q] = jnt_solimp[5*id+q];
       } else {
         const float* c = s_con + id * CON_STRIDE;
         const int g1 = __float_as_int(c[13]), g2 = __float_as_int(c[14]), dim = __float_as_int(c[15]);
         const int b1 = geom_bodyid[g1], b2 = geom_bodyid[g2];
         pos = c[0]; margin = c[16];
         // contact parameters (mj_contactParam): max friction, solmix-weighted solref/solimp
-        float f0 = fmaxf(geom_friction[3*g1], geom_friction[3*g2]), f1 = fmaxf(geom_friction[3*g1+1], geom_friction[3*g2+1]),
-              f2 = fmaxf(geom_friction[3*g1+2], geom_friction[3*g2+2]);
-        const int k = (type == MJH_CNSTR_CONTACT_FRICTIONLESS) ? 0 : 1 + (sub >> 1);  // pyramid edge direction index 1..dim-1
-        const float sgn = (sub & 1) ? -1.0f : 1.0f;
-        const float mu = (k == 0) ? 0.0f : (k <= 2 ? f0 : (k == 3 ? f1 : f2));
-        const float tran = body_invweight0[2*b1] + body_invweight0[2*b2], rot = body_invweight0[2*b1+1] + body_invweight0[2*b2+1];
-        (void)dim;
-        if (k == 0) diagA = tran;
-        else { diagA = tran + f0*f0*tran; float mu0 = f0 * rsqrtf(M.impratio); rscale = 2 * mu0 * mu0; }  // Rpy = 2 mu^2 R(first row)
-        t1 = body_treeid[b1]; t2 = body_treeid[b2];
-        if (t1 < 0) { t1 = t2; t2 = -1; }
-        if (t2 == t1) t2 = -1;
-        const float* n = c + 4; const float* tk = c + 4 + 3 * (k <= 2 ? k : k - 3);
-        // Jacobian difference (body2 - body1) projected on (normal + sgn*mu*direction_k)
+        const float f0 = fmaxf(geom_friction[3*g1], geom_friction[3*g2]), f1 = fmaxf(geom_friction[3*g1+1], geom_friction[3*g2+1]);
+        mu1 = f0; mu3 = f1;
+        const float tran = s_p_binv[2*b1] + s_p_binv[2*b2];
+        if (dim == 1) diagA = tran;
+        else { diagA = tran + f0*f0*tran; const float mu0 = f0 * rsqrtf(M.impratio); rscale = 2 * mu0 * mu0; }  // Rpy = 2 mu^2 R(first row)
+        const float a = geom_solmix[g1], bq = geom_solmix[g2];
+        const float mix = (a >= MJ_MINVAL && bq >= MJ_MINVAL) ? a / (a + bq) : ((a < MJ_MINVAL && bq < MJ_MINVAL) ? 0.5f : (a < MJ_MINVAL ? 0.0f : 1.0f));
+        sr[0] = mix*geom_solref[2*g1] + (1-mix)*geom_solref[2*g2]; sr[1] = mix*geom_solref[2*g1+1] + (1-mix)*geom_solref[2*g2+1];
 #pragma unroll
-        for (int side = 0; side < 2; side++) {
-          const int b = side ? b2 : b1; const float ss = side ? 1.0f : -1.0f;
-          int i = body_lastdof[b];
-          if (i < 0) continue;
-          const float* com = s_com + 3*body_rootid[b];
-          const float off[3] = {c[1] - com[0], c[2] - com[1], c[3] - com[2]};
-          const int tr = dof_treeid[i];
-          const int o = (tr == t1) ? -tree_dofadr[t1] : tree_dofnum[t1] - tree_dofadr[t2];
-          for (; i >= 0; i = dof_parentid[i]) {
-            const float* cd = s_cdof + 6*i;
-            float cr[3]; cross3(cr, cd, off);
-            float jp[3] = {cd[3] + cr[0], cd[4] + cr[1], cd[5] + cr[2]};
-            float v = dot3(n, jp);
-            if (k >= 1 && k <= 2) v += sgn * mu * dot3(tk, jp);
-            else if (k >= 3) v += sgn * mu * dot3(tk, cd);
-            J[o + i] += ss * v;
-          }
-        }
-        {
-          const float a = geom_solmix[g1], bq = geom_solmix[g2];
-          float mix = (a >= MJ_MINVAL && bq >= MJ_MINVAL) ? a / (a + bq) : ((a < MJ_MINVAL && bq < MJ_MINVAL) ? 0.5f : (a < MJ_MINVAL ? 0.0f : 1.0f));
-          float* sr = s_tmpv;  // unused here; parameters are mixed into registers below
-          (void)sr;
-          float srm[2] = {mix*geom_solref[2*g1] + (1-mix)*geom_solref[2*g2], mix*geom_solref[2*g1+1] + (1-mix)*geom_solref[2*g2+1]};
-          float sim[5];
-#pragma unroll
-          for (int q = 0; q < 5; q++) sim[q] = mix*geom_solimp[5*g1+q] + (1-mix)*geom_solimp[5*g2+q];
-          // finish this row here (parameters live in registers)
-          float imp = get_impedance(sim, pos, margin);
-          float R = fmaxf(MJ_MINVAL, (1 - imp) * diagA / imp);
-          if (rscale > 0) R = fmaxf(MJ_MINVAL, rscale * R);
-          float sr0 = srm[0], sr1 = srm[1], dmax = fminf(MAXIMP, fmaxf(MINIMP, sim[1])), K, Bc;
-          if (sr0 > 0) {
-            if (!(M.disableflags & MJH_DSBL_REFSAFE)) sr0 = fmaxf(sr0, 2 * h);
-            K = 1 / fmaxf(MJ_MINVAL, dmax*dmax * sr0*sr0 * sr1*sr1); Bc = 2 / fmaxf(MJ_MINVAL, dmax * sr0);
-          } else { K = -sr0 / fmaxf(MJ_MINVAL, dmax*dmax); Bc = -sr1 / fmaxf(MJ_MINVAL, dmax); }
-          rf[0] = K * imp * (pos - margin); rf[1] = Bc; rf[2] = R; rf[6] = lo; rf[7] = hi;
-          hd[2] = tree_dofadr[t1] | (tree_dofnum[t1] << 16); hd[3] = t2 >= 0 ? (tree_dofadr[t2] | (tree_dofnum[t2] << 16)) : 0;
-          continue;
-        }
+        for (int q = 0; q < 5; q++) si[q] = mix*geom_solimp[5*g1+q] + (1-mix)*geom_solimp[5*g2+q];
       }
-      float imp = get_impedance(solimp, pos, margin);
+      const float imp = get_impedance(si, pos, margin);
       float R = fmaxf(MJ_MINVAL, (1 - imp) * diagA / imp);
-      float sr0 = solref[0], sr1 = solref[1], dmax = fminf(MAXIMP, fmaxf(MINIMP, solimp[1])), K, Bc;
+      if (rscale > 0) R = fmaxf(MJ_MINVAL, rscale * R);
+      float sr0 = sr[0], K, Bc; const float sr1 = sr[1], dmax = fminf(MAXIMP, fmaxf(MINIMP, si[1]));
       if (sr0 > 0) {
         if (!(M.disableflags & MJH_DSBL_REFSAFE)) sr0 = fmaxf(sr0, 2 * h);
         K = 1 / fmaxf(MJ_MINVAL, dmax*dmax * sr0*sr0 * sr1*sr1); Bc = 2 / fmaxf(MJ_MINVAL, dmax * sr0);
       } else { K = -sr0 / fmaxf(MJ_MINVAL, dmax*dmax); Bc = -sr1 / fmaxf(MJ_MINVAL, dmax); }
-      if (type == MJH_CNSTR_FRICTION_DOF) K = 0;
-      rf[0] = K * imp * (pos - margin); rf[1] = Bc; rf[2] = R; rf[6] = lo; rf[7] = hi;
-      hd[2] = tree_dofadr[t1] | (tree_dofnum[t1] << 16); hd[3] = t2 >= 0 ? (tree_dofadr[t2] | (tree_dofnum[t2] << 16)) : 0;
+      if (rtype == RT_FL) K = 0;
+      bf[0] = R; bf[1] = fl; bf[2] = mu1; bf[3] = mu3;
+      bf[BF_A + 4] = K * imp * (pos - margin); bf[BF_A + 8] = Bc;   // KI, Bc live in two unused lower-triangle slots of A
     }
     WSYNC();
     PROF(7);
-    // B = M^-1 J^T per row (mj_projectConstraint without the dense AR), ARinv = 1/(J.B + R)
-    for (int r = lane; r < nefc; r += 64) {
-      const int* hd = s_rowi_i + r * ROWI_STRIDE;
-      ROW_TREES(hd[2], hd[3]);
-      const float* J = s_J + r * M.rowW; float* B = s_B + r * M.rowW; float* rf = s_rowf + r * ROWF_STRIDE;
-      int wdt = n1;
-      for (int k = 0; k < n1; k++) B[k] = J[k];
-      solve_tree(B - a1, s_qLD, s_qLDinv, dof_parentid, dof_Madr, a1, n1);
-      if (n2 > 0) {
-        for (int k = 0; k < n2; k++) B[n1 + k] = J[n1 + k];
-        solve_tree(B + n1 - a2, s_qLD, s_qLDinv, dof_parentid, dof_Madr, a2, n2);
-        wdt += n2;
+    // ---- B = M^-1 J^T per base row (skipped when every tree has a diagonal M: B_d = J_d / M_dd on the fly)
+    if (!DIAGM) {
+      for (int t = lane; t < 4 * nblk; t += 64) {
+        const int b = t >> 2, jb = t & 3;
+        const int* hd = s_blki_i + b * BLKI_STRIDE;
+        if (jb >= ((hd[0] >> 8) & 15)) { for (int k = 0; k < rowW; k++) s_B[(b * rowW + k) * 4 + jb] = 0; continue; }
+        ROW_TREES(hd[2], hd[3]);
+        const float* J = s_J + b * rowW * 4 + jb; float* B = s_B + b * rowW * 4 + jb;
+        for (int k = 0; k < rowW; k++) B[4*k] = J[4*k];
+        solve_tree<4>(B - 4*a1, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a1, n1);
+        if (n2 > 0) solve_tree<4>(B + 4*(n1 - a2), s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a2, n2);
       }
-      float d = rf[2];
-      for (int k = 0; k < wdt; k++) d += J[k] * B[k];
-      rf[3] = 1.0f / d;
+      WSYNC();
+    }
+    // ---- A_c = J_base M^-1 J_base^T, upper triangle (lanes = (block, base jb): row jb)
+    for (int t = lane; t < 4 * nblk; t += 64) {
+      const int b = t >> 2, jb = t & 3;
+      const int* hd = s_blki_i + b * BLKI_STRIDE;
+      const int nb = (hd[0] >> 8) & 15;
+      if (jb >= nb) continue;
+      ROW_TREES(hd[2], hd[3]);
+      float acc[4] = {0, 0, 0, 0};
+      for (int k = 0; k < n1 + n2; k++) {
+        const float4 jk = *(const float4*)(s_J + (b * rowW + k) * 4);
+        const float jv[4] = {jk.x, jk.y, jk.z, jk.w};
+        float bk;
+        if (DIAGM) bk = jv[jb] * s_qLDinv[k < n1 ? a1 + k : a2 + k - n1]; else bk = s_B[(b * rowW + k) * 4 + jb];
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[i] += jv[i] * bk;
+      }
+      float* A = s_blkf + b * BLKF_STRIDE + BF_A;
+#pragma unroll
+      for (int i = 0; i < 4; i++) if (i >= jb && i < nb) A[4*jb + i] = acc[i];
     }
     WSYNC();
-
     PROF(8);
-    // ================================================================ velocity stage (lambda: used by step1, inverse, step2-alone)
+
+    // dot products of every base row with a dof-space vector: out[4b+j] = J[b][.][j] . vec   (lanes = (block, base))
+    auto base_dots = [&](const float* vec, float* out) {
+      for (int t = lane; t < 4 * nblk; t += 64) {
+        const int b = t >> 2, jb = t & 3;
+        const int* hd = s_blki_i + b * BLKI_STRIDE;
+        ROW_TREES(hd[2], hd[3]);
+        const float* J = s_J + b * rowW * 4 + jb;
+        float v = 0;
+        for (int k = 0; k < n1; k++) v += J[4*k] * vec[a1 + k];
+        for (int k = 0; k < n2; k++) v += J[4*(n1 + k)] * vec[a2 + k];
+        out[t] = v;
+      }
+      WSYNC();
+    };
+    // out[d] = sum over blocks/bases of X[b][d][j] * phi[4b+j]   (lanes = dofs; X = J, or B = M^-1 J^T when useB)
+    auto accum_T = [&](bool useB, const float* phi, float* out) {
+      for (int d = lane; d < nv; d += 64) {
+        float acc = 0;
+        const float minv = s_qLDinv[d];
+        for (int b = 0; b < nblk; b++) {
+          const int4 hd = *(const int4*)(s_blki_i + b * BLKI_STRIDE);
+          ROW_TREES(hd.z, hd.w);
+          const int o = row_off(d, a1, n1, a2, n2);
+          if (o < 0) continue;
+          const float4 x = *(const float4*)(((useB && !DIAGM) ? s_B : s_J) + (b * rowW + o) * 4);
+          const float4 p = *(const float4*)(phi + 4*b);
+          acc += x.x*p.x + x.y*p.y + x.z*p.z + x.w*p.w;
+        }
+        out[d] = (useB && DIAGM) ? acc * minv : acc;
+      }
+      WSYNC();
+    };
+    // pyramid row r of a block: direction index k (1..3) and signed friction coefficient c
+#define PYR_KC(r, mu1, mu3, k, c) const int k = 1 + ((r) >> 1); const float c = (((r) & 1) ? -1.0f : 1.0f) * (k < 3 ? (mu1) : (mu3))
+    // per-row force response to jar = J a - aref  (mj_constraintUpdate, pyramidal cones), and base forces phi
+    auto forces_from = [&](const float* bv, bool keep) {
+      for (int b = lane; b < nblk; b += 64) {
+        const int* hd = s_blki_i + b * BLKI_STRIDE;
+        float* bf = s_blkf + b * BLKF_STRIDE;
+        const int kind = hd[0] & 15, nr = (hd[0] >> 4) & 15, clamp = (hd[0] >> 12) & 3, jadr = 4 * b;
+        const float R = bf[0], D = 1.0f / R, flv = bf[1], mu1 = bf[2], mu3 = bf[3];
+        float ph[4] = {0, 0, 0, 0};
+        for (int r = 0; r < nr; r++) {
+          PYR_KC(r, mu1, mu3, k, c);
+          const bool pyr = kind != BK_SINGLE;
+          const float jar = bv[jadr] + (pyr ? c * bv[jadr + k] : 0.0f) - bf[BF_AREF + r];
+          float f;
+          if (clamp == 0) f = -D * jar;
+          else if (clamp == 2) f = (jar <= -R*flv) ? flv : ((jar >= R*flv) ? -flv : -D * jar);
+          else f = jar < 0 ? -D * jar : 0.0f;
+          if (keep) bf[BF_F + r] = f;
+          ph[0] += f;
+          if (pyr) { if (k == 1) ph[1] += c * f; else if (k == 2) ph[2] += c * f; else ph[3] += c * f; }
+        }
+        for (int j = 0; j < 4; j++) s_phi[jadr + j] = ph[j];
+      }
+      WSYNC();
+    };
+    auto phi_from_forces = [&]() {
+      for (int b = lane; b < nblk; b += 64) {
+        const int* hd = s_blki_i + b * BLKI_STRIDE;
+        const float* bf = s_blkf + b * BLKF_STRIDE;
+        const int kind = hd[0] & 15, nr = (hd[0] >> 4) & 15, jadr = 4 * b;
+        float ph[4] = {0, 0, 0, 0};
+        for (int r = 0; r < nr; r++) {
+          PYR_KC(r, bf[2], bf[3], k, c);
+          const float f = bf[BF_F + r];
+          ph[0] += f;
+          if (kind != BK_SINGLE) { if (k == 1) ph[1] += c * f; else if (k == 2) ph[2] += c * f; else ph[3] += c * f; }
+        }
+        for (int j = 0; j < 4; j++) s_phi[jadr + j] = ph[j];
+      }
+      WSYNC();
+    };
+
+    // ================================================================ velocity stage (lambdas: used by step1, inverse, step2-alone)
     auto vel_levels = [&](const float* qv, const float* qa, float* out) {
       // mj_comVel + mj_rne forward/backward; qa != null adds cdof*qacc (flg_acc)
       if (lane == 0) { for (int k = 0; k < 6; k++) { s_cvel[k] = 0; s_cacc[k] = (k >= 3) ? -grav[k-3] : 0.0f; s_cfrc[k] = 0; } }
@@ -646,21 +780,25 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
             const float off[3] = {s_xipos[3*b] - com[0], s_xipos[3*b+1] - com[1], s_xipos[3*b+2] - com[2]};
             const float* cd = s_cdof + 6*d;
             float cr[3]; cross3(cr, cd, off);
-            const float sc = -body_mass[b] * body_gravcomp[b];
+            const float sc = -s_p_mass[b] * body_gravcomp[b];
             v += sc * ((cd[3] + cr[0]) * grav[0] + (cd[4] + cr[1]) * grav[1] + (cd[5] + cr[2]) * grav[2]);
           }
         }
         s_passive[d] = v;
       }
-      // mj_referenceConstraint: aref = -B (J qvel) - K imp (pos - margin)
-      for (int r = lane; r < nefc; r += 64) {
-        const int* hd = s_rowi_i + r * ROWI_STRIDE;
-        ROW_TREES(hd[2], hd[3]);
-        const float* J = s_J + r * M.rowW; float* rf = s_rowf + r * ROWF_STRIDE;
-        float vel = 0;
-        for (int k = 0; k < n1; k++) vel += J[k] * qv[a1 + k];
-        for (int k = 0; k < n2; k++) vel += J[n1 + k] * qv[a2 + k];
-        rf[4] = -rf[1] * vel - rf[0];
+      // mj_referenceConstraint: aref = -B (J qvel) - K imp (pos - margin), per row of every block
+      WSYNC();
+      base_dots(qv, s_bv);
+      for (int b = lane; b < nblk; b += 64) {
+        const int* hd = s_blki_i + b * BLKI_STRIDE;
+        float* bf = s_blkf + b * BLKF_STRIDE;
+        const int kind = hd[0] & 15, nr = (hd[0] >> 4) & 15, jadr = 4 * b;
+        const float KI = bf[BF_A + 4], Bc = bf[BF_A + 8];
+        for (int r = 0; r < nr; r++) {
+          PYR_KC(r, bf[2], bf[3], k, c);
+          const float vel = s_bv[jadr] + (kind != BK_SINGLE ? c * s_bv[jadr + k] : 0.0f);
+          bf[BF_AREF + r] = -Bc * vel - KI;
+        }
       }
       WSYNC();
     };
@@ -671,7 +809,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
       if ((xflags & XF_FORCE) && S.x_energy) {  // mj_energyPos / mj_energyVel
         float pe = 0, ke = 0;
         for (int b = lane; b < nbody; b += 64) if (b > 0) {
-          pe -= body_mass[b] * (grav[0]*s_xipos[3*b] + grav[1]*s_xipos[3*b+1] + grav[2]*s_xipos[3*b+2]);
+          pe -= s_p_mass[b] * (grav[0]*s_xipos[3*b] + grav[1]*s_xipos[3*b+1] + grav[2]*s_xipos[3*b+2]);
           float t[6]; mul_inert_vec(t, s_cinert + 10*b, s_cvel + 6*b);
           for (int q = 0; q < 6; q++) ke += 0.5f * t[q] * s_cvel[6*b+q];
         }
@@ -689,8 +827,8 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
       WSYNC();
       if (anydd) {  // tau = M ddq (mj_mulM, :1057)
         for (int i = lane; i < nv; i += 64) {
-          int adr = dof_Madr[i]; float vi = s_tmpv[i], acc = s_qM[adr] * vi; int k = 1;
-          for (int j = dof_parentid[i]; j >= 0; j = dof_parentid[j]) { float mij = s_qM[adr + k]; acc += mij * s_tmpv[j]; atomicAdd(&s_applied[j], mij * vi); k++; }
+          int adr = s_dofMadr_i[i]; float vi = s_tmpv[i], acc = s_qM[adr] * vi; int k = 1;
+          for (int j = s_dofpar_i[i]; j >= 0; j = s_dofpar_i[j]) { float mij = s_qM[adr + k]; acc += mij * s_tmpv[j]; atomicAdd(&s_applied[j], mij * vi); k++; }
           atomicAdd(&s_applied[i], acc);
         }
         WSYNC();
@@ -715,32 +853,9 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
     // ================================================================ inverse (mj_inverse, mj_hw_interface.cpp:61)
     if (ph & PH_INV) {
       // analytic constraint force at the current qacc (mj_constraintUpdate), qc = J^T f
-      for (int r = lane; r < nefc; r += 64) {
-        const int* hd = s_rowi_i + r * ROWI_STRIDE;
-        ROW_TREES(hd[2], hd[3]);
-        const float* J = s_J + r * M.rowW; float* rf = s_rowf + r * ROWF_STRIDE;
-        float jar = -rf[4];
-        for (int k = 0; k < n1; k++) jar += J[k] * s_qacc[a1 + k];
-        for (int k = 0; k < n2; k++) jar += J[n1 + k] * s_qacc[a2 + k];
-        const float D = 1.0f / rf[2], R = rf[2];
-        float f;
-        if ((hd[0] & 0xff) == MJH_CNSTR_EQUALITY) f = -D * jar;
-        else if ((hd[0] & 0xff) == MJH_CNSTR_FRICTION_DOF) { float fl = rf[7]; f = (jar <= -R*fl) ? fl : ((jar >= R*fl) ? -fl : -D * jar); }
-        else f = jar < 0 ? -D * jar : 0.0f;
-        rf[5] = f;
-      }
-      WSYNC();
-      for (int d = lane; d < nv; d += 64) {
-        float acc = 0;
-        for (int r = 0; r < nefc; r++) {
-          const int* hd = s_rowi_i + r * ROWI_STRIDE;
-          ROW_TREES(hd[2], hd[3]);
-          const int o = row_off(d, a1, n1, a2, n2);
-          if (o >= 0) acc += s_J[r * M.rowW + o] * s_rowf[r * ROWF_STRIDE + 5];
-        }
-        s_tmpv2[d] = acc;
-      }
-      WSYNC();
+      base_dots(s_qacc, s_bv);
+      forces_from(s_bv, false);
+      accum_T(false, s_phi, s_tmpv2);
       vel_levels(s_qvel, s_qacc, s_tmpv);  // RNE with acceleration
       for (int d = lane; d < nv; d += 64) S.qfrc_inverse[vrow + d] = s_tmpv[d] + dof_armature[d] * s_qacc[d] - s_passive[d] - s_tmpv2[d];
     }
@@ -751,7 +866,8 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
       // ---- smooth acceleration (mj_fwdAcceleration)
       for (int d = lane; d < nv; d += 64) { float f = s_passive[d] - s_bias[d] + s_applied[d]; s_smooth[d] = f; s_asmooth[d] = f; }
       WSYNC();
-      for (int t = lane; t < M.ntree; t += 64) solve_tree(s_asmooth, s_qLD, s_qLDinv, dof_parentid, dof_Madr, tree_dofadr[t], tree_dofnum[t]);
+      if (DIAGM) { for (int d = lane; d < nv; d += 64) s_asmooth[d] *= s_qLDinv[d]; }
+      else for (int t = lane; t < M.ntree; t += 64) solve_tree(s_asmooth, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t]);
       WSYNC();
       niter = 0;
       PROF(11);
@@ -759,132 +875,122 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
         for (int d = lane; d < nv; d += 64) { s_qacc[d] = s_asmooth[d]; s_ws[d] = s_asmooth[d]; s_tmpv2[d] = 0; }
         WSYNC();
       } else {
-        // ---- warm start (mj_fwdConstraint): forces implied by qacc_warmstart, kept if dual cost < 0
+        // ---- warm start (mj_fwdConstraint): forces implied by qacc_warmstart, kept if their dual cost < 0
         const bool warm = !(M.disableflags & MJH_DSBL_WARMSTART);
-        for (int r = lane; r < nefc; r += 64) {
-          float* rf = s_rowf + r * ROWF_STRIDE; float f = 0;
-          if (warm) {
-            const int* hd = s_rowi_i + r * ROWI_STRIDE;
-            ROW_TREES(hd[2], hd[3]);
-            const float* J = s_J + r * M.rowW;
-            float jar = -rf[4];
-            for (int k = 0; k < n1; k++) jar += J[k] * s_ws[a1 + k];
-            for (int k = 0; k < n2; k++) jar += J[n1 + k] * s_ws[a2 + k];
-            const float D = 1.0f / rf[2], R = rf[2];
-            if ((hd[0] & 0xff) == MJH_CNSTR_EQUALITY) f = -D * jar;
-            else if ((hd[0] & 0xff) == MJH_CNSTR_FRICTION_DOF) { float fl = rf[7]; f = (jar <= -R*fl) ? fl : ((jar >= R*fl) ? -fl : -D * jar); }
-            else f = jar < 0 ? -D * jar : 0.0f;
-          }
-          rf[5] = f;
-          rf[0] = 1.0f / rf[3];  // AR_ii: KI is dead once aref is known (rows are rebuilt every step)
-        }
-        WSYNC();
-        // da = sum_i B_i f_i  (lanes = dofs)
-        for (int d = lane; d < nv; d += 64) {
-          float acc = 0;
-          if (warm) for (int r = 0; r < nefc; r++) {
-            const int* hd = s_rowi_i + r * ROWI_STRIDE;
-            ROW_TREES(hd[2], hd[3]);
-            const int o = row_off(d, a1, n1, a2, n2);
-            if (o >= 0) acc += s_B[r * M.rowW + o] * s_rowf[r * ROWF_STRIDE + 5];
-          }
-          s_tmpv[d] = acc;
-        }
-        WSYNC();
+        bool zero_f = !warm;
         if (warm) {
+          base_dots(s_ws, s_bv);
+          forces_from(s_bv, true);
+          accum_T(true, s_phi, s_tmpv);               // da = M^-1 J^T f
+          base_dots(s_tmpv, s_bv);                    // J da
+          base_dots(s_asmooth, s_phi);                // J a_smooth  (phi is free again)
           float cost = 0;
-          for (int r = lane; r < nefc; r += 64) {
-            const int* hd = s_rowi_i + r * ROWI_STRIDE;
-            ROW_TREES(hd[2], hd[3]);
-            const float* J = s_J + r * M.rowW; const float* rf = s_rowf + r * ROWF_STRIDE;
-            float jda = 0, b = -rf[4];
-            for (int k = 0; k < n1; k++) { jda += J[k] * s_tmpv[a1 + k]; b += J[k] * s_asmooth[a1 + k]; }
-            for (int k = 0; k < n2; k++) { jda += J[n1 + k] * s_tmpv[a2 + k]; b += J[n1 + k] * s_asmooth[a2 + k]; }
-            const float f = rf[5];
-            cost += f * (0.5f * (jda + rf[2] * f) + b);
+          for (int b = lane; b < nblk; b += 64) {
+            const int* hd = s_blki_i + b * BLKI_STRIDE;
+            const float* bf = s_blkf + b * BLKF_STRIDE;
+            const int kind = hd[0] & 15, nr = (hd[0] >> 4) & 15, jadr = 4 * b;
+            for (int r = 0; r < nr; r++) {
+              PYR_KC(r, bf[2], bf[3], k, c);
+              const bool pyr = kind != BK_SINGLE;
+              const float jda = s_bv[jadr] + (pyr ? c * s_bv[jadr + k] : 0.0f);
+              const float bb = s_phi[jadr] + (pyr ? c * s_phi[jadr + k] : 0.0f) - bf[BF_AREF + r];
+              const float f = bf[BF_F + r];
+              cost += f * (0.5f * (jda + bf[0] * f) + bb);
+            }
           }
           cost = wave_sum<4>(cost);
-          if (cost > 0) {
-            for (int r = lane; r < nefc; r += 64) s_rowf[r * ROWF_STRIDE + 5] = 0;
-            for (int d = lane; d < nv; d += 64) s_tmpv[d] = 0;
-          }
-          WSYNC();
+          zero_f = cost > 0;
         }
+        if (zero_f) {
+          for (int b = lane; b < nblk; b += 64) { float* bf = s_blkf + b * BLKF_STRIDE; for (int r = 0; r < 6; r++) bf[BF_F + r] = 0; }
+          for (int d = lane; d < nv; d += 64) s_tmpv[d] = 0;
+        }
+        WSYNC();
         PROF(12);
-        // ---- PGS (mj_solPGS) in matrix-free form: lanes = dofs, running acceleration a in registers.
-        //      row i:  res = J_i.a - aref_i + R_i f_i ;  f_i <- clamp(f_i - res/AR_ii) ;  a += B_i * delta
-        // TODO(perf, next round): nv > 64 needs several dofs per lane
+        // ---- PGS (mj_solPGS), matrix-free, one block at a time.  lanes = dofs, running acceleration `a` in a
+        //      register.  Per block: u = J_base.a (nbase wave reductions, interleaved); its 2(dim-1) pyramid rows
+        //      are then updated with uniform scalar math in contact space:
+        //        res_r = e_r.u - aref_r + R f_r ;  f_r <- max(0, f_r - res_r/AR_rr) ;  u += A_c e_r delta
+        //      and `a` is touched once per block:  a += B_base^T dphi.
+        // TODO(perf): nv > 64 needs several dofs per lane
         const int d0 = lane;
         float a = (d0 < nv) ? s_asmooth[d0] + s_tmpv[d0] : 0.0f;
+        const float minv0 = (d0 < nv) ? s_qLDinv[d0] : 0.0f;
         const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
-        const int rowW = M.rowW;
-        // forces live in registers: lane l holds f of rows l, 64+l, 128+l, 192+l (maxefc <= 256);
-        // nothing is stored to LDS inside the sweep, so next-row operands can be fetched early
-        float fr[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) fr[c] = (64*c + lane < nefc) ? s_rowf[(64*c + lane) * ROWF_STRIDE + 5] : 0.0f;
-        struct RowOp { float Jd, Bd, aref, R, AR, ARinv, lo, hi; };
-        auto fetch = [&](int r) {
-          RowOp op;
-          const int4 hd = *(const int4*)(s_rowi_i + r * ROWI_STRIDE);
-          const float4 ra = *(const float4*)(s_rowf + r * ROWF_STRIDE);      // KI, Bc, R, ARinv
-          const float4 rb = *(const float4*)(s_rowf + r * ROWF_STRIDE + 4);  // aref, f, lo, hi
+        const float4* blkf4 = (const float4*)s_blkf;
+        const int4* blki4 = (const int4*)s_blki_i;
+        const float4* J4 = (const float4*)s_J;
+        const float4* B4 = (const float4*)s_B;
+        // operands of one block: 1 header + 1 (2) Jacobian + 8 parameter ds_read_b128 per lane
+        struct BlkOp { int hx; float4 J, B, P, r0, r1, r2, A0, A1, A2, A3; };
+        auto fetch = [&](int b) {
+          BlkOp op;
+          const int4 hd = blki4[b];
           ROW_TREES(hd.z, hd.w);
           const int o = row_off(d0, a1, n1, a2, n2);
-          const int oc = r * rowW + max(o, 0);
-          const float jv = s_J[oc], bv = s_B[oc];
-          op.Jd = o >= 0 ? jv : 0.0f; op.Bd = o >= 0 ? bv : 0.0f;
-          op.aref = rb.x; op.R = ra.z; op.AR = ra.x; op.ARinv = ra.w; op.lo = rb.z; op.hi = rb.w;
+          const int ja = b * rowW + max(o, 0);
+          const float msk = o >= 0 ? 1.0f : 0.0f;
+          float4 jv = J4[ja];
+          jv.x *= msk; jv.y *= msk; jv.z *= msk; jv.w *= msk;
+          op.J = jv;
+          if (DIAGM) { op.B.x = jv.x * minv0; op.B.y = jv.y * minv0; op.B.z = jv.z * minv0; op.B.w = jv.w * minv0; }
+          else { float4 bv4 = B4[ja]; bv4.x *= msk; bv4.y *= msk; bv4.z *= msk; bv4.w *= msk; op.B = bv4; }
+          op.P = blkf4[8*b]; op.r0 = blkf4[8*b+1]; op.r1 = blkf4[8*b+2]; op.r2 = blkf4[8*b+3];
+          op.A0 = blkf4[8*b+4]; op.A1 = blkf4[8*b+5]; op.A2 = blkf4[8*b+6]; op.A3 = blkf4[8*b+7];
+          op.hx = hd.x;
           return op;
+        };
+        auto process = [&](BlkOp& op, int b, float& improvement) {
+          const int kind = __builtin_amdgcn_readfirstlane(op.hx & 15);
+          float f[6] = {op.r1.z, op.r1.w, op.r2.x, op.r2.y, op.r2.z, op.r2.w};
+          const float aref[6] = {op.r0.x, op.r0.y, op.r0.z, op.r0.w, op.r1.x, op.r1.y};
+          const float A[16] = {op.A0.x, op.A0.y, op.A0.z, op.A0.w, op.A1.x, op.A1.y, op.A1.z, op.A1.w,
+                               op.A2.x, op.A2.y, op.A2.z, op.A2.w, op.A3.x, op.A3.y, op.A3.z, op.A3.w};
+          const float P[4] = {op.P.x, op.P.y, op.P.z, op.P.w};
+          const float Jd[4] = {op.J.x, op.J.y, op.J.z, op.J.w}, Bd[4] = {op.B.x, op.B.y, op.B.z, op.B.w};
+          if (kind == BK_PYR4) pgs_pyramid<4, 6, NROW>(P, aref, f, A, Jd, Bd, a, improvement);
+          else if (kind == BK_PYR3) pgs_pyramid<3, 4, NROW>(P, aref, f, A, Jd, Bd, a, improvement);
+          else {
+            const int clamp = __builtin_amdgcn_readfirstlane((op.hx >> 12) & 3);
+            const float u0 = wave_sum<NROW>(Jd[0] * a);
+            const float R = P[0], AR = A[0] + R, ARinv = __builtin_amdgcn_rcpf(AR), fold = f[0];
+            const float res = u0 - aref[0] + R * fold;
+            float fn = fold - res * ARinv;
+            if (clamp == 1) fn = fmaxf(0.0f, fn); else if (clamp == 2) fn = fminf(P[1], fmaxf(-P[1], fn));
+            float delta = fn - fold;
+            const float change = delta * (0.5f * delta * AR + res);
+            if (change > 1e-10f) { fn = fold; delta = 0; } else improvement -= change;
+            a += Bd[0] * delta;
+            f[0] = fn;
+          }
+          if (lane == 0) {
+            float* bf = s_blkf + b * BLKF_STRIDE + BF_F;
+            *(float2*)(bf) = make_float2(f[0], f[1]);
+            *(float4*)(bf + 2) = make_float4(f[2], f[3], f[4], f[5]);
+          }
         };
         for (int it = 0; it < M.iterations; it++) {
           float improvement = 0;
-          RowOp cur = fetch(0);
-#pragma unroll
-          for (int c = 0; c < 4; c++) {
-            if (64*c >= nefc) break;
-            const int nr = min(64, nefc - 64*c);
-            float fc = fr[c];
-            for (int rr = 0; rr < nr; rr++) {
-              const int r = 64*c + rr;
-              const RowOp nxt = fetch(r + 1 < nefc ? r + 1 : 0);
-              float s = cur.Jd * a;
-              s = wave_sum<NROW>(s);
-              const float fold = readlane_f(fc, rr);
-              const float res = s - cur.aref + cur.R * fold;
-              float f = fminf(cur.hi, fmaxf(cur.lo, fold - res * cur.ARinv));
-              float delta = f - fold;
-              const float change = delta * (0.5f * delta * cur.AR + res);
-              if (change > 1e-10f) { f = fold; delta = 0; } else improvement -= change;
-              a += cur.Bd * delta;
-              fc = (lane == rr) ? f : fc;
-              cur = nxt;
+          // two operand buffers in ping-pong: the next block's LDS reads are in flight while this one is solved
+          BlkOp opA = fetch(0), opB;
+          for (int b = 0; b < nblk; b += 2) {
+            opB = fetch(b + 1 < nblk ? b + 1 : b);
+            process(opA, b, improvement);
+            if (b + 1 < nblk) {
+              opA = fetch(b + 2 < nblk ? b + 2 : b + 1);
+              process(opB, b + 1, improvement);
             }
-            fr[c] = fc;
           }
           niter = it + 1;
           if (improvement * scale < M.tolerance) break;
+          WSYNC();   // the next sweep re-reads the forces from LDS
         }
-#pragma unroll
-        for (int c = 0; c < 4; c++) if (64*c + lane < nefc) s_rowf[(64*c + lane) * ROWF_STRIDE + 5] = fr[c];
-        PROF(13);
         WSYNC();
         if (d0 < nv) { s_qacc[d0] = a; s_ws[d0] = a; }
+        PROF(13);
         WSYNC();
         // qfrc_constraint = J^T f (only needed by the implicit-damping integrator and for export)
-        if (M.has_damping || (xflags & XF_FORCE)) {
-          for (int d = lane; d < nv; d += 64) {
-            float acc = 0;
-            for (int r = 0; r < nefc; r++) {
-              const int* hd = s_rowi_i + r * ROWI_STRIDE;
-              ROW_TREES(hd[2], hd[3]);
-              const int o = row_off(d, a1, n1, a2, n2);
-              if (o >= 0) acc += s_J[r * M.rowW + o] * s_rowf[r * ROWF_STRIDE + 5];
-            }
-            s_tmpv2[d] = acc;
-          }
-          WSYNC();
-        }
+        if (M.has_damping || (xflags & XF_FORCE)) { phi_from_forces(); accum_T(false, s_phi, s_tmpv2); }
       }
       if (xflags & XF_FORCE) {
         const size_t e = (size_t)blockIdx.x * M.nvp;
@@ -906,11 +1012,11 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
           for (int i = lane; i < M.nM; i += 64) s_qLD[i] = s_qM[i];
           for (int d = lane; d < nv; d += 64) s_tmpv[d] = s_smooth[d] + s_tmpv2[d];
           WSYNC();
-          for (int d = lane; d < nv; d += 64) s_qLD[dof_Madr[d]] += h * dof_damping[d];
+          for (int d = lane; d < nv; d += 64) s_qLD[s_dofMadr_i[d]] += h * dof_damping[d];
           WSYNC();
           for (int t = lane; t < M.ntree; t += 64) {
-            factor_tree(s_qLD, s_qLDinv, dof_parentid, dof_Madr, tree_dofadr[t], tree_dofnum[t]);
-            solve_tree(s_tmpv, s_qLD, s_qLDinv, dof_parentid, dof_Madr, tree_dofadr[t], tree_dofnum[t]);
+            factor_tree(s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t]);
+            solve_tree(s_tmpv, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t]);
           }
           WSYNC();
           qint = s_tmpv;
