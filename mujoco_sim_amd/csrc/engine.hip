@@ -190,13 +190,19 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     L.qvel = put(nv); L.qvref = put(nv); L.ws = put(nv); L.qacc = put(nv); L.smooth = put(nv); L.asmooth = put(nv); L.passive = put(nv);
     L.bias = put(nv); L.applied = put(nv); L.tmpv = put(nv); L.tmpv2 = put(nv);
     L.xpos = put(3*nb); L.xquat = put(4*nb); L.xmat = put(9*nb); L.xipos = put(3*nb); L.ximat = put(9*nb); L.com = put(3*nb);
-    L.cinert = put(10*nb); L.crb = put(10*nb); L.cvel = put(6*nb); L.cacc = put(6*nb); L.cfrc = put(6*nb); L.cfrcsub = put(6*nb);
-    L.xanchor = put(3*nj); L.xaxis = put(3*nj); L.cdof = put(6*nv); L.cdofdot = put(6*nv);
-    L.qM = put(m->nM); L.qLD = put(m->nM); L.qLDinv = put(nv);
+    L.cinert = put(10*nb); L.crb = put(10*nb);
+    L.xanchor = put(3*nj); L.xaxis = put(3*nj); L.cdof = put(6*nv);
+    L.qM = put(m->nM); L.qLD = diagM ? L.qM : put(m->nM); L.qLDinv = put(nv);   // diagonal M: no factor storage
     L.gpos = put(3*ng); L.gmat = put(9*ng);
     L.dofpar = put(nv); L.dofMadr = put(nv);
     L.p_gsize = put(3*ng); L.p_rbound = put(ng); L.p_mass = put(nb); L.p_inertia = put(3*nb); L.p_binv = put(2*nb); L.p_dinv = put(nv);
-    L.con = put(M.maxcon * CON_STRIDE); L.blki = put(nblkcap * BLKI_STRIDE); L.blkf = put(nblkcap * BLKF_STRIDE);
+    {  // the contact records die once the blocks are built; the velocity-stage spatial vectors reuse their space
+      const int a4 = [](int n) { return ((std::max(n, 1) + 3) / 4) * 4; }(6*nb);
+      const int velsz = 4 * a4 + ((6*nv + 3) / 4) * 4;
+      L.con = put(std::max(M.maxcon * CON_STRIDE, velsz));
+      L.cvel = L.con; L.cacc = L.con + a4; L.cfrc = L.con + 2*a4; L.cfrcsub = L.con + 3*a4; L.cdofdot = L.con + 4*a4;
+    }
+    L.blki = put(nblkcap * BLKI_STRIDE); L.blkf = put(nblkcap * BLKF_STRIDE);
     L.bv = put(nblkcap * 4); L.phi = put(nblkcap * 4);
     L.J = put(jsz); L.B = diagM ? L.J : put(jsz);
     L.total = off;

@@ -74,8 +74,9 @@ extern "C" mjh_model* mjh_scene_s24(void) {
     std::snprintf(name, sizeof name, "box%d_geom", k);
     mjh_builder_add_geom(b, name, body, MJH_GEOM_BOX, sz, nullptr, nullptr, nullptr, -1, -1, -1, -1);
   }
-  // capacity: 4 boxes x 4 floor points (6 rows) + box-box / box-wall manifolds (4 rows)
-  mjh_builder_set_capacity(b, 48, 16 * 6 + 32 * 4);
+  // capacity: measured over 4096 envs x 1400 steps the pile never exceeds 30 contacts / 128 rows
+  // (tools/ncon_hist.py); overflow drops the excess contacts and raises the per-env flag
+  mjh_builder_set_capacity(b, 32, 32 * 6);
   mjh_model* m = mjh_builder_compile(b);
   mjh_builder_destroy(b);
   return m;

@@ -85,22 +85,24 @@ DEV void pgs_pyramid(const float* P, const float* aref, float* f, const float* A
   wave_sum4<NROW, NB>(u);
 #pragma unroll
   for (int j = 0; j < NB; j++) dphi[j] = 0;
-  const float R = P[0];
+  const float R = P[0], t0 = A[0] + R;
 #pragma unroll
   for (int r = 0; r < NR; r++) {
     const int k = 1 + (r >> 1);
-    const float c = ((r & 1) ? -1.0f : 1.0f) * (k < 3 ? P[2] : P[3]);
-    const float AR = A[0] + c * (2.0f * A[k] + c * A[4*k + k]) + R;
+    const bool neg = r & 1;
+    // AR_rr = A_nn +- 2 A_nk + A_kk + R   (friction bases are pre-scaled by mu_k)
+    const float AR = neg ? (t0 + A[4*k + k]) - 2.0f * A[k] : (t0 + A[4*k + k]) + 2.0f * A[k];
     const float ARinv = __builtin_amdgcn_rcpf(AR);
     const float fold = f[r];
-    const float res = u[0] + c * u[k] - aref[r] + R * fold;
-    float fn = fmaxf(0.0f, fold - res * ARinv);
-    float delta = fn - fold;
-    const float change = delta * (0.5f * delta * AR + res);
-    if (change > 1e-10f) { fn = fold; delta = 0; } else improvement -= change;
+    const float res = (neg ? u[0] - u[k] : u[0] + u[k]) - aref[r] + R * fold;
+    const float fn = fmaxf(0.0f, fold - res * ARinv);
+    const float delta = fn - fold;
+    // cost change delta*(res + delta*AR/2) <= 0 for every projected scalar update, so the
+    // reference's "revert if the cost went up" guard is dead code for pyramidal rows and is not evaluated here
+    improvement -= delta * (res + 0.5f * AR * delta);
 #pragma unroll
-    for (int j = 0; j < NB; j++) u[j] += (A_SYM(A, j, 0) + c * A_SYM(A, j, k)) * delta;
-    dphi[0] += delta; dphi[k] += c * delta;
+    for (int j = 0; j < NB; j++) u[j] += (neg ? A_SYM(A, j, 0) - A_SYM(A, j, k) : A_SYM(A, j, 0) + A_SYM(A, j, k)) * delta;
+    dphi[0] += delta; dphi[k] += neg ? -delta : delta;
     f[r] = fn;
   }
 #pragma unroll
@@ -108,7 +110,7 @@ DEV void pgs_pyramid(const float* P, const float* aref, float* f, const float* A
 }
 
 template <int NROW, bool DIAGM>
-__global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DState S, const Lay L, int env0, int nsteps, int ph, int xflags) {
+__global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DModel M, const DState S, const Lay L, int env0, int nsteps, int ph, int xflags) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x;
   const int env = env0 + blockIdx.x;
@@ -499,9 +501,11 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
         if (t1 < 0) { t1 = t2; t2 = -1; }
         if (t2 == t1) t2 = -1;
         const float* dir = c + 4 + 3 * (jb < 3 ? jb : 0);   // base 0..2: translation along n,t1,t2 ; base 3: rotation about n
+        // friction bases carry their coefficient (J_k <- mu_k J_k), so every pyramid row is simply J_n +- J_k
+        const float musc = jb == 0 ? 1.0f : (jb < 3 ? fmaxf(geom_friction[3*g1], geom_friction[3*g2]) : fmaxf(geom_friction[3*g1+1], geom_friction[3*g2+1]));
 #pragma unroll
         for (int sd = 0; sd < 2; sd++) {
-          const int bd = sd ? b2 : b1; const float ss = sd ? 1.0f : -1.0f;
+          const int bd = sd ? b2 : b1; const float ss = (sd ? 1.0f : -1.0f) * musc;
           int i = body_lastdof[bd];
           if (i < 0) continue;
           const float* com = s_com + 3*body_rootid[bd];
@@ -651,7 +655,7 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
       WSYNC();
     };
     // pyramid row r of a block: direction index k (1..3) and signed friction coefficient c
-#define PYR_KC(r, mu1, mu3, k, c) const int k = 1 + ((r) >> 1); const float c = (((r) & 1) ? -1.0f : 1.0f) * (k < 3 ? (mu1) : (mu3))
+#define PYR_KC(r, mu1, mu3, k, c) const int k = 1 + ((r) >> 1); const float c = ((r) & 1) ? -1.0f : 1.0f
     // per-row force response to jar = J a - aref  (mj_constraintUpdate, pyramidal cones), and base forces phi
     auto forces_from = [&](const float* bv, bool keep) {
       for (int b = lane; b < nblk; b += 64) {
@@ -957,9 +961,8 @@ __global__ __launch_bounds__(64) void mjh_step_kernel(const DModel M, const DSta
             const float res = u0 - aref[0] + R * fold;
             float fn = fold - res * ARinv;
             if (clamp == 1) fn = fmaxf(0.0f, fn); else if (clamp == 2) fn = fminf(P[1], fmaxf(-P[1], fn));
-            float delta = fn - fold;
-            const float change = delta * (0.5f * delta * AR + res);
-            if (change > 1e-10f) { fn = fold; delta = 0; } else improvement -= change;
+            const float delta = fn - fold;
+            improvement -= delta * (res + 0.5f * AR * delta);
             a += Bd[0] * delta;
             f[0] = fn;
           }
