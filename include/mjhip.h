@@ -247,6 +247,12 @@ int mjh_state_stride(const mjh_engine*);
 /* debug: mean shader-clock ticks from kernel start to each of the 16 stage boundaries of one fused step */
 int mjh_debug_stage_cycles(mjh_engine*, int with_inverse, double* out16);
 
+/* ROS-free harness of the host loop (csrc/host_sim.cpp: simulate() + MjhHWInterface, mirrors of
+ * mj_main.cpp:76-164 and mj_hw_interface.cpp:59-110) with an in-process PD effort controller on
+ * every hinge/slide joint of env `env`; returns final joint positions / efforts and the real-time factor */
+int mjh_host_run_pd(mjh_engine*, int env, const double* target, double kp, double kd, long nsteps,
+                    double* out_qpos, double* out_effort, double* out_rtf);
+
 /* introspection */
 int mjh_nenv(const mjh_engine*);
 const mjh_model* mjh_engine_model(const mjh_engine*);

@@ -1,0 +1,141 @@
+// host_sim.cpp — see host_sim.h.  Host C++ only; every physics call goes through the C ABI.
+#include "host_sim.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <thread>
+
+static const double kMinVal = 1e-15;  // mjMINVAL (mj_hw_interface.cpp:81, mj_sim.cpp:1069)
+
+int MjhSim::sync_controlled() {
+  std::vector<int> mask(model->nv > 0 ? model->nv : 1, 0);
+  for (const std::string& j : controlled_joints) {
+    const int id = mjh_name2id(model, 1, j.c_str());
+    if (id < 0) continue;
+    mask[model->jnt_dofadr[id]] = 1;  // hinge / slide joints: one dof (the reference indexes jnt_dofadr the same way)
+  }
+  return mjh_set_controlled_dofs(engine, mask.data());
+}
+
+int MjhSim::sync_odom(const std::string& robot) {
+  static const char* lin[3] = {"_lin_odom_x_joint", "_lin_odom_y_joint", "_lin_odom_z_joint"};
+  static const char* ang[3] = {"_ang_odom_x_joint", "_ang_odom_y_joint", "_ang_odom_z_joint"};
+  int l[3], a[3], aq[3];
+  for (int k = 0; k < 3; k++) {
+    const int jl = mjh_name2id(model, 1, (robot + lin[k]).c_str()), ja = mjh_name2id(model, 1, (robot + ang[k]).c_str());
+    l[k] = jl >= 0 ? model->jnt_dofadr[jl] : -1;
+    a[k] = ja >= 0 ? model->jnt_dofadr[ja] : -1;
+    aq[k] = ja >= 0 ? model->jnt_qposadr[ja] : -1;
+  }
+  return mjh_set_odom_dofs(engine, l, a, aq);
+}
+
+int MjhSim::push_odom_vels(const std::string& robot) {
+  static const char* names[6] = {"_lin_odom_x_joint", "_lin_odom_y_joint", "_lin_odom_z_joint",
+                                 "_ang_odom_x_joint", "_ang_odom_y_joint", "_ang_odom_z_joint"};
+  double twist[6];
+  for (int k = 0; k < 6; k++) { auto it = odom_vels.find(robot + names[k]); twist[k] = it == odom_vels.end() ? 0.0 : it->second; }
+  return mjh_set_odom_vel(engine, env, 1, twist);
+}
+
+MjhHWInterface::MjhHWInterface(MjhSim* sim, const std::string& robot) : sim_(sim) {
+  joint_names = sim->joint_names[robot];
+  const size_t n = joint_names.size();
+  joint_positions.assign(n, 0.0); joint_velocities.assign(n, 0.0); joint_efforts.assign(n, 0.0);
+  joint_velocities_command.assign(n, 0.0); joint_efforts_command.assign(n, 0.0);
+  for (const std::string& j : joint_names) {  // resolved once; the reference calls mj_name2id per joint per step
+    const int id = mjh_name2id(sim->model, 1, j.c_str());
+    qpos_id_.push_back(id >= 0 ? sim->model->jnt_qposadr[id] : -1);
+    dof_id_.push_back(id >= 0 ? sim->model->jnt_dofadr[id] : -1);
+  }
+  qpos_.assign(sim->model->nq, 0.0); qvel_.assign(sim->model->nv, 0.0); qfrc_.assign(sim->model->nv, 0.0);
+  ddq_.assign(sim->model->nv, 0.0); dq_.assign(sim->model->nv, 0.0);
+}
+
+void MjhHWInterface::read() {
+  mjh_inverse(sim_->engine);
+  mjh_get_joint_state(sim_->engine, sim_->env, 1, qpos_.data(), qvel_.data(), qfrc_.data());
+  for (size_t i = 0; i < joint_names.size(); i++) {
+    if (dof_id_[i] < 0) continue;
+    joint_positions[i] = qpos_[qpos_id_[i]];
+    joint_velocities[i] = qvel_[dof_id_[i]];
+    joint_efforts[i] = qfrc_[dof_id_[i]];
+  }
+}
+
+void MjhHWInterface::write() {
+  std::fill(ddq_.begin(), ddq_.end(), 0.0); std::fill(dq_.begin(), dq_.end(), 0.0);
+  for (size_t i = 0; i < joint_names.size(); i++) {
+    if (dof_id_[i] < 0 || sim_->controlled_joints.find(joint_names[i]) == sim_->controlled_joints.end()) continue;
+    if (std::fabs(joint_velocities_command[i]) > kMinVal) dq_[dof_id_[i]] = joint_velocities_command[i];
+    else ddq_[dof_id_[i]] = joint_efforts_command[i];
+  }
+  mjh_set_cmd(sim_->engine, sim_->env, 1, ddq_.data(), dq_.data());
+}
+
+void MjhHWInterface::doSwitch(const std::vector<std::string>& stopped) {
+  for (const std::string& name : stopped)
+    for (size_t i = 0; i < joint_names.size(); i++) if (joint_names[i] == name) joint_efforts_command[i] = 0.0;
+}
+
+SimulateStats simulate(MjhSim* sim, std::vector<MjhHWInterface*>& hw, const std::function<void(double, double)>& update,
+                       long nsteps, bool real_time) {
+  using clk = std::chrono::steady_clock;
+  SimulateStats st;
+  const double dt = sim->model->opt.timestep;
+  double sim_time = 0, last_sim_time = 0;
+  const auto t0 = clk::now();
+  std::deque<double> win_sim, win_wall;
+  const size_t num_step = (size_t)std::ceil(1.0 / dt);
+  for (long s = 0; s < nsteps; s++) {
+    const double sim_period = sim_time - last_sim_time;
+    mjh_step1(sim->engine);                                  // mj_main.cpp:83 (+ controller callback :49-52)
+    if (sim_period >= 1.0 / 10000.0 || s == 0) {             // :85 controller update at <= 10 kHz
+      last_sim_time = sim_time;
+      for (MjhHWInterface* h : hw) h->read();                // :93
+      if (update) update(sim_time, sim_period);              // :99 controller_manager->update
+    }
+    for (MjhHWInterface* h : hw) h->write();                 // :105
+    mjh_step2(sim->engine);                                  // :108, set_odom_vels :110 runs inside
+    sim_time += dt;
+    const double wall = std::chrono::duration<double>(clk::now() - t0).count();
+    if (real_time) {                                         // :127-131 spin until wall-clock >= sim-time
+      while (std::chrono::duration<double>(clk::now() - t0).count() - sim_time < -1e-6) std::this_thread::yield();
+    }
+    win_sim.push_front(sim_time); win_wall.push_front(wall);  // :115-147 real-time factor over a sliding 1 s window
+    if (win_sim.size() > num_step) { st.rtf = (sim_time - win_sim.back()) / (wall - win_wall.back() + 1e-12); win_sim.pop_back(); win_wall.pop_back(); }
+  }
+  mjh_synchronize(sim->engine);
+  st.sim_time = sim_time; st.steps = nsteps;
+  st.wall_time = std::chrono::duration<double>(clk::now() - t0).count();
+  if (st.rtf == 0 && st.wall_time > 0) st.rtf = sim_time / st.wall_time;
+  return st;
+}
+
+// ---- C shim used by the tests: runs simulate() with an in-process PD "effort controller"
+// (ros_control PID with i = 0: p 200, d 50 in model/ontology/box/box.yaml:5-13) on every joint of the model.
+extern "C" int mjh_host_run_pd(mjh_engine* engine, int env, const double* target, double kp, double kd, long nsteps,
+                               double* out_qpos, double* out_effort, double* out_rtf) {
+  if (!engine) return MJH_ERR_ARG;
+  const mjh_model* m = mjh_engine_model(engine);
+  MjhSim sim; sim.engine = engine; sim.model = m; sim.env = env;
+  std::vector<std::string> names;
+  for (int j = 0; j < m->njnt; j++) if (m->jnt_type[j] == MJH_JNT_HINGE || m->jnt_type[j] == MJH_JNT_SLIDE) names.push_back(m->jnt_names[j]);
+  sim.joint_names["robot"] = names; sim.robot_names.insert("robot");
+  for (const std::string& n : names) sim.controlled_joints.insert(n);
+  int rc = sim.sync_controlled();
+  if (rc) return rc;
+  MjhHWInterface hwi(&sim, "robot");
+  std::vector<MjhHWInterface*> hw{&hwi};
+  auto update = [&](double, double) {
+    for (size_t i = 0; i < names.size(); i++)
+      hwi.joint_efforts_command[i] = kp * (target[i] - hwi.joint_positions[i]) - kd * hwi.joint_velocities[i];
+  };
+  SimulateStats st = simulate(&sim, hw, update, nsteps, false);
+  hwi.read();
+  for (size_t i = 0; i < names.size(); i++) { if (out_qpos) out_qpos[i] = hwi.joint_positions[i]; if (out_effort) out_effort[i] = hwi.joint_efforts[i]; }
+  if (out_rtf) *out_rtf = st.rtf;
+  return MJH_OK;
+}

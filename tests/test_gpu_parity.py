@@ -175,6 +175,28 @@ def test_arm7_c3_controller_inverse_limits():
     e.close()
 
 
+def test_host_cpp_simulate_loop_matches_python_loop():
+    """csrc/host_sim.cpp: simulate() + MjhHWInterface (C++ mirrors of mj_main.cpp:76-164 / mj_hw_interface.cpp)
+    drive the split step1 / inverse / step2 API; same closed loop as the Python loop above and the oracle"""
+    import ctypes as C
+
+    from mujoco_sim_amd import capi
+
+    g = np.load(os.path.join(G, "arm7_golden.npz"))
+    m = ms.scene("arm7", 1)
+    e = ms.Engine(m, 2)
+    e.set_initial_qpos(np.tile(g["q0"], (2, 1))); e.reset()
+    q = np.zeros(7); f = np.zeros(7); rtf = C.c_double(0)
+    tgt = np.ascontiguousarray(g["target"], dtype=np.float64)
+    rc = capi.load().mjh_host_run_pd(e.h, 0, capi.dptr(tgt), 200.0, 50.0, 300, capi.dptr(q), capi.dptr(f), C.byref(rtf))
+    assert rc == 0
+    # the reference loop reads (mj_inverse) BEFORE the controller update of the same step, i.e. exactly the
+    # sequence of tests/golden/make_golden.py::arm7
+    np.testing.assert_allclose(q, g["step300_qpos"], atol=2e-3)
+    assert rtf.value > 0
+    e.close()
+
+
 def test_velocity_command_override_and_limits():
     m = ms.scene("arm7", 1)
     e = ms.Engine(m, 1)
