@@ -36,7 +36,10 @@ def s24():
 def test_s24_stage_parity_after_forward(s24):
     m, e, tab, ds = s24
     e.reset(); [d.call("reset") for d in ds]
-    e.step(60); [d.step(60) for d in ds]        # get some contacts first
+    [d.step(60) for d in ds]                    # get some contacts first
+    # stage parity is measured from IDENTICAL states: load the oracle's step-60 state into the engine
+    e.set_state(qpos=np.array([d.f("qpos") for d in ds]), qvel=np.array([d.f("qvel") for d in ds]),
+                time=np.array([d.f("time")[0] for d in ds]), warmstart=np.array([d.f("qacc_warmstart") for d in ds]))
     e.forward(); e.synchronize()
     for d in ds:
         d.call("forward")
