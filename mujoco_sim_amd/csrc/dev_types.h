@@ -63,6 +63,8 @@ struct Lay {
   int total;  // floats
 };
 
+struct DConst { DModel M; Lay L; };
+
 // kernel phases
 enum { PH_STEP1 = 1, PH_INV = 2, PH_STEP2 = 4, PH_NOINT = 8, PH_FKONLY = 16, PH_MULM = 32, PH_RESET = 64 };
 // export flags

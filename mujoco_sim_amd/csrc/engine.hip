@@ -32,7 +32,7 @@ struct mjh_engine {
   DState S{};
   Lay L{};
   int lds_bytes = 0;
-  int* dI = nullptr; float* dF = nullptr;
+  int* dI = nullptr; float* dF = nullptr; DConst* dC = nullptr;
   std::vector<int> hI;  // host copy of the int tables (controlled / odom are patched in place)
   int o_controlled = 0, o_odom = 0;
   std::vector<void*> allocs;
@@ -62,7 +62,7 @@ static int ensure_scratch(mjh_engine* e, size_t floats) {
 
 static int launch(mjh_engine* e, int env0, int n, int nsteps, int ph, int xflags) {
   if (n <= 0) return MJH_OK;
-#define MJH_LAUNCH(NR, DG) hipLaunchKernelGGL((mjh_step_kernel<NR, DG>), dim3(n), dim3(64), (size_t)e->lds_bytes, e->stream, e->M, e->S, e->L, env0, nsteps, ph, xflags)
+#define MJH_LAUNCH(NR, DG) hipLaunchKernelGGL((mjh_step_kernel<NR, DG>), dim3(n), dim3(64), (size_t)e->lds_bytes, e->stream, e->dC, e->S, env0, nsteps, ph, xflags)
   const int nr = e->M.nv <= 16 ? 1 : (e->M.nv <= 32 ? 2 : 4);
   if (e->M.diagM) { if (nr == 1) MJH_LAUNCH(1, true); else if (nr == 2) MJH_LAUNCH(2, true); else MJH_LAUNCH(4, true); }
   else { if (nr == 1) MJH_LAUNCH(1, false); else if (nr == 2) MJH_LAUNCH(2, false); else MJH_LAUNCH(4, false); }
@@ -208,6 +208,12 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     L.total = off;
     e->lds_bytes = off * (int)sizeof(float);
   }
+  {
+    DConst hc; hc.M = e->M; hc.L = e->L;
+    if (dev_alloc(e, &e->dC, 1, false)) { delete e; return MJH_ERR_NO_DEVICE; }
+    HIPCHK(hipMemcpyAsync(e->dC, &hc, sizeof hc, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
   if (e->lds_bytes > 160 * 1024) {
     mjh_set_error("mjh_create: per-env working set exceeds the 160 KiB LDS of one CU (" + std::to_string(e->lds_bytes) + " B)");
     mjh_destroy(e); return MJH_ERR_CAPACITY;
@@ -262,8 +268,11 @@ extern "C" int mjh_step2(mjh_engine* e) {
 extern "C" int mjh_forward(mjh_engine* e) { ENG(e); return launch(e, 0, e->nenv, 1, PH_STEP1 | PH_NOINT, XF_FORCE); }
 extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
   ENG(e);
-  if (nsteps <= 0) return MJH_OK;
-  return launch(e, 0, e->nenv, nsteps, PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0), 0);
+  for (int s = 0; s < nsteps; s++) {   // one launch per step (commands are consumed by the first one)
+    int rc = launch(e, 0, e->nenv, 1, PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0), 0);
+    if (rc) return rc;
+  }
+  return MJH_OK;
 }
 extern "C" int mjh_synchronize(mjh_engine* e) { ENG(e); HIPCHK(hipStreamSynchronize(e->stream)); return MJH_OK; }
 

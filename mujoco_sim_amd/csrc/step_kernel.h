@@ -33,6 +33,12 @@ DEV float get_impedance(const float* si, float pos, float margin) {
   return s0 + y * (s1 - s0);
 }
 
+template <class T> struct Tab {
+  const T* base; int off;
+  DEV T operator[](int i) const { return base[off + i]; }
+  DEV const T* operator+(int k) const { return base + off + k; }
+};
+
 // in-place x <- M^-1 x over one tree's contiguous dof range, x addressed by absolute dof index
 template <int STRIDE = 1>
 DEV void solve_tree(float* x, const float* qLD, const float* qLDinv, const int* dof_parentid, const int* dof_Madr, int adr, int num) {
@@ -110,16 +116,22 @@ DEV void pgs_pyramid(const float* P, const float* aref, float* f, const float* A
 }
 
 template <int NROW, bool DIAGM>
-__global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DModel M, const DState S, const Lay L, int env0, int nsteps, int ph, int xflags) {
+__global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restrict__ C, const DState S, int env0, int nsteps, int ph, int xflags) {
+  // model descriptor + LDS layout live in device memory (uploaded once): uniform scalar loads on demand instead
+  // of a by-value kernarg struct that the lambdas below would force into a private (scratch) copy
+  const DModel& M = C->M;
+  const Lay& L = C->L;
   extern __shared__ float lds[];
   const int lane = threadIdx.x;
   const int env = env0 + blockIdx.x;
   const int nq = M.nq, nv = M.nv, nbody = M.nbody, njnt = M.njnt, ngeom = M.ngeom;
 
-#define IT(n) const int* n = M.I + M.o_##n;
+  // model tables: one base pointer per element type + a kernarg-resident offset per table (kept as
+  // (base, offset) pairs so that ~70 table addresses do not each pin an SGPR pair for the whole kernel)
+#define IT(n) const Tab<int> n{M.I, M.o_##n};
   MJH_INT_TABLES(IT)
 #undef IT
-#define FT(n) const float* n = M.F + M.o_##n;
+#define FT(n) const Tab<float> n{M.F, M.o_##n};
   MJH_FLT_TABLES(FT)
 #undef FT
 #define LA(n) float* s_##n = lds + L.n;
@@ -162,7 +174,11 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DModel M, const D
   WSYNC();
   PROF(1);
 
-  for (int step = 0; step < nsteps; step++) {
+  // one step per launch: an in-kernel step loop would keep every table pointer live across the whole body
+  // (loop-carried), which is what used to spill ~1 KB/lane to scratch; mjh_step(n) issues n launches instead
+  (void)nsteps;
+  {
+    const int step = 0;
     // ---- bad-state check (mj_checkPos / mj_checkVel): reset this env
     {
       bool badv = false;
@@ -259,7 +275,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DModel M, const D
       if (S.x_gpos) for (int i = lane; i < 3*ngeom; i += 64) S.x_gpos[e*3*ngeom + i] = s_gpos[i];
       if (S.x_gmat) for (int i = lane; i < 9*ngeom; i += 64) S.x_gmat[e*9*ngeom + i] = s_gmat[i];
     }
-    if (ph & PH_FKONLY) break;
+    if (ph & PH_FKONLY) return;
     PROF(2);
 
     // ---- subtree COM of every tree root, COM-based inertias, motion axes (mj_comPos)
@@ -340,7 +356,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DModel M, const D
       }
       WSYNC();
       for (int i = lane; i < nv; i += 64) S.x_res[(size_t)blockIdx.x * M.nvp + i] = s_tmpv2[i];
-      break;
+      return;
     }
     PROF(3);
     // ---- L'DL factorisation (mj_factorM): one lane per kinematic tree
@@ -417,7 +433,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DModel M, const D
     nefc = 0;
     int nblk = 0, nbrow = 0;
     if (!(M.disableflags & MJH_DSBL_CONSTRAINT)) {
-      auto put_block = [&](int b, int kind, int nrows, int nb, int clamp, int, int id, int rtype, int side) {
+      auto put_block = [&](int b, int kind, int nrows, int nb, int clamp, int, int id, int rtype, int side) __attribute__((always_inline)) {
         int* hd = s_blki_i + b * BLKI_STRIDE;
         hd[0] = kind | (nrows << 4) | (nb << 8) | (clamp << 12); hd[1] = id | (rtype << 24) | (side << 28);
       };
@@ -623,7 +639,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DModel M, const D
     PROF(8);
 
     // dot products of every base row with a dof-space vector: out[4b+j] = J[b][.][j] . vec   (lanes = (block, base))
-    auto base_dots = [&](const float* vec, float* out) {
+    auto base_dots = [&](const float* vec, float* out) __attribute__((always_inline)) {
       for (int t = lane; t < 4 * nblk; t += 64) {
         const int b = t >> 2, jb = t & 3;
         const int* hd = s_blki_i + b * BLKI_STRIDE;
@@ -637,7 +653,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DModel M, const D
       WSYNC();
     };
     // out[d] = sum over blocks/bases of X[b][d][j] * phi[4b+j]   (lanes = dofs; X = J, or B = M^-1 J^T when useB)
-    auto accum_T = [&](bool useB, const float* phi, float* out) {
+    auto accum_T = [&](bool useB, const float* phi, float* out) __attribute__((always_inline)) {
       for (int d = lane; d < nv; d += 64) {
         float acc = 0;
         const float minv = s_qLDinv[d];
@@ -657,7 +673,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DModel M, const D
     // pyramid row r of a block: direction index k (1..3) and signed friction coefficient c
 #define PYR_KC(r, mu1, mu3, k, c) const int k = 1 + ((r) >> 1); const float c = ((r) & 1) ? -1.0f : 1.0f
     // per-row force response to jar = J a - aref  (mj_constraintUpdate, pyramidal cones), and base forces phi
-    auto forces_from = [&](const float* bv, bool keep) {
+    auto forces_from = [&](const float* bv, bool keep) __attribute__((always_inline)) {
       for (int b = lane; b < nblk; b += 64) {
         const int* hd = s_blki_i + b * BLKI_STRIDE;
         float* bf = s_blkf + b * BLKF_STRIDE;
@@ -680,7 +696,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DModel M, const D
       }
       WSYNC();
     };
-    auto phi_from_forces = [&]() {
+    auto phi_from_forces = [&]() __attribute__((always_inline)) {
       for (int b = lane; b < nblk; b += 64) {
         const int* hd = s_blki_i + b * BLKI_STRIDE;
         const float* bf = s_blkf + b * BLKF_STRIDE;
@@ -698,7 +714,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DModel M, const D
     };
 
     // ================================================================ velocity stage (lambdas: used by step1, inverse, step2-alone)
-    auto vel_levels = [&](const float* qv, const float* qa, float* out) {
+    auto vel_levels = [&](const float* qv, const float* qa, float* out) __attribute__((always_inline)) {
       // mj_comVel + mj_rne forward/backward; qa != null adds cdof*qacc (flg_acc)
       if (lane == 0) { for (int k = 0; k < 6; k++) { s_cvel[k] = 0; s_cacc[k] = (k >= 3) ? -grav[k-3] : 0.0f; s_cfrc[k] = 0; } }
       WSYNC();
@@ -767,7 +783,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DModel M, const D
       }
       WSYNC();
     };
-    auto vel_stage = [&](const float* qv) {
+    auto vel_stage = [&](const float* qv) __attribute__((always_inline)) {
       vel_levels(qv, nullptr, s_bias);
       // mj_passive: springs, dampers, gravity compensation (gravcomp: mj_sim.cpp:301-310)
       for (int d = lane; d < nv; d += 64) {
@@ -927,7 +943,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DModel M, const D
         const float4* B4 = (const float4*)s_B;
         // operands of one block: 1 header + 1 (2) Jacobian + 8 parameter ds_read_b128 per lane
         struct BlkOp { int hx; float4 J, B, P, r0, r1, r2, A0, A1, A2, A3; };
-        auto fetch = [&](int b) {
+        auto fetch = [&](int b) __attribute__((always_inline)) {
           BlkOp op;
           const int4 hd = blki4[b];
           ROW_TREES(hd.z, hd.w);
@@ -944,7 +960,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DModel M, const D
           op.hx = hd.x;
           return op;
         };
-        auto process = [&](BlkOp& op, int b, float& improvement) {
+        auto process = [&](BlkOp& op, int b, float& improvement) __attribute__((always_inline)) {
           const int kind = __builtin_amdgcn_readfirstlane(op.hx & 15);
           float f[6] = {op.r1.z, op.r1.w, op.r2.x, op.r2.y, op.r2.z, op.r2.w};
           const float aref[6] = {op.r0.x, op.r0.y, op.r0.z, op.r0.w, op.r1.x, op.r1.y};
