@@ -73,12 +73,13 @@ enum { XF_BODY = 1, XF_GEOM = 2, XF_CON = 4, XF_FORCE = 8, XF_PROF = 16 };
 #define CON_STRIDE 17  // dist, pos3, frame9, g1, g2, dim, includemargin
 // constraint blocks: header int4 + 32 floats per block
 //   hd.x = kind | nrows<<4 | nbase<<8 | clamp<<12 | jadr<<16 ; hd.y = id | rtype<<24 | side<<28 ; hd.z = a1 | n1<<16 ; hd.w = a2 | n2<<16
-//   floats: [0..3] R, frictionloss, mu_tangent, mu_torsion ; [4..9] aref per row ; [10..15] force per row ;
-//           [16..31] A_c = J_base M^-1 J_base^T (upper triangle; slots (1,0),(2,0) carry KI and Bc until the solve)
+//   floats: [0..3] R, frictionloss, KI, Bc ; [4..7] aref per BASE row (row r = n +- k has aref_n +- aref_k) ;
+//           [8..13] force per row ; [16..31] A_c = J_base M^-1 J_base^T (upper triangle; the 6 lower-triangle
+//           slots carry 1/AR_rr of the block's rows)
 #define BLKI_STRIDE 4
 #define BLKF_STRIDE 32
 #define BF_AREF 4
-#define BF_F 10
+#define BF_F 8
 #define BF_A 16
 enum { BK_SINGLE = 0, BK_PYR3 = 3, BK_PYR4 = 4 };
 enum { RT_EQ = 0, RT_FL = 1, RT_LIMIT = 2, RT_CONTACT = 3 };

@@ -86,26 +86,27 @@ DEV int row_off(int d, int a1, int n1, int a2, int n2) {
 // One pyramidal contact block of the PGS sweep: NB base rows (normal, tangents[, torsion]), NR = 2(NB-1) rows
 //   row r = J_n + c_r J_k,  k = 1 + r/2,  c_r = +-mu_k.   Everything after the NB reductions is wave-uniform.
 template <int NB, int NR, int NROW>
-DEV void pgs_pyramid(const float* P, const float* aref, float* f, const float* A, const float* Jd, const float* Bd, float& a, float& improvement) {
+DEV void pgs_pyramid(const float* P, const float* ab, float* f, const float* A, const float* Jd, const float* Bd, float& a, float& improvement) {
   float u[4] = {Jd[0] * a, Jd[1] * a, Jd[2] * a, NB > 3 ? Jd[3] * a : 0.0f}, dphi[NB];
   wave_sum4<NROW, NB>(u);
 #pragma unroll
-  for (int j = 0; j < NB; j++) dphi[j] = 0;
-  const float R = P[0], t0 = A[0] + R;
+  for (int j = 0; j < NB; j++) { u[j] -= ab[j]; dphi[j] = 0; }     // u <- J a - aref  (per base; rows are n +- k)
+  const float R = P[0], ht0 = 0.5f * (A[0] + R);
+  const int slot[6] = {4, 8, 9, 12, 13, 14};
 #pragma unroll
   for (int r = 0; r < NR; r++) {
     const int k = 1 + (r >> 1);
     const bool neg = r & 1;
-    // AR_rr = A_nn +- 2 A_nk + A_kk + R   (friction bases are pre-scaled by mu_k)
-    const float AR = neg ? (t0 + A[4*k + k]) - 2.0f * A[k] : (t0 + A[4*k + k]) + 2.0f * A[k];
-    const float ARinv = __builtin_amdgcn_rcpf(AR);
+    const float hs = ht0 + 0.5f * A[4*k + k];
+    const float hAR = neg ? hs - A[k] : hs + A[k];                 // AR_rr / 2
+    const float ARinv = A[slot[r]];                                // precomputed when the block was built
     const float fold = f[r];
-    const float res = (neg ? u[0] - u[k] : u[0] + u[k]) - aref[r] + R * fold;
+    const float res = (neg ? u[0] - u[k] : u[0] + u[k]) + R * fold;
     const float fn = fmaxf(0.0f, fold - res * ARinv);
     const float delta = fn - fold;
     // cost change delta*(res + delta*AR/2) <= 0 for every projected scalar update, so the
     // reference's "revert if the cost went up" guard is dead code for pyramidal rows and is not evaluated here
-    improvement -= delta * (res + 0.5f * AR * delta);
+    improvement -= delta * (res + hAR * delta);
 #pragma unroll
     for (int j = 0; j < NB; j++) u[j] += (neg ? A_SYM(A, j, 0) - A_SYM(A, j, k) : A_SYM(A, j, 0) + A_SYM(A, j, k)) * delta;
     dphi[0] += delta; dphi[k] += neg ? -delta : delta;
@@ -596,8 +597,8 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         K = 1 / fmaxf(MJ_MINVAL, dmax*dmax * sr0*sr0 * sr1*sr1); Bc = 2 / fmaxf(MJ_MINVAL, dmax * sr0);
       } else { K = -sr0 / fmaxf(MJ_MINVAL, dmax*dmax); Bc = -sr1 / fmaxf(MJ_MINVAL, dmax); }
       if (rtype == RT_FL) K = 0;
-      bf[0] = R; bf[1] = fl; bf[2] = mu1; bf[3] = mu3;
-      bf[BF_A + 4] = K * imp * (pos - margin); bf[BF_A + 8] = Bc;   // KI, Bc live in two unused lower-triangle slots of A
+      (void)mu1; (void)mu3;   // friction coefficients are folded into the base rows
+      bf[0] = R; bf[1] = fl; bf[2] = K * imp * (pos - margin); bf[3] = Bc;
     }
     WSYNC();
     PROF(7);
@@ -634,6 +635,18 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       float* A = s_blkf + b * BLKF_STRIDE + BF_A;
 #pragma unroll
       for (int i = 0; i < 4; i++) if (i >= jb && i < nb) A[4*jb + i] = acc[i];
+    }
+    WSYNC();
+    // 1/AR_rr of every row, AR_rr = A_nn +- 2 A_nk + A_kk + R, parked in the 6 unused lower-triangle slots of A
+    for (int b = lane; b < nblk; b += 64) {
+      const int* hd = s_blki_i + b * BLKI_STRIDE;
+      float* bf = s_blkf + b * BLKF_STRIDE;
+      float* A = bf + BF_A;
+      const int kind = hd[0] & 15, nr = (hd[0] >> 4) & 15;
+      const float t0 = A[0] + bf[0];
+      const int slot[6] = {4, 8, 9, 12, 13, 14};
+      if (kind == BK_SINGLE) A[4] = 1.0f / t0;
+      else for (int r = 0; r < nr; r++) { const int k = 1 + (r >> 1); A[slot[r]] = 1.0f / (t0 + A[4*k + k] + ((r & 1) ? -2.0f : 2.0f) * A[k]); }
     }
     WSYNC();
     PROF(8);
@@ -678,12 +691,12 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         const int* hd = s_blki_i + b * BLKI_STRIDE;
         float* bf = s_blkf + b * BLKF_STRIDE;
         const int kind = hd[0] & 15, nr = (hd[0] >> 4) & 15, clamp = (hd[0] >> 12) & 3, jadr = 4 * b;
-        const float R = bf[0], D = 1.0f / R, flv = bf[1], mu1 = bf[2], mu3 = bf[3];
+        const float R = bf[0], D = 1.0f / R, flv = bf[1];
         float ph[4] = {0, 0, 0, 0};
         for (int r = 0; r < nr; r++) {
           PYR_KC(r, mu1, mu3, k, c);
           const bool pyr = kind != BK_SINGLE;
-          const float jar = bv[jadr] + (pyr ? c * bv[jadr + k] : 0.0f) - bf[BF_AREF + r];
+          const float jar = bv[jadr] + (pyr ? c * bv[jadr + k] : 0.0f) - (bf[BF_AREF] + (pyr ? c * bf[BF_AREF + k] : 0.0f));
           float f;
           if (clamp == 0) f = -D * jar;
           else if (clamp == 2) f = (jar <= -R*flv) ? flv : ((jar >= R*flv) ? -flv : -D * jar);
@@ -813,12 +826,11 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         const int* hd = s_blki_i + b * BLKI_STRIDE;
         float* bf = s_blkf + b * BLKF_STRIDE;
         const int kind = hd[0] & 15, nr = (hd[0] >> 4) & 15, jadr = 4 * b;
-        const float KI = bf[BF_A + 4], Bc = bf[BF_A + 8];
-        for (int r = 0; r < nr; r++) {
-          PYR_KC(r, bf[2], bf[3], k, c);
-          const float vel = s_bv[jadr] + (kind != BK_SINGLE ? c * s_bv[jadr + k] : 0.0f);
-          bf[BF_AREF + r] = -Bc * vel - KI;
-        }
+        // aref of row r = J_n +- J_k is  ab[0] +- ab[k]  with the per-base values  ab[j] = -Bc (J_j qvel) - (j == 0) KI
+        const float KI = bf[2], Bc = bf[3];
+        (void)kind; (void)nr;
+#pragma unroll
+        for (int j = 0; j < 4; j++) bf[BF_AREF + j] = -Bc * s_bv[jadr + j] - (j == 0 ? KI : 0.0f);
       }
       WSYNC();
     };
@@ -913,7 +925,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
               PYR_KC(r, bf[2], bf[3], k, c);
               const bool pyr = kind != BK_SINGLE;
               const float jda = s_bv[jadr] + (pyr ? c * s_bv[jadr + k] : 0.0f);
-              const float bb = s_phi[jadr] + (pyr ? c * s_phi[jadr + k] : 0.0f) - bf[BF_AREF + r];
+              const float bb = s_phi[jadr] + (pyr ? c * s_phi[jadr + k] : 0.0f) - (bf[BF_AREF] + (pyr ? c * bf[BF_AREF + k] : 0.0f));
               const float f = bf[BF_F + r];
               cost += f * (0.5f * (jda + bf[0] * f) + bb);
             }
@@ -962,8 +974,8 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         };
         auto process = [&](BlkOp& op, int b, float& improvement) __attribute__((always_inline)) {
           const int kind = __builtin_amdgcn_readfirstlane(op.hx & 15);
-          float f[6] = {op.r1.z, op.r1.w, op.r2.x, op.r2.y, op.r2.z, op.r2.w};
-          const float aref[6] = {op.r0.x, op.r0.y, op.r0.z, op.r0.w, op.r1.x, op.r1.y};
+          float f[6] = {op.r1.x, op.r1.y, op.r1.z, op.r1.w, op.r2.x, op.r2.y};
+          const float aref[4] = {op.r0.x, op.r0.y, op.r0.z, op.r0.w};
           const float A[16] = {op.A0.x, op.A0.y, op.A0.z, op.A0.w, op.A1.x, op.A1.y, op.A1.z, op.A1.w,
                                op.A2.x, op.A2.y, op.A2.z, op.A2.w, op.A3.x, op.A3.y, op.A3.z, op.A3.w};
           const float P[4] = {op.P.x, op.P.y, op.P.z, op.P.w};
@@ -973,7 +985,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           else {
             const int clamp = __builtin_amdgcn_readfirstlane((op.hx >> 12) & 3);
             const float u0 = wave_sum<NROW>(Jd[0] * a);
-            const float R = P[0], AR = A[0] + R, ARinv = __builtin_amdgcn_rcpf(AR), fold = f[0];
+            const float R = P[0], AR = A[0] + R, ARinv = A[4], fold = f[0];
             const float res = u0 - aref[0] + R * fold;
             float fn = fold - res * ARinv;
             if (clamp == 1) fn = fmaxf(0.0f, fn); else if (clamp == 2) fn = fminf(P[1], fmaxf(-P[1], fn));
@@ -984,8 +996,8 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           }
           if (lane == 0) {
             float* bf = s_blkf + b * BLKF_STRIDE + BF_F;
-            *(float2*)(bf) = make_float2(f[0], f[1]);
-            *(float4*)(bf + 2) = make_float4(f[2], f[3], f[4], f[5]);
+            *(float4*)(bf) = make_float4(f[0], f[1], f[2], f[3]);
+            *(float2*)(bf + 4) = make_float2(f[4], f[5]);
           }
         };
         for (int it = 0; it < M.iterations; it++) {
