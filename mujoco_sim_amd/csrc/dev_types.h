@@ -53,7 +53,7 @@ struct DState {
   X(qpos) X(qvel) X(qvref) X(ws) X(qacc) X(smooth) X(asmooth) X(passive) X(bias) X(applied)        \
   X(tmpv) X(tmpv2) X(xpos) X(xquat) X(xmat) X(xipos) X(ximat) X(com) X(cinert) X(crb) X(cvel)      \
   X(cacc) X(cfrc) X(cfrcsub) X(xanchor) X(xaxis) X(cdof) X(cdofdot) X(qM) X(qLD) X(qLDinv)          \
-  X(gpos) X(gmat) X(con) X(blki) X(blkf) X(bv) X(phi) X(J) X(B) X(dofpar) X(dofMadr)               \
+  X(gpos) X(gmat) X(con) X(blki) X(blkf) X(bv) X(phi) X(sched) X(order) X(J) X(B) X(dofpar) X(dofMadr)               \
   X(p_gsize) X(p_rbound) X(p_mass) X(p_inertia) X(p_binv) X(p_dinv)
 
 struct Lay {

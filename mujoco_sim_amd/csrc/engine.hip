@@ -203,7 +203,7 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
       L.cvel = L.con; L.cacc = L.con + a4; L.cfrc = L.con + 2*a4; L.cfrcsub = L.con + 3*a4; L.cdofdot = L.con + 4*a4;
     }
     L.blki = put(nblkcap * BLKI_STRIDE); L.blkf = put(nblkcap * BLKF_STRIDE);
-    L.bv = put(nblkcap * 4); L.phi = put(nblkcap * 4);
+    L.bv = put(nblkcap * 4); L.phi = put(nblkcap * 4); L.sched = put(nblkcap * 2); L.order = put(nblkcap);
     L.J = put(jsz); L.B = diagM ? L.J : put(jsz);
     L.total = off;
     e->lds_bytes = off * (int)sizeof(float);

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
 #define LA(n) float* s_##n = lds + L.n;
   MJH_LDS_ARRAYS(LA)
 #undef LA
-  int* s_blki_i = (int*)s_blki; int* s_dofpar_i = (int*)s_dofpar; int* s_dofMadr_i = (int*)s_dofMadr;
+  int* s_blki_i = (int*)s_blki; int* s_sched_i = (int*)s_sched; int* s_order_i = (int*)s_order; int* s_dofpar_i = (int*)s_dofpar; int* s_dofMadr_i = (int*)s_dofMadr;
   float* s_stage = s_J;  // raw-contact staging aliases the (not yet built) base-row storage
   const int rowW = M.rowW;
 
@@ -649,6 +649,32 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       else for (int r = 0; r < nr; r++) { const int k = 1 + (r >> 1); A[slot[r]] = 1.0f / (t0 + A[4*k + k] + ((r & 1) ? -2.0f : 2.0f) * A[k]); }
     }
     WSYNC();
+    // ---- Gauss-Seidel visiting order (shared with the oracle): block i, then the first later unvisited block
+    //      that shares no kinematic tree with it.  Pairs (i, q) are independent and can be solved side by side.
+    int ngrp = 0;
+    {
+      int ta = -1, tb = -1;
+      if (lane < nblk) { const int* hd = s_blki_i + lane * BLKI_STRIDE; ta = hd[2] & 0xffff; tb = (hd[3] >> 16) ? (hd[3] & 0xffff) : -1; }
+      if (nblk > 64) {   // (capacity of the 64-bit bookkeeping below) plain order, no pairs
+        for (int i = lane; i < nblk; i += 64) { s_sched_i[2*i] = i; s_sched_i[2*i+1] = -1; s_order_i[i] = i; }
+        ngrp = nblk;
+      } else {
+        unsigned long long used = 0; int k = 0;
+        for (int i = 0; i < nblk; i++) {
+          if ((used >> i) & 1ull) continue;
+          used |= 1ull << i;
+          const int ia = __builtin_amdgcn_readlane(ta, i), ib = __builtin_amdgcn_readlane(tb, i);
+          const bool share = ta == ia || (ib >= 0 && ta == ib) || (tb >= 0 && (tb == ia || tb == ib));
+          const bool cand = lane < nblk && lane > i && !((used >> lane) & 1ull) && !share;
+          const unsigned long long bal = __ballot(cand);
+          int q = -1;
+          if (bal) { q = __ffsll((long long)bal) - 1; used |= 1ull << q; }
+          if (lane == 0) { s_sched_i[2*ngrp] = i; s_sched_i[2*ngrp+1] = q; s_order_i[k] = i; if (q >= 0) s_order_i[k+1] = q; }
+          k += q >= 0 ? 2 : 1; ngrp++;
+        }
+      }
+    }
+    WSYNC();
     PROF(8);
 
     // dot products of every base row with a dof-space vector: out[4b+j] = J[b][.][j] . vec   (lanes = (block, base))
@@ -1003,13 +1029,14 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         for (int it = 0; it < M.iterations; it++) {
           float improvement = 0;
           // two operand buffers in ping-pong: the next block's LDS reads are in flight while this one is solved
-          BlkOp opA = fetch(0), opB;
-          for (int b = 0; b < nblk; b += 2) {
-            opB = fetch(b + 1 < nblk ? b + 1 : b);
-            process(opA, b, improvement);
-            if (b + 1 < nblk) {
-              opA = fetch(b + 2 < nblk ? b + 2 : b + 1);
-              process(opB, b + 1, improvement);
+          BlkOp opA = fetch(s_order_i[0]), opB;
+          for (int k = 0; k < nblk; k += 2) {
+            const int b0 = s_order_i[k], b1 = s_order_i[k + 1 < nblk ? k + 1 : k], b2 = s_order_i[k + 2 < nblk ? k + 2 : k];
+            opB = fetch(b1);
+            process(opA, b0, improvement);
+            if (k + 1 < nblk) {
+              opA = fetch(b2);
+              process(opB, b1, improvement);
             }
           }
           niter = it + 1;

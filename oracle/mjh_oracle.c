@@ -968,6 +968,58 @@ static void constraint_update(orc_data* d, const double* jar, double* force) {
   }
 }
 
+/* Gauss-Seidel visiting order shared with the HIP path: rows are grouped into blocks
+ * (one per equality / friction-loss / limit row, one per contact = its pyramid rows); blocks are visited in
+ * the greedy "independent pair" order — block i, then the first later unvisited block that shares no
+ * kinematic tree with it — so that the device can solve the two blocks of a pair side by side in the two
+ * halves of a wavefront.  Any permutation is a valid PGS order (MuJoCo uses plain row order); the converged
+ * solution is the same. */
+static void block_trees(const orc_data* d, int row, int* t1, int* t2) {
+  const mjh_model* m = d->m; int id = d->efc_id[row];
+  *t1 = *t2 = -1;
+  switch (d->efc_type[row]) {
+    case MJH_CNSTR_EQUALITY:
+      *t1 = m->dof_treeid[m->jnt_dofadr[m->eq_obj1id[id]]];
+      if (m->eq_obj2id[id] >= 0) *t2 = m->dof_treeid[m->jnt_dofadr[m->eq_obj2id[id]]];
+      break;
+    case MJH_CNSTR_FRICTION_DOF: *t1 = m->dof_treeid[id]; break;
+    case MJH_CNSTR_LIMIT_JOINT: *t1 = m->dof_treeid[m->jnt_dofadr[id]]; break;
+    default:
+      *t1 = m->body_treeid[m->geom_bodyid[d->contact[id].geom1]];
+      *t2 = m->body_treeid[m->geom_bodyid[d->contact[id].geom2]];
+  }
+}
+static int pgs_order(const orc_data* d, int* order) {
+  int nefc = d->nefc, nblk = 0;
+  int* bstart = (int*)malloc(sizeof(int) * (size_t)(nefc + 1) * 5);
+  int *bnum = bstart + nefc + 1, *bt1 = bnum + nefc + 1, *bt2 = bt1 + nefc + 1, *used = bt2 + nefc + 1;
+  for (int i = 0; i < nefc;) {
+    int n = 1;
+    if (d->efc_type[i] == MJH_CNSTR_CONTACT_PYRAMIDAL)
+      while (i + n < nefc && d->efc_type[i+n] == MJH_CNSTR_CONTACT_PYRAMIDAL && d->efc_id[i+n] == d->efc_id[i]) n++;
+    bstart[nblk] = i; bnum[nblk] = n; block_trees(d, i, bt1 + nblk, bt2 + nblk); used[nblk] = 0;
+    nblk++; i += n;
+  }
+  int k = 0;
+  if (nblk > 64) { for (int i = 0; i < nefc; i++) order[i] = i; free(bstart); return nefc; }   /* device bookkeeping limit */
+  for (int i = 0; i < nblk; i++) {
+    if (used[i]) continue;
+    used[i] = 1;
+    for (int r = 0; r < bnum[i]; r++) order[k++] = bstart[i] + r;
+    for (int j = i + 1; j < nblk; j++) {
+      if (used[j]) continue;
+      int a1 = bt1[i], a2 = bt2[i], c1 = bt1[j], c2 = bt2[j];
+      int share = (a1 >= 0 && (a1 == c1 || a1 == c2)) || (a2 >= 0 && (a2 == c1 || a2 == c2));
+      if (share) continue;
+      used[j] = 1;
+      for (int r = 0; r < bnum[j]; r++) order[k++] = bstart[j] + r;
+      break;
+    }
+  }
+  free(bstart);
+  return k;
+}
+
 /* warm start + projected Gauss-Seidel on the dual + map back [UPSTREAM mj_fwdConstraint / mj_solPGS] */
 void orc_fwd_constraint(orc_data* d) {
   const mjh_model* m = d->m; int nv = m->nv, nefc = d->nefc;
@@ -992,9 +1044,12 @@ void orc_fwd_constraint(orc_data* d) {
   /* PGS sweeps */
   double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
   int iter = 0;
+  int* order = (int*)malloc(sizeof(int) * (size_t)nefc);
+  pgs_order(d, order);
   while (iter < m->opt.iterations) {
     double improvement = 0;
-    for (int i = 0; i < nefc; i++) {
+    for (int k = 0; k < nefc; k++) {
+      const int i = order[k];
       double Aii = d->efc_AR[(size_t)i*nefc + i];
       double r = d->efc_b[i] + dotn(d->efc_AR + (size_t)i*nefc, d->efc_force, nefc);
       double old = d->efc_force[i], f = old - r / Aii;
@@ -1008,6 +1063,7 @@ void orc_fwd_constraint(orc_data* d) {
     iter++;
     if (improvement * scale < m->opt.tolerance) break;
   }
+  free(order);
   d->solver_iter = iter;
   /* qfrc_constraint = J^T f ; qacc = qacc_smooth + M^-1 qfrc_constraint */
   zero(d->qfrc_constraint, nv);
