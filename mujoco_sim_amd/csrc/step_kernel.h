@@ -116,6 +116,68 @@ DEV void pgs_pyramid(const float* P, const float* ab, float* f, const float* A, 
   for (int j = 0; j < NB; j++) a += Bd[j] * dphi[j];
 }
 
+
+// ---- dual-block PGS (wavefronts with nv <= 32): the two 32-lane halves of the wave solve the two blocks of an
+// independent pair at the same time.  Every "uniform" quantity of the single-block solver becomes uniform
+// per half; a half-wide sum is a 4-step DPP butterfly inside each 16-lane row plus one v_permlane16_swap.
+DEV void swap16_sum4(float* v, const int n) {   // v[j] <- v[j] + (v[j] of the partner 16-lane row), j < n
+  float y0 = v[0], y1 = v[1], y2 = v[2], y3 = v[3];
+  if (n == 4) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                           : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));
+  else if (n == 3) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %3\n\tv_permlane16_swap_b32 %1, %4\n\tv_permlane16_swap_b32 %2, %5\n\ts_nop 1"
+                                : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(y0), "+v"(y1), "+v"(y2));
+  else asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(v[0]), "+v"(y0));
+  v[0] += y0; if (n > 1) v[1] += y1; if (n > 2) v[2] += y2; if (n > 3) v[3] += y3;
+}
+DEV float swap32_sum(float x) {                  // x + (x of the other 32-lane half)
+  float y = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  return x + y;
+}
+#define MJH_DPP_BF4(v, N, ctrl) do { MJH_DPP_ADD(v[0], ctrl, 0xf, true); if (N > 1) MJH_DPP_ADD(v[1], ctrl, 0xf, true); \
+    if (N > 2) MJH_DPP_ADD(v[2], ctrl, 0xf, true); if (N > 3) MJH_DPP_ADD(v[3], ctrl, 0xf, true); } while (0)
+template <int N> DEV void half_sum4(float* v) {   // sums over each 32-lane half, result in every lane of the half
+  MJH_DPP_BF4(v, N, 0xB1);    // quad_perm [1,0,3,2]
+  MJH_DPP_BF4(v, N, 0x4E);    // quad_perm [2,3,0,1]
+  MJH_DPP_BF4(v, N, 0x141);   // row_half_mirror
+  MJH_DPP_BF4(v, N, 0x140);   // row_mirror
+  swap16_sum4(v, N);
+}
+template <int NB, int NR>
+DEV float pgs_dual(const float* P, const float* ab, float* f, const float* A, const float* Jd, const float* Bd, int clamp, float& a) {
+  float u[4] = {Jd[0] * a, NB > 1 ? Jd[1] * a : 0.0f, NB > 2 ? Jd[2] * a : 0.0f, NB > 3 ? Jd[3] * a : 0.0f}, dphi[4] = {0, 0, 0, 0};
+  half_sum4<NB>(u);
+#pragma unroll
+  for (int j = 0; j < NB; j++) u[j] -= ab[j];
+  const float R = P[0], ht0 = 0.5f * (A[0] + R);
+  const float lo = clamp == 0 ? -3.0e38f : (clamp == 2 ? -P[1] : 0.0f), hi = clamp == 2 ? P[1] : 3.0e38f;
+  const int slot[6] = {4, 8, 9, 12, 13, 14};
+  float imp = 0;
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    const int k = NB > 1 ? 1 + (r >> 1) : 0;
+    const bool neg = r & 1;
+    const float hs = NB > 1 ? ht0 + 0.5f * A[4*k + k] : ht0;
+    const float hAR = NB > 1 ? (neg ? hs - A[k] : hs + A[k]) : hs;
+    const float ARinv = A[slot[r]];
+    const float fold = f[r];
+    const float un = NB > 1 ? (neg ? u[0] - u[k] : u[0] + u[k]) : u[0];
+    const float res = un + R * fold;
+    const float fn = fminf(hi, fmaxf(lo, fold - res * ARinv));
+    const float delta = fn - fold;
+    imp -= delta * (res + hAR * delta);
+#pragma unroll
+    for (int j = 0; j < NB; j++) u[j] += (NB > 1 ? (neg ? A_SYM(A, j, 0) - A_SYM(A, j, k) : A_SYM(A, j, 0) + A_SYM(A, j, k)) : A[0]) * delta;
+    dphi[0] += delta; if (NB > 1) dphi[k] += neg ? -delta : delta;
+    f[r] = fn;
+  }
+  float da = 0;
+#pragma unroll
+  for (int j = 0; j < NB; j++) da += Bd[j] * dphi[j];
+  a += swap32_sum(da);       // the pair's blocks touch disjoint dofs: both halves end up with the same `a`
+  return imp;
+}
+
 template <int NROW, bool DIAGM>
 __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restrict__ C, const DState S, int env0, int nsteps, int ph, int xflags) {
   // model descriptor + LDS layout live in device memory (uploaded once): uniform scalar loads on demand instead
@@ -545,6 +607,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       const int* hd = s_blki_i + b * BLKI_STRIDE;
       const int id = hd[1] & 0xffffff, rtype = (hd[1] >> 24) & 15, side = (hd[1] >> 28) & 1;
       float* bf = s_blkf + b * BLKF_STRIDE;
+      for (int k = 0; k < BLKF_STRIDE; k++) bf[k] = 0;   // unused rows / bases must be inert (dual-block solver)
       float pos = 0, margin = 0, diagA = 0, fl = 0, mu1 = 0, mu3 = 0, rscale = -1, sr[2], si[5];
       if (rtype == RT_EQ) {
         const int j1 = eq_obj1id[id], j2 = eq_obj2id[id];
@@ -971,7 +1034,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         //        res_r = e_r.u - aref_r + R f_r ;  f_r <- max(0, f_r - res_r/AR_rr) ;  u += A_c e_r delta
         //      and `a` is touched once per block:  a += B_base^T dphi.
         // TODO(perf): nv > 64 needs several dofs per lane
-        const int d0 = lane;
+        const int d0 = (NROW <= 2) ? (lane & 31) : lane;   // dual mode: both halves carry a copy of the dof vector
         float a = (d0 < nv) ? s_asmooth[d0] + s_tmpv[d0] : 0.0f;
         const float minv0 = (d0 < nv) ? s_qLDinv[d0] : 0.0f;
         const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
@@ -979,6 +1042,70 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         const int4* blki4 = (const int4*)s_blki_i;
         const float4* J4 = (const float4*)s_J;
         const float4* B4 = (const float4*)s_B;
+        if constexpr (NROW <= 2) {
+          // ======== dual-block sweep: half 0 solves block p, half 1 its independent partner q of the schedule
+          const int hh = lane >> 5;
+          struct DOp { int hx, b; float act; float4 J, B, P, r0, r1, r2, A0, A1, A2, A3; };
+          auto fetchD = [&](int g) __attribute__((always_inline)) {
+            DOp op;
+            const int2 pq = *(const int2*)(s_sched_i + 2*g);
+            const int bsel = hh ? pq.y : pq.x;
+            const bool act = bsel >= 0;
+            const int b = act ? bsel : pq.x;
+            const int4 hd = blki4[b];
+            ROW_TREES(hd.z, hd.w);
+            const int o = row_off(d0, a1, n1, a2, n2);
+            const int ja = b * rowW + max(o, 0);
+            const float msk = (o >= 0 && act) ? 1.0f : 0.0f;
+            float4 jv = J4[ja];
+            jv.x *= msk; jv.y *= msk; jv.z *= msk; jv.w *= msk;
+            op.J = jv;
+            if (DIAGM) { op.B.x = jv.x * minv0; op.B.y = jv.y * minv0; op.B.z = jv.z * minv0; op.B.w = jv.w * minv0; }
+            else { float4 bv4 = B4[ja]; bv4.x *= msk; bv4.y *= msk; bv4.z *= msk; bv4.w *= msk; op.B = bv4; }
+            op.P = blkf4[8*b]; op.r0 = blkf4[8*b+1]; op.r1 = blkf4[8*b+2]; op.r2 = blkf4[8*b+3];
+            op.A0 = blkf4[8*b+4]; op.A1 = blkf4[8*b+5]; op.A2 = blkf4[8*b+6]; op.A3 = blkf4[8*b+7];
+            op.hx = act ? hd.x : 0; op.b = b; op.act = act ? 1.0f : 0.0f;
+            return op;
+          };
+          auto processD = [&](DOp& op, float& improvement) __attribute__((always_inline)) {
+            // the unrolled row count follows the larger of the two blocks; the smaller one's extra rows are inert
+            const int k0 = __builtin_amdgcn_readlane(op.hx & 15, 0), k1 = __builtin_amdgcn_readlane(op.hx & 15, 32);
+            const int kind = k0 > k1 ? k0 : k1;
+            float f[6] = {op.r1.x, op.r1.y, op.r1.z, op.r1.w, op.r2.x, op.r2.y};
+            const float ab[4] = {op.r0.x, op.r0.y, op.r0.z, op.r0.w};
+            const float A[16] = {op.A0.x, op.A0.y, op.A0.z, op.A0.w, op.A1.x, op.A1.y, op.A1.z, op.A1.w,
+                                 op.A2.x, op.A2.y, op.A2.z, op.A2.w, op.A3.x, op.A3.y, op.A3.z, op.A3.w};
+            const float P[4] = {op.P.x, op.P.y, op.P.z, op.P.w};
+            const float Jd[4] = {op.J.x, op.J.y, op.J.z, op.J.w}, Bd[4] = {op.B.x, op.B.y, op.B.z, op.B.w};
+            const int clamp = (op.hx >> 12) & 3;
+            float imp;
+            if (kind == BK_PYR4) imp = pgs_dual<4, 6>(P, ab, f, A, Jd, Bd, clamp, a);
+            else if (kind == BK_PYR3) imp = pgs_dual<3, 4>(P, ab, f, A, Jd, Bd, clamp, a);
+            else imp = pgs_dual<1, 1>(P, ab, f, A, Jd, Bd, clamp, a);
+            improvement += op.act * imp;
+            if (d0 == 0 && op.act > 0.0f) {
+              float* bf = s_blkf + op.b * BLKF_STRIDE + BF_F;
+              *(float4*)(bf) = make_float4(f[0], f[1], f[2], f[3]);
+              *(float2*)(bf + 4) = make_float2(f[4], f[5]);
+            }
+          };
+          for (int it = 0; it < M.iterations; it++) {
+            float impl = 0;
+            DOp opA = fetchD(0), opB;
+            for (int g = 0; g < ngrp; g += 2) {
+              opB = fetchD(g + 1 < ngrp ? g + 1 : g);
+              processD(opA, impl);
+              if (g + 1 < ngrp) {
+                opA = fetchD(g + 2 < ngrp ? g + 2 : g + 1);
+                processD(opB, impl);
+              }
+            }
+            niter = it + 1;
+            const float improvement = readlane_f(impl, 0) + readlane_f(impl, 32);
+            if (improvement * scale < M.tolerance) break;
+            WSYNC();
+          }
+        } else {
         // operands of one block: 1 header + 1 (2) Jacobian + 8 parameter ds_read_b128 per lane
         struct BlkOp { int hx; float4 J, B, P, r0, r1, r2, A0, A1, A2, A3; };
         auto fetch = [&](int b) __attribute__((always_inline)) {
@@ -1043,8 +1170,9 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           if (improvement * scale < M.tolerance) break;
           WSYNC();   // the next sweep re-reads the forces from LDS
         }
+        }
         WSYNC();
-        if (d0 < nv) { s_qacc[d0] = a; s_ws[d0] = a; }
+        if (d0 < nv && lane < 64 / (NROW <= 2 ? 2 : 1)) { s_qacc[d0] = a; s_ws[d0] = a; }
         PROF(13);
         WSYNC();
         // qfrc_constraint = J^T f (only needed by the implicit-damping integrator and for export)
