@@ -219,7 +219,8 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   for (int i = lane; i < nq; i += 64) s_qpos[i] = S.qpos[qrow + i];
   for (int i = lane; i < nv; i += 64) {
     s_qvel[i] = S.qvel[vrow + i]; s_ws[i] = S.qacc_ws[vrow + i]; s_qacc[i] = S.qacc[vrow + i];
-    s_qvref[i] = S.qvel_ref[vrow + i]; s_applied[i] = S.qfrc_applied[vrow + i];
+    // qvel_ref / qfrc_applied only cross launches in the split API (step1 | inverse | step2 as separate calls)
+    if (!(ph & PH_STEP1)) { s_qvref[i] = S.qvel_ref[vrow + i]; s_applied[i] = S.qfrc_applied[vrow + i]; }
   }
   // hot chain-walk tables and the (possibly per-env) model parameters go to LDS once per launch
   for (int i = lane; i < nv; i += 64) {
@@ -1245,7 +1246,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   for (int i = lane; i < nq; i += 64) S.qpos[qrow + i] = s_qpos[i];
   for (int i = lane; i < nv; i += 64) {
     S.qvel[vrow + i] = s_qvel[i]; S.qacc_ws[vrow + i] = s_ws[i]; S.qacc[vrow + i] = s_qacc[i];
-    S.qvel_ref[vrow + i] = s_qvref[i]; S.qfrc_applied[vrow + i] = s_applied[i];
+    if (!((ph & PH_STEP1) && (ph & PH_STEP2))) { S.qvel_ref[vrow + i] = s_qvref[i]; S.qfrc_applied[vrow + i] = s_applied[i]; }
   }
   if (lane == 0) {
     S.time[env] = time;
