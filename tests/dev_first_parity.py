@@ -1,7 +1,7 @@
 """Ad-hoc GPU-vs-oracle comparison used while bringing the kernel up (not a test)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import mujoco_sim_amd as ms
 import orc

@@ -267,6 +267,60 @@ def test_odom_velocities_on_device(lib):
     e.close()
 
 
+def _compare_rollout(m, q0, nsteps_list, tols, v0=None, nenv=2):
+    e = ms.Engine(m, nenv)
+    e.set_initial_qpos(np.tile(q0, (nenv, 1))); e.reset()
+    d = orc.OrcData(m.ptr); d.set_qpos(q0); d.call("reset")
+    if v0 is not None:
+        e.set_state(qvel=np.tile(v0, (nenv, 1))); d.f("qvel")[:] = v0
+    done = 0
+    for n, tol in zip(nsteps_list, tols):
+        e.step(n - done); d.step(n - done); done = n
+        _, q, v, _ = e.get_state()
+        st = e.get_stats()
+        assert st[0, 3] == 0 and d.i("warn") == 0
+        np.testing.assert_allclose(q[0], d.f("qpos"), atol=tol, err_msg=f"step {n}")
+        np.testing.assert_array_equal(q[0], q[1])
+    out = (e.get_stats()[0].copy(), d.i("ncon"), d.i("nefc"))
+    e.close()
+    return out
+
+
+def test_box_pile_nv48_single_block_sweep(lib):
+    """8 free boxes (nv = 48 > 32): exercises the full-wave single-block PGS sweep (NROW = 4) and box-box stacks"""
+    m = ms.scene("boxpile", 8)
+    assert m.nv == 48
+    q0 = m.array("qpos0").copy()
+    rng = np.random.default_rng(7)
+    for k in range(8):                       # drop them closer together so they collide with each other
+        q0[7*k:7*k+2] *= 0.55; q0[7*k+2] = 0.12 + 0.22 * (k // 4) + 0.01 * k
+        quat = rng.normal(size=4) * 0.15 + np.array([1, 0, 0, 0]); q0[7*k+3:7*k+7] = quat / np.linalg.norm(quat)
+    st, ncon, nefc = _compare_rollout(m, q0, [1, 40, 120], [1e-5, 5e-4, 2e-2])
+    assert ncon >= 8 and st[0] == ncon and st[1] == nefc
+
+
+def test_mixed_primitives_scene(lib):
+    """sphere / capsule / box free bodies on the plane and on each other: every narrow-phase routine on the device"""
+    b = lib.mjh_builder_create()
+    set_opt(lib, b, timestep=0.005)
+    lib.mjh_builder_add_geom(b, b"floor", 0, 0, D(0, 0, 0.05), None, None, None, -1, -1, -1, -1)
+    specs = [(b"s1", 2, (0.08, 0, 0), (0.0, 0.0, 0.30)), (b"s2", 2, (0.06, 0, 0), (0.02, 0.01, 0.52)),
+             (b"c1", 3, (0.04, 0.12, 0), (0.25, 0.0, 0.10)), (b"c2", 3, (0.04, 0.10, 0), (0.27, 0.03, 0.30)),
+             (b"b1", 6, (0.10, 0.08, 0.05), (0.0, 0.0, 0.06)), (b"s3", 2, (0.05, 0, 0), (0.27, 0.0, 0.45))]
+    for name, gt, size, pos in specs:
+        bd = lib.mjh_builder_add_body(b, name, 0, D(*pos), None, 0.0)
+        lib.mjh_builder_add_joint(b, None, bd, 0, None, None, None, 0, 0, 0, 0, 0)
+        lib.mjh_builder_add_geom(b, None, bd, gt, D(*size), None, None, None, -1, -1, -1, -1)
+    m = ms.Model(lib.mjh_builder_compile(b), lib)
+    lib.mjh_builder_destroy(b)
+    assert m.nv == 36
+    q0 = m.array("qpos0").copy()
+    q0[7*2+3:7*2+7] = [np.cos(0.7), 0, np.sin(0.7), 0]      # tilt the capsules
+    q0[7*3+3:7*3+7] = [np.cos(0.5), np.sin(0.5), 0, 0]
+    st, ncon, nefc = _compare_rollout(m, q0, [1, 60, 160], [1e-5, 1e-3, 3e-2])
+    assert ncon >= 4
+
+
 def test_reset_and_bad_state_recovery(s24):
     m, e, tab, ds = s24
     e.reset(); e.step(30)
