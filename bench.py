@@ -54,7 +54,7 @@ def cpu_baseline(model, eng, tab, env_offset, sample_envs, sample_steps, with_in
     ncores = os.cpu_count() or 1
     out = {}
     for label, threads in (("mt", ncores), ("st", 1)):
-        n_envs = sample_envs if threads > 1 else max(1, min(sample_envs, 4))
+        n_envs = sample_envs if threads > 1 else max(1, min(sample_envs, 8))
         L.orc_set_threads(threads)
         t0 = time.perf_counter()
         L.orc_step_many(arr, n_envs, sample_steps, with_inverse)
@@ -76,11 +76,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--with-inverse", type=int, default=0, help="also run mj_inverse every step (MjHWInterface::read)")
-    ap.add_argument("--fuse", type=int, default=1, help="steps per kernel launch (1 = reference-shaped host loop)")
+    ap.add_argument("--fuse", type=int, default=1, help="steps between host hand-offs (one kernel launch per step either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--cpu-envs", type=int, default=64)
-    ap.add_argument("--cpu-steps", type=int, default=40)
+    ap.add_argument("--cpu-envs", type=int, default=1024)
+    ap.add_argument("--cpu-steps", type=int, default=100)
     args = ap.parse_args()
 
     import torch
@@ -159,7 +159,7 @@ def main():
         except Exception:
             traffic = None
     out = {
-        "metric": "env-steps/sec (whole node) at 4096 envs/GPU, 24-DoF/30-contact scene (S24)",
+        "metric": "env-steps/sec (whole node) at 4096 envs, 24-DoF/30-contact scene; 1/2/4/8 GPUs",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
