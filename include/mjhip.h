@@ -158,6 +158,13 @@ void mjh_model_destroy(mjh_model*);
 int mjh_name2id(const mjh_model*, int objtype /*0 body,1 joint,2 geom*/, const char* name);
 const char* mjh_id2name(const mjh_model*, int objtype, int id);
 
+/* MJCF-subset loader: replaces load_XML -> mj_loadXML (include/mujoco_sim/mj_util.h:185-193) for the element
+ * subset the reference models use on the step path (see csrc/mjcf_loader.cpp).  Returns NULL + mjh_last_error()
+ * on failure; mjh_load_note() lists what was skipped (mesh geoms, <include>, default classes, ...). */
+mjh_model* mjh_load_mjcf_string(const char* xml);
+mjh_model* mjh_load_mjcf_file(const char* path);
+const char* mjh_load_note(void);
+
 /* ------------------------------------------------------ scene builders */
 /* SURVEY.md §8-d configs, as programmatic models.  `seed_base+env` seeds PCG32. */
 mjh_model* mjh_scene_s24(void); /* 4 free boxes in a walled pen on the empty.xml floor  */

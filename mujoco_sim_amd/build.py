@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmjhip.so")
-SOURCES = ["engine.hip", "model_builder.cpp", "scenes.cpp", "host_sim.cpp"]
+SOURCES = ["engine.hip", "model_builder.cpp", "scenes.cpp", "host_sim.cpp", "mjcf_loader.cpp"]
 DEPS = SOURCES + ["step_kernel.h", "dev_math.h", "dev_collide.h", "dev_types.h", "hmath.h", "host_sim.h",
                   os.path.join("..", "..", "include", "mjhip.h")]
 

@@ -105,6 +105,9 @@ SYMBOLS = [
     ("mjh_model_destroy", None, [Model_p]),
     ("mjh_name2id", C.c_int, [Model_p, C.c_int, C.c_char_p]),
     ("mjh_id2name", C.c_char_p, [Model_p, C.c_int, C.c_int]),
+    ("mjh_load_mjcf_string", Model_p, [C.c_char_p]),
+    ("mjh_load_mjcf_file", Model_p, [C.c_char_p]),
+    ("mjh_load_note", C.c_char_p, []),
     ("mjh_scene_s24", Model_p, []),
     ("mjh_scene_s24_randomize", C.c_int, [Model_p, C.c_int, C.c_int, C.c_uint] + [c_double_p] * 7),
     ("mjh_scene_pendulum", Model_p, []),

@@ -1,0 +1,283 @@
+// mjcf_loader.cpp — MJCF-subset loader: the model-ingest boundary of the reference
+// (load_XML -> mj_loadXML, include/mujoco_sim/mj_util.h:185-193) for the element subset its models use on
+// the step path: <compiler angle autolimits>, <option timestep gravity impratio iterations tolerance>,
+// root <default> (<geom>, <joint>), <worldbody>/<body> trees with <inertial>, <joint> (free, ball, hinge, slide),
+// <freejoint>, <geom> (plane, sphere, capsule, cylinder, box; mesh geoms are skipped with a note), gravcomp,
+// <contact><exclude>, <equality><joint polycoef>.  Everything is translated into mjh_builder_* calls; physics
+// defaults follow MuJoCo's documented defaults (angle = degree, hinge axis 0 0 1, geom type sphere, ...).
+// Not handled (reported in the returned note): <include>, default classes, tendons, actuators, sensors, mocap, fromto.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/mjhip.h"
+#include "hmath.h"
+
+void mjh_set_error(const std::string& s);
+
+namespace {
+
+struct Node {
+  std::string tag;
+  std::vector<std::pair<std::string, std::string>> attr;
+  std::vector<std::unique_ptr<Node>> kids;
+  const char* get(const char* k) const { for (auto& a : attr) if (a.first == k) return a.second.c_str(); return nullptr; }
+};
+
+// ---- minimal XML reader: elements, attributes, comments, declarations; character data is ignored
+struct Xml {
+  const char* p; const char* end; std::string err;
+  void skip_ws() { while (p < end && std::isspace((unsigned char)*p)) p++; }
+  bool starts(const char* s) const { size_t n = std::strlen(s); return (size_t)(end - p) >= n && std::strncmp(p, s, n) == 0; }
+  bool skip_misc() {  // whitespace, comments, <? ?>, <! >, text
+    for (;;) {
+      while (p < end && *p != '<') p++;
+      if (p >= end) return true;
+      if (starts("<!--")) { const char* q = std::strstr(p + 4, "-->"); if (!q) { err = "unterminated comment"; return false; } p = q + 3; continue; }
+      if (starts("<?")) { const char* q = std::strstr(p + 2, "?>"); if (!q) { err = "unterminated declaration"; return false; } p = q + 2; continue; }
+      if (starts("<!")) { const char* q = std::strchr(p, '>'); if (!q) { err = "unterminated <!"; return false; } p = q + 1; continue; }
+      return true;
+    }
+  }
+  std::unique_ptr<Node> element() {
+    if (!skip_misc() || p >= end || *p != '<' || p[1] == '/') return nullptr;
+    p++;
+    auto n = std::make_unique<Node>();
+    while (p < end && !std::isspace((unsigned char)*p) && *p != '>' && *p != '/') n->tag.push_back(*p++);
+    for (;;) {
+      skip_ws();
+      if (p >= end) { err = "unexpected end in <" + n->tag + ">"; return nullptr; }
+      if (*p == '/') { if (p + 1 < end && p[1] == '>') { p += 2; return n; } err = "bad '/' in <" + n->tag + ">"; return nullptr; }
+      if (*p == '>') { p++; break; }
+      std::string k, v;
+      while (p < end && *p != '=' && !std::isspace((unsigned char)*p)) k.push_back(*p++);
+      skip_ws();
+      if (p >= end || *p != '=') { err = "attribute without value in <" + n->tag + ">"; return nullptr; }
+      p++; skip_ws();
+      if (p >= end || (*p != '"' && *p != '\'')) { err = "unquoted attribute in <" + n->tag + ">"; return nullptr; }
+      const char q = *p++;
+      while (p < end && *p != q) v.push_back(*p++);
+      if (p >= end) { err = "unterminated attribute in <" + n->tag + ">"; return nullptr; }
+      p++;
+      n->attr.push_back({k, v});
+    }
+    for (;;) {  // children until the matching close tag
+      if (!skip_misc()) return nullptr;
+      if (p >= end) { err = "missing </" + n->tag + ">"; return nullptr; }
+      if (p[1] == '/') {
+        const char* q = std::strchr(p, '>');
+        if (!q) { err = "unterminated close tag"; return nullptr; }
+        std::string t(p + 2, q); while (!t.empty() && std::isspace((unsigned char)t.back())) t.pop_back();
+        if (t != n->tag) { err = "mismatched </" + t + "> for <" + n->tag + ">"; return nullptr; }
+        p = q + 1; return n;
+      }
+      auto c = element();
+      if (!c) return nullptr;
+      n->kids.push_back(std::move(c));
+    }
+  }
+};
+
+int nums(const char* s, double* out, int maxn) {
+  int n = 0; if (!s) return 0;
+  char* e;
+  while (n < maxn) { while (*s && (std::isspace((unsigned char)*s) || *s == ',')) s++; if (!*s) break; double v = std::strtod(s, &e); if (e == s) break; out[n++] = v; s = e; }
+  return n;
+}
+
+struct Defaults {
+  double geom_friction[3] = {1, 0.005, 0.0001}; int geom_condim = 3, geom_contype = 1, geom_conaffinity = 1; double geom_density = 1000;
+  double jnt_damping = 0, jnt_stiffness = 0, jnt_armature = 0, jnt_frictionloss = 0;
+};
+
+struct Loader {
+  mjh_builder* b = nullptr;
+  bool degree = true, autolimits = false;
+  Defaults def;
+  std::map<std::string, int> body_id, joint_id;
+  std::string note;
+  int nameless = 0;
+
+  double ang(double v) const { return degree ? v * 3.14159265358979323846 / 180.0 : v; }
+  bool orientation(const Node& n, double* quat) {   // quat | euler (xyz) ; returns false if neither
+    double v[4];
+    if (nums(n.get("quat"), v, 4) == 4) { for (int i = 0; i < 4; i++) quat[i] = v[i]; hm::normalize4(quat); return true; }
+    if (nums(n.get("euler"), v, 3) == 3) {
+      double q[4] = {1, 0, 0, 0};
+      for (int k = 0; k < 3; k++) { double ax[3] = {0, 0, 0}; ax[k] = 1; double r[4], t[4]; hm::axisangle2quat(r, ax, ang(v[k])); hm::mulquat(t, q, r); std::memcpy(q, t, sizeof q); }
+      std::memcpy(quat, q, sizeof q); return true;
+    }
+    return false;
+  }
+  void geom(const Node& n, int body) {
+    const char* type = n.get("type");
+    int gt = MJH_GEOM_SPHERE;
+    if (type) {
+      std::string t = type;
+      if (t == "plane") gt = MJH_GEOM_PLANE; else if (t == "sphere") gt = MJH_GEOM_SPHERE; else if (t == "capsule") gt = MJH_GEOM_CAPSULE;
+      else if (t == "cylinder") gt = MJH_GEOM_CYLINDER; else if (t == "box") gt = MJH_GEOM_BOX;
+      else { note += "skipped <geom type=\"" + t + "\">; "; return; }
+    }
+    if (n.get("fromto")) { note += "skipped <geom fromto>; "; return; }
+    double size[3] = {0, 0, 0}, pos[3] = {0, 0, 0}, quat[4] = {1, 0, 0, 0}, fr[3];
+    nums(n.get("size"), size, 3); nums(n.get("pos"), pos, 3); orientation(n, quat);
+    std::memcpy(fr, def.geom_friction, sizeof fr);
+    double t3[3]; int nf = nums(n.get("friction"), t3, 3); for (int i = 0; i < nf; i++) fr[i] = t3[i];
+    double v; int condim = def.geom_condim, contype = def.geom_contype, conaff = def.geom_conaffinity; double density = def.geom_density;
+    if (nums(n.get("condim"), &v, 1)) condim = (int)v;
+    if (nums(n.get("contype"), &v, 1)) contype = (int)v;
+    if (nums(n.get("conaffinity"), &v, 1)) conaff = (int)v;
+    if (nums(n.get("density"), &v, 1)) density = v;
+    mjh_builder_add_geom(b, n.get("name"), body, gt, size, pos, quat, fr, condim, contype, conaff, density);
+  }
+  bool joint(const Node& n, int body, bool freejoint) {
+    int type = MJH_JNT_HINGE;
+    if (freejoint) type = MJH_JNT_FREE;
+    else if (const char* t = n.get("type")) {
+      std::string s = t;
+      if (s == "free") type = MJH_JNT_FREE; else if (s == "ball") type = MJH_JNT_BALL; else if (s == "slide") type = MJH_JNT_SLIDE; else if (s == "hinge") type = MJH_JNT_HINGE;
+      else { mjh_set_error("unknown joint type " + s); return false; }
+    }
+    double pos[3] = {0, 0, 0}, axis[3] = {0, 0, 1}, range[2] = {0, 0}, v;
+    nums(n.get("pos"), pos, 3); nums(n.get("axis"), axis, 3);
+    const bool hasrange = nums(n.get("range"), range, 2) == 2;
+    bool limited = false;
+    if (const char* l = n.get("limited")) { std::string s = l; limited = s == "true" || (s == "auto" && hasrange); }
+    else limited = autolimits && hasrange;
+    if (limited && type == MJH_JNT_HINGE) { range[0] = ang(range[0]); range[1] = ang(range[1]); }
+    double damping = def.jnt_damping, stiffness = def.jnt_stiffness, armature = def.jnt_armature, floss = def.jnt_frictionloss, ref = 0;
+    if (nums(n.get("damping"), &v, 1)) damping = v;
+    if (nums(n.get("stiffness"), &v, 1)) stiffness = v;
+    if (nums(n.get("armature"), &v, 1)) armature = v;
+    if (nums(n.get("frictionloss"), &v, 1)) floss = v;
+    if (nums(n.get("ref"), &v, 1)) ref = type == MJH_JNT_HINGE ? ang(v) : v;
+    std::string name = n.get("name") ? n.get("name") : ("joint" + std::to_string(nameless++));
+    int id = mjh_builder_add_joint(b, name.c_str(), body, type, pos, axis, limited ? range : nullptr, damping, stiffness, armature, floss, ref);
+    if (id < 0) return false;
+    joint_id[name] = id;
+    return true;
+  }
+  bool body(const Node& n, int parent) {
+    double pos[3] = {0, 0, 0}, quat[4] = {1, 0, 0, 0}, gc = 0;
+    nums(n.get("pos"), pos, 3); orientation(n, quat); nums(n.get("gravcomp"), &gc, 1);
+    std::string name = n.get("name") ? n.get("name") : ("body" + std::to_string(nameless++));
+    int id = mjh_builder_add_body(b, name.c_str(), parent, pos, quat, gc);
+    if (id < 0) return false;
+    body_id[name] = id;
+    return children(n, id);
+  }
+  bool children(const Node& n, int body) {
+    for (auto& c : n.kids) {
+      if (c->tag == "geom") geom(*c, body);
+      else if (c->tag == "body") { if (!this->body(*c, body)) return false; }
+      else if (c->tag == "joint" || c->tag == "freejoint") {
+        if (body == 0) { mjh_set_error("joint in worldbody"); return false; }
+        if (!joint(*c, body, c->tag == "freejoint")) return false;
+      } else if (c->tag == "inertial") {
+        double ipos[3] = {0, 0, 0}, iq[4] = {1, 0, 0, 0}, mass = 0, di[3] = {0, 0, 0};
+        nums(c->get("pos"), ipos, 3); orientation(*c, iq); nums(c->get("mass"), &mass, 1);
+        if (nums(c->get("diaginertia"), di, 3) != 3) { mjh_set_error("<inertial> needs diaginertia (fullinertia is not supported)"); return false; }
+        mjh_builder_set_inertial(b, body, mass, ipos, iq, di);
+      } else if (c->tag != "light" && c->tag != "camera" && c->tag != "site") note += "ignored <" + c->tag + ">; ";
+    }
+    return true;
+  }
+  mjh_model* run(const Node& root) {
+    if (root.tag != "mujoco") { mjh_set_error("root element must be <mujoco>"); return nullptr; }
+    b = mjh_builder_create();
+    mjh_option o; mjh_builder_get_option(b, &o);
+    // first pass: compiler / option / default (they may appear after worldbody in a file)
+    for (auto& c : root.kids) {
+      if (c->tag == "compiler") {
+        if (const char* a = c->get("angle")) degree = std::string(a) != "radian";
+        if (const char* a = c->get("autolimits")) autolimits = std::string(a) == "true";
+      } else if (c->tag == "option") {
+        double v, g[3];
+        if (nums(c->get("timestep"), &v, 1)) o.timestep = v;
+        if (nums(c->get("gravity"), g, 3) == 3) std::memcpy(o.gravity, g, sizeof g);
+        if (nums(c->get("impratio"), &v, 1)) o.impratio = v;
+        if (nums(c->get("iterations"), &v, 1)) o.iterations = (int)v;
+        if (nums(c->get("tolerance"), &v, 1)) o.tolerance = v;
+        if (nums(c->get("noslip_iterations"), &v, 1)) { o.noslip_iterations = (int)v; if (v > 0) note += "noslip_iterations ignored; "; }
+        if (const char* s = c->get("solver")) if (std::string(s) != "PGS") note += std::string("solver=") + s + " -> PGS; ";
+        for (auto& f : c->kids) if (f->tag == "flag") {
+          if (const char* s = f->get("gravity")) if (std::string(s) == "disable") o.disableflags |= MJH_DSBL_GRAVITY;
+          if (const char* s = f->get("contact")) if (std::string(s) == "disable") o.disableflags |= MJH_DSBL_CONTACT;
+          if (const char* s = f->get("limit")) if (std::string(s) == "disable") o.disableflags |= MJH_DSBL_LIMIT;
+          if (const char* s = f->get("warmstart")) if (std::string(s) == "disable") o.disableflags |= MJH_DSBL_WARMSTART;
+        }
+      } else if (c->tag == "default") {
+        for (auto& dflt : c->kids) {
+          double v, t3[3];
+          if (dflt->tag == "geom") {
+            int nf = nums(dflt->get("friction"), t3, 3); for (int i = 0; i < nf; i++) def.geom_friction[i] = t3[i];
+            if (nums(dflt->get("condim"), &v, 1)) def.geom_condim = (int)v;
+            if (nums(dflt->get("contype"), &v, 1)) def.geom_contype = (int)v;
+            if (nums(dflt->get("conaffinity"), &v, 1)) def.geom_conaffinity = (int)v;
+            if (nums(dflt->get("density"), &v, 1)) def.geom_density = v;
+          } else if (dflt->tag == "joint") {
+            if (nums(dflt->get("damping"), &v, 1)) def.jnt_damping = v;
+            if (nums(dflt->get("stiffness"), &v, 1)) def.jnt_stiffness = v;
+            if (nums(dflt->get("armature"), &v, 1)) def.jnt_armature = v;
+            if (nums(dflt->get("frictionloss"), &v, 1)) def.jnt_frictionloss = v;
+          } else if (dflt->tag == "default") note += "default classes ignored; ";
+        }
+      }
+    }
+    mjh_builder_set_option(b, &o);
+    for (auto& c : root.kids) if (c->tag == "worldbody") if (!children(*c, 0)) { mjh_builder_destroy(b); return nullptr; }
+    for (auto& c : root.kids) {
+      if (c->tag == "contact") {
+        for (auto& e : c->kids) if (e->tag == "exclude") {
+          auto i1 = body_id.find(e->get("body1") ? e->get("body1") : ""), i2 = body_id.find(e->get("body2") ? e->get("body2") : "");
+          if (i1 == body_id.end() || i2 == body_id.end()) { mjh_set_error("<exclude> names an unknown body"); mjh_builder_destroy(b); return nullptr; }
+          mjh_builder_add_exclude(b, i1->second, i2->second);
+        }
+      } else if (c->tag == "equality") {
+        for (auto& e : c->kids) {
+          if (e->tag != "joint") { note += "ignored <equality><" + e->tag + ">; "; continue; }
+          auto j1 = joint_id.find(e->get("joint1") ? e->get("joint1") : "");
+          if (j1 == joint_id.end()) { mjh_set_error("<equality><joint> names an unknown joint1"); mjh_builder_destroy(b); return nullptr; }
+          int j2 = -1;
+          if (e->get("joint2")) { auto it = joint_id.find(e->get("joint2")); if (it == joint_id.end()) { mjh_set_error("unknown joint2"); mjh_builder_destroy(b); return nullptr; } j2 = it->second; }
+          double poly[5] = {0, 1, 0, 0, 0}, t5[5]; int np = nums(e->get("polycoef"), t5, 5); for (int i = 0; i < np; i++) poly[i] = t5[i];
+          mjh_builder_add_eq_joint(b, j1->second, j2, poly);
+        }
+      } else if (c->tag != "compiler" && c->tag != "option" && c->tag != "default" && c->tag != "worldbody" && c->tag != "asset" && c->tag != "visual" && c->tag != "size" && c->tag != "statistic")
+        note += "ignored <" + c->tag + ">; ";
+    }
+    mjh_model* m = mjh_builder_compile(b);
+    mjh_builder_destroy(b);
+    return m;
+  }
+};
+
+thread_local std::string g_note;
+
+}  // namespace
+
+extern "C" mjh_model* mjh_load_mjcf_string(const char* xml) {
+  g_note.clear();
+  if (!xml) { mjh_set_error("null xml"); return nullptr; }
+  Xml x{xml, xml + std::strlen(xml), {}};
+  auto root = x.element();
+  if (!root) { mjh_set_error("MJCF parse error: " + (x.err.empty() ? std::string("no root element") : x.err)); return nullptr; }
+  Loader L;
+  mjh_model* m = L.run(*root);
+  g_note = L.note;
+  return m;
+}
+extern "C" mjh_model* mjh_load_mjcf_file(const char* path) {
+  std::ifstream f(path ? path : "");
+  if (!f) { mjh_set_error(std::string("cannot open ") + (path ? path : "(null)")); return nullptr; }
+  std::stringstream ss; ss << f.rdbuf();
+  return mjh_load_mjcf_string(ss.str().c_str());
+}
+extern "C" const char* mjh_load_note(void) { return g_note.c_str(); }

@@ -55,6 +55,15 @@ class Model:
         return out
 
 
+def load_mjcf(xml=None, path=None):
+    """MJCF-subset loader (mj_loadXML boundary, mj_util.h:185-193)"""
+    lib = capi.load()
+    ptr = lib.mjh_load_mjcf_file(path.encode()) if path else lib.mjh_load_mjcf_string(xml.encode())
+    m = Model(ptr, lib)
+    m.note = lib.mjh_load_note().decode()
+    return m
+
+
 def scene(name, *args):
     lib = capi.load()
     fn = {"s24": lib.mjh_scene_s24, "pendulum": lib.mjh_scene_pendulum, "arm7": lib.mjh_scene_arm7,

@@ -1,0 +1,111 @@
+"""MJCF-subset loader — CPU tests.  The XML below is this repo's own test data; the last
+test additionally parses the reference's pendulum.xml when the reference tree is present (CPU container only)."""
+import os
+
+import numpy as np
+import pytest
+
+import mujoco_sim_amd as ms
+import orc
+from helpers import D, set_opt
+
+ARM = """<?xml version="1.0"?>
+<mujoco model="two_link">
+  <compiler angle="degree" autolimits="true"/>
+  <option timestep="0.002" gravity="0 0 -9.81" iterations="50" tolerance="1e-9"><flag warmstart="enable"/></option>
+  <default><joint damping="0.2"/><geom friction="0.8 0.01 0.001" condim="4"/></default>
+  <!-- a comment <with> markup -->
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    <body name="upper" pos="0 0 1.5" euler="0 0 90">
+      <joint name="shoulder" axis="0 1 0" range="-90 45"/>
+      <geom name="upper_g" type="capsule" size=".04 .25" pos="0 0 -.25"/>
+      <body name="lower" pos="0 0 -.5">
+        <joint name="elbow" type="hinge" axis="0 1 0" damping="0.05" limited="false" range="-10 10"/>
+        <inertial pos="0 0 -.2" mass="1.2" diaginertia=".02 .02 .002"/>
+        <geom type="box" size=".03 .03 .2" pos="0 0 -.2" friction="1.5"/>
+      </body>
+    </body>
+    <body name="ball" pos="0.5 0 0.3" gravcomp="1">
+      <freejoint name="ball_free"/>
+      <geom type="sphere" size=".1" density="500"/>
+      <geom type="mesh" mesh="nope"/>
+    </body>
+  </worldbody>
+  <contact><exclude body1="upper" body2="lower"/></contact>
+  <equality><joint joint1="elbow" joint2="shoulder" polycoef="0.1 2"/></equality>
+  <actuator/>
+</mujoco>
+"""
+
+
+def test_loader_matches_builder_api(lib):
+    m = ms.load_mjcf(ARM)
+    assert "mesh" in m.note and "actuator" in m.note
+    assert (m.nq, m.nv, m.nbody, m.njnt, m.neq) == (9, 8, 4, 3, 1)
+    assert m.opt.timestep == 0.002 and m.opt.iterations == 50 and m.opt.tolerance == 1e-9
+    assert [m.name2id(1, n) for n in ("shoulder", "elbow", "ball_free")] == [0, 1, 2]
+    # degrees -> radians for hinge ranges, autolimits, explicit limited="false"
+    np.testing.assert_allclose(m.array("jnt_range")[:2], np.deg2rad([-90, 45]))
+    np.testing.assert_array_equal(m.array("jnt_limited"), [1, 0, 0])
+    np.testing.assert_allclose(m.array("dof_damping")[:2], [0.2, 0.05])
+    # euler 0 0 90 (degrees) -> quaternion about z
+    np.testing.assert_allclose(m.array("body_quat")[4:8], [np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)], atol=1e-12)
+    # defaults + overrides on geoms
+    fr = m.array("geom_friction").reshape(-1, 3)
+    np.testing.assert_allclose(fr[m.name2id(2, "upper_g")], [0.8, 0.01, 0.001]); np.testing.assert_allclose(fr[2], [1.5, 0.01, 0.001])
+    assert (m.array("geom_condim") == 4).all()
+    # explicit inertial vs geom-derived (sphere, density 500)
+    mass = m.array("body_mass")
+    np.testing.assert_allclose(mass[2], 1.2); np.testing.assert_allclose(mass[3], 500 * 4 / 3 * np.pi * 1e-3)
+    assert m.array("body_gravcomp")[3] == 1
+    np.testing.assert_allclose(m.array("eq_data")[:2], [0.1, 2.0])
+    # the upper/lower pair is excluded (and parent-filtered anyway); ball vs arm geoms remain
+    pairs = set(zip(m.array("pair_geom1").tolist(), m.array("pair_geom2").tolist()))
+    assert (1, 2) not in pairs and len(pairs) >= 3
+    # same model through the builder API gives the same derived constants
+    b = lib.mjh_builder_create(); set_opt(lib, b, timestep=0.002, iterations=50, tolerance=1e-9)
+    fr = D(0.8, 0.01, 0.001)
+    lib.mjh_builder_add_geom(b, b"floor", 0, 0, D(0, 0, .05), None, None, fr, 4, -1, -1, -1)
+    u = lib.mjh_builder_add_body(b, b"upper", 0, D(0, 0, 1.5), D(np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)), 0.0)
+    lib.mjh_builder_add_joint(b, b"shoulder", u, 3, None, D(0, 1, 0), D(*np.deg2rad([-90, 45])), 0.2, 0, 0, 0, 0)
+    lib.mjh_builder_add_geom(b, b"upper_g", u, 3, D(.04, .25, 0), D(0, 0, -.25), None, fr, 4, -1, -1, -1)
+    lo = lib.mjh_builder_add_body(b, b"lower", u, D(0, 0, -.5), None, 0.0)
+    lib.mjh_builder_add_joint(b, b"elbow", lo, 3, None, D(0, 1, 0), None, 0.05, 0, 0, 0, 0)
+    lib.mjh_builder_set_inertial(b, lo, 1.2, D(0, 0, -.2), None, D(.02, .02, .002))
+    lib.mjh_builder_add_geom(b, None, lo, 6, D(.03, .03, .2), D(0, 0, -.2), None, D(1.5, 0.01, 0.001), 4, -1, -1, -1)
+    ba = lib.mjh_builder_add_body(b, b"ball", 0, D(.5, 0, .3), None, 1.0)
+    lib.mjh_builder_add_joint(b, b"ball_free", ba, 0, None, None, None, 0.2, 0, 0, 0, 0)
+    lib.mjh_builder_add_geom(b, None, ba, 2, D(.1, 0, 0), None, None, fr, 4, -1, -1, 500.0)
+    lib.mjh_builder_add_exclude(b, u, lo); lib.mjh_builder_add_eq_joint(b, 1, 0, D(0.1, 2, 0, 0, 0))
+    ref = ms.Model(lib.mjh_builder_compile(b), lib); lib.mjh_builder_destroy(b)
+    for name in ("body_mass", "body_inertia", "body_invweight0", "dof_invweight0", "qpos0", "geom_rbound", "dof_damping"):
+        np.testing.assert_allclose(m.array(name), ref.array(name), rtol=1e-12, atol=1e-14, err_msg=name)
+    assert abs(m.meaninertia - ref.meaninertia) < 1e-12
+    # and it steps in the oracle
+    d = orc.OrcData(m.ptr); d.step(50)
+    assert np.isfinite(d.f("qpos")).all() and d.i("nefc") >= 1          # the joint equality row is always there
+
+
+def test_loader_rejects_malformed_input(lib):
+    for bad, msg in (("<mujoco><worldbody><body></worldbody></mujoco>", "mismatched"), ("<nope/>", "root element"),
+                     ("<mujoco><worldbody><joint/></worldbody></mujoco>", "joint in worldbody"),
+                     ("<mujoco><worldbody><body><joint type='screw'/></body></worldbody></mujoco>", "unknown joint type")):
+        assert not lib.mjh_load_mjcf_string(bad.encode())
+        assert msg in lib.mjh_last_error().decode(), (bad, lib.mjh_last_error())
+    assert not lib.mjh_load_mjcf_file(b"/no/such/file.xml")
+
+
+REF_PENDULUM = "/root/reference/model/test/pendulum.xml"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_PENDULUM), reason="reference tree only exists in the CPU container")
+def test_reference_pendulum_xml_equals_the_restated_scene(lib):
+    """C1: the programmatic scene (csrc/scenes.cpp) restates model/test/pendulum.xml exactly"""
+    a = ms.load_mjcf(path=REF_PENDULUM)
+    b = ms.scene("pendulum")
+    assert (a.nq, a.nv, a.nbody, a.ngeom) == (b.nq, b.nv, b.nbody, b.ngeom)
+    for name in ("body_pos", "body_mass", "body_inertia", "jnt_pos", "jnt_type", "dof_damping", "geom_type", "geom_size", "qpos0",
+                 "body_invweight0", "dof_invweight0"):
+        np.testing.assert_allclose(a.array(name), b.array(name), rtol=1e-12, atol=1e-14, err_msg=name)
+    assert a.opt.timestep == b.opt.timestep and a.opt.gravity[2] == b.opt.gravity[2] == -0.1
