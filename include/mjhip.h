@@ -245,6 +245,12 @@ int mjh_set_env_param(mjh_engine*, int which, int env0, int n, const double* val
 int mjh_set_initial_qpos(mjh_engine*, int env0, int n, const double* qpos);
 int mjh_reset(mjh_engine*, const int* env_ids, int n);
 
+/* spawn / destroy as per-env slot toggling (reference: spawn_objects / destroy_objects services,
+ * mj_ros.cpp:859-1507, which re-compile the whole model): an inactive slot does not collide and is frozen */
+int mjh_set_slot_active(mjh_engine*, int env0, int n, int body, int active);
+/* initial pose / twist of a spawned free body (mj_ros.cpp:1406-1412) */
+int mjh_set_body_pose(mjh_engine*, int env, int body, const double pos[3], const double quat[4], const double vel[6]);
+
 /* zero-copy export for the single ROS state topic: packs time(1)+qpos(nq)+qvel(nv)
  * fp32 per env into a caller-provided DEVICE buffer [nenv*(1+nq+nv)] on the engine's
  * stream (feeds the RCCL all-gather). */

@@ -137,6 +137,8 @@ SYMBOLS = [
     ("mjh_set_env_param", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, c_double_p]),
     ("mjh_set_initial_qpos", C.c_int, [_vp, C.c_int, C.c_int, c_double_p]),
     ("mjh_reset", C.c_int, [_vp, c_int_p, C.c_int]),
+    ("mjh_set_slot_active", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("mjh_set_body_pose", C.c_int, [_vp, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p]),
     ("mjh_export_state_device", C.c_int, [_vp, _vp]),
     ("mjh_state_stride", C.c_int, [_vp]),
     ("mjh_debug_stage_cycles", C.c_int, [_vp, C.c_int, c_double_p]),

@@ -479,6 +479,37 @@ extern "C" int mjh_reset(mjh_engine* e, const int* env_ids, int n) {
   return MJH_OK;
 }
 
+// spawn/destroy as batched slot re-layout (reference: spawn_objects / destroy_objects,
+// mj_ros.cpp:906-1507 -> full XML round trip + recompile): a pre-allocated free body is toggled per env.
+extern "C" int mjh_set_slot_active(mjh_engine* e, int env0, int n, int body, int active) {
+  ENG(e); RANGE(e, env0, n);
+  if (body <= 0 || body >= e->M.nbody || body >= 32) { mjh_set_error("mjh_set_slot_active: body must be in [1, 32)"); return MJH_ERR_ARG; }
+  if (!e->S.slot_mask) { int rc = dev_alloc(e, &e->S.slot_mask, (size_t)e->nenv); if (rc) return rc; }
+  std::vector<unsigned> h(n);
+  HIPCHK(hipMemcpyAsync(h.data(), e->S.slot_mask + env0, n * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (int i = 0; i < n; i++) h[i] = active ? (h[i] & ~(1u << body)) : (h[i] | (1u << body));
+  HIPCHK(hipMemcpyAsync(e->S.slot_mask + env0, h.data(), n * sizeof(unsigned), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return MJH_OK;
+}
+// pose + twist of one free body of one env (initial state of a spawned object, mj_ros.cpp:1406-1412)
+extern "C" int mjh_set_body_pose(mjh_engine* e, int env, int body, const double pos[3], const double quat[4], const double vel[6]) {
+  ENG(e); RANGE(e, env, 1);
+  const mjh_model* m = e->model;
+  if (body <= 0 || body >= m->nbody || m->body_jntnum[body] != 1 || m->jnt_type[m->body_jntadr[body]] != MJH_JNT_FREE) {
+    mjh_set_error("mjh_set_body_pose: not a free body"); return MJH_ERR_ARG; }
+  const int qa = m->jnt_qposadr[m->body_jntadr[body]], da = m->body_dofadr[body];
+  float q[7], v[6];
+  for (int k = 0; k < 3; k++) q[k] = (float)pos[k];
+  for (int k = 0; k < 4; k++) q[3+k] = (float)(quat ? quat[k] : (k == 0));
+  for (int k = 0; k < 6; k++) v[k] = (float)(vel ? vel[k] : 0.0);
+  HIPCHK(hipMemcpyAsync(e->S.qpos + (size_t)env * e->M.nqp + qa, q, sizeof q, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->S.qvel + (size_t)env * e->M.nvp + da, v, sizeof v, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return MJH_OK;
+}
+
 extern "C" int mjh_state_stride(const mjh_engine* e) { return e ? 1 + e->M.nq + e->M.nv : 0; }
 extern "C" int mjh_export_state_device(mjh_engine* e, void* d_out) {
   ENG(e); if (!d_out) return MJH_ERR_ARG;

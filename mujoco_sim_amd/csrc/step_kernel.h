@@ -233,6 +233,8 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   for (int i = lane; i < 3 * nbody; i += 64) s_p_inertia[i] = S.p_body_inertia ? S.p_body_inertia[(size_t)env * 3 * nbody + i] : body_inertia[i];
   for (int i = lane; i < 2 * nbody; i += 64) s_p_binv[i] = S.p_body_invweight0 ? S.p_body_invweight0[(size_t)env * 2 * nbody + i] : body_invweight0[i];
   float time = S.time[env];
+  // spawn/destroy as slot toggling: bit b set = body b is an INACTIVE slot in this env
+  const unsigned slotmask = S.slot_mask ? (unsigned)__builtin_amdgcn_readfirstlane((int)S.slot_mask[env]) : 0u;
   int flags = 0, ncon = 0, nefc = 0, niter = 0;
   PROF(0);
   WSYNC();
@@ -448,10 +450,12 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
 #pragma unroll
           for (int k = 0; k < 9; k++) { m1[k] = s_gmat[9*g1+k]; m2[k] = s_gmat[9*g2+k]; }
           bool cull;
+          const int sb1 = geom_bodyid[g1], sb2 = geom_bodyid[g2];
+          const bool parked = ((sb1 < 32 && ((slotmask >> sb1) & 1u)) || (sb2 < 32 && ((slotmask >> sb2) & 1u)));
           float tt[3] = {p2[0]-p1[0], p2[1]-p1[1], p2[2]-p1[2]};
           if (t1 == MJH_GEOM_PLANE) { float nn[3] = {m1[2], m1[5], m1[8]}; cull = dot3(tt, nn) > s_p_rbound[g2] + margin; }
           else { float bound = s_p_rbound[g1] + s_p_rbound[g2] + margin; cull = dot3(tt, tt) > bound * bound; }
-          if (!cull) {
+          if (!cull && !parked) {
             if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_BOX) n = c_plane_box(p1, m1, p2, m2, z2, margin, st);
             else if (t1 == MJH_GEOM_BOX && t2 == MJH_GEOM_BOX) n = c_box_box(p1, m1, z1, p2, m2, z2, margin, st);
             else if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_SPHERE) n = c_plane_sphere(p1, m1, p2, z2[0], margin, st, 0);
@@ -1208,7 +1212,12 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           WSYNC();
           qint = s_tmpv;
         }
-        for (int d = lane; d < nv; d += 64) s_qvel[d] += h * qint[d];
+        for (int d = lane; d < nv; d += 64) {
+          const int bd = dof_bodyid[d];
+          const bool parked = bd < 32 && ((slotmask >> bd) & 1u);      // inactive slot: frozen in place
+          s_qvel[d] = parked ? 0.0f : s_qvel[d] + h * qint[d];
+          if (parked) { s_qacc[d] = 0; s_ws[d] = 0; }
+        }
         WSYNC();
         for (int j = lane; j < njnt; j += 64) {
           const int qa = jnt_qposadr[j], da = jnt_dofadr[j], jt = jnt_type[j];

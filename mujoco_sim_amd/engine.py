@@ -197,6 +197,14 @@ class Engine:
             ids = np.ascontiguousarray(env_ids, dtype=np.int32)
             _chk(self.lib, self.lib.mjh_reset(self.h, capi.iptr(ids), ids.shape[0]), "mjh_reset")
 
+    def set_slot_active(self, body, active, env0=0, n=None):
+        n = self.nenv - env0 if n is None else n
+        _chk(self.lib, self.lib.mjh_set_slot_active(self.h, env0, n, body, int(active)), "mjh_set_slot_active")
+
+    def set_body_pose(self, env, body, pos, quat=None, vel=None):
+        a = [None if x is None else np.ascontiguousarray(x, dtype=np.float64) for x in (pos, quat, vel)]
+        _chk(self.lib, self.lib.mjh_set_body_pose(self.h, env, body, *[capi.dptr(x) for x in a]), "mjh_set_body_pose")
+
     def export_state_device(self, device_ptr):
         _chk(self.lib, self.lib.mjh_export_state_device(self.h, C.c_void_p(device_ptr)), "mjh_export_state_device")
 

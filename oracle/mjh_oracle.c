@@ -628,6 +628,8 @@ void orc_collision(orc_data* d) {
       for (int q = 0; q < n; q++) { rc[q].dist = bd[q]; copyv(rc[q].pos, bp + 3*q, 3); copyv(rc[q].n, bn, 3); }
     }
     if (!n) continue;
+    { int sb1 = m->geom_bodyid[g1], sb2 = m->geom_bodyid[g2];   /* inactive spawn/destroy slots do not collide */
+      if ((sb1 < 32 && ((d->slot_mask >> sb1) & 1u)) || (sb2 < 32 && ((d->slot_mask >> sb2) & 1u))) continue; }
     /* contact parameters [UPSTREAM mj_contactParam]: max condim, max friction, solmix-weighted solref/solimp */
     int dim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
     double fr[3], mix;
@@ -1091,7 +1093,11 @@ void orc_euler(orc_data* d) {
     solve_ld(m, qacc, MhB, dinv);
   }
   double h = m->opt.timestep;
-  for (int i = 0; i < nv; i++) d->qvel[i] += h * qacc[i];
+  for (int i = 0; i < nv; i++) {
+    int bd = m->dof_bodyid[i];
+    if (bd < 32 && ((d->slot_mask >> bd) & 1u)) { d->qvel[i] = 0; d->qacc[i] = 0; d->qacc_warmstart[i] = 0; }  /* parked slot */
+    else d->qvel[i] += h * qacc[i];
+  }
   for (int j = 0; j < m->njnt; j++) {
     int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
     switch (m->jnt_type[j]) {
@@ -1197,8 +1203,10 @@ int orc_int(orc_data* d, const char* name) {
   if (!strcmp(name, "nefc")) return d->nefc;
   if (!strcmp(name, "solver_iter")) return d->solver_iter;
   if (!strcmp(name, "warn")) return d->warn;
+  if (!strcmp(name, "slot_mask")) return (int)d->slot_mask;
   return -1;
 }
+void orc_set_slot_mask(orc_data* d, unsigned mask) { d->slot_mask = mask; }
 int* orc_int_field(orc_data* d, const char* name, int* n) {
   if (!strcmp(name, "controlled")) { *n = d->m->nv; return d->controlled; }
   if (!strcmp(name, "efc_type")) { *n = d->nefc; return d->efc_type; }

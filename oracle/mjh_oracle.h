@@ -54,6 +54,7 @@ typedef struct orc_data {
   double *ddq, *dq, *tau; int* controlled;
   int odom_lin[3], odom_ang[3], odom_angq[3]; double odom_vel[6];
   double* initial_qpos;
+  unsigned slot_mask; /* bit b = body b is an inactive spawn/destroy slot */
   /* scratch */
   double *scr_nv[6], *scr_nM, *scr_efc[3], *scr_B, *scr_body6[3];
 } orc_data;
@@ -107,6 +108,7 @@ int orc_get_contact(orc_data* d, int k, double* dist, double* pos, double* frame
 /* multi-env convenience for the CPU baseline: steps `nenv` independent datas */
 void orc_step_many(orc_data** ds, int nenv, int nsteps, int with_inverse);
 void orc_set_threads(int n);
+void orc_set_slot_mask(orc_data* d, unsigned mask);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,7 @@ def lib():
         L.orc_box_box.restype = C.c_int; L.orc_box_box.argtypes = [dp] * 6 + [C.c_double] + [dp] * 3
         L.orc_step_many.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int]
         L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_set_slot_mask.argtypes = [vp, C.c_uint]
         _lib = L
     return _lib
 

@@ -321,6 +321,45 @@ def test_mixed_primitives_scene(lib):
     assert ncon >= 4
 
 
+def test_mjcf_model_with_equality_limits_and_contacts():
+    """MJCF-loaded model: joint equality (two joints of one tree), hinge limits, gravcomp, ball-vs-arm contacts"""
+    from test_mjcf_loader import ARM
+
+    m = ms.load_mjcf(ARM)
+    q0 = m.array("qpos0").copy()
+    q0[0] = 0.3; q0[1] = 0.7                    # violate the equality a little: it must pull the elbow back
+    q0[2:5] = [0.05, 0.0, 1.6]                   # drop the ball onto the arm
+    st, ncon, nefc = _compare_rollout(m, q0, [1, 80, 250], [1e-5, 2e-3, 3e-2])
+    assert nefc >= 1
+
+
+def test_spawn_destroy_as_slot_toggle(s24):
+    """F2: a destroyed slot neither collides nor moves; re-spawned with a pose and a twist it falls again"""
+    m, e, tab, ds = s24
+    e.reset(); [d.call("reset") for d in ds]
+    top = 4                                           # body id of box3 (top of the column)
+    e.set_slot_active(top, False, env0=2, n=3)        # destroy in envs 2,3,4
+    for i in (2, 3, 4):
+        ds[i].L.orc_set_slot_mask(ds[i].d, 1 << top)
+    e.step(150); [d.step(150) for d in ds[:6]]
+    _, q, v, _ = e.get_state()
+    for i in (2, 3, 4):
+        np.testing.assert_allclose(q[i, 21:28], tab["qpos"][i, 21:28], atol=1e-6)     # parked where it was
+        assert (v[i, 18:24] == 0).all()
+    assert q[0, 23] < tab["qpos"][0, 23] - 0.2                                       # in untouched envs it fell
+    err = np.abs(q[:6] - np.array([d.f("qpos") for d in ds[:6]])).max(axis=1)
+    assert (err < 2e-2).sum() >= 5, err
+    # spawn again: pose + twist, as the spawn service does (mj_ros.cpp:1406-1412)
+    e.set_slot_active(top, True, env0=2, n=3)
+    e.set_body_pose(3, top, [0.0, 0.0, 1.2], [1, 0, 0, 0], [0, 0, -1.0, 0, 0, 0])
+    e.step(60)
+    _, q2, _, _ = e.get_state()
+    assert q2[3, 23] < 1.0
+    e.set_slot_active(top, True); e.reset()
+    for d in ds:
+        d.L.orc_set_slot_mask(d.d, 0)
+
+
 def test_reset_and_bad_state_recovery(s24):
     m, e, tab, ds = s24
     e.reset(); e.step(30)
