@@ -270,6 +270,7 @@ int mjh_host_run_pd(mjh_engine*, int env, const double* target, double kp, doubl
 int mjh_nenv(const mjh_engine*);
 const mjh_model* mjh_engine_model(const mjh_engine*);
 int mjh_lds_bytes(const mjh_engine*);  /* dynamic LDS per env (= per workgroup) */
+int mjh_query_lds_bytes(const mjh_model*); /* same figure without a device: capacity planning (160 KiB per CU) */
 const char* mjh_last_error(void);
 const char* mjh_version(void);
 

@@ -79,21 +79,11 @@ static int pair_cap(int t1, int t2) {
   return 1;
 }
 
-extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream, mjh_engine** out) {
-  if (!m || nenv <= 0 || !out) { mjh_set_error("mjh_create: bad argument"); return MJH_ERR_ARG; }
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-    mjh_set_error("mjh_create: no HIP device visible (this engine has no CPU fallback)");
-    return MJH_ERR_NO_DEVICE;
-  }
-  if (device < 0 || device >= ndev) { mjh_set_error("mjh_create: bad device index"); return MJH_ERR_ARG; }
-  if (m->nv > 64) { mjh_set_error("mjh_create: nv > 64 not supported yet (PGS maps one dof per lane)"); return MJH_ERR_CAPACITY; }
-  for (int g = 0; g < m->ngeom; g++) if (m->geom_condim[g] != 1 && m->geom_condim[g] != 3 && m->geom_condim[g] != 4) {
-    mjh_set_error("mjh_create: condim must be 1, 3 or 4 (rolling friction, condim 6, is not implemented)"); return MJH_ERR_UNSUPPORTED; }
-  HIPCHK(hipSetDevice(device));
-  mjh_engine* e = new mjh_engine();
-  e->model = m; e->nenv = nenv; e->device = device; e->stream = (hipStream_t)stream;
-
+// Host-only derivation of the device model: packed tables, derived topology tables, capacities and the LDS
+// layout.  Needs no HIP device (mjh_query_lds_bytes uses it for capacity planning and in the CPU tests).
+struct HostPack { DModel M{}; Lay L{}; std::vector<int> I; std::vector<float> F; int o_controlled = 0, o_odom = 0, lds_bytes = 0; };
+static void derive_device_model(const mjh_model* m, HostPack& hp) {
+  DModel& M = hp.M; std::vector<int>& I = hp.I; std::vector<float>& F = hp.F;
   // ---- derived integer tables
   const int nb = m->nbody, nv = m->nv, nj = m->njnt, ng = m->ngeom;
   std::vector<int> subtreesize(nb, 1), lastdof(nb, -1), stageadr(m->npair, 0), fl_dof, gc_body, controlled(std::max(nv, 1), 0), odom(10, -1);
@@ -119,20 +109,18 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   }
   rowW = ((rowW + 3) / 4) * 4;
   // every tree a single free body about its own COM with principal axes = body axes  =>  M is diagonal
-  bool diagM = m->ntree > 0;
+  bool diagM = m->ntree > 0 && m->neq == 0;   // (also implies: no limit / equality rows, every block is a contact)
   for (int t = 0; t < m->ntree && diagM; t++) {
     const int b = m->tree_bodyid[t];
     diagM = m->tree_dofnum[t] == 6 && m->body_jntnum[b] == 1 && m->jnt_type[m->body_jntadr[b]] == MJH_JNT_FREE && subtreesize[b] == 1 &&
             m->body_ipos[3*b] == 0 && m->body_ipos[3*b+1] == 0 && m->body_ipos[3*b+2] == 0 && m->body_iquat[4*b] == 1;
   }
   bool has_damping = false, has_limits = false;
-  for (int d = 0; d < nv; d++) { if (m->dof_frictionloss[d] > 0) fl_dof.push_back(d); if (m->dof_damping[d] > 0) has_damping = true; }
+  for (int d = 0; d < nv; d++) { if (m->dof_frictionloss[d] > 0) { fl_dof.push_back(d); diagM = false; } if (m->dof_damping[d] > 0) has_damping = true; }
   for (int j = 0; j < nj; j++) if (m->jnt_limited[j]) has_limits = true;
   for (int b = 1; b < nb; b++) if (m->body_gravcomp[b] != 0) gc_body.push_back(b);
 
   // ---- pack tables
-  std::vector<int> I; std::vector<float> F;
-  DModel& M = e->M;
   auto addI = [&](const int* p, size_t n) { int o = (int)I.size(); I.insert(I.end(), p, p + n); while (I.size() % 4) I.push_back(0); return o; };
   auto addF = [&](const double* p, size_t n) { int o = (int)F.size(); for (size_t i = 0; i < n; i++) F.push_back((float)p[i]); while (F.size() % 4) F.push_back(0); return o; };
 #define PI(name, n) M.o_##name = addI(m->name, (size_t)(n))
@@ -146,8 +134,8 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   PI(pair_geom1, m->npair); PI(pair_geom2, m->npair); M.o_pair_stageadr = addI(stageadr.data(), m->npair);
   PI(eq_obj1id, m->neq); PI(eq_obj2id, m->neq); PI(eq_active, m->neq);
   M.o_fl_dof = addI(fl_dof.data(), fl_dof.size()); M.o_gc_body = addI(gc_body.data(), gc_body.size());
-  M.o_controlled = e->o_controlled = addI(controlled.data(), controlled.size());
-  M.o_odom = e->o_odom = addI(odom.data(), odom.size());
+  M.o_controlled = hp.o_controlled = addI(controlled.data(), controlled.size());
+  M.o_odom = hp.o_odom = addI(odom.data(), odom.size());
   PF(body_pos, 3*nb); PF(body_quat, 4*nb); PF(body_ipos, 3*nb); PF(body_iquat, 4*nb); PF(body_mass, nb); PF(body_inertia, 3*nb);
   PF(body_gravcomp, nb); PF(body_invweight0, 2*nb);
   PF(jnt_pos, 3*nj); PF(jnt_axis, 3*nj); PF(jnt_stiffness, nj); PF(jnt_range, 2*nj); PF(jnt_margin, nj); PF(jnt_solref, 2*nj); PF(jnt_solimp, 5*nj);
@@ -164,26 +152,21 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   M.maxlevel = maxlevel; M.nfl = (int)fl_dof.size(); M.ngc = (int)gc_body.size(); M.rowW = rowW; M.nstage = nstage;
   M.has_damping = has_damping; M.has_limits = has_limits; M.diagM = diagM;
   {
-    int nlim = 0; for (int j = 0; j < nj; j++) if (m->jnt_limited[j]) nlim++;
-    const int nfix = m->neq + (int)fl_dof.size() + 2 * nlim;
+    // a limited joint can have both sides active only if its margins overlap (range narrower than 2 margins)
+    int nlim = 0; for (int j = 0; j < nj; j++) if (m->jnt_limited[j]) nlim += (m->jnt_range[2*j+1] - m->jnt_range[2*j] <= 2 * m->jnt_margin[j]) ? 2 : 1;
+    const int nfix = m->neq + (int)fl_dof.size() + nlim;
     M.maxblk = nfix + M.maxcon; M.maxbrow = nfix + 4 * M.maxcon;
   }
   M.iterations = m->opt.iterations; M.disableflags = m->opt.disableflags;
   M.timestep = (float)m->opt.timestep; for (int k = 0; k < 3; k++) M.gravity[k] = (float)m->opt.gravity[k];
   M.tolerance = (float)m->opt.tolerance; M.impratio = (float)m->opt.impratio; M.meaninertia = (float)m->meaninertia;
-  e->hI = I;
-  if (dev_alloc(e, &e->dI, I.size(), false) || dev_alloc(e, &e->dF, F.size(), false)) { delete e; return MJH_ERR_NO_DEVICE; }
-  HIPCHK(hipMemcpyAsync(e->dI, I.data(), I.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipMemcpyAsync(e->dF, F.data(), F.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  M.I = e->dI; M.F = e->dF;
-
   // ---- LDS layout (float offsets, 16-byte aligned)
   {
-    Lay& L = e->L; int off = 0;
+    Lay& L = hp.L; int off = 0;
     auto put = [&](int n) { int o = off; off += ((std::max(n, 1) + 3) / 4) * 4; return o; };
     const int nblkcap = M.maxblk + 2;
-    int jsz = nblkcap * rowW * 4;
+    // J / B pools: one row per non-contact block (equality, friction loss, limits), four interleaved rows per contact
+    int jsz = (M.maxblk - M.maxcon + 1) * rowW + (M.maxcon + 1) * rowW * 4;
     const int need = nstage * RAW_STRIDE;            // raw-contact staging aliases J (+B)
     if ((diagM ? 1 : 2) * jsz < need) jsz = diagM ? need : (need + 1) / 2;
     L.qpos = put(m->nq);
@@ -206,8 +189,41 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     L.bv = put(nblkcap * 4); L.phi = put(nblkcap * 4); L.sched = put(nblkcap * 2); L.order = put(nblkcap);
     L.J = put(jsz); L.B = diagM ? L.J : put(jsz);
     L.total = off;
-    e->lds_bytes = off * (int)sizeof(float);
+    hp.lds_bytes = off * (int)sizeof(float);
   }
+}
+
+extern "C" int mjh_query_lds_bytes(const mjh_model* m) {
+  if (!m) return MJH_ERR_ARG;
+  HostPack hp; derive_device_model(m, hp);
+  return hp.lds_bytes;
+}
+
+extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream, mjh_engine** out) {
+  if (!m || nenv <= 0 || !out) { mjh_set_error("mjh_create: bad argument"); return MJH_ERR_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    mjh_set_error("mjh_create: no HIP device visible (this engine has no CPU fallback)");
+    return MJH_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) { mjh_set_error("mjh_create: bad device index"); return MJH_ERR_ARG; }
+  if (m->nv > 64) { mjh_set_error("mjh_create: nv > 64 not supported yet (PGS maps one dof per lane)"); return MJH_ERR_CAPACITY; }
+  for (int g = 0; g < m->ngeom; g++) if (m->geom_condim[g] != 1 && m->geom_condim[g] != 3 && m->geom_condim[g] != 4) {
+    mjh_set_error("mjh_create: condim must be 1, 3 or 4 (rolling friction, condim 6, is not implemented)"); return MJH_ERR_UNSUPPORTED; }
+  HIPCHK(hipSetDevice(device));
+  mjh_engine* e = new mjh_engine();
+  e->model = m; e->nenv = nenv; e->device = device; e->stream = (hipStream_t)stream;
+
+  HostPack hp; derive_device_model(m, hp);
+  e->M = hp.M; e->L = hp.L; e->lds_bytes = hp.lds_bytes; e->o_controlled = hp.o_controlled; e->o_odom = hp.o_odom;
+  DModel& M = e->M; std::vector<int>& I = hp.I; std::vector<float>& F = hp.F;
+  e->hI = I;
+  if (dev_alloc(e, &e->dI, I.size(), false) || dev_alloc(e, &e->dF, F.size(), false)) { delete e; return MJH_ERR_NO_DEVICE; }
+  HIPCHK(hipMemcpyAsync(e->dI, I.data(), I.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->dF, F.data(), F.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  M.I = e->dI; M.F = e->dF;
+
   {
     DConst hc; hc.M = e->M; hc.L = e->L;
     if (dev_alloc(e, &e->dC, 1, false)) { delete e; return MJH_ERR_NO_DEVICE; }

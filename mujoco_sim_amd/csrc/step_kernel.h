@@ -40,8 +40,7 @@ template <class T> struct Tab {
 };
 
 // in-place x <- M^-1 x over one tree's contiguous dof range, x addressed by absolute dof index
-template <int STRIDE = 1>
-DEV void solve_tree(float* x, const float* qLD, const float* qLDinv, const int* dof_parentid, const int* dof_Madr, int adr, int num) {
+DEV void solve_tree(float* x, const float* qLD, const float* qLDinv, const int* dof_parentid, const int* dof_Madr, int adr, int num, const int STRIDE = 1) {
   for (int k = adr + num - 1; k >= adr; k--) {
     float xk = x[k * STRIDE];
     if (xk == 0) continue;
@@ -74,6 +73,10 @@ DEV void factor_tree(float* qLD, float* qLDinv, const int* dof_parentid, const i
 // row header: hd[0] = type | sub << 8, hd[1] = id, hd[2] = a1 | n1 << 16, hd[3] = a2 | n2 << 16
 // where (a1,n1) ++ (a2,n2) are the contiguous dof ranges of the (up to two) kinematic trees the row touches
 #define ROW_TREES(hd2, hd3) const int a1 = (hd2) & 0xffff, n1 = (hd2) >> 16, a2 = (hd3) & 0xffff, n2 = (hd3) >> 16
+// Jacobian storage of a block: hd.x >> 16 = offset (in float4 units) into the J / B pools; a contact block keeps its
+// (up to) 4 base rows interleaved J[k][4], every other block is a single row J[k]
+#define BLK_JOFF(hx) ((((unsigned)(hx)) >> 16) << 2)
+#define BLK_SLOTS(hy) (((((hy) >> 24) & 15) == RT_CONTACT) ? 4 : 1)
 // offset of dof d inside the compact storage of a row spanning trees (a1,n1) ++ (a2,n2); -1 if outside
 DEV int row_off(int d, int a1, int n1, int a2, int n2) {
   unsigned r1 = (unsigned)(d - a1), r2 = (unsigned)(d - a2);
@@ -501,14 +504,16 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
     nefc = 0;
     int nblk = 0, nbrow = 0;
     if (!(M.disableflags & MJH_DSBL_CONSTRAINT)) {
-      auto put_block = [&](int b, int kind, int nrows, int nb, int clamp, int, int id, int rtype, int side) __attribute__((always_inline)) {
+      // non-contact blocks come first and own one row of rowW floats each; contact block c owns 4*rowW floats
+      auto put_block = [&](int b, int kind, int nrows, int nb, int clamp, int joff4, int id, int rtype, int side) __attribute__((always_inline)) {
         int* hd = s_blki_i + b * BLKI_STRIDE;
-        hd[0] = kind | (nrows << 4) | (nb << 8) | (clamp << 12); hd[1] = id | (rtype << 24) | (side << 28);
+        hd[0] = kind | (nrows << 4) | (nb << 8) | (clamp << 12) | (joff4 << 16); hd[1] = id | (rtype << 24) | (side << 28);
       };
+      const int w4 = rowW >> 2;
       if (!(M.disableflags & MJH_DSBL_EQUALITY))
-        for (int e = 0; e < M.neq; e++) if (eq_active[e]) { if (lane == 0) put_block(nblk, BK_SINGLE, 1, 1, 0, nbrow, e, RT_EQ, 0); nblk++; nbrow++; nefc++; }
+        for (int e = 0; e < M.neq; e++) if (eq_active[e]) { if (lane == 0) put_block(nblk, BK_SINGLE, 1, 1, 0, nblk * w4, e, RT_EQ, 0); nblk++; nbrow++; nefc++; }
       if (!(M.disableflags & MJH_DSBL_FRICTIONLOSS)) {
-        for (int f = lane; f < M.nfl; f += 64) put_block(nblk + f, BK_SINGLE, 1, 1, 2, nbrow + f, fl_dof[f], RT_FL, 0);
+        for (int f = lane; f < M.nfl; f += 64) put_block(nblk + f, BK_SINGLE, 1, 1, 2, (nblk + f) * w4, fl_dof[f], RT_FL, 0);
         nblk += M.nfl; nbrow += M.nfl; nefc += M.nfl;
       }
       if (M.has_limits && !(M.disableflags & MJH_DSBL_LIMIT)) {
@@ -520,13 +525,14 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           }
           const int n = lo + hi, incl = wave_incl_scan_i(n, lane);
           int r = incl - n;
-          if (lo) { put_block(nblk + r, BK_SINGLE, 1, 1, 1, nbrow + r, j, RT_LIMIT, 0); r++; }
-          if (hi) put_block(nblk + r, BK_SINGLE, 1, 1, 1, nbrow + r, j, RT_LIMIT, 1);
+          if (lo) { put_block(nblk + r, BK_SINGLE, 1, 1, 1, (nblk + r) * w4, j, RT_LIMIT, 0); r++; }
+          if (hi) put_block(nblk + r, BK_SINGLE, 1, 1, 1, (nblk + r) * w4, j, RT_LIMIT, 1);
           const int tot = __shfl(incl, 63);
           nblk += tot; nbrow += tot; nefc += tot;
         }
       }
       // contacts: a contact whose rows do not fit drops it and every later contact (oracle rule)
+      const int nfix = nblk;
       bool stop = false;
       for (int base = 0; base < ncon && !stop; base += 64) {
         const int ic = base + lane; int nr = 0, nb = 0, dim = 0;
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         const unsigned long long over = __ballot(inc && nefc + sr > M.maxefc);
         const int firstover = over ? __ffsll((long long)over) - 1 : 64;
         if (inc && lane < firstover)
-          put_block(nblk + sc - 1, dim == 1 ? BK_SINGLE : (dim == 3 ? BK_PYR3 : BK_PYR4), nr, nb, 1, nbrow + sb - nb, ic, RT_CONTACT, 0);
+          put_block(nblk + sc - 1, dim == 1 ? BK_SINGLE : (dim == 3 ? BK_PYR3 : BK_PYR4), nr, nb, 1, (nfix + 4 * (nblk + sc - 1 - nfix)) * w4, ic, RT_CONTACT, 0);
         int last = 63;
         if (over) { flags |= 2; stop = true; last = firstover - 1; }
         if (last >= 0) { nefc += __shfl(sr, last); nbrow += __shfl(sb, last); nblk += __shfl(sc, last); }
@@ -556,8 +562,10 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       const int b = t >> 2, jb = t & 3;
       int* hd = s_blki_i + b * BLKI_STRIDE;
       const int nb = (hd[0] >> 8) & 15;
-      float* J = s_J + b * rowW * 4 + jb;
-      for (int k = 0; k < rowW; k++) J[4*k] = 0;
+      const int SL = BLK_SLOTS(hd[1]);
+      if (jb >= SL) continue;
+      float* J = s_J + BLK_JOFF(hd[0]) + jb;
+      for (int k = 0; k < rowW; k++) J[SL*k] = 0;
       if (jb >= nb) continue;
       const int id = hd[1] & 0xffffff, rtype = (hd[1] >> 24) & 15, side = (hd[1] >> 28) & 1;
       int t1 = -1, t2 = -1;
@@ -566,17 +574,17 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         const float* dat = eq_data + 11*id;
         const int d1 = jnt_dofadr[j1];
         t1 = dof_treeid[d1];
-        J[4*(d1 - tree_dofadr[t1])] = 1;
+        J[SL*(d1 - tree_dofadr[t1])] = 1;
         if (j2 >= 0) {
           const int d2 = jnt_dofadr[j2];
           const float p2 = s_qpos[jnt_qposadr[j2]] - qpos0[jnt_qposadr[j2]];
           const float deriv = dat[1] + p2*(2*dat[2] + p2*(3*dat[3] + p2*4*dat[4]));
           const int tt = dof_treeid[d2];
-          if (tt == t1) J[4*(d2 - tree_dofadr[t1])] += -deriv;
-          else { t2 = tt; J[4*(tree_dofnum[t1] + d2 - tree_dofadr[t2])] = -deriv; }
+          if (tt == t1) J[SL*(d2 - tree_dofadr[t1])] += -deriv;
+          else { t2 = tt; J[SL*(tree_dofnum[t1] + d2 - tree_dofadr[t2])] = -deriv; }
         }
-      } else if (rtype == RT_FL) { t1 = dof_treeid[id]; J[4*(id - tree_dofadr[t1])] = 1; }
-      else if (rtype == RT_LIMIT) { const int d = jnt_dofadr[id]; t1 = dof_treeid[d]; J[4*(d - tree_dofadr[t1])] = side ? -1.0f : 1.0f; }
+      } else if (rtype == RT_FL) { t1 = dof_treeid[id]; J[SL*(id - tree_dofadr[t1])] = 1; }
+      else if (rtype == RT_LIMIT) { const int d = jnt_dofadr[id]; t1 = dof_treeid[d]; J[SL*(d - tree_dofadr[t1])] = side ? -1.0f : 1.0f; }
       else {
         const float* c = s_con + id * CON_STRIDE;
         const int g1 = __float_as_int(c[13]), g2 = __float_as_int(c[14]);
@@ -601,7 +609,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             float v;
             if (jb < 3) { float cr[3]; cross3(cr, cd, off); const float jp[3] = {cd[3] + cr[0], cd[4] + cr[1], cd[5] + cr[2]}; v = dot3(dir, jp); }
             else v = dot3(dir, cd);
-            J[4*(o + i)] += ss * v;
+            J[SL*(o + i)] += ss * v;
           }
         }
       }
@@ -675,12 +683,14 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       for (int t = lane; t < 4 * nblk; t += 64) {
         const int b = t >> 2, jb = t & 3;
         const int* hd = s_blki_i + b * BLKI_STRIDE;
-        if (jb >= ((hd[0] >> 8) & 15)) { for (int k = 0; k < rowW; k++) s_B[(b * rowW + k) * 4 + jb] = 0; continue; }
+        const int SL = BLK_SLOTS(hd[1]);
+        if (jb >= SL) continue;
+        const float* J = s_J + BLK_JOFF(hd[0]) + jb; float* B = s_B + BLK_JOFF(hd[0]) + jb;
+        if (jb >= ((hd[0] >> 8) & 15)) { for (int k = 0; k < rowW; k++) B[SL*k] = 0; continue; }
         ROW_TREES(hd[2], hd[3]);
-        const float* J = s_J + b * rowW * 4 + jb; float* B = s_B + b * rowW * 4 + jb;
-        for (int k = 0; k < rowW; k++) B[4*k] = J[4*k];
-        solve_tree<4>(B - 4*a1, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a1, n1);
-        if (n2 > 0) solve_tree<4>(B + 4*(n1 - a2), s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a2, n2);
+        for (int k = 0; k < rowW; k++) B[SL*k] = J[SL*k];
+        solve_tree(B - SL*a1, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a1, n1, SL);
+        if (n2 > 0) solve_tree(B + SL*(n1 - a2), s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a2, n2, SL);
       }
       WSYNC();
     }
@@ -692,11 +702,13 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       if (jb >= nb) continue;
       ROW_TREES(hd[2], hd[3]);
       float acc[4] = {0, 0, 0, 0};
+      const int SL = BLK_SLOTS(hd[1]), jo = BLK_JOFF(hd[0]);
       for (int k = 0; k < n1 + n2; k++) {
-        const float4 jk = *(const float4*)(s_J + (b * rowW + k) * 4);
-        const float jv[4] = {jk.x, jk.y, jk.z, jk.w};
+        float jv[4] = {0, 0, 0, 0};
+        if (SL == 4) { const float4 jk = *(const float4*)(s_J + jo + 4*k); jv[0] = jk.x; jv[1] = jk.y; jv[2] = jk.z; jv[3] = jk.w; }
+        else jv[0] = s_J[jo + k];
         float bk;
-        if (DIAGM) bk = jv[jb] * s_qLDinv[k < n1 ? a1 + k : a2 + k - n1]; else bk = s_B[(b * rowW + k) * 4 + jb];
+        if (DIAGM) bk = jv[jb] * s_qLDinv[k < n1 ? a1 + k : a2 + k - n1]; else bk = s_B[jo + SL*k + jb];
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[i] += jv[i] * bk;
       }
@@ -751,10 +763,13 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         const int b = t >> 2, jb = t & 3;
         const int* hd = s_blki_i + b * BLKI_STRIDE;
         ROW_TREES(hd[2], hd[3]);
-        const float* J = s_J + b * rowW * 4 + jb;
+        const int SL = BLK_SLOTS(hd[1]);
         float v = 0;
-        for (int k = 0; k < n1; k++) v += J[4*k] * vec[a1 + k];
-        for (int k = 0; k < n2; k++) v += J[4*(n1 + k)] * vec[a2 + k];
+        if (jb < SL) {
+          const float* J = s_J + BLK_JOFF(hd[0]) + jb;
+          for (int k = 0; k < n1; k++) v += J[SL*k] * vec[a1 + k];
+          for (int k = 0; k < n2; k++) v += J[SL*(n1 + k)] * vec[a2 + k];
+        }
         out[t] = v;
       }
       WSYNC();
@@ -769,9 +784,10 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           ROW_TREES(hd.z, hd.w);
           const int o = row_off(d, a1, n1, a2, n2);
           if (o < 0) continue;
-          const float4 x = *(const float4*)(((useB && !DIAGM) ? s_B : s_J) + (b * rowW + o) * 4);
+          const float* X = ((useB && !DIAGM) ? s_B : s_J) + BLK_JOFF(hd.x);
           const float4 p = *(const float4*)(phi + 4*b);
-          acc += x.x*p.x + x.y*p.y + x.z*p.z + x.w*p.w;
+          if (BLK_SLOTS(hd.y) == 4) { const float4 x = *(const float4*)(X + 4*o); acc += x.x*p.x + x.y*p.y + x.z*p.z + x.w*p.w; }
+          else acc += X[o] * p.x;
         }
         out[d] = (useB && DIAGM) ? acc * minv : acc;
       }
@@ -1045,8 +1061,6 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
         const float4* blkf4 = (const float4*)s_blkf;
         const int4* blki4 = (const int4*)s_blki_i;
-        const float4* J4 = (const float4*)s_J;
-        const float4* B4 = (const float4*)s_B;
         if constexpr (NROW <= 2) {
           // ======== dual-block sweep: half 0 solves block p, half 1 its independent partner q of the schedule
           const int hh = lane >> 5;
@@ -1060,13 +1074,16 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             const int4 hd = blki4[b];
             ROW_TREES(hd.z, hd.w);
             const int o = row_off(d0, a1, n1, a2, n2);
-            const int ja = b * rowW + max(o, 0);
             const float msk = (o >= 0 && act) ? 1.0f : 0.0f;
-            float4 jv = J4[ja];
+            const int jo = BLK_JOFF(hd.x), oc = max(o, 0);
+            const bool quad = DIAGM || BLK_SLOTS(hd.y) == 4;   // DIAGM models have contact blocks only (engine.hip)
+            float4 jv = make_float4(0, 0, 0, 0), bv4 = make_float4(0, 0, 0, 0);
+            if (quad) jv = *(const float4*)(s_J + jo + 4*oc); else jv.x = s_J[jo + oc];
             jv.x *= msk; jv.y *= msk; jv.z *= msk; jv.w *= msk;
             op.J = jv;
             if (DIAGM) { op.B.x = jv.x * minv0; op.B.y = jv.y * minv0; op.B.z = jv.z * minv0; op.B.w = jv.w * minv0; }
-            else { float4 bv4 = B4[ja]; bv4.x *= msk; bv4.y *= msk; bv4.z *= msk; bv4.w *= msk; op.B = bv4; }
+            else { if (quad) bv4 = *(const float4*)(s_B + jo + 4*oc); else bv4.x = s_B[jo + oc];
+                   bv4.x *= msk; bv4.y *= msk; bv4.z *= msk; bv4.w *= msk; op.B = bv4; }
             op.P = blkf4[8*b]; op.r0 = blkf4[8*b+1]; op.r1 = blkf4[8*b+2]; op.r2 = blkf4[8*b+3];
             op.A0 = blkf4[8*b+4]; op.A1 = blkf4[8*b+5]; op.A2 = blkf4[8*b+6]; op.A3 = blkf4[8*b+7];
             op.hx = act ? hd.x : 0; op.b = b; op.act = act ? 1.0f : 0.0f;
@@ -1118,13 +1135,16 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           const int4 hd = blki4[b];
           ROW_TREES(hd.z, hd.w);
           const int o = row_off(d0, a1, n1, a2, n2);
-          const int ja = b * rowW + max(o, 0);
           const float msk = o >= 0 ? 1.0f : 0.0f;
-          float4 jv = J4[ja];
+          const int jo = BLK_JOFF(hd.x), oc = max(o, 0);
+          const bool quad = DIAGM || BLK_SLOTS(hd.y) == 4;   // DIAGM models have contact blocks only (engine.hip)
+          float4 jv = make_float4(0, 0, 0, 0), bv4 = make_float4(0, 0, 0, 0);
+          if (quad) jv = *(const float4*)(s_J + jo + 4*oc); else jv.x = s_J[jo + oc];
           jv.x *= msk; jv.y *= msk; jv.z *= msk; jv.w *= msk;
           op.J = jv;
           if (DIAGM) { op.B.x = jv.x * minv0; op.B.y = jv.y * minv0; op.B.z = jv.z * minv0; op.B.w = jv.w * minv0; }
-          else { float4 bv4 = B4[ja]; bv4.x *= msk; bv4.y *= msk; bv4.z *= msk; bv4.w *= msk; op.B = bv4; }
+          else { if (quad) bv4 = *(const float4*)(s_B + jo + 4*oc); else bv4.x = s_B[jo + oc];
+                 bv4.x *= msk; bv4.y *= msk; bv4.z *= msk; bv4.w *= msk; op.B = bv4; }
           op.P = blkf4[8*b]; op.r0 = blkf4[8*b+1]; op.r1 = blkf4[8*b+2]; op.r2 = blkf4[8*b+3];
           op.A0 = blkf4[8*b+4]; op.A1 = blkf4[8*b+5]; op.A2 = blkf4[8*b+6]; op.A3 = blkf4[8*b+7];
           op.hx = hd.x;
