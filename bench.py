@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--fuse", type=int, default=1, help="steps between host hand-offs (one kernel launch per step either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the publish all-gather even with one rank (self-test of the multi-GPU path)")
     ap.add_argument("--cpu-envs", type=int, default=1024)
     ap.add_argument("--cpu-steps", type=int, default=100)
     args = ap.parse_args()
@@ -94,8 +95,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import mujoco_sim_amd as ms
@@ -107,7 +111,7 @@ def main():
     tab = eng.load_s24(env_offset=rank * nenv)
     stride = eng.state_stride
     pub = torch.empty(nenv * stride, dtype=torch.float32, device="cuda")
-    gathered = torch.empty(world * nenv * stride, dtype=torch.float32, device="cuda") if world > 1 else None
+    gathered = torch.empty(world * nenv * stride, dtype=torch.float32, device="cuda") if use_dist else None
     publish_every = max(1, int(round(1.0 / (60.0 * model.opt.timestep))))  # 60 Hz of simulated time
 
     def run(nsteps, timed=False):
@@ -122,24 +126,24 @@ def main():
             if timed:
                 b.record(stream); evs.append((a, b))
             s += k
-            if world > 1 and not args.no_gather and (s % publish_every) < k:
+            if use_dist and not args.no_gather and (s % publish_every) < k:
                 eng.export_state_device(pub.data_ptr())
                 dist.all_gather_into_tensor(gathered, pub)
         return evs
 
     run(args.warmup)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     evs = run(args.steps, timed=True)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -177,13 +181,19 @@ def main():
     }
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, eng, tab, 0, min(args.cpu_envs, nenv), args.cpu_steps, args.with_inverse)
-    if world > 1:
+    if use_dist:
         dist.barrier()
-    if rank == 0:
-        print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        try:  # RCCL prints its banner through C stdio: flush it first so that the JSON is the LAST line of stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
