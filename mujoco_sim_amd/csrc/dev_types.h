@@ -38,6 +38,7 @@ struct DState {
   float *qpos, *qvel, *qacc, *qacc_ws, *qvel_ref, *qfrc_applied, *ddq, *dq, *qfrc_inverse, *time;
   float *initial_qpos, *odom_vel;
   int* stats;  // [nenv*4]: ncon, nefc, solver iterations, flags
+  const int* env_order;  // launch order of the envs (longest job first) or null
   unsigned* slot_mask;  // [nenv] bit b = body b inactive (spawn/destroy slots); may be null
   // optional exports (may be null)
   float *x_xpos, *x_xquat, *x_gpos, *x_gmat;

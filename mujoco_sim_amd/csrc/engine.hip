@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -38,6 +39,8 @@ struct mjh_engine {
   std::vector<void*> allocs;
   float* scratch = nullptr; size_t scratch_floats = 0;  // export staging
   float* p_tables[MJH_EP_COUNT] = {nullptr};
+  int* d_order = nullptr;   // LPT launch order (mjh_order_kernel)
+  bool lpt = true;
   bool step1_done = false;
 };
 
@@ -212,6 +215,7 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     mjh_set_error("mjh_create: condim must be 1, 3 or 4 (rolling friction, condim 6, is not implemented)"); return MJH_ERR_UNSUPPORTED; }
   HIPCHK(hipSetDevice(device));
   mjh_engine* e = new mjh_engine();
+  if (const char* v = getenv("MJH_LPT")) e->lpt = atoi(v) != 0;
   e->model = m; e->nenv = nenv; e->device = device; e->stream = (hipStream_t)stream;
 
   HostPack hp; derive_device_model(m, hp);
@@ -284,8 +288,18 @@ extern "C" int mjh_step2(mjh_engine* e) {
 extern "C" int mjh_forward(mjh_engine* e) { ENG(e); return launch(e, 0, e->nenv, 1, PH_STEP1 | PH_NOINT, XF_FORCE); }
 extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
   ENG(e);
+  if (e->lpt && !e->d_order && e->nenv >= 2048) {
+    int rc = dev_alloc(e, &e->d_order, (size_t)e->nenv);
+    if (rc) return rc;
+  }
   for (int s = 0; s < nsteps; s++) {   // one launch per step (commands are consumed by the first one)
+    DState saved = e->S;
+    if (e->lpt && e->d_order) {         // dispatch the envs with the most solver work first (shorter kernel tail)
+      hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, e->stream, (const int*)e->S.stats, e->d_order, e->nenv);
+      e->S.env_order = e->d_order;
+    }
     int rc = launch(e, 0, e->nenv, 1, PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0), 0);
+    e->S = saved;
     if (rc) return rc;
   }
   return MJH_OK;

@@ -189,7 +189,9 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   const Lay& L = C->L;
   extern __shared__ float lds[];
   const int lane = threadIdx.x;
-  const int env = env0 + blockIdx.x;
+  // longest-job-first dispatch: workgroups are issued in blockIdx order, so the envs that needed the most solver work
+  // in the previous step go first (S.env_order, built by mjh_order_kernel); results do not depend on the order
+  const int env = S.env_order ? S.env_order[env0 + blockIdx.x] : env0 + (int)blockIdx.x;
   const int nq = M.nq, nv = M.nv, nbody = M.nbody, njnt = M.njnt, ngeom = M.ngeom;
 
   // model tables: one base pointer per element type + a kernarg-resident offset per table (kept as
@@ -1291,4 +1293,19 @@ __global__ void mjh_export_kernel(const DState S, float* out, int nenv, int nq, 
     const int e = (int)(i / stride), k = (int)(i % stride);
     out[i] = (k == 0) ? S.time[e] : (k <= nq ? S.qpos[(size_t)e * nqp + k - 1] : S.qvel[(size_t)e * nvp + k - 1 - nq]);
   }
+}
+
+// Longest-processing-time-first order of the environments for the next launch: counting sort (descending) of the
+// previous step's cost estimate (solver sweeps x constraint rows) in one 1024-thread workgroup.
+__global__ __launch_bounds__(1024) void mjh_order_kernel(const int* __restrict__ stats, int* __restrict__ order, int nenv) {
+  __shared__ int hist[256], base[256];
+  const int t = threadIdx.x;
+  if (t < 256) hist[t] = 0;
+  __syncthreads();
+  auto bucket = [&](int e) { const int cost = stats[4*e + 2] * (stats[4*e + 1] + 24); int b = cost >> 6; return b > 255 ? 255 : b; };   // 100 it x 232 rows -> 362 -> clamp
+  for (int e = t; e < nenv; e += 1024) atomicAdd(&hist[255 - bucket(e)], 1);
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int b = 0; b < 256; b++) { base[b] = acc; acc += hist[b]; } }
+  __syncthreads();
+  for (int e = t; e < nenv; e += 1024) order[atomicAdd(&base[255 - bucket(e)], 1)] = e;
 }
