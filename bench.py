@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--with-inverse", type=int, default=0, help="also run mj_inverse every step (MjHWInterface::read)")
     ap.add_argument("--fuse", type=int, default=1, help="steps between host hand-offs (one kernel launch per step either way)")
+    ap.add_argument("--cohorts", type=int, default=-1, help="env cohorts stepped on separate HIP streams (-1: engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the publish all-gather even with one rank (self-test of the multi-GPU path)")
@@ -109,35 +110,32 @@ def main():
     stream = torch.cuda.current_stream()
     eng = ms.Engine(model, nenv, device=local_rank, stream=stream.cuda_stream)
     tab = eng.load_s24(env_offset=rank * nenv)
+    if args.cohorts > 0:
+        eng.set_cohorts(args.cohorts)
     stride = eng.state_stride
     pub = torch.empty(nenv * stride, dtype=torch.float32, device="cuda")
     gathered = torch.empty(world * nenv * stride, dtype=torch.float32, device="cuda") if use_dist else None
     publish_every = max(1, int(round(1.0 / (60.0 * model.opt.timestep))))  # 60 Hz of simulated time
 
-    def run(nsteps, timed=False):
-        evs = []
+    def run(nsteps):
         s = 0
         while s < nsteps:
             k = min(args.fuse, nsteps - s)
-            if timed:
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(stream)
             eng.step(k, args.with_inverse)
-            if timed:
-                b.record(stream); evs.append((a, b))
             s += k
             if use_dist and not args.no_gather and (s % publish_every) < k:
                 eng.export_state_device(pub.data_ptr())
                 dist.all_gather_into_tensor(gathered, pub)
-        return evs
 
     run(args.warmup)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    # the engine brackets every step-kernel launch with HIP events on the stream it is launched on (cohort streams)
+    eng.set_launch_timing(True)
     t0 = time.perf_counter()
-    evs = run(args.steps, timed=True)
+    run(args.steps)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -147,14 +145,16 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs])) if evs else float("nan")
+    kernel_ms, n_launches = eng.get_launch_timing()
+    eng.set_launch_timing(False)
+    cohorts = eng.cohorts
 
     st = eng.get_stats()
     total_envs = nenv * world
     value = total_envs * args.steps / elapsed
     bytes_step = algorithmic_bytes_per_env_step(model.nq, model.nv)
-    launches_steps = min(args.fuse, args.steps)
-    achieved = bytes_step * nenv * launches_steps / (kernel_ms * 1e-3) / 1e9
+    envs_per_launch = nenv * args.steps / max(n_launches, 1)   # one launch = one step of one cohort
+    achieved = bytes_step * envs_per_launch / (kernel_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
@@ -168,7 +168,7 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "S24: 4 free boxes (24 DoF) in a walled pen on the empty.xml floor, PGS 100 it / tol 1e-8",
-                   "envs_per_gpu": nenv, "envs_total": total_envs, "steps_per_launch": args.fuse,
+                   "envs_per_gpu": nenv, "envs_total": total_envs, "steps_per_launch": 1, "steps_per_call": args.fuse, "cohorts": cohorts,
                    "with_inverse": bool(args.with_inverse), "parallelism": f"env-sharded x{world}",
                    "mean_ncon": float(st[:, 0].mean()), "max_ncon": int(st[:, 0].max()), "mean_nefc": float(st[:, 1].mean()),
                    "max_nefc": int(st[:, 1].max()), "mean_solver_iter": float(st[:, 2].mean()),
@@ -176,6 +176,7 @@ def main():
                    "lds_bytes_per_env": eng.lds_bytes},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel": "mjh_step_kernel", "kernel_ms": kernel_ms,
+                     "launches": n_launches, "envs_per_launch": envs_per_launch, "concurrent_launches": cohorts,
                      "algorithmic_bytes_per_env_step": bytes_step,
                      "note": "fused per-env pipeline keeps intermediates in LDS: the path is latency/LDS-bound, far below the HBM roofline by design (DESIGN.md)"},
     }

@@ -259,6 +259,23 @@ int mjh_state_stride(const mjh_engine*);
 
 /* debug: mean shader-clock ticks from kernel start to each of the 16 stage boundaries of one fused step */
 int mjh_debug_stage_cycles(mjh_engine*, int with_inverse, double* out16);
+/* debug: raw stamps of one step launch, out[nenv*20] indexed by launch position: [0..15] shader-clock stage stamps,
+ * [16],[17] 100 MHz wall clock at start/end, [18] HW_ID | XCC_ID<<32, [19] env id (tools/timeline.py) */
+int mjh_debug_stage_raw(mjh_engine*, int with_inverse, long long* out);
+
+/* ---- launch scheduling (no reference counterpart: the reference steps one mjData on one CPU thread,
+ * mj_main.cpp:82-112).  Environments are independent, so mjh_step() may split them into `n` cohorts
+ * (contiguous env ranges, 1..8), each stepped on its own HIP stream: the low-occupancy tail of one cohort's
+ * step kernel then overlaps the bulk of another's, across consecutive mjh_step calls too.  The caller's
+ * stream forks into the cohort streams inside mjh_step and is joined again by the next call of any other
+ * entry point, so results and ordering seen through this API do not depend on `n`.  Within a launch the
+ * envs are dispatched longest-solver-job first (order rebuilt on the device every step). */
+int mjh_set_cohorts(mjh_engine*, int n);
+int mjh_get_cohorts(const mjh_engine*);
+/* HIP-event timing of every step-kernel launch on the stream it runs on: enable, step, then read the mean
+ * duration [ms] and the number of launches since the last read (bench.py's roofline leg). */
+int mjh_set_launch_timing(mjh_engine*, int on);
+int mjh_get_launch_timing(mjh_engine*, double* mean_ms, int* count);
 
 /* ROS-free harness of the host loop (csrc/host_sim.cpp: simulate() + MjhHWInterface, mirrors of
  * mj_main.cpp:76-164 and mj_hw_interface.cpp:59-110) with an in-process PD effort controller on

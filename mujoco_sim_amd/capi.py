@@ -142,6 +142,11 @@ SYMBOLS = [
     ("mjh_export_state_device", C.c_int, [_vp, _vp]),
     ("mjh_state_stride", C.c_int, [_vp]),
     ("mjh_debug_stage_cycles", C.c_int, [_vp, C.c_int, c_double_p]),
+    ("mjh_debug_stage_raw", C.c_int, [_vp, C.c_int, _vp]),
+    ("mjh_set_cohorts", C.c_int, [_vp, C.c_int]),
+    ("mjh_get_cohorts", C.c_int, [_vp]),
+    ("mjh_set_launch_timing", C.c_int, [_vp, C.c_int]),
+    ("mjh_get_launch_timing", C.c_int, [_vp, c_double_p, C.POINTER(C.c_int)]),
     ("mjh_nenv", C.c_int, [_vp]),
     ("mjh_engine_model", Model_p, [_vp]),
     ("mjh_lds_bytes", C.c_int, [_vp]),

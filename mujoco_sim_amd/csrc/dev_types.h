@@ -34,6 +34,7 @@ struct DModel {
 };
 
 // per-env state in HBM (fp32, env-major rows)
+#define PROF_STRIDE 20   // x_prof: 16 stage stamps (shader clock), [16],[17] wall clock start/end, [18] HW_ID|XCC_ID<<32
 struct DState {
   float *qpos, *qvel, *qacc, *qacc_ws, *qvel_ref, *qfrc_applied, *ddq, *dq, *qfrc_inverse, *time;
   float *initial_qpos, *odom_vel;

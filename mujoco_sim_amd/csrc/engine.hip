@@ -25,6 +25,7 @@ void mjh_set_error(const std::string& s);  // model_builder.cpp
     }                                                                                            \
   } while (0)
 
+#define MJH_MAX_COHORTS 8
 struct mjh_engine {
   const mjh_model* model = nullptr;
   int nenv = 0, device = 0;
@@ -41,6 +42,16 @@ struct mjh_engine {
   float* p_tables[MJH_EP_COUNT] = {nullptr};
   int* d_order = nullptr;   // LPT launch order (mjh_order_kernel)
   bool lpt = true;
+  // Cohorts: mjh_step() splits the envs into ncohort contiguous groups, each stepped on its own stream, so that the
+  // low-occupancy tail of one cohort's step kernel overlaps the next cohort's (or its own next step's) bulk.  The
+  // caller's stream forks into the cohort streams at mjh_step and joins them again at the next other API call.
+  int ncohort = 1;
+  hipStream_t cstream[MJH_MAX_COHORTS] = {nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[MJH_MAX_COHORTS] = {nullptr};
+  bool forked = false;
+  // optional per-launch timing of the step kernels (mjh_set_launch_timing)
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> tev; size_t tev_used = 0;
   bool step1_done = false;
 };
 
@@ -63,14 +74,47 @@ static int ensure_scratch(mjh_engine* e, size_t floats) {
   return MJH_OK;
 }
 
-static int launch(mjh_engine* e, int env0, int n, int nsteps, int ph, int xflags) {
+static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps, int ph, int xflags) {
   if (n <= 0) return MJH_OK;
-#define MJH_LAUNCH(NR, DG) hipLaunchKernelGGL((mjh_step_kernel<NR, DG>), dim3(n), dim3(64), (size_t)e->lds_bytes, e->stream, e->dC, e->S, env0, nsteps, ph, xflags)
+#define MJH_LAUNCH(NR, DG) hipLaunchKernelGGL((mjh_step_kernel<NR, DG>), dim3(n), dim3(64), (size_t)e->lds_bytes, st, e->dC, e->S, env0, nsteps, ph, xflags)
   const int nr = e->M.nv <= 16 ? 1 : (e->M.nv <= 32 ? 2 : 4);
   if (e->M.diagM) { if (nr == 1) MJH_LAUNCH(1, true); else if (nr == 2) MJH_LAUNCH(2, true); else MJH_LAUNCH(4, true); }
   else { if (nr == 1) MJH_LAUNCH(1, false); else if (nr == 2) MJH_LAUNCH(2, false); else MJH_LAUNCH(4, false); }
 #undef MJH_LAUNCH
   HIPCHK(hipGetLastError());
+  return MJH_OK;
+}
+
+static int launch(mjh_engine* e, int env0, int n, int nsteps, int ph, int xflags) { return launch_on(e, e->stream, env0, n, nsteps, ph, xflags); }
+
+static int fork_cohorts(mjh_engine* e) {
+  if (e->forked || e->ncohort <= 1) return MJH_OK;
+  HIPCHK(hipEventRecord(e->ev_fork, e->stream));
+  for (int g = 0; g < e->ncohort; g++) HIPCHK(hipStreamWaitEvent(e->cstream[g], e->ev_fork, 0));
+  e->forked = true;
+  return MJH_OK;
+}
+static int join_cohorts(mjh_engine* e) {
+  if (!e->forked) return MJH_OK;
+  for (int g = 0; g < e->ncohort; g++) {
+    HIPCHK(hipEventRecord(e->ev_join[g], e->cstream[g]));
+    HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join[g], 0));
+  }
+  e->forked = false;
+  return MJH_OK;
+}
+static int set_cohorts(mjh_engine* e, int n) {
+  n = std::max(1, std::min(n, MJH_MAX_COHORTS));
+  int rc = join_cohorts(e);
+  if (rc) return rc;
+  if (n > 1) {
+    if (!e->ev_fork) HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    for (int g = 0; g < n; g++) {
+      if (!e->cstream[g]) HIPCHK(hipStreamCreateWithFlags(&e->cstream[g], hipStreamNonBlocking));
+      if (!e->ev_join[g]) HIPCHK(hipEventCreateWithFlags(&e->ev_join[g], hipEventDisableTiming));
+    }
+  }
+  e->ncohort = n;
   return MJH_OK;
 }
 
@@ -262,19 +306,27 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     HIPCHK(hipMemcpyAsync(S.initial_qpos, q0.data(), nq_all * sizeof(float), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
   }
+  { int nc = nenv >= 1024 ? 2 : 1;   // 2 cohorts recover ~95% of the slot-limited throughput; more need GPU_MAX_HW_QUEUES > 4
+    if (const char* v = getenv("MJH_COHORTS")) nc = atoi(v); if (set_cohorts(e, nc)) { mjh_destroy(e); return MJH_ERR_NO_DEVICE; } }
   *out = e;
   return MJH_OK;
 }
 
 extern "C" void mjh_destroy(mjh_engine* e) {
   if (!e) return;
+  (void)join_cohorts(e);
   (void)hipStreamSynchronize(e->stream);
+  for (int g = 0; g < MJH_MAX_COHORTS; g++) { if (e->cstream[g]) (void)hipStreamDestroy(e->cstream[g]); if (e->ev_join[g]) (void)hipEventDestroy(e->ev_join[g]); }
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  for (auto& p : e->tev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->scratch) (void)hipFree(e->scratch);
   delete e;
 }
 
-#define ENG(e) if (!(e)) { mjh_set_error("null engine"); return MJH_ERR_ARG; }
+#define ENG_NOJOIN(e) if (!(e)) { mjh_set_error("null engine"); return MJH_ERR_ARG; }
+// every entry point except mjh_step first joins the cohort streams back into the caller's stream
+#define ENG(e) ENG_NOJOIN(e) { int rcj_ = join_cohorts(e); if (rcj_) return rcj_; }
 #define RANGE(e, env0, n) if ((env0) < 0 || (n) < 0 || (env0) + (n) > (e)->nenv) { mjh_set_error("env range out of bounds"); return MJH_ERR_ARG; }
 
 extern "C" int mjh_step1(mjh_engine* e) { ENG(e); e->step1_done = true; return launch(e, 0, e->nenv, 1, PH_STEP1, XF_FORCE); }
@@ -287,23 +339,51 @@ extern "C" int mjh_step2(mjh_engine* e) {
 }
 extern "C" int mjh_forward(mjh_engine* e) { ENG(e); return launch(e, 0, e->nenv, 1, PH_STEP1 | PH_NOINT, XF_FORCE); }
 extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
-  ENG(e);
-  if (e->lpt && !e->d_order && e->nenv >= 2048) {
-    int rc = dev_alloc(e, &e->d_order, (size_t)e->nenv);
+  ENG_NOJOIN(e);
+  if (e->lpt && !e->d_order && e->nenv >= 1024) {
+    int rc = join_cohorts(e);
+    if (!rc) rc = dev_alloc(e, &e->d_order, (size_t)e->nenv);
     if (rc) return rc;
   }
-  for (int s = 0; s < nsteps; s++) {   // one launch per step (commands are consumed by the first one)
-    DState saved = e->S;
-    if (e->lpt && e->d_order) {         // dispatch the envs with the most solver work first (shorter kernel tail)
-      hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, e->stream, (const int*)e->S.stats, e->d_order, e->nenv);
-      e->S.env_order = e->d_order;
+  const int G = e->ncohort > 1 && e->nenv >= 64 * e->ncohort ? e->ncohort : 1;
+  int rc = G > 1 ? fork_cohorts(e) : join_cohorts(e);
+  if (rc) return rc;
+  const int ph = PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0);
+  DState saved = e->S;
+  if (e->lpt && e->d_order) e->S.env_order = e->d_order;
+  for (int s = 0; s < nsteps && !rc; s++) {   // one launch per step and cohort (commands are consumed by the first one)
+    for (int g = 0; g < G && !rc; g++) {
+      const int g0 = (int)((long long)e->nenv * g / G), g1 = (int)((long long)e->nenv * (g + 1) / G);
+      hipStream_t st = G > 1 ? e->cstream[g] : e->stream;
+      if (e->S.env_order)   // dispatch the envs with the most solver work first (shorter kernel tail)
+        hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, st, (const int*)e->S.stats, e->d_order, g0, g1 - g0);
+      hipEvent_t ta = nullptr, tb = nullptr;
+      if (e->timing) {
+        if (e->tev_used == e->tev.size()) { hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); e->tev.push_back({a, b}); }
+        ta = e->tev[e->tev_used].first; tb = e->tev[e->tev_used].second; e->tev_used++;
+        HIPCHK(hipEventRecord(ta, st));
+      }
+      rc = launch_on(e, st, g0, g1 - g0, 1, ph, 0);
+      if (ta && !rc) HIPCHK(hipEventRecord(tb, st));
     }
-    int rc = launch(e, 0, e->nenv, 1, PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0), 0);
-    e->S = saved;
-    if (rc) return rc;
   }
+  e->S = saved;
+  return rc;
+}
+// Per-launch timing of the step kernels with HIP events on the streams they are launched on (bench.py's roofline leg).
+extern "C" int mjh_set_launch_timing(mjh_engine* e, int on) { ENG(e); e->timing = on != 0; e->tev_used = 0; return MJH_OK; }
+extern "C" int mjh_get_launch_timing(mjh_engine* e, double* mean_ms, int* count) {
+  ENG(e);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  double acc = 0;
+  for (size_t i = 0; i < e->tev_used; i++) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e->tev[i].first, e->tev[i].second)); acc += ms; }
+  if (mean_ms) *mean_ms = e->tev_used ? acc / (double)e->tev_used : 0.0;
+  if (count) *count = (int)e->tev_used;
+  e->tev_used = 0;
   return MJH_OK;
 }
+extern "C" int mjh_set_cohorts(mjh_engine* e, int n) { ENG(e); return set_cohorts(e, n); }
+extern "C" int mjh_get_cohorts(const mjh_engine* e) { return e ? e->ncohort : 0; }
 extern "C" int mjh_synchronize(mjh_engine* e) { ENG(e); HIPCHK(hipStreamSynchronize(e->stream)); return MJH_OK; }
 
 // ---- host <-> device marshalling helpers (double on the host side, padded fp32 rows on the device)
@@ -555,20 +635,39 @@ extern "C" int mjh_export_state_device(mjh_engine* e, void* d_out) {
 extern "C" int mjh_debug_stage_cycles(mjh_engine* e, int with_inverse, double* out) {
   ENG(e);
   long long* buf = nullptr;
-  HIPCHK(hipMalloc((void**)&buf, (size_t)e->nenv * 16 * sizeof(long long)));
-  HIPCHK(hipMemsetAsync(buf, 0, (size_t)e->nenv * 16 * sizeof(long long), e->stream));
+  HIPCHK(hipMalloc((void**)&buf, (size_t)e->nenv * PROF_STRIDE * sizeof(long long)));
+  HIPCHK(hipMemsetAsync(buf, 0, (size_t)e->nenv * PROF_STRIDE * sizeof(long long), e->stream));
   DState saved = e->S;
   e->S.x_prof = buf;
   int rc = launch(e, 0, e->nenv, 1, PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0), XF_PROF);
   e->S = saved;
-  std::vector<long long> h((size_t)e->nenv * 16);
+  std::vector<long long> h((size_t)e->nenv * PROF_STRIDE);
   if (!rc) { HIPCHK(hipMemcpyAsync(h.data(), buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }
   (void)hipFree(buf);
   if (rc) return rc;
   for (int k = 0; k < 16; k++) out[k] = 0;
-  for (int en = 0; en < e->nenv; en++) for (int k = 0; k < 16; k++) { long long v = h[(size_t)en*16+k]; out[k] += v ? (double)(v - h[(size_t)en*16]) : 0.0; }
+  for (int en = 0; en < e->nenv; en++) for (int k = 0; k < 16; k++) { long long v = h[(size_t)en*PROF_STRIDE+k]; out[k] += v ? (double)(v - h[(size_t)en*PROF_STRIDE]) : 0.0; }
   for (int k = 0; k < 16; k++) out[k] /= e->nenv;
   return MJH_OK;
+}
+
+// raw per-env stamps of one LPT-ordered step launch (debug timeline tool): out[nenv*PROF_STRIDE]
+extern "C" int mjh_debug_stage_raw(mjh_engine* e, int with_inverse, long long* out) {
+  ENG(e);
+  long long* buf = nullptr;
+  HIPCHK(hipMalloc((void**)&buf, (size_t)e->nenv * PROF_STRIDE * sizeof(long long)));
+  HIPCHK(hipMemsetAsync(buf, 0, (size_t)e->nenv * PROF_STRIDE * sizeof(long long), e->stream));
+  DState saved = e->S;
+  e->S.x_prof = buf;
+  if (e->lpt && e->d_order) {
+    hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, e->stream, (const int*)e->S.stats, e->d_order, 0, e->nenv);
+    e->S.env_order = e->d_order;
+  }
+  int rc = launch(e, 0, e->nenv, 1, PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0), XF_PROF);
+  e->S = saved;
+  if (!rc) { HIPCHK(hipMemcpyAsync(out, buf, (size_t)e->nenv * PROF_STRIDE * sizeof(long long), hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }
+  (void)hipFree(buf);
+  return rc;
 }
 
 extern "C" int mjh_nenv(const mjh_engine* e) { return e ? e->nenv : 0; }

@@ -15,7 +15,7 @@
 #include "dev_types.h"
 
 #define WSYNC() __syncthreads()
-#define PROF(k) do { if ((xflags & XF_PROF) && lane == 0) S.x_prof[(size_t)blockIdx.x * 16 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define PROF(k) do { if ((xflags & XF_PROF) && lane == 0) S.x_prof[(size_t)blockIdx.x * PROF_STRIDE + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #define MINIMP 0.0001f
 #define MAXIMP 0.9999f
 
@@ -242,6 +242,11 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   const unsigned slotmask = S.slot_mask ? (unsigned)__builtin_amdgcn_readfirstlane((int)S.slot_mask[env]) : 0u;
   int flags = 0, ncon = 0, nefc = 0, niter = 0;
   PROF(0);
+  if ((xflags & XF_PROF) && lane == 0) {   // 100 MHz wall clock (comparable across CUs) and where this env ran: HW_ID | XCC_ID << 32
+    S.x_prof[(size_t)blockIdx.x * PROF_STRIDE + 16] = (long long)__builtin_amdgcn_s_memrealtime();
+    S.x_prof[(size_t)blockIdx.x * PROF_STRIDE + 19] = env;
+    S.x_prof[(size_t)blockIdx.x * PROF_STRIDE + 18] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(63508) << 32);
+  }
   WSYNC();
   PROF(1);
 
@@ -1284,6 +1289,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
     S.stats[4*env] = ncon; S.stats[4*env+1] = nefc; S.stats[4*env+2] = niter; S.stats[4*env+3] |= flags;
   }
   PROF(15);
+  if ((xflags & XF_PROF) && lane == 0) S.x_prof[(size_t)blockIdx.x * PROF_STRIDE + 17] = (long long)__builtin_amdgcn_s_memrealtime();
 }
 
 // pack time + qpos + qvel per env into one contiguous fp32 buffer (feeds the RCCL all-gather)
@@ -1297,7 +1303,8 @@ __global__ void mjh_export_kernel(const DState S, float* out, int nenv, int nq, 
 
 // Longest-processing-time-first order of the environments for the next launch: counting sort (descending) of the
 // previous step's cost estimate (solver sweeps x constraint rows) in one 1024-thread workgroup.
-__global__ __launch_bounds__(1024) void mjh_order_kernel(const int* __restrict__ stats, int* __restrict__ order, int nenv) {
+__global__ __launch_bounds__(1024) void mjh_order_kernel(const int* __restrict__ stats, int* __restrict__ order, int env0, int nenv) {
+  stats += 4 * (size_t)env0; order += env0;   // this cohort's slice; order[] holds absolute env ids
   __shared__ int hist[256], base[256];
   const int t = threadIdx.x;
   if (t < 256) hist[t] = 0;
@@ -1307,5 +1314,5 @@ __global__ __launch_bounds__(1024) void mjh_order_kernel(const int* __restrict__
   __syncthreads();
   if (t == 0) { int acc = 0; for (int b = 0; b < 256; b++) { base[b] = acc; acc += hist[b]; } }
   __syncthreads();
-  for (int e = t; e < nenv; e += 1024) order[atomicAdd(&base[255 - bucket(e)], 1)] = e;
+  for (int e = t; e < nenv; e += 1024) order[atomicAdd(&base[255 - bucket(e)], 1)] = env0 + e;
 }

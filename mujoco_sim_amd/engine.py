@@ -103,6 +103,17 @@ class Engine:
     def step(self, n=1, with_inverse=False): _chk(self.lib, self.lib.mjh_step(self.h, n, int(with_inverse)), "mjh_step")
     def synchronize(self): _chk(self.lib, self.lib.mjh_synchronize(self.h), "mjh_synchronize")
 
+    # ---- launch scheduling / timing (include/mjhip.h "launch scheduling")
+    def set_cohorts(self, n): _chk(self.lib, self.lib.mjh_set_cohorts(self.h, int(n)), "mjh_set_cohorts")
+    @property
+    def cohorts(self): return self.lib.mjh_get_cohorts(self.h)
+    def set_launch_timing(self, on=True): _chk(self.lib, self.lib.mjh_set_launch_timing(self.h, int(on)), "mjh_set_launch_timing")
+    def get_launch_timing(self):
+        """-> (mean step-kernel duration [ms], launches) since the last call"""
+        ms_, cnt = C.c_double(0), C.c_int(0)
+        _chk(self.lib, self.lib.mjh_get_launch_timing(self.h, C.byref(ms_), C.byref(cnt)), "mjh_get_launch_timing")
+        return ms_.value, cnt.value
+
     # ---- commands (mj_hw_interface.cpp:73-91)
     def set_cmd(self, ddq=None, dq=None, env0=0):
         a = None if ddq is None else np.ascontiguousarray(ddq, dtype=np.float64).reshape(-1, self.nv)
