@@ -28,7 +28,7 @@ struct DModel {
 #undef X
   int nq, nv, nbody, njnt, ngeom, neq, npair, nM, ntree, maxcon, maxefc;
   int nqp, nvp;        // padded row strides of the per-env state arrays (floats)
-  int maxlevel, nfl, ngc, rowW, nstage, has_damping, has_limits, diagM, maxblk, maxbrow;
+  int maxlevel, nfl, ngc, rowW, nstage, has_damping, has_limits, diagM, maxblk, maxbrow, has_dim4;
   int iterations, disableflags;
   float timestep, gravity[3], tolerance, impratio, meaninertia;
 };
@@ -56,7 +56,7 @@ struct DState {
   X(qpos) X(qvel) X(qvref) X(ws) X(qacc) X(smooth) X(asmooth) X(passive) X(bias) X(applied)        \
   X(tmpv) X(tmpv2) X(xpos) X(xquat) X(xmat) X(xipos) X(ximat) X(com) X(cinert) X(crb) X(cvel)      \
   X(cacc) X(cfrc) X(cfrcsub) X(xanchor) X(xaxis) X(cdof) X(cdofdot) X(qM) X(qLD) X(qLDinv)          \
-  X(gpos) X(gmat) X(con) X(blki) X(blkf) X(bv) X(phi) X(sched) X(order) X(J) X(B) X(dofpar) X(dofMadr)               \
+  X(gpos) X(gmat) X(con) X(blki) X(blkf) X(bv) X(phi) X(sched) X(order) X(J) X(B) X(ext) X(zero) X(dofpar) X(dofMadr)               \
   X(p_gsize) X(p_rbound) X(p_mass) X(p_inertia) X(p_binv) X(p_dinv)
 
 struct Lay {
@@ -77,12 +77,13 @@ enum { XF_BODY = 1, XF_GEOM = 2, XF_CON = 4, XF_FORCE = 8, XF_PROF = 16 };
 // constraint blocks: header int4 + 32 floats per block
 //   hd.x = kind | nrows<<4 | nbase<<8 | clamp<<12 | jadr<<16 ; hd.y = id | rtype<<24 | side<<28 ; hd.z = a1 | n1<<16 ; hd.w = a2 | n2<<16
 //   floats: [0..3] R, frictionloss, KI, Bc ; [4..7] aref per BASE row (row r = n +- k has aref_n +- aref_k) ;
-//           [8..13] force per row ; [16..31] A_c = J_base M^-1 J_base^T (upper triangle; the 6 lower-triangle
-//           slots carry 1/AR_rr of the block's rows)
+//           [8..13] force per row ; [14..15] lo, hi ; [16..31] A_c = J_base M^-1 J_base^T (upper triangle) while the block is built,
+//           then the row-space solver data Q (step_kernel.h: pgs_rows) ; condim-4 models add 12 floats per block in s_ext
 #define BLKI_STRIDE 4
 #define BLKF_STRIDE 32
 #define BF_AREF 4
 #define BF_F 8
+#define BF_LO 14   // [14],[15]: projection interval lo, hi of the block's rows
 #define BF_A 16
 enum { BK_SINGLE = 0, BK_PYR3 = 3, BK_PYR4 = 4 };
 enum { RT_EQ = 0, RT_FL = 1, RT_LIMIT = 2, RT_CONTACT = 3 };

@@ -198,6 +198,8 @@ static void derive_device_model(const mjh_model* m, HostPack& hp) {
   M.nqp = pad32(m->nq); M.nvp = pad32(std::max(nv, 1));
   M.maxlevel = maxlevel; M.nfl = (int)fl_dof.size(); M.ngc = (int)gc_body.size(); M.rowW = rowW; M.nstage = nstage;
   M.has_damping = has_damping; M.has_limits = has_limits; M.diagM = diagM;
+  M.has_dim4 = 0;
+  for (int g = 0; g < ng; g++) if (m->geom_condim[g] == 4) M.has_dim4 = 1;
   {
     // a limited joint can have both sides active only if its margins overlap (range narrower than 2 margins)
     int nlim = 0; for (int j = 0; j < nj; j++) if (m->jnt_limited[j]) nlim += (m->jnt_range[2*j+1] - m->jnt_range[2*j] <= 2 * m->jnt_margin[j]) ? 2 : 1;
@@ -235,6 +237,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp) {
     L.blki = put(nblkcap * BLKI_STRIDE); L.blkf = put(nblkcap * BLKF_STRIDE);
     L.bv = put(nblkcap * 4); L.phi = put(nblkcap * 4); L.sched = put(nblkcap * 2); L.order = put(nblkcap);
     L.J = put(jsz); L.B = diagM ? L.J : put(jsz);
+    L.ext = put(M.has_dim4 ? nblkcap * SOLX_N : 0); L.zero = put(4);
     L.total = off;
     hp.lds_bytes = off * (int)sizeof(float);
   }

@@ -84,42 +84,70 @@ DEV int row_off(int d, int a1, int n1, int a2, int n2) {
 }
 
 
-// A_c is stored as its upper triangle in a 4x4 row-major array
-#define A_SYM(A, i, j) ((i) <= (j) ? (A)[4*(i)+(j)] : (A)[4*(j)+(i)])
-// One pyramidal contact block of the PGS sweep: NB base rows (normal, tangents[, torsion]), NR = 2(NB-1) rows
-//   row r = J_n + c_r J_k,  k = 1 + r/2,  c_r = +-mu_k.   Everything after the NB reductions is wave-uniform.
-template <int NB, int NR, int NROW>
-DEV void pgs_pyramid(const float* P, const float* ab, float* f, const float* A, const float* Jd, const float* Bd, float& a, float& improvement) {
-  float u[4] = {Jd[0] * a, Jd[1] * a, Jd[2] * a, NB > 3 ? Jd[3] * a : 0.0f}, dphi[NB];
-  wave_sum4<NROW, NB>(u);
-#pragma unroll
-  for (int j = 0; j < NB; j++) { u[j] -= ab[j]; dphi[j] = 0; }     // u <- J a - aref  (per base; rows are n +- k)
-  const float R = P[0], ht0 = 0.5f * (A[0] + R);
-  const int slot[6] = {4, 8, 9, 12, 13, 14};
+// Row-space solver data of a block (written once per step by the "AR" pass):
+//   Q[16] (block floats 16..31) and, for models with condim-4 contacts, X[12] (s_ext):
+//     1/AR_rr      : r < 4 -> Q[r]     ; r = 4,5 -> Q[14], Q[15]
+//     AR_rr / 2    : r < 4 -> Q[4 + r] ; r = 4,5 -> X[0], X[1]
+//     AR_rs, r < s : 01 02 03 12 13 23 -> Q[8..13] ; 04 05 14 15 24 25 34 35 45 -> X[2..10]
+//   (AR = E A_c E^T + R I over the block's rows e_r = e_n +- e_k; a block with fewer rows has zeros in the unused
+//   slots, which makes the extra unrolled rows of a wider template inert.)
+#define SOLQ_N 16
+#define SOLX_N 12
+DEV constexpr int ar_off_slot(int r, int s) {   // r < s; < 16: Q index, >= 16: 16 + X index
+  return r == 0 ? (s <= 3 ? 7 + s : 16 + s - 2) : r == 1 ? (s <= 3 ? 9 + s : 16 + s) : r == 2 ? (s == 3 ? 13 : 16 + s + 2) : r == 3 ? 16 + s + 4 : 16 + 10;
+}
+#define AR_INV(Q, X, r) ((r) < 4 ? (Q)[r] : (Q)[10 + (r)])
+#define AR_HALF(Q, X, r) ((r) < 4 ? (Q)[4 + (r)] : (X)[(r) - 4])
+#define AR_OFF(Q, X, r, s) (ar_off_slot(r, s) < 16 ? (Q)[ar_off_slot(r, s) & 15] : (X)[ar_off_slot(r, s) & 15])
+// The NR rows of one block, Gauss-Seidel in row space.  u[j] = (J_base a - aref)_j on entry.  Everything here is
+// uniform over the lanes that own the block.  Returns the cost decrease; dphi = E^T delta (per base).
+template <int NB, int NR>
+DEV float pgs_rows(const float R, const float lo, const float hi, const float* u, float* f, const float* Q, const float* X, float* dphi) {
+  float res[NR], dl[NR];
 #pragma unroll
   for (int r = 0; r < NR; r++) {
-    const int k = 1 + (r >> 1);
-    const bool neg = r & 1;
-    const float hs = ht0 + 0.5f * A[4*k + k];
-    const float hAR = neg ? hs - A[k] : hs + A[k];                 // AR_rr / 2
-    const float ARinv = A[slot[r]];                                // precomputed when the block was built
-    const float fold = f[r];
-    const float res = (neg ? u[0] - u[k] : u[0] + u[k]) + R * fold;
-    const float fn = fmaxf(0.0f, fold - res * ARinv);
-    const float delta = fn - fold;
-    // cost change delta*(res + delta*AR/2) <= 0 for every projected scalar update (DESIGN.md §solver), so the
-    // reference's "revert if the cost went up" guard is dead code for pyramidal rows and is not evaluated here
-    improvement -= delta * (res + hAR * delta);
-#pragma unroll
-    for (int j = 0; j < NB; j++) u[j] += (neg ? A_SYM(A, j, 0) - A_SYM(A, j, k) : A_SYM(A, j, 0) + A_SYM(A, j, k)) * delta;
-    dphi[0] += delta; dphi[k] += neg ? -delta : delta;
-    f[r] = fn;
+    const int k = NB > 1 ? 1 + (r >> 1) : 0;
+    res[r] = R * f[r] + (NB > 1 ? ((r & 1) ? u[0] - u[k] : u[0] + u[k]) : u[0]);
   }
+  float imp = 0;
 #pragma unroll
-  for (int j = 0; j < NB; j++) a += Bd[j] * dphi[j];
+  for (int r = 0; r < NR; r++) {
+    const float fn = __builtin_amdgcn_fmed3f(f[r] - res[r] * AR_INV(Q, X, r), lo, hi);
+    const float delta = fn - f[r];
+    // cost change delta*(res + delta*AR/2) <= 0 for every projected scalar update (DESIGN.md §solver), so the
+    // reference's "revert if the cost went up" guard is dead code and is not evaluated here
+    imp -= delta * (res[r] + AR_HALF(Q, X, r) * delta);
+#pragma unroll
+    for (int q = r + 1; q < NR; q++) res[q] += AR_OFF(Q, X, r, q) * delta;
+    f[r] = fn; dl[r] = delta;
+  }
+  dphi[0] = dl[0];
+#pragma unroll
+  for (int r = 1; r < NR; r++) dphi[0] += dl[r];
+#pragma unroll
+  for (int k = 1; k < NB; k++) dphi[k] = dl[2*k - 2] - dl[2*k - 1];
+  return imp;
+}
+// One block of the single-block sweep (nv > 32): NB full-wave reductions, then uniform row math.
+template <int NB, int NR, int NROW>
+DEV void pgs_block(const float R, const float lo, const float hi, const float* ab, float* f, const float* Q, const float* X, const float* Jd, const float* Bd,
+                   const float bscale, float& a, float& improvement) {
+  float u[4] = {Jd[0] * a, NB > 1 ? Jd[1] * a : 0.0f, NB > 2 ? Jd[2] * a : 0.0f, NB > 3 ? Jd[3] * a : 0.0f}, dphi[4];
+  if (NB == 1) u[0] = wave_sum<NROW>(u[0]); else wave_sum4<NROW, NB>(u);
+#pragma unroll
+  for (int j = 0; j < NB; j++) u[j] -= ab[j];
+  improvement += pgs_rows<NB, NR>(R, lo, hi, u, f, Q, X, dphi);
+  float da = Bd[0] * dphi[0];
+#pragma unroll
+  for (int j = 1; j < NB; j++) da += Bd[j] * dphi[j];
+  a += da * bscale;
 }
 
 
+// Keeps every component of a loaded vector formally alive until this point.  Without it the register allocator
+// reuses the unused components of an in-flight ds_read_b128 as scratch, and the resulting write-after-write
+// hazard makes the compiler wait for the load right after issuing it (defeating the software pipeline).
+#define KEEP4(v) asm volatile("" :: "v"((v).x), "v"((v).y), "v"((v).z), "v"((v).w))
 // ---- dual-block PGS (wavefronts with nv <= 32): the two 32-lane halves of the wave solve the two blocks of an
 // independent pair at the same time.  Every "uniform" quantity of the single-block solver becomes uniform
 // per half; a half-wide sum is a 4-step DPP butterfly inside each 16-lane row plus one v_permlane16_swap.
@@ -147,37 +175,17 @@ template <int N> DEV void half_sum4(float* v) {   // sums over each 32-lane half
   swap16_sum4(v, N);
 }
 template <int NB, int NR>
-DEV float pgs_dual(const float* P, const float* ab, float* f, const float* A, const float* Jd, const float* Bd, int clamp, float& a) {
-  float u[4] = {Jd[0] * a, NB > 1 ? Jd[1] * a : 0.0f, NB > 2 ? Jd[2] * a : 0.0f, NB > 3 ? Jd[3] * a : 0.0f}, dphi[4] = {0, 0, 0, 0};
+DEV float pgs_dual(const float R, const float lo, const float hi, const float* ab, float* f, const float* Q, const float* X, const float* Jd, const float* Bd,
+                   const float bscale, float& a) {
+  float u[4] = {Jd[0] * a, NB > 1 ? Jd[1] * a : 0.0f, NB > 2 ? Jd[2] * a : 0.0f, NB > 3 ? Jd[3] * a : 0.0f}, dphi[4];
   half_sum4<NB>(u);
 #pragma unroll
   for (int j = 0; j < NB; j++) u[j] -= ab[j];
-  const float R = P[0], ht0 = 0.5f * (A[0] + R);
-  const float lo = clamp == 0 ? -3.0e38f : (clamp == 2 ? -P[1] : 0.0f), hi = clamp == 2 ? P[1] : 3.0e38f;
-  const int slot[6] = {4, 8, 9, 12, 13, 14};
-  float imp = 0;
+  const float imp = pgs_rows<NB, NR>(R, lo, hi, u, f, Q, X, dphi);
+  float da = Bd[0] * dphi[0];
 #pragma unroll
-  for (int r = 0; r < NR; r++) {
-    const int k = NB > 1 ? 1 + (r >> 1) : 0;
-    const bool neg = r & 1;
-    const float hs = NB > 1 ? ht0 + 0.5f * A[4*k + k] : ht0;
-    const float hAR = NB > 1 ? (neg ? hs - A[k] : hs + A[k]) : hs;
-    const float ARinv = A[slot[r]];
-    const float fold = f[r];
-    const float un = NB > 1 ? (neg ? u[0] - u[k] : u[0] + u[k]) : u[0];
-    const float res = un + R * fold;
-    const float fn = fminf(hi, fmaxf(lo, fold - res * ARinv));
-    const float delta = fn - fold;
-    imp -= delta * (res + hAR * delta);
-#pragma unroll
-    for (int j = 0; j < NB; j++) u[j] += (NB > 1 ? (neg ? A_SYM(A, j, 0) - A_SYM(A, j, k) : A_SYM(A, j, 0) + A_SYM(A, j, k)) : A[0]) * delta;
-    dphi[0] += delta; if (NB > 1) dphi[k] += neg ? -delta : delta;
-    f[r] = fn;
-  }
-  float da = 0;
-#pragma unroll
-  for (int j = 0; j < NB; j++) da += Bd[j] * dphi[j];
-  a += swap32_sum(da);       // the pair's blocks touch disjoint dofs: both halves end up with the same `a`
+  for (int j = 1; j < NB; j++) da += Bd[j] * dphi[j];
+  a += swap32_sum(da * bscale);       // the pair's blocks touch disjoint dofs: both halves end up with the same `a`
   return imp;
 }
 
@@ -227,6 +235,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
     // qvel_ref / qfrc_applied only cross launches in the split API (step1 | inverse | step2 as separate calls)
     if (!(ph & PH_STEP1)) { s_qvref[i] = S.qvel_ref[vrow + i]; s_applied[i] = S.qfrc_applied[vrow + i]; }
   }
+  if (lane < 4) s_zero[lane] = 0;   // what lanes outside a block read instead of its Jacobian
   // hot chain-walk tables and the (possibly per-env) model parameters go to LDS once per launch
   for (int i = lane; i < nv; i += 64) {
     s_dofpar_i[i] = dof_parentid[i]; s_dofMadr_i[i] = dof_Madr[i];
@@ -724,16 +733,54 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       for (int i = 0; i < 4; i++) if (i >= jb && i < nb) A[4*jb + i] = acc[i];
     }
     WSYNC();
-    // 1/AR_rr of every row, AR_rr = A_nn +- 2 A_nk + A_kk + R, parked in the 6 unused lower-triangle slots of A
+    // ---- row-space matrix of every block: AR = E A_c E^T + R I (rows e_r = e_n +- e_k), laid out for pgs_rows()
     for (int b = lane; b < nblk; b += 64) {
       const int* hd = s_blki_i + b * BLKI_STRIDE;
       float* bf = s_blkf + b * BLKF_STRIDE;
-      float* A = bf + BF_A;
+      float* Q = bf + BF_A;
       const int kind = hd[0] & 15, nr = (hd[0] >> 4) & 15;
-      const float t0 = A[0] + bf[0];
-      const int slot[6] = {4, 8, 9, 12, 13, 14};
-      if (kind == BK_SINGLE) A[4] = 1.0f / t0;
-      else for (int r = 0; r < nr; r++) { const int k = 1 + (r >> 1); A[slot[r]] = 1.0f / (t0 + A[4*k + k] + ((r & 1) ? -2.0f : 2.0f) * A[k]); }
+      float Ac[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = i; j < 4; j++) { Ac[i][j] = Q[4*i + j]; Ac[j][i] = Ac[i][j]; }
+      const float R = bf[0];
+      float q[SOLQ_N], x[SOLX_N];
+#pragma unroll
+      for (int i = 0; i < SOLQ_N; i++) q[i] = 0;
+#pragma unroll
+      for (int i = 0; i < SOLX_N; i++) x[i] = 0;
+      if (kind == BK_SINGLE) { const float AR = Ac[0][0] + R; q[0] = 1.0f / AR; q[4] = 0.5f * AR; }
+      else {
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          if (r >= nr) continue;
+          const int kr = 1 + (r >> 1); const float cr = (r & 1) ? -1.0f : 1.0f;
+          const float AR = Ac[0][0] + 2.0f * cr * Ac[0][kr] + Ac[kr][kr] + R;
+          const float inv = 1.0f / AR, half = 0.5f * AR;
+          if (r < 4) { q[r] = inv; q[4 + r] = half; } else { q[10 + r] = inv; x[r - 4] = half; }
+#pragma unroll
+          for (int t = r + 1; t < 6; t++) {
+            if (t >= nr) continue;
+            const int kt = 1 + (t >> 1); const float ct = (t & 1) ? -1.0f : 1.0f;
+            const float v = Ac[0][0] + ct * Ac[0][kt] + cr * Ac[kr][0] + cr * ct * Ac[kr][kt];
+            const int sl = ar_off_slot(r, t);
+            if (sl < 16) q[sl] = v; else x[sl - 16] = v;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < SOLQ_N; i++) Q[i] = q[i];
+      {   // projection interval of the block's rows: equality (-inf, inf), friction loss [-fl, fl], everything else [0, inf)
+        const int clamp = (hd[0] >> 12) & 3;
+        bf[BF_LO] = clamp == 0 ? -3.0e38f : (clamp == 2 ? -bf[1] : 0.0f);
+        bf[BF_LO + 1] = clamp == 2 ? bf[1] : 3.0e38f;
+      }
+      if (M.has_dim4) {
+        float* X = s_ext + b * SOLX_N;
+#pragma unroll
+        for (int i = 0; i < SOLX_N; i++) X[i] = x[i];
+      }
     }
     WSYNC();
     // ---- Gauss-Seidel visiting order (shared with the oracle): block i, then the first later unvisited block
@@ -1068,49 +1115,68 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
         const float4* blkf4 = (const float4*)s_blkf;
         const int4* blki4 = (const int4*)s_blki_i;
+        const bool has_dim4 = M.has_dim4 != 0;   // condim-4 contacts present: blocks carry the X extension
         if constexpr (NROW <= 2) {
           // ======== dual-block sweep: half 0 solves block p, half 1 its independent partner q of the schedule
           const int hh = lane >> 5;
-          struct DOp { int hx, b; float act; float4 J, B, P, r0, r1, r2, A0, A1, A2, A3; };
-          auto fetchD = [&](int g) __attribute__((always_inline)) {
-            DOp op;
-            const int2 pq = *(const int2*)(s_sched_i + 2*g);
+          // software pipeline over the (cyclic) schedule, every stage consuming LDS data requested one step earlier:
+          //   S: pair of step t+3  ->  H: block header of step t+2  ->  L: operands of step t+1  ->  solve step t
+          struct DHd { int4 hd; int b; float act; };
+          struct DOp { int hx, b; float act, R; float4 J, B, r0, r1, r2, A0, A1, A2, A3, X0, X1, X2; };
+          int gS = 0;
+          auto nextS = [&]() __attribute__((always_inline)) {
+            const int2 pq = *(const int2*)(s_sched_i + 2*gS);
+            gS = gS + 1 == ngrp ? 0 : gS + 1;
+            return pq;
+          };
+          auto hdrOf = [&](const int2 pq) __attribute__((always_inline)) {
+            DHd h;
             const int bsel = hh ? pq.y : pq.x;
             const bool act = bsel >= 0;
-            const int b = act ? bsel : pq.x;
-            const int4 hd = blki4[b];
-            ROW_TREES(hd.z, hd.w);
+            h.b = act ? bsel : pq.x; h.act = act ? 1.0f : 0.0f;
+            h.hd = blki4[h.b];
+            return h;
+          };
+          auto loadOp = [&](const DHd& h) __attribute__((always_inline)) {
+            DOp op;
+            KEEP4(h.hd);
+            ROW_TREES(h.hd.z, h.hd.w);
             const int o = row_off(d0, a1, n1, a2, n2);
-            const float msk = (o >= 0 && act) ? 1.0f : 0.0f;
-            const int jo = BLK_JOFF(hd.x), oc = max(o, 0);
-            const bool quad = DIAGM || BLK_SLOTS(hd.y) == 4;   // DIAGM models have contact blocks only (engine.hip)
-            float4 jv = make_float4(0, 0, 0, 0), bv4 = make_float4(0, 0, 0, 0);
-            if (quad) jv = *(const float4*)(s_J + jo + 4*oc); else jv.x = s_J[jo + oc];
-            jv.x *= msk; jv.y *= msk; jv.z *= msk; jv.w *= msk;
-            op.J = jv;
-            if (DIAGM) { op.B.x = jv.x * minv0; op.B.y = jv.y * minv0; op.B.z = jv.z * minv0; op.B.w = jv.w * minv0; }
-            else { if (quad) bv4 = *(const float4*)(s_B + jo + 4*oc); else bv4.x = s_B[jo + oc];
-                   bv4.x *= msk; bv4.y *= msk; bv4.z *= msk; bv4.w *= msk; op.B = bv4; }
-            op.P = blkf4[8*b]; op.r0 = blkf4[8*b+1]; op.r1 = blkf4[8*b+2]; op.r2 = blkf4[8*b+3];
+            const bool on = o >= 0 && h.act > 0.0f;            // lanes outside the block read the zero slot
+            const int jo = BLK_JOFF(h.hd.x), b = h.b;
+            const bool quad = DIAGM || BLK_SLOTS(h.hd.y) == 4; // DIAGM models have contact blocks only (engine.hip)
+            if (quad) op.J = *(const float4*)(on ? s_J + jo + 4*o : s_zero);
+            else op.J = make_float4(on ? s_J[jo + o] : 0.0f, 0, 0, 0);
+            if (!DIAGM) {
+              if (quad) op.B = *(const float4*)(on ? s_B + jo + 4*o : s_zero);
+              else op.B = make_float4(on ? s_B[jo + o] : 0.0f, 0, 0, 0);
+            }
+            op.R = s_blkf[BLKF_STRIDE * b]; op.r0 = blkf4[8*b+1]; op.r1 = blkf4[8*b+2]; op.r2 = blkf4[8*b+3];
             op.A0 = blkf4[8*b+4]; op.A1 = blkf4[8*b+5]; op.A2 = blkf4[8*b+6]; op.A3 = blkf4[8*b+7];
-            op.hx = act ? hd.x : 0; op.b = b; op.act = act ? 1.0f : 0.0f;
+            if (has_dim4) { const float4* x4 = (const float4*)(s_ext + b * SOLX_N); op.X0 = x4[0]; op.X1 = x4[1]; op.X2 = x4[2]; }
+            op.hx = h.act > 0.0f ? h.hd.x : 0; op.b = b; op.act = h.act;
             return op;
           };
           auto processD = [&](DOp& op, float& improvement) __attribute__((always_inline)) {
             // the unrolled row count follows the larger of the two blocks; the smaller one's extra rows are inert
             const int k0 = __builtin_amdgcn_readlane(op.hx & 15, 0), k1 = __builtin_amdgcn_readlane(op.hx & 15, 32);
             const int kind = k0 > k1 ? k0 : k1;
+            KEEP4(op.J); KEEP4(op.r0); KEEP4(op.r1); KEEP4(op.r2); KEEP4(op.A0); KEEP4(op.A1); KEEP4(op.A2); KEEP4(op.A3);
+            if (!DIAGM) KEEP4(op.B);
+            if (has_dim4) { KEEP4(op.X0); KEEP4(op.X1); KEEP4(op.X2); }
             float f[6] = {op.r1.x, op.r1.y, op.r1.z, op.r1.w, op.r2.x, op.r2.y};
+            const float lo = op.r2.z, hi = op.r2.w;
             const float ab[4] = {op.r0.x, op.r0.y, op.r0.z, op.r0.w};
-            const float A[16] = {op.A0.x, op.A0.y, op.A0.z, op.A0.w, op.A1.x, op.A1.y, op.A1.z, op.A1.w,
+            const float Q[16] = {op.A0.x, op.A0.y, op.A0.z, op.A0.w, op.A1.x, op.A1.y, op.A1.z, op.A1.w,
                                  op.A2.x, op.A2.y, op.A2.z, op.A2.w, op.A3.x, op.A3.y, op.A3.z, op.A3.w};
-            const float P[4] = {op.P.x, op.P.y, op.P.z, op.P.w};
+            const float X[12] = {op.X0.x, op.X0.y, op.X0.z, op.X0.w, op.X1.x, op.X1.y, op.X1.z, op.X1.w, op.X2.x, op.X2.y, op.X2.z, op.X2.w};
             const float Jd[4] = {op.J.x, op.J.y, op.J.z, op.J.w}, Bd[4] = {op.B.x, op.B.y, op.B.z, op.B.w};
-            const int clamp = (op.hx >> 12) & 3;
+            const float* Bp = DIAGM ? Jd : Bd;                 // diagonal M: B = J / M_dd, applied as one scale of da
+            const float bs = DIAGM ? minv0 : 1.0f;
             float imp;
-            if (kind == BK_PYR4) imp = pgs_dual<4, 6>(P, ab, f, A, Jd, Bd, clamp, a);
-            else if (kind == BK_PYR3) imp = pgs_dual<3, 4>(P, ab, f, A, Jd, Bd, clamp, a);
-            else imp = pgs_dual<1, 1>(P, ab, f, A, Jd, Bd, clamp, a);
+            if (kind == BK_PYR4) imp = pgs_dual<4, 6>(op.R, lo, hi, ab, f, Q, X, Jd, Bp, bs, a);
+            else if (kind == BK_PYR3) imp = pgs_dual<3, 4>(op.R, lo, hi, ab, f, Q, X, Jd, Bp, bs, a);
+            else imp = pgs_dual<1, 1>(op.R, lo, hi, ab, f, Q, X, Jd, Bp, bs, a);
             improvement += op.act * imp;
             if (d0 == 0 && op.act > 0.0f) {
               float* bf = s_blkf + op.b * BLKF_STRIDE + BF_F;
@@ -1118,42 +1184,56 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
               *(float2*)(bf + 4) = make_float2(f[4], f[5]);
             }
           };
-          for (int it = 0; it < M.iterations; it++) {
-            float impl = 0;
-            DOp opA = fetchD(0), opB;
-            for (int g = 0; g < ngrp; g += 2) {
-              opB = fetchD(g + 1 < ngrp ? g + 1 : g);
-              processD(opA, impl);
-              if (g + 1 < ngrp) {
-                opA = fetchD(g + 2 < ngrp ? g + 2 : g + 1);
-                processD(opB, impl);
-              }
+          if (ngrp == 1) {
+            // a single group: its operands (the forces) change under the prefetch, so no pipeline
+            for (int it = 0; it < M.iterations; it++) {
+              float impl = 0;
+              DOp op = loadOp(hdrOf(*(const int2*)s_sched_i));
+              processD(op, impl);
+              niter = it + 1;
+              const float improvement = readlane_f(impl, 0) + readlane_f(impl, 32);
+              if (improvement * scale < M.tolerance) break;
             }
-            niter = it + 1;
-            const float improvement = readlane_f(impl, 0) + readlane_f(impl, 32);
-            if (improvement * scale < M.tolerance) break;
-            WSYNC();
+          } else {
+            int2 pqN = nextS();                      // pair of step 0
+            DHd hN = hdrOf(pqN); pqN = nextS();      // header of step 0, pair of step 1
+            DOp opA = loadOp(hN), opB;               // operands of step 0
+            hN = hdrOf(pqN); pqN = nextS();          // header of step 1, pair of step 2
+            for (int it = 0; it < M.iterations; it++) {
+              float impl = 0;
+              for (int g = 0; g < ngrp; g += 2) {
+                opB = loadOp(hN); hN = hdrOf(pqN); pqN = nextS();
+                processD(opA, impl);
+                if (g + 1 < ngrp) {
+                  opA = loadOp(hN); hN = hdrOf(pqN); pqN = nextS();
+                  processD(opB, impl);
+                } else opA = opB;                    // odd group count: step 0 of the next sweep was loaded into B
+              }
+              niter = it + 1;
+              const float improvement = readlane_f(impl, 0) + readlane_f(impl, 32);
+              if (improvement * scale < M.tolerance) break;
+            }
           }
         } else {
         // operands of one block: 1 header + 1 (2) Jacobian + 8 parameter ds_read_b128 per lane
-        struct BlkOp { int hx; float4 J, B, P, r0, r1, r2, A0, A1, A2, A3; };
+        struct BlkOp { int hx; float4 J, B, P, r0, r1, r2, A0, A1, A2, A3, X0, X1, X2; };
         auto fetch = [&](int b) __attribute__((always_inline)) {
           BlkOp op;
           const int4 hd = blki4[b];
           ROW_TREES(hd.z, hd.w);
           const int o = row_off(d0, a1, n1, a2, n2);
-          const float msk = o >= 0 ? 1.0f : 0.0f;
-          const int jo = BLK_JOFF(hd.x), oc = max(o, 0);
+          const bool on = o >= 0;                            // lanes outside the block read the zero slot
+          const int jo = BLK_JOFF(hd.x);
           const bool quad = DIAGM || BLK_SLOTS(hd.y) == 4;   // DIAGM models have contact blocks only (engine.hip)
-          float4 jv = make_float4(0, 0, 0, 0), bv4 = make_float4(0, 0, 0, 0);
-          if (quad) jv = *(const float4*)(s_J + jo + 4*oc); else jv.x = s_J[jo + oc];
-          jv.x *= msk; jv.y *= msk; jv.z *= msk; jv.w *= msk;
-          op.J = jv;
-          if (DIAGM) { op.B.x = jv.x * minv0; op.B.y = jv.y * minv0; op.B.z = jv.z * minv0; op.B.w = jv.w * minv0; }
-          else { if (quad) bv4 = *(const float4*)(s_B + jo + 4*oc); else bv4.x = s_B[jo + oc];
-                 bv4.x *= msk; bv4.y *= msk; bv4.z *= msk; bv4.w *= msk; op.B = bv4; }
+          if (quad) op.J = *(const float4*)(on ? s_J + jo + 4*o : s_zero);
+          else op.J = make_float4(on ? s_J[jo + o] : 0.0f, 0, 0, 0);
+          if (!DIAGM) {
+            if (quad) op.B = *(const float4*)(on ? s_B + jo + 4*o : s_zero);
+            else op.B = make_float4(on ? s_B[jo + o] : 0.0f, 0, 0, 0);
+          }
           op.P = blkf4[8*b]; op.r0 = blkf4[8*b+1]; op.r1 = blkf4[8*b+2]; op.r2 = blkf4[8*b+3];
           op.A0 = blkf4[8*b+4]; op.A1 = blkf4[8*b+5]; op.A2 = blkf4[8*b+6]; op.A3 = blkf4[8*b+7];
+          if (has_dim4) { const float4* x4 = (const float4*)(s_ext + b * SOLX_N); op.X0 = x4[0]; op.X1 = x4[1]; op.X2 = x4[2]; }
           op.hx = hd.x;
           return op;
         };
@@ -1161,24 +1241,16 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           const int kind = __builtin_amdgcn_readfirstlane(op.hx & 15);
           float f[6] = {op.r1.x, op.r1.y, op.r1.z, op.r1.w, op.r2.x, op.r2.y};
           const float aref[4] = {op.r0.x, op.r0.y, op.r0.z, op.r0.w};
-          const float A[16] = {op.A0.x, op.A0.y, op.A0.z, op.A0.w, op.A1.x, op.A1.y, op.A1.z, op.A1.w,
+          const float Q[16] = {op.A0.x, op.A0.y, op.A0.z, op.A0.w, op.A1.x, op.A1.y, op.A1.z, op.A1.w,
                                op.A2.x, op.A2.y, op.A2.z, op.A2.w, op.A3.x, op.A3.y, op.A3.z, op.A3.w};
-          const float P[4] = {op.P.x, op.P.y, op.P.z, op.P.w};
+          const float X[12] = {op.X0.x, op.X0.y, op.X0.z, op.X0.w, op.X1.x, op.X1.y, op.X1.z, op.X1.w, op.X2.x, op.X2.y, op.X2.z, op.X2.w};
           const float Jd[4] = {op.J.x, op.J.y, op.J.z, op.J.w}, Bd[4] = {op.B.x, op.B.y, op.B.z, op.B.w};
-          if (kind == BK_PYR4) pgs_pyramid<4, 6, NROW>(P, aref, f, A, Jd, Bd, a, improvement);
-          else if (kind == BK_PYR3) pgs_pyramid<3, 4, NROW>(P, aref, f, A, Jd, Bd, a, improvement);
-          else {
-            const int clamp = __builtin_amdgcn_readfirstlane((op.hx >> 12) & 3);
-            const float u0 = wave_sum<NROW>(Jd[0] * a);
-            const float R = P[0], AR = A[0] + R, ARinv = A[4], fold = f[0];
-            const float res = u0 - aref[0] + R * fold;
-            float fn = fold - res * ARinv;
-            if (clamp == 1) fn = fmaxf(0.0f, fn); else if (clamp == 2) fn = fminf(P[1], fmaxf(-P[1], fn));
-            const float delta = fn - fold;
-            improvement -= delta * (res + 0.5f * AR * delta);
-            a += Bd[0] * delta;
-            f[0] = fn;
-          }
+          const float* Bp = DIAGM ? Jd : Bd;
+          const float bs = DIAGM ? minv0 : 1.0f;
+          const float R = op.P.x, lo = op.r2.z, hi = op.r2.w;
+          if (kind == BK_PYR4) pgs_block<4, 6, NROW>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, a, improvement);
+          else if (kind == BK_PYR3) pgs_block<3, 4, NROW>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, a, improvement);
+          else pgs_block<1, 1, NROW>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, a, improvement);
           if (lane == 0) {
             float* bf = s_blkf + b * BLKF_STRIDE + BF_F;
             *(float4*)(bf) = make_float4(f[0], f[1], f[2], f[3]);
