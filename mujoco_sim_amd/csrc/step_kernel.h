@@ -629,7 +629,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           }
         }
       }
-      if (jb == 0) { hd[2] = tree_dofadr[t1] | (tree_dofnum[t1] << 16); hd[3] = t2 >= 0 ? (tree_dofadr[t2] | (tree_dofnum[t2] << 16)) : 0; }
+      if (jb == 0) { hd[2] = tree_dofadr[t1] | (tree_dofnum[t1] << 16); hd[3] = t2 >= 0 ? (tree_dofadr[t2] | (tree_dofnum[t2] << 16)) : 0xffff; }   // no second tree: n2 = 0, a2 matches no dof
     }
     // ---- block parameters: impedance, regulariser R, reference gains (lanes = blocks)
     for (int b = lane; b < nblk; b += 64) {
@@ -1112,6 +1112,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         const int d0 = (NROW <= 2) ? (lane & 31) : lane;   // dual mode: both halves carry a copy of the dof vector
         float a = (d0 < nv) ? s_asmooth[d0] + s_tmpv[d0] : 0.0f;
         const float minv0 = (d0 < nv) ? s_qLDinv[d0] : 0.0f;
+        const int r6 = d0 % 6, dbase6 = d0 < nv ? d0 - r6 : -1;   // DIAGM: dof inside its free body / first dof of that body
         const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
         const float4* blkf4 = (const float4*)s_blkf;
         const int4* blki4 = (const int4*)s_blki_i;
@@ -1141,8 +1142,9 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             DOp op;
             KEEP4(h.hd);
             ROW_TREES(h.hd.z, h.hd.w);
-            const int o = row_off(d0, a1, n1, a2, n2);
-            const bool on = o >= 0 && h.act > 0.0f;            // lanes outside the block read the zero slot
+            int o; bool on;                                    // lanes outside the block read the zero slot
+            if (DIAGM) { const bool on2 = dbase6 == a2; o = r6 + (on2 ? 6 : 0); on = (dbase6 == a1 || on2) && h.act > 0.0f; }   // free bodies: 6 dofs each
+            else { o = row_off(d0, a1, n1, a2, n2); on = o >= 0 && h.act > 0.0f; }
             const int jo = BLK_JOFF(h.hd.x), b = h.b;
             const bool quad = DIAGM || BLK_SLOTS(h.hd.y) == 4; // DIAGM models have contact blocks only (engine.hip)
             if (quad) op.J = *(const float4*)(on ? s_J + jo + 4*o : s_zero);
@@ -1221,8 +1223,9 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           BlkOp op;
           const int4 hd = blki4[b];
           ROW_TREES(hd.z, hd.w);
-          const int o = row_off(d0, a1, n1, a2, n2);
-          const bool on = o >= 0;                            // lanes outside the block read the zero slot
+          int o; bool on;                                    // lanes outside the block read the zero slot
+          if (DIAGM) { const bool on2 = dbase6 == a2; o = r6 + (on2 ? 6 : 0); on = dbase6 == a1 || on2; }   // free bodies: 6 dofs each
+          else { o = row_off(d0, a1, n1, a2, n2); on = o >= 0; }
           const int jo = BLK_JOFF(hd.x);
           const bool quad = DIAGM || BLK_SLOTS(hd.y) == 4;   // DIAGM models have contact blocks only (engine.hip)
           if (quad) op.J = *(const float4*)(on ? s_J + jo + 4*o : s_zero);
