@@ -231,13 +231,15 @@ static void derive_device_model(const mjh_model* m, HostPack& hp) {
     {  // the contact records die once the blocks are built; the velocity-stage spatial vectors reuse their space
       const int a4 = [](int n) { return ((std::max(n, 1) + 3) / 4) * 4; }(6*nb);
       const int velsz = 4 * a4 + ((6*nv + 3) / 4) * 4;
-      L.con = put(std::max(M.maxcon * CON_STRIDE, velsz));
+      // (and, once those are dead too, the solver's per-block X extension of condim-4 models)
+      L.con = put(std::max(std::max(M.maxcon * CON_STRIDE, velsz), M.has_dim4 ? (M.maxblk + 2) * SOLX_N : 0));
+      L.ext = L.con;
       L.cvel = L.con; L.cacc = L.con + a4; L.cfrc = L.con + 2*a4; L.cfrcsub = L.con + 3*a4; L.cdofdot = L.con + 4*a4;
     }
     L.blki = put(nblkcap * BLKI_STRIDE); L.blkf = put(nblkcap * BLKF_STRIDE);
     L.bv = put(nblkcap * 4); L.phi = put(nblkcap * 4); L.sched = put(nblkcap * 2); L.order = put(nblkcap);
     L.J = put(jsz); L.B = diagM ? L.J : put(jsz);
-    L.ext = put(M.has_dim4 ? nblkcap * SOLX_N : 0); L.zero = put(4);
+    L.zero = put(4);
     L.total = off;
     hp.lds_bytes = off * (int)sizeof(float);
   }

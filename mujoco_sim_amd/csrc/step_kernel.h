@@ -733,56 +733,6 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       for (int i = 0; i < 4; i++) if (i >= jb && i < nb) A[4*jb + i] = acc[i];
     }
     WSYNC();
-    // ---- row-space matrix of every block: AR = E A_c E^T + R I (rows e_r = e_n +- e_k), laid out for pgs_rows()
-    for (int b = lane; b < nblk; b += 64) {
-      const int* hd = s_blki_i + b * BLKI_STRIDE;
-      float* bf = s_blkf + b * BLKF_STRIDE;
-      float* Q = bf + BF_A;
-      const int kind = hd[0] & 15, nr = (hd[0] >> 4) & 15;
-      float Ac[4][4];
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = i; j < 4; j++) { Ac[i][j] = Q[4*i + j]; Ac[j][i] = Ac[i][j]; }
-      const float R = bf[0];
-      float q[SOLQ_N], x[SOLX_N];
-#pragma unroll
-      for (int i = 0; i < SOLQ_N; i++) q[i] = 0;
-#pragma unroll
-      for (int i = 0; i < SOLX_N; i++) x[i] = 0;
-      if (kind == BK_SINGLE) { const float AR = Ac[0][0] + R; q[0] = 1.0f / AR; q[4] = 0.5f * AR; }
-      else {
-#pragma unroll
-        for (int r = 0; r < 6; r++) {
-          if (r >= nr) continue;
-          const int kr = 1 + (r >> 1); const float cr = (r & 1) ? -1.0f : 1.0f;
-          const float AR = Ac[0][0] + 2.0f * cr * Ac[0][kr] + Ac[kr][kr] + R;
-          const float inv = 1.0f / AR, half = 0.5f * AR;
-          if (r < 4) { q[r] = inv; q[4 + r] = half; } else { q[10 + r] = inv; x[r - 4] = half; }
-#pragma unroll
-          for (int t = r + 1; t < 6; t++) {
-            if (t >= nr) continue;
-            const int kt = 1 + (t >> 1); const float ct = (t & 1) ? -1.0f : 1.0f;
-            const float v = Ac[0][0] + ct * Ac[0][kt] + cr * Ac[kr][0] + cr * ct * Ac[kr][kt];
-            const int sl = ar_off_slot(r, t);
-            if (sl < 16) q[sl] = v; else x[sl - 16] = v;
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < SOLQ_N; i++) Q[i] = q[i];
-      {   // projection interval of the block's rows: equality (-inf, inf), friction loss [-fl, fl], everything else [0, inf)
-        const int clamp = (hd[0] >> 12) & 3;
-        bf[BF_LO] = clamp == 0 ? -3.0e38f : (clamp == 2 ? -bf[1] : 0.0f);
-        bf[BF_LO + 1] = clamp == 2 ? bf[1] : 3.0e38f;
-      }
-      if (M.has_dim4) {
-        float* X = s_ext + b * SOLX_N;
-#pragma unroll
-        for (int i = 0; i < SOLX_N; i++) X[i] = x[i];
-      }
-    }
-    WSYNC();
     // ---- Gauss-Seidel visiting order (shared with the oracle): block i, then the first later unvisited block
     //      that shares no kinematic tree with it.  Pairs (i, q) are independent and can be solved side by side.
     int ngrp = 0;
@@ -1100,6 +1050,57 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         if (zero_f) {
           for (int b = lane; b < nblk; b += 64) { float* bf = s_blkf + b * BLKF_STRIDE; for (int r = 0; r < 6; r++) bf[BF_F + r] = 0; }
           for (int d = lane; d < nv; d += 64) s_tmpv[d] = 0;
+        }
+        WSYNC();
+        // ---- row-space matrix of every block: AR = E A_c E^T + R I (rows e_r = e_n +- e_k), laid out for pgs_rows().
+        //      Done here, after the last user of the velocity-stage spatial vectors: the X extension aliases them.
+        for (int b = lane; b < nblk; b += 64) {
+          const int* hd = s_blki_i + b * BLKI_STRIDE;
+          float* bf = s_blkf + b * BLKF_STRIDE;
+          float* Q = bf + BF_A;
+          const int kind = hd[0] & 15, nr = (hd[0] >> 4) & 15;
+          float Ac[4][4];
+    #pragma unroll
+          for (int i = 0; i < 4; i++)
+    #pragma unroll
+            for (int j = i; j < 4; j++) { Ac[i][j] = Q[4*i + j]; Ac[j][i] = Ac[i][j]; }
+          const float R = bf[0];
+          float q[SOLQ_N], x[SOLX_N];
+    #pragma unroll
+          for (int i = 0; i < SOLQ_N; i++) q[i] = 0;
+    #pragma unroll
+          for (int i = 0; i < SOLX_N; i++) x[i] = 0;
+          if (kind == BK_SINGLE) { const float AR = Ac[0][0] + R; q[0] = 1.0f / AR; q[4] = 0.5f * AR; }
+          else {
+    #pragma unroll
+            for (int r = 0; r < 6; r++) {
+              if (r >= nr) continue;
+              const int kr = 1 + (r >> 1); const float cr = (r & 1) ? -1.0f : 1.0f;
+              const float AR = Ac[0][0] + 2.0f * cr * Ac[0][kr] + Ac[kr][kr] + R;
+              const float inv = 1.0f / AR, half = 0.5f * AR;
+              if (r < 4) { q[r] = inv; q[4 + r] = half; } else { q[10 + r] = inv; x[r - 4] = half; }
+    #pragma unroll
+              for (int t = r + 1; t < 6; t++) {
+                if (t >= nr) continue;
+                const int kt = 1 + (t >> 1); const float ct = (t & 1) ? -1.0f : 1.0f;
+                const float v = Ac[0][0] + ct * Ac[0][kt] + cr * Ac[kr][0] + cr * ct * Ac[kr][kt];
+                const int sl = ar_off_slot(r, t);
+                if (sl < 16) q[sl] = v; else x[sl - 16] = v;
+              }
+            }
+          }
+    #pragma unroll
+          for (int i = 0; i < SOLQ_N; i++) Q[i] = q[i];
+          {   // projection interval of the block's rows: equality (-inf, inf), friction loss [-fl, fl], everything else [0, inf)
+            const int clamp = (hd[0] >> 12) & 3;
+            bf[BF_LO] = clamp == 0 ? -3.0e38f : (clamp == 2 ? -bf[1] : 0.0f);
+            bf[BF_LO + 1] = clamp == 2 ? bf[1] : 3.0e38f;
+          }
+          if (M.has_dim4) {
+            float* X = s_ext + b * SOLX_N;
+    #pragma unroll
+            for (int i = 0; i < SOLX_N; i++) X[i] = x[i];
+          }
         }
         WSYNC();
         PROF(12);

@@ -124,3 +124,11 @@ def test_engine_fails_loudly_without_gpu(lib):
     m = ms.scene("s24")
     with pytest.raises(ms.engine.MjhError, match="no HIP device"):
         ms.Engine(m, 4)
+
+
+def test_s24_working_set_fits_eight_envs_per_cu(lib):
+    """The headline scene must keep 8 environments resident per CU: 160 KiB of LDS / 8 = 20480 B per env
+    (a ninth-of-a-CU regression silently costs 12% of the throughput)."""
+    m = ms.scene("s24")
+    nbytes = lib.mjh_query_lds_bytes(m.ptr)
+    assert 0 < nbytes <= 160 * 1024 // 8, nbytes
