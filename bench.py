@@ -159,7 +159,10 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("bytes_per_launch")
+            tj = json.load(open(tpath))   # rocprofv3 PMC measurement of the committed profile run, per launch
+            traffic = tj.get("bytes_per_launch")
+            if traffic is not None and tj.get("envs_per_launch"):
+                traffic = traffic * envs_per_launch / tj["envs_per_launch"]
         except Exception:
             traffic = None
     out = {

@@ -8,8 +8,8 @@ nenv = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 settle = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 m = ms.scene("s24"); e = ms.Engine(m, nenv); e.load_s24()
 e.step(settle); e.synchronize()
-names = ["load", "sync", "FK+geoms", "COM/cdof/CRBA/M", "factor", "collision", "row headers", "row fill", "B=M^-1J^T", "(lambda defs)",
-         "vel stage", "controller", "smooth acc", "warmstart", "PGS", "euler", "store"]
+names = ["", "load state", "FK + geoms", "COM/cdof/CRBA", "factor", "collision", "row headers", "J rows + params", "B, A_c, schedule",
+         "vel stage (RNE, aref)", "controller/inverse", "smooth acc", "warmstart + AR", "PGS sweeps", "checkAcc + integrate", "store"]
 out = np.zeros(16)
 for rep in range(3):
     capi.load().mjh_debug_stage_cycles(e.h, 0, capi.dptr(out))

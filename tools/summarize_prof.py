@@ -1,14 +1,18 @@
 """Summarise rocprofv3 rocpd (.db) outputs of tools/profile_gpu.sh into profiles/<tag>_*.{md,csv}.
-usage: python tools/summarize_prof.py <tag> [timed_launches]"""
+usage: python tools/summarize_prof.py <tag> [timed_steps] [cohorts]     (one launch = one step of one cohort)"""
 import glob, json, os, sqlite3, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-timed = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+cohorts = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+timed = steps * cohorts                      # launches inside bench.py's timed region
+envs_per_launch = 4096 // cohorts
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-lines = [f"# rocprofv3 summary `{tag}` — `python bench.py --steps {timed} --warmup 400 --no-cpu-baseline` (S24, 4096 envs, 1 MI355X)", ""]
+lines = [f"# rocprofv3 summary `{tag}` — `python bench.py --steps {steps} --warmup 400 --no-cpu-baseline` (S24, 4096 envs, 1 MI355X)", "",
+         f"One launch of `mjh_step_kernel` = one step of one cohort = {envs_per_launch} environments ({cohorts} cohorts on separate HIP streams, launches overlap).", ""]
 
 def db(path):
     f = glob.glob(os.path.join(src, path, "*.db"))
@@ -44,13 +48,13 @@ if tot:
     lines += ["## HBM traffic (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, separate passes; units of 1 KiB; last %d launches)" % timed, "",
               f"- FETCH_SIZE = {f:.1f} KiB/launch, WRITE_SIZE = {w:.1f} KiB/launch",
               f"- raw (FETCH+WRITE)*1024 = {(f + w) * 1024 / 1e6:.2f} MB/launch; with the gfx950 x2 read correction for wide coalesced reads (MI355X_MICROARCH.md §HBM): {(2 * f + w) * 1024 / 1e6:.2f} MB/launch",
-              f"- algorithmic bytes = 800 B/env-step x 4096 envs = 3.28 MB/launch", ""]
+              f"- algorithmic bytes = 800 B/env-step x {envs_per_launch} envs = {800 * envs_per_launch / 1e6:.2f} MB/launch", ""]
     lines += ["Calibration of FETCH_SIZE for THIS access pattern (4 B/lane rows of <=128 B per wave): the bytes one launch must read are",
-              "state rows 592 B + per-env parameter tables 360 B + time 4 B = 956 B/env -> 3.9 MB for 4096 envs, plus the shared model tables;",
+              f"state rows 592 B + per-env parameter tables 360 B + time 4 B = 956 B/env -> {956 * envs_per_launch / 1e6:.2f} MB for {envs_per_launch} envs, plus the shared model tables;",
               "FETCH_SIZE reports about that figure un-doubled, so the x2 wide-read correction does not apply here and `roofline.traffic`",
               "records the RAW (FETCH+WRITE)*1024 bytes.", ""]
-    json.dump({"tag": tag, "fetch_kib": f, "write_kib": w, "bytes_per_launch": (f + w) * 1024, "bytes_per_launch_x2_read_bound": (2 * f + w) * 1024,
-               "note": "rocprofv3 PMC, separate passes; raw FETCH_SIZE+WRITE_SIZE (4 B/lane row reads calibrate 1:1 against the known 3.9 MB of mandatory reads)"},
+    json.dump({"tag": tag, "fetch_kib": f, "write_kib": w, "envs_per_launch": envs_per_launch, "bytes_per_launch": (f + w) * 1024, "bytes_per_launch_x2_read_bound": (2 * f + w) * 1024,
+               "note": "rocprofv3 PMC, separate passes; raw FETCH_SIZE+WRITE_SIZE (4 B/lane row reads calibrate 1:1 against the known mandatory reads)"},
               open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 con = db("pmc_sq")
 if con:
@@ -61,7 +65,7 @@ if con:
         last = [r[0] for r in rows[-timed:]]
         if last:
             v = sum(last) / len(last)
-            lines.append(f"| {n} | {v:.4g} | {v / 4096:.4g} |")
+            lines.append(f"| {n} | {v:.4g} | {v / envs_per_launch:.4g} |")
     lines.append("")
 for jf in ("bench_trace.json",):
     p = os.path.join(src, jf)
