@@ -1,0 +1,66 @@
+"""Compiles the reference's robot MJCF files (data: model/test/<robot>/<robot>.xml) with THIS repo's MJCF-subset
+loader and stores (i) every field of the compiled mjh_model and (ii) an oracle (fp64) trajectory as fixtures, so
+that the GPU box — which has no /root/reference — can rebuild the model and check the HIP path against it.
+
+    python tests/golden/make_robot_fixtures.py        (CPU container only; needs /root/reference)
+
+Mesh geoms are skipped by the loader, so these models exercise the articulated-body half of the
+path: 30-50 dof single trees, equality constraints, joint limits, friction loss, damping, gravity compensation."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
+import mujoco_sim_amd as ms  # noqa: E402
+import orc  # noqa: E402
+from helpers import save_model_tables  # noqa: E402
+
+REF = "/root/reference/model/test"
+ROBOTS = {"pr2": 16, "tiago": 40, "hsrb4s": 8}   # name -> contact capacity (LDS budget; the meshes are skipped anyway)
+STEPS = 300
+KEEP = (1, 10, 50, 100, 200, 300)
+
+
+def command(m, k):
+    """a smooth joint-space acceleration command on every hinge/slide dof (what MjHWInterface::write feeds)"""
+    nv = m.nv
+    jt = m.array("jnt_type"); da = m.array("jnt_dofadr")
+    ddq = np.zeros(nv)
+    for j in range(m.njnt):
+        if jt[j] in (2, 3):
+            ddq[da[j]] = 0.8 * np.sin(0.05 * k + 0.37 * j)
+    return ddq
+
+
+def main():
+    for name, cap in ROBOTS.items():
+        m = ms.load_mjcf(path=os.path.join(REF, name, name + ".xml"))
+        m.c.maxcon = cap; m.c.maxefc = 6 * cap + m.neq + 2 * m.njnt + m.nv
+        d = orc.OrcData(m.ptr)
+        ctrl = np.zeros(m.nv, dtype=np.int32)
+        jt = m.array("jnt_type"); da = m.array("jnt_dofadr")
+        for j in range(m.njnt):
+            if jt[j] in (2, 3):
+                ctrl[da[j]] = 1
+        d.ifield("controlled")[:] = ctrl
+        out = {}
+        maxcon_seen = 0
+        for k in range(1, STEPS + 1):
+            d.f("ddq")[:] = command(m, k)
+            d.step(1, 1)
+            assert d.i("warn") == 0 and d.i("ncon") < cap, (name, k, d.i("warn"), d.i("ncon"))   # no capacity overflow, no reset
+            maxcon_seen = max(maxcon_seen, d.i("ncon"))
+            if k in KEEP:
+                out[f"qpos_{k}"] = d.f("qpos").copy(); out[f"qvel_{k}"] = d.f("qvel").copy()
+                out[f"qfrc_inverse_{k}"] = d.f("qfrc_inverse").copy()
+                out[f"nefc_{k}"] = np.int64(d.i("nefc"))
+        save_model_tables(m, os.path.join(HERE, f"robot_{name}.npz"), controlled=ctrl, **out)
+        print(name, "nq", m.nq, "nv", m.nv, "neq", m.neq, "nefc", d.i("nefc"), "|qvel|max %.3f" % np.abs(d.f("qvel")).max(),
+              "max ncon", maxcon_seen, "file %.1f KB" % (os.path.getsize(os.path.join(HERE, f"robot_{name}.npz")) / 1e3))
+
+
+if __name__ == "__main__":
+    main()

