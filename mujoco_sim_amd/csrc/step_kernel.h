@@ -733,16 +733,26 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       for (int i = 0; i < 4; i++) if (i >= jb && i < nb) A[4*jb + i] = acc[i];
     }
     WSYNC();
-    // ---- Gauss-Seidel visiting order (shared with the oracle): block i, then the first later unvisited block
-    //      that shares no kinematic tree with it.  Pairs (i, q) are independent and can be solved side by side.
+    // ---- Gauss-Seidel visiting order (shared with the oracle).  Sequence: the blocks that couple two kinematic trees
+    //      first (they are the hard ones to pair), then the single-tree blocks, each group in constraint order.  Then
+    //      greedy: a block, and the first later unvisited block of the sequence that shares no tree with it.  Pairs
+    //      (i, q) are independent and can be solved side by side.
     int ngrp = 0;
     {
-      int ta = -1, tb = -1;
-      if (lane < nblk) { const int* hd = s_blki_i + lane * BLKI_STRIDE; ta = hd[2] & 0xffff; tb = (hd[3] >> 16) ? (hd[3] & 0xffff) : -1; }
       if (nblk > 64) {   // (capacity of the 64-bit bookkeeping below) plain order, no pairs
         for (int i = lane; i < nblk; i += 64) { s_sched_i[2*i] = i; s_sched_i[2*i+1] = -1; s_order_i[i] = i; }
         ngrp = nblk;
       } else {
+        {   // stable partition (two-tree blocks first): position of block `lane` in the sequence
+          const bool two = lane < nblk && (s_blki_i[lane * BLKI_STRIDE + 3] >> 16) != 0;
+          const unsigned long long m2 = __ballot(two), m1 = __ballot(lane < nblk && !two), lt = (1ull << lane) - 1ull;
+          const int pos = two ? __popcll(m2 & lt) : __popcll(m2) + __popcll(m1 & lt);
+          if (lane < nblk) s_order_i[pos] = lane;
+        }
+        WSYNC();
+        int ta = -1, tb = -1, bid = -1;   // lanes = sequence positions
+        if (lane < nblk) { bid = s_order_i[lane]; const int* hd = s_blki_i + bid * BLKI_STRIDE; ta = hd[2] & 0xffff; tb = (hd[3] >> 16) ? (hd[3] & 0xffff) : -1; }
+        WSYNC();
         unsigned long long used = 0; int k = 0;
         for (int i = 0; i < nblk; i++) {
           if ((used >> i) & 1ull) continue;
@@ -753,7 +763,8 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           const unsigned long long bal = __ballot(cand);
           int q = -1;
           if (bal) { q = __ffsll((long long)bal) - 1; used |= 1ull << q; }
-          if (lane == 0) { s_sched_i[2*ngrp] = i; s_sched_i[2*ngrp+1] = q; s_order_i[k] = i; if (q >= 0) s_order_i[k+1] = q; }
+          const int bi = __builtin_amdgcn_readlane(bid, i), bq = q >= 0 ? __builtin_amdgcn_readlane(bid, q) : -1;
+          if (lane == 0) { s_sched_i[2*ngrp] = bi; s_sched_i[2*ngrp+1] = bq; s_order_i[k] = bi; if (q >= 0) s_order_i[k+1] = bq; }
           k += q >= 0 ? 2 : 1; ngrp++;
         }
       }

@@ -1004,11 +1004,23 @@ static int pgs_order(const orc_data* d, int* order) {
   }
   int k = 0;
   if (nblk > 64) { for (int i = 0; i < nefc; i++) order[i] = i; free(bstart); return nefc; }   /* device bookkeeping limit */
-  for (int i = 0; i < nblk; i++) {
+  /* visiting sequence: blocks that couple two kinematic trees first (they are the hard ones to pair), then the
+   * single-tree blocks, each group in constraint order; then greedy: a block, and the first later unvisited block
+   * of the sequence that shares no tree with it */
+  int* seq = (int*)malloc(sizeof(int) * (size_t)(nblk + 1));
+  int ns = 0;
+  for (int pass = 0; pass < 2; pass++)
+    for (int i = 0; i < nblk; i++) {
+      int two = bt1[i] >= 0 && bt2[i] >= 0 && bt1[i] != bt2[i];
+      if (two == (pass == 0)) seq[ns++] = i;
+    }
+  for (int ii = 0; ii < nblk; ii++) {
+    int i = seq[ii];
     if (used[i]) continue;
     used[i] = 1;
     for (int r = 0; r < bnum[i]; r++) order[k++] = bstart[i] + r;
-    for (int j = i + 1; j < nblk; j++) {
+    for (int jj = ii + 1; jj < nblk; jj++) {
+      int j = seq[jj];
       if (used[j]) continue;
       int a1 = bt1[i], a2 = bt2[i], c1 = bt1[j], c2 = bt2[j];
       int share = (a1 >= 0 && (a1 == c1 || a1 == c2)) || (a2 >= 0 && (a2 == c1 || a2 == c2));
@@ -1018,6 +1030,7 @@ static int pgs_order(const orc_data* d, int* order) {
       break;
     }
   }
+  free(seq);
   free(bstart);
   return k;
 }
