@@ -167,18 +167,35 @@ DEV float swap32_sum(float x) {                  // x + (x of the other 32-lane 
 }
 #define MJH_DPP_BF4(v, N, ctrl) do { MJH_DPP_ADD(v[0], ctrl, 0xf, true); if (N > 1) MJH_DPP_ADD(v[1], ctrl, 0xf, true); \
     if (N > 2) MJH_DPP_ADD(v[2], ctrl, 0xf, true); if (N > 3) MJH_DPP_ADD(v[3], ctrl, 0xf, true); } while (0)
-template <int N> DEV void half_sum4(float* v) {   // sums over each 32-lane half, result in every lane of the half
+template <int N> DEV void half_sum4(float* v, const int lq) {   // sums over each 32-lane half, result in every lane of the half (lq = lane & 3)
   MJH_DPP_BF4(v, N, 0xB1);    // quad_perm [1,0,3,2]
-  MJH_DPP_BF4(v, N, 0x4E);    // quad_perm [2,3,0,1]
-  MJH_DPP_BF4(v, N, 0x141);   // row_half_mirror
-  MJH_DPP_BF4(v, N, 0x140);   // row_mirror
-  swap16_sum4(v, N);
+  MJH_DPP_BF4(v, N, 0x4E);    // quad_perm [2,3,0,1]   -> every lane holds its quad's sum of each component
+  if (N == 1) {
+    MJH_DPP_BF4(v, N, 0x141);   // row_half_mirror
+    MJH_DPP_BF4(v, N, 0x140);   // row_mirror
+    swap16_sum4(v, N);
+    return;
+  }
+  // transpose: lane (4q + j) carries component j from here on, so the cross-quad part runs on ONE register
+  float w = v[0];
+  w = lq == 1 ? v[1] : w;
+  if (N > 2) w = lq == 2 ? v[2] : w;
+  if (N > 3) w = lq == 3 ? v[3] : w;
+  MJH_DPP_ADD(w, 0x124, 0xf, true);   // row_ror:4  (rotations by whole quads keep lane & 3)
+  MJH_DPP_ADD(w, 0x128, 0xf, true);   // row_ror:8  -> sum over the 4 quads of the 16-lane row
+  swap16_sum4(&w, 1);                 // + the partner row of the half
+  // broadcast component j from lane 4q + j to its quad
+#define MJH_QBCAST(j) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, w), (j) * 0x55, 0xf, 0xf, true))
+  v[0] = MJH_QBCAST(0); v[1] = MJH_QBCAST(1);
+  if (N > 2) v[2] = MJH_QBCAST(2);
+  if (N > 3) v[3] = MJH_QBCAST(3);
+#undef MJH_QBCAST
 }
 template <int NB, int NR>
 DEV float pgs_dual(const float R, const float lo, const float hi, const float* ab, float* f, const float* Q, const float* X, const float* Jd, const float* Bd,
-                   const float bscale, float& a) {
+                   const float bscale, const int lq, float& a) {
   float u[4] = {Jd[0] * a, NB > 1 ? Jd[1] * a : 0.0f, NB > 2 ? Jd[2] * a : 0.0f, NB > 3 ? Jd[3] * a : 0.0f}, dphi[4];
-  half_sum4<NB>(u);
+  half_sum4<NB>(u, lq);
 #pragma unroll
   for (int j = 0; j < NB; j++) u[j] -= ab[j];
   const float imp = pgs_rows<NB, NR>(R, lo, hi, u, f, Q, X, dphi);
@@ -1131,7 +1148,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         const bool has_dim4 = M.has_dim4 != 0;   // condim-4 contacts present: blocks carry the X extension
         if constexpr (NROW <= 2) {
           // ======== dual-block sweep: half 0 solves block p, half 1 its independent partner q of the schedule
-          const int hh = lane >> 5;
+          const int hh = lane >> 5, lq = lane & 3;
           // software pipeline over the (cyclic) schedule, every stage consuming LDS data requested one step earlier:
           //   S: pair of step t+3  ->  H: block header of step t+2  ->  L: operands of step t+1  ->  solve step t
           struct DHd { int4 hd; int b; float act; };
@@ -1188,9 +1205,9 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             const float* Bp = DIAGM ? Jd : Bd;                 // diagonal M: B = J / M_dd, applied as one scale of da
             const float bs = DIAGM ? minv0 : 1.0f;
             float imp;
-            if (kind == BK_PYR4) imp = pgs_dual<4, 6>(op.R, lo, hi, ab, f, Q, X, Jd, Bp, bs, a);
-            else if (kind == BK_PYR3) imp = pgs_dual<3, 4>(op.R, lo, hi, ab, f, Q, X, Jd, Bp, bs, a);
-            else imp = pgs_dual<1, 1>(op.R, lo, hi, ab, f, Q, X, Jd, Bp, bs, a);
+            if (kind == BK_PYR4) imp = pgs_dual<4, 6>(op.R, lo, hi, ab, f, Q, X, Jd, Bp, bs, lq, a);
+            else if (kind == BK_PYR3) imp = pgs_dual<3, 4>(op.R, lo, hi, ab, f, Q, X, Jd, Bp, bs, lq, a);
+            else imp = pgs_dual<1, 1>(op.R, lo, hi, ab, f, Q, X, Jd, Bp, bs, lq, a);
             improvement += op.act * imp;
             if (d0 == 0 && op.act > 0.0f) {
               float* bf = s_blkf + op.b * BLKF_STRIDE + BF_F;
