@@ -195,6 +195,8 @@ template <int NB, int NR>
 DEV float pgs_dual(const float R, const float lo, const float hi, const float* ab, float* f, const float* Q, const float* X, const float* Jd, const float* Bd,
                    const float bscale, const int lq, float& a) {
   float u[4] = {Jd[0] * a, NB > 1 ? Jd[1] * a : 0.0f, NB > 2 ? Jd[2] * a : 0.0f, NB > 3 ? Jd[3] * a : 0.0f}, dphi[4];
+  // (opaque products: otherwise u + dpp(u) is contracted to fma(J, a, dpp(u)), which costs an extra v_mov_dpp per base)
+  asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]));
   half_sum4<NB>(u, lq);
 #pragma unroll
   for (int j = 0; j < NB; j++) u[j] -= ab[j];
