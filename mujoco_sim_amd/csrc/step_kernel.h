@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           // software pipeline over the (cyclic) schedule, every stage consuming LDS data requested one step earlier:
           //   S: pair of step t+3  ->  H: block header of step t+2  ->  L: operands of step t+1  ->  solve step t
           struct DHd { int4 hd; int b; float act; };
-          struct DOp { int hx, b; float act, R; float4 J, B, r0, r1, r2, A0, A1, A2, A3, X0, X1, X2; };
+          struct DOp { int hx, b, kind; float act, R; float4 J, B, r0, r1, r2, A0, A1, A2, A3, X0, X1, X2; };
           int gS = 0;
           auto nextS = [&]() __attribute__((always_inline)) {
             const int2 pq = *(const int2*)(s_sched_i + 2*gS);
@@ -1186,17 +1186,18 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             }
             op.R = s_blkf[BLKF_STRIDE * b]; op.r0 = blkf4[8*b+1]; op.r1 = blkf4[8*b+2]; op.r2 = blkf4[8*b+3];
             op.A0 = blkf4[8*b+4]; op.A1 = blkf4[8*b+5]; op.A2 = blkf4[8*b+6]; op.A3 = blkf4[8*b+7];
-            if (has_dim4) { const float4* x4 = (const float4*)(s_ext + b * SOLX_N); op.X0 = x4[0]; op.X1 = x4[1]; op.X2 = x4[2]; }
             op.hx = h.act > 0.0f ? h.hd.x : 0; op.b = b; op.act = h.act;
+            // the unrolled row count follows the larger of the two blocks; the smaller one's extra rows are inert
+            const int k0 = __builtin_amdgcn_readlane(op.hx & 15, 0), k1 = __builtin_amdgcn_readlane(op.hx & 15, 32);
+            op.kind = k0 > k1 ? k0 : k1;
+            if (has_dim4 && op.kind == BK_PYR4) { const float4* x4 = (const float4*)(s_ext + b * SOLX_N); op.X0 = x4[0]; op.X1 = x4[1]; op.X2 = x4[2]; }
             return op;
           };
           auto processD = [&](DOp& op, float& improvement) __attribute__((always_inline)) {
-            // the unrolled row count follows the larger of the two blocks; the smaller one's extra rows are inert
-            const int k0 = __builtin_amdgcn_readlane(op.hx & 15, 0), k1 = __builtin_amdgcn_readlane(op.hx & 15, 32);
-            const int kind = k0 > k1 ? k0 : k1;
+            const int kind = op.kind;
             KEEP4(op.J); KEEP4(op.r0); KEEP4(op.r1); KEEP4(op.r2); KEEP4(op.A0); KEEP4(op.A1); KEEP4(op.A2); KEEP4(op.A3);
             if (!DIAGM) KEEP4(op.B);
-            if (has_dim4) { KEEP4(op.X0); KEEP4(op.X1); KEEP4(op.X2); }
+            if (has_dim4 && kind == BK_PYR4) { KEEP4(op.X0); KEEP4(op.X1); KEEP4(op.X2); }
             float f[6] = {op.r1.x, op.r1.y, op.r1.z, op.r1.w, op.r2.x, op.r2.y};
             const float lo = op.r2.z, hi = op.r2.w;
             const float ab[4] = {op.r0.x, op.r0.y, op.r0.z, op.r0.w};
