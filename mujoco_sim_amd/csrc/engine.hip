@@ -42,6 +42,7 @@ struct mjh_engine {
   float* p_tables[MJH_EP_COUNT] = {nullptr};
   int* d_order = nullptr;   // LPT launch order (mjh_order_kernel)
   bool lpt = true;
+  bool order_valid = false;   // d_order holds a full-range permutation (split API); mjh_step sorts per cohort
   // Cohorts: mjh_step() splits the envs into ncohort contiguous groups, each stepped on its own stream, so that the
   // low-occupancy tail of one cohort's step kernel overlaps the next cohort's (or its own next step's) bulk.  The
   // caller's stream forks into the cohort streams at mjh_step and joins them again at the next other API call.
@@ -334,15 +335,31 @@ extern "C" void mjh_destroy(mjh_engine* e) {
 #define ENG(e) ENG_NOJOIN(e) { int rcj_ = join_cohorts(e); if (rcj_) return rcj_; }
 #define RANGE(e, env0, n) if ((env0) < 0 || (n) < 0 || (env0) + (n) > (e)->nenv) { mjh_set_error("env range out of bounds"); return MJH_ERR_ARG; }
 
-extern "C" int mjh_step1(mjh_engine* e) { ENG(e); e->step1_done = true; return launch(e, 0, e->nenv, 1, PH_STEP1, XF_FORCE); }
-extern "C" int mjh_inverse(mjh_engine* e) { ENG(e); return launch(e, 0, e->nenv, 1, PH_INV, XF_FORCE); }
+// full-range launch on the caller's stream in longest-job-first order (split API: step1 | inverse | step2 | forward);
+// `resort` rebuilds the order from the previous step's solver statistics, otherwise the last order is reused
+static int launch_lpt(mjh_engine* e, int ph, int xflags, bool resort) {
+  if (e->lpt && e->nenv >= 1024) {
+    if (!e->d_order) { int rc = dev_alloc(e, &e->d_order, (size_t)e->nenv); if (rc) return rc; e->order_valid = false; }
+    if (resort || !e->order_valid) {
+      hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, e->stream, (const int*)e->S.stats, e->d_order, 0, e->nenv);
+      e->order_valid = true;
+    }
+  }
+  DState saved = e->S;
+  if (e->lpt && e->d_order && e->order_valid) e->S.env_order = e->d_order;
+  int rc = launch(e, 0, e->nenv, 1, ph, xflags);
+  e->S = saved;
+  return rc;
+}
+extern "C" int mjh_step1(mjh_engine* e) { ENG(e); e->step1_done = true; return launch_lpt(e, PH_STEP1, XF_FORCE, true); }
+extern "C" int mjh_inverse(mjh_engine* e) { ENG(e); return launch_lpt(e, PH_INV, XF_FORCE, false); }
 extern "C" int mjh_step2(mjh_engine* e) {
   ENG(e);
   if (!e->step1_done) { mjh_set_error("mjh_step2 called before mjh_step1"); return MJH_ERR_STATE; }
   e->step1_done = false;
-  return launch(e, 0, e->nenv, 1, PH_STEP2, XF_FORCE);
+  return launch_lpt(e, PH_STEP2, XF_FORCE, false);
 }
-extern "C" int mjh_forward(mjh_engine* e) { ENG(e); return launch(e, 0, e->nenv, 1, PH_STEP1 | PH_NOINT, XF_FORCE); }
+extern "C" int mjh_forward(mjh_engine* e) { ENG(e); return launch_lpt(e, PH_STEP1 | PH_NOINT, XF_FORCE, true); }
 extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
   ENG_NOJOIN(e);
   if (e->lpt && !e->d_order && e->nenv >= 1024) {
@@ -373,6 +390,7 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
     }
   }
   e->S = saved;
+  if (e->lpt && e->d_order) e->order_valid = true;   // the per-cohort sorts tile a full permutation
   return rc;
 }
 // Per-launch timing of the step kernels with HIP events on the streams they are launched on (bench.py's roofline leg).

@@ -219,6 +219,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   // longest-job-first dispatch: workgroups are issued in blockIdx order, so the envs that needed the most solver work
   // in the previous step go first (S.env_order, built by mjh_order_kernel); results do not depend on the order
   const int env = S.env_order ? S.env_order[env0 + blockIdx.x] : env0 + (int)blockIdx.x;
+  const int xrow = env - env0;   // row of this env in the x_* export buffers of a ranged launch
   const int nq = M.nq, nv = M.nv, nbody = M.nbody, njnt = M.njnt, ngeom = M.ngeom;
 
   // model tables: one base pointer per element type + a kernarg-resident offset per table (kept as
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
     }
     if (xflags & (XF_BODY | XF_GEOM)) {
       WSYNC();
-      const size_t e = blockIdx.x;
+      const size_t e = xrow;
       if (S.x_xpos) for (int i = lane; i < 3*nbody; i += 64) S.x_xpos[e*3*nbody + i] = s_xpos[i];
       if (S.x_xquat) for (int i = lane; i < 4*nbody; i += 64) S.x_xquat[e*4*nbody + i] = s_xquat[i];
       if (S.x_gpos) for (int i = lane; i < 3*ngeom; i += 64) S.x_gpos[e*3*ngeom + i] = s_gpos[i];
@@ -990,7 +991,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           for (int q = 0; q < 6; q++) ke += 0.5f * t[q] * s_cvel[6*b+q];
         }
         pe = wave_sum<4>(pe); ke = wave_sum<4>(ke);
-        if (lane == 0) { S.x_energy[2*blockIdx.x] = pe; S.x_energy[2*blockIdx.x+1] = ke; }
+        if (lane == 0) { S.x_energy[2*xrow] = pe; S.x_energy[2*xrow+1] = ke; }
       }
       // ---- controller (MjSim::controller, mj_sim.cpp:1055-1077)
       bool anydd = false, anydq = false;
@@ -1022,7 +1023,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       vel_stage(s_qvref);
     }
     if ((xflags & XF_FORCE) && (ph & (PH_STEP1 | PH_INV))) {
-      const size_t e = (size_t)blockIdx.x * M.nvp;
+      const size_t e = (size_t)xrow * M.nvp;
       for (int d = lane; d < nv; d += 64) { if (S.x_bias) S.x_bias[e + d] = s_bias[d]; if (S.x_passive) S.x_passive[e + d] = s_passive[d]; }
     }
 
@@ -1318,7 +1319,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         if (M.has_damping || (xflags & XF_FORCE)) { phi_from_forces(); accum_T(false, s_phi, s_tmpv2); }
       }
       if (xflags & XF_FORCE) {
-        const size_t e = (size_t)blockIdx.x * M.nvp;
+        const size_t e = (size_t)xrow * M.nvp;
         for (int d = lane; d < nv; d += 64) { if (S.x_smooth) S.x_smooth[e + d] = s_asmooth[d]; if (S.x_constraint) S.x_constraint[e + d] = s_tmpv2[d]; }
       }
       if (ph & PH_STEP2) {
