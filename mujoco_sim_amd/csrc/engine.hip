@@ -222,11 +222,14 @@ static void derive_device_model(const mjh_model* m, HostPack& hp) {
     L.qpos = put(m->nq);
     L.qvel = put(nv); L.qvref = put(nv); L.ws = put(nv); L.qacc = put(nv); L.smooth = put(nv); L.asmooth = put(nv); L.passive = put(nv);
     L.bias = put(nv); L.applied = put(nv); L.tmpv = put(nv); L.tmpv2 = put(nv);
-    L.xpos = put(3*nb); L.xquat = put(4*nb); L.xmat = put(9*nb); L.xipos = put(3*nb); L.ximat = put(9*nb); L.com = put(3*nb);
-    L.cinert = put(10*nb); L.crb = put(10*nb);
-    L.xanchor = put(3*nj); L.xaxis = put(3*nj); L.cdof = put(6*nv);
+    // K1: frames, composite inertias, joint anchors/axes and geom poses are dead once the position stage, CRBA and the
+    // collision stage are done; the solver's per-base scratch vectors (bv, phi: first used by the velocity stage) reuse them
+    const int k1 = off;
+    L.xpos = put(3*nb); L.xquat = put(4*nb); L.xmat = put(9*nb); L.ximat = put(9*nb); L.crb = put(10*nb);
+    L.xanchor = put(3*nj); L.xaxis = put(3*nj); L.gpos = put(3*ng); L.gmat = put(9*ng);
+    const int k1_size = off - k1;
+    L.xipos = put(3*nb); L.com = put(3*nb); L.cinert = put(10*nb); L.cdof = put(6*nv);
     L.qM = put(m->nM); L.qLD = diagM ? L.qM : put(m->nM); L.qLDinv = put(nv);   // diagonal M: no factor storage
-    L.gpos = put(3*ng); L.gmat = put(9*ng);
     L.dofpar = put(nv); L.dofMadr = put(nv);
     L.p_gsize = put(3*ng); L.p_rbound = put(ng); L.p_mass = put(nb); L.p_inertia = put(3*nb); L.p_binv = put(2*nb); L.p_dinv = put(nv);
     {  // the contact records die once the blocks are built; the velocity-stage spatial vectors reuse their space
@@ -238,7 +241,9 @@ static void derive_device_model(const mjh_model* m, HostPack& hp) {
       L.cvel = L.con; L.cacc = L.con + a4; L.cfrc = L.con + 2*a4; L.cfrcsub = L.con + 3*a4; L.cdofdot = L.con + 4*a4;
     }
     L.blki = put(nblkcap * BLKI_STRIDE); L.blkf = put(nblkcap * BLKF_STRIDE);
-    L.bv = put(nblkcap * 4); L.phi = put(nblkcap * 4); L.sched = put(nblkcap * 2); L.order = put(nblkcap);
+    if (2 * nblkcap * 4 <= k1_size) { L.bv = k1; L.phi = k1 + nblkcap * 4; }
+    else { L.bv = put(nblkcap * 4); L.phi = put(nblkcap * 4); }
+    L.sched = put(nblkcap * 2); L.order = put(nblkcap);
     L.J = put(jsz); L.B = diagM ? L.J : put(jsz);
     L.zero = put(4);
     L.total = off;
