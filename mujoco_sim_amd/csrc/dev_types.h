@@ -56,8 +56,8 @@ struct DState {
   X(qpos) X(qvel) X(qvref) X(ws) X(qacc) X(smooth) X(asmooth) X(passive) X(bias) X(applied)        \
   X(tmpv) X(tmpv2) X(xpos) X(xquat) X(xmat) X(xipos) X(ximat) X(com) X(cinert) X(crb) X(cvel)      \
   X(cacc) X(cfrc) X(cfrcsub) X(xanchor) X(xaxis) X(cdof) X(cdofdot) X(qM) X(qLD) X(qLDinv)          \
-  X(gpos) X(gmat) X(con) X(blki) X(blkf) X(bv) X(phi) X(sched) X(order) X(J) X(B) X(ext) X(zero) X(dofpar) X(dofMadr)               \
-  X(p_gsize) X(p_rbound) X(p_mass) X(p_inertia) X(p_binv) X(p_dinv)
+  X(gpos) X(gmat) X(con) X(blki) X(blkf) X(blkq) X(bv) X(phi) X(sched) X(order) X(J) X(B) X(ext) X(zero) X(dofpar) X(dofMadr)               \
+  X(p_gsize) X(p_rbound) X(p_mass) X(p_inertia)
 
 struct Lay {
 #define X(n) int n;
@@ -73,17 +73,22 @@ enum { PH_STEP1 = 1, PH_INV = 2, PH_STEP2 = 4, PH_NOINT = 8, PH_FKONLY = 16, PH_
 // export flags
 enum { XF_BODY = 1, XF_GEOM = 2, XF_CON = 4, XF_FORCE = 8, XF_PROF = 16 };
 
-#define CON_STRIDE 17  // dist, pos3, frame9, g1, g2, dim, includemargin
-// constraint blocks: header int4 + 32 floats per block
+#define CON_STRIDE 16  // dist, pos3, frame9, [13] geom1 | geom2 << 12 | dim << 24, [14] includemargin, [15] pad
+#define CON_GEOMS 13
+#define CON_MARGIN 14
+#define CON_G1(c) (__float_as_int((c)[CON_GEOMS]) & 0xfff)
+#define CON_G2(c) ((__float_as_int((c)[CON_GEOMS]) >> 12) & 0xfff)
+#define CON_DIM(c) (__float_as_int((c)[CON_GEOMS]) >> 24)
+// constraint blocks: header int4 + 16 parameter floats (s_blkf) + 16 solver-matrix floats (s_blkq) per block
 //   hd.x = kind | nrows<<4 | nbase<<8 | clamp<<12 | jadr<<16 ; hd.y = id | rtype<<24 | side<<28 ; hd.z = a1 | n1<<16 ; hd.w = a2 | n2<<16
 //   floats: [0..3] R, frictionloss, KI, Bc ; [4..7] aref per BASE row (row r = n +- k has aref_n +- aref_k) ;
-//           [8..13] force per row ; [14..15] lo, hi ; [16..31] A_c = J_base M^-1 J_base^T (upper triangle) while the block is built,
-//           then the row-space solver data Q (step_kernel.h: pgs_rows) ; condim-4 models add 12 floats per block in s_ext
+//           [8..13] force per row ; [14..15] lo, hi ; s_blkq[0..15]: A_c = J_base M^-1 J_base^T (upper triangle), converted in
+//           place into the row-space solver data Q (step_kernel.h: pgs_rows) when the solver starts ; condim-4 models add 12 floats per block in s_ext
 #define BLKI_STRIDE 4
-#define BLKF_STRIDE 32
+#define BLKF_STRIDE 16
+#define BLKQ_STRIDE 16
 #define BF_AREF 4
 #define BF_F 8
 #define BF_LO 14   // [14],[15]: projection interval lo, hi of the block's rows
-#define BF_A 16
 enum { BK_SINGLE = 0, BK_PYR3 = 3, BK_PYR4 = 4 };
 enum { RT_EQ = 0, RT_FL = 1, RT_LIMIT = 2, RT_CONTACT = 3 };

@@ -214,9 +214,9 @@ static void derive_device_model(const mjh_model* m, HostPack& hp) {
   {
     Lay& L = hp.L; int off = 0;
     auto put = [&](int n) { int o = off; off += ((std::max(n, 1) + 3) / 4) * 4; return o; };
-    const int nblkcap = M.maxblk + 2;
+    const int nblkcap = std::max(M.maxblk, 1);   // exact: the block builder never creates more than maxblk blocks
     // J / B pools: one row per non-contact block (equality, friction loss, limits), four interleaved rows per contact
-    int jsz = (M.maxblk - M.maxcon + 1) * rowW + (M.maxcon + 1) * rowW * 4;
+    int jsz = std::max((M.maxblk - M.maxcon) * rowW + M.maxcon * rowW * 4, 4);
     const int need = nstage * RAW_STRIDE;            // raw-contact staging aliases J (+B)
     if ((diagM ? 1 : 2) * jsz < need) jsz = diagM ? need : (need + 1) / 2;
     L.qpos = put(m->nq);
@@ -229,21 +229,26 @@ static void derive_device_model(const mjh_model* m, HostPack& hp) {
     L.xanchor = put(3*nj); L.xaxis = put(3*nj); L.gpos = put(3*ng); L.gmat = put(9*ng);
     const int k1_size = off - k1;
     L.xipos = put(3*nb); L.com = put(3*nb); L.cinert = put(10*nb); L.cdof = put(6*nv);
+    const int k2_size = off - k1;   // ... and all of these are dead when the solver sweeps run: the X extension of condim-4 models
     L.qM = put(m->nM); L.qLD = diagM ? L.qM : put(m->nM); L.qLDinv = put(nv);   // diagonal M: no factor storage
     L.dofpar = put(nv); L.dofMadr = put(nv);
-    L.p_gsize = put(3*ng); L.p_rbound = put(ng); L.p_mass = put(nb); L.p_inertia = put(3*nb); L.p_binv = put(2*nb); L.p_dinv = put(nv);
+    L.p_gsize = put(3*ng); L.p_rbound = put(ng); L.p_mass = put(nb); L.p_inertia = put(3*nb);
     {  // the contact records die once the blocks are built; the velocity-stage spatial vectors reuse their space
       const int a4 = [](int n) { return ((std::max(n, 1) + 3) / 4) * 4; }(6*nb);
       const int velsz = 4 * a4 + ((6*nv + 3) / 4) * 4;
       // (and, once those are dead too, the solver's per-block X extension of condim-4 models)
-      L.con = put(std::max(std::max(M.maxcon * CON_STRIDE, velsz), M.has_dim4 ? (M.maxblk + 2) * SOLX_N : 0));
-      L.ext = L.con;
+      // (and, once those are dead too, the per-block solver matrices A_c / Q, built when the solver starts)
+      L.con = put(std::max(std::max(M.maxcon * CON_STRIDE, velsz), nblkcap * BLKQ_STRIDE));
+      L.blkq = L.con;
       L.cvel = L.con; L.cacc = L.con + a4; L.cfrc = L.con + 2*a4; L.cfrcsub = L.con + 3*a4; L.cdofdot = L.con + 4*a4;
     }
     L.blki = put(nblkcap * BLKI_STRIDE); L.blkf = put(nblkcap * BLKF_STRIDE);
     if (2 * nblkcap * 4 <= k1_size) { L.bv = k1; L.phi = k1 + nblkcap * 4; }
     else { L.bv = put(nblkcap * 4); L.phi = put(nblkcap * 4); }
-    L.sched = put(nblkcap * 2); L.order = put(nblkcap);
+    L.sched = put(nblkcap * 2);
+    // the dual-block sweep (nv <= 32) reads the pair schedule only; `order` is then just scratch of the schedule builder
+    L.order = (nv <= 32 && nblkcap <= k1_size) ? L.bv : put(nblkcap);
+    { const int extsz = M.has_dim4 ? nblkcap * SOLX_N : 0; L.ext = extsz <= k2_size ? k1 : put(extsz); }
     L.J = put(jsz); L.B = diagM ? L.J : put(jsz);
     L.zero = put(4);
     L.total = off;
@@ -266,6 +271,7 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   }
   if (device < 0 || device >= ndev) { mjh_set_error("mjh_create: bad device index"); return MJH_ERR_ARG; }
   if (m->nv > 64) { mjh_set_error("mjh_create: nv > 64 not supported yet (PGS maps one dof per lane)"); return MJH_ERR_CAPACITY; }
+  if (m->ngeom > 4095) { mjh_set_error("mjh_create: more than 4095 geoms (contact records pack the geom ids in 12 bits)"); return MJH_ERR_CAPACITY; }
   for (int g = 0; g < m->ngeom; g++) if (m->geom_condim[g] != 1 && m->geom_condim[g] != 3 && m->geom_condim[g] != 4) {
     mjh_set_error("mjh_create: condim must be 1, 3 or 4 (rolling friction, condim 6, is not implemented)"); return MJH_ERR_UNSUPPORTED; }
   HIPCHK(hipSetDevice(device));
@@ -558,7 +564,7 @@ extern "C" int mjh_get_contacts(mjh_engine* e, int env, double* dist, double* po
     if (dist) dist[c] = r[0];
     if (pos) for (int k = 0; k < 3; k++) pos[3*c+k] = r[1+k];
     if (frame) for (int k = 0; k < 9; k++) frame[9*c+k] = r[4+k];
-    if (geom) { int g1, g2; std::memcpy(&g1, r + 13, 4); std::memcpy(&g2, r + 14, 4); geom[2*c] = g1; geom[2*c+1] = g2; }
+    if (geom) { int g; std::memcpy(&g, r + CON_GEOMS, 4); geom[2*c] = g & 0xfff; geom[2*c+1] = (g >> 12) & 0xfff; }
   }
   return ncon;
 }

@@ -259,13 +259,11 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   // hot chain-walk tables and the (possibly per-env) model parameters go to LDS once per launch
   for (int i = lane; i < nv; i += 64) {
     s_dofpar_i[i] = dof_parentid[i]; s_dofMadr_i[i] = dof_Madr[i];
-    s_p_dinv[i] = S.p_dof_invweight0 ? S.p_dof_invweight0[(size_t)env * nv + i] : dof_invweight0[i];
   }
   for (int i = lane; i < 3 * ngeom; i += 64) s_p_gsize[i] = S.p_geom_size ? S.p_geom_size[(size_t)env * 3 * ngeom + i] : geom_size[i];
   for (int i = lane; i < ngeom; i += 64) s_p_rbound[i] = S.p_geom_rbound ? S.p_geom_rbound[(size_t)env * ngeom + i] : geom_rbound[i];
   for (int i = lane; i < nbody; i += 64) s_p_mass[i] = S.p_body_mass ? S.p_body_mass[(size_t)env * nbody + i] : body_mass[i];
   for (int i = lane; i < 3 * nbody; i += 64) s_p_inertia[i] = S.p_body_inertia ? S.p_body_inertia[(size_t)env * 3 * nbody + i] : body_inertia[i];
-  for (int i = lane; i < 2 * nbody; i += 64) s_p_binv[i] = S.p_body_invweight0 ? S.p_body_invweight0[(size_t)env * 2 * nbody + i] : body_invweight0[i];
   float time = S.time[env];
   // spawn/destroy as slot toggling: bit b set = body b is an INACTIVE slot in this env
   const unsigned slotmask = S.slot_mask ? (unsigned)__builtin_amdgcn_readfirstlane((int)S.slot_mask[env]) : 0u;
@@ -518,8 +516,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           c[0] = r[0]; c[1] = r[1]; c[2] = r[2]; c[3] = r[3];
 #pragma unroll
           for (int k = 0; k < 9; k++) c[4+k] = fr[k];
-          c[13] = __int_as_float(g1); c[14] = __int_as_float(g2);
-          c[15] = __int_as_float(max(geom_condim[g1], geom_condim[g2])); c[16] = margin - gap;
+          c[CON_GEOMS] = __int_as_float(g1 | (g2 << 12) | (max(geom_condim[g1], geom_condim[g2]) << 24)); c[CON_MARGIN] = margin - gap;
         }
         conbase += total;
       }
@@ -574,8 +571,8 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         const int ic = base + lane; int nr = 0, nb = 0, dim = 0;
         if (ic < ncon) {
           const float* c = s_con + ic * CON_STRIDE;
-          dim = __float_as_int(c[15]);
-          if (c[0] < c[16]) { nr = dim == 1 ? 1 : 2 * (dim - 1); nb = dim == 1 ? 1 : (dim == 3 ? 3 : 4); }
+          dim = CON_DIM(c);
+          if (c[0] < c[CON_MARGIN]) { nr = dim == 1 ? 1 : 2 * (dim - 1); nb = dim == 1 ? 1 : (dim == 3 ? 3 : 4); }
         }
         const int inc = nr > 0;
         const int sr = wave_incl_scan_i(nr, lane), sb = wave_incl_scan_i(nb, lane), sc = wave_incl_scan_i(inc, lane);
@@ -623,7 +620,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       else if (rtype == RT_LIMIT) { const int d = jnt_dofadr[id]; t1 = dof_treeid[d]; J[SL*(d - tree_dofadr[t1])] = side ? -1.0f : 1.0f; }
       else {
         const float* c = s_con + id * CON_STRIDE;
-        const int g1 = __float_as_int(c[13]), g2 = __float_as_int(c[14]);
+        const int g1 = CON_G1(c), g2 = CON_G2(c);
         const int b1 = geom_bodyid[g1], b2 = geom_bodyid[g2];
         t1 = body_treeid[b1]; t2 = body_treeid[b2];
         if (t1 < 0) { t1 = t2; t2 = -1; }
@@ -652,6 +649,8 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       if (jb == 0) { hd[2] = tree_dofadr[t1] | (tree_dofnum[t1] << 16); hd[3] = t2 >= 0 ? (tree_dofadr[t2] | (tree_dofnum[t2] << 16)) : 0xffff; }   // no second tree: n2 = 0, a2 matches no dof
     }
     // ---- block parameters: impedance, regulariser R, reference gains (lanes = blocks)
+    auto p_dinv = [&](int d) __attribute__((always_inline)) { return S.p_dof_invweight0 ? S.p_dof_invweight0[(size_t)env * nv + d] : dof_invweight0[d]; };
+    auto p_binv = [&](int i) __attribute__((always_inline)) { return S.p_body_invweight0 ? S.p_body_invweight0[(size_t)env * 2 * nbody + i] : body_invweight0[i]; };
     for (int b = lane; b < nblk; b += 64) {
       const int* hd = s_blki_i + b * BLKI_STRIDE;
       const int id = hd[1] & 0xffffff, rtype = (hd[1] >> 24) & 15, side = (hd[1] >> 28) & 1;
@@ -662,36 +661,36 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         const int j1 = eq_obj1id[id], j2 = eq_obj2id[id];
         const float* dat = eq_data + 11*id;
         const float pos1 = s_qpos[jnt_qposadr[j1]] - qpos0[jnt_qposadr[j1]];
-        diagA = s_p_dinv[jnt_dofadr[j1]];
+        diagA = p_dinv(jnt_dofadr[j1]);
         if (j2 >= 0) {
           const float p2 = s_qpos[jnt_qposadr[j2]] - qpos0[jnt_qposadr[j2]];
           pos = pos1 - (dat[0] + p2*(dat[1] + p2*(dat[2] + p2*(dat[3] + p2*dat[4]))));
-          diagA += s_p_dinv[jnt_dofadr[j2]];
+          diagA += p_dinv(jnt_dofadr[j2]);
         } else pos = pos1 - dat[0];
         sr[0] = eq_solref[2*id]; sr[1] = eq_solref[2*id+1];
 #pragma unroll
         for (int q = 0; q < 5; q++) si[q] = eq_solimp[5*id+q];
       } else if (rtype == RT_FL) {
-        diagA = s_p_dinv[id]; fl = dof_frictionloss[id];
+        diagA = p_dinv(id); fl = dof_frictionloss[id];
         sr[0] = dof_solref[2*id]; sr[1] = dof_solref[2*id+1];
 #pragma unroll
         for (int q = 0; q < 5; q++) si[q] = dof_solimp[5*id+q];
       } else if (rtype == RT_LIMIT) {
         const float val = s_qpos[jnt_qposadr[id]];
         pos = side ? jnt_range[2*id+1] - val : val - jnt_range[2*id];
-        margin = jnt_margin[id]; diagA = s_p_dinv[jnt_dofadr[id]];
+        margin = jnt_margin[id]; diagA = p_dinv(jnt_dofadr[id]);
         sr[0] = jnt_solref[2*id]; sr[1] = jnt_solref[2*id+1];
 #pragma unroll
         for (int q = 0; q < 5; q++) si[q] = jnt_solimp[5*id+q];
       } else {
         const float* c = s_con + id * CON_STRIDE;
-        const int g1 = __float_as_int(c[13]), g2 = __float_as_int(c[14]), dim = __float_as_int(c[15]);
+        const int g1 = CON_G1(c), g2 = CON_G2(c), dim = CON_DIM(c);
         const int b1 = geom_bodyid[g1], b2 = geom_bodyid[g2];
-        pos = c[0]; margin = c[16];
+        pos = c[0]; margin = c[CON_MARGIN];
         // contact parameters (mj_contactParam): max friction, solmix-weighted solref/solimp
         const float f0 = fmaxf(geom_friction[3*g1], geom_friction[3*g2]), f1 = fmaxf(geom_friction[3*g1+1], geom_friction[3*g2+1]);
         mu1 = f0; mu3 = f1;
-        const float tran = s_p_binv[2*b1] + s_p_binv[2*b2];
+        const float tran = p_binv(2*b1) + p_binv(2*b2);
         if (dim == 1) diagA = tran;
         else { diagA = tran + f0*f0*tran; const float mu0 = f0 * rsqrtf(M.impratio); rscale = 2 * mu0 * mu0; }  // Rpy = 2 mu^2 R(first row)
         const float a = geom_solmix[g1], bq = geom_solmix[g2];
@@ -730,29 +729,6 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       }
       WSYNC();
     }
-    // ---- A_c = J_base M^-1 J_base^T, upper triangle (lanes = (block, base jb): row jb)
-    for (int t = lane; t < 4 * nblk; t += 64) {
-      const int b = t >> 2, jb = t & 3;
-      const int* hd = s_blki_i + b * BLKI_STRIDE;
-      const int nb = (hd[0] >> 8) & 15;
-      if (jb >= nb) continue;
-      ROW_TREES(hd[2], hd[3]);
-      float acc[4] = {0, 0, 0, 0};
-      const int SL = BLK_SLOTS(hd[1]), jo = BLK_JOFF(hd[0]);
-      for (int k = 0; k < n1 + n2; k++) {
-        float jv[4] = {0, 0, 0, 0};
-        if (SL == 4) { const float4 jk = *(const float4*)(s_J + jo + 4*k); jv[0] = jk.x; jv[1] = jk.y; jv[2] = jk.z; jv[3] = jk.w; }
-        else jv[0] = s_J[jo + k];
-        float bk;
-        if (DIAGM) bk = jv[jb] * s_qLDinv[k < n1 ? a1 + k : a2 + k - n1]; else bk = s_B[jo + SL*k + jb];
-#pragma unroll
-        for (int i = 0; i < 4; i++) acc[i] += jv[i] * bk;
-      }
-      float* A = s_blkf + b * BLKF_STRIDE + BF_A;
-#pragma unroll
-      for (int i = 0; i < 4; i++) if (i >= jb && i < nb) A[4*jb + i] = acc[i];
-    }
-    WSYNC();
     // ---- Gauss-Seidel visiting order (shared with the oracle).  Sequence: the blocks that couple two kinematic trees
     //      first (they are the hard ones to pair), then the single-tree blocks, each group in constraint order.  Then
     //      greedy: a block, and the first later unvisited block of the sequence that shares no tree with it.  Pairs
@@ -1083,12 +1059,37 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           for (int d = lane; d < nv; d += 64) s_tmpv[d] = 0;
         }
         WSYNC();
+        // ---- A_c = J_base M^-1 J_base^T, upper triangle (lanes = (block, base jb): row jb).  Built here, after the last user
+        //      of the contact records and the velocity-stage spatial vectors: s_blkq reuses their space.
+        for (int t = lane; t < 4 * nblk; t += 64) {
+          const int b = t >> 2, jb = t & 3;
+          const int* hd = s_blki_i + b * BLKI_STRIDE;
+          const int nb = (hd[0] >> 8) & 15;
+          float* A = s_blkq + b * BLKQ_STRIDE;
+          A[4*jb] = 0; A[4*jb+1] = 0; A[4*jb+2] = 0; A[4*jb+3] = 0;   // unused rows / bases must be inert (dual-block solver)
+          if (jb >= nb) continue;
+          ROW_TREES(hd[2], hd[3]);
+          float acc[4] = {0, 0, 0, 0};
+          const int SL = BLK_SLOTS(hd[1]), jo = BLK_JOFF(hd[0]);
+          for (int k = 0; k < n1 + n2; k++) {
+            float jv[4] = {0, 0, 0, 0};
+            if (SL == 4) { const float4 jk = *(const float4*)(s_J + jo + 4*k); jv[0] = jk.x; jv[1] = jk.y; jv[2] = jk.z; jv[3] = jk.w; }
+            else jv[0] = s_J[jo + k];
+            float bk;
+            if (DIAGM) bk = jv[jb] * s_qLDinv[k < n1 ? a1 + k : a2 + k - n1]; else bk = s_B[jo + SL*k + jb];
+    #pragma unroll
+            for (int i = 0; i < 4; i++) acc[i] += jv[i] * bk;
+          }
+    #pragma unroll
+          for (int i = 0; i < 4; i++) if (i >= jb && i < nb) A[4*jb + i] = acc[i];
+        }
+        WSYNC();
         // ---- row-space matrix of every block: AR = E A_c E^T + R I (rows e_r = e_n +- e_k), laid out for pgs_rows().
         //      Done here, after the last user of the velocity-stage spatial vectors: the X extension aliases them.
         for (int b = lane; b < nblk; b += 64) {
           const int* hd = s_blki_i + b * BLKI_STRIDE;
           float* bf = s_blkf + b * BLKF_STRIDE;
-          float* Q = bf + BF_A;
+          float* Q = s_blkq + b * BLKQ_STRIDE;
           const int kind = hd[0] & 15, nr = (hd[0] >> 4) & 15;
           float Ac[4][4];
     #pragma unroll
@@ -1147,6 +1148,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         const int r6 = d0 % 6, dbase6 = d0 < nv ? d0 - r6 : -1;   // DIAGM: dof inside its free body / first dof of that body
         const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
         const float4* blkf4 = (const float4*)s_blkf;
+        const float4* blkq4 = (const float4*)s_blkq;
         const int4* blki4 = (const int4*)s_blki_i;
         const bool has_dim4 = M.has_dim4 != 0;   // condim-4 contacts present: blocks carry the X extension
         if constexpr (NROW <= 2) {
@@ -1185,8 +1187,8 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
               if (quad) op.B = *(const float4*)(on ? s_B + jo + 4*o : s_zero);
               else op.B = make_float4(on ? s_B[jo + o] : 0.0f, 0, 0, 0);
             }
-            op.R = s_blkf[BLKF_STRIDE * b]; op.r0 = blkf4[8*b+1]; op.r1 = blkf4[8*b+2]; op.r2 = blkf4[8*b+3];
-            op.A0 = blkf4[8*b+4]; op.A1 = blkf4[8*b+5]; op.A2 = blkf4[8*b+6]; op.A3 = blkf4[8*b+7];
+            op.R = s_blkf[BLKF_STRIDE * b]; op.r0 = blkf4[4*b+1]; op.r1 = blkf4[4*b+2]; op.r2 = blkf4[4*b+3];
+            op.A0 = blkq4[4*b]; op.A1 = blkq4[4*b+1]; op.A2 = blkq4[4*b+2]; op.A3 = blkq4[4*b+3];
             op.hx = h.act > 0.0f ? h.hd.x : 0; op.b = b; op.act = h.act;
             // the unrolled row count follows the larger of the two blocks; the smaller one's extra rows are inert
             const int k0 = __builtin_amdgcn_readlane(op.hx & 15, 0), k1 = __builtin_amdgcn_readlane(op.hx & 15, 32);
@@ -1267,8 +1269,8 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             if (quad) op.B = *(const float4*)(on ? s_B + jo + 4*o : s_zero);
             else op.B = make_float4(on ? s_B[jo + o] : 0.0f, 0, 0, 0);
           }
-          op.P = blkf4[8*b]; op.r0 = blkf4[8*b+1]; op.r1 = blkf4[8*b+2]; op.r2 = blkf4[8*b+3];
-          op.A0 = blkf4[8*b+4]; op.A1 = blkf4[8*b+5]; op.A2 = blkf4[8*b+6]; op.A3 = blkf4[8*b+7];
+          op.P = blkf4[4*b]; op.r0 = blkf4[4*b+1]; op.r1 = blkf4[4*b+2]; op.r2 = blkf4[4*b+3];
+          op.A0 = blkq4[4*b]; op.A1 = blkq4[4*b+1]; op.A2 = blkq4[4*b+2]; op.A3 = blkq4[4*b+3];
           if (has_dim4) { const float4* x4 = (const float4*)(s_ext + b * SOLX_N); op.X0 = x4[0]; op.X1 = x4[1]; op.X2 = x4[2]; }
           op.hx = hd.x;
           return op;

@@ -126,9 +126,10 @@ def test_engine_fails_loudly_without_gpu(lib):
         ms.Engine(m, 4)
 
 
-def test_s24_working_set_fits_eight_envs_per_cu(lib):
-    """The headline scene must keep 8 environments resident per CU: 160 KiB of LDS / 8 = 20480 B per env
-    (a ninth-of-a-CU regression silently costs 12% of the throughput)."""
+def test_s24_working_set_fits_ten_envs_per_cu(lib):
+    """The headline scene must keep 10 environments resident per CU.  LDS is allocated in 1280-byte granules on gfx950
+    (measured: 15 328 B -> 10 per CU, 15 664 B -> 9), so the budget is 12 granules = 15 360 B per env; one granule more
+    silently costs a tenth of the resident environments."""
     m = ms.scene("s24")
     nbytes = lib.mjh_query_lds_bytes(m.ptr)
-    assert 0 < nbytes <= 160 * 1024 // 8, nbytes
+    assert 0 < nbytes <= 12 * 1280, nbytes

@@ -543,3 +543,38 @@ def test_split_api_large_batch_uses_launch_order_and_matches_fused():
     tab = m.s24_randomize(0, nenv)
     np.testing.assert_allclose(bias[:, 2], 9.81 * tab["body_mass"][:, 1], rtol=1e-5)
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_capacity_saturation_matches_oracle_drop_rule():
+    """Contact / row capacities far below what the scene produces: the LDS pools are sized exactly for the capacities,
+    contacts beyond maxcon are dropped in pair order, a contact whose rows do not fit drops it and every later one
+    (same rule in the oracle), the overflow flags are raised and the step stays finite and in parity."""
+    import mujoco_sim_amd as ms
+    m = ms.scene("s24")
+    nenv = 64
+    full = ms.Engine(m, nenv); tab = full.load_s24(); full.step(300)
+    t, q, v, w = full.get_state(); st_full = full.get_stats(); full.close()
+    assert st_full[:, 0].max() > 14
+    m.c.maxcon = 10; m.c.maxefc = 46          # 10 contacts, but only 46 rows: condim-4 floor contacts use 6 each
+    e = ms.Engine(m, nenv)
+    for k in EP:
+        e.set_env_param(k, tab[k])
+    e.set_initial_qpos(tab["qpos"])
+    e.set_state(qpos=q, qvel=v, warmstart=w)
+    e.step(1)
+    st = e.get_stats()
+    assert (st[:, 0] <= 10).all() and (st[:, 1] <= 46).all()
+    assert (st[:, 3] & 3).any(), "the scene must overflow these capacities"
+    t1, q1, v1, w1 = e.get_state()
+    assert np.isfinite(q1).all() and np.isfinite(v1).all()
+    for i in (0, 7, 21, 40, 63):
+        d = oracle_s24(m, tab, i)
+        d.set_qpos(q[i]); d.f("qvel")[:] = v[i]; d.f("qacc_warmstart")[:] = w[i]
+        d.step()
+        assert d.i("ncon") == st[i, 0] and d.i("nefc") == st[i, 1], (i, d.i("ncon"), d.i("nefc"), st[i])
+        np.testing.assert_allclose(q1[i], d.f("qpos"), rtol=0, atol=5e-6)
+        np.testing.assert_allclose(v1[i], d.f("qvel"), rtol=0, atol=2e-3)
+    e.step(50)
+    assert np.isfinite(e.get_state()[1]).all()
+    e.close()
