@@ -262,6 +262,9 @@ int mjh_debug_stage_cycles(mjh_engine*, int with_inverse, double* out16);
 /* debug: raw stamps of one step launch, out[nenv*20] indexed by launch position: [0..15] shader-clock stage stamps,
  * [16],[17] 100 MHz wall clock at start/end, [18] HW_ID | XCC_ID<<32, [19] env id (tools/timeline.py) */
 int mjh_debug_stage_raw(mjh_engine*, int with_inverse, long long* out);
+/* debug: one step launch that returns at stage boundary `stage` (1..14) and stores nothing (tools/stage_valu.sh:
+ * per-stage hardware-counter differences) */
+int mjh_debug_stop_at(mjh_engine*, int stage, int with_inverse);
 
 /* ---- launch scheduling (no reference counterpart: the reference steps one mjData on one CPU thread,
  * mj_main.cpp:82-112).  Environments are independent, so mjh_step() may split them into `n` cohorts

@@ -656,10 +656,25 @@ extern "C" int mjh_set_body_pose(mjh_engine* e, int env, int body, const double 
 
 extern "C" int mjh_state_stride(const mjh_engine* e) { return e ? 1 + e->M.nq + e->M.nv : 0; }
 extern "C" int mjh_export_state_device(mjh_engine* e, void* d_out) {
-  ENG(e); if (!d_out) return MJH_ERR_ARG;
-  const size_t total = (size_t)e->nenv * (1 + e->M.nq + e->M.nv);
-  const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
-  hipLaunchKernelGGL(mjh_export_kernel, dim3(blocks), dim3(256), 0, e->stream, e->S, (float*)d_out, e->nenv, e->M.nq, e->M.nv, e->M.nqp, e->M.nvp);
+  ENG_NOJOIN(e); if (!d_out) return MJH_ERR_ARG;
+  const int stride = 1 + e->M.nq + e->M.nv;
+  auto run = [&](hipStream_t st, int g0, int n) {
+    const size_t total = (size_t)n * stride;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(mjh_export_kernel, dim3(blocks), dim3(256), 0, st, e->S, (float*)d_out, g0, n, e->M.nq, e->M.nv, e->M.nqp, e->M.nvp);
+  };
+  if (!e->forked) { run(e->stream, 0, e->nenv); HIPCHK(hipGetLastError()); return MJH_OK; }
+  // Read-only and forked: every cohort exports its own range on its own stream, right behind its last step, and the
+  // caller's stream waits for those exports only.  The cohorts stay forked, so publishing does not drain the step
+  // pipeline.  (The cohort streams first wait for the caller's earlier work: it may still be reading d_out.)
+  HIPCHK(hipEventRecord(e->ev_fork, e->stream));
+  for (int g = 0; g < e->ncohort; g++) {
+    const int g0 = (int)((long long)e->nenv * g / e->ncohort), g1 = (int)((long long)e->nenv * (g + 1) / e->ncohort);
+    HIPCHK(hipStreamWaitEvent(e->cstream[g], e->ev_fork, 0));
+    run(e->cstream[g], g0, g1 - g0);
+    HIPCHK(hipEventRecord(e->ev_join[g], e->cstream[g]));
+    HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join[g], 0));
+  }
   HIPCHK(hipGetLastError());
   return MJH_OK;
 }
@@ -702,6 +717,13 @@ extern "C" int mjh_debug_stage_raw(mjh_engine* e, int with_inverse, long long* o
   if (!rc) { HIPCHK(hipMemcpyAsync(out, buf, (size_t)e->nenv * PROF_STRIDE * sizeof(long long), hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }
   (void)hipFree(buf);
   return rc;
+}
+
+// debug: one full-range step launch that returns at stage boundary `stage` (1..14) without storing anything
+extern "C" int mjh_debug_stop_at(mjh_engine* e, int stage, int with_inverse) {
+  ENG(e);
+  if (stage < 1 || stage > 14) { mjh_set_error("mjh_debug_stop_at: stage must be 1..14"); return MJH_ERR_ARG; }
+  return launch(e, 0, e->nenv, 1, PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0), stage << 8);
 }
 
 extern "C" int mjh_nenv(const mjh_engine* e) { return e ? e->nenv : 0; }

@@ -15,7 +15,10 @@
 #include "dev_types.h"
 
 #define WSYNC() __syncthreads()
-#define PROF(k) do { if ((xflags & XF_PROF) && lane == 0) S.x_prof[(size_t)blockIdx.x * PROF_STRIDE + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+// stage boundary k: optional shader-clock stamp (XF_PROF) and optional early exit (xflags bits 8..11 = k, debug:
+// per-stage instruction counts are differences of the hardware counters of launches that stop at successive stages)
+#define PROF(k) do { if ((xflags & XF_PROF) && lane == 0) S.x_prof[(size_t)blockIdx.x * PROF_STRIDE + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
+                     if (((xflags >> 8) & 15) == (k) && (k) > 0) return; } while (0)
 #define MINIMP 0.0001f
 #define MAXIMP 0.9999f
 
@@ -1403,10 +1406,11 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
 }
 
 // pack time + qpos + qvel per env into one contiguous fp32 buffer (feeds the RCCL all-gather)
-__global__ void mjh_export_kernel(const DState S, float* out, int nenv, int nq, int nv, int nqp, int nvp) {
+__global__ void mjh_export_kernel(const DState S, float* out, int env0, int nenv, int nq, int nv, int nqp, int nvp) {
   const int stride = 1 + nq + nv;
+  out += (size_t)env0 * stride;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)nenv * stride; i += (size_t)gridDim.x * blockDim.x) {
-    const int e = (int)(i / stride), k = (int)(i % stride);
+    const int e = env0 + (int)(i / stride), k = (int)(i % stride);
     out[i] = (k == 0) ? S.time[e] : (k <= nq ? S.qpos[(size_t)e * nqp + k - 1] : S.qvel[(size_t)e * nvp + k - 1 - nq]);
   }
 }

@@ -578,3 +578,28 @@ def test_capacity_saturation_matches_oracle_drop_rule():
     e.step(50)
     assert np.isfinite(e.get_state()[1]).all()
     e.close()
+
+
+@pytest.mark.gpu
+def test_forked_export_publishes_without_joining_the_cohorts():
+    """mjh_export_state_device while the cohorts are forked: each cohort exports its range on its own stream (the
+    step pipeline is not drained); the published buffer must equal the state after exactly the steps queued so far."""
+    import torch
+    m = ms.scene("s24")
+    nenv = 2048
+    a = ms.Engine(m, nenv); a.load_s24(); a.set_cohorts(2)
+    b = ms.Engine(m, nenv); b.load_s24(); b.set_cohorts(1)
+    bufs = [torch.zeros(nenv * a.state_stride, dtype=torch.float32, device="cuda") for _ in range(3)]
+    for k in range(3):
+        a.step(7)
+        a.export_state_device(bufs[k].data_ptr())      # forked: no join
+    a.step(5)
+    a.synchronize(); torch.cuda.synchronize()
+    for k in range(3):
+        b.step(7)
+        t, q, v, _ = b.get_state()
+        out = bufs[k].cpu().numpy().reshape(nenv, -1)
+        assert np.array_equal(out[:, 1:1 + m.nq], q.astype(np.float32)) and np.array_equal(out[:, 1 + m.nq:], v.astype(np.float32))
+    b.step(5)
+    assert np.array_equal(a.get_state()[1], b.get_state()[1])
+    a.close(); b.close()
