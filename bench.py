@@ -10,7 +10,8 @@ hand-off to ros_control).  Inputs are resident in HBM when the timed region star
 
 N > 1: launched by torch.distributed.run, one rank per GPU; environments are sharded
 (rank r owns envs [r*4096, (r+1)*4096)), no data-path collective; the only collective is the
-RCCL all-gather of the published state slice at 60 Hz of simulated time.
+RCCL all-gather of the published state slice at 60 Hz of simulated time.  The slice is packed
+(mjh_export_state_device) at that rate at every N, so that per-GPU work does not depend on N.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -127,9 +128,10 @@ def main():
             k = min(args.fuse, nsteps - s)
             eng.step(k, args.with_inverse)
             s += k
-            if use_dist and not args.no_gather and (s % publish_every) < k:
+            if not args.no_gather and (s % publish_every) < k:   # 60 Hz publish: packed state slice (+ RCCL all-gather)
                 eng.export_state_device(pub.data_ptr())
-                dist.all_gather_into_tensor(gathered, pub)
+                if use_dist:
+                    dist.all_gather_into_tensor(gathered, pub)
 
     run(args.warmup)
     torch.cuda.synchronize()
