@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--with-inverse", type=int, default=0, help="also run mj_inverse every step (MjHWInterface::read)")
     ap.add_argument("--fuse", type=int, default=1, help="steps between host hand-offs (one kernel launch per step either way)")
     ap.add_argument("--cohorts", type=int, default=-1, help="env cohorts stepped on separate HIP streams (-1: engine default)")
+    ap.add_argument("--maxcon", type=int, default=0, help="override the scene's contact capacity per env (rows: 6 per contact); 0 = scene default (32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the publish all-gather even with one rank (self-test of the multi-GPU path)")
@@ -111,6 +112,8 @@ def main():
     import mujoco_sim_amd as ms
 
     model = ms.scene("s24")
+    if args.maxcon > 0:
+        model.c.maxcon = args.maxcon; model.c.maxefc = 6 * args.maxcon
     nenv = args.envs_per_gpu
     stream = torch.cuda.current_stream()
     eng = ms.Engine(model, nenv, device=local_rank, stream=stream.cuda_stream)
@@ -182,7 +185,7 @@ def main():
                    "mean_ncon": float(st[:, 0].mean()), "max_ncon": int(st[:, 0].max()), "mean_nefc": float(st[:, 1].mean()),
                    "max_nefc": int(st[:, 1].max()), "mean_solver_iter": float(st[:, 2].mean()),
                    "overflow_envs": int((st[:, 3] & 3 != 0).sum()), "reset_envs": int((st[:, 3] & 4 != 0).sum()),
-                   "lds_bytes_per_env": eng.lds_bytes},
+                   "lds_bytes_per_env": eng.lds_bytes, "contact_capacity": int(model.maxcon)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel": "mjh_step_kernel", "kernel_ms": kernel_ms,
                      "launches": n_launches, "envs_per_launch": envs_per_launch, "concurrent_launches": cohorts,

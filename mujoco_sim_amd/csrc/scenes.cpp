@@ -74,9 +74,10 @@ extern "C" mjh_model* mjh_scene_s24(void) {
     std::snprintf(name, sizeof name, "box%d_geom", k);
     mjh_builder_add_geom(b, name, body, MJH_GEOM_BOX, sz, nullptr, nullptr, nullptr, -1, -1, -1, -1);
   }
-  // capacity: measured over 4096 envs x 1400 steps the pile never exceeds 30 contacts / 128 rows
+  // capacity: over 4096 envs the pile stays below 31 contacts in the benchmark window (1400 steps) and reaches 35 in a
+  // 20 000-step soak (the piles keep compacting); 40 contacts x 6 rows leaves a margin (overflow is flagged, not silent)
   // (tools/ncon_hist.py); overflow drops the excess contacts and raises the per-env flag
-  mjh_builder_set_capacity(b, 32, 32 * 6);
+  mjh_builder_set_capacity(b, 40, 40 * 6);
   mjh_model* m = mjh_builder_compile(b);
   mjh_builder_destroy(b);
   return m;

@@ -236,7 +236,10 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
 #define LA(n) float* s_##n = lds + L.n;
   MJH_LDS_ARRAYS(LA)
 #undef LA
-  int* s_blki_i = (int*)s_blki; int* s_sched_i = (int*)s_sched; int* s_order_i = (int*)s_order; int* s_dofpar_i = (int*)s_dofpar; int* s_dofMadr_i = (int*)s_dofMadr;
+  int* s_blki_i = (int*)s_blki; int* s_sched_i = (int*)s_sched; int* s_order_i = (int*)s_order; 
+  // chain-walk tables: LDS copies for articulated models; free-body models (DIAGM) walk 6-dof chains a few times per step
+  // and read the shared tables instead (their LDS space is not allocated)
+  const int* s_dofpar_i = DIAGM ? (dof_parentid + 0) : (const int*)s_dofpar; const int* s_dofMadr_i = DIAGM ? (dof_Madr + 0) : (const int*)s_dofMadr;
   float* s_stage = s_J;  // raw-contact staging aliases the (not yet built) base-row storage
   const int rowW = M.rowW;
 
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   if (lane < 4) s_zero[lane] = 0;   // what lanes outside a block read instead of its Jacobian
   // hot chain-walk tables and the (possibly per-env) model parameters go to LDS once per launch
   for (int i = lane; i < nv; i += 64) {
-    s_dofpar_i[i] = dof_parentid[i]; s_dofMadr_i[i] = dof_Madr[i];
+    if (!DIAGM) { ((int*)s_dofpar)[i] = dof_parentid[i]; ((int*)s_dofMadr)[i] = dof_Madr[i]; }
   }
   for (int i = lane; i < 3 * ngeom; i += 64) s_p_gsize[i] = S.p_geom_size ? S.p_geom_size[(size_t)env * 3 * ngeom + i] : geom_size[i];
   for (int i = lane; i < ngeom; i += 64) s_p_rbound[i] = S.p_geom_rbound ? S.p_geom_rbound[(size_t)env * ngeom + i] : geom_rbound[i];
