@@ -78,9 +78,9 @@ static int ensure_scratch(mjh_engine* e, size_t floats) {
 static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps, int ph, int xflags) {
   if (n <= 0) return MJH_OK;
 #define MJH_LAUNCH(NR, DG) hipLaunchKernelGGL((mjh_step_kernel<NR, DG>), dim3(n), dim3(64), (size_t)e->lds_bytes, st, e->dC, e->S, env0, nsteps, ph, xflags)
-  const int nr = e->M.nv <= 16 ? 1 : (e->M.nv <= 32 ? 2 : 4);
-  if (e->M.diagM) { if (nr == 1) MJH_LAUNCH(1, true); else if (nr == 2) MJH_LAUNCH(2, true); else MJH_LAUNCH(4, true); }
-  else { if (nr == 1) MJH_LAUNCH(1, false); else if (nr == 2) MJH_LAUNCH(2, false); else MJH_LAUNCH(4, false); }
+  const int nr = e->M.nv <= 16 ? 1 : (e->M.nv <= 32 ? 2 : (e->M.nv <= 64 ? 4 : 8));   // 8: running acceleration in LDS
+  if (e->M.diagM) { if (nr == 1) MJH_LAUNCH(1, true); else if (nr == 2) MJH_LAUNCH(2, true); else if (nr == 4) MJH_LAUNCH(4, true); else MJH_LAUNCH(8, true); }
+  else { if (nr == 1) MJH_LAUNCH(1, false); else if (nr == 2) MJH_LAUNCH(2, false); else if (nr == 4) MJH_LAUNCH(4, false); else MJH_LAUNCH(8, false); }
 #undef MJH_LAUNCH
   HIPCHK(hipGetLastError());
   return MJH_OK;
@@ -271,7 +271,7 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     return MJH_ERR_NO_DEVICE;
   }
   if (device < 0 || device >= ndev) { mjh_set_error("mjh_create: bad device index"); return MJH_ERR_ARG; }
-  if (m->nv > 64) { mjh_set_error("mjh_create: nv > 64 not supported yet (PGS maps one dof per lane)"); return MJH_ERR_CAPACITY; }
+
   if (m->ngeom > 4095) { mjh_set_error("mjh_create: more than 4095 geoms (contact records pack the geom ids in 12 bits)"); return MJH_ERR_CAPACITY; }
   for (int g = 0; g < m->ngeom; g++) if (m->geom_condim[g] != 1 && m->geom_condim[g] != 3 && m->geom_condim[g] != 4) {
     mjh_set_error("mjh_create: condim must be 1, 3 or 4 (rolling friction, condim 6, is not implemented)"); return MJH_ERR_UNSUPPORTED; }
@@ -296,12 +296,16 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     HIPCHK(hipMemcpyAsync(e->dC, &hc, sizeof hc, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
   }
+  if (m->nv > 64 && e->M.rowW > 64) {
+    mjh_set_error("mjh_create: nv > 64 needs every constraint to touch at most 64 dofs (this model: " + std::to_string(e->M.rowW) + "); the solver maps one dof of a block per lane");
+    mjh_destroy(e); return MJH_ERR_CAPACITY;
+  }
   if (e->lds_bytes > 160 * 1024) {
     mjh_set_error("mjh_create: per-env working set exceeds the 160 KiB LDS of one CU (" + std::to_string(e->lds_bytes) + " B)");
     mjh_destroy(e); return MJH_ERR_CAPACITY;
   }
 #define MJH_ATTR(NR, DG) HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<NR, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes))
-  MJH_ATTR(1, true); MJH_ATTR(2, true); MJH_ATTR(4, true); MJH_ATTR(1, false); MJH_ATTR(2, false); MJH_ATTR(4, false);
+  MJH_ATTR(1, true); MJH_ATTR(2, true); MJH_ATTR(4, true); MJH_ATTR(8, true); MJH_ATTR(1, false); MJH_ATTR(2, false); MJH_ATTR(4, false); MJH_ATTR(8, false);
 #undef MJH_ATTR
 
   // ---- per-env state

@@ -136,7 +136,8 @@ template <int NB, int NR, int NROW>
 DEV void pgs_block(const float R, const float lo, const float hi, const float* ab, float* f, const float* Q, const float* X, const float* Jd, const float* Bd,
                    const float bscale, float& a, float& improvement) {
   float u[4] = {Jd[0] * a, NB > 1 ? Jd[1] * a : 0.0f, NB > 2 ? Jd[2] * a : 0.0f, NB > 3 ? Jd[3] * a : 0.0f}, dphi[4];
-  if (NB == 1) u[0] = wave_sum<NROW>(u[0]); else wave_sum4<NROW, NB>(u);
+  constexpr int WR = NROW > 4 ? 4 : NROW;   // NROW 8 (nv > 64): full-wave sums over the block's compact dofs
+  if (NB == 1) u[0] = wave_sum<WR>(u[0]); else wave_sum4<WR, NB>(u);
 #pragma unroll
   for (int j = 0; j < NB; j++) u[j] -= ab[j];
   improvement += pgs_rows<NB, NR>(R, lo, hi, u, f, Q, X, dphi);
@@ -1147,17 +1148,64 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         //      are then updated with uniform scalar math in contact space:
         //        res_r = e_r.u - aref_r + R f_r ;  f_r <- max(0, f_r - res_r/AR_rr) ;  u += A_c e_r delta
         //      and `a` is touched once per block:  a += B_base^T dphi.
-        // TODO(perf): nv > 64 needs several dofs per lane
         const int d0 = (NROW <= 2) ? (lane & 31) : lane;   // dual mode: both halves carry a copy of the dof vector
-        float a = (d0 < nv) ? s_asmooth[d0] + s_tmpv[d0] : 0.0f;
-        const float minv0 = (d0 < nv) ? s_qLDinv[d0] : 0.0f;
+        float a = (NROW != 8 && d0 < nv) ? s_asmooth[d0] + s_tmpv[d0] : 0.0f;
+        const float minv0 = (NROW != 8 && d0 < nv) ? s_qLDinv[d0] : 0.0f;
         const int r6 = d0 % 6, dbase6 = d0 < nv ? d0 - r6 : -1;   // DIAGM: dof inside its free body / first dof of that body
         const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
         const float4* blkf4 = (const float4*)s_blkf;
         const float4* blkq4 = (const float4*)s_blkq;
         const int4* blki4 = (const int4*)s_blki_i;
         const bool has_dim4 = M.has_dim4 != 0;   // condim-4 contacts present: blocks carry the X extension
-        if constexpr (NROW <= 2) {
+        if constexpr (NROW == 8) {
+          // ======== nv > 64: the running acceleration lives in LDS (s_qacc); lanes = the compact dofs of ONE block
+          //          (at most 64: rowW), gathered before and scattered after the block's update.  A functional path
+          //          for many-body models: one LDS round trip per block, no operand prefetch.
+          for (int d = lane; d < nv; d += 64) s_qacc[d] = s_asmooth[d] + s_tmpv[d];
+          WSYNC();
+          for (int it = 0; it < M.iterations; it++) {
+            float improvement = 0;
+            for (int k = 0; k < nblk; k++) {
+              const int b = s_order_i[k];
+              const int4 hd = blki4[b];
+              ROW_TREES(hd.z, hd.w);
+              const bool on = lane < n1 + n2;
+              const int d = lane < n1 ? a1 + lane : a2 + lane - n1;
+              float ak = on ? s_qacc[d] : 0.0f;
+              const int jo = BLK_JOFF(hd.x);
+              const bool quad = BLK_SLOTS(hd.y) == 4;
+              float4 j4 = make_float4(0, 0, 0, 0), b4 = make_float4(0, 0, 0, 0);
+              if (on) { if (quad) j4 = *(const float4*)(s_J + jo + 4*lane); else j4.x = s_J[jo + lane]; }
+              if (!DIAGM && on) { if (quad) b4 = *(const float4*)(s_B + jo + 4*lane); else b4.x = s_B[jo + lane]; }
+              const float4 p0 = blkf4[4*b], r0 = blkf4[4*b+1], r1 = blkf4[4*b+2], r2 = blkf4[4*b+3];
+              const float4 A0 = blkq4[4*b], A1 = blkq4[4*b+1], A2 = blkq4[4*b+2], A3 = blkq4[4*b+3];
+              float4 X0 = make_float4(0, 0, 0, 0), X1 = X0, X2 = X0;
+              if (has_dim4) { const float4* x4 = (const float4*)(s_ext + b * SOLX_N); X0 = x4[0]; X1 = x4[1]; X2 = x4[2]; }
+              const int kind = __builtin_amdgcn_readfirstlane(hd.x & 15);
+              float f[6] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
+              const float aref[4] = {r0.x, r0.y, r0.z, r0.w};
+              const float Q[16] = {A0.x, A0.y, A0.z, A0.w, A1.x, A1.y, A1.z, A1.w, A2.x, A2.y, A2.z, A2.w, A3.x, A3.y, A3.z, A3.w};
+              const float X[12] = {X0.x, X0.y, X0.z, X0.w, X1.x, X1.y, X1.z, X1.w, X2.x, X2.y, X2.z, X2.w};
+              const float Jd[4] = {j4.x, j4.y, j4.z, j4.w}, Bd[4] = {b4.x, b4.y, b4.z, b4.w};
+              const float* Bp = DIAGM ? Jd : Bd;
+              const float bs = DIAGM ? (on ? s_qLDinv[d] : 0.0f) : 1.0f;
+              const float R = p0.x, lo = r2.z, hi = r2.w;
+              if (kind == BK_PYR4) pgs_block<4, 6, NROW>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
+              else if (kind == BK_PYR3) pgs_block<3, 4, NROW>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
+              else pgs_block<1, 1, NROW>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
+              if (on) s_qacc[d] = ak;
+              if (lane == 0) {
+                float* bf = s_blkf + b * BLKF_STRIDE + BF_F;
+                *(float4*)(bf) = make_float4(f[0], f[1], f[2], f[3]);
+                *(float2*)(bf + 4) = make_float2(f[4], f[5]);
+              }
+              WSYNC();
+            }
+            niter = it + 1;
+            if (improvement * scale < M.tolerance) break;
+          }
+          for (int d = lane; d < nv; d += 64) s_ws[d] = s_qacc[d];
+        } else if constexpr (NROW <= 2) {
           // ======== dual-block sweep: half 0 solves block p, half 1 its independent partner q of the schedule
           const int hh = lane >> 5, lq = lane & 3;
           // software pipeline over the (cyclic) schedule, every stage consuming LDS data requested one step earlier:
@@ -1320,7 +1368,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         }
         }
         WSYNC();
-        if (d0 < nv && lane < 64 / (NROW <= 2 ? 2 : 1)) { s_qacc[d0] = a; s_ws[d0] = a; }
+        if (NROW != 8 && d0 < nv && lane < 64 / (NROW <= 2 ? 2 : 1)) { s_qacc[d0] = a; s_ws[d0] = a; }
         PROF(13);
         WSYNC();
         // qfrc_constraint = J^T f (only needed by the implicit-damping integrator and for export)

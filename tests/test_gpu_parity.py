@@ -300,6 +300,22 @@ def test_box_pile_nv48_single_block_sweep(lib):
     assert ncon >= 8 and st[0] == ncon and st[1] == nefc
 
 
+def test_box_pile_nv96_lds_resident_acceleration(lib):
+    """16 free boxes (nv = 96 > 64): the running acceleration of the PGS sweep lives in LDS and every block gathers /
+    scatters its <= 12 dofs (NROW = 8 path); capacities set by hand (the default is every pair at full manifold)"""
+    m = ms.scene("boxpile", 16)
+    assert m.nv == 96
+    m.c.maxcon = 96; m.c.maxefc = 96 * 4
+    assert lib.mjh_query_lds_bytes(m.ptr) <= 160 * 1024
+    q0 = m.array("qpos0").copy()
+    rng = np.random.default_rng(11)
+    for k in range(16):                      # drop them closer together so they collide with each other
+        q0[7*k:7*k+2] *= 0.55; q0[7*k+2] = 0.12 + 0.22 * (k // 8) + 0.005 * k
+        quat = rng.normal(size=4) * 0.12 + np.array([1, 0, 0, 0]); q0[7*k+3:7*k+7] = quat / np.linalg.norm(quat)
+    st, ncon, nefc = _compare_rollout(m, q0, [1, 40, 100], [1e-5, 5e-4, 2e-2])
+    assert ncon >= 16 and st[0] == ncon and st[1] == nefc
+
+
 def test_mixed_primitives_scene(lib):
     """sphere / capsule / box free bodies on the plane and on each other: every narrow-phase routine on the device"""
     b = lib.mjh_builder_create()
