@@ -138,6 +138,8 @@ void mjh_builder_destroy(mjh_builder*);
 void mjh_builder_set_option(mjh_builder*, const mjh_option*);
 void mjh_builder_get_option(const mjh_builder*, mjh_option*);
 void mjh_builder_set_capacity(mjh_builder*, int maxcon, int maxefc);
+/* <compiler boundmass boundinertia>: lower bounds on the mass / principal inertias of every body except the world */
+void mjh_builder_set_bounds(mjh_builder*, double boundmass, double boundinertia);
 /* returns body id (>0) ; parent 0 = world.  mass<=0 -> inertia inferred from geoms (density 1000) */
 int mjh_builder_add_body(mjh_builder*, const char* name, int parent, const double pos[3],
                          const double quat[4], double gravcomp);
@@ -164,6 +166,9 @@ const char* mjh_id2name(const mjh_model*, int objtype, int id);
 mjh_model* mjh_load_mjcf_string(const char* xml);
 mjh_model* mjh_load_mjcf_file(const char* path);
 const char* mjh_load_note(void);
+/* process-wide floor for <compiler boundmass boundinertia> of every file loaded afterwards: the reference writes
+ * 1e-6 / 1e-6 into each file before mj_loadXML (mj_sim.cpp:584-590) */
+void mjh_load_set_bounds(double boundmass, double boundinertia);
 
 /* ------------------------------------------------------ scene builders */
 /* SURVEY.md §8-d configs, as programmatic models.  `seed_base+env` seeds PCG32. */

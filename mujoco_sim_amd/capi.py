@@ -93,6 +93,7 @@ SYMBOLS = [
     ("mjh_builder_set_option", None, [_vp, C.POINTER(Option)]),
     ("mjh_builder_get_option", None, [_vp, C.POINTER(Option)]),
     ("mjh_builder_set_capacity", None, [_vp, C.c_int, C.c_int]),
+    ("mjh_builder_set_bounds", None, [_vp, C.c_double, C.c_double]),
     ("mjh_builder_add_body", C.c_int, [_vp, C.c_char_p, C.c_int, c_double_p, c_double_p, C.c_double]),
     ("mjh_builder_set_inertial", C.c_int, [_vp, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p]),
     ("mjh_builder_add_joint", C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p,
@@ -108,6 +109,7 @@ SYMBOLS = [
     ("mjh_load_mjcf_string", Model_p, [C.c_char_p]),
     ("mjh_load_mjcf_file", Model_p, [C.c_char_p]),
     ("mjh_load_note", C.c_char_p, []),
+    ("mjh_load_set_bounds", None, [C.c_double, C.c_double]),
     ("mjh_scene_s24", Model_p, []),
     ("mjh_scene_s24_randomize", C.c_int, [Model_p, C.c_int, C.c_int, C.c_uint] + [c_double_p] * 7),
     ("mjh_scene_pendulum", Model_p, []),

@@ -97,9 +97,14 @@ struct Defaults {
   double jnt_damping = 0, jnt_stiffness = 0, jnt_armature = 0, jnt_frictionloss = 0;
 };
 
+// floor applied to every file loaded afterwards: MjSim::init() writes boundmass = boundinertia = 1e-6 into the <compiler>
+// element of whatever it loads (mj_sim.cpp:584-590)
+static double g_boundmass = 0, g_boundinertia = 0;
+
 struct Loader {
   mjh_builder* b = nullptr;
   bool degree = true, autolimits = false;
+  double bmass = 0, binertia = 0;   // <compiler boundmass boundinertia>, raised to the process-wide floor of mjh_load_set_bounds
   Defaults def;
   std::map<std::string, int> body_id, joint_id;
   std::string note;
@@ -198,6 +203,9 @@ struct Loader {
       if (c->tag == "compiler") {
         if (const char* a = c->get("angle")) degree = std::string(a) != "radian";
         if (const char* a = c->get("autolimits")) autolimits = std::string(a) == "true";
+        double v;
+        if (nums(c->get("boundmass"), &v, 1)) bmass = std::max(bmass, v);
+        if (nums(c->get("boundinertia"), &v, 1)) binertia = std::max(binertia, v);
       } else if (c->tag == "option") {
         double v, g[3];
         if (nums(c->get("timestep"), &v, 1)) o.timestep = v;
@@ -253,6 +261,7 @@ struct Loader {
       } else if (c->tag != "compiler" && c->tag != "option" && c->tag != "default" && c->tag != "worldbody" && c->tag != "asset" && c->tag != "visual" && c->tag != "size" && c->tag != "statistic")
         note += "ignored <" + c->tag + ">; ";
     }
+    mjh_builder_set_bounds(b, std::max(bmass, g_boundmass), std::max(binertia, g_boundinertia));
     mjh_model* m = mjh_builder_compile(b);
     mjh_builder_destroy(b);
     return m;
@@ -281,3 +290,4 @@ extern "C" mjh_model* mjh_load_mjcf_file(const char* path) {
   return mjh_load_mjcf_string(ss.str().c_str());
 }
 extern "C" const char* mjh_load_note(void) { return g_note.c_str(); }
+extern "C" void mjh_load_set_bounds(double boundmass, double boundinertia) { g_boundmass = boundmass; g_boundinertia = boundinertia; }

@@ -38,6 +38,7 @@ struct BEq { int j1, j2; double poly[5]; };
 struct mjh_builder {
   mjh_option opt;
   int maxcon = 0, maxefc = 0;
+  double boundmass = 0, boundinertia = 0;   // <compiler boundmass boundinertia> (the reference forces 1e-6, mj_sim.cpp:584-590)
   std::vector<BBody> bodies;
   std::vector<BJoint> joints;
   std::vector<BGeom> geoms;
@@ -66,6 +67,7 @@ extern "C" void mjh_builder_destroy(mjh_builder* b) { delete b; }
 extern "C" void mjh_builder_set_option(mjh_builder* b, const mjh_option* o) { b->opt = *o; }
 extern "C" void mjh_builder_get_option(const mjh_builder* b, mjh_option* o) { *o = b->opt; }
 extern "C" void mjh_builder_set_capacity(mjh_builder* b, int maxcon, int maxefc) { b->maxcon = maxcon; b->maxefc = maxefc; }
+extern "C" void mjh_builder_set_bounds(mjh_builder* b, double boundmass, double boundinertia) { b->boundmass = boundmass; b->boundinertia = boundinertia; }
 
 extern "C" int mjh_builder_add_body(mjh_builder* b, const char* name, int parent, const double pos[3],
                                     const double quat[4], double gravcomp) {
@@ -352,6 +354,11 @@ extern "C" mjh_model* mjh_builder_compile(mjh_builder* B) {
   }
   body_iquat[0] = 1;
 
+  // lower bounds on mass / inertia of every body except the world (mjCompiler boundmass / boundinertia)
+  for (int i = 1; i < nbody; i++) {
+    if (B->boundmass > 0 && body_mass[i] < B->boundmass) body_mass[i] = B->boundmass;
+    if (B->boundinertia > 0) for (int k = 0; k < 3; k++) if (body_inertia[3*i+k] < B->boundinertia) body_inertia[3*i+k] = B->boundinertia;
+  }
   // ---- dofs
   for (int j = 0; j < njnt; j++) {
     const BJoint& J = B->joints[jorder[j]];

@@ -19,7 +19,9 @@ import orc  # noqa: E402
 from helpers import save_model_tables  # noqa: E402
 
 REF = "/root/reference/model/test"
-ROBOTS = {"pr2": 16, "tiago": 40, "hsrb4s": 8}   # name -> contact capacity (LDS budget; the meshes are skipped anyway)
+# name -> (file under model/test, contact capacity: LDS budget; the meshes are skipped anyway)
+ROBOTS = {"pr2": ("pr2/pr2.xml", 16), "tiago": ("tiago/tiago.xml", 40), "hsrb4s": ("hsrb4s/hsrb4s.xml", 8),
+          "ridgeback_panda": ("ridgeback_panda/ridgeback_panda.xml", 32)}
 STEPS = 300
 KEEP = (1, 10, 50, 100, 200, 300)
 
@@ -36,8 +38,10 @@ def command(m, k):
 
 
 def main():
-    for name, cap in ROBOTS.items():
-        m = ms.load_mjcf(path=os.path.join(REF, name, name + ".xml"))
+    # the reference writes boundmass = boundinertia = 1e-6 into every file before mj_loadXML (mj_sim.cpp:584-590)
+    ms.capi.load().mjh_load_set_bounds(1e-6, 1e-6)
+    for name, (rel, cap) in ROBOTS.items():
+        m = ms.load_mjcf(path=os.path.join(REF, rel))
         m.c.maxcon = cap; m.c.maxefc = 6 * cap + m.neq + 2 * m.njnt + m.nv
         d = orc.OrcData(m.ptr)
         ctrl = np.zeros(m.nv, dtype=np.int32)
