@@ -165,11 +165,13 @@ def main():
     envs_per_launch = nenv * args.steps / max(n_launches, 1)   # one launch = one step of one cohort
     achieved = bytes_step * envs_per_launch / (kernel_ms * 1e-3) / 1e9
     traffic = None
+    valu_busy = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))   # rocprofv3 PMC measurement of the committed profile run, per launch
             traffic = tj.get("bytes_per_launch")
+            valu_busy = tj.get("valu_issue_busy")
             if traffic is not None and tj.get("envs_per_launch"):
                 traffic = traffic * envs_per_launch / tj["envs_per_launch"]
         except Exception:
@@ -190,7 +192,8 @@ def main():
                      "traffic": traffic, "kernel": "mjh_step_kernel", "kernel_ms": kernel_ms,
                      "launches": n_launches, "envs_per_launch": envs_per_launch, "concurrent_launches": cohorts,
                      "algorithmic_bytes_per_env_step": bytes_step,
-                     "note": "fused per-env pipeline keeps intermediates in LDS: the path is latency/LDS-bound, far below the HBM roofline by design (DESIGN.md)"},
+                     "valu_issue_busy": valu_busy,   # SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x resident waves per SIMD (profiles/): the binding resource
+                     "note": "fused per-env pipeline keeps intermediates in LDS: the path is VALU-issue bound, far below the HBM roofline by design (DESIGN.md)"},
     }
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, eng, tab, 0, min(args.cpu_envs, nenv), args.cpu_steps, args.with_inverse)

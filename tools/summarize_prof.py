@@ -1,5 +1,5 @@
 """Summarise rocprofv3 rocpd (.db) outputs of tools/profile_gpu.sh into profiles/<tag>_*.{md,csv}.
-usage: python tools/summarize_prof.py <tag> [timed_steps] [cohorts]     (one launch = one step of one cohort)"""
+usage: python tools/summarize_prof.py <tag> [timed_steps] [cohorts] [workgroups_per_cu]     (one launch = one step of one cohort)"""
 import glob, json, os, sqlite3, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -56,7 +56,22 @@ if tot:
     json.dump({"tag": tag, "fetch_kib": f, "write_kib": w, "envs_per_launch": envs_per_launch, "bytes_per_launch": (f + w) * 1024, "bytes_per_launch_x2_read_bound": (2 * f + w) * 1024,
                "note": "rocprofv3 PMC, separate passes; raw FETCH_SIZE+WRITE_SIZE (4 B/lane row reads calibrate 1:1 against the known mandatory reads)"},
               open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+sqvals = {}
 con = db("pmc_sq")
+if con:
+    for n in ("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU"):
+        rows = con.execute("select value from counters_collection where kernel_name like '%mjh_step_kernel%' and counter_name=? order by start", (n,)).fetchall()
+        last = [r[0] for r in rows[-timed:]]
+        if last:
+            sqvals[n] = sum(last) / len(last)
+    tp = os.path.join(dst, "hbm_traffic.json")
+    if os.path.exists(tp) and "SQ_ACTIVE_INST_VALU" in sqvals and "SQ_WAVE_CYCLES" in sqvals:
+        tj = json.load(open(tp))
+        wg_per_cu = int(sys.argv[4]) if len(sys.argv) > 4 else 9          # LDS-limited resident workgroups per CU (tools/timeline.py)
+        per_wave = sqvals["SQ_ACTIVE_INST_VALU"] / sqvals["SQ_WAVE_CYCLES"]
+        tj.update({"valu_active_frac_per_wave": per_wave, "workgroups_per_cu": wg_per_cu, "valu_issue_busy": per_wave * wg_per_cu / 4.0,
+                   "valu_instructions_per_env_step": sqvals.get("SQ_INSTS_VALU", 0.0) / envs_per_launch})
+        json.dump(tj, open(tp, "w"), indent=1)
 if con:
     lines += ["## SQ counters (per launch, averages over the last %d launches)" % timed, "", "| counter | value | per wave |", "|---|---|---|"]
     names = [r[0] for r in con.execute("select distinct counter_name from counters_collection")]
