@@ -49,9 +49,12 @@ struct DState {
   long long* x_prof;     // [n*16] s_memtime stamps at stage boundaries (debug)
   // per-env model parameter tables (null -> shared model)
   const float *p_geom_size, *p_geom_rbound, *p_body_mass, *p_body_inertia, *p_body_invweight0, *p_dof_invweight0;
+  // many-body models (nv > 64): per-env pools that do not fit LDS (contacts, blocks, Jacobians) live here; a negative
+  // Lay offset -1-k addresses float k of the env's slice
+  float* gscratch; long long gstride;
 };
 
-// LDS layout (float offsets into the dynamic shared array)
+// LDS layout (float offsets into the dynamic shared array; negative: offset into the env's global scratch slice)
 #define MJH_LDS_ARRAYS(X)                                                                          \
   X(qpos) X(qvel) X(qvref) X(ws) X(qacc) X(smooth) X(asmooth) X(passive) X(bias) X(applied)        \
   X(tmpv) X(tmpv2) X(xpos) X(xquat) X(xmat) X(xipos) X(ximat) X(com) X(cinert) X(crb) X(cvel)      \

@@ -129,7 +129,7 @@ static int pair_cap(int t1, int t2) {
 
 // Host-only derivation of the device model: packed tables, derived topology tables, capacities and the LDS
 // layout.  Needs no HIP device (mjh_query_lds_bytes uses it for capacity planning and in the CPU tests).
-struct HostPack { DModel M{}; Lay L{}; std::vector<int> I; std::vector<float> F; int o_controlled = 0, o_odom = 0, lds_bytes = 0; };
+struct HostPack { DModel M{}; Lay L{}; std::vector<int> I; std::vector<float> F; int o_controlled = 0, o_odom = 0, lds_bytes = 0; long long gstride = 0; };
 static void derive_device_model(const mjh_model* m, HostPack& hp) {
   DModel& M = hp.M; std::vector<int>& I = hp.I; std::vector<float>& F = hp.F;
   // ---- derived integer tables
@@ -212,12 +212,16 @@ static void derive_device_model(const mjh_model* m, HostPack& hp) {
   M.tolerance = (float)m->opt.tolerance; M.impratio = (float)m->opt.impratio; M.meaninertia = (float)m->meaninertia;
   // ---- LDS layout (float offsets, 16-byte aligned)
   {
-    Lay& L = hp.L; int off = 0;
+    Lay& L = hp.L; int off = 0; long long goff = 0;
     auto put = [&](int n) { int o = off; off += ((std::max(n, 1) + 3) / 4) * 4; return o; };
+    // many-body models (nv > 64, NROW = 8 kernels): the contact / block / Jacobian pools go to a per-env slice of global
+    // memory (negative offsets), only the per-body / per-dof arrays stay in LDS
+    const bool big = nv > 64;
+    auto gput = [&](long long n) { long long o = goff; goff += ((std::max<long long>(n, 1) + 3) / 4) * 4; return (int)(-1 - o); };
     const int nblkcap = std::max(M.maxblk, 1);   // exact: the block builder never creates more than maxblk blocks
     // J / B pools: one row per non-contact block (equality, friction loss, limits), four interleaved rows per contact
-    int jsz = std::max((M.maxblk - M.maxcon) * rowW + M.maxcon * rowW * 4, 4);
-    const int need = nstage * RAW_STRIDE;            // raw-contact staging aliases J (+B)
+    long long jsz = std::max<long long>((long long)(M.maxblk - M.maxcon) * rowW + (long long)M.maxcon * rowW * 4, 4);
+    const long long need = (long long)nstage * RAW_STRIDE;            // raw-contact staging aliases J (+B)
     if ((diagM ? 1 : 2) * jsz < need) jsz = diagM ? need : (need + 1) / 2;
     L.qpos = put(m->nq);
     L.qvel = put(nv); L.qvref = put(nv); L.ws = put(nv); L.qacc = put(nv); L.smooth = put(nv); L.asmooth = put(nv); L.passive = put(nv);
@@ -237,21 +241,32 @@ static void derive_device_model(const mjh_model* m, HostPack& hp) {
     {  // the contact records die once the blocks are built; the velocity-stage spatial vectors reuse their space
       const int a4 = [](int n) { return ((std::max(n, 1) + 3) / 4) * 4; }(6*nb);
       const int velsz = 4 * a4 + ((6*nv + 3) / 4) * 4;
-      // (and, once those are dead too, the solver's per-block X extension of condim-4 models)
-      // (and, once those are dead too, the per-block solver matrices A_c / Q, built when the solver starts)
-      L.con = put(std::max(std::max(M.maxcon * CON_STRIDE, velsz), nblkcap * BLKQ_STRIDE));
-      L.blkq = L.con;
-      L.cvel = L.con; L.cacc = L.con + a4; L.cfrc = L.con + 2*a4; L.cfrcsub = L.con + 3*a4; L.cdofdot = L.con + 4*a4;
+      int vel;
+      if (big) { L.con = gput((long long)M.maxcon * CON_STRIDE); L.blkq = gput((long long)nblkcap * BLKQ_STRIDE); vel = put(velsz); }
+      else {
+        // (and, once those are dead too, the per-block solver matrices A_c / Q, built when the solver starts)
+        L.con = put(std::max(std::max(M.maxcon * CON_STRIDE, velsz), nblkcap * BLKQ_STRIDE));
+        L.blkq = L.con; vel = L.con;
+      }
+      L.cvel = vel; L.cacc = vel + a4; L.cfrc = vel + 2*a4; L.cfrcsub = vel + 3*a4; L.cdofdot = vel + 4*a4;
     }
-    L.blki = put(nblkcap * BLKI_STRIDE); L.blkf = put(nblkcap * BLKF_STRIDE);
-    if (2 * nblkcap * 4 <= k1_size) { L.bv = k1; L.phi = k1 + nblkcap * 4; }
-    else { L.bv = put(nblkcap * 4); L.phi = put(nblkcap * 4); }
-    L.sched = put(nblkcap * 2);
-    // the dual-block sweep (nv <= 32) reads the pair schedule only; `order` is then just scratch of the schedule builder
-    L.order = (nv <= 32 && nblkcap <= k1_size) ? L.bv : put(nblkcap);
-    { const int extsz = M.has_dim4 ? nblkcap * SOLX_N : 0; L.ext = extsz <= k2_size ? k1 : put(extsz); }
-    L.J = put(jsz); L.B = diagM ? L.J : put(jsz);
+    const int extsz = M.has_dim4 ? nblkcap * SOLX_N : 0;
+    if (big) {
+      L.blki = gput((long long)nblkcap * BLKI_STRIDE); L.blkf = gput((long long)nblkcap * BLKF_STRIDE);
+      L.bv = gput((long long)nblkcap * 4); L.phi = gput((long long)nblkcap * 4); L.sched = gput((long long)nblkcap * 2); L.order = gput(nblkcap);
+      L.ext = gput(extsz); L.J = gput(jsz); L.B = diagM ? L.J : gput(jsz);
+    } else {
+      L.blki = put(nblkcap * BLKI_STRIDE); L.blkf = put(nblkcap * BLKF_STRIDE);
+      if (2 * nblkcap * 4 <= k1_size) { L.bv = k1; L.phi = k1 + nblkcap * 4; }
+      else { L.bv = put(nblkcap * 4); L.phi = put(nblkcap * 4); }
+      L.sched = put(nblkcap * 2);
+      // the dual-block sweep (nv <= 32) reads the pair schedule only; `order` is then just scratch of the schedule builder
+      L.order = (nv <= 32 && nblkcap <= k1_size) ? L.bv : put(nblkcap);
+      L.ext = extsz <= k2_size ? k1 : put(extsz);
+      L.J = put((int)jsz); L.B = diagM ? L.J : put((int)jsz);
+    }
     L.zero = put(4);
+    hp.gstride = goff;
     L.total = off;
     hp.lds_bytes = off * (int)sizeof(float);
   }
@@ -296,6 +311,10 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     HIPCHK(hipMemcpyAsync(e->dC, &hc, sizeof hc, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
   }
+  if ((long long)(e->M.maxblk - e->M.maxcon) * e->M.rowW + (long long)e->M.maxcon * e->M.rowW * 4 >= 4LL * 65536) {   // hd.x >> 16 holds the offset in float4 units
+    mjh_set_error("mjh_create: Jacobian pool too large for the 16-bit block offsets (lower the contact capacity)");
+    mjh_destroy(e); return MJH_ERR_CAPACITY;
+  }
   if (m->nv > 64 && e->M.rowW > 64) {
     mjh_set_error("mjh_create: nv > 64 needs every constraint to touch at most 64 dofs (this model: " + std::to_string(e->M.rowW) + "); the solver maps one dof of a block per lane");
     mjh_destroy(e); return MJH_ERR_CAPACITY;
@@ -316,6 +335,8 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   rc |= dev_alloc(e, &S.qvel, nv_all); rc |= dev_alloc(e, &S.qacc, nv_all); rc |= dev_alloc(e, &S.qacc_ws, nv_all);
   rc |= dev_alloc(e, &S.qvel_ref, nv_all); rc |= dev_alloc(e, &S.qfrc_applied, nv_all); rc |= dev_alloc(e, &S.ddq, nv_all);
   rc |= dev_alloc(e, &S.dq, nv_all); rc |= dev_alloc(e, &S.qfrc_inverse, nv_all);
+  S.gscratch = nullptr; S.gstride = hp.gstride;
+  if (m->nv > 64) rc |= dev_alloc(e, &S.gscratch, (size_t)nenv * (size_t)hp.gstride, false);   // many-body models: contact / block / Jacobian pools
   rc |= dev_alloc(e, &S.time, (size_t)nenv); rc |= dev_alloc(e, &S.odom_vel, (size_t)nenv * 6); rc |= dev_alloc(e, &S.stats, (size_t)nenv * 4);
   rc |= dev_alloc(e, &S.x_bias, nv_all); rc |= dev_alloc(e, &S.x_passive, nv_all); rc |= dev_alloc(e, &S.x_smooth, nv_all);
   rc |= dev_alloc(e, &S.x_constraint, nv_all); rc |= dev_alloc(e, &S.x_energy, (size_t)nenv * 2);

@@ -234,7 +234,8 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
 #define FT(n) const Tab<float> n{M.F, M.o_##n};
   MJH_FLT_TABLES(FT)
 #undef FT
-#define LA(n) float* s_##n = lds + L.n;
+  float* const gs = NROW == 8 ? S.gscratch + (size_t)env * (size_t)S.gstride : nullptr;   // many-body models: big pools in global memory
+#define LA(n) float* s_##n = (NROW == 8 && L.n < 0) ? gs + (-1 - L.n) : lds + L.n;
   MJH_LDS_ARRAYS(LA)
 #undef LA
   int* s_blki_i = (int*)s_blki; int* s_sched_i = (int*)s_sched; int* s_order_i = (int*)s_order; 

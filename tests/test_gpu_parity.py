@@ -316,6 +316,23 @@ def test_box_pile_nv96_lds_resident_acceleration(lib):
     assert ncon >= 16 and st[0] == ncon and st[1] == nefc
 
 
+def test_c2_64_box_lattice_many_body_pools(lib):
+    """BASELINE config C2: 64 free boxes (nv 384, 2080 candidate pairs) released from the 4x4x4 lattice of
+    mjh_scene_boxpile.  The contact / block / Jacobian pools of such models live in per-env global memory; capacities are
+    set by hand (600 contacts).  A short horizon: the oracle's dense AR is (4 ncon)^2."""
+    m = ms.scene("boxpile", 64)
+    assert m.nv == 384 and m.npair == 2080
+    m.c.maxcon = 600; m.c.maxefc = 600 * 4
+    assert lib.mjh_query_lds_bytes(m.ptr) <= 160 * 1024
+    q0 = m.array("qpos0").copy()
+    rng = np.random.default_rng(5)
+    for k in range(64):                      # tighter lattice, slightly tilted boxes: contacts within a few steps
+        q0[7*k:7*k+2] *= 0.62; q0[7*k+2] = 0.095 + 0.19 * (k // 16) + 0.002 * (k % 16)
+        quat = rng.normal(size=4) * 0.05 + np.array([1, 0, 0, 0]); q0[7*k+3:7*k+7] = quat / np.linalg.norm(quat)
+    st, ncon, nefc = _compare_rollout(m, q0, [1, 12, 30], [1e-5, 2e-4, 5e-3])
+    assert ncon >= 100 and st[0] == ncon and st[1] == nefc
+
+
 def test_mixed_primitives_scene(lib):
     """sphere / capsule / box free bodies on the plane and on each other: every narrow-phase routine on the device"""
     b = lib.mjh_builder_create()
