@@ -78,7 +78,7 @@ static int ensure_scratch(mjh_engine* e, size_t floats) {
 static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps, int ph, int xflags) {
   if (n <= 0) return MJH_OK;
 #define MJH_LAUNCH(NR, DG) hipLaunchKernelGGL((mjh_step_kernel<NR, DG>), dim3(n), dim3(64), (size_t)e->lds_bytes, st, e->dC, e->S, env0, nsteps, ph, xflags)
-  const int nr = e->M.nv <= 16 ? 1 : (e->M.nv <= 32 ? 2 : (e->M.nv <= 64 ? 4 : 8));   // 8: running acceleration in LDS
+  const int nr = e->M.big ? 8 : (e->M.nv <= 16 ? 1 : (e->M.nv <= 32 ? 2 : 4));   // 8: many-body layout, running acceleration in LDS
   if (e->M.diagM) { if (nr == 1) MJH_LAUNCH(1, true); else if (nr == 2) MJH_LAUNCH(2, true); else if (nr == 4) MJH_LAUNCH(4, true); else MJH_LAUNCH(8, true); }
   else { if (nr == 1) MJH_LAUNCH(1, false); else if (nr == 2) MJH_LAUNCH(2, false); else if (nr == 4) MJH_LAUNCH(4, false); else MJH_LAUNCH(8, false); }
 #undef MJH_LAUNCH
@@ -130,7 +130,7 @@ static int pair_cap(int t1, int t2) {
 // Host-only derivation of the device model: packed tables, derived topology tables, capacities and the LDS
 // layout.  Needs no HIP device (mjh_query_lds_bytes uses it for capacity planning and in the CPU tests).
 struct HostPack { DModel M{}; Lay L{}; std::vector<int> I; std::vector<float> F; int o_controlled = 0, o_odom = 0, lds_bytes = 0; long long gstride = 0; };
-static void derive_device_model(const mjh_model* m, HostPack& hp) {
+static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big = false) {
   DModel& M = hp.M; std::vector<int>& I = hp.I; std::vector<float>& F = hp.F;
   // ---- derived integer tables
   const int nb = m->nbody, nv = m->nv, nj = m->njnt, ng = m->ngeom;
@@ -216,7 +216,8 @@ static void derive_device_model(const mjh_model* m, HostPack& hp) {
     auto put = [&](int n) { int o = off; off += ((std::max(n, 1) + 3) / 4) * 4; return o; };
     // many-body models (nv > 64, NROW = 8 kernels): the contact / block / Jacobian pools go to a per-env slice of global
     // memory (negative offsets), only the per-body / per-dof arrays stay in LDS
-    const bool big = nv > 64;
+    const bool big = force_big || nv > 64;
+    M.big = big;
     auto gput = [&](long long n) { long long o = goff; goff += ((std::max<long long>(n, 1) + 3) / 4) * 4; return (int)(-1 - o); };
     const int nblkcap = std::max(M.maxblk, 1);   // exact: the block builder never creates more than maxblk blocks
     // J / B pools: one row per non-contact block (equality, friction loss, limits), four interleaved rows per contact
@@ -272,9 +273,15 @@ static void derive_device_model(const mjh_model* m, HostPack& hp) {
   }
 }
 
+// models whose LDS-resident working set exceeds one CU's LDS fall back to the many-body layout (pools in global memory)
+static void derive_fitting(const mjh_model* m, HostPack& hp) {
+  derive_device_model(m, hp);
+  if (hp.lds_bytes > 160 * 1024 && !hp.M.big && hp.M.rowW <= 64) { HostPack big; derive_device_model(m, big, true); hp = big; }
+}
+
 extern "C" int mjh_query_lds_bytes(const mjh_model* m) {
   if (!m) return MJH_ERR_ARG;
-  HostPack hp; derive_device_model(m, hp);
+  HostPack hp; derive_fitting(m, hp);
   return hp.lds_bytes;
 }
 
@@ -295,7 +302,7 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   if (const char* v = getenv("MJH_LPT")) e->lpt = atoi(v) != 0;
   e->model = m; e->nenv = nenv; e->device = device; e->stream = (hipStream_t)stream;
 
-  HostPack hp; derive_device_model(m, hp);
+  HostPack hp; derive_fitting(m, hp);
   e->M = hp.M; e->L = hp.L; e->lds_bytes = hp.lds_bytes; e->o_controlled = hp.o_controlled; e->o_odom = hp.o_odom;
   DModel& M = e->M; std::vector<int>& I = hp.I; std::vector<float>& F = hp.F;
   e->hI = I;
@@ -315,7 +322,7 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     mjh_set_error("mjh_create: Jacobian pool too large for the 16-bit block offsets (lower the contact capacity)");
     mjh_destroy(e); return MJH_ERR_CAPACITY;
   }
-  if (m->nv > 64 && e->M.rowW > 64) {
+  if (e->M.big && e->M.rowW > 64) {
     mjh_set_error("mjh_create: nv > 64 needs every constraint to touch at most 64 dofs (this model: " + std::to_string(e->M.rowW) + "); the solver maps one dof of a block per lane");
     mjh_destroy(e); return MJH_ERR_CAPACITY;
   }
@@ -336,7 +343,7 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   rc |= dev_alloc(e, &S.qvel_ref, nv_all); rc |= dev_alloc(e, &S.qfrc_applied, nv_all); rc |= dev_alloc(e, &S.ddq, nv_all);
   rc |= dev_alloc(e, &S.dq, nv_all); rc |= dev_alloc(e, &S.qfrc_inverse, nv_all);
   S.gscratch = nullptr; S.gstride = hp.gstride;
-  if (m->nv > 64) rc |= dev_alloc(e, &S.gscratch, (size_t)nenv * (size_t)hp.gstride, false);   // many-body models: contact / block / Jacobian pools
+  if (M.big) rc |= dev_alloc(e, &S.gscratch, (size_t)nenv * (size_t)hp.gstride, false);   // many-body models: contact / block / Jacobian pools
   rc |= dev_alloc(e, &S.time, (size_t)nenv); rc |= dev_alloc(e, &S.odom_vel, (size_t)nenv * 6); rc |= dev_alloc(e, &S.stats, (size_t)nenv * 4);
   rc |= dev_alloc(e, &S.x_bias, nv_all); rc |= dev_alloc(e, &S.x_passive, nv_all); rc |= dev_alloc(e, &S.x_smooth, nv_all);
   rc |= dev_alloc(e, &S.x_constraint, nv_all); rc |= dev_alloc(e, &S.x_energy, (size_t)nenv * 2);

@@ -636,3 +636,27 @@ def test_forked_export_publishes_without_joining_the_cohorts():
     b.step(5)
     assert np.array_equal(a.get_state()[1], b.get_state()[1])
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_pr2_with_large_capacity_falls_back_to_global_pools(lib):
+    """A working set beyond one CU's LDS (PR2 at a 128-contact capacity: 49-dof rows) selects the many-body layout:
+    pools in per-env global memory, block-at-a-time sweep with M^-1 J^T rows, equality and limit rows.  Same golden."""
+    from helpers import load_model_tables
+    from test_robot_fixtures import robot_command
+    m, z = load_model_tables(os.path.join(ROOT, "tests", "golden", "robot_pr2.npz"))
+    small = lib.mjh_query_lds_bytes(m.ptr)
+    m.c.maxcon = 128; m.c.maxefc = 6 * 128 + 200
+    assert lib.mjh_query_lds_bytes(m.ptr) < small            # pools left LDS
+    e = ms.Engine(m, 2)
+    e.set_controlled_dofs(z["controlled"].astype(np.int32))
+    for k in range(1, 101):
+        e.set_cmd(ddq=np.tile(robot_command(m, k), (2, 1)))
+        e.step(1, True)
+        if k in (1, 10, 50, 100):
+            t, q, v, w = e.get_state()
+            np.testing.assert_allclose(q[0], z[f"qpos_{k}"], rtol=0, atol=4e-4 * max(1.0, np.abs(z[f"qpos_{k}"]).max()))
+            ref = z[f"qfrc_inverse_{k}"]
+            np.testing.assert_allclose(e.get_field("qfrc_inverse")[0], ref, rtol=0, atol=5e-3 * max(1.0, np.abs(ref).max()))
+            assert e.get_stats()[0, 1] == int(z[f"nefc_{k}"])
+    e.close()
