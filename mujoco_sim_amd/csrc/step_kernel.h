@@ -235,8 +235,12 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   MJH_FLT_TABLES(FT)
 #undef FT
   float* const gs = NROW == 8 ? S.gscratch + (size_t)env * (size_t)S.gstride : nullptr;   // many-body models: big pools in global memory
-#define LA(n) float* s_##n = (NROW == 8 && L.n < 0) ? gs + (-1 - L.n) : lds + L.n;
-  MJH_LDS_ARRAYS(LA)
+  // (compile-time choice per instantiation: the address space of every array is known to the compiler)
+#define LA(n) float* s_##n = lds + L.n;
+  MJH_LDS_SMALL(LA)
+#undef LA
+#define LA(n) float* s_##n = NROW == 8 ? gs + (-1 - L.n) : lds + L.n;
+  MJH_LDS_POOLS(LA)
 #undef LA
   int* s_blki_i = (int*)s_blki; int* s_sched_i = (int*)s_sched; int* s_order_i = (int*)s_order; 
   // chain-walk tables: LDS copies for articulated models; free-body models (DIAGM) walk 6-dof chains a few times per step
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
     //      Jacobians: 1 row (equality / friction loss / limit / frictionless contact) or the 2(dim-1)
     //      pyramid rows of a contact, which are all  J_n +- mu_k J_k  over nbase = dim base rows.
     nefc = 0;
-    int nblk = 0, nbrow = 0;
+    int nblk = 0, nbrow = 0, nfixblk = 0;   // nfixblk: number of non-contact blocks (they come first)
     if (!(M.disableflags & MJH_DSBL_CONSTRAINT)) {
       // non-contact blocks come first and own one row of rowW floats each; contact block c owns 4*rowW floats
       auto put_block = [&](int b, int kind, int nrows, int nb, int clamp, int joff4, int id, int rtype, int side) __attribute__((always_inline)) {
@@ -573,7 +577,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         }
       }
       // contacts: a contact whose rows do not fit drops it and every later contact (oracle rule)
-      const int nfix = nblk;
+      const int nfix = nblk; nfixblk = nblk;
       bool stop = false;
       for (int base = 0; base < ncon && !stop; base += 64) {
         const int ic = base + lane; int nr = 0, nb = 0, dim = 0;
@@ -1160,51 +1164,84 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         const bool has_dim4 = M.has_dim4 != 0;   // condim-4 contacts present: blocks carry the X extension
         if constexpr (NROW == 8) {
           // ======== nv > 64: the running acceleration lives in LDS (s_qacc); lanes = the compact dofs of ONE block
-          //          (at most 64: rowW), gathered before and scattered after the block's update.  A functional path
-          //          for many-body models: one LDS round trip per block, no operand prefetch.
+          //          (at most 64: rowW), gathered before and scattered after the block's update; the block's operands come
+          //          from the global pools and are prefetched one block ahead.
           for (int d = lane; d < nv; d += 64) s_qacc[d] = s_asmooth[d] + s_tmpv[d];
           WSYNC();
-          for (int it = 0; it < M.iterations; it++) {
-            float improvement = 0;
-            for (int k = 0; k < nblk; k++) {
-              const int b = s_order_i[k];
-              const int4 hd = blki4[b];
-              ROW_TREES(hd.z, hd.w);
-              const bool on = lane < n1 + n2;
-              const int d = lane < n1 ? a1 + lane : a2 + lane - n1;
-              float ak = on ? s_qacc[d] : 0.0f;
-              const int jo = BLK_JOFF(hd.x);
-              const bool quad = BLK_SLOTS(hd.y) == 4;
-              float4 j4 = make_float4(0, 0, 0, 0), b4 = make_float4(0, 0, 0, 0);
-              if (on) { if (quad) j4 = *(const float4*)(s_J + jo + 4*lane); else j4.x = s_J[jo + lane]; }
-              if (!DIAGM && on) { if (quad) b4 = *(const float4*)(s_B + jo + 4*lane); else b4.x = s_B[jo + lane]; }
-              const float4 p0 = blkf4[4*b], r0 = blkf4[4*b+1], r1 = blkf4[4*b+2], r2 = blkf4[4*b+3];
-              const float4 A0 = blkq4[4*b], A1 = blkq4[4*b+1], A2 = blkq4[4*b+2], A3 = blkq4[4*b+3];
-              float4 X0 = make_float4(0, 0, 0, 0), X1 = X0, X2 = X0;
-              if (has_dim4) { const float4* x4 = (const float4*)(s_ext + b * SOLX_N); X0 = x4[0]; X1 = x4[1]; X2 = x4[2]; }
-              const int kind = __builtin_amdgcn_readfirstlane(hd.x & 15);
-              float f[6] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
-              const float aref[4] = {r0.x, r0.y, r0.z, r0.w};
-              const float Q[16] = {A0.x, A0.y, A0.z, A0.w, A1.x, A1.y, A1.z, A1.w, A2.x, A2.y, A2.z, A2.w, A3.x, A3.y, A3.z, A3.w};
-              const float X[12] = {X0.x, X0.y, X0.z, X0.w, X1.x, X1.y, X1.z, X1.w, X2.x, X2.y, X2.z, X2.w};
-              const float Jd[4] = {j4.x, j4.y, j4.z, j4.w}, Bd[4] = {b4.x, b4.y, b4.z, b4.w};
-              const float* Bp = DIAGM ? Jd : Bd;
-              const float bs = DIAGM ? (on ? s_qLDinv[d] : 0.0f) : 1.0f;
-              const float R = p0.x, lo = r2.z, hi = r2.w;
-              if (kind == BK_PYR4) pgs_block<4, 6, NROW>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
-              else if (kind == BK_PYR3) pgs_block<3, 4, NROW>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
-              else pgs_block<1, 1, NROW>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
-              if (on) s_qacc[d] = ak;
-              if (lane == 0) {
-                float* bf = s_blkf + b * BLKF_STRIDE + BF_F;
-                *(float4*)(bf) = make_float4(f[0], f[1], f[2], f[3]);
-                *(float2*)(bf + 4) = make_float2(f[4], f[5]);
-              }
-              WSYNC();
+          nfixblk = __builtin_amdgcn_readfirstlane(nfixblk);
+          // operands of one block; every address follows from the block index alone (contact blocks are laid out
+          // regularly behind the nfixblk non-contact ones), so all loads of block k+1 are in flight while block k is solved
+          struct MOp { int4 hd; int b; float4 J, B, p0, r0, r1, r2, A0, A1, A2, A3, X0, X1, X2; };
+          auto blockAt = [&](int k) __attribute__((always_inline)) { return nblk > 64 ? k : s_order_i[k]; };   // beyond 64 blocks: plain order
+          auto fetch8 = [&](int b) __attribute__((always_inline)) {
+            MOp op; op.b = b; op.hd = blki4[b];
+            const bool quad = b >= nfixblk;
+            const int jo = (quad ? nfixblk + 4 * (b - nfixblk) : b) * rowW;      // = BLK_JOFF(hd.x), see put_block
+            op.J = make_float4(0, 0, 0, 0); op.B = op.J;
+            if (lane < rowW) {                                                  // dofs beyond the block's trees hold zeros
+              if (quad) op.J = *(const float4*)(s_J + jo + 4*lane); else op.J.x = s_J[jo + lane];
+              if (!DIAGM) { if (quad) op.B = *(const float4*)(s_B + jo + 4*lane); else op.B.x = s_B[jo + lane]; }
             }
-            niter = it + 1;
-            if (improvement * scale < M.tolerance) break;
+            op.p0 = blkf4[4*b]; op.r0 = blkf4[4*b+1]; op.r1 = blkf4[4*b+2]; op.r2 = blkf4[4*b+3];
+            op.A0 = blkq4[4*b]; op.A1 = blkq4[4*b+1]; op.A2 = blkq4[4*b+2]; op.A3 = blkq4[4*b+3];
+            op.X0 = make_float4(0, 0, 0, 0); op.X1 = op.X0; op.X2 = op.X0;
+            if (has_dim4) { const float4* x4 = (const float4*)(s_ext + b * SOLX_N); op.X0 = x4[0]; op.X1 = x4[1]; op.X2 = x4[2]; }
+            return op;
+          };
+          auto process8 = [&](MOp& op, float& improvement) __attribute__((always_inline)) {
+            KEEP4(op.hd); KEEP4(op.J); KEEP4(op.p0); KEEP4(op.r0); KEEP4(op.r1); KEEP4(op.r2); KEEP4(op.A0); KEEP4(op.A1); KEEP4(op.A2); KEEP4(op.A3);
+            if (!DIAGM) KEEP4(op.B);
+            if (has_dim4) { KEEP4(op.X0); KEEP4(op.X1); KEEP4(op.X2); }
+            ROW_TREES(op.hd.z, op.hd.w);
+            const bool on = lane < n1 + n2;
+            const int d = lane < n1 ? a1 + lane : a2 + lane - n1;
+            float ak = on ? s_qacc[d] : 0.0f;                                    // gather
+            const int kind = __builtin_amdgcn_readfirstlane(op.hd.x & 15);
+            float f[6] = {op.r1.x, op.r1.y, op.r1.z, op.r1.w, op.r2.x, op.r2.y};
+            const float aref[4] = {op.r0.x, op.r0.y, op.r0.z, op.r0.w};
+            const float Q[16] = {op.A0.x, op.A0.y, op.A0.z, op.A0.w, op.A1.x, op.A1.y, op.A1.z, op.A1.w,
+                                 op.A2.x, op.A2.y, op.A2.z, op.A2.w, op.A3.x, op.A3.y, op.A3.z, op.A3.w};
+            const float X[12] = {op.X0.x, op.X0.y, op.X0.z, op.X0.w, op.X1.x, op.X1.y, op.X1.z, op.X1.w, op.X2.x, op.X2.y, op.X2.z, op.X2.w};
+            const float Jd[4] = {on ? op.J.x : 0.0f, on ? op.J.y : 0.0f, on ? op.J.z : 0.0f, on ? op.J.w : 0.0f};
+            const float Bd[4] = {on ? op.B.x : 0.0f, on ? op.B.y : 0.0f, on ? op.B.z : 0.0f, on ? op.B.w : 0.0f};
+            const float* Bp = DIAGM ? Jd : Bd;
+            const float bs = DIAGM ? (on ? s_qLDinv[d] : 0.0f) : 1.0f;
+            const float R = op.p0.x, lo = op.r2.z, hi = op.r2.w;
+            if (kind == BK_PYR4) pgs_block<4, 6, NROW>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
+            else if (kind == BK_PYR3) pgs_block<3, 4, NROW>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
+            else pgs_block<1, 1, NROW>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
+            if (on) s_qacc[d] = ak;                                              // scatter
+            if (lane == 0) {
+              float* bf = s_blkf + op.b * BLKF_STRIDE + BF_F;
+              *(float4*)(bf) = make_float4(f[0], f[1], f[2], f[3]);
+              *(float2*)(bf + 4) = make_float2(f[4], f[5]);
+            }
+          };
+          if (nblk < 3) {
+            // (the prefetch would read the forces of a block before its pending update is stored)
+            for (int it = 0; it < M.iterations; it++) {
+              float improvement = 0;
+              for (int k = 0; k < nblk; k++) { MOp op = fetch8(blockAt(k)); process8(op, improvement); WSYNC(); }
+              niter = it + 1;
+              if (improvement * scale < M.tolerance) break;
+            }
+          } else {
+            MOp opA = fetch8(blockAt(0)), opB;
+            for (int it = 0; it < M.iterations; it++) {
+              float improvement = 0;
+              for (int k = 0; k < nblk; k += 2) {
+                opB = fetch8(blockAt(k + 1 < nblk ? k + 1 : 0));
+                process8(opA, improvement);
+                if (k + 1 < nblk) {
+                  opA = fetch8(blockAt(k + 2 < nblk ? k + 2 : 0));
+                  process8(opB, improvement);
+                } else opA = opB;                  // odd block count: block 0 of the next sweep was loaded into B
+              }
+              niter = it + 1;
+              if (improvement * scale < M.tolerance) break;
+            }
           }
+          WSYNC();
           for (int d = lane; d < nv; d += 64) s_ws[d] = s_qacc[d];
         } else if constexpr (NROW <= 2) {
           // ======== dual-block sweep: half 0 solves block p, half 1 its independent partner q of the schedule
