@@ -263,7 +263,9 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   }
   for (int i = lane; i < nq; i += 64) s_qpos[i] = S.qpos[qrow + i];
   for (int i = lane; i < nv; i += 64) {
-    s_qvel[i] = S.qvel[vrow + i]; s_ws[i] = S.qacc_ws[vrow + i]; s_qacc[i] = S.qacc[vrow + i];
+    s_qvel[i] = S.qvel[vrow + i]; s_ws[i] = S.qacc_ws[vrow + i];
+    // last step's qacc is an input of mj_inverse only; a launch that will not overwrite it (no step2) carries it through
+    s_qacc[i] = ((ph & PH_INV) || !(ph & PH_STEP2)) ? S.qacc[vrow + i] : 0.0f;
     // qvel_ref / qfrc_applied only cross launches in the split API (step1 | inverse | step2 as separate calls)
     if (!(ph & PH_STEP1)) { s_qvref[i] = S.qvel_ref[vrow + i]; s_applied[i] = S.qfrc_applied[vrow + i]; }
   }
