@@ -30,6 +30,50 @@ DEV int c_plane_capsule(const float* pp, const float* pm, const float* c, const 
   return n;
 }
 
+// plane - cylinder: deepest rim point of the cap facing the plane, the same rim direction on the other cap, and two more
+// points of the near cap at +-120 degrees (a triangle under a standing cylinder); at most 4
+DEV int c_plane_cylinder(const float* pp, const float* pm, const float* c, const float* cm, const float* size, float margin, float* st) {
+  const float n[3] = {pm[2], pm[5], pm[8]}, t[3] = {c[0]-pp[0], c[1]-pp[1], c[2]-pp[2]};
+  float ax[3] = {cm[2], cm[5], cm[8]};
+  const float r = size[0], h = size[1];
+  float prjaxis = dot3(n, ax);
+  if (prjaxis > 0) { ax[0] = -ax[0]; ax[1] = -ax[1]; ax[2] = -ax[2]; prjaxis = -prjaxis; }   // axis points towards the plane
+  const float dist0 = dot3(t, n);
+  float vec[3] = {ax[0]*prjaxis - n[0], ax[1]*prjaxis - n[1], ax[2]*prjaxis - n[2]};          // -normal without its axial part
+  const float len2 = dot3(vec, vec);
+  if (len2 >= 1e-10f) { const float sc = r * rsqrtf(len2); vec[0] *= sc; vec[1] *= sc; vec[2] *= sc; }   // (threshold shared with the oracle)
+  else { vec[0] = cm[0] * r; vec[1] = cm[3] * r; vec[2] = cm[6] * r; }                        // cap parallel to the plane: cylinder x axis
+  const float prjvec = dot3(vec, n);
+  ax[0] *= h; ax[1] *= h; ax[2] *= h; prjaxis *= h;
+  const float d1 = dist0 + prjaxis + prjvec;
+  if (d1 > margin) return 0;
+  int cnt = 0;
+  { const float pos[3] = {c[0] + vec[0] + ax[0] - n[0]*0.5f*d1, c[1] + vec[1] + ax[1] - n[1]*0.5f*d1, c[2] + vec[2] + ax[2] - n[2]*0.5f*d1};
+    raw_emit(st, cnt, d1, pos, n); cnt++; }
+  const float d2 = dist0 - prjaxis + prjvec;
+  if (d2 <= margin) {
+    const float pos[3] = {c[0] + vec[0] - ax[0] - n[0]*0.5f*d2, c[1] + vec[1] - ax[1] - n[1]*0.5f*d2, c[2] + vec[2] - ax[2] - n[2]*0.5f*d2};
+    raw_emit(st, cnt, d2, pos, n); cnt++;
+  }
+  const float d3 = dist0 + prjaxis - 0.5f * prjvec;
+  if (d3 <= margin) {
+    float v1[3]; cross3(v1, vec, ax);
+    const float l2 = dot3(v1, v1);
+    if (l2 > MJ_MINVAL * MJ_MINVAL) {
+      const float sc = r * 0.8660254037844386f * rsqrtf(l2);
+      v1[0] *= sc; v1[1] *= sc; v1[2] *= sc;
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const float sg = q ? -1.0f : 1.0f;
+        const float pos[3] = {c[0] + sg*v1[0] + ax[0] - 0.5f*vec[0] - n[0]*0.5f*d3, c[1] + sg*v1[1] + ax[1] - 0.5f*vec[1] - n[1]*0.5f*d3,
+                              c[2] + sg*v1[2] + ax[2] - 0.5f*vec[2] - n[2]*0.5f*d3};
+        raw_emit(st, cnt, d3, pos, n); cnt++;
+      }
+    }
+  }
+  return cnt;
+}
+
 DEV int c_plane_box(const float* pp, const float* pm, const float* c, const float* bm, const float* size, float margin, float* st) {
   float n[3] = {pm[2], pm[5], pm[8]}, t[3] = {c[0]-pp[0], c[1]-pp[1], c[2]-pp[2]};
   float dist = dot3(t, n);

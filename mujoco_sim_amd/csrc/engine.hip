@@ -123,6 +123,7 @@ static int pair_cap(int t1, int t2) {
   if (t1 > t2) std::swap(t1, t2);
   if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_BOX) return 4;
   if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_CAPSULE) return 2;
+  if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_CYLINDER) return 4;
   if (t1 == MJH_GEOM_BOX && t2 == MJH_GEOM_BOX) return 8;
   return 1;
 }

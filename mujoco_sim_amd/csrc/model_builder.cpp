@@ -175,7 +175,7 @@ static bool pair_supported(int t1, int t2) {
   if (is(t1, MJH_GEOM_PLANE))
     return t2 == MJH_GEOM_SPHERE || t2 == MJH_GEOM_CAPSULE || t2 == MJH_GEOM_BOX || t2 == MJH_GEOM_CYLINDER;
   if (is(t1, MJH_GEOM_SPHERE)) return t2 == MJH_GEOM_SPHERE || t2 == MJH_GEOM_CAPSULE || t2 == MJH_GEOM_BOX;
-  if (is(t1, MJH_GEOM_CAPSULE)) return t2 == MJH_GEOM_CAPSULE || t2 == MJH_GEOM_BOX;
+  if (is(t1, MJH_GEOM_CAPSULE)) return t2 == MJH_GEOM_CAPSULE;   // capsule-box: no narrow phase yet
   if (is(t1, MJH_GEOM_BOX)) return t2 == MJH_GEOM_BOX;
   return false;
 }
@@ -183,9 +183,8 @@ static int pair_maxcon(int t1, int t2) {
   if (t1 > t2) std::swap(t1, t2);
   if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_BOX) return 4;
   if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_CAPSULE) return 2;
-  if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_CYLINDER) return 3;
+  if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_CYLINDER) return 4;
   if (t1 == MJH_GEOM_BOX && t2 == MJH_GEOM_BOX) return 8;
-  if (t1 == MJH_GEOM_CAPSULE && t2 == MJH_GEOM_BOX) return 2;
   return 1;
 }
 

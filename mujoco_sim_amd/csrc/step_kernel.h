@@ -511,6 +511,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             else if (t1 == MJH_GEOM_BOX && t2 == MJH_GEOM_BOX) n = c_box_box(p1, m1, z1, p2, m2, z2, margin, st);
             else if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_SPHERE) n = c_plane_sphere(p1, m1, p2, z2[0], margin, st, 0);
             else if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_CAPSULE) n = c_plane_capsule(p1, m1, p2, m2, z2, margin, st);
+            else if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_CYLINDER) n = c_plane_cylinder(p1, m1, p2, m2, z2, margin, st);
             else if (t1 == MJH_GEOM_SPHERE && t2 == MJH_GEOM_SPHERE) n = c_sphere_sphere(p1, z1[0], p2, z2[0], margin, st);
             else if (t1 == MJH_GEOM_SPHERE && t2 == MJH_GEOM_CAPSULE) n = c_sphere_capsule(p1, z1[0], p2, m2, z2, margin, st);
             else if (t1 == MJH_GEOM_CAPSULE && t2 == MJH_GEOM_CAPSULE) n = c_capsule_capsule(p1, m1, z1, p2, m2, z2, margin, st);

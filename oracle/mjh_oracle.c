@@ -394,6 +394,51 @@ static int c_plane_capsule(const double* pp, const double* pm, const double* c, 
   n += c_plane_sphere(pp, pm, e, size[0], margin, out + n);
   return n;
 }
+/* [UPSTREAM mjc_PlaneCylinder]: deepest rim point of the cap facing the plane, the same rim direction on the other cap,
+ * and two more points of the near cap at +-120 degrees (a triangle under a standing cylinder); at most 4 */
+static int c_plane_cylinder(const double* pp, const double* pm, const double* c, const double* cm, const double* size, double margin, rawcon* out) {
+  double n[3] = {pm[2], pm[5], pm[8]}, ax[3] = {cm[2], cm[5], cm[8]}, t[3] = {c[0]-pp[0], c[1]-pp[1], c[2]-pp[2]};
+  const double r = size[0], h = size[1];
+  double prjaxis = dot3(n, ax);
+  if (prjaxis > 0) { for (int k = 0; k < 3; k++) ax[k] = -ax[k]; prjaxis = -prjaxis; }   /* axis points towards the plane */
+  const double dist0 = dot3(t, n);
+  double vec[3], len2 = 0;
+  for (int k = 0; k < 3; k++) { vec[k] = ax[k] * prjaxis - n[k]; len2 += vec[k] * vec[k]; }   /* -normal without its axial part */
+  /* (the parallel-cap test uses 1e-10 instead of mjMINVAL^2 so that the fp32 engine, whose rotation matrices carry
+   * 1e-7 noise, takes the same branch as this fp64 restatement) */
+  if (len2 >= 1e-10) { const double sc = r / sqrt(len2); for (int k = 0; k < 3; k++) vec[k] *= sc; }
+  else { vec[0] = cm[0] * r; vec[1] = cm[3] * r; vec[2] = cm[6] * r; }                       /* cap parallel to the plane: cylinder x axis */
+  const double prjvec = dot3(vec, n);
+  for (int k = 0; k < 3; k++) ax[k] *= h;
+  prjaxis *= h;
+  int cnt = 0;
+  double d1 = dist0 + prjaxis + prjvec;
+  if (d1 > margin) return 0;
+  out[cnt].dist = d1; copyv(out[cnt].n, n, 3);
+  for (int k = 0; k < 3; k++) out[cnt].pos[k] = c[k] + vec[k] + ax[k] - n[k] * 0.5 * d1;
+  cnt++;
+  double d2 = dist0 - prjaxis + prjvec;
+  if (d2 <= margin) {
+    out[cnt].dist = d2; copyv(out[cnt].n, n, 3);
+    for (int k = 0; k < 3; k++) out[cnt].pos[k] = c[k] + vec[k] - ax[k] - n[k] * 0.5 * d2;
+    cnt++;
+  }
+  double d3 = dist0 + prjaxis - 0.5 * prjvec;
+  if (d3 <= margin) {
+    double v1[3]; cross3(v1, vec, ax);
+    double l = sqrt(dot3(v1, v1));
+    if (l > MINVAL) {
+      const double sc = r * 0.8660254037844386 / l;
+      for (int k = 0; k < 3; k++) v1[k] *= sc;
+      for (int sgn = 1; sgn >= -1; sgn -= 2) {
+        out[cnt].dist = d3; copyv(out[cnt].n, n, 3);
+        for (int k = 0; k < 3; k++) out[cnt].pos[k] = c[k] + sgn * v1[k] + ax[k] - 0.5 * vec[k] - n[k] * 0.5 * d3;
+        cnt++;
+      }
+    }
+  }
+  return cnt;
+}
 /* [UPSTREAM mjc_PlaneBox]: corners below the centre, at most 4 */
 static int c_plane_box(const double* pp, const double* pm, const double* c, const double* bm, const double* size, double margin, rawcon* out) {
   double n[3] = {pm[2], pm[5], pm[8]}, t[3] = {c[0]-pp[0], c[1]-pp[1], c[2]-pp[2]};
@@ -619,6 +664,7 @@ void orc_collision(orc_data* d) {
     if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_SPHERE) n = c_plane_sphere(p1, m1, p2, s2[0], margin, rc);
     else if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_CAPSULE) n = c_plane_capsule(p1, m1, p2, m2, s2, margin, rc);
     else if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_BOX) n = c_plane_box(p1, m1, p2, m2, s2, margin, rc);
+    else if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_CYLINDER) n = c_plane_cylinder(p1, m1, p2, m2, s2, margin, rc);
     else if (t1 == MJH_GEOM_SPHERE && t2 == MJH_GEOM_SPHERE) n = c_sphere_sphere(p1, s1[0], p2, s2[0], margin, rc);
     else if (t1 == MJH_GEOM_SPHERE && t2 == MJH_GEOM_CAPSULE) n = c_sphere_capsule(p1, s1[0], p2, m2, s2, margin, rc);
     else if (t1 == MJH_GEOM_CAPSULE && t2 == MJH_GEOM_CAPSULE) n = c_capsule_capsule(p1, m1, s1, p2, m2, s2, margin, rc);

@@ -333,6 +333,28 @@ def test_c2_64_box_lattice_many_body_pools(lib):
     assert ncon >= 100 and st[0] == ncon and st[1] == nefc
 
 
+def test_cylinders_on_the_plane(lib):
+    """plane - cylinder narrow phase (wheels of the reference's robots): a standing, a lying (rolling) and a tilted
+    free cylinder, device vs oracle"""
+    b = lib.mjh_builder_create()
+    set_opt(lib, b, timestep=0.004)
+    lib.mjh_builder_add_geom(b, b"floor", 0, 0, D(0, 0, 0.05), None, None, None, -1, -1, -1, -1)
+    specs = [(b"stand", (0.06, 0.10), (0.0, 0.0, 0.12), (1, 0, 0, 0)),
+             (b"roll", (0.05, 0.08), (0.4, 0.0, 0.07), (np.cos(np.pi / 4), np.sin(np.pi / 4), 0, 0)),
+             (b"tilt", (0.07, 0.05), (0.0, 0.4, 0.16), (np.cos(0.3), 0, np.sin(0.3), 0))]
+    for name, size, pos, quat in specs:
+        bd = lib.mjh_builder_add_body(b, name, 0, D(*pos), D(*quat), 0.0)
+        lib.mjh_builder_add_joint(b, None, bd, 0, None, None, None, 0, 0, 0, 0, 0)
+        lib.mjh_builder_add_geom(b, None, bd, 5, D(size[0], size[1], 0), None, None, None, -1, -1, -1, -1)
+    m = ms.Model(lib.mjh_builder_compile(b), lib)
+    lib.mjh_builder_destroy(b)
+    assert m.nv == 18 and m.npair == 3
+    q0 = m.array("qpos0").copy()
+    v0 = np.zeros(m.nv); v0[6] = 0.5; v0[6 + 4] = 0.0; v0[12 + 3] = 1.0      # push the lying one along x, spin the tilted one
+    st, ncon, nefc = _compare_rollout(m, q0, [1, 50, 150], [1e-5, 1e-3, 3e-2], v0=v0)
+    assert ncon >= 5 and st[0] == ncon
+
+
 def test_mixed_primitives_scene(lib):
     """sphere / capsule / box free bodies on the plane and on each other: every narrow-phase routine on the device"""
     b = lib.mjh_builder_create()

@@ -162,3 +162,35 @@ def test_contact_parameter_mixing_and_rows(lib):
     np.testing.assert_allclose(np.abs(0.5 * (J[0] - J[1]))[:3].max(), 2.0, atol=1e-12)   # mu1 = 2 on a unit tangent
     R = d.f("efc_R")
     assert np.allclose(R[:6], R[0]) and R[0] > 0
+
+
+def test_plane_cylinder_contacts_and_rest(lib):
+    """plane - cylinder (mjc_PlaneCylinder structure): standing -> a triangle of 3 points under the cap, lying -> the two
+    ends of the line of touch; both rest with sum of normal forces = m g."""
+    import orc
+    from helpers import D, set_opt
+    for quat, expect in (((1, 0, 0, 0), 3), ((np.cos(np.pi / 4), np.sin(np.pi / 4), 0, 0), 2)):
+        b = lib.mjh_builder_create(); set_opt(lib, b, timestep=0.002)
+        lib.mjh_builder_add_geom(b, b"floor", 0, 0, D(0, 0, 0.05), None, None, None, -1, -1, -1, -1)
+        r, h = 0.06, 0.10
+        z0 = (h if expect == 3 else r) - 1e-4
+        bd = lib.mjh_builder_add_body(b, b"cyl", 0, D(0, 0, z0), D(*quat), 0.0)
+        lib.mjh_builder_add_joint(b, None, bd, 0, None, None, None, 0, 0, 0, 0, 0)
+        lib.mjh_builder_add_geom(b, None, bd, 5, D(r, h, 0), None, None, None, -1, -1, -1, -1)
+        import mujoco_sim_amd as ms
+        m = ms.Model(lib.mjh_builder_compile(b), lib); lib.mjh_builder_destroy(b)
+        mass = m.array("body_mass")[1]
+        np.testing.assert_allclose(mass, 1000 * np.pi * r * r * 2 * h, rtol=1e-12)
+        d = orc.OrcData(m.ptr)
+        d.call("forward")
+        cons = d.contacts()
+        assert len(cons) == expect, (expect, cons)
+        for c in cons:
+            np.testing.assert_allclose(c["frame"][:3], [0, 0, 1], atol=1e-12)
+            assert abs(c["pos"][2]) < 1e-3 and c["dist"] < 0
+            assert np.hypot(c["pos"][0], c["pos"][1]) <= r + (h if expect == 2 else 0) + 1e-9
+        if expect == 3:      # the three points span the cap: centroid on the axis
+            np.testing.assert_allclose(np.mean([c["pos"][:2] for c in cons], axis=0), [0, 0], atol=1e-9)
+        d.step(1500)
+        assert np.abs(d.f("qvel")).max() < 2e-3
+        np.testing.assert_allclose(d.f("qpos")[2], z0 + 1e-4, atol=2e-3)
