@@ -165,6 +165,9 @@ const char* mjh_id2name(const mjh_model*, int objtype, int id);
  * on failure; mjh_load_note() lists what was skipped (mesh geoms, <include>, default classes, ...). */
 mjh_model* mjh_load_mjcf_string(const char* xml);
 mjh_model* mjh_load_mjcf_file(const char* path);
+/* one model from several files: the reference composes a world file and robot files into one MJCF before mj_loadXML
+ * (MjSim::init, mj_sim.cpp:573-710).  <option> comes from the first file; names must be unique across files. */
+mjh_model* mjh_load_mjcf_files(const char* const* paths, int n);
 const char* mjh_load_note(void);
 /* process-wide floor for <compiler boundmass boundinertia> of every file loaded afterwards: the reference writes
  * 1e-6 / 1e-6 into each file before mj_loadXML (mj_sim.cpp:584-590) */

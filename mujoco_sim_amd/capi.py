@@ -108,6 +108,7 @@ SYMBOLS = [
     ("mjh_id2name", C.c_char_p, [Model_p, C.c_int, C.c_int]),
     ("mjh_load_mjcf_string", Model_p, [C.c_char_p]),
     ("mjh_load_mjcf_file", Model_p, [C.c_char_p]),
+    ("mjh_load_mjcf_files", Model_p, [C.POINTER(C.c_char_p), C.c_int]),
     ("mjh_load_note", C.c_char_p, []),
     ("mjh_load_set_bounds", None, [C.c_double, C.c_double]),
     ("mjh_scene_s24", Model_p, []),

@@ -194,9 +194,13 @@ struct Loader {
     }
     return true;
   }
-  mjh_model* run(const Node& root) {
-    if (root.tag != "mujoco") { mjh_set_error("root element must be <mujoco>"); return nullptr; }
-    b = mjh_builder_create();
+  // One model from several files, the way the reference composes a world file and robot files (MjSim::init,
+  // mj_sim.cpp:573-710): every file contributes its <worldbody>, <contact>, <equality> under its own <compiler> and
+  // <default> settings; <option> is taken from the first file (the world) only.
+  bool add(const Node& root, bool first) {
+    if (root.tag != "mujoco") { mjh_set_error("root element must be <mujoco>"); return false; }
+    if (first) b = mjh_builder_create();
+    degree = true; autolimits = false; def = Defaults();
     mjh_option o; mjh_builder_get_option(b, &o);
     // first pass: compiler / option / default (they may appear after worldbody in a file)
     for (auto& c : root.kids) {
@@ -239,32 +243,40 @@ struct Loader {
         }
       }
     }
-    mjh_builder_set_option(b, &o);
-    for (auto& c : root.kids) if (c->tag == "worldbody") if (!children(*c, 0)) { mjh_builder_destroy(b); return nullptr; }
+    if (first) mjh_builder_set_option(b, &o);
+    for (auto& c : root.kids) if (c->tag == "worldbody") if (!children(*c, 0)) return false;
     for (auto& c : root.kids) {
       if (c->tag == "contact") {
         for (auto& e : c->kids) if (e->tag == "exclude") {
           auto i1 = body_id.find(e->get("body1") ? e->get("body1") : ""), i2 = body_id.find(e->get("body2") ? e->get("body2") : "");
-          if (i1 == body_id.end() || i2 == body_id.end()) { mjh_set_error("<exclude> names an unknown body"); mjh_builder_destroy(b); return nullptr; }
+          if (i1 == body_id.end() || i2 == body_id.end()) { mjh_set_error("<exclude> names an unknown body"); return false; }
           mjh_builder_add_exclude(b, i1->second, i2->second);
         }
       } else if (c->tag == "equality") {
         for (auto& e : c->kids) {
           if (e->tag != "joint") { note += "ignored <equality><" + e->tag + ">; "; continue; }
           auto j1 = joint_id.find(e->get("joint1") ? e->get("joint1") : "");
-          if (j1 == joint_id.end()) { mjh_set_error("<equality><joint> names an unknown joint1"); mjh_builder_destroy(b); return nullptr; }
+          if (j1 == joint_id.end()) { mjh_set_error("<equality><joint> names an unknown joint1"); return false; }
           int j2 = -1;
-          if (e->get("joint2")) { auto it = joint_id.find(e->get("joint2")); if (it == joint_id.end()) { mjh_set_error("unknown joint2"); mjh_builder_destroy(b); return nullptr; } j2 = it->second; }
+          if (e->get("joint2")) { auto it = joint_id.find(e->get("joint2")); if (it == joint_id.end()) { mjh_set_error("unknown joint2"); return false; } j2 = it->second; }
           double poly[5] = {0, 1, 0, 0, 0}, t5[5]; int np = nums(e->get("polycoef"), t5, 5); for (int i = 0; i < np; i++) poly[i] = t5[i];
           mjh_builder_add_eq_joint(b, j1->second, j2, poly);
         }
       } else if (c->tag != "compiler" && c->tag != "option" && c->tag != "default" && c->tag != "worldbody" && c->tag != "asset" && c->tag != "visual" && c->tag != "size" && c->tag != "statistic")
         note += "ignored <" + c->tag + ">; ";
     }
+    return true;
+  }
+  mjh_model* finish() {
     mjh_builder_set_bounds(b, std::max(bmass, g_boundmass), std::max(binertia, g_boundinertia));
     mjh_model* m = mjh_builder_compile(b);
-    mjh_builder_destroy(b);
+    mjh_builder_destroy(b); b = nullptr;
     return m;
+  }
+  void abort() { if (b) mjh_builder_destroy(b); b = nullptr; }
+  mjh_model* run(const Node& root) {
+    if (!add(root, true)) { abort(); return nullptr; }
+    return finish();
   }
 };
 
@@ -288,6 +300,24 @@ extern "C" mjh_model* mjh_load_mjcf_file(const char* path) {
   if (!f) { mjh_set_error(std::string("cannot open ") + (path ? path : "(null)")); return nullptr; }
   std::stringstream ss; ss << f.rdbuf();
   return mjh_load_mjcf_string(ss.str().c_str());
+}
+extern "C" mjh_model* mjh_load_mjcf_files(const char* const* paths, int n) {
+  g_note.clear();
+  if (!paths || n <= 0) { mjh_set_error("mjh_load_mjcf_files: no files"); return nullptr; }
+  Loader L;
+  for (int i = 0; i < n; i++) {
+    std::ifstream f(paths[i] ? paths[i] : "");
+    if (!f) { mjh_set_error(std::string("cannot open ") + (paths[i] ? paths[i] : "(null)")); L.abort(); return nullptr; }
+    std::stringstream ss; ss << f.rdbuf();
+    const std::string text = ss.str();
+    Xml x{text.c_str(), text.c_str() + text.size(), {}};
+    auto root = x.element();
+    if (!root) { mjh_set_error(std::string("MJCF parse error in ") + paths[i] + ": " + (x.err.empty() ? std::string("no root element") : x.err)); L.abort(); return nullptr; }
+    if (!L.add(*root, i == 0)) { L.abort(); return nullptr; }
+  }
+  mjh_model* m = L.finish();
+  g_note = L.note;
+  return m;
 }
 extern "C" const char* mjh_load_note(void) { return g_note.c_str(); }
 extern "C" void mjh_load_set_bounds(double boundmass, double boundinertia) { g_boundmass = boundmass; g_boundinertia = boundinertia; }

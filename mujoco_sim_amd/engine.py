@@ -55,10 +55,14 @@ class Model:
         return out
 
 
-def load_mjcf(xml=None, path=None):
-    """MJCF-subset loader (mj_loadXML boundary, mj_util.h:185-193)"""
+def load_mjcf(xml=None, path=None, paths=None):
+    """MJCF-subset loader (mj_loadXML boundary, mj_util.h:185-193); `paths`: world file + robot files composed into one model"""
     lib = capi.load()
-    ptr = lib.mjh_load_mjcf_file(path.encode()) if path else lib.mjh_load_mjcf_string(xml.encode())
+    if paths:
+        arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        ptr = lib.mjh_load_mjcf_files(arr, len(paths))
+    else:
+        ptr = lib.mjh_load_mjcf_file(path.encode()) if path else lib.mjh_load_mjcf_string(xml.encode())
     m = Model(ptr, lib)
     m.note = lib.mjh_load_note().decode()
     return m

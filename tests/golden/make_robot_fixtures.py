@@ -21,7 +21,10 @@ from helpers import save_model_tables  # noqa: E402
 REF = "/root/reference/model/test"
 # name -> (file under model/test, contact capacity: LDS budget; the meshes are skipped anyway)
 ROBOTS = {"pr2": ("pr2/pr2.xml", 16), "tiago": ("tiago/tiago.xml", 40), "hsrb4s": ("hsrb4s/hsrb4s.xml", 8),
-          "ridgeback_panda": ("ridgeback_panda/ridgeback_panda.xml", 32)}
+          "ridgeback_panda": ("ridgeback_panda/ridgeback_panda.xml", 32),
+          # composed with the reference's world file (floor plane, condim 4) the way MjSim::init composes them: the robot
+          # stands on its wheels / casters (plane-cylinder, plane-sphere, plane-box contacts)
+          "pr2_world": ("../world/empty.xml+pr2/pr2.xml", 48), "hsrb4s_world": ("../world/empty.xml+hsrb4s/hsrb4s.xml", 24)}
 STEPS = 300
 KEEP = (1, 10, 50, 100, 200, 300)
 
@@ -41,7 +44,7 @@ def main():
     # the reference writes boundmass = boundinertia = 1e-6 into every file before mj_loadXML (mj_sim.cpp:584-590)
     ms.capi.load().mjh_load_set_bounds(1e-6, 1e-6)
     for name, (rel, cap) in ROBOTS.items():
-        m = ms.load_mjcf(path=os.path.join(REF, rel))
+        m = ms.load_mjcf(paths=[os.path.join(REF, r) for r in rel.split("+")])
         m.c.maxcon = cap; m.c.maxefc = 6 * cap + m.neq + 2 * m.njnt + m.nv
         d = orc.OrcData(m.ptr)
         ctrl = np.zeros(m.nv, dtype=np.int32)

@@ -529,7 +529,7 @@ def test_cohort_streams_do_not_change_results():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["pr2", "tiago", "hsrb4s", "ridgeback_panda"])
+@pytest.mark.parametrize("name", ["pr2", "tiago", "hsrb4s", "ridgeback_panda", "pr2_world", "hsrb4s_world"])
 def test_reference_robot_models_match_oracle(name):
     """C4-type articulated models (the reference's pr2 / tiago / hsrb4s test assets, compiled to table fixtures by
     tests/golden/make_robot_fixtures.py; meshes skipped): 32-49 dof single trees with equality constraints, joint

@@ -11,9 +11,10 @@ import orc
 from conftest import ROOT
 from helpers import load_model_tables
 
-ROBOTS = ["pr2", "tiago", "hsrb4s", "ridgeback_panda"]
+ROBOTS = ["pr2", "tiago", "hsrb4s", "ridgeback_panda", "pr2_world", "hsrb4s_world"]
 FILES = {"pr2": "pr2/pr2.xml", "tiago": "tiago/tiago.xml", "hsrb4s": "hsrb4s/hsrb4s.xml",
-         "ridgeback_panda": "ridgeback_panda/ridgeback_panda.xml"}
+         "ridgeback_panda": "ridgeback_panda/ridgeback_panda.xml",
+         "pr2_world": "../world/empty.xml+pr2/pr2.xml", "hsrb4s_world": "../world/empty.xml+hsrb4s/hsrb4s.xml"}
 KEEP = (1, 10, 50, 100, 200, 300)
 REF = "/root/reference/model/test"
 
@@ -31,6 +32,8 @@ def robot_command(m, k):
 def test_oracle_reproduces_robot_golden(lib, name):
     m, z = load_model_tables(os.path.join(ROOT, "tests", "golden", f"robot_{name}.npz"))
     assert m.ntree == 1 and m.nv >= 20
+    if name.endswith("_world"):
+        assert m.array("geom_type")[0] == 0 and m.array("geom_condim")[0] == 4      # the world file's floor plane
     d = orc.OrcData(m.ptr)
     d.ifield("controlled")[:] = z["controlled"]
     for k in range(1, 101):
@@ -52,7 +55,7 @@ def test_loader_still_produces_the_fixture_tables(lib, name):
     from mujoco_sim_amd import capi
     lib.mjh_load_set_bounds(1e-6, 1e-6)      # as the reference does before mj_loadXML (mj_sim.cpp:584-590)
     try:
-        m = ms.load_mjcf(path=os.path.join(REF, FILES[name]))
+        m = ms.load_mjcf(paths=[os.path.join(REF, r) for r in FILES[name].split("+")])
     finally:
         lib.mjh_load_set_bounds(0.0, 0.0)
     f, z = load_model_tables(os.path.join(ROOT, "tests", "golden", f"robot_{name}.npz"))
