@@ -109,3 +109,51 @@ def test_reference_pendulum_xml_equals_the_restated_scene(lib):
                  "body_invweight0", "dof_invweight0"):
         np.testing.assert_allclose(a.array(name), b.array(name), rtol=1e-12, atol=1e-14, err_msg=name)
     assert a.opt.timestep == b.opt.timestep and a.opt.gravity[2] == b.opt.gravity[2] == -0.1
+
+
+WORLD = """<mujoco>
+  <option timestep="0.004" gravity="0 0 -9.81"/>
+  <worldbody><geom name="floor" type="plane" size="0 0 .05" condim="4" friction="2 0.05 0.01"/></worldbody>
+</mujoco>"""
+CART = """<mujoco model="cart">
+  <compiler angle="radian"/>
+  <option timestep="0.001"/>
+  <default><geom friction="0.7 0.005 0.0001"/></default>
+  <worldbody>
+    <body name="cart" pos="0 0 0.06">
+      <freejoint name="cart_free"/>
+      <geom name="chassis" type="box" size=".2 .1 .02"/>
+      <body name="frame" pos="0 0 0.05"><joint name="tilt" axis="0 1 0" limited="true" range="-1 1"/></body>
+      <body name="wheel_l" pos="0 .12 0" quat="0.7071068 0.7071068 0 0"><joint name="wl" axis="0 0 1"/><geom type="cylinder" size=".06 .01"/></body>
+      <body name="wheel_r" pos="0 -.12 0" quat="0.7071068 0.7071068 0 0"><joint name="wr" axis="0 0 1"/><geom type="cylinder" size=".06 .01"/></body>
+    </body>
+  </worldbody>
+</mujoco>"""
+
+
+def test_world_plus_robot_composition_and_bounds(lib, tmp_path):
+    """mjh_load_mjcf_files: <option> from the first (world) file, <compiler>/<default> per file, bodies of every file in one
+    model; mjh_load_set_bounds: the reference's boundmass / boundinertia floor makes the massless frame body admissible."""
+    w = tmp_path / "world.xml"; w.write_text(WORLD)
+    c = tmp_path / "cart.xml"; c.write_text(CART)
+    with pytest.raises(Exception, match="positive definite"):
+        ms.load_mjcf(paths=[str(w), str(c)])                       # massless moving body
+    lib.mjh_load_set_bounds(1e-6, 1e-6)
+    try:
+        m = ms.load_mjcf(paths=[str(w), str(c)])
+    finally:
+        lib.mjh_load_set_bounds(0.0, 0.0)
+    assert m.opt.timestep == 0.004                                  # the world file's option wins
+    assert (m.nbody, m.njnt, m.nv, m.ngeom) == (5, 4, 9, 4)
+    assert m.array("geom_type").tolist() == [0, 6, 5, 5] and m.array("geom_condim")[0] == 4
+    np.testing.assert_allclose(m.array("geom_friction").reshape(-1, 3)[1], [0.7, 0.005, 0.0001])   # the cart file's default
+    np.testing.assert_allclose(m.array("geom_friction").reshape(-1, 3)[0], [2, 0.05, 0.01])
+    assert m.array("jnt_limited").tolist() == [0, 1, 0, 0]
+    np.testing.assert_allclose(m.array("jnt_range")[2:4], [-1, 1])      # radians (the cart file's <compiler>)
+    bm = m.array("body_mass"); assert bm[m.name2id(0, "frame")] == 1e-6
+    # plane-cylinder + plane-box pairs are in the pair list; the cart settles on its wheels in the oracle
+    pairs = set(zip(m.array("pair_geom1").tolist(), m.array("pair_geom2").tolist()))
+    assert {(0, 1), (0, 2), (0, 3)} <= pairs
+    d = orc.OrcData(m.ptr)
+    d.step(600)
+    assert d.i("ncon") >= 4 and np.abs(d.f("qvel")).max() < 0.05 and abs(d.f("qpos")[2] - 0.06) < 5e-3
