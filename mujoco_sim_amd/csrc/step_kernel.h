@@ -212,6 +212,92 @@ DEV float pgs_dual(const float R, const float lo, const float hi, const float* a
   return imp;
 }
 
+// ---- many-body sweep (nv > 64 or pools in global memory): the running acceleration lives in LDS (c.qacc), lanes = the
+// compact dofs of ONE block (at most 64: rowW), gathered before and scattered after the block's update; the block's
+// operands come from the pools and are prefetched one block ahead.  Shared by the fused step kernel and mjh_solve_kernel.
+struct ManyCtx {
+  const float *J, *B, *blkq, *ext; float* blkf; const int *blki, *order;
+  float* qacc; const float* qLDinv;
+  int nblk, nfixblk, rowW, iterations; bool has_dim4; float scale, tolerance;
+};
+template <bool DIAGM>
+DEV int pgs_many_body(const ManyCtx& c, const int lane) {
+  int niter = 0;
+  // operands of one block; every address follows from the block index alone (contact blocks are laid out
+  // regularly behind the c.nfixblk non-contact ones), so all loads of block k+1 are in flight while block k is solved
+  struct MOp { int4 hd; int b; float4 J, B, p0, r0, r1, r2, A0, A1, A2, A3, X0, X1, X2; };
+  auto blockAt = [&](int k) __attribute__((always_inline)) { return c.nblk > 64 ? k : c.order[k]; };   // beyond 64 blocks: plain order
+  auto fetch8 = [&](int b) __attribute__((always_inline)) {
+    MOp op; op.b = b; op.hd = ((const int4*)c.blki)[b];
+    const bool quad = b >= c.nfixblk;
+    const int jo = (quad ? c.nfixblk + 4 * (b - c.nfixblk) : b) * c.rowW;      // = BLK_JOFF(hd.x), see put_block
+    op.J = make_float4(0, 0, 0, 0); op.B = op.J;
+    if (lane < c.rowW) {                                                  // dofs beyond the block's trees hold zeros
+      if (quad) op.J = *(const float4*)(c.J + jo + 4*lane); else op.J.x = c.J[jo + lane];
+      if (!DIAGM) { if (quad) op.B = *(const float4*)(c.B + jo + 4*lane); else op.B.x = c.B[jo + lane]; }
+    }
+    op.p0 = ((const float4*)c.blkf)[4*b]; op.r0 = ((const float4*)c.blkf)[4*b+1]; op.r1 = ((const float4*)c.blkf)[4*b+2]; op.r2 = ((const float4*)c.blkf)[4*b+3];
+    op.A0 = ((const float4*)c.blkq)[4*b]; op.A1 = ((const float4*)c.blkq)[4*b+1]; op.A2 = ((const float4*)c.blkq)[4*b+2]; op.A3 = ((const float4*)c.blkq)[4*b+3];
+    op.X0 = make_float4(0, 0, 0, 0); op.X1 = op.X0; op.X2 = op.X0;
+    if (c.has_dim4) { const float4* x4 = (const float4*)(c.ext + b * SOLX_N); op.X0 = x4[0]; op.X1 = x4[1]; op.X2 = x4[2]; }
+    return op;
+  };
+  auto process8 = [&](MOp& op, float& improvement) __attribute__((always_inline)) {
+    KEEP4(op.hd); KEEP4(op.J); KEEP4(op.p0); KEEP4(op.r0); KEEP4(op.r1); KEEP4(op.r2); KEEP4(op.A0); KEEP4(op.A1); KEEP4(op.A2); KEEP4(op.A3);
+    if (!DIAGM) KEEP4(op.B);
+    if (c.has_dim4) { KEEP4(op.X0); KEEP4(op.X1); KEEP4(op.X2); }
+    ROW_TREES(op.hd.z, op.hd.w);
+    const bool on = lane < n1 + n2;
+    const int d = lane < n1 ? a1 + lane : a2 + lane - n1;
+    float ak = on ? c.qacc[d] : 0.0f;                                    // gather
+    const int kind = __builtin_amdgcn_readfirstlane(op.hd.x & 15);
+    float f[6] = {op.r1.x, op.r1.y, op.r1.z, op.r1.w, op.r2.x, op.r2.y};
+    const float aref[4] = {op.r0.x, op.r0.y, op.r0.z, op.r0.w};
+    const float Q[16] = {op.A0.x, op.A0.y, op.A0.z, op.A0.w, op.A1.x, op.A1.y, op.A1.z, op.A1.w,
+                         op.A2.x, op.A2.y, op.A2.z, op.A2.w, op.A3.x, op.A3.y, op.A3.z, op.A3.w};
+    const float X[12] = {op.X0.x, op.X0.y, op.X0.z, op.X0.w, op.X1.x, op.X1.y, op.X1.z, op.X1.w, op.X2.x, op.X2.y, op.X2.z, op.X2.w};
+    const float Jd[4] = {on ? op.J.x : 0.0f, on ? op.J.y : 0.0f, on ? op.J.z : 0.0f, on ? op.J.w : 0.0f};
+    const float Bd[4] = {on ? op.B.x : 0.0f, on ? op.B.y : 0.0f, on ? op.B.z : 0.0f, on ? op.B.w : 0.0f};
+    const float* Bp = DIAGM ? Jd : Bd;
+    const float bs = DIAGM ? (on ? c.qLDinv[d] : 0.0f) : 1.0f;
+    const float R = op.p0.x, lo = op.r2.z, hi = op.r2.w;
+    if (kind == BK_PYR4) pgs_block<4, 6, 8>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
+    else if (kind == BK_PYR3) pgs_block<3, 4, 8>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
+    else pgs_block<1, 1, 8>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
+    if (on) c.qacc[d] = ak;                                              // scatter
+    if (lane == 0) {
+      float* bf = c.blkf + op.b * BLKF_STRIDE + BF_F;
+      *(float4*)(bf) = make_float4(f[0], f[1], f[2], f[3]);
+      *(float2*)(bf + 4) = make_float2(f[4], f[5]);
+    }
+  };
+  if (c.nblk < 3) {
+    // (the prefetch would read the forces of a block before its pending update is stored)
+    for (int it = 0; it < c.iterations; it++) {
+      float improvement = 0;
+      for (int k = 0; k < c.nblk; k++) { MOp op = fetch8(blockAt(k)); process8(op, improvement); __syncthreads(); }
+      niter = it + 1;
+      if (improvement * c.scale < c.tolerance) break;
+    }
+  } else {
+    MOp opA = fetch8(blockAt(0)), opB;
+    for (int it = 0; it < c.iterations; it++) {
+      float improvement = 0;
+      for (int k = 0; k < c.nblk; k += 2) {
+        opB = fetch8(blockAt(k + 1 < c.nblk ? k + 1 : 0));
+        process8(opA, improvement);
+        if (k + 1 < c.nblk) {
+          opA = fetch8(blockAt(k + 2 < c.nblk ? k + 2 : 0));
+          process8(opB, improvement);
+        } else opA = opB;                  // odd block count: block 0 of the next sweep was loaded into B
+      }
+      niter = it + 1;
+      if (improvement * c.scale < c.tolerance) break;
+    }
+  }
+  return niter;
+}
+
 template <int NROW, bool DIAGM>
 __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restrict__ C, const DState S, int env0, int nsteps, int ph, int xflags) {
   // model descriptor + LDS layout live in device memory (uploaded once): uniform scalar loads on demand instead
@@ -1171,78 +1257,13 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           //          from the global pools and are prefetched one block ahead.
           for (int d = lane; d < nv; d += 64) s_qacc[d] = s_asmooth[d] + s_tmpv[d];
           WSYNC();
-          nfixblk = __builtin_amdgcn_readfirstlane(nfixblk);
-          // operands of one block; every address follows from the block index alone (contact blocks are laid out
-          // regularly behind the nfixblk non-contact ones), so all loads of block k+1 are in flight while block k is solved
-          struct MOp { int4 hd; int b; float4 J, B, p0, r0, r1, r2, A0, A1, A2, A3, X0, X1, X2; };
-          auto blockAt = [&](int k) __attribute__((always_inline)) { return nblk > 64 ? k : s_order_i[k]; };   // beyond 64 blocks: plain order
-          auto fetch8 = [&](int b) __attribute__((always_inline)) {
-            MOp op; op.b = b; op.hd = blki4[b];
-            const bool quad = b >= nfixblk;
-            const int jo = (quad ? nfixblk + 4 * (b - nfixblk) : b) * rowW;      // = BLK_JOFF(hd.x), see put_block
-            op.J = make_float4(0, 0, 0, 0); op.B = op.J;
-            if (lane < rowW) {                                                  // dofs beyond the block's trees hold zeros
-              if (quad) op.J = *(const float4*)(s_J + jo + 4*lane); else op.J.x = s_J[jo + lane];
-              if (!DIAGM) { if (quad) op.B = *(const float4*)(s_B + jo + 4*lane); else op.B.x = s_B[jo + lane]; }
-            }
-            op.p0 = blkf4[4*b]; op.r0 = blkf4[4*b+1]; op.r1 = blkf4[4*b+2]; op.r2 = blkf4[4*b+3];
-            op.A0 = blkq4[4*b]; op.A1 = blkq4[4*b+1]; op.A2 = blkq4[4*b+2]; op.A3 = blkq4[4*b+3];
-            op.X0 = make_float4(0, 0, 0, 0); op.X1 = op.X0; op.X2 = op.X0;
-            if (has_dim4) { const float4* x4 = (const float4*)(s_ext + b * SOLX_N); op.X0 = x4[0]; op.X1 = x4[1]; op.X2 = x4[2]; }
-            return op;
-          };
-          auto process8 = [&](MOp& op, float& improvement) __attribute__((always_inline)) {
-            KEEP4(op.hd); KEEP4(op.J); KEEP4(op.p0); KEEP4(op.r0); KEEP4(op.r1); KEEP4(op.r2); KEEP4(op.A0); KEEP4(op.A1); KEEP4(op.A2); KEEP4(op.A3);
-            if (!DIAGM) KEEP4(op.B);
-            if (has_dim4) { KEEP4(op.X0); KEEP4(op.X1); KEEP4(op.X2); }
-            ROW_TREES(op.hd.z, op.hd.w);
-            const bool on = lane < n1 + n2;
-            const int d = lane < n1 ? a1 + lane : a2 + lane - n1;
-            float ak = on ? s_qacc[d] : 0.0f;                                    // gather
-            const int kind = __builtin_amdgcn_readfirstlane(op.hd.x & 15);
-            float f[6] = {op.r1.x, op.r1.y, op.r1.z, op.r1.w, op.r2.x, op.r2.y};
-            const float aref[4] = {op.r0.x, op.r0.y, op.r0.z, op.r0.w};
-            const float Q[16] = {op.A0.x, op.A0.y, op.A0.z, op.A0.w, op.A1.x, op.A1.y, op.A1.z, op.A1.w,
-                                 op.A2.x, op.A2.y, op.A2.z, op.A2.w, op.A3.x, op.A3.y, op.A3.z, op.A3.w};
-            const float X[12] = {op.X0.x, op.X0.y, op.X0.z, op.X0.w, op.X1.x, op.X1.y, op.X1.z, op.X1.w, op.X2.x, op.X2.y, op.X2.z, op.X2.w};
-            const float Jd[4] = {on ? op.J.x : 0.0f, on ? op.J.y : 0.0f, on ? op.J.z : 0.0f, on ? op.J.w : 0.0f};
-            const float Bd[4] = {on ? op.B.x : 0.0f, on ? op.B.y : 0.0f, on ? op.B.z : 0.0f, on ? op.B.w : 0.0f};
-            const float* Bp = DIAGM ? Jd : Bd;
-            const float bs = DIAGM ? (on ? s_qLDinv[d] : 0.0f) : 1.0f;
-            const float R = op.p0.x, lo = op.r2.z, hi = op.r2.w;
-            if (kind == BK_PYR4) pgs_block<4, 6, NROW>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
-            else if (kind == BK_PYR3) pgs_block<3, 4, NROW>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
-            else pgs_block<1, 1, NROW>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
-            if (on) s_qacc[d] = ak;                                              // scatter
-            if (lane == 0) {
-              float* bf = s_blkf + op.b * BLKF_STRIDE + BF_F;
-              *(float4*)(bf) = make_float4(f[0], f[1], f[2], f[3]);
-              *(float2*)(bf + 4) = make_float2(f[4], f[5]);
-            }
-          };
-          if (nblk < 3) {
-            // (the prefetch would read the forces of a block before its pending update is stored)
-            for (int it = 0; it < M.iterations; it++) {
-              float improvement = 0;
-              for (int k = 0; k < nblk; k++) { MOp op = fetch8(blockAt(k)); process8(op, improvement); WSYNC(); }
-              niter = it + 1;
-              if (improvement * scale < M.tolerance) break;
-            }
-          } else {
-            MOp opA = fetch8(blockAt(0)), opB;
-            for (int it = 0; it < M.iterations; it++) {
-              float improvement = 0;
-              for (int k = 0; k < nblk; k += 2) {
-                opB = fetch8(blockAt(k + 1 < nblk ? k + 1 : 0));
-                process8(opA, improvement);
-                if (k + 1 < nblk) {
-                  opA = fetch8(blockAt(k + 2 < nblk ? k + 2 : 0));
-                  process8(opB, improvement);
-                } else opA = opB;                  // odd block count: block 0 of the next sweep was loaded into B
-              }
-              niter = it + 1;
-              if (improvement * scale < M.tolerance) break;
-            }
+          {
+            ManyCtx mc;
+            mc.J = s_J; mc.B = s_B; mc.blkf = s_blkf; mc.blkq = s_blkq; mc.ext = s_ext; mc.blki = s_blki_i; mc.order = s_order_i;
+            mc.qacc = s_qacc; mc.qLDinv = s_qLDinv;
+            mc.nblk = nblk; mc.nfixblk = __builtin_amdgcn_readfirstlane(nfixblk); mc.rowW = rowW; mc.iterations = M.iterations;
+            mc.has_dim4 = has_dim4; mc.scale = scale; mc.tolerance = M.tolerance;
+            niter = pgs_many_body<DIAGM>(mc, lane);
           }
           WSYNC();
           for (int d = lane; d < nv; d += 64) s_ws[d] = s_qacc[d];
