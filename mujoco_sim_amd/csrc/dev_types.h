@@ -70,12 +70,18 @@ struct Lay {
   MJH_LDS_ARRAYS(X)
 #undef X
   int total;  // floats
+  // many-body layout, three-launch step: float offsets into the env's global scratch slice of the hand-over vectors
+  // (initial acceleration, 1/M_dd, velocity after the controller, smooth force, solved acceleration) and of 8 ints of
+  // meta data (nblk, nfixblk, nefc, ncon, flags, solver iterations)
+  int g_a0, g_minv, g_qvel, g_smooth, g_qacc, g_meta;
 };
 
 struct DConst { DModel M; Lay L; };
 
 // kernel phases
-enum { PH_STEP1 = 1, PH_INV = 2, PH_STEP2 = 4, PH_NOINT = 8, PH_FKONLY = 16, PH_MULM = 32, PH_RESET = 64 };
+enum { PH_STEP1 = 1, PH_INV = 2, PH_STEP2 = 4, PH_NOINT = 8, PH_FKONLY = 16, PH_MULM = 32, PH_RESET = 64,
+       // many-body layout only: the fused step as three launches  assemble (PH_PRE) -> mjh_solve_kernel -> integrate (PH_POST)
+       PH_PRE = 128, PH_POST = 256 };
 // export flags
 enum { XF_BODY = 1, XF_GEOM = 2, XF_CON = 4, XF_FORCE = 8, XF_PROF = 16 };
 

@@ -42,6 +42,7 @@ struct mjh_engine {
   float* p_tables[MJH_EP_COUNT] = {nullptr};
   int* d_order = nullptr;   // LPT launch order (mjh_order_kernel)
   bool lpt = true;
+  bool split3 = true;         // many-body layout: three-launch step (MJH_SPLIT3=0: fused kernel)
   bool order_valid = false;   // d_order holds a full-range permutation (split API); mjh_step sorts per cohort
   // Cohorts: mjh_step() splits the envs into ncohort contiguous groups, each stepped on its own stream, so that the
   // low-occupancy tail of one cohort's step kernel overlaps the next cohort's (or its own next step's) bulk.  The
@@ -268,6 +269,10 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       L.J = put((int)jsz); L.B = diagM ? L.J : put((int)jsz);
     }
     L.zero = put(4);
+    if (big) {   // hand-over vectors of the three-launch step (non-negative offsets into the scratch slice)
+      auto graw = [&](int n) { long long o = goff; goff += ((std::max(n, 1) + 3) / 4) * 4; return (int)o; };
+      L.g_a0 = graw(nv); L.g_minv = graw(nv); L.g_qvel = graw(nv); L.g_smooth = graw(nv); L.g_qacc = graw(nv); L.g_meta = graw(8);
+    }
     hp.gstride = goff;
     L.total = off;
     hp.lds_bytes = off * (int)sizeof(float);
@@ -301,6 +306,7 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   HIPCHK(hipSetDevice(device));
   mjh_engine* e = new mjh_engine();
   if (const char* v = getenv("MJH_LPT")) e->lpt = atoi(v) != 0;
+  if (const char* v = getenv("MJH_SPLIT3")) e->split3 = atoi(v) != 0;
   e->model = m; e->nenv = nenv; e->device = device; e->stream = (hipStream_t)stream;
 
   HostPack hp; derive_fitting(m, hp);
@@ -430,7 +436,18 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
         ta = e->tev[e->tev_used].first; tb = e->tev[e->tev_used].second; e->tev_used++;
         HIPCHK(hipEventRecord(ta, st));
       }
-      rc = launch_on(e, st, g0, g1 - g0, 1, ph, 0);
+      if (e->M.big && e->split3) {
+        // many-body layout: assemble -> solve (3 KB of LDS per env instead of ~70 KB: many more resident envs during the
+        // sweeps, which are > 90 % of such a step) -> integrate
+        rc = launch_on(e, st, g0, g1 - g0, 1, ph | PH_PRE, 0);
+        if (!rc) {
+          const size_t lds = 2 * (size_t)(((e->M.nv + 3) / 4) * 4) * sizeof(float);
+          if (e->M.diagM) hipLaunchKernelGGL((mjh_solve_kernel<true>), dim3(g1 - g0), dim3(64), lds, st, e->dC, e->S, g0);
+          else hipLaunchKernelGGL((mjh_solve_kernel<false>), dim3(g1 - g0), dim3(64), lds, st, e->dC, e->S, g0);
+          HIPCHK(hipGetLastError());
+          rc = launch_on(e, st, g0, g1 - g0, 1, PH_STEP2 | PH_POST, 0);
+        }
+      } else rc = launch_on(e, st, g0, g1 - g0, 1, ph, 0);
       if (ta && !rc) HIPCHK(hipEventRecord(tb, st));
     }
   }

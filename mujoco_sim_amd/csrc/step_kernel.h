@@ -364,6 +364,10 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   for (int i = lane; i < ngeom; i += 64) s_p_rbound[i] = S.p_geom_rbound ? S.p_geom_rbound[(size_t)env * ngeom + i] : geom_rbound[i];
   for (int i = lane; i < nbody; i += 64) s_p_mass[i] = S.p_body_mass ? S.p_body_mass[(size_t)env * nbody + i] : body_mass[i];
   for (int i = lane; i < 3 * nbody; i += 64) s_p_inertia[i] = S.p_body_inertia ? S.p_body_inertia[(size_t)env * 3 * nbody + i] : body_inertia[i];
+  // many-body layout, three-launch step (engine.hip): PH_PRE stops in front of the solver sweeps and hands over through the
+  // env's scratch slice; PH_POST skips everything between the factorisation and the end of the sweeps
+  const bool pre = NROW == 8 && (ph & PH_PRE), post = NROW == 8 && (ph & PH_POST);
+  if (post) for (int i = lane; i < nv; i += 64) s_qvel[i] = gs[L.g_qvel + i];     // (the controller may have overridden velocities)
   float time = S.time[env];
   // spawn/destroy as slot toggling: bit b set = body b is an INACTIVE slot in this env
   const unsigned slotmask = S.slot_mask ? (unsigned)__builtin_amdgcn_readfirstlane((int)S.slot_mask[env]) : 0u;
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
     PROF(4);
     // ---- collision (mj_collision): lanes = candidate geom pairs of the static pair list
     ncon = 0;
-    if (!(M.disableflags & (MJH_DSBL_CONTACT | MJH_DSBL_CONSTRAINT))) {
+    if (!post && !(M.disableflags & (MJH_DSBL_CONTACT | MJH_DSBL_CONSTRAINT))) {
       int conbase = 0;
       for (int base = 0; base < M.npair; base += 64) {
         const int ip = base + lane;
@@ -637,7 +641,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
     //      pyramid rows of a contact, which are all  J_n +- mu_k J_k  over nbase = dim base rows.
     nefc = 0;
     int nblk = 0, nbrow = 0, nfixblk = 0;   // nfixblk: number of non-contact blocks (they come first)
-    if (!(M.disableflags & MJH_DSBL_CONSTRAINT)) {
+    if (!post && !(M.disableflags & MJH_DSBL_CONSTRAINT)) {
       // non-contact blocks come first and own one row of rowW floats each; contact block c owns 4*rowW floats
       auto put_block = [&](int b, int kind, int nrows, int nb, int clamp, int joff4, int id, int rtype, int side) __attribute__((always_inline)) {
         int* hd = s_blki_i + b * BLKI_STRIDE;
@@ -868,6 +872,11 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
     }
     WSYNC();
     PROF(8);
+    if (post) {   // the blocks were built by the PH_PRE launch and live in the pools
+      const int* meta = (const int*)(gs + L.g_meta);
+      nblk = __builtin_amdgcn_readfirstlane(meta[0]); nfixblk = __builtin_amdgcn_readfirstlane(meta[1]);
+      nefc = __builtin_amdgcn_readfirstlane(meta[2]); ncon = __builtin_amdgcn_readfirstlane(meta[3]); flags |= __builtin_amdgcn_readfirstlane(meta[4]);
+    }
 
     // dot products of every base row with a dof-space vector: out[4b+j] = J[b][.][j] . vec   (lanes = (block, base))
     auto base_dots = [&](const float* vec, float* out) __attribute__((always_inline)) {
@@ -1094,7 +1103,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       }
       WSYNC();
       if ((ph & PH_INV) && anydq) { vel_stage(s_qvel); for (int d = lane; d < nv; d += 64) s_qvref[d] = s_qvel[d]; WSYNC(); }
-    } else {
+    } else if (!post) {
       // split API: re-create the velocity-stage quantities the previous call left behind
       if (ph & PH_INV) { for (int d = lane; d < nv; d += 64) s_qvref[d] = s_qvel[d]; WSYNC(); }
       vel_stage(s_qvref);
@@ -1117,6 +1126,13 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
     PROF(10);
     // ================================================================ step2 (mj_step2, mj_main.cpp:108)
     if (ph & (PH_STEP2 | PH_NOINT)) {
+      if (post) {
+        const int* meta = (const int*)(gs + L.g_meta);
+        niter = __builtin_amdgcn_readfirstlane(meta[5]);
+        for (int d = lane; d < nv; d += 64) { const float qa = gs[L.g_qacc + d]; s_qacc[d] = qa; s_ws[d] = qa; s_smooth[d] = gs[L.g_smooth + d]; s_asmooth[d] = 0; s_tmpv2[d] = 0; }
+        WSYNC();
+        if (nefc > 0 && (M.has_damping || (xflags & XF_FORCE))) { phi_from_forces(); accum_T(false, s_phi, s_tmpv2); }
+      } else {
       // ---- smooth acceleration (mj_fwdAcceleration)
       for (int d = lane; d < nv; d += 64) { float f = s_passive[d] - s_bias[d] + s_applied[d]; s_smooth[d] = f; s_asmooth[d] = f; }
       WSYNC();
@@ -1125,6 +1141,12 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       WSYNC();
       niter = 0;
       PROF(11);
+      if (pre) {   // hand-over to mjh_solve_kernel / the PH_POST launch
+        int* meta = (int*)(gs + L.g_meta);
+        for (int d = lane; d < nv; d += 64) { gs[L.g_qvel + d] = s_qvel[d]; gs[L.g_smooth + d] = s_smooth[d]; if (nefc == 0) gs[L.g_qacc + d] = s_asmooth[d]; }
+        if (lane == 0) { meta[0] = nefc == 0 ? 0 : nblk; meta[1] = nfixblk; meta[2] = nefc; meta[3] = ncon; meta[4] = flags; meta[5] = 0; }
+        if (nefc == 0) return;
+      }
       if (nefc == 0) {
         for (int d = lane; d < nv; d += 64) { s_qacc[d] = s_asmooth[d]; s_ws[d] = s_asmooth[d]; s_tmpv2[d] = 0; }
         WSYNC();
@@ -1237,6 +1259,10 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         }
         WSYNC();
         PROF(12);
+        if (pre) {   // initial acceleration and 1/M_dd for the stand-alone solver; the blocks are in the pools already
+          for (int d = lane; d < nv; d += 64) { gs[L.g_a0 + d] = s_asmooth[d] + s_tmpv[d]; gs[L.g_minv + d] = s_qLDinv[d]; }
+          return;
+        }
         // ---- PGS (mj_solPGS), matrix-free, one block at a time.  lanes = dofs, running acceleration `a` in a
         //      register.  Per block: u = J_base.a (nbase wave reductions, interleaved); its 2(dim-1) pyramid rows
         //      are then updated with uniform scalar math in contact space:
@@ -1436,6 +1462,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         // qfrc_constraint = J^T f (only needed by the implicit-damping integrator and for export)
         if (M.has_damping || (xflags & XF_FORCE)) { phi_from_forces(); accum_T(false, s_phi, s_tmpv2); }
       }
+      }   // !post
       if (xflags & XF_FORCE) {
         const size_t e = (size_t)xrow * M.nvp;
         for (int d = lane; d < nv; d += 64) { if (S.x_smooth) S.x_smooth[e + d] = s_asmooth[d]; if (S.x_constraint) S.x_constraint[e + d] = s_tmpv2[d]; }
@@ -1542,4 +1569,33 @@ __global__ __launch_bounds__(1024) void mjh_order_kernel(const int* __restrict__
   if (t == 0) { int acc = 0; for (int b = 0; b < 256; b++) { base[b] = acc; acc += hist[b]; } }
   __syncthreads();
   for (int e = t; e < nenv; e += 1024) order[atomicAdd(&base[255 - bucket(e)], 1)] = env0 + e;
+}
+
+// Stand-alone solver of the many-body layout's three-launch step: everything it needs is in the env's scratch slice
+// (pools + hand-over vectors), its LDS footprint is two dof vectors, so many environments are resident per CU while the
+// fused kernel holds ~70 KB per env for the stages around the sweeps.
+template <bool DIAGM>
+__global__ __launch_bounds__(64) void mjh_solve_kernel(const DConst* __restrict__ C, const DState S, int env0) {
+  const DModel& M = C->M;
+  const Lay& L = C->L;
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x, nv = M.nv;
+  const int env = S.env_order ? S.env_order[env0 + blockIdx.x] : env0 + (int)blockIdx.x;
+  float* const gs = S.gscratch + (size_t)env * (size_t)S.gstride;
+  int* meta = (int*)(gs + L.g_meta);
+  const int nblk = __builtin_amdgcn_readfirstlane(meta[0]);
+  if (nblk == 0) return;                                  // unconstrained env: the assemble launch wrote qacc itself
+  float* s_qacc = lds; float* s_minv = lds + ((nv + 3) / 4) * 4;
+  for (int d = lane; d < nv; d += 64) { s_qacc[d] = gs[L.g_a0 + d]; s_minv[d] = gs[L.g_minv + d]; }
+  __syncthreads();
+  ManyCtx mc;
+  mc.J = gs + (-1 - L.J); mc.B = gs + (-1 - L.B); mc.blkf = gs + (-1 - L.blkf); mc.blkq = gs + (-1 - L.blkq); mc.ext = gs + (-1 - L.ext);
+  mc.blki = (const int*)(gs + (-1 - L.blki)); mc.order = (const int*)(gs + (-1 - L.order));
+  mc.qacc = s_qacc; mc.qLDinv = s_minv;
+  mc.nblk = nblk; mc.nfixblk = __builtin_amdgcn_readfirstlane(meta[1]); mc.rowW = M.rowW; mc.iterations = M.iterations;
+  mc.has_dim4 = M.has_dim4 != 0; mc.scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1)); mc.tolerance = M.tolerance;
+  const int niter = pgs_many_body<DIAGM>(mc, lane);
+  __syncthreads();
+  for (int d = lane; d < nv; d += 64) gs[L.g_qacc + d] = s_qacc[d];
+  if (lane == 0) meta[5] = niter;
 }
