@@ -281,6 +281,11 @@ int mjh_debug_stop_at(mjh_engine*, int stage, int with_inverse);
  * stream forks into the cohort streams inside mjh_step and is joined again by the next call of any other
  * entry point, so results and ordering seen through this API do not depend on `n`.  Within a launch the
  * envs are dispatched longest-solver-job first (order rebuilt on the device every step). */
+/* Memory layout of engines created afterwards (process-wide; no reference counterpart).  0 (default): per-env
+ * contact / block / Jacobian pools in LDS while they are small (<= 24 KB per env), otherwise in a per-env slice of global
+ * memory with the step issued as three launches (assemble, solve, integrate); 1: LDS whenever the working set fits one
+ * CU's 160 KiB; 2: global pools whenever possible.  Results do not depend on the layout beyond fp32 rounding. */
+void mjh_set_layout_policy(int policy);
 int mjh_set_cohorts(mjh_engine*, int n);
 int mjh_get_cohorts(const mjh_engine*);
 /* HIP-event timing of every step-kernel launch on the stream it runs on: enable, step, then read the mean

@@ -287,8 +287,9 @@ def _compare_rollout(m, q0, nsteps_list, tols, v0=None, nenv=2):
     return out
 
 
-def test_box_pile_nv48_single_block_sweep(lib):
+def test_box_pile_nv48_single_block_sweep(lib, layout_policy):
     """8 free boxes (nv = 48 > 32): exercises the full-wave single-block PGS sweep (NROW = 4) and box-box stacks"""
+    layout_policy(1)          # keep the pools in LDS (116 KB at full-manifold capacity)
     m = ms.scene("boxpile", 8)
     assert m.nv == 48
     q0 = m.array("qpos0").copy()
@@ -528,9 +529,19 @@ def test_cohort_streams_do_not_change_results():
             assert np.array_equal(a, b)
 
 
+@pytest.fixture
+def layout_policy(lib):
+    """mjh_set_layout_policy for one test, restored to the default afterwards"""
+    def set_policy(p):
+        lib.mjh_set_layout_policy(p)
+    yield set_policy
+    lib.mjh_set_layout_policy(0)
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("layout", [1, 2], ids=["lds-resident", "global-pools"])
 @pytest.mark.parametrize("name", ["pr2", "tiago", "hsrb4s", "ridgeback_panda", "pr2_world", "hsrb4s_world"])
-def test_reference_robot_models_match_oracle(name):
+def test_reference_robot_models_match_oracle(name, layout, layout_policy):
     """C4-type articulated models (the reference's pr2 / tiago / hsrb4s test assets, compiled to table fixtures by
     tests/golden/make_robot_fixtures.py; meshes skipped): 32-49 dof single trees with equality constraints, joint
     limits, friction loss, damping.  nv <= 32 takes the dual-block sweep with general (non-diagonal) M, nv > 32 the
@@ -540,6 +551,7 @@ def test_reference_robot_models_match_oracle(name):
     from test_robot_fixtures import KEEP, robot_command
     m, z = load_model_tables(os.path.join(ROOT, "tests", "golden", f"robot_{name}.npz"))
     nenv = 4
+    layout_policy(layout)     # both memory layouts: pools in LDS (dual / single-block sweeps) and in global memory (three-launch step)
     e = ms.Engine(m, nenv)
     e.set_controlled_dofs(z["controlled"].astype(np.int32))
     d = orc.OrcData(m.ptr); d.ifield("controlled")[:] = z["controlled"]
@@ -661,12 +673,13 @@ def test_forked_export_publishes_without_joining_the_cohorts():
 
 
 @pytest.mark.gpu
-def test_pr2_with_large_capacity_falls_back_to_global_pools(lib):
+def test_pr2_with_large_capacity_falls_back_to_global_pools(lib, layout_policy):
     """A working set beyond one CU's LDS (PR2 at a 128-contact capacity: 49-dof rows) selects the many-body layout:
     pools in per-env global memory, block-at-a-time sweep with M^-1 J^T rows, equality and limit rows.  Same golden."""
     from helpers import load_model_tables
     from test_robot_fixtures import robot_command
     m, z = load_model_tables(os.path.join(ROOT, "tests", "golden", "robot_pr2.npz"))
+    layout_policy(1)                                         # "LDS whenever it fits": at this capacity it does not
     small = lib.mjh_query_lds_bytes(m.ptr)
     m.c.maxcon = 128; m.c.maxefc = 6 * 128 + 200
     assert lib.mjh_query_lds_bytes(m.ptr) < small            # pools left LDS
