@@ -60,7 +60,7 @@ struct DState {
   X(qpos) X(qvel) X(qvref) X(ws) X(qacc) X(smooth) X(asmooth) X(passive) X(bias) X(applied)        \
   X(tmpv) X(tmpv2) X(xpos) X(xquat) X(xmat) X(xipos) X(ximat) X(com) X(cinert) X(crb) X(cvel)      \
   X(cacc) X(cfrc) X(cfrcsub) X(xanchor) X(xaxis) X(cdof) X(cdofdot) X(qM) X(qLD) X(qLDinv)          \
-  X(gpos) X(gmat) X(zero) X(dofpar) X(dofMadr) X(p_gsize) X(p_rbound) X(p_mass) X(p_inertia)
+  X(gpos) X(gmat) X(zero) X(dofpar) X(dofMadr) X(anc) X(p_gsize) X(p_rbound) X(p_mass) X(p_inertia)
 // contact / block / Jacobian pools: LDS, or (many-body layout, NROW = 8 kernels) the env's slice of global memory
 #define MJH_LDS_POOLS(X) X(con) X(blki) X(blkf) X(blkq) X(bv) X(phi) X(sched) X(order) X(J) X(B) X(ext)
 #define MJH_LDS_ARRAYS(X) MJH_LDS_SMALL(X) MJH_LDS_POOLS(X)

@@ -238,8 +238,8 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     L.xipos = put(3*nb); L.com = put(3*nb); L.cinert = put(10*nb); L.cdof = put(6*nv);
     const int k2_size = off - k1;   // ... and all of these are dead when the solver sweeps run: the X extension of condim-4 models
     L.qM = put(m->nM); L.qLD = diagM ? L.qM : put(m->nM); L.qLDinv = put(nv);   // diagonal M: no factor storage
-    if (diagM) { L.dofpar = 0; L.dofMadr = 0; }   // free-body models read the shared chain-walk tables (step_kernel.h)
-    else { L.dofpar = put(nv); L.dofMadr = put(nv); }
+    if (diagM) { L.dofpar = 0; L.dofMadr = 0; L.anc = 0; }   // free-body models read the shared chain-walk tables (step_kernel.h)
+    else { L.dofpar = put(nv); L.dofMadr = put(nv); L.anc = put(m->nM); }
     L.p_gsize = put(3*ng); L.p_rbound = put(ng); L.p_mass = put(nb); L.p_inertia = put(3*nb);
     {  // the contact records die once the blocks are built; the velocity-stage spatial vectors reuse their space
       const int a4 = [](int n) { return ((std::max(n, 1) + 3) / 4) * 4; }(6*nb);

@@ -73,6 +73,54 @@ DEV void factor_tree(float* qLD, float* qLDinv, const int* dof_parentid, const i
   }
 }
 
+// ---- wave-cooperative versions for long kinematic trees (articulated robots: one 20-50 dof tree per env, for which the
+// lane-per-tree routines above leave 63 lanes idle during O(n depth^2) work).  Sequential over the dofs k of the tree,
+// lanes = ancestors a_p of k (p = 1..depth); every update of one k touches a different row / entry per lane.
+#define MJH_WAVE_TREE_MIN 12
+// anc[dof_Madr[k] + p] = p-th ancestor of dof k (p = 0: k itself): same layout as the rows of qLD, built once per launch.
+// The depth of k is the length of its qLD row minus one.
+DEV void factor_tree_wave(float* qLD, float* qLDinv, const int* anc, const int* dof_Madr, int adr, int num, int nM, int nv, const int lane) {
+  for (int k = adr + num - 1; k >= adr; k--) {
+    const int Mk = dof_Madr[k], d = (k + 1 < nv ? dof_Madr[k + 1] : nM) - Mk - 1;
+    const float inv = 1.0f / qLD[Mk];
+    // lanes = (p, q) with 1 <= p <= q <= d: row a_p, column a_q  -=  (M_kp / M_kk) M_kq   (row k is only read)
+    for (int p0 = 1; p0 <= d; p0 += 4) {
+      const int pp = p0 + (lane >> 4);
+      for (int q0 = 1; q0 <= d; q0 += 16) {
+        const int q = q0 + (lane & 15);
+        if (pp <= d && q >= pp && q <= d) {
+          const int ai = dof_Madr[anc[Mk + pp]];
+          qLD[ai + (q - pp)] -= qLD[Mk + pp] * inv * qLD[Mk + q];
+        }
+      }
+    }
+    __syncthreads();
+    for (int p = 1 + lane; p <= d; p += 64) qLD[Mk + p] *= inv;
+    if (lane == 0) qLDinv[k] = inv;
+    __syncthreads();
+  }
+}
+DEV void solve_tree_wave(float* x, const float* qLD, const float* qLDinv, const int* anc, const int* dof_Madr, int adr, int num, int nM, int nv, const int lane) {
+  for (int k = adr + num - 1; k >= adr; k--) {                                // x <- L^-T x
+    const float xk = x[k];
+    if (xk != 0) {
+      const int Mk = dof_Madr[k], d = (k + 1 < nv ? dof_Madr[k + 1] : nM) - Mk - 1;
+      for (int p = 1 + lane; p <= d; p += 64) x[anc[Mk + p]] -= qLD[Mk + p] * xk;
+    }
+    __syncthreads();
+  }
+  for (int k = adr + lane; k < adr + num; k += 64) x[k] *= qLDinv[k];          // D^-1
+  __syncthreads();
+  for (int k = adr; k < adr + num; k++) {                                     // x <- L^-1 x
+    const int Mk = dof_Madr[k], d = (k + 1 < nv ? dof_Madr[k + 1] : nM) - Mk - 1;
+    float part = 0;
+    for (int p = 1 + lane; p <= d; p += 64) part += qLD[Mk + p] * x[anc[Mk + p]];
+    part = wave_sum<4>(part);
+    if (lane == 0) x[k] -= part;
+    __syncthreads();
+  }
+}
+
 // row header: hd[0] = type | sub << 8, hd[1] = id, hd[2] = a1 | n1 << 16, hd[3] = a2 | n2 << 16
 // where (a1,n1) ++ (a2,n2) are the contiguous dof ranges of the (up to two) kinematic trees the row touches
 #define ROW_TREES(hd2, hd3) const int a1 = (hd2) & 0xffff, n1 = (hd2) >> 16, a2 = (hd3) & 0xffff, n2 = (hd3) >> 16
@@ -332,6 +380,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   // chain-walk tables: LDS copies for articulated models; free-body models (DIAGM) walk 6-dof chains a few times per step
   // and read the shared tables instead (their LDS space is not allocated)
   const int* s_dofpar_i = DIAGM ? (dof_parentid + 0) : (const int*)s_dofpar; const int* s_dofMadr_i = DIAGM ? (dof_Madr + 0) : (const int*)s_dofMadr;
+  int* s_anc_i = (int*)s_anc;
   float* s_stage = s_J;  // raw-contact staging aliases the (not yet built) base-row storage
   const int rowW = M.rowW;
 
@@ -358,7 +407,11 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   if (lane < 4) s_zero[lane] = 0;   // what lanes outside a block read instead of its Jacobian
   // hot chain-walk tables and the (possibly per-env) model parameters go to LDS once per launch
   for (int i = lane; i < nv; i += 64) {
-    if (!DIAGM) { ((int*)s_dofpar)[i] = dof_parentid[i]; ((int*)s_dofMadr)[i] = dof_Madr[i]; }
+    if (!DIAGM) {
+      ((int*)s_dofpar)[i] = dof_parentid[i]; ((int*)s_dofMadr)[i] = dof_Madr[i];
+      int a = dof_Madr[i]; s_anc_i[a] = i;                      // ancestor lists (wave-cooperative factor / solve)
+      for (int j = dof_parentid[i]; j >= 0; j = dof_parentid[j]) s_anc_i[++a] = j;
+    }
   }
   for (int i = lane; i < 3 * ngeom; i += 64) s_p_gsize[i] = S.p_geom_size ? S.p_geom_size[(size_t)env * 3 * ngeom + i] : geom_size[i];
   for (int i = lane; i < ngeom; i += 64) s_p_rbound[i] = S.p_geom_rbound ? S.p_geom_rbound[(size_t)env * ngeom + i] : geom_rbound[i];
@@ -568,7 +621,10 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
     PROF(3);
     // ---- L'DL factorisation (mj_factorM): one lane per kinematic tree
     if (DIAGM) { for (int d = lane; d < nv; d += 64) s_qLDinv[d] = 1.0f / s_qM[s_dofMadr_i[d]]; }   // every tree: M is diagonal (single free body about its COM)
-    else for (int t = lane; t < M.ntree; t += 64) factor_tree(s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t]);
+    else {
+      for (int t = 0; t < M.ntree; t++) if (tree_dofnum[t] >= MJH_WAVE_TREE_MIN) factor_tree_wave(s_qLD, s_qLDinv, s_anc_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t], M.nM, nv, lane);
+      for (int t = lane; t < M.ntree; t += 64) if (tree_dofnum[t] < MJH_WAVE_TREE_MIN) factor_tree(s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t]);
+    }
     WSYNC();
 
     PROF(4);
@@ -1137,7 +1193,10 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       for (int d = lane; d < nv; d += 64) { float f = s_passive[d] - s_bias[d] + s_applied[d]; s_smooth[d] = f; s_asmooth[d] = f; }
       WSYNC();
       if (DIAGM) { for (int d = lane; d < nv; d += 64) s_asmooth[d] *= s_qLDinv[d]; }
-      else for (int t = lane; t < M.ntree; t += 64) solve_tree(s_asmooth, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t]);
+      else {
+        for (int t = 0; t < M.ntree; t++) if (tree_dofnum[t] >= MJH_WAVE_TREE_MIN) solve_tree_wave(s_asmooth, s_qLD, s_qLDinv, s_anc_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t], M.nM, nv, lane);
+        for (int t = lane; t < M.ntree; t += 64) if (tree_dofnum[t] < MJH_WAVE_TREE_MIN) solve_tree(s_asmooth, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t]);
+      }
       WSYNC();
       niter = 0;
       PROF(11);
@@ -1485,7 +1544,11 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           WSYNC();
           for (int d = lane; d < nv; d += 64) s_qLD[s_dofMadr_i[d]] += h * dof_damping[d];
           WSYNC();
-          for (int t = lane; t < M.ntree; t += 64) {
+          for (int t = 0; t < M.ntree; t++) if (tree_dofnum[t] >= MJH_WAVE_TREE_MIN) {
+            factor_tree_wave(s_qLD, s_qLDinv, s_anc_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t], M.nM, nv, lane);
+            solve_tree_wave(s_tmpv, s_qLD, s_qLDinv, s_anc_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t], M.nM, nv, lane);
+          }
+          for (int t = lane; t < M.ntree; t += 64) if (tree_dofnum[t] < MJH_WAVE_TREE_MIN) {
             factor_tree(s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t]);
             solve_tree(s_tmpv, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t]);
           }

@@ -1,0 +1,26 @@
+"""Per-stage shader-clock breakdown of a robot fixture (fused kernel): python tools/robot_stage_profile.py <name> [nenv]"""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import mujoco_sim_amd as ms
+from mujoco_sim_amd import capi
+from helpers import load_model_tables
+from test_robot_fixtures import robot_command
+name = sys.argv[1]; nenv = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+m, z = load_model_tables(os.path.join(ROOT, "tests", "golden", f"robot_{name}.npz"))
+e = ms.Engine(m, nenv); e.set_controlled_dofs(z["controlled"].astype(np.int32))
+for k in range(1, 60):
+    e.set_cmd(ddq=np.tile(robot_command(m, k), (nenv, 1))); e.step(1, True)
+names = ["", "load state", "FK + geoms", "COM/cdof/CRBA", "factor", "collision", "row headers", "J rows + params", "B, schedule",
+         "vel stage (RNE, aref)", "controller/inverse", "smooth acc", "warmstart + A_c + AR", "PGS sweeps", "checkAcc + integrate", "store"]
+out = np.zeros(16)
+for rep in range(2):
+    capi.load().mjh_debug_stage_cycles(e.h, 1, capi.dptr(out))
+st = e.get_stats()
+print(name, "nv", m.nv, "lds", e.lds_bytes, "mean ncon %.1f nefc %.1f iter %.1f" % (st[:,0].mean(), st[:,1].mean(), st[:,2].mean()))
+prev = 0
+for k in range(1, 16):
+    if out[k] == 0: continue
+    print(f"{k:2d} {names[k]:24s} +{out[k]-prev:10.0f} ticks   cum {out[k]:10.0f}")
+    prev = out[k]
