@@ -322,7 +322,7 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   e->M = hp.M; e->L = hp.L; e->lds_bytes = hp.lds_bytes; e->o_controlled = hp.o_controlled; e->o_odom = hp.o_odom;
   DModel& M = e->M; std::vector<int>& I = hp.I; std::vector<float>& F = hp.F;
   e->hI = I;
-  if (dev_alloc(e, &e->dI, I.size(), false) || dev_alloc(e, &e->dF, F.size(), false)) { delete e; return MJH_ERR_NO_DEVICE; }
+  if (dev_alloc(e, &e->dI, I.size(), false) || dev_alloc(e, &e->dF, F.size(), false)) { mjh_destroy(e); return MJH_ERR_NO_DEVICE; }
   HIPCHK(hipMemcpyAsync(e->dI, I.data(), I.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipMemcpyAsync(e->dF, F.data(), F.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -330,7 +330,7 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
 
   {
     DConst hc; hc.M = e->M; hc.L = e->L;
-    if (dev_alloc(e, &e->dC, 1, false)) { delete e; return MJH_ERR_NO_DEVICE; }
+    if (dev_alloc(e, &e->dC, 1, false)) { mjh_destroy(e); return MJH_ERR_NO_DEVICE; }
     HIPCHK(hipMemcpyAsync(e->dC, &hc, sizeof hc, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
   }
