@@ -235,6 +235,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     L.xpos = put(3*nb); L.xquat = put(4*nb); L.xmat = put(9*nb); L.ximat = put(9*nb); L.crb = put(10*nb);
     L.xanchor = put(3*nj); L.xaxis = put(3*nj); L.gpos = put(3*ng); L.gmat = put(9*ng);
     const int k1_size = off - k1;
+    M.k1_floats = k1_size;
     L.xipos = put(3*nb); L.com = put(3*nb); L.cinert = put(10*nb); L.cdof = put(6*nv);
     const int k2_size = off - k1;   // ... and all of these are dead when the solver sweeps run: the X extension of condim-4 models
     L.qM = put(m->nM); L.qLD = diagM ? L.qM : put(m->nM); L.qLDinv = put(nv);   // diagonal M: no factor storage
@@ -450,7 +451,7 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
         // sweeps, which are > 90 % of such a step) -> integrate
         rc = launch_on(e, st, g0, g1 - g0, 1, ph | PH_PRE, 0);
         if (!rc) {
-          const size_t lds = 2 * (size_t)(((e->M.nv + 3) / 4) * 4) * sizeof(float);
+          const size_t lds = (2 * (size_t)(((e->M.nv + 3) / 4) * 4) + 2 * (size_t)std::max(e->M.maxblk, 1) + 4) * sizeof(float);   // 2 dof vectors + visiting order + group starts
           if (e->M.diagM) hipLaunchKernelGGL((mjh_solve_kernel<true>), dim3(g1 - g0), dim3(64), lds, st, e->dC, e->S, g0);
           else hipLaunchKernelGGL((mjh_solve_kernel<false>), dim3(g1 - g0), dim3(64), lds, st, e->dC, e->S, g0);
           HIPCHK(hipGetLastError());

@@ -264,7 +264,8 @@ DEV float pgs_dual(const float R, const float lo, const float hi, const float* a
 // compact dofs of ONE block (at most 64: rowW), gathered before and scattered after the block's update; the block's
 // operands come from the pools and are prefetched one block ahead.  Shared by the fused step kernel and mjh_solve_kernel.
 struct ManyCtx {
-  const float *J, *B, *blkq, *ext; float* blkf; const int *blki, *order;
+  const float *J, *B, *blkq, *ext; float* blkf; const int *blki, *order, *gstart;   // order / gstart: LDS copies (visiting order, group starts)
+  int ngrp;
   float* qacc; const float* qLDinv;
   int nblk, nfixblk, rowW, iterations; bool has_dim4; float scale, tolerance;
 };
@@ -274,7 +275,7 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
   // operands of one block; every address follows from the block index alone (contact blocks are laid out
   // regularly behind the c.nfixblk non-contact ones), so all loads of block k+1 are in flight while block k is solved
   struct MOp { int4 hd; int b; float4 J, B, p0, r0, r1, r2, A0, A1, A2, A3, X0, X1, X2; };
-  auto blockAt = [&](int k) __attribute__((always_inline)) { return c.nblk > 64 ? k : c.order[k]; };   // beyond 64 blocks: plain order
+  auto blockAt = [&](int k) __attribute__((always_inline)) { return c.order[k]; };   // visiting order (LDS copy)
   auto fetch8 = [&](int b) __attribute__((always_inline)) {
     MOp op; op.b = b; op.hd = ((const int4*)c.blki)[b];
     const bool quad = b >= c.nfixblk;
@@ -896,9 +897,79 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
     //      (i, q) are independent and can be solved side by side.
     int ngrp = 0;
     {
-      if (nblk > 64) {   // (capacity of the 64-bit bookkeeping below) plain order, no pairs
-        for (int i = lane; i < nblk; i += 64) { s_sched_i[2*i] = i; s_sched_i[2*i+1] = -1; s_order_i[i] = i; }
-        ngrp = nblk;
+      if (nblk > 64) {
+        // many-block models: groups of up to 4 mutually independent blocks (the many-body solver puts one block on each
+        // 16-lane row of the wave; sequential sweeps just follow the order).  Same rule as the oracle: two-tree blocks
+        // first, then first fit: a block plus up to three later unvisited blocks of the sequence that share no tree with any
+        // block already in the group.  s_order_i[k] = k-th block, s_sched_i[g] = first k of group g (s_sched_i[ngrp] = nblk).
+        // Scratch: one packed word per sequence position (block | tree1 | tree2+1 | used) in LDS that is dead here.
+        int* info = (int*)(NROW == 8 ? s_xpos : s_bv);
+        const bool fits = (NROW != 8 || nblk <= M.k1_floats) && nblk < 2048 && nv < 1023;
+        if (!fits) {   // (cannot happen with the capacities the host accepts; keep a valid order)
+          for (int i = lane; i < nblk; i += 64) { s_order_i[i] = i; s_sched_i[i] = i; }
+          if (lane == 0) s_sched_i[nblk] = nblk;
+          ngrp = nblk; flags |= 2;
+        } else {
+          int c = 0;
+          for (int pass = 0; pass < 2; pass++)
+            for (int base = 0; base < nblk; base += 64) {
+              const int b = base + lane;
+              int w = 0; bool mine = false;
+              if (b < nblk) {
+                const int* hd = s_blki_i + b * BLKI_STRIDE;
+                const int ta = hd[2] & 0xffff, tb1 = (hd[3] >> 16) ? (hd[3] & 0xffff) + 1 : 0;
+                mine = (tb1 != 0) == (pass == 0);
+                w = b | (ta << 11) | (tb1 << 21);
+              }
+              const unsigned long long mk = __ballot(mine);
+              if (mine) info[c + __popcll(mk & ((1ull << lane) - 1ull))] = w;
+              c += __popcll(mk);
+            }
+          WSYNC();
+          int k = 0, cursor = 0;
+          while (k < nblk) {
+            // first unvisited position
+            int p0 = -1;
+            for (int base = cursor; base < nblk && p0 < 0; base += 64) {
+              const int p = base + lane;
+              const unsigned long long mk = __ballot(p < nblk && info[p] >= 0);
+              if (mk) p0 = base + __ffsll((long long)mk) - 1;
+            }
+            int w0 = info[p0];
+            int gt0 = (w0 >> 11) & 1023, gt1 = ((w0 >> 21) & 1023) - 1, gt2 = -2, gt3 = -2, gt4 = -2, gt5 = -2;   // trees of the group (-2: none)
+            if (lane == 0) { info[p0] = w0 | 0x80000000; s_sched_i[ngrp] = k; s_order_i[k] = w0 & 2047; }
+            k++; cursor = p0 + 1;
+            int cnt = 1, pos = p0 + 1;
+            WSYNC();
+            while (cnt < 4 && pos < nblk) {
+              const int p = pos + lane;
+              bool cand = false; int w = 0;
+              if (p < nblk) {
+                w = info[p];
+                const int ta = (w >> 11) & 1023, tb = ((w >> 21) & 1023) - 1;
+                const bool sh = ta == gt0 || ta == gt1 || ta == gt2 || ta == gt3 || ta == gt4 || ta == gt5 ||
+                                (tb >= 0 && (tb == gt0 || tb == gt1 || tb == gt2 || tb == gt3 || tb == gt4 || tb == gt5));
+                cand = w >= 0 && !sh;
+              }
+              const unsigned long long mk = __ballot(cand);
+              if (!mk) { pos += 64; continue; }
+              const int q = __ffsll((long long)mk) - 1;
+              const int wq = __builtin_amdgcn_readlane(w, q);
+              if (lane == 0) { info[pos + q] = wq | 0x80000000; s_order_i[k] = wq & 2047; }
+              const int ta = (wq >> 11) & 1023, tb = ((wq >> 21) & 1023) - 1;
+              if (cnt == 1) { gt2 = ta; gt3 = tb >= 0 ? tb : -2; } else { gt4 = ta; gt5 = tb >= 0 ? tb : -2; }
+              k++; cnt++; pos = pos + q + 1;
+              WSYNC();
+            }
+            ngrp++;
+          }
+          if (lane == 0) s_sched_i[ngrp] = nblk;
+          if (NROW <= 2) {   // the dual-block sweep reads (block, partner) pairs: follow the order, no partners
+            WSYNC();
+            for (int i = lane; i < nblk; i += 64) { s_sched_i[2*i] = s_order_i[i]; s_sched_i[2*i+1] = -1; }
+            ngrp = nblk;
+          }
+        }
       } else {
         {   // stable partition (two-tree blocks first): position of block `lane` in the sequence
           const bool two = lane < nblk && (s_blki_i[lane * BLKI_STRIDE + 3] >> 16) != 0;
@@ -1203,7 +1274,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       if (pre) {   // hand-over to mjh_solve_kernel / the PH_POST launch
         int* meta = (int*)(gs + L.g_meta);
         for (int d = lane; d < nv; d += 64) { gs[L.g_qvel + d] = s_qvel[d]; gs[L.g_smooth + d] = s_smooth[d]; if (nefc == 0) gs[L.g_qacc + d] = s_asmooth[d]; }
-        if (lane == 0) { meta[0] = nefc == 0 ? 0 : nblk; meta[1] = nfixblk; meta[2] = nefc; meta[3] = ncon; meta[4] = flags; meta[5] = 0; }
+        if (lane == 0) { meta[0] = nefc == 0 ? 0 : nblk; meta[1] = nfixblk; meta[2] = nefc; meta[3] = ncon; meta[4] = flags; meta[5] = 0; meta[6] = ngrp; }
         if (nefc == 0) return;
       }
       if (nefc == 0) {
@@ -1344,7 +1415,16 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           WSYNC();
           {
             ManyCtx mc;
-            mc.J = s_J; mc.B = s_B; mc.blkf = s_blkf; mc.blkq = s_blkq; mc.ext = s_ext; mc.blki = s_blki_i; mc.order = s_order_i;
+            mc.J = s_J; mc.B = s_B; mc.blkf = s_blkf; mc.blkq = s_blkq; mc.ext = s_ext; mc.blki = s_blki_i;
+            // visiting order and group starts: LDS copies in the (dead) position-stage arrays when they fit
+            mc.order = s_order_i; mc.gstart = s_sched_i; mc.ngrp = ngrp;
+            if (nblk + ngrp + 2 <= M.k1_floats) {
+              int* ol = (int*)s_xpos; int* gl = ol + nblk;
+              for (int i = lane; i < nblk; i += 64) ol[i] = s_order_i[i];
+              if (nblk > 64) for (int i = lane; i <= ngrp; i += 64) gl[i] = s_sched_i[i];
+              WSYNC();
+              mc.order = ol; mc.gstart = gl;
+            }
             mc.qacc = s_qacc; mc.qLDinv = s_qLDinv;
             mc.nblk = nblk; mc.nfixblk = __builtin_amdgcn_readfirstlane(nfixblk); mc.rowW = rowW; mc.iterations = M.iterations;
             mc.has_dim4 = has_dim4; mc.scale = scale; mc.tolerance = M.tolerance;
@@ -1648,12 +1728,17 @@ __global__ __launch_bounds__(64) void mjh_solve_kernel(const DConst* __restrict_
   int* meta = (int*)(gs + L.g_meta);
   const int nblk = __builtin_amdgcn_readfirstlane(meta[0]);
   if (nblk == 0) return;                                  // unconstrained env: the assemble launch wrote qacc itself
-  float* s_qacc = lds; float* s_minv = lds + ((nv + 3) / 4) * 4;
+  const int nv4 = ((nv + 3) / 4) * 4, ngrp = __builtin_amdgcn_readfirstlane(meta[6]);
+  float* s_qacc = lds; float* s_minv = lds + nv4;
+  int* s_ord = (int*)(lds + 2 * nv4); int* s_gst = s_ord + nblk;          // visiting order, group starts (many-block models)
+  const int* g_ord = (const int*)(gs + (-1 - L.order)); const int* g_gst = (const int*)(gs + (-1 - L.sched));
   for (int d = lane; d < nv; d += 64) { s_qacc[d] = gs[L.g_a0 + d]; s_minv[d] = gs[L.g_minv + d]; }
+  for (int i = lane; i < nblk; i += 64) s_ord[i] = g_ord[i];
+  if (nblk > 64) for (int i = lane; i <= ngrp; i += 64) s_gst[i] = g_gst[i];
   __syncthreads();
   ManyCtx mc;
   mc.J = gs + (-1 - L.J); mc.B = gs + (-1 - L.B); mc.blkf = gs + (-1 - L.blkf); mc.blkq = gs + (-1 - L.blkq); mc.ext = gs + (-1 - L.ext);
-  mc.blki = (const int*)(gs + (-1 - L.blki)); mc.order = (const int*)(gs + (-1 - L.order));
+  mc.blki = (const int*)(gs + (-1 - L.blki)); mc.order = s_ord; mc.gstart = s_gst; mc.ngrp = ngrp;
   mc.qacc = s_qacc; mc.qLDinv = s_minv;
   mc.nblk = nblk; mc.nfixblk = __builtin_amdgcn_readfirstlane(meta[1]); mc.rowW = M.rowW; mc.iterations = M.iterations;
   mc.has_dim4 = M.has_dim4 != 0; mc.scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1)); mc.tolerance = M.tolerance;

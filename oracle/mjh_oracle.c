@@ -1049,7 +1049,41 @@ static int pgs_order(const orc_data* d, int* order) {
     nblk++; i += n;
   }
   int k = 0;
-  if (nblk > 64) { for (int i = 0; i < nefc; i++) order[i] = i; free(bstart); return nefc; }   /* device bookkeeping limit */
+  if (nblk > 64) {
+    /* many-block models (the device solves them four independent blocks at a time, one per 16-lane row of the wave):
+     * same two-tree-first sequence; a group = a block plus up to three later unvisited blocks of the sequence, each sharing
+     * no tree with any block already in the group (first fit) */
+    int* seq = (int*)malloc(sizeof(int) * (size_t)(nblk + 1));
+    int ns = 0;
+    for (int pass = 0; pass < 2; pass++)
+      for (int i = 0; i < nblk; i++) {
+        int two = bt1[i] >= 0 && bt2[i] >= 0 && bt1[i] != bt2[i];
+        if (two == (pass == 0)) seq[ns++] = i;
+      }
+    for (int ii = 0; ii < nblk; ii++) {
+      int i = seq[ii];
+      if (used[i]) continue;
+      int gt[8], ngt = 0, cnt = 1;
+      used[i] = 1;
+      for (int r = 0; r < bnum[i]; r++) order[k++] = bstart[i] + r;
+      if (bt1[i] >= 0) gt[ngt++] = bt1[i];
+      if (bt2[i] >= 0) gt[ngt++] = bt2[i];
+      for (int jj = ii + 1; jj < nblk && cnt < 4; jj++) {
+        int j = seq[jj];
+        if (used[j]) continue;
+        int share = 0;
+        for (int q = 0; q < ngt; q++) if (gt[q] == bt1[j] || gt[q] == bt2[j]) share = 1;
+        if (share) continue;
+        used[j] = 1;
+        for (int r = 0; r < bnum[j]; r++) order[k++] = bstart[j] + r;
+        if (bt1[j] >= 0) gt[ngt++] = bt1[j];
+        if (bt2[j] >= 0) gt[ngt++] = bt2[j];
+        cnt++;
+      }
+    }
+    free(seq); free(bstart);
+    return k;
+  }
   /* visiting sequence: blocks that couple two kinematic trees first (they are the hard ones to pair), then the
    * single-tree blocks, each group in constraint order; then greedy: a block, and the first later unvisited block
    * of the sequence that shares no tree with it */
