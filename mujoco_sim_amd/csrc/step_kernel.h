@@ -320,6 +320,86 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
       *(float2*)(bf + 4) = make_float2(f[4], f[5]);
     }
   };
+  if (c.nblk > 64 && c.rowW <= 16 && c.ngrp >= 2) {
+    // ======== four blocks per step: the blocks of a group (mutually independent by construction of the order) sit on the
+    //          four 16-lane rows of the wave; lanes of a row = the compact dofs of its block.  Everything "uniform" of the
+    //          single-block step is uniform per row; a row-wide sum is a 4-step DPP butterfly inside the row.
+    const int row = lane >> 4, l = lane & 15;
+    struct QOp { int4 hd; int b; float act; float4 J, B, p0, r0, r1, r2, A0, A1, A2, A3, X0, X1, X2; };
+    auto fetchQ = [&](int g) __attribute__((always_inline)) {
+      QOp op;
+      const int st = c.gstart[g], sz = c.gstart[g + 1] - st;
+      const bool act = row < sz;
+      const int b = c.order[st + (act ? row : 0)];
+      op.b = b; op.act = act ? 1.0f : 0.0f; op.hd = ((const int4*)c.blki)[b];
+      const bool quad = b >= c.nfixblk;
+      const int jo = (quad ? c.nfixblk + 4 * (b - c.nfixblk) : b) * c.rowW;
+      op.J = make_float4(0, 0, 0, 0); op.B = op.J;
+      if (l < c.rowW) {
+        if (quad) op.J = *(const float4*)(c.J + jo + 4*l); else op.J.x = c.J[jo + l];
+        if (!DIAGM) { if (quad) op.B = *(const float4*)(c.B + jo + 4*l); else op.B.x = c.B[jo + l]; }
+      }
+      op.p0 = ((const float4*)c.blkf)[4*b]; op.r0 = ((const float4*)c.blkf)[4*b+1]; op.r1 = ((const float4*)c.blkf)[4*b+2]; op.r2 = ((const float4*)c.blkf)[4*b+3];
+      op.A0 = ((const float4*)c.blkq)[4*b]; op.A1 = ((const float4*)c.blkq)[4*b+1]; op.A2 = ((const float4*)c.blkq)[4*b+2]; op.A3 = ((const float4*)c.blkq)[4*b+3];
+      op.X0 = make_float4(0, 0, 0, 0); op.X1 = op.X0; op.X2 = op.X0;
+      if (c.has_dim4) { const float4* x4 = (const float4*)(c.ext + b * SOLX_N); op.X0 = x4[0]; op.X1 = x4[1]; op.X2 = x4[2]; }
+      return op;
+    };
+    auto processQ = [&](QOp& op, float& impl) __attribute__((always_inline)) {
+      KEEP4(op.hd); KEEP4(op.J); KEEP4(op.p0); KEEP4(op.r0); KEEP4(op.r1); KEEP4(op.r2); KEEP4(op.A0); KEEP4(op.A1); KEEP4(op.A2); KEEP4(op.A3);
+      if (!DIAGM) KEEP4(op.B);
+      if (c.has_dim4) { KEEP4(op.X0); KEEP4(op.X1); KEEP4(op.X2); }
+      ROW_TREES(op.hd.z, op.hd.w);
+      const bool on = op.act > 0.0f && l < n1 + n2;
+      const int d = l < n1 ? a1 + l : a2 + l - n1;
+      float ak = on ? c.qacc[d] : 0.0f;                                       // gather
+      const int kk = op.act > 0.0f ? (op.hd.x & 15) : 0;
+      const int k01 = max(__builtin_amdgcn_readlane(kk, 0), __builtin_amdgcn_readlane(kk, 16));
+      const int k23 = max(__builtin_amdgcn_readlane(kk, 32), __builtin_amdgcn_readlane(kk, 48));
+      const int kind = max(k01, k23);                                          // rows of smaller blocks are inert
+      float f[6] = {op.r1.x, op.r1.y, op.r1.z, op.r1.w, op.r2.x, op.r2.y};
+      const float aref[4] = {op.r0.x, op.r0.y, op.r0.z, op.r0.w};
+      const float Q[16] = {op.A0.x, op.A0.y, op.A0.z, op.A0.w, op.A1.x, op.A1.y, op.A1.z, op.A1.w,
+                           op.A2.x, op.A2.y, op.A2.z, op.A2.w, op.A3.x, op.A3.y, op.A3.z, op.A3.w};
+      const float X[12] = {op.X0.x, op.X0.y, op.X0.z, op.X0.w, op.X1.x, op.X1.y, op.X1.z, op.X1.w, op.X2.x, op.X2.y, op.X2.z, op.X2.w};
+      const float Jd[4] = {on ? op.J.x : 0.0f, on ? op.J.y : 0.0f, on ? op.J.z : 0.0f, on ? op.J.w : 0.0f};
+      const float Bd[4] = {on ? op.B.x : 0.0f, on ? op.B.y : 0.0f, on ? op.B.z : 0.0f, on ? op.B.w : 0.0f};
+      const float* Bp = DIAGM ? Jd : Bd;
+      const float bs = DIAGM ? (on ? c.qLDinv[d] : 0.0f) : 1.0f;
+      const float R = op.p0.x, lo = op.r2.z, hi = op.r2.w;
+      float u[4] = {Jd[0] * ak, Jd[1] * ak, Jd[2] * ak, Jd[3] * ak}, dphi[4] = {0, 0, 0, 0};
+      asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]));
+      float imp;
+#define MJH_ROWSUM(N) do { MJH_DPP_BF4(u, N, 0xB1); MJH_DPP_BF4(u, N, 0x4E); MJH_DPP_BF4(u, N, 0x141); MJH_DPP_BF4(u, N, 0x140); } while (0)
+      if (kind == BK_PYR4) { MJH_ROWSUM(4); for (int j = 0; j < 4; j++) u[j] -= aref[j]; imp = pgs_rows<4, 6>(R, lo, hi, u, f, Q, X, dphi); }
+      else if (kind == BK_PYR3) { MJH_ROWSUM(3); for (int j = 0; j < 3; j++) u[j] -= aref[j]; imp = pgs_rows<3, 4>(R, lo, hi, u, f, Q, X, dphi); }
+      else { MJH_ROWSUM(1); u[0] -= aref[0]; imp = pgs_rows<1, 1>(R, lo, hi, u, f, Q, X, dphi); }
+#undef MJH_ROWSUM
+      ak += (Bp[0] * dphi[0] + Bp[1] * dphi[1] + Bp[2] * dphi[2] + Bp[3] * dphi[3]) * bs;
+      if (on) c.qacc[d] = ak;                                                 // scatter (the group's blocks touch disjoint dofs)
+      impl += op.act * imp;
+      if (l == 0 && op.act > 0.0f) {
+        float* bf = c.blkf + op.b * BLKF_STRIDE + BF_F;
+        *(float4*)(bf) = make_float4(f[0], f[1], f[2], f[3]);
+        *(float2*)(bf + 4) = make_float2(f[4], f[5]);
+      }
+    };
+    QOp opA = fetchQ(0), opB;
+    for (int it = 0; it < c.iterations; it++) {
+      float impl = 0;
+      for (int g = 0; g < c.ngrp; g += 2) {
+        opB = fetchQ(g + 1 < c.ngrp ? g + 1 : 0);
+        processQ(opA, impl);
+        if (g + 1 < c.ngrp) {
+          opA = fetchQ(g + 2 < c.ngrp ? g + 2 : 0);
+          processQ(opB, impl);
+        } else opA = opB;
+      }
+      niter = it + 1;
+      const float improvement = readlane_f(impl, 0) + readlane_f(impl, 16) + readlane_f(impl, 32) + readlane_f(impl, 48);
+      if (improvement * c.scale < c.tolerance) break;
+    }
+  } else
   if (c.nblk < 3) {
     // (the prefetch would read the forces of a block before its pending update is stored)
     for (int it = 0; it < c.iterations; it++) {
