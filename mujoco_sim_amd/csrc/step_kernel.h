@@ -1104,6 +1104,27 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
     };
     // out[d] = sum over blocks/bases of X[b][d][j] * phi[4b+j]   (lanes = dofs; X = J, or B = M^-1 J^T when useB)
     auto accum_T = [&](bool useB, const float* phi, float* out) __attribute__((always_inline)) {
+      if constexpr (NROW == 8) {
+        // many-body layout: the gather below is O(nv x nblk) header reads from the global pools; scatter instead, lanes =
+        // blocks, each adding its <= rowW entries to the dof vector with LDS atomics (lane order: deterministic)
+        for (int d = lane; d < nv; d += 64) out[d] = 0;
+        WSYNC();
+        for (int b = lane; b < nblk; b += 64) {
+          const int4 hd = *(const int4*)(s_blki_i + b * BLKI_STRIDE);
+          ROW_TREES(hd.z, hd.w);
+          const float* X = ((useB && !DIAGM) ? s_B : s_J) + BLK_JOFF(hd.x);
+          const float4 p = *(const float4*)(phi + 4*b);
+          const bool quad = BLK_SLOTS(hd.y) == 4;
+          for (int k = 0; k < n1 + n2; k++) {
+            const int d = k < n1 ? a1 + k : a2 + k - n1;
+            float v;
+            if (quad) { const float4 x = *(const float4*)(X + 4*k); v = x.x*p.x + x.y*p.y + x.z*p.z + x.w*p.w; } else v = X[k] * p.x;
+            if (v != 0) atomicAdd(&out[d], (useB && DIAGM) ? v * s_qLDinv[d] : v);
+          }
+        }
+        WSYNC();
+        return;
+      }
       for (int d = lane; d < nv; d += 64) {
         float acc = 0;
         const float minv = s_qLDinv[d];
