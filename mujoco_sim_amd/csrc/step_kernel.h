@@ -713,11 +713,11 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
     ncon = 0;
     if (!post && !(M.disableflags & (MJH_DSBL_CONTACT | MJH_DSBL_CONSTRAINT))) {
       int conbase = 0;
-      for (int base = 0; base < M.npair; base += 64) {
-        const int ip = base + lane;
+      // one round: narrow phase of (up to) 64 candidate pairs, contacts appended in lane (= pair) order
+      auto collide_round = [&](const int ip) __attribute__((always_inline)) {
         int n = 0, g1 = 0, g2 = 0; float margin = 0, gap = 0;
         float* st = s_stage;
-        if (ip < M.npair) {
+        if (ip >= 0) {
           g1 = pair_geom1[ip]; g2 = pair_geom2[ip];
           st = s_stage + pair_stageadr[ip] * RAW_STRIDE;
           const int t1 = geom_type[g1], t2 = geom_type[g2];
@@ -761,6 +761,41 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           c[CON_GEOMS] = __int_as_float(g1 | (g2 << 12) | (max(geom_condim[g1], geom_condim[g2]) << 24)); c[CON_MARGIN] = margin - gap;
         }
         conbase += total;
+      };
+      // bounding-sphere / plane-distance cull of one pair (the narrow phase repeats it; it is cheap)
+      auto survives = [&](const int ip) __attribute__((always_inline)) {
+        const int g1 = pair_geom1[ip], g2 = pair_geom2[ip];
+        const float margin = fmaxf(geom_margin[g1], geom_margin[g2]);
+        const int sb1 = geom_bodyid[g1], sb2 = geom_bodyid[g2];
+        if ((sb1 < 32 && ((slotmask >> sb1) & 1u)) || (sb2 < 32 && ((slotmask >> sb2) & 1u))) return false;
+        const float tt[3] = {s_gpos[3*g2] - s_gpos[3*g1], s_gpos[3*g2+1] - s_gpos[3*g1+1], s_gpos[3*g2+2] - s_gpos[3*g1+2]};
+        if (geom_type[g1] == MJH_GEOM_PLANE) { const float nn[3] = {s_gmat[9*g1+2], s_gmat[9*g1+5], s_gmat[9*g1+8]}; return !(dot3(tt, nn) > s_p_rbound[g2] + margin); }
+        const float bound = s_p_rbound[g1] + s_p_rbound[g2] + margin;
+        return !(dot3(tt, tt) > bound * bound);
+      };
+      // Many candidate pairs (64 free boxes: 2080): the divergent narrow phase would run once per 64 pairs whether or not
+      // anything is close; first compact the pairs that pass the cull (pair order is preserved, so is the contact order),
+      // then run the narrow phase on full rounds of survivors.  The list lives in dof vectors that are unused until the
+      // velocity stage (smooth, asmooth, passive, bias: contiguous).
+      const int listcap = (4 * (((nv + 3) / 4) * 4)) & ~63;
+      if (M.npair > 64 && listcap >= 64) {
+        int* list = (int*)s_smooth;
+        for (int c0 = 0; c0 < M.npair; c0 += listcap) {
+          const int c1 = min(c0 + listcap, M.npair);
+          int cnt = 0;
+          for (int base = c0; base < c1; base += 64) {
+            const int ip = base + lane;
+            const bool sv = ip < c1 && survives(ip);
+            const unsigned long long mk = __ballot(sv);
+            if (sv) list[cnt + __popcll(mk & ((1ull << lane) - 1ull))] = ip;
+            cnt += __popcll(mk);
+          }
+          WSYNC();
+          for (int b2 = 0; b2 < cnt; b2 += 64) collide_round(b2 + lane < cnt ? list[b2 + lane] : -1);
+          WSYNC();
+        }
+      } else {
+        for (int base = 0; base < M.npair; base += 64) collide_round(base + lane < M.npair ? base + lane : -1);
       }
       if (conbase > M.maxcon) { flags |= 1; conbase = M.maxcon; }
       ncon = __builtin_amdgcn_readfirstlane(conbase);
