@@ -991,7 +991,28 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
     WSYNC();
     PROF(7);
     // ---- B = M^-1 J^T per base row (skipped when every tree has a diagonal M: B_d = J_d / M_dd on the fly)
-    if (!DIAGM) {
+    if (!DIAGM && NROW == 8 && M.k1_floats >= 16 * rowW) {
+      // many-body layout: the rows live in global memory and the back-substitutions are long read-modify-write chains, so
+      // every lane solves its row in a private LDS vector (dead position-stage arrays) and writes the result back once
+      const int P = min(64, M.k1_floats / rowW);        // rows per pass
+      for (int t0 = 0; t0 < 4 * nblk; t0 += P) {
+        const int t = t0 + lane;
+        if (lane >= P || t >= 4 * nblk) continue;
+        const int b = t >> 2, jb = t & 3;
+        const int* hd = s_blki_i + b * BLKI_STRIDE;
+        const int SL = BLK_SLOTS(hd[1]);
+        if (jb >= SL) continue;
+        const float* J = s_J + BLK_JOFF(hd[0]) + jb; float* B = s_B + BLK_JOFF(hd[0]) + jb;
+        if (jb >= ((hd[0] >> 8) & 15)) { for (int k = 0; k < rowW; k++) B[SL*k] = 0; continue; }
+        ROW_TREES(hd[2], hd[3]);
+        float* x = s_xpos + lane * rowW;
+        for (int k = 0; k < rowW; k++) x[k] = J[SL*k];
+        solve_tree(x - a1, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a1, n1, 1);
+        if (n2 > 0) solve_tree(x + (n1 - a2), s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a2, n2, 1);
+        for (int k = 0; k < rowW; k++) B[SL*k] = x[k];
+      }
+      WSYNC();
+    } else if (!DIAGM) {
       for (int t = lane; t < 4 * nblk; t += 64) {
         const int b = t >> 2, jb = t & 3;
         const int* hd = s_blki_i + b * BLKI_STRIDE;
