@@ -695,3 +695,39 @@ def test_pr2_with_large_capacity_falls_back_to_global_pools(lib, layout_policy):
             np.testing.assert_allclose(e.get_field("qfrc_inverse")[0], ref, rtol=0, atol=5e-3 * max(1.0, np.abs(ref).max()))
             assert e.get_stats()[0, 1] == int(z[f"nefc_{k}"])
     e.close()
+
+
+@pytest.mark.gpu
+def test_many_body_layout_keeps_environments_apart():
+    """Global-pool layout with heterogeneous environments (different commands and initial joint positions per env), enough of
+    them for cohorts and longest-job-first dispatch to be active: every sampled env must follow ITS oracle."""
+    from helpers import load_model_tables
+    from test_robot_fixtures import robot_command
+    m, z = load_model_tables(os.path.join(ROOT, "tests", "golden", "robot_hsrb4s_world.npz"))
+    nenv = 1100
+    e = ms.Engine(m, nenv)
+    assert e.cohorts == 2
+    e.set_controlled_dofs(z["controlled"].astype(np.int32))
+    rng = np.random.default_rng(3)
+    scale = rng.uniform(0.2, 1.5, nenv)
+    q0 = np.tile(m.array("qpos0"), (nenv, 1))
+    jt = m.array("jnt_type"); qa = m.array("jnt_qposadr")
+    hinge = [int(qa[j]) for j in range(m.njnt) if jt[j] == 3]
+    q0[:, hinge[-6:]] += rng.uniform(-0.05, 0.05, (nenv, 6))
+    e.set_initial_qpos(q0); e.reset()
+    sample = [0, 1, 547, 548, 1099]
+    ds = []
+    for i in sample:
+        d = orc.OrcData(m.ptr); d.set_qpos(q0[i]); d.call("reset"); d.ifield("controlled")[:] = z["controlled"]; ds.append(d)
+    for k in range(1, 61):
+        base = robot_command(m, k)
+        e.set_cmd(ddq=scale[:, None] * base[None, :])
+        e.step(1, True)
+        for i, d in zip(sample, ds):
+            d.f("ddq")[:] = scale[i] * base; d.step(1, 1)
+    t, q, v, w = e.get_state()
+    for i, d in zip(sample, ds):
+        np.testing.assert_allclose(q[i], d.f("qpos"), rtol=0, atol=5e-4 * max(1.0, np.abs(d.f("qpos")).max()), err_msg=f"env {i}")
+    assert not np.allclose(q[0], q[1], atol=1e-4)         # the envs really differ
+    assert (e.get_stats()[:, 3] == 0).all()
+    e.close()
