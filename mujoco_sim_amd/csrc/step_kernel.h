@@ -384,20 +384,31 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
         *(float2*)(bf + 4) = make_float2(f[4], f[5]);
       }
     };
-    QOp opA = fetchQ(0), opB;
-    for (int it = 0; it < c.iterations; it++) {
-      float impl = 0;
-      for (int g = 0; g < c.ngrp; g += 2) {
-        opB = fetchQ(g + 1 < c.ngrp ? g + 1 : 0);
-        processQ(opA, impl);
-        if (g + 1 < c.ngrp) {
-          opA = fetchQ(g + 2 < c.ngrp ? g + 2 : 0);
-          processQ(opB, impl);
-        } else opA = opB;
-      }
-      niter = it + 1;
+    // operands are requested two group-steps ahead (three register sets in rotation): the pools of a cohort exceed the L2
+    // and one group-step is shorter than a miss
+    int gf = 0, g = 0;
+    auto nextFetch = [&]() __attribute__((always_inline)) { QOp o = fetchQ(gf); gf = gf + 1 == c.ngrp ? 0 : gf + 1; return o; };
+    float impl = 0; bool done = false;
+    auto stepDone = [&]() __attribute__((always_inline)) {          // end of a sweep: convergence test
+      if (++g < c.ngrp) return;
+      g = 0; niter++;
       const float improvement = readlane_f(impl, 0) + readlane_f(impl, 16) + readlane_f(impl, 32) + readlane_f(impl, 48);
-      if (improvement * c.scale < c.tolerance) break;
+      impl = 0;
+      done = improvement * c.scale < c.tolerance || niter >= c.iterations;
+    };
+    if (c.ngrp >= 3) {
+      QOp o0 = nextFetch(), o1 = nextFetch(), o2;
+      while (true) {
+        o2 = nextFetch(); processQ(o0, impl); stepDone(); if (done) break;
+        o0 = nextFetch(); processQ(o1, impl); stepDone(); if (done) break;
+        o1 = nextFetch(); processQ(o2, impl); stepDone(); if (done) break;
+      }
+    } else {
+      QOp o0 = nextFetch(), o1;
+      while (true) {
+        o1 = nextFetch(); processQ(o0, impl); stepDone(); if (done) break;
+        o0 = nextFetch(); processQ(o1, impl); stepDone(); if (done) break;
+      }
     }
   } else
   if (c.nblk < 3) {
