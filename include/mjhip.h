@@ -281,6 +281,11 @@ int mjh_debug_stop_at(mjh_engine*, int stage, int with_inverse);
  * stream forks into the cohort streams inside mjh_step and is joined again by the next call of any other
  * entry point, so results and ordering seen through this API do not depend on `n`.  Within a launch the
  * envs are dispatched longest-solver-job first (order rebuilt on the device every step). */
+/* m->opt.timestep of a running engine: simulate() doubles it while the simulation lags the wall clock by > 1 ms (up to
+ * max_time_step) and halves it back otherwise (mj_main.cpp:150-163) */
+int mjh_set_timestep(mjh_engine*, double dt);
+double mjh_get_timestep(const mjh_engine*);
+
 /* Memory layout of engines created afterwards (process-wide; no reference counterpart).  0 (default): per-env
  * contact / block / Jacobian pools in LDS while they are small (<= 24 KB per env), otherwise in a per-env slice of global
  * memory with the step issued as three launches (assemble, solve, integrate); 1: LDS whenever the working set fits one

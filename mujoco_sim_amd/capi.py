@@ -147,6 +147,8 @@ SYMBOLS = [
     ("mjh_debug_stage_cycles", C.c_int, [_vp, C.c_int, c_double_p]),
     ("mjh_debug_stage_raw", C.c_int, [_vp, C.c_int, _vp]),
     ("mjh_debug_stop_at", C.c_int, [_vp, C.c_int, C.c_int]),
+    ("mjh_set_timestep", C.c_int, [_vp, C.c_double]),
+    ("mjh_get_timestep", C.c_double, [_vp]),
     ("mjh_set_layout_policy", None, [C.c_int]),
     ("mjh_set_cohorts", C.c_int, [_vp, C.c_int]),
     ("mjh_get_cohorts", C.c_int, [_vp]),

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -477,6 +478,17 @@ extern "C" int mjh_get_launch_timing(mjh_engine* e, double* mean_ms, int* count)
   e->tev_used = 0;
   return MJH_OK;
 }
+// m->opt.timestep is mutable in the reference: simulate() doubles / halves it when the simulation lags the wall clock
+// (mj_main.cpp:150-163).  Takes effect with the next launch.
+extern "C" int mjh_set_timestep(mjh_engine* e, double dt) {
+  ENG(e);
+  if (!(dt > 0)) { mjh_set_error("mjh_set_timestep: dt must be positive"); return MJH_ERR_ARG; }
+  e->M.timestep = (float)dt;
+  HIPCHK(hipMemcpyAsync((char*)e->dC + offsetof(DConst, M) + offsetof(DModel, timestep), &e->M.timestep, sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return MJH_OK;
+}
+extern "C" double mjh_get_timestep(const mjh_engine* e) { return e ? (double)e->M.timestep : 0.0; }
 extern "C" int mjh_set_cohorts(mjh_engine* e, int n) { ENG(e); return set_cohorts(e, n); }
 extern "C" int mjh_get_cohorts(const mjh_engine* e) { return e ? e->ncohort : 0; }
 extern "C" int mjh_synchronize(mjh_engine* e) { ENG(e); HIPCHK(hipStreamSynchronize(e->stream)); return MJH_OK; }

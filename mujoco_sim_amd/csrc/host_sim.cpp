@@ -84,11 +84,12 @@ SimulateStats simulate(MjhSim* sim, std::vector<MjhHWInterface*>& hw, const std:
                        long nsteps, bool real_time) {
   using clk = std::chrono::steady_clock;
   SimulateStats st;
-  const double dt = sim->model->opt.timestep;
+  const double time_step = sim->model->opt.timestep;   // the configured step; dt is what the engine currently integrates with
+  double dt = mjh_get_timestep(sim->engine) > 0 ? mjh_get_timestep(sim->engine) : time_step;
   double sim_time = 0, last_sim_time = 0;
   const auto t0 = clk::now();
   std::deque<double> win_sim, win_wall;
-  const size_t num_step = (size_t)std::ceil(1.0 / dt);
+  const size_t num_step = (size_t)std::ceil(1.0 / time_step);
   for (long s = 0; s < nsteps; s++) {
     const double sim_period = sim_time - last_sim_time;
     mjh_step1(sim->engine);                                  // mj_main.cpp:83 (+ controller callback :49-52)
@@ -106,7 +107,15 @@ SimulateStats simulate(MjhSim* sim, std::vector<MjhHWInterface*>& hw, const std:
     }
     win_sim.push_front(sim_time); win_wall.push_front(wall);  // :115-147 real-time factor over a sliding 1 s window
     if (win_sim.size() > num_step) { st.rtf = (sim_time - win_sim.back()) / (wall - win_wall.back() + 1e-12); win_sim.pop_back(); win_wall.pop_back(); }
+    if (real_time) {                                         // :150-163 change the timestep when out of sync
+      const double error_time = std::chrono::duration<double>(clk::now() - t0).count() - sim_time;
+      double ndt = dt;
+      if (error_time > 1e-3) { if (dt < sim->max_time_step) ndt = dt * 2; }
+      else if (dt > time_step) ndt = dt / 2;
+      if (ndt != dt) { dt = ndt; mjh_set_timestep(sim->engine, dt); st.dt_changes++; }
+    }
   }
+  st.final_dt = dt;
   mjh_synchronize(sim->engine);
   st.sim_time = sim_time; st.steps = nsteps;
   st.wall_time = std::chrono::duration<double>(clk::now() - t0).count();

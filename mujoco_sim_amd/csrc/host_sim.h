@@ -53,7 +53,7 @@ class MjhHWInterface {
   std::vector<double> qpos_, qvel_, qfrc_, ddq_, dq_;
 };
 
-struct SimulateStats { double sim_time = 0, wall_time = 0, rtf = 0; long steps = 0; };
+struct SimulateStats { double sim_time = 0, wall_time = 0, rtf = 0, final_dt = 0; long steps = 0, dt_changes = 0; };
 // One pass of the reference loop per step: step1 -> read -> controller update -> write -> step2 (+odom).
 // `update(sim_time, sim_period)` stands in for controller_manager->update (mj_main.cpp:99).
 // real_time = true reproduces the wall-clock spin of mj_main.cpp:127-131.

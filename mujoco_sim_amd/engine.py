@@ -107,6 +107,10 @@ class Engine:
     def step(self, n=1, with_inverse=False): _chk(self.lib, self.lib.mjh_step(self.h, n, int(with_inverse)), "mjh_step")
     def synchronize(self): _chk(self.lib, self.lib.mjh_synchronize(self.h), "mjh_synchronize")
 
+    def set_timestep(self, dt): _chk(self.lib, self.lib.mjh_set_timestep(self.h, float(dt)), "mjh_set_timestep")
+    @property
+    def timestep(self): return self.lib.mjh_get_timestep(self.h)
+
     # ---- launch scheduling / timing (include/mjhip.h "launch scheduling")
     def set_cohorts(self, n): _chk(self.lib, self.lib.mjh_set_cohorts(self.h, int(n)), "mjh_set_cohorts")
     @property

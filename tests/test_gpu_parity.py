@@ -731,3 +731,26 @@ def test_many_body_layout_keeps_environments_apart():
     assert not np.allclose(q[0], q[1], atol=1e-4)         # the envs really differ
     assert (e.get_stats()[:, 3] == 0).all()
     e.close()
+
+
+@pytest.mark.gpu
+def test_set_timestep_takes_effect_with_the_next_launch(lib):
+    """m->opt.timestep is mutable in the reference (adaptive dt of simulate(), mj_main.cpp:150-163): free fall integrated
+    with dt, then 2 dt, then dt again equals the semi-implicit Euler sums."""
+    from helpers import free_body_model
+    m = free_body_model(lib, geom_type=2, size=(0.1, 0.1, 0.1), pos=(0, 0, 10), floor=False, timestep=0.002)
+    e = ms.Engine(m, 3)
+    g = -9.81; z = 10.0; vz = 0.0; t = 0.0
+    for dt, n in ((0.002, 40), (0.004, 25), (0.002, 10)):
+        e.set_timestep(dt)
+        assert abs(e.timestep - dt) < 1e-9
+        e.step(n)
+        for _ in range(n):
+            vz += dt * g; z += dt * vz; t += dt
+    tt, q, v, w = e.get_state()
+    np.testing.assert_allclose(q[:, 2], z, rtol=2e-6)
+    np.testing.assert_allclose(v[:, 2], vz, rtol=2e-6)
+    np.testing.assert_allclose(tt, t, rtol=1e-5)
+    with pytest.raises(MjhError):
+        e.set_timestep(0.0)
+    e.close()
