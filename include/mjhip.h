@@ -265,6 +265,22 @@ int mjh_set_body_pose(mjh_engine*, int env, int body, const double pos[3], const
 int mjh_export_state_device(mjh_engine*, void* d_out);
 int mjh_state_stride(const mjh_engine*);
 
+/* Pinned host mirror of envs [env0, env0+n) for the publisher threads: the reference's ROS layer
+ * reads d->qpos / qvel / qfrc_inverse (joint states, mj_ros.cpp:2164-2194), d->xpos / xquat (tf, object states,
+ * :2096-2149) and d->geom_xpos / geom_xmat (markers, :1968-2094) at each topic's own rate.  mjh_mirror_update() enqueues
+ * an asynchronous refresh of the selected parts behind the steps queued so far and returns at once; mjh_mirror_wait()
+ * blocks until the latest refresh has landed; mjh_mirror_field() returns the fp32 rows (env-major, `row_width` floats per
+ * env) inside the pinned block. */
+typedef struct mjh_mirror mjh_mirror;
+enum { MJH_MIRROR_JOINTS = 1, MJH_MIRROR_BODIES = 2, MJH_MIRROR_GEOMS = 4 };
+enum { MJH_MIRROR_TIME = 0, MJH_MIRROR_QPOS = 1, MJH_MIRROR_QVEL = 2, MJH_MIRROR_QFRC_INVERSE = 3, MJH_MIRROR_XPOS = 4,
+       MJH_MIRROR_XQUAT = 5, MJH_MIRROR_GEOM_XPOS = 6, MJH_MIRROR_GEOM_XMAT = 7 };
+int mjh_mirror_create(mjh_engine*, int env0, int n, mjh_mirror** out);
+void mjh_mirror_destroy(mjh_mirror*);
+int mjh_mirror_update(mjh_mirror*, int what);
+int mjh_mirror_wait(mjh_mirror*);
+const float* mjh_mirror_field(const mjh_mirror*, int which, int* row_width);
+
 /* debug: mean shader-clock ticks from kernel start to each of the 16 stage boundaries of one fused step */
 int mjh_debug_stage_cycles(mjh_engine*, int with_inverse, double* out16);
 /* debug: raw stamps of one step launch, out[nenv*20] indexed by launch position: [0..15] shader-clock stage stamps,

@@ -144,6 +144,11 @@ SYMBOLS = [
     ("mjh_set_body_pose", C.c_int, [_vp, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p]),
     ("mjh_export_state_device", C.c_int, [_vp, _vp]),
     ("mjh_state_stride", C.c_int, [_vp]),
+    ("mjh_mirror_create", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    ("mjh_mirror_destroy", None, [_vp]),
+    ("mjh_mirror_update", C.c_int, [_vp, C.c_int]),
+    ("mjh_mirror_wait", C.c_int, [_vp]),
+    ("mjh_mirror_field", C.POINTER(C.c_float), [_vp, C.c_int, C.POINTER(C.c_int)]),
     ("mjh_debug_stage_cycles", C.c_int, [_vp, C.c_int, c_double_p]),
     ("mjh_debug_stage_raw", C.c_int, [_vp, C.c_int, _vp]),
     ("mjh_debug_stop_at", C.c_int, [_vp, C.c_int, C.c_int]),

@@ -727,6 +727,75 @@ extern "C" int mjh_set_body_pose(mjh_engine* e, int env, int body, const double 
   return MJH_OK;
 }
 
+// ---- pinned host mirror of a range of environments: what the reference's publisher threads read from
+// mjData (mj_ros.cpp:1968-2194: qpos / qvel / qfrc_inverse for joint states, xpos / xquat for tf and object states,
+// geom_xpos / geom_xmat for markers), refreshed asynchronously at each topic's rate instead of per step.
+struct mjh_mirror {
+  mjh_engine* e = nullptr; int env0 = 0, n = 0;
+  float* host = nullptr; float* dev = nullptr;          // pinned block / device staging of the FK exports
+  size_t off[8] = {0}; int width[8] = {0}; size_t total = 0, fk_floats = 0;
+  hipEvent_t ev = nullptr;
+};
+extern "C" int mjh_mirror_create(mjh_engine* e, int env0, int n, mjh_mirror** out) {
+  ENG(e); RANGE(e, env0, n);
+  if (!out || n <= 0) { mjh_set_error("mjh_mirror_create: bad argument"); return MJH_ERR_ARG; }
+  mjh_mirror* m = new mjh_mirror(); m->e = e; m->env0 = env0; m->n = n;
+  const int w[8] = {1, e->M.nq, e->M.nv, e->M.nv, 3 * e->M.nbody, 4 * e->M.nbody, 3 * e->M.ngeom, 9 * e->M.ngeom};
+  for (int k = 0; k < 8; k++) { m->width[k] = w[k]; m->off[k] = m->total; m->total += (size_t)n * w[k]; }
+  m->fk_floats = m->total - m->off[4];
+  if (hipHostMalloc((void**)&m->host, m->total * sizeof(float), hipHostMallocDefault) != hipSuccess ||
+      hipMalloc((void**)&m->dev, std::max<size_t>(m->fk_floats, 1) * sizeof(float)) != hipSuccess ||
+      hipEventCreateWithFlags(&m->ev, hipEventDisableTiming) != hipSuccess) {
+    mjh_set_error("mjh_mirror_create: allocation failed");
+    if (m->host) (void)hipHostFree(m->host); if (m->dev) (void)hipFree(m->dev); delete m; return MJH_ERR_NO_DEVICE;
+  }
+  std::memset(m->host, 0, m->total * sizeof(float));
+  *out = m;
+  return MJH_OK;
+}
+extern "C" void mjh_mirror_destroy(mjh_mirror* m) {
+  if (!m) return;
+  (void)hipEventSynchronize(m->ev);
+  (void)hipHostFree(m->host); (void)hipFree(m->dev); (void)hipEventDestroy(m->ev);
+  delete m;
+}
+// enqueue a refresh of the selected parts (MJH_MIRROR_* bits) behind everything queued so far; returns at once
+extern "C" int mjh_mirror_update(mjh_mirror* m, int what) {
+  if (!m) { mjh_set_error("null mirror"); return MJH_ERR_ARG; }
+  mjh_engine* e = m->e;
+  ENG(e);
+  const int n = m->n, env0 = m->env0;
+  auto rows = [&](int k, const float* src, int stride) {
+    return hipMemcpy2DAsync(m->host + m->off[k], (size_t)m->width[k] * sizeof(float), src + (size_t)env0 * stride, (size_t)stride * sizeof(float),
+                            (size_t)m->width[k] * sizeof(float), (size_t)n, hipMemcpyDeviceToHost, e->stream);
+  };
+  if (what & MJH_MIRROR_JOINTS) {
+    HIPCHK(rows(0, e->S.time, 1)); HIPCHK(rows(1, e->S.qpos, e->M.nqp)); HIPCHK(rows(2, e->S.qvel, e->M.nvp)); HIPCHK(rows(3, e->S.qfrc_inverse, e->M.nvp));
+  }
+  if (what & (MJH_MIRROR_BODIES | MJH_MIRROR_GEOMS)) {
+    DState saved = e->S;
+    float* d = m->dev;
+    e->S.x_xpos = d; e->S.x_xquat = d + (m->off[5] - m->off[4]); e->S.x_gpos = d + (m->off[6] - m->off[4]); e->S.x_gmat = d + (m->off[7] - m->off[4]);
+    const int xf = ((what & MJH_MIRROR_BODIES) ? XF_BODY : 0) | ((what & MJH_MIRROR_GEOMS) ? XF_GEOM : 0);
+    int rc = launch(e, env0, n, 1, PH_FKONLY, xf);
+    e->S = saved;
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(m->host + m->off[4], d, m->fk_floats * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  }
+  HIPCHK(hipEventRecord(m->ev, e->stream));
+  return MJH_OK;
+}
+extern "C" int mjh_mirror_wait(mjh_mirror* m) {
+  if (!m) { mjh_set_error("null mirror"); return MJH_ERR_ARG; }
+  HIPCHK(hipEventSynchronize(m->ev));
+  return MJH_OK;
+}
+extern "C" const float* mjh_mirror_field(const mjh_mirror* m, int which, int* row_width) {
+  if (!m || which < 0 || which > 7) return nullptr;
+  if (row_width) *row_width = m->width[which];
+  return m->host + m->off[which];
+}
+
 extern "C" int mjh_state_stride(const mjh_engine* e) { return e ? 1 + e->M.nq + e->M.nv : 0; }
 extern "C" int mjh_export_state_device(mjh_engine* e, void* d_out) {
   ENG_NOJOIN(e); if (!d_out) return MJH_ERR_ARG;

@@ -754,3 +754,36 @@ def test_set_timestep_takes_effect_with_the_next_launch(lib):
     with pytest.raises(MjhError):
         e.set_timestep(0.0)
     e.close()
+
+
+@pytest.mark.gpu
+def test_pinned_host_mirror_matches_getters(s24, lib):
+    """F3: the asynchronous pinned mirror of an env range (joint state, body poses, geom poses) equals the blocking getters"""
+    import ctypes as C
+    m, e, tab, ds = s24
+    e.reset(); e.step(30, True)
+    env0, n = 2, 5
+    h = C.c_void_p()
+    assert lib.mjh_mirror_create(e.h, env0, n, C.byref(h)) == 0
+    try:
+        assert lib.mjh_mirror_update(h, 1 | 2 | 4) == 0
+        e.step(3)                                   # more work queued behind the refresh: the mirror keeps the earlier state
+        assert lib.mjh_mirror_wait(h) == 0
+        def field(which):
+            w = C.c_int(0)
+            p = lib.mjh_mirror_field(h, which, C.byref(w))
+            return np.ctypeslib.as_array(p, shape=(n, w.value)).copy()
+        got = {k: field(k) for k in range(8)}
+    finally:
+        lib.mjh_mirror_destroy(h)
+    f = ms.Engine(m, e.nenv); 
+    for k in EP: f.set_env_param(k, tab[k])
+    f.set_initial_qpos(tab["qpos"]); f.reset(); f.step(30, True)
+    t, q, v, w = f.get_state(env0, n); qj, vj, fi = f.get_joint_state(env0, n)
+    xp, xq = f.get_body_state(env0, n); gp, gm = f.get_geom_state(env0, n)
+    f.close()
+    np.testing.assert_allclose(got[0][:, 0], t, rtol=1e-6)
+    assert np.array_equal(got[1], q.astype(np.float32)) and np.array_equal(got[2], v.astype(np.float32))
+    assert np.array_equal(got[3], fi.astype(np.float32))
+    np.testing.assert_allclose(got[4], xp.reshape(n, -1), atol=1e-6); np.testing.assert_allclose(got[5], xq.reshape(n, -1), atol=1e-6)
+    np.testing.assert_allclose(got[6], gp.reshape(n, -1), atol=1e-6); np.testing.assert_allclose(got[7], gm.reshape(n, -1), atol=1e-6)
