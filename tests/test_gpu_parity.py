@@ -787,3 +787,17 @@ def test_pinned_host_mirror_matches_getters(s24, lib):
     assert np.array_equal(got[3], fi.astype(np.float32))
     np.testing.assert_allclose(got[4], xp.reshape(n, -1), atol=1e-6); np.testing.assert_allclose(got[5], xq.reshape(n, -1), atol=1e-6)
     np.testing.assert_allclose(got[6], gp.reshape(n, -1), atol=1e-6); np.testing.assert_allclose(got[7], gm.reshape(n, -1), atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nenv", [1, 63, 1025, 2051])
+def test_odd_batch_sizes_with_cohorts_and_launch_order(nenv):
+    """uneven cohort splits, env counts that are not multiples of the wave / bucket sizes: bitwise equal to one cohort"""
+    m = ms.scene("s24")
+    a = ms.Engine(m, nenv); a.load_s24(); a.set_cohorts(3 if nenv > 64 else 1)
+    b = ms.Engine(m, nenv); b.load_s24(); b.set_cohorts(1)
+    a.step(45); b.step(45)
+    ta, qa, va, wa = a.get_state(); tb, qb, vb, wb = b.get_state()
+    assert np.array_equal(qa, qb) and np.array_equal(va, vb) and np.array_equal(a.get_stats(), b.get_stats())
+    assert np.isfinite(qa).all()
+    a.close(); b.close()
