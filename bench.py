@@ -195,7 +195,7 @@ def main():
                      "valu_issue_busy": valu_busy,   # SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x resident waves per SIMD (profiles/): the binding resource
                      "note": "fused per-env pipeline keeps intermediates in LDS: the path is VALU-issue bound, far below the HBM roofline by design (DESIGN.md)"},
     }
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is timed at N = 1 only
         out["cpu_baseline"] = cpu_baseline(model, eng, tab, 0, min(args.cpu_envs, nenv), args.cpu_steps, args.with_inverse)
     if use_dist:
         dist.barrier()
