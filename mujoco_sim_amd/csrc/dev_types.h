@@ -73,7 +73,7 @@ struct Lay {
   // many-body layout, three-launch step: float offsets into the env's global scratch slice of the hand-over vectors
   // (initial acceleration, 1/M_dd, velocity after the controller, smooth force, solved acceleration) and of 8 ints of
   // meta data (nblk, nfixblk, nefc, ncon, flags, solver iterations)
-  int g_a0, g_minv, g_qvel, g_smooth, g_qacc, g_meta;
+  int g_a0, g_minv, g_qvel, g_smooth, g_qacc, g_meta, g_qM;
 };
 
 struct DConst { DModel M; Lay L; };

@@ -273,7 +273,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     L.zero = put(4);
     if (big) {   // hand-over vectors of the three-launch step (non-negative offsets into the scratch slice)
       auto graw = [&](int n) { long long o = goff; goff += ((std::max(n, 1) + 3) / 4) * 4; return (int)o; };
-      L.g_a0 = graw(nv); L.g_minv = graw(nv); L.g_qvel = graw(nv); L.g_smooth = graw(nv); L.g_qacc = graw(nv); L.g_meta = graw(8);
+      L.g_a0 = graw(nv); L.g_minv = graw(nv); L.g_qvel = graw(nv); L.g_smooth = graw(nv); L.g_qacc = graw(nv); L.g_meta = graw(8); L.g_qM = graw(m->nM);
     }
     hp.gstride = goff;
     L.total = off;

@@ -544,6 +544,20 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       }
     }
     // ================================================================ position stage
+    if (post) {
+      // three-launch step: the integrate launch only needs what mj_kinematics does to qpos (quaternion normalisation) and
+      // the mass matrix for the implicit-damping solve, handed over by the assemble launch
+      for (int j = lane; j < njnt; j += 64) {
+        const int jt = jnt_type[j], qa = jnt_qposadr[j] + (jt == MJH_JNT_FREE ? 3 : 0);
+        if (jt == MJH_JNT_FREE || jt == MJH_JNT_BALL) {
+          float q[4] = {s_qpos[qa], s_qpos[qa+1], s_qpos[qa+2], s_qpos[qa+3]};
+          normalize4(q);
+          s_qpos[qa] = q[0]; s_qpos[qa+1] = q[1]; s_qpos[qa+2] = q[2]; s_qpos[qa+3] = q[3];
+        }
+      }
+      for (int i = lane; i < M.nM; i += 64) s_qM[i] = gs[L.g_qM + i];
+      WSYNC();
+    } else {
     // ---- FK (mj_kinematics)
     if (lane == 0) {
       s_xpos[0] = s_xpos[1] = s_xpos[2] = 0; s_xquat[0] = 1; s_xquat[1] = s_xquat[2] = s_xquat[3] = 0;
@@ -718,6 +732,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       for (int t = lane; t < M.ntree; t += 64) if (tree_dofnum[t] < MJH_WAVE_TREE_MIN) factor_tree(s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t]);
     }
     WSYNC();
+    }   // !post
 
     PROF(4);
     // ---- collision (mj_collision): lanes = candidate geom pairs of the static pair list
@@ -1442,6 +1457,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       if (pre) {   // hand-over to mjh_solve_kernel / the PH_POST launch
         int* meta = (int*)(gs + L.g_meta);
         for (int d = lane; d < nv; d += 64) { gs[L.g_qvel + d] = s_qvel[d]; gs[L.g_smooth + d] = s_smooth[d]; if (nefc == 0) gs[L.g_qacc + d] = s_asmooth[d]; }
+        for (int i = lane; i < M.nM; i += 64) gs[L.g_qM + i] = s_qM[i];
         if (lane == 0) { meta[0] = nefc == 0 ? 0 : nblk; meta[1] = nfixblk; meta[2] = nefc; meta[3] = ncon; meta[4] = flags; meta[5] = 0; meta[6] = ngrp; }
         if (nefc == 0) return;
       }
