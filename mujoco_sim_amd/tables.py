@@ -1,0 +1,48 @@
+"""Compiled model tables <-> .npz: every field of struct mjh_model (include/mjhip.h) in one file, so that a model compiled once
+(e.g. from a reference data file by the MJCF loader) can be rebuilt where the file is not available.  Plumbing for tests,
+fixtures and the bench tools; no physics."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .engine import Model
+
+_OPT_FIELDS = ["timestep", "iterations", "tolerance", "impratio", "noslip_iterations", "disableflags"]
+
+
+def save_model_tables(m, path, **extra):
+    d = {"int__" + k: np.int64(getattr(m.c, k)) for k in capi._INT_SIZES}
+    d["meaninertia"] = np.float64(m.c.meaninertia)
+    for k in _OPT_FIELDS:
+        d["opt__" + k] = np.float64(getattr(m.c.opt, k))
+    d["opt__gravity"] = np.array(list(m.c.opt.gravity), dtype=np.float64)
+    for n, t, _ in capi._ARRAYS:
+        d["arr__" + n] = m.array(n)
+    d.update(extra)
+    np.savez_compressed(path, **d)
+
+
+def load_model_tables(path):
+    """-> (ms.Model over a ctypes mjh_model whose arrays are numpy buffers kept alive by the object, npz)"""
+    z = np.load(path)
+    st = capi.Model()
+    for k in capi._INT_SIZES:
+        setattr(st, k, int(z["int__" + k]))
+    st.meaninertia = float(z["meaninertia"])
+    for k in _OPT_FIELDS:
+        v = z["opt__" + k]
+        setattr(st.opt, k, int(v) if k in ("iterations", "noslip_iterations", "disableflags") else float(v))
+    for i in range(3):
+        st.opt.gravity[i] = float(z["opt__gravity"][i])
+    keep = []
+    for n, t, _ in capi._ARRAYS:
+        a = np.ascontiguousarray(z["arr__" + n], dtype=np.int32 if t == "i" else np.float64)
+        if a.size == 0:
+            a = np.zeros(1, dtype=a.dtype)
+        keep.append(a)
+        setattr(st, n, a.ctypes.data_as(capi.c_int_p if t == "i" else capi.c_double_p))
+    m = Model(C.pointer(st))
+    m._keep = (st, keep)
+    m.note = "rebuilt from compiled tables"
+    return m, z

@@ -2,11 +2,11 @@
    name: pr2_world | hsrb4s_world | ridgeback_panda | tiago | ...   (C3: ridgeback_panda at 8192 envs, C4: pr2_world at 2048)"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import mujoco_sim_amd as ms
-from helpers import load_model_tables
-from test_robot_fixtures import robot_command
+from mujoco_sim_amd.tables import load_model_tables
+from robot_common import robot_command
 name = sys.argv[1]; nenv = int(sys.argv[2]) if len(sys.argv) > 2 else 2048; steps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 m, z = load_model_tables(os.path.join(ROOT, "tests", "golden", f"robot_{name}.npz"))
 e = ms.Engine(m, nenv); e.set_controlled_dofs(z["controlled"].astype(np.int32))
