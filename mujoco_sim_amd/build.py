@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmjhip.so")
 SOURCES = ["engine.hip", "model_builder.cpp", "scenes.cpp", "host_sim.cpp", "mjcf_loader.cpp"]
-DEPS = SOURCES + ["step_kernel.h", "dev_math.h", "dev_collide.h", "dev_types.h", "hmath.h", "host_sim.h",
+DEPS = SOURCES + ["step_kernel.h", "dev_math.h", "dev_collide.h", "dev_convex.h", "dev_types.h", "hmath.h", "host_sim.h",
                   os.path.join("..", "..", "include", "mjhip.h")]
 
 

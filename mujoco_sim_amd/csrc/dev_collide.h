@@ -74,6 +74,24 @@ DEV int c_plane_cylinder(const float* pp, const float* pm, const float* c, const
   return cnt;
 }
 
+// plane - ellipsoid: the support point of the ellipsoid against the plane normal
+DEV int c_plane_ellipsoid(const float* pp, const float* pm, const float* c, const float* em, const float* size, float margin, float* st) {
+  const float n[3] = {pm[2], pm[5], pm[8]}, nn[3] = {-n[0], -n[1], -n[2]};
+  float dl[3], pl[3], pw[3];
+  rotvecT(dl, em, nn);
+  const float w[3] = {size[0]*size[0]*dl[0], size[1]*size[1]*dl[1], size[2]*size[2]*dl[2]};
+  const float inv = rsqrtf(fmaxf(w[0]*dl[0] + w[1]*dl[1] + w[2]*dl[2], 1e-30f));
+  pl[0] = w[0]*inv; pl[1] = w[1]*inv; pl[2] = w[2]*inv;
+  rotvec(pw, em, pl);
+  pw[0] += c[0]; pw[1] += c[1]; pw[2] += c[2];
+  const float t[3] = {pw[0]-pp[0], pw[1]-pp[1], pw[2]-pp[2]};
+  const float dist = dot3(t, n);
+  if (dist > margin) return 0;
+  const float pos[3] = {pw[0] - n[0]*0.5f*dist, pw[1] - n[1]*0.5f*dist, pw[2] - n[2]*0.5f*dist};
+  raw_emit(st, 0, dist, pos, n);
+  return 1;
+}
+
 DEV int c_plane_box(const float* pp, const float* pm, const float* c, const float* bm, const float* size, float margin, float* st) {
   float n[3] = {pm[2], pm[5], pm[8]}, t[3] = {c[0]-pp[0], c[1]-pp[1], c[2]-pp[2]};
   float dist = dot3(t, n);

@@ -28,7 +28,7 @@ struct DModel {
 #undef X
   int nq, nv, nbody, njnt, ngeom, neq, npair, nM, ntree, maxcon, maxefc;
   int nqp, nvp;        // padded row strides of the per-env state arrays (floats)
-  int maxlevel, nfl, ngc, rowW, nstage, has_damping, has_limits, diagM, maxblk, maxbrow, has_dim4, big, k1_floats;
+  int maxlevel, nfl, ngc, rowW, nstage, has_damping, has_limits, diagM, maxblk, maxbrow, has_dim4, big, k1_floats, has_convex;
   int iterations, disableflags;
   float timestep, gravity[3], tolerance, impratio, meaninertia;
 };

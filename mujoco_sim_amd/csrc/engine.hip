@@ -204,6 +204,12 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
   M.has_damping = has_damping; M.has_limits = has_limits; M.diagM = diagM;
   M.has_dim4 = 0;
   for (int g = 0; g < ng; g++) if (m->geom_condim[g] == 4) M.has_dim4 = 1;
+  M.has_convex = 0;   // some pair needs the generic convex narrow phase (cylinder-x, capsule-box, ellipsoid-x)
+  for (int i = 0; i < m->npair; i++) {
+    const int t1 = m->geom_type[m->pair_geom1[i]], t2 = m->geom_type[m->pair_geom2[i]];
+    if (t1 != MJH_GEOM_PLANE && (t1 == MJH_GEOM_ELLIPSOID || t2 == MJH_GEOM_ELLIPSOID || t1 == MJH_GEOM_CYLINDER || t2 == MJH_GEOM_CYLINDER ||
+                                 t2 == MJH_GEOM_MESH || (t1 == MJH_GEOM_CAPSULE && t2 == MJH_GEOM_BOX))) M.has_convex = 1;
+  }
   {
     // a limited joint can have both sides active only if its margins overlap (range narrower than 2 margins)
     int nlim = 0; for (int j = 0; j < nj; j++) if (m->jnt_limited[j]) nlim += (m->jnt_range[2*j+1] - m->jnt_range[2*j] <= 2 * m->jnt_margin[j]) ? 2 : 1;

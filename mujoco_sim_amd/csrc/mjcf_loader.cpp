@@ -127,7 +127,7 @@ struct Loader {
     if (type) {
       std::string t = type;
       if (t == "plane") gt = MJH_GEOM_PLANE; else if (t == "sphere") gt = MJH_GEOM_SPHERE; else if (t == "capsule") gt = MJH_GEOM_CAPSULE;
-      else if (t == "cylinder") gt = MJH_GEOM_CYLINDER; else if (t == "box") gt = MJH_GEOM_BOX;
+      else if (t == "cylinder") gt = MJH_GEOM_CYLINDER; else if (t == "box") gt = MJH_GEOM_BOX; else if (t == "ellipsoid") gt = MJH_GEOM_ELLIPSOID;
       else { note += "skipped <geom type=\"" + t + "\">; "; return; }
     }
     if (n.get("fromto")) { note += "skipped <geom fromto>; "; return; }

@@ -153,6 +153,10 @@ static bool geom_massprops(const BGeom& g, double* mass, double I[3]) {
       double Izz = 0.5 * mc * r*r + 0.4 * ms * r*r;
       double Ixx = mc * (3*r*r + 4*h*h) / 12.0 + ms * (0.4*r*r + h*h + 0.75*r*h);
       I[0] = I[1] = Ixx; I[2] = Izz; return true; }
+    case MJH_GEOM_ELLIPSOID: {
+      double m = g.density * 4.0 / 3.0 * pi * s[0]*s[1]*s[2];
+      *mass = m;
+      I[0] = 0.2 * m * (s[1]*s[1] + s[2]*s[2]); I[1] = 0.2 * m * (s[0]*s[0] + s[2]*s[2]); I[2] = 0.2 * m * (s[0]*s[0] + s[1]*s[1]); return true; }
     default: return false;  // plane etc: no mass
   }
 }
@@ -163,6 +167,7 @@ static double geom_rbound(int type, const double* s) {
     case MJH_GEOM_CAPSULE: return s[0] + s[1];
     case MJH_GEOM_CYLINDER: return std::sqrt(s[0]*s[0] + s[1]*s[1]);
     case MJH_GEOM_BOX: return std::sqrt(s[0]*s[0] + s[1]*s[1] + s[2]*s[2]);
+    case MJH_GEOM_ELLIPSOID: return std::max(s[0], std::max(s[1], s[2]));
     default: return 0;  // plane: unbounded, handled by the pair routine
   }
 }
@@ -172,12 +177,9 @@ extern "C" double mjh_geom_rbound(int type, const double* size) { return geom_rb
 static bool pair_supported(int t1, int t2) {
   if (t1 > t2) std::swap(t1, t2);
   auto is = [](int t, int a) { return t == a; };
-  if (is(t1, MJH_GEOM_PLANE))
-    return t2 == MJH_GEOM_SPHERE || t2 == MJH_GEOM_CAPSULE || t2 == MJH_GEOM_BOX || t2 == MJH_GEOM_CYLINDER;
-  if (is(t1, MJH_GEOM_SPHERE)) return t2 == MJH_GEOM_SPHERE || t2 == MJH_GEOM_CAPSULE || t2 == MJH_GEOM_BOX;
-  if (is(t1, MJH_GEOM_CAPSULE)) return t2 == MJH_GEOM_CAPSULE;   // capsule-box: no narrow phase yet
-  if (is(t1, MJH_GEOM_BOX)) return t2 == MJH_GEOM_BOX;
-  return false;
+  if (is(t1, MJH_GEOM_HFIELD) || is(t2, MJH_GEOM_HFIELD) || is(t2, MJH_GEOM_MESH)) return false;   // mesh geoms: not yet
+  if (is(t1, MJH_GEOM_PLANE)) return t2 != MJH_GEOM_PLANE;
+  return true;   // analytic routine, or the generic convex narrow phase (cylinder-x, capsule-box, ellipsoid-x)
 }
 static int pair_maxcon(int t1, int t2) {
   if (t1 > t2) std::swap(t1, t2);

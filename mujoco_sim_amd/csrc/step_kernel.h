@@ -12,6 +12,7 @@
 //   MjSim::set_odom_vels (mj_sim.cpp:1079-1153)          "odom"
 #pragma once
 #include "dev_collide.h"
+#include "dev_convex.h"
 #include "dev_types.h"
 
 #define WSYNC() __syncthreads()
@@ -748,7 +749,9 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           st = s_stage + pair_stageadr[ip] * RAW_STRIDE;
           const int t1 = geom_type[g1], t2 = geom_type[g2];
           margin = fmaxf(geom_margin[g1], geom_margin[g2]); gap = fmaxf(geom_gap[g1], geom_gap[g2]);
-          float p1[3], p2[3], m1[9], m2[9], z1[3], z2[3];
+          CvxGeom G1, G2;
+          G1.type = t1; G2.type = t2; G1.vert = G2.vert = nullptr; G1.nvert = G2.nvert = 0;
+          float *p1 = G1.pos, *p2 = G2.pos, *m1 = G1.mat, *m2 = G2.mat, *z1 = G1.size, *z2 = G2.size;
 #pragma unroll
           for (int k = 0; k < 3; k++) { p1[k] = s_gpos[3*g1+k]; p2[k] = s_gpos[3*g2+k]; z1[k] = s_p_gsize[3*g1+k]; z2[k] = s_p_gsize[3*g2+k]; }
 #pragma unroll
@@ -769,6 +772,8 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             else if (t1 == MJH_GEOM_SPHERE && t2 == MJH_GEOM_CAPSULE) n = c_sphere_capsule(p1, z1[0], p2, m2, z2, margin, st);
             else if (t1 == MJH_GEOM_CAPSULE && t2 == MJH_GEOM_CAPSULE) n = c_capsule_capsule(p1, m1, z1, p2, m2, z2, margin, st);
             else if (t1 == MJH_GEOM_SPHERE && t2 == MJH_GEOM_BOX) n = c_sphere_box(p1, z1[0], p2, m2, z2, margin, st);
+            else if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_ELLIPSOID) n = c_plane_ellipsoid(p1, m1, p2, m2, z2, margin, st);
+            else if (M.has_convex && pair_is_convex(t1, t2)) n = c_convex(G1, G2, margin, st);
           }
         }
         const int incl = wave_incl_scan_i(n, lane);

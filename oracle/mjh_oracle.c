@@ -440,6 +440,22 @@ static int c_plane_cylinder(const double* pp, const double* pm, const double* c,
   return cnt;
 }
 /* [UPSTREAM mjc_PlaneBox]: corners below the centre, at most 4 */
+/* [UPSTREAM mjc_PlaneConvex for an ellipsoid]: the support point of the ellipsoid against the plane normal */
+static int c_plane_ellipsoid(const double* pp, const double* pm, const double* c, const double* em, const double* size, double margin, rawcon* out) {
+  double n[3] = {pm[2], pm[5], pm[8]}, nn[3] = {-n[0], -n[1], -n[2]}, dl[3], pl[3], pw[3], w[3];
+  rotvecT(dl, em, nn);
+  for (int k = 0; k < 3; k++) w[k] = size[k]*size[k]*dl[k];
+  double den = sqrt(fmax(w[0]*dl[0] + w[1]*dl[1] + w[2]*dl[2], 1e-30));
+  for (int k = 0; k < 3; k++) pl[k] = w[k] / den;
+  rotvec(pw, em, pl);
+  double t[3];
+  for (int k = 0; k < 3; k++) { pw[k] += c[k]; t[k] = pw[k] - pp[k]; }
+  double dist = dot3(t, n);
+  if (dist > margin) return 0;
+  out->dist = dist; copyv(out->n, n, 3);
+  for (int k = 0; k < 3; k++) out->pos[k] = pw[k] - n[k] * 0.5 * dist;
+  return 1;
+}
 static int c_plane_box(const double* pp, const double* pm, const double* c, const double* bm, const double* size, double margin, rawcon* out) {
   double n[3] = {pm[2], pm[5], pm[8]}, t[3] = {c[0]-pp[0], c[1]-pp[1], c[2]-pp[2]};
   double dist = dot3(t, n);
@@ -636,6 +652,194 @@ int orc_box_box(const double* p1, const double* m1, const double* s1, const doub
   return cnt;
 }
 
+/* ---- generic convex - convex narrow phase: Minkowski portal refinement (MPR, G. Snethen, "XenoCollide", Game
+ * Programming Gems 7) over support mappings, one contact per pair.  [UPSTREAM mjc_Convex: MuJoCo 2.3.7 sends every
+ * pair without an analytic routine (cylinder-x, capsule-box, ellipsoid-x, mesh-x) through libccd's MPR with
+ * mpr_tolerance 1e-6 and mpr_iterations 50 and keeps a single contact; margin is handled by inflating both geoms by
+ * margin/2.]  The restatement below is this project's own; the device routine (csrc/dev_convex.h) follows it step
+ * for step in fp32. */
+#define MPR_TOL 1e-6
+#define MPR_ITER 50
+#define MPR_EPS 1e-10
+typedef struct { int type; const double *pos, *mat, *size; double pad; const double* vert; int nvert; } cvx_geom;
+typedef struct { double v[3], a[3], b[3]; } mpr_pt;   /* v = a - b: point of the Minkowski difference with its witnesses */
+
+/* farthest point of the geom along the unit world direction `dir` */
+static void cvx_support(const cvx_geom* g, const double* dir, double* out) {
+  double dl[3], pl[3] = {0, 0, 0};
+  rotvecT(dl, g->mat, dir);
+  const double* s = g->size;
+  switch (g->type) {
+    case MJH_GEOM_SPHERE: for (int k = 0; k < 3; k++) pl[k] = s[0] * dl[k]; break;
+    case MJH_GEOM_CAPSULE: for (int k = 0; k < 3; k++) pl[k] = s[0] * dl[k]; pl[2] += dl[2] >= 0 ? s[1] : -s[1]; break;
+    case MJH_GEOM_CYLINDER: {
+      double r2 = dl[0]*dl[0] + dl[1]*dl[1];
+      if (r2 > MPR_EPS) { double sc = s[0] / sqrt(r2); pl[0] = dl[0] * sc; pl[1] = dl[1] * sc; }
+      pl[2] = dl[2] >= 0 ? s[1] : -s[1];
+    } break;
+    case MJH_GEOM_BOX: for (int k = 0; k < 3; k++) pl[k] = dl[k] >= 0 ? s[k] : -s[k]; break;
+    case MJH_GEOM_ELLIPSOID: {
+      double w[3] = {s[0]*s[0]*dl[0], s[1]*s[1]*dl[1], s[2]*s[2]*dl[2]};
+      double den = sqrt(w[0]*dl[0] + w[1]*dl[1] + w[2]*dl[2]);
+      if (den > MINVAL) for (int k = 0; k < 3; k++) pl[k] = w[k] / den;
+    } break;
+    case MJH_GEOM_MESH: {
+      double best = -1e300; int bi = 0;
+      for (int i = 0; i < g->nvert; i++) { double dp = dot3(g->vert + 3*i, dl); if (dp > best) { best = dp; bi = i; } }
+      if (g->nvert) copyv(pl, g->vert + 3*bi, 3);
+    } break;
+    default: break;
+  }
+  rotvec(out, g->mat, pl);
+  for (int k = 0; k < 3; k++) out[k] += g->pos[k] + g->pad * dir[k];
+}
+static void mpr_support(const cvx_geom* g1, const cvx_geom* g2, const double* dir, mpr_pt* p) {
+  double nd[3] = {-dir[0], -dir[1], -dir[2]};
+  cvx_support(g1, dir, p->a); cvx_support(g2, nd, p->b);
+  for (int k = 0; k < 3; k++) p->v[k] = p->a[k] - p->b[k];
+}
+static void tri_normal(double* n, const mpr_pt* p1, const mpr_pt* p2, const mpr_pt* p3) {
+  double e1[3], e2[3];
+  for (int k = 0; k < 3; k++) { e1[k] = p2->v[k] - p1->v[k]; e2[k] = p3->v[k] - p1->v[k]; }
+  cross3(n, e1, e2); normalize3(n);
+}
+/* the support point p4 is no further out along n than the portal by more than the tolerance */
+static int mpr_converged(const mpr_pt* p1, const mpr_pt* p2, const mpr_pt* p3, const mpr_pt* p4, const double* n) {
+  double d4 = dot3(p4->v, n), m = d4 - dot3(p1->v, n), m2 = d4 - dot3(p2->v, n), m3 = d4 - dot3(p3->v, n);
+  if (m2 < m) m = m2;
+  if (m3 < m) m = m3;
+  return m <= MPR_TOL;
+}
+/* replace the portal vertex that keeps the ray (interior point -> origin) inside the portal */
+static void mpr_expand(const mpr_pt* p0, mpr_pt* p1, mpr_pt* p2, mpr_pt* p3, const mpr_pt* p4) {
+  double c[3];
+  cross3(c, p4->v, p0->v);
+  if (dot3(p1->v, c) > 0) { if (dot3(p2->v, c) > 0) *p1 = *p4; else *p3 = *p4; }
+  else { if (dot3(p3->v, c) > 0) *p2 = *p4; else *p1 = *p4; }
+}
+/* closest point of triangle (a,b,c) to the origin (Voronoi-region walk) */
+static void tri_closest_to_origin(const double* a, const double* b, const double* c, double* out) {
+  double ab[3], ac[3], ap[3], bp[3], cp[3];
+  for (int k = 0; k < 3; k++) { ab[k] = b[k]-a[k]; ac[k] = c[k]-a[k]; ap[k] = -a[k]; bp[k] = -b[k]; cp[k] = -c[k]; }
+  double d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+  if (d1 <= 0 && d2 <= 0) { copyv(out, a, 3); return; }
+  double d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+  if (d3 >= 0 && d4 <= d3) { copyv(out, b, 3); return; }
+  double vc = d1*d4 - d3*d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) { double t = d1 / (d1 - d3); for (int k = 0; k < 3; k++) out[k] = a[k] + t*ab[k]; return; }
+  double d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+  if (d6 >= 0 && d5 <= d6) { copyv(out, c, 3); return; }
+  double vb = d5*d2 - d1*d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) { double t = d2 / (d2 - d6); for (int k = 0; k < 3; k++) out[k] = a[k] + t*ac[k]; return; }
+  double va = d3*d6 - d5*d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { double t = (d4 - d3) / ((d4 - d3) + (d5 - d6)); for (int k = 0; k < 3; k++) out[k] = b[k] + t*(c[k]-b[k]); return; }
+  double den = 1.0 / (va + vb + vc), v = vb * den, w = vc * den;
+  for (int k = 0; k < 3; k++) out[k] = a[k] + v*ab[k] + w*ac[k];
+}
+/* 1 = the geoms overlap: depth, direction (geom1 -> geom2) and position of the single contact */
+static int mpr_penetration(const cvx_geom* g1, const cvx_geom* g2, double* depth, double* dir, double* pos) {
+  mpr_pt p0, p1, p2, p3, p4;
+  double n[3], c[3];
+  /* interior point of the Minkowski difference: the centre difference */
+  for (int k = 0; k < 3; k++) { p0.a[k] = g1->pos[k]; p0.b[k] = g2->pos[k]; p0.v[k] = p0.a[k] - p0.b[k]; }
+  if (dot3(p0.v, p0.v) < MPR_EPS) p0.v[0] += 1e-4;
+  for (int k = 0; k < 3; k++) n[k] = -p0.v[k];
+  normalize3(n);
+  mpr_support(g1, g2, n, &p1);
+  if (dot3(p1.v, n) <= 0) return 0;
+  cross3(n, p0.v, p1.v);
+  if (dot3(n, n) < 1e-12 * dot3(p0.v, p0.v) * dot3(p1.v, p1.v)) {   /* the origin lies on the ray through p0 and p1: penetration along that ray */
+    *depth = norm3(p1.v);
+    copyv(dir, p1.v, 3); normalize3(dir);
+    for (int k = 0; k < 3; k++) pos[k] = 0.5 * (p1.a[k] + p1.b[k]);
+    return 1;
+  }
+  normalize3(n);
+  mpr_support(g1, g2, n, &p2);
+  if (dot3(p2.v, n) <= 0) return 0;
+  /* portal discovery: a triangle (p1,p2,p3) that the ray p0 -> origin passes through */
+  { double e1[3], e2[3];
+    for (int k = 0; k < 3; k++) { e1[k] = p1.v[k] - p0.v[k]; e2[k] = p2.v[k] - p0.v[k]; }
+    cross3(n, e1, e2); normalize3(n);
+    if (dot3(n, p0.v) > 0) { mpr_pt t = p1; p1 = p2; p2 = t; for (int k = 0; k < 3; k++) n[k] = -n[k]; } }
+  for (int it = 0;; it++) {
+    if (it > MPR_ITER) return 0;
+    mpr_support(g1, g2, n, &p3);
+    if (dot3(p3.v, n) <= 0) return 0;
+    int again = 0;
+    cross3(c, p1.v, p3.v);
+    if (dot3(c, p0.v) < -MPR_EPS) { p2 = p3; again = 1; }
+    else { cross3(c, p3.v, p2.v); if (dot3(c, p0.v) < -MPR_EPS) { p1 = p3; again = 1; } }
+    if (!again) break;
+    double e1[3], e2[3];
+    for (int k = 0; k < 3; k++) { e1[k] = p1.v[k] - p0.v[k]; e2[k] = p2.v[k] - p0.v[k]; }
+    cross3(n, e1, e2); normalize3(n);
+  }
+  /* portal refinement until the origin is on the inner side of the portal (hit) or provably outside (miss) */
+  for (int it = 0;; it++) {
+    tri_normal(n, &p1, &p2, &p3);
+    if (dot3(n, p1.v) >= -MPR_EPS) break;
+    mpr_support(g1, g2, n, &p4);
+    if (dot3(p4.v, n) < -MPR_EPS || mpr_converged(&p1, &p2, &p3, &p4, n) || it > MPR_ITER) return 0;
+    mpr_expand(&p0, &p1, &p2, &p3, &p4);
+  }
+  /* push the portal to the surface */
+  for (int it = 0;; it++) {
+    tri_normal(n, &p1, &p2, &p3);
+    mpr_support(g1, g2, n, &p4);
+    if (mpr_converged(&p1, &p2, &p3, &p4, n) || it > MPR_ITER) break;
+    mpr_expand(&p0, &p1, &p2, &p3, &p4);
+  }
+  tri_closest_to_origin(p1.v, p2.v, p3.v, c);
+  *depth = norm3(c);
+  if (*depth < MPR_EPS) copyv(dir, n, 3); else for (int k = 0; k < 3; k++) dir[k] = c[k] / *depth;
+  /* position: barycentric coordinates of the origin in the tetrahedron (p0,p1,p2,p3) applied to the witnesses */
+  { double b[4], x[3], sum;
+    cross3(x, p1.v, p2.v); b[0] = dot3(x, p3.v);
+    cross3(x, p3.v, p2.v); b[1] = dot3(x, p0.v);
+    cross3(x, p0.v, p1.v); b[2] = dot3(x, p3.v);
+    cross3(x, p2.v, p1.v); b[3] = dot3(x, p0.v);
+    sum = b[0] + b[1] + b[2] + b[3];
+    if (sum <= 0) {
+      b[0] = 0;
+      cross3(x, p2.v, p3.v); b[1] = dot3(x, n);
+      cross3(x, p3.v, p1.v); b[2] = dot3(x, n);
+      cross3(x, p1.v, p2.v); b[3] = dot3(x, n);
+      sum = b[1] + b[2] + b[3];
+    }
+    const mpr_pt* P[4] = {&p0, &p1, &p2, &p3};
+    for (int k = 0; k < 3; k++) {
+      double acc = 0;
+      for (int q = 0; q < 4; q++) acc += b[q] * (P[q]->a[k] + P[q]->b[k]);
+      pos[k] = 0.5 * acc / sum;
+    } }
+  return 1;
+}
+static int c_convex(const cvx_geom* g1, const cvx_geom* g2, double margin, rawcon* out) {
+  cvx_geom a = *g1, b = *g2;
+  a.pad = b.pad = 0.5 * margin;
+  double depth, dir[3], pos[3];
+  if (!mpr_penetration(&a, &b, &depth, dir, pos)) return 0;
+  out->dist = margin - depth; copyv(out->pos, pos, 3); copyv(out->n, dir, 3);
+  return 1;
+}
+/* test hook: one convex pair */
+int orc_convex_pair(int t1, const double* p1, const double* m1, const double* s1, int t2, const double* p2, const double* m2, const double* s2,
+                    double margin, double* dist, double* pos, double* normal) {
+  cvx_geom a = {t1, p1, m1, s1, 0, 0, 0}, b = {t2, p2, m2, s2, 0, 0, 0};
+  rawcon rc;
+  int n = c_convex(&a, &b, margin, &rc);
+  if (n) { *dist = rc.dist; copyv(pos, rc.pos, 3); copyv(normal, rc.n, 3); }
+  return n;
+}
+
+/* pairs without an analytic routine go through the generic convex narrow phase (types ordered t1 <= t2) */
+static int pair_is_convex(int t1, int t2) {
+  if (t1 == MJH_GEOM_PLANE || t1 == MJH_GEOM_HFIELD || t2 == MJH_GEOM_HFIELD) return 0;
+  if (t1 == MJH_GEOM_ELLIPSOID || t2 == MJH_GEOM_ELLIPSOID || t1 == MJH_GEOM_CYLINDER || t2 == MJH_GEOM_CYLINDER) return 1;
+  if (t2 == MJH_GEOM_MESH) return 1;
+  return t1 == MJH_GEOM_CAPSULE && t2 == MJH_GEOM_BOX;
+}
 static double mixd(double a, double b, double mix) { return mix * a + (1 - mix) * b; }
 
 /* broad phase over the compiled pair list + narrow phase [UPSTREAM mj_collision],
@@ -672,6 +876,11 @@ void orc_collision(orc_data* d) {
     else if (t1 == MJH_GEOM_BOX && t2 == MJH_GEOM_BOX) {
       n = orc_box_box(p1, m1, s1, p2, m2, s2, margin, bd, bp, bn);
       for (int q = 0; q < n; q++) { rc[q].dist = bd[q]; copyv(rc[q].pos, bp + 3*q, 3); copyv(rc[q].n, bn, 3); }
+    }
+    else if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_ELLIPSOID) n = c_plane_ellipsoid(p1, m1, p2, m2, s2, margin, rc);
+    else if (pair_is_convex(t1, t2)) {
+      cvx_geom a = {t1, p1, m1, s1, 0, 0, 0}, b = {t2, p2, m2, s2, 0, 0, 0};
+      n = c_convex(&a, &b, margin, rc);
     }
     if (!n) continue;
     { int sb1 = m->geom_bodyid[g1], sb2 = m->geom_bodyid[g2];   /* inactive spawn/destroy slots do not collide */

@@ -349,7 +349,7 @@ def test_cylinders_on_the_plane(lib):
         lib.mjh_builder_add_geom(b, None, bd, 5, D(size[0], size[1], 0), None, None, None, -1, -1, -1, -1)
     m = ms.Model(lib.mjh_builder_compile(b), lib)
     lib.mjh_builder_destroy(b)
-    assert m.nv == 18 and m.npair == 3
+    assert m.nv == 18 and m.npair == 6      # 3 plane-cylinder + 3 cylinder-cylinder (generic convex; they stay apart here)
     q0 = m.array("qpos0").copy()
     v0 = np.zeros(m.nv); v0[6] = 0.5; v0[6 + 4] = 0.0; v0[12 + 3] = 1.0      # push the lying one along x, spin the tilted one
     st, ncon, nefc = _compare_rollout(m, q0, [1, 50, 150], [1e-5, 1e-3, 3e-2], v0=v0)
@@ -801,3 +801,83 @@ def test_odd_batch_sizes_with_cohorts_and_launch_order(nenv):
     assert np.array_equal(qa, qb) and np.array_equal(va, vb) and np.array_equal(a.get_stats(), b.get_stats())
     assert np.isfinite(qa).all()
     a.close(); b.close()
+
+
+def _convex_zoo(lib, with_floor):
+    """a static box and five free bodies whose pairs all go through the generic convex narrow phase (or plane-x)"""
+    b = lib.mjh_builder_create()
+    set_opt(lib, b, timestep=0.004)
+    if with_floor:
+        lib.mjh_builder_add_geom(b, b"floor", 0, 0, D(0, 0, 0.05), None, None, None, -1, -1, -1, -1)
+    lib.mjh_builder_add_geom(b, b"block", 0, 6, D(0.25, 0.2, 0.1), D(0, 0, 0.1), None, None, -1, -1, -1, -1)
+    specs = [(b"cyl1", 5, (0.07, 0.06, 0)), (b"cap", 3, (0.04, 0.09, 0)), (b"ell", 4, (0.09, 0.06, 0.04)),
+             (b"cyl2", 5, (0.05, 0.10, 0)), (b"sph", 2, (0.06, 0, 0))]
+    for k, (name, gt, size) in enumerate(specs):
+        bd = lib.mjh_builder_add_body(b, name, 0, D(0.15 * k - 0.3, 0, 0.6), None, 0.0)
+        lib.mjh_builder_add_joint(b, None, bd, 0, None, None, None, 0, 0, 0, 0, 0)
+        lib.mjh_builder_add_geom(b, None, bd, gt, D(*size), None, None, None, -1, -1, -1, -1)
+    m = ms.Model(lib.mjh_builder_compile(b), lib)
+    lib.mjh_builder_destroy(b)
+    return m
+
+
+@pytest.mark.gpu
+def test_generic_convex_contacts_match_oracle(lib):
+    """cylinder-x, capsule-box, ellipsoid-x (no analytic routine -> portal refinement over support mappings): contacts of
+    64 random clusters, device (fp32) against the oracle (fp64), from identical poses"""
+    m = _convex_zoo(lib, with_floor=False)
+    assert m.nv == 30 and m.npair == 5 + 10      # every free geom against the block and against each other
+    nenv = 192
+    rng = np.random.default_rng(11)
+    q = np.zeros((nenv, m.nq))
+    for i in range(nenv):
+        for k in range(5):
+            p = rng.normal(size=3); p *= rng.uniform(0.05, 0.32) / np.linalg.norm(p)
+            p[2] = abs(p[2]) + 0.2 + rng.uniform(0.0, 0.12)              # above the block's top face (z = 0.2), close together
+            quat = rng.normal(size=4); quat /= np.linalg.norm(quat)
+            q[i, 7*k:7*k+3] = p; q[i, 7*k+3:7*k+7] = quat
+    e = ms.Engine(m, nenv)
+    e.set_initial_qpos(q); e.reset(); e.forward(); e.synchronize()
+    st = e.get_stats()
+    npairs = nsoft = nmiss = 0
+    for i in range(nenv):
+        d = orc.OrcData(m.ptr); d.set_qpos(q[i]); d.call("reset"); d.call("forward")
+        oc = {x["geom"]: x for x in d.contacts()}
+        c = e.get_contacts(i)
+        dc = {tuple(int(v) for v in g): k for k, g in enumerate(c["geom"])}
+        assert len(dc) == len(c["dist"])                                   # one contact per convex pair
+        for key in set(oc) | set(dc):
+            if key not in oc or key not in dc:                             # only grazing contacts may be seen by one side only
+                depth = -oc[key]["dist"] if key in oc else -c["dist"][dc[key]]
+                assert depth < 2e-4, (i, key, depth)
+                nmiss += 1
+                continue
+            o, k = oc[key], dc[key]
+            npairs += 1
+            if o["dist"] < -0.03:                                          # deep overlaps are ill-conditioned (see the oracle test)
+                continue
+            np.testing.assert_allclose(c["dist"][k], o["dist"], atol=3e-4, err_msg=str((i, key)))
+            if np.abs(c["frame"][k][:3] - o["frame"][:3]).max() > 0.05 or np.abs(c["pos"][k] - o["pos"]).max() > 5e-3:
+                nsoft += 1                                                 # exit point next to an edge of the Minkowski difference
+    e.close()
+    assert npairs >= 150 and nsoft <= 0.12 * npairs and nmiss <= 0.05 * npairs, (npairs, nsoft, nmiss)
+
+
+@pytest.mark.gpu
+def test_generic_convex_rollout(lib):
+    """the same bodies dropped on the block and the floor: short-horizon trajectory parity, then both come to rest
+    without sinking in (one contact per convex pair: flat-on-flat rests are soft, so only bounds are compared late)"""
+    m = _convex_zoo(lib, with_floor=True)
+    q0 = m.array("qpos0").copy()
+    rng = np.random.default_rng(3)
+    for k in range(5):
+        q0[7*k:7*k+3] = [0.11 * k - 0.22, 0.03 * (k % 2), 0.32 + 0.02 * k]
+        quat = rng.normal(size=4); q0[7*k+3:7*k+7] = quat / np.linalg.norm(quat)
+    st, ncon, nefc = _compare_rollout(m, q0, [1, 10, 20], [1e-4, 5e-4, 2e-3])   # bodies start in contact: the contact points carry the 1e-6 portal tolerance
+    e = ms.Engine(m, 2)
+    e.set_initial_qpos(np.tile(q0, (2, 1))); e.reset(); e.step(1500)
+    _, q, v, _ = e.get_state()
+    assert e.get_stats()[0, 3] == 0
+    assert np.all(q[0, 2::7] > 0.03) and np.all(q[0, 2::7] < 0.45)          # nothing fell through the floor or flew away
+    assert np.abs(v[0]).max() < 30.0                                        # (the round ones keep rolling: no rolling friction at condim 3)
+    e.close()

@@ -194,3 +194,94 @@ def test_plane_cylinder_contacts_and_rest(lib):
         d.step(1500)
         assert np.abs(d.f("qvel")).max() < 2e-3
         np.testing.assert_allclose(d.f("qpos")[2], z0 + 1e-4, atol=2e-3)
+
+
+# ---- generic convex pairs (MPR over support mappings): cylinder-x, capsule-box, ellipsoid-x
+SPH, CAP, ELL, CYL, BOX = 2, 3, 4, 5, 6
+
+
+def convex_pair(t1, p1, R1, s1, t2, p2, R2, s2, margin=0.0):
+    L = orc.lib()
+    a = lambda x: np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1))
+    p1, R1, s1, p2, R2, s2 = map(a, (p1, R1, s1, p2, R2, s2))
+    d = np.zeros(1); pos = np.zeros(3); n = np.zeros(3)
+    P = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+    k = L.orc_convex_pair(t1, P(p1), P(R1), P(s1), t2, P(p2), P(R2), P(s2), margin, P(d), P(pos), P(n))
+    return k, d[0], pos, n
+
+
+def test_convex_reproduces_analytic_pairs():
+    I = np.eye(3)
+    # sphere - sphere through the generic routine = the analytic pair (origin on the centre ray)
+    c2 = np.array([1.5, 0.2, 0.1]); l = np.linalg.norm(c2)
+    k, d, pos, n = convex_pair(SPH, [0, 0, 0], I, [1, 0, 0], SPH, c2, I, [1, 0, 0])
+    assert k == 1
+    np.testing.assert_allclose(d, l - 2, atol=1e-9)
+    np.testing.assert_allclose(n, c2 / l, atol=1e-9)
+    np.testing.assert_allclose(pos, c2 / l * (1 + 0.5 * (l - 2)), atol=1e-9)
+    # axis-aligned boxes overlapping by 0.1 along x
+    k, d, pos, n = convex_pair(BOX, [0, 0, 0], I, [1, 1, 1], BOX, [1.9, 0.3, 0.2], I, [1, 1, 1])
+    assert k == 1
+    np.testing.assert_allclose(d, -0.1, atol=1e-7); np.testing.assert_allclose(n, [1, 0, 0], atol=1e-6)
+    assert abs(pos[0] - 0.95) < 1e-6
+    # sphere on an ellipsoid along a principal axis
+    k, d, pos, n = convex_pair(SPH, [0, 0, 0], I, [0.5, 0, 0], ELL, [0, 0, 0.95], I, [1, 0.7, 0.5])
+    assert k == 1
+    np.testing.assert_allclose(d, -0.05, atol=1e-7); np.testing.assert_allclose(n, [0, 0, 1], atol=1e-6)
+    np.testing.assert_allclose(pos, [0, 0, 0.475], atol=1e-6)
+
+
+def test_convex_cylinder_and_capsule_on_box():
+    I = np.eye(3); box = ([0, 0, 0], I, [1, 1, 1])
+    r, h = 0.3, 0.1
+    # standing cylinder: the cap is 0.01 inside the top face; normal from the cylinder (geom 1) into the box
+    k, d, pos, n = convex_pair(CYL, [0.1, 0.05, 1.09], I, [r, h, 0], BOX, *box)
+    assert k == 1
+    np.testing.assert_allclose(d, -0.01, atol=1e-6); np.testing.assert_allclose(n, [0, 0, -1], atol=1e-5)
+    assert abs(pos[2] - 0.995) < 5e-3 and np.hypot(pos[0] - 0.1, pos[1] - 0.05) <= r + 1e-6
+    # lying cylinder: line of touch, depth r - height
+    k, d, pos, n = convex_pair(CYL, [0.1, 0.05, 1.29], rot([1, 0, 0], np.pi / 2), [r, h, 0], BOX, *box)
+    assert k == 1
+    np.testing.assert_allclose(d, -0.01, atol=2e-6); np.testing.assert_allclose(n, [0, 0, -1], atol=1e-5)
+    # tilted cylinder: the lowest rim point
+    th = 0.7
+    k, d, pos, n = convex_pair(CYL, [0.1, 0.05, 1.2], rot([1, 0.3, 0], th), [r, h, 0], BOX, *box)
+    lowest = 1.2 - (r * np.sin(th) + h * np.cos(th))
+    assert k == 1
+    np.testing.assert_allclose(d, lowest - 1.0, atol=2e-6); np.testing.assert_allclose(n, [0, 0, -1], atol=1e-5)
+    # separated -> nothing; separated by less than the margin -> positive distance
+    assert convex_pair(CYL, [0.1, 0.05, 1.5], rot([1, 0.3, 0], th), [r, h, 0], BOX, *box)[0] == 0
+    k, d, pos, n = convex_pair(CYL, [0.1, 0.05, 1.105], I, [r, h, 0], BOX, *box, margin=0.01)
+    assert k == 1
+    np.testing.assert_allclose(d, 0.005, atol=2e-6)
+    # capsule tilted over the face: depth = radius - height of the lower end point
+    ang = 0.5
+    k, d, pos, n = convex_pair(CAP, [0, 0, 1.25], rot([0, 1, 0], ang), [0.1, 0.3, 0], BOX, *box)
+    assert k == 1
+    np.testing.assert_allclose(d, (1.25 - 0.3 * np.cos(ang) - 0.1) - 1.0, atol=2e-6); np.testing.assert_allclose(n, [0, 0, -1], atol=1e-5)
+
+
+def test_convex_is_invariant_under_rigid_motion_and_separates_the_pair():
+    """depth and the frame-relative contact are the same in any world frame; translating geom 2 by depth along the
+    normal brings the pair to touching (depth ~ 0)"""
+    rng = np.random.default_rng(5)
+    hits = soft = 0
+    for _ in range(900):
+        t1, t2 = [(CYL, CYL), (CYL, BOX), (CAP, BOX), (SPH, CYL), (ELL, BOX), (CAP, CYL)][rng.integers(6)]
+        s1 = rng.uniform(0.1, 0.4, 3); s2 = rng.uniform(0.1, 0.4, 3)
+        R1 = rot(rng.normal(size=3), rng.uniform(0, 3)); R2 = rot(rng.normal(size=3), rng.uniform(0, 3))
+        p1 = np.zeros(3); p2 = rng.normal(size=3); p2 *= rng.uniform(0.2, 0.7) / np.linalg.norm(p2)
+        k, d, pos, n = convex_pair(t1, p1, R1, s1, t2, p2, R2, s2)
+        if not k or d < -0.04:     # deep overlaps (a centre inside the other geom) are ill-conditioned for portal refinement
+            continue
+        hits += 1
+        assert d <= 1e-9 and abs(np.linalg.norm(n) - 1) < 1e-9
+        Q = rot(rng.normal(size=3), rng.uniform(0, 3)); t = rng.normal(size=3)
+        k2, d2, pos2, n2 = convex_pair(t1, Q @ p1 + t, Q @ R1, s1, t2, Q @ p2 + t, Q @ R2, s2)
+        assert k2 == 1
+        np.testing.assert_allclose(d2, d, atol=2e-4)
+        soft += np.abs(n2 - Q @ n).max() > 0.02   # the ray leaves the Minkowski difference next to an edge: either face normal
+        # moved apart by the depth (+ a little) the pair no longer overlaps by more than the tolerance
+        k3, d3, _, _ = convex_pair(t1, p1, R1, s1, t2, p2 + n * (-d + 1e-4), R2, s2)
+        assert k3 == 0 or d3 > -2e-4
+    assert hits >= 40 and soft <= 0.15 * hits, (hits, soft)
