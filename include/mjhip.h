@@ -93,6 +93,7 @@ typedef struct mjh_model {
   int nq, nv, nbody, njnt, ngeom, neq, npair, nM, ntree, nexclude;
   int maxcon;  /* contact capacity per env (contacts beyond it are dropped + flagged) */
   int maxefc;  /* constraint-row capacity per env                                     */
+  int nmesh, nmeshvert; /* convex mesh assets: count, total vertices                    */
   mjh_option opt;
   double meaninertia; /* stat.meaninertia: mean diag(M(qpos0)) — scales solver tolerance */
 
@@ -123,6 +124,11 @@ typedef struct mjh_model {
   /* equality constraints */
   int *eq_type, *eq_obj1id, *eq_obj2id, *eq_active;
   double *eq_data, *eq_solref, *eq_solimp; /* [11*neq], [2*neq], [5*neq] */
+  /* convex mesh assets (mjModel mesh_vert / geom_dataid; pr2.xml:5-22): the support-relevant vertices of each
+   * mesh in the mesh geom's own frame (origin = centre of mass, axes = principal axes) */
+  int *geom_dataid;                /* [ngeom] mesh id of a mesh geom, -1 otherwise */
+  int *mesh_vertadr, *mesh_vertnum; /* [nmesh] */
+  double *mesh_vert;                /* [3*nmeshvert] */
   /* name tables: resolved ONCE on the host (the reference calls mj_name2id per
    * joint per step: mj_hw_interface.cpp:64,79; mj_sim.cpp:1060,1083-1146) */
   char **body_names, **jnt_names, **geom_names;
@@ -152,6 +158,15 @@ int mjh_builder_add_joint(mjh_builder*, const char* name, int body, int type, co
 int mjh_builder_add_geom(mjh_builder*, const char* name, int body, int type, const double size[3],
                          const double pos[3], const double quat[4], const double friction[3],
                          int condim, int contype, int conaffinity, double density);
+/* convex mesh asset (the <asset><mesh> of the reference's robots, pr2.xml:5-22): a vertex cloud, optionally with
+ * triangles (volume, centre of mass and principal axes from the faces as mj_loadXML derives them; from the
+ * bounding box otherwise).  Collides as its convex hull, like MuJoCo: the builder keeps the vertices that are
+ * extreme along a dense set of directions.  scale may be NULL.  Returns the mesh id (>= 0) or a negative code. */
+int mjh_builder_add_mesh(mjh_builder*, const double* vert, int nvert, const int* face, int nface, const double scale[3]);
+int mjh_builder_add_mesh_stl(mjh_builder*, const char* path, const double scale[3]);   /* binary STL */
+/* mesh geom: pos/quat place the MESH FILE's frame in the body, as <geom type="mesh" pos quat> does */
+int mjh_builder_add_mesh_geom(mjh_builder*, const char* name, int body, int mesh, const double pos[3], const double quat[4],
+                              const double friction[3], int condim, int contype, int conaffinity, double density);
 int mjh_builder_add_exclude(mjh_builder*, int body1, int body2);
 int mjh_builder_add_eq_joint(mjh_builder*, int joint1, int joint2, const double polycoef[5]);
 /* compile: derives inertias, qpos0, invweight0, meaninertia, rbound, pair list */
@@ -169,6 +184,9 @@ mjh_model* mjh_load_mjcf_file(const char* path);
  * (MjSim::init, mj_sim.cpp:573-710).  <option> comes from the first file; names must be unique across files. */
 mjh_model* mjh_load_mjcf_files(const char* const* paths, int n);
 const char* mjh_load_note(void);
+/* 1 (default): <asset><mesh> files are read and mesh geoms collide as convex hulls; 0: mesh geoms are dropped (and
+ * listed in mjh_load_note), which leaves the primitive collision geometry only */
+void mjh_load_set_mesh_mode(int mode);
 /* process-wide floor for <compiler boundmass boundinertia> of every file loaded afterwards: the reference writes
  * 1e-6 / 1e-6 into each file before mj_loadXML (mj_sim.cpp:584-590) */
 void mjh_load_set_bounds(double boundmass, double boundinertia);

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmjhip.so")
+LIB_PATH = os.environ.get("MJHIP_LIB") or os.path.join(_HERE, "libmjhip.so")   # (MJHIP_LIB: A/B builds of the library)
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
@@ -27,7 +27,7 @@ class Option(C.Structure):
     ]
 
 
-_INT_SIZES = ["nq", "nv", "nbody", "njnt", "ngeom", "neq", "npair", "nM", "ntree", "nexclude", "maxcon", "maxefc"]
+_INT_SIZES = ["nq", "nv", "nbody", "njnt", "ngeom", "neq", "npair", "nM", "ntree", "nexclude", "maxcon", "maxefc", "nmesh", "nmeshvert"]
 
 # (name, ctype, length expression) in the exact order of struct mjh_model
 _ARRAYS = [
@@ -57,6 +57,8 @@ _ARRAYS = [
     ("pair_geom1", "i", "npair"), ("pair_geom2", "i", "npair"),
     ("eq_type", "i", "neq"), ("eq_obj1id", "i", "neq"), ("eq_obj2id", "i", "neq"), ("eq_active", "i", "neq"),
     ("eq_data", "d", "11*neq"), ("eq_solref", "d", "2*neq"), ("eq_solimp", "d", "5*neq"),
+    ("geom_dataid", "i", "ngeom"), ("mesh_vertadr", "i", "nmesh"), ("mesh_vertnum", "i", "nmesh"),
+    ("mesh_vert", "d", "3*nmeshvert"),
 ]
 
 
@@ -100,6 +102,10 @@ SYMBOLS = [
                                        C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
     ("mjh_builder_add_geom", C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p,
                                       c_double_p, C.c_int, C.c_int, C.c_int, C.c_double]),
+    ("mjh_builder_add_mesh", C.c_int, [_vp, c_double_p, C.c_int, c_int_p, C.c_int, c_double_p]),
+    ("mjh_builder_add_mesh_stl", C.c_int, [_vp, C.c_char_p, c_double_p]),
+    ("mjh_builder_add_mesh_geom", C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p,
+                                           C.c_int, C.c_int, C.c_int, C.c_double]),
     ("mjh_builder_add_exclude", C.c_int, [_vp, C.c_int, C.c_int]),
     ("mjh_builder_add_eq_joint", C.c_int, [_vp, C.c_int, C.c_int, c_double_p]),
     ("mjh_builder_compile", Model_p, [_vp]),
@@ -111,6 +117,7 @@ SYMBOLS = [
     ("mjh_load_mjcf_files", Model_p, [C.POINTER(C.c_char_p), C.c_int]),
     ("mjh_load_note", C.c_char_p, []),
     ("mjh_load_set_bounds", None, [C.c_double, C.c_double]),
+    ("mjh_load_set_mesh_mode", None, [C.c_int]),
     ("mjh_scene_s24", Model_p, []),
     ("mjh_scene_s24_randomize", C.c_int, [Model_p, C.c_int, C.c_int, C.c_uint] + [c_double_p] * 7),
     ("mjh_scene_pendulum", Model_p, []),

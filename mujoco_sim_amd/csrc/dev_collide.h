@@ -92,6 +92,57 @@ DEV int c_plane_ellipsoid(const float* pp, const float* pm, const float* c, cons
   return 1;
 }
 
+// plane - convex mesh: vertices below the margin; the deepest one, the one farthest from it, the one farthest from the
+// line through those two and the one farthest on the other side of that line; at most 4 (same definition as the oracle)
+#define PLANE_MESH_EPS2 1e-8f
+DEV int c_plane_mesh(const float* pp, const float* pm, const float* c, const float* mm, const float* vert, int nvert, float margin, float* st) {
+  const float n[3] = {pm[2], pm[5], pm[8]}, t[3] = {c[0]-pp[0], c[1]-pp[1], c[2]-pp[2]};
+  float nl[3];
+  rotvecT(nl, mm, n);
+  const float d0 = dot3(t, n);
+  float best = 3.0e38f; int i1 = -1, i2 = -1, ipos = -1, ineg = -1;
+  for (int i = 0; i < nvert; i++) { const float di = d0 + vert[3*i]*nl[0] + vert[3*i+1]*nl[1] + vert[3*i+2]*nl[2]; if (di < best) { best = di; i1 = i; } }
+  if (i1 < 0 || best > margin) return 0;
+  const float v1[3] = {vert[3*i1], vert[3*i1+1], vert[3*i1+2]};
+  best = PLANE_MESH_EPS2;
+  for (int i = 0; i < nvert; i++) {
+    const float x = vert[3*i], y = vert[3*i+1], z = vert[3*i+2];
+    if (d0 + x*nl[0] + y*nl[1] + z*nl[2] > margin) continue;
+    const float e[3] = {x - v1[0], y - v1[1], z - v1[2]}, l2 = dot3(e, e);
+    if (l2 > best) { best = l2; i2 = i; }
+  }
+  bool posfirst = true;
+  if (i2 >= 0) {
+    const float e12[3] = {vert[3*i2] - v1[0], vert[3*i2+1] - v1[1], vert[3*i2+2] - v1[2]};
+    float side[3];
+    cross3(side, e12, nl);
+    float bpos = sqrtf(PLANE_MESH_EPS2 * dot3(e12, e12)), bneg = bpos;
+    for (int i = 0; i < nvert; i++) {
+      const float x = vert[3*i], y = vert[3*i+1], z = vert[3*i+2];
+      if (d0 + x*nl[0] + y*nl[1] + z*nl[2] > margin) continue;
+      const float sd = (x - v1[0])*side[0] + (y - v1[1])*side[1] + (z - v1[2])*side[2];
+      if (sd > bpos) { bpos = sd; ipos = i; }
+      if (-sd > bneg) { bneg = -sd; ineg = i; }
+    }
+    posfirst = bpos >= bneg;
+  }
+  const int third = (ipos >= 0 && ineg >= 0) ? (posfirst ? ipos : ineg) : (ipos >= 0 ? ipos : ineg);
+  const int fourth = (ipos >= 0 && ineg >= 0) ? (posfirst ? ineg : ipos) : -1;
+  int cnt = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int iv = q == 0 ? i1 : q == 1 ? i2 : q == 2 ? third : fourth;
+    if (iv < 0) continue;
+    const float v[3] = {vert[3*iv], vert[3*iv+1], vert[3*iv+2]};
+    float w[3];
+    rotvec(w, mm, v);
+    const float di = d0 + dot3(v, nl);
+    const float pos[3] = {c[0] + w[0] - n[0]*0.5f*di, c[1] + w[1] - n[1]*0.5f*di, c[2] + w[2] - n[2]*0.5f*di};
+    raw_emit(st, cnt, di, pos, n); cnt++;
+  }
+  return cnt;
+}
+
 DEV int c_plane_box(const float* pp, const float* pm, const float* c, const float* bm, const float* size, float margin, float* st) {
   float n[3] = {pm[2], pm[5], pm[8]}, t[3] = {c[0]-pp[0], c[1]-pp[1], c[2]-pp[2]};
   float dist = dot3(t, n);

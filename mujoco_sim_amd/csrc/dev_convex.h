@@ -88,63 +88,77 @@ DEV void tri_closest_to_origin(const float* a, const float* b, const float* c, f
   out[0] = a[0] + v*ab[0] + w*ac[0]; out[1] = a[1] + v*ab[1] + w*ac[1]; out[2] = a[2] + v*ab[2] + w*ac[2];
 }
 
-// one raw contact {dist, pos, normal from geom1 to geom2} or nothing
+// one raw contact {dist, pos, normal from geom1 to geom2} or nothing.  The five places of the algorithm that ask for a
+// support point (first and second portal vertex, portal discovery, refinement, push to the surface) share ONE support
+// evaluation per trip of a phase loop: a fifth of the code of the straight-line form, and lanes that are in different
+// phases still evaluate their support mappings together.
 DEV int c_convex(CvxGeom& g1, CvxGeom& g2, float margin, float* st) {
   g1.pad = g2.pad = 0.5f * margin;
   MprPt p0, p1, p2, p3, p4;
-  float n[3], c[3], depth, dir[3], pos[3];
+  float n[3], c[3];
 #pragma unroll
-  for (int k = 0; k < 3; k++) { p0.v[k] = g1.pos[k] - g2.pos[k]; p0.s[k] = g1.pos[k] + g2.pos[k]; }
+  for (int k = 0; k < 3; k++) { p0.v[k] = g1.pos[k] - g2.pos[k]; p0.s[k] = g1.pos[k] + g2.pos[k]; p1.v[k] = p2.v[k] = p3.v[k] = 0; p1.s[k] = p2.s[k] = p3.s[k] = 0; }
   if (dot3(p0.v, p0.v) < MPR_EPS_LEN2) p0.v[0] += 1e-4f;
   n[0] = -p0.v[0]; n[1] = -p0.v[1]; n[2] = -p0.v[2];
   normalize3(n);
-  mpr_support(g1, g2, n, p1);
-  if (dot3(p1.v, n) <= 0) return 0;
-  cross3(n, p0.v, p1.v);
-  if (dot3(n, n) < 1e-12f * dot3(p0.v, p0.v) * dot3(p1.v, p1.v)) {   // origin on the ray p0 -> p1
-    depth = norm3(p1.v);
-    dir[0] = p1.v[0]; dir[1] = p1.v[1]; dir[2] = p1.v[2]; normalize3(dir);
-    pos[0] = 0.5f * p1.s[0]; pos[1] = 0.5f * p1.s[1]; pos[2] = 0.5f * p1.s[2];
-    raw_emit(st, 0, margin - depth, pos, dir);
-    return 1;
-  }
-  normalize3(n);
-  mpr_support(g1, g2, n, p2);
-  if (dot3(p2.v, n) <= 0) return 0;
-  {
-    const float e1[3] = {p1.v[0]-p0.v[0], p1.v[1]-p0.v[1], p1.v[2]-p0.v[2]}, e2[3] = {p2.v[0]-p0.v[0], p2.v[1]-p0.v[1], p2.v[2]-p0.v[2]};
-    cross3(n, e1, e2); normalize3(n);
-    const bool sw = dot3(n, p0.v) > 0;
-    const MprPt t = p1;
-    mpr_take(p1, p2, sw); mpr_take(p2, t, sw);
-    n[0] = sw ? -n[0] : n[0]; n[1] = sw ? -n[1] : n[1]; n[2] = sw ? -n[2] : n[2];
-  }
-  for (int it = 0;; it++) {   // portal discovery
-    if (it > MPR_ITER) return 0;
-    mpr_support(g1, g2, n, p3);
-    if (dot3(p3.v, n) <= 0) return 0;
-    cross3(c, p1.v, p3.v);
-    const bool t2 = dot3(c, p0.v) < -MPR_EPS_VOL;
-    cross3(c, p3.v, p2.v);
-    const bool t1 = !t2 && dot3(c, p0.v) < -MPR_EPS_VOL;
-    if (!t1 && !t2) break;
-    mpr_take(p2, p3, t2); mpr_take(p1, p3, t1);
-    const float e1[3] = {p1.v[0]-p0.v[0], p1.v[1]-p0.v[1], p1.v[2]-p0.v[2]}, e2[3] = {p2.v[0]-p0.v[0], p2.v[1]-p0.v[1], p2.v[2]-p0.v[2]};
-    cross3(n, e1, e2); normalize3(n);
-  }
-  for (int it = 0;; it++) {   // refinement: hit or miss
-    mpr_tri_normal(n, p1, p2, p3);
-    if (dot3(n, p1.v) >= -MPR_EPS_VOL) break;
+  enum { PH_FIRST, PH_SECOND, PH_DISCOVER, PH_REFINE, PH_PUSH };
+  int phase = PH_FIRST, it = 0;
+  for (;;) {
     mpr_support(g1, g2, n, p4);
-    if (dot3(p4.v, n) < -MPR_EPS_VOL || mpr_converged(p1, p2, p3, p4, n) || it > MPR_ITER) return 0;
-    mpr_expand(p0, p1, p2, p3, p4);
+    const float d4 = dot3(p4.v, n);
+    if (phase == PH_FIRST) {
+      if (d4 <= 0) return 0;
+      p1 = p4;
+      cross3(n, p0.v, p1.v);
+      if (dot3(n, n) < 1e-12f * dot3(p0.v, p0.v) * dot3(p1.v, p1.v)) {   // origin on the ray p0 -> p1
+        const float depth = norm3(p1.v);
+        float dir[3] = {p1.v[0], p1.v[1], p1.v[2]}; normalize3(dir);
+        const float pos[3] = {0.5f * p1.s[0], 0.5f * p1.s[1], 0.5f * p1.s[2]};
+        raw_emit(st, 0, margin - depth, pos, dir);
+        return 1;
+      }
+      normalize3(n);
+      phase = PH_SECOND;
+    } else if (phase == PH_SECOND) {
+      if (d4 <= 0) return 0;
+      p2 = p4;
+      const float e1[3] = {p1.v[0]-p0.v[0], p1.v[1]-p0.v[1], p1.v[2]-p0.v[2]}, e2[3] = {p2.v[0]-p0.v[0], p2.v[1]-p0.v[1], p2.v[2]-p0.v[2]};
+      cross3(n, e1, e2); normalize3(n);
+      const bool sw = dot3(n, p0.v) > 0;
+      const MprPt t = p1;
+      mpr_take(p1, p2, sw); mpr_take(p2, t, sw);
+      n[0] = sw ? -n[0] : n[0]; n[1] = sw ? -n[1] : n[1]; n[2] = sw ? -n[2] : n[2];
+      phase = PH_DISCOVER; it = 0;
+    } else if (phase == PH_DISCOVER) {
+      if (d4 <= 0 || it > MPR_ITER) return 0;
+      it++;
+      cross3(c, p1.v, p4.v);
+      const bool t2 = dot3(c, p0.v) < -MPR_EPS_VOL;
+      cross3(c, p4.v, p2.v);
+      const bool t1 = !t2 && dot3(c, p0.v) < -MPR_EPS_VOL;
+      if (t1 || t2) {
+        mpr_take(p2, p4, t2); mpr_take(p1, p4, t1);
+        const float e1[3] = {p1.v[0]-p0.v[0], p1.v[1]-p0.v[1], p1.v[2]-p0.v[2]}, e2[3] = {p2.v[0]-p0.v[0], p2.v[1]-p0.v[1], p2.v[2]-p0.v[2]};
+        cross3(n, e1, e2); normalize3(n);
+      } else {
+        p3 = p4;
+        mpr_tri_normal(n, p1, p2, p3);
+        phase = dot3(n, p1.v) >= -MPR_EPS_VOL ? PH_PUSH : PH_REFINE; it = 0;
+      }
+    } else if (phase == PH_REFINE) {
+      if (d4 < -MPR_EPS_VOL || mpr_converged(p1, p2, p3, p4, n) || it > MPR_ITER) return 0;
+      it++;
+      mpr_expand(p0, p1, p2, p3, p4);
+      mpr_tri_normal(n, p1, p2, p3);
+      if (dot3(n, p1.v) >= -MPR_EPS_VOL) { phase = PH_PUSH; it = 0; }
+    } else {
+      if (mpr_converged(p1, p2, p3, p4, n) || it > MPR_ITER) break;
+      it++;
+      mpr_expand(p0, p1, p2, p3, p4);
+      mpr_tri_normal(n, p1, p2, p3);
+    }
   }
-  for (int it = 0;; it++) {   // push the portal to the surface
-    mpr_tri_normal(n, p1, p2, p3);
-    mpr_support(g1, g2, n, p4);
-    if (mpr_converged(p1, p2, p3, p4, n) || it > MPR_ITER) break;
-    mpr_expand(p0, p1, p2, p3, p4);
-  }
+  float depth, dir[3], pos[3];
   tri_closest_to_origin(p1.v, p2.v, p3.v, c);
   depth = norm3(c);
   if (depth < 1e-7f) { dir[0] = n[0]; dir[1] = n[1]; dir[2] = n[2]; } else { const float inv = 1.0f / depth; dir[0] = c[0]*inv; dir[1] = c[1]*inv; dir[2] = c[2]*inv; }

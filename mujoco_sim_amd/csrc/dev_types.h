@@ -31,6 +31,8 @@ struct DModel {
   int maxlevel, nfl, ngc, rowW, nstage, has_damping, has_limits, diagM, maxblk, maxbrow, has_dim4, big, k1_floats, has_convex;
   int iterations, disableflags;
   float timestep, gravity[3], tolerance, impratio, meaninertia;
+  // convex mesh assets (read by the CONVEX kernel instances only)
+  int o_geom_dataid, o_mesh_vertadr, o_mesh_vertnum, o_mesh_vert;
 };
 
 // per-env state in HBM (fp32, env-major rows)

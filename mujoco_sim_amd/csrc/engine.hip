@@ -79,10 +79,12 @@ static int ensure_scratch(mjh_engine* e, size_t floats) {
 
 static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps, int ph, int xflags) {
   if (n <= 0) return MJH_OK;
-#define MJH_LAUNCH(NR, DG) hipLaunchKernelGGL((mjh_step_kernel<NR, DG>), dim3(n), dim3(64), (size_t)e->lds_bytes, st, e->dC, e->S, env0, nsteps, ph, xflags)
+#define MJH_LAUNCH2(NR, DG, CX) hipLaunchKernelGGL((mjh_step_kernel<NR, DG, CX>), dim3(n), dim3(64), (size_t)e->lds_bytes, st, e->dC, e->S, env0, nsteps, ph, xflags)
+#define MJH_LAUNCH(NR, DG) do { if (e->M.has_convex) MJH_LAUNCH2(NR, DG, true); else MJH_LAUNCH2(NR, DG, false); } while (0)
   const int nr = e->M.big ? 8 : (e->M.nv <= 16 ? 1 : (e->M.nv <= 32 ? 2 : 4));   // 8: many-body layout, running acceleration in LDS
   if (e->M.diagM) { if (nr == 1) MJH_LAUNCH(1, true); else if (nr == 2) MJH_LAUNCH(2, true); else if (nr == 4) MJH_LAUNCH(4, true); else MJH_LAUNCH(8, true); }
   else { if (nr == 1) MJH_LAUNCH(1, false); else if (nr == 2) MJH_LAUNCH(2, false); else if (nr == 4) MJH_LAUNCH(4, false); else MJH_LAUNCH(8, false); }
+#undef MJH_LAUNCH2
 #undef MJH_LAUNCH
   HIPCHK(hipGetLastError());
   return MJH_OK;
@@ -126,6 +128,7 @@ static int pair_cap(int t1, int t2) {
   if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_BOX) return 4;
   if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_CAPSULE) return 2;
   if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_CYLINDER) return 4;
+  if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_MESH) return 4;
   if (t1 == MJH_GEOM_BOX && t2 == MJH_GEOM_BOX) return 8;
   return 1;
 }
@@ -195,6 +198,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
   PF(geom_pos, 3*ng); PF(geom_quat, 4*ng); PF(geom_size, 3*ng); PF(geom_rbound, ng); PF(geom_friction, 3*ng); PF(geom_solmix, ng);
   PF(geom_solref, 2*ng); PF(geom_solimp, 5*ng); PF(geom_margin, ng); PF(geom_gap, ng);
   PF(eq_data, 11*m->neq); PF(eq_solref, 2*m->neq); PF(eq_solimp, 5*m->neq);
+  PI(geom_dataid, ng); PI(mesh_vertadr, m->nmesh); PI(mesh_vertnum, m->nmesh); PF(mesh_vert, 3 * (size_t)m->nmeshvert);
 #undef PI
 #undef PF
   M.nq = m->nq; M.nv = nv; M.nbody = nb; M.njnt = nj; M.ngeom = ng; M.neq = m->neq; M.npair = m->npair; M.nM = m->nM; M.ntree = m->ntree;
@@ -207,6 +211,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
   M.has_convex = 0;   // some pair needs the generic convex narrow phase (cylinder-x, capsule-box, ellipsoid-x)
   for (int i = 0; i < m->npair; i++) {
     const int t1 = m->geom_type[m->pair_geom1[i]], t2 = m->geom_type[m->pair_geom2[i]];
+    if (t2 == MJH_GEOM_MESH) M.has_convex = 1;
     if (t1 != MJH_GEOM_PLANE && (t1 == MJH_GEOM_ELLIPSOID || t2 == MJH_GEOM_ELLIPSOID || t1 == MJH_GEOM_CYLINDER || t2 == MJH_GEOM_CYLINDER ||
                                  t2 == MJH_GEOM_MESH || (t1 == MJH_GEOM_CAPSULE && t2 == MJH_GEOM_BOX))) M.has_convex = 1;
   }
@@ -354,7 +359,8 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     mjh_set_error("mjh_create: per-env working set exceeds the 160 KiB LDS of one CU (" + std::to_string(e->lds_bytes) + " B)");
     mjh_destroy(e); return MJH_ERR_CAPACITY;
   }
-#define MJH_ATTR(NR, DG) HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<NR, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes))
+#define MJH_ATTR(NR, DG) do { HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<NR, DG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes)); \
+                              HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<NR, DG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes)); } while (0)
   MJH_ATTR(1, true); MJH_ATTR(2, true); MJH_ATTR(4, true); MJH_ATTR(8, true); MJH_ATTR(1, false); MJH_ATTR(2, false); MJH_ATTR(4, false); MJH_ATTR(8, false);
 #undef MJH_ATTR
 

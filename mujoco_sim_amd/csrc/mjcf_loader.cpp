@@ -100,14 +100,15 @@ struct Defaults {
 // floor applied to every file loaded afterwards: MjSim::init() writes boundmass = boundinertia = 1e-6 into the <compiler>
 // element of whatever it loads (mj_sim.cpp:584-590)
 static double g_boundmass = 0, g_boundinertia = 0;
+static int g_load_meshes = 1;   // mjh_load_set_mesh_mode: 0 = skip mesh assets (their geoms are reported and dropped)
 
 struct Loader {
   mjh_builder* b = nullptr;
   bool degree = true, autolimits = false;
   double bmass = 0, binertia = 0;   // <compiler boundmass boundinertia>, raised to the process-wide floor of mjh_load_set_bounds
   Defaults def;
-  std::map<std::string, int> body_id, joint_id;
-  std::string note;
+  std::map<std::string, int> body_id, joint_id, mesh_id;
+  std::string note, basedir, meshdir;   // directory of the file being read (empty for a string), <compiler meshdir>
   int nameless = 0;
 
   double ang(double v) const { return degree ? v * 3.14159265358979323846 / 180.0 : v; }
@@ -128,8 +129,9 @@ struct Loader {
       std::string t = type;
       if (t == "plane") gt = MJH_GEOM_PLANE; else if (t == "sphere") gt = MJH_GEOM_SPHERE; else if (t == "capsule") gt = MJH_GEOM_CAPSULE;
       else if (t == "cylinder") gt = MJH_GEOM_CYLINDER; else if (t == "box") gt = MJH_GEOM_BOX; else if (t == "ellipsoid") gt = MJH_GEOM_ELLIPSOID;
+      else if (t == "mesh") gt = MJH_GEOM_MESH;
       else { note += "skipped <geom type=\"" + t + "\">; "; return; }
-    }
+    } else if (n.get("mesh")) gt = MJH_GEOM_MESH;
     if (n.get("fromto")) { note += "skipped <geom fromto>; "; return; }
     double size[3] = {0, 0, 0}, pos[3] = {0, 0, 0}, quat[4] = {1, 0, 0, 0}, fr[3];
     nums(n.get("size"), size, 3); nums(n.get("pos"), pos, 3); orientation(n, quat);
@@ -140,6 +142,12 @@ struct Loader {
     if (nums(n.get("contype"), &v, 1)) contype = (int)v;
     if (nums(n.get("conaffinity"), &v, 1)) conaff = (int)v;
     if (nums(n.get("density"), &v, 1)) density = v;
+    if (gt == MJH_GEOM_MESH) {
+      auto it = mesh_id.find(n.get("mesh") ? n.get("mesh") : "");
+      if (it == mesh_id.end()) { note += std::string("skipped mesh geom (mesh ") + (n.get("mesh") ? n.get("mesh") : "?") + " not loaded); "; return; }
+      mjh_builder_add_mesh_geom(b, n.get("name"), body, it->second, pos, quat, fr, condim, contype, conaff, density);
+      return;
+    }
     mjh_builder_add_geom(b, n.get("name"), body, gt, size, pos, quat, fr, condim, contype, conaff, density);
   }
   bool joint(const Node& n, int body, bool freejoint) {
@@ -197,16 +205,17 @@ struct Loader {
   // One model from several files, the way the reference composes a world file and robot files (MjSim::init,
   // mj_sim.cpp:573-710): every file contributes its <worldbody>, <contact>, <equality> under its own <compiler> and
   // <default> settings; <option> is taken from the first file (the world) only.
-  bool add(const Node& root, bool first) {
+  bool add(const Node& root, bool first, const std::string& dir = std::string()) {
     if (root.tag != "mujoco") { mjh_set_error("root element must be <mujoco>"); return false; }
     if (first) b = mjh_builder_create();
-    degree = true; autolimits = false; def = Defaults();
+    degree = true; autolimits = false; def = Defaults(); basedir = dir; meshdir.clear(); mesh_id.clear();
     mjh_option o; mjh_builder_get_option(b, &o);
     // first pass: compiler / option / default (they may appear after worldbody in a file)
     for (auto& c : root.kids) {
       if (c->tag == "compiler") {
         if (const char* a = c->get("angle")) degree = std::string(a) != "radian";
         if (const char* a = c->get("autolimits")) autolimits = std::string(a) == "true";
+        if (const char* a = c->get("meshdir")) { meshdir = a; if (!meshdir.empty() && meshdir.back() != '/') meshdir += '/'; }
         double v;
         if (nums(c->get("boundmass"), &v, 1)) bmass = std::max(bmass, v);
         if (nums(c->get("boundinertia"), &v, 1)) binertia = std::max(binertia, v);
@@ -244,6 +253,23 @@ struct Loader {
       }
     }
     if (first) mjh_builder_set_option(b, &o);
+    // <asset><mesh>: binary STL files next to the MJCF file (pr2.xml:4-23); a mesh that cannot be read is reported and
+    // the geoms that use it are skipped
+    for (auto& c : root.kids) if (c->tag == "asset") for (auto& a : c->kids) if (a->tag == "mesh") {
+      const char* file = a->get("file");
+      if (!file) { note += "skipped <mesh> without file; "; continue; }
+      std::string fn = file, name;
+      if (const char* nm = a->get("name")) name = nm;
+      else { size_t sl = fn.find_last_of('/'), dot = fn.find_last_of('.'); name = fn.substr(sl == std::string::npos ? 0 : sl + 1, dot == std::string::npos ? std::string::npos : dot - (sl == std::string::npos ? 0 : sl + 1)); }
+      if (!g_load_meshes) { note += "mesh " + name + " skipped (mesh mode 0); "; continue; }
+      if (basedir.empty() && fn[0] != '/') { note += "mesh " + name + " not loaded (MJCF given as a string: no directory); "; continue; }
+      const std::string path = fn[0] == '/' ? fn : basedir + meshdir + fn;
+      double sc[3] = {1, 1, 1};
+      nums(a->get("scale"), sc, 3);
+      const int id = mjh_builder_add_mesh_stl(b, path.c_str(), sc);
+      if (id < 0) { note += "mesh " + name + " not loaded (" + mjh_last_error() + "); "; continue; }
+      mesh_id[name] = id;
+    }
     for (auto& c : root.kids) if (c->tag == "worldbody") if (!children(*c, 0)) return false;
     for (auto& c : root.kids) {
       if (c->tag == "contact") {
@@ -295,12 +321,12 @@ extern "C" mjh_model* mjh_load_mjcf_string(const char* xml) {
   g_note = L.note;
   return m;
 }
-extern "C" mjh_model* mjh_load_mjcf_file(const char* path) {
-  std::ifstream f(path ? path : "");
-  if (!f) { mjh_set_error(std::string("cannot open ") + (path ? path : "(null)")); return nullptr; }
-  std::stringstream ss; ss << f.rdbuf();
-  return mjh_load_mjcf_string(ss.str().c_str());
+static std::string dir_of(const char* path) {
+  std::string p = path ? path : "";
+  size_t sl = p.find_last_of('/');
+  return sl == std::string::npos ? std::string("./") : p.substr(0, sl + 1);
 }
+extern "C" mjh_model* mjh_load_mjcf_file(const char* path) { return mjh_load_mjcf_files(&path, 1); }
 extern "C" mjh_model* mjh_load_mjcf_files(const char* const* paths, int n) {
   g_note.clear();
   if (!paths || n <= 0) { mjh_set_error("mjh_load_mjcf_files: no files"); return nullptr; }
@@ -313,7 +339,7 @@ extern "C" mjh_model* mjh_load_mjcf_files(const char* const* paths, int n) {
     Xml x{text.c_str(), text.c_str() + text.size(), {}};
     auto root = x.element();
     if (!root) { mjh_set_error(std::string("MJCF parse error in ") + paths[i] + ": " + (x.err.empty() ? std::string("no root element") : x.err)); L.abort(); return nullptr; }
-    if (!L.add(*root, i == 0)) { L.abort(); return nullptr; }
+    if (!L.add(*root, i == 0, dir_of(paths[i]))) { L.abort(); return nullptr; }
   }
   mjh_model* m = L.finish();
   g_note = L.note;
@@ -321,3 +347,4 @@ extern "C" mjh_model* mjh_load_mjcf_files(const char* const* paths, int n) {
 }
 extern "C" const char* mjh_load_note(void) { return g_note.c_str(); }
 extern "C" void mjh_load_set_bounds(double boundmass, double boundinertia) { g_boundmass = boundmass; g_boundinertia = boundinertia; }
+extern "C" void mjh_load_set_mesh_mode(int mode) { g_load_meshes = mode != 0; }

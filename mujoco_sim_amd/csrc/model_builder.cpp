@@ -10,7 +10,9 @@
 // from the CRBA used on the device, so the two cross-check each other in tests.
 #include <algorithm>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -29,7 +31,14 @@ struct BJoint {
 };
 struct BGeom {
   std::string name; int body, type; double size[3], pos[3], quat[4], friction[3];
-  int condim, contype, conaffinity; double density;
+  int condim, contype, conaffinity; double density; int mesh = -1;
+};
+// convex mesh asset in its own frame: origin = centre of mass, axes = principal axes of inertia
+struct BMesh {
+  std::vector<double> vert;        // support-relevant vertices, own frame
+  double pos[3], quat[4];          // own frame in the mesh file's frame
+  double volume, inertia[3];       // unit density
+  double rbound;
 };
 struct BEq { int j1, j2; double poly[5]; };
 
@@ -42,6 +51,7 @@ struct mjh_builder {
   std::vector<BBody> bodies;
   std::vector<BJoint> joints;
   std::vector<BGeom> geoms;
+  std::vector<BMesh> meshes;
   std::vector<std::pair<int,int>> excludes;
   std::vector<BEq> eqs;
 };
@@ -122,6 +132,132 @@ extern "C" int mjh_builder_add_geom(mjh_builder* b, const char* name, int body, 
   return (int)b->geoms.size() - 1;
 }
 
+// ---- convex mesh assets
+// Volume, centre of mass and inertia of a closed triangle mesh by signed tetrahedra against the origin
+// [UPSTREAM: mj_loadXML derives mesh inertia from the faces]; thin or open meshes fall back to the bounding box.
+static int add_mesh_impl(mjh_builder* b, std::vector<double> v, const int* face, int nface, const double scale[3]) {
+  int nv = (int)v.size() / 3;
+  if (nv < 4) { g_err = "add_mesh: fewer than 4 vertices"; return MJH_ERR_ARG; }
+  if (scale) for (int i = 0; i < nv; i++) for (int k = 0; k < 3; k++) v[3*i+k] *= scale[k];
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int i = 0; i < nv; i++) for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], v[3*i+k]); hi[k] = std::max(hi[k], v[3*i+k]); }
+  const double ext[3] = {hi[0]-lo[0], hi[1]-lo[1], hi[2]-lo[2]}, boxvol = ext[0]*ext[1]*ext[2];
+  double vol = 0, com[3] = {0, 0, 0}, C[9] = {0};   // C = integral of x x^T
+  for (int f = 0; f < nface; f++) {
+    const int ia = face[3*f], ib = face[3*f+1], ic = face[3*f+2];
+    if (ia < 0 || ib < 0 || ic < 0 || ia >= nv || ib >= nv || ic >= nv) { g_err = "add_mesh: face index out of range"; return MJH_ERR_ARG; }
+    const double *A = &v[3*ia], *Bv = &v[3*ib], *Cv = &v[3*ic];
+    double bc[3]; hm::cross(bc, Bv, Cv);
+    const double tv = hm::dot3(A, bc) / 6.0, sm[3] = {A[0]+Bv[0]+Cv[0], A[1]+Bv[1]+Cv[1], A[2]+Bv[2]+Cv[2]};
+    vol += tv;
+    for (int k = 0; k < 3; k++) com[k] += tv * sm[k] / 4.0;
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
+      C[3*r+c] += tv / 20.0 * (A[r]*A[c] + Bv[r]*Bv[c] + Cv[r]*Cv[c] + sm[r]*sm[c]);
+  }
+  if (vol < 0) { vol = -vol; for (int k = 0; k < 3; k++) com[k] = -com[k]; for (int k = 0; k < 9; k++) C[k] = -C[k]; }   // inward-facing triangles
+  BMesh M;
+  double It[9];
+  if (nface > 0 && boxvol > 0 && vol > 1e-4 * boxvol) {
+    for (int k = 0; k < 3; k++) com[k] /= vol;
+    double Cc[9];   // about the centre of mass
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Cc[3*r+c] = C[3*r+c] - vol * com[r] * com[c];
+    const double tr = Cc[0] + Cc[4] + Cc[8];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) It[3*r+c] = (r == c ? tr : 0.0) - Cc[3*r+c];
+    M.volume = vol;
+  } else {                                            // no usable faces: the bounding box stands in
+    for (int k = 0; k < 3; k++) com[k] = 0.5 * (lo[k] + hi[k]);
+    M.volume = std::max(boxvol, 1e-12);
+    for (int k = 0; k < 9; k++) It[k] = 0;
+    It[0] = M.volume / 12.0 * (ext[1]*ext[1] + ext[2]*ext[2]); It[4] = M.volume / 12.0 * (ext[0]*ext[0] + ext[2]*ext[2]);
+    It[8] = M.volume / 12.0 * (ext[0]*ext[0] + ext[1]*ext[1]);
+  }
+  double R[9] = {1,0,0, 0,1,0, 0,0,1};
+  if (std::fabs(It[1]) + std::fabs(It[2]) + std::fabs(It[5]) < 1e-12 * (It[0] + It[4] + It[8])) {
+    M.inertia[0] = It[0]; M.inertia[1] = It[4]; M.inertia[2] = It[8];
+  } else {
+    double e[3], V[9]; hm::eig3(It, e, V);
+    double c0[3] = {V[0], V[3], V[6]}, c1[3] = {V[1], V[4], V[7]}, c2[3];
+    hm::cross(c2, c0, c1);
+    const double Rm[9] = {c0[0], c1[0], c2[0], c0[1], c1[1], c2[1], c0[2], c1[2], c2[2]};
+    std::memcpy(R, Rm, sizeof R);
+    for (int k = 0; k < 3; k++) M.inertia[k] = e[k];
+  }
+  hm::mat2quat(M.quat, R);
+  for (int k = 0; k < 3; k++) M.pos[k] = com[k];
+  // own-frame coordinates
+  for (int i = 0; i < nv; i++) {
+    double d[3] = {v[3*i]-com[0], v[3*i+1]-com[1], v[3*i+2]-com[2]}, r[3];
+    hm::rotvecT(r, R, d);
+    v[3*i] = r[0]; v[3*i+1] = r[1]; v[3*i+2] = r[2];
+  }
+  // The mesh collides as its convex hull, and the hull's support mapping only ever returns hull vertices: keep the
+  // vertices that are extreme along a dense direction set (Fibonacci sphere + the 26 axis/diagonal directions).  An
+  // inner approximation of the hull: a hull vertex that is never selected is within a fraction of a degree of one.
+  std::vector<char> keep(nv, 0);
+  auto take = [&](const double* dir) {
+    double best = -1e300; int bi = 0;
+    for (int i = 0; i < nv; i++) { const double dp = v[3*i]*dir[0] + v[3*i+1]*dir[1] + v[3*i+2]*dir[2]; if (dp > best) { best = dp; bi = i; } }
+    keep[bi] = 1;
+  };
+  for (int x = -1; x <= 1; x++) for (int y = -1; y <= 1; y++) for (int z = -1; z <= 1; z++) if (x || y || z) { const double d[3] = {(double)x, (double)y, (double)z}; take(d); }
+  const int NDIR = 1500;
+  for (int i = 0; i < NDIR; i++) {
+    const double z = 1.0 - 2.0 * (i + 0.5) / NDIR, r = std::sqrt(std::max(0.0, 1.0 - z*z)), ph = i * 2.399963229728653;   // golden angle
+    const double d[3] = {r * std::cos(ph), r * std::sin(ph), z};
+    take(d);
+  }
+  M.rbound = 0;
+  for (int i = 0; i < nv; i++) if (keep[i]) {
+    M.vert.push_back(v[3*i]); M.vert.push_back(v[3*i+1]); M.vert.push_back(v[3*i+2]);
+    M.rbound = std::max(M.rbound, std::sqrt(v[3*i]*v[3*i] + v[3*i+1]*v[3*i+1] + v[3*i+2]*v[3*i+2]));
+  }
+  b->meshes.push_back(M);
+  return (int)b->meshes.size() - 1;
+}
+extern "C" int mjh_builder_add_mesh(mjh_builder* b, const double* vert, int nvert, const int* face, int nface, const double scale[3]) {
+  if (!b || !vert || nvert < 4 || (nface > 0 && !face)) { g_err = "add_mesh: bad arguments"; return MJH_ERR_ARG; }
+  return add_mesh_impl(b, std::vector<double>(vert, vert + 3 * (size_t)nvert), face, nface, scale);
+}
+// binary STL: 80-byte header, uint32 triangle count, 50 bytes per triangle (normal, 3 vertices, attribute)
+extern "C" int mjh_builder_add_mesh_stl(mjh_builder* b, const char* path, const double scale[3]) {
+  if (!b || !path) { g_err = "add_mesh_stl: bad arguments"; return MJH_ERR_ARG; }
+  FILE* f = std::fopen(path, "rb");
+  if (!f) { g_err = std::string("add_mesh_stl: cannot open ") + path; return MJH_ERR_ARG; }
+  unsigned char head[84];
+  unsigned ntri = 0;
+  if (std::fread(head, 1, 84, f) != 84) { std::fclose(f); g_err = std::string("add_mesh_stl: short file ") + path; return MJH_ERR_ARG; }
+  std::memcpy(&ntri, head + 80, 4);
+  if (ntri == 0 || ntri > 5000000u) { std::fclose(f); g_err = std::string("add_mesh_stl: not a binary STL: ") + path; return MJH_ERR_ARG; }
+  std::vector<unsigned char> buf((size_t)ntri * 50);
+  const size_t got = std::fread(buf.data(), 1, buf.size(), f);
+  std::fclose(f);
+  if (got != buf.size()) { g_err = std::string("add_mesh_stl: truncated (or ASCII) STL: ") + path; return MJH_ERR_ARG; }
+  std::vector<double> v((size_t)ntri * 9);
+  std::vector<int> face((size_t)ntri * 3);
+  for (unsigned t = 0; t < ntri; t++) {
+    float xyz[9]; std::memcpy(xyz, buf.data() + (size_t)t * 50 + 12, 36);
+    for (int k = 0; k < 9; k++) v[(size_t)t * 9 + k] = xyz[k];
+    for (int k = 0; k < 3; k++) face[(size_t)t * 3 + k] = (int)t * 3 + k;
+  }
+  return add_mesh_impl(b, std::move(v), face.data(), (int)ntri, scale);
+}
+extern "C" int mjh_builder_add_mesh_geom(mjh_builder* b, const char* name, int body, int mesh, const double pos[3], const double quat[4],
+                                         const double friction[3], int condim, int contype, int conaffinity, double density) {
+  if (!b || mesh < 0 || mesh >= (int)b->meshes.size()) { g_err = "add_mesh_geom: bad mesh id"; return MJH_ERR_ARG; }
+  const BMesh& M = b->meshes[mesh];
+  // geom frame = (file frame in the body) o (own frame in the file frame)
+  double q[4] = {1, 0, 0, 0}, p[3] = {0, 0, 0}, R[9], off[3], gq[4];
+  if (quat) { for (int k = 0; k < 4; k++) q[k] = quat[k]; hm::normalize4(q); }
+  if (pos) for (int k = 0; k < 3; k++) p[k] = pos[k];
+  hm::quat2mat(R, q); hm::rotvec(off, R, M.pos);
+  for (int k = 0; k < 3; k++) p[k] += off[k];
+  hm::mulquat(gq, q, M.quat);
+  const double size[3] = {M.rbound, 0, 0};
+  const int g = mjh_builder_add_geom(b, name, body, MJH_GEOM_MESH, size, p, gq, friction, condim, contype, conaffinity, density);
+  if (g >= 0) b->geoms[g].mesh = mesh;
+  return g;
+}
+
 extern "C" int mjh_builder_add_exclude(mjh_builder* b, int b1, int b2) { b->excludes.push_back({b1, b2}); return MJH_OK; }
 extern "C" int mjh_builder_add_eq_joint(mjh_builder* b, int j1, int j2, const double poly[5]) {
   BEq e; e.j1 = j1; e.j2 = j2; for (int i = 0; i < 5; i++) e.poly[i] = poly[i];
@@ -129,7 +265,7 @@ extern "C" int mjh_builder_add_eq_joint(mjh_builder* b, int j1, int j2, const do
 }
 
 // ---- geom mass properties (density * volume; inertia about geom centre, geom frame)
-static bool geom_massprops(const BGeom& g, double* mass, double I[3]) {
+static bool geom_massprops(const mjh_builder* B, const BGeom& g, double* mass, double I[3]) {
   const double pi = 3.14159265358979323846;
   const double* s = g.size;
   switch (g.type) {
@@ -153,6 +289,12 @@ static bool geom_massprops(const BGeom& g, double* mass, double I[3]) {
       double Izz = 0.5 * mc * r*r + 0.4 * ms * r*r;
       double Ixx = mc * (3*r*r + 4*h*h) / 12.0 + ms * (0.4*r*r + h*h + 0.75*r*h);
       I[0] = I[1] = Ixx; I[2] = Izz; return true; }
+    case MJH_GEOM_MESH: {
+      if (g.mesh < 0) return false;
+      const BMesh& M = B->meshes[g.mesh];
+      *mass = g.density * M.volume;
+      for (int k = 0; k < 3; k++) I[k] = g.density * M.inertia[k];
+      return true; }
     case MJH_GEOM_ELLIPSOID: {
       double m = g.density * 4.0 / 3.0 * pi * s[0]*s[1]*s[2];
       *mass = m;
@@ -168,6 +310,7 @@ static double geom_rbound(int type, const double* s) {
     case MJH_GEOM_CYLINDER: return std::sqrt(s[0]*s[0] + s[1]*s[1]);
     case MJH_GEOM_BOX: return std::sqrt(s[0]*s[0] + s[1]*s[1] + s[2]*s[2]);
     case MJH_GEOM_ELLIPSOID: return std::max(s[0], std::max(s[1], s[2]));
+    case MJH_GEOM_MESH: return s[0];   // size[0] of a mesh geom = bounding radius of its vertices about the centre of mass
     default: return 0;  // plane: unbounded, handled by the pair routine
   }
 }
@@ -177,15 +320,16 @@ extern "C" double mjh_geom_rbound(int type, const double* size) { return geom_rb
 static bool pair_supported(int t1, int t2) {
   if (t1 > t2) std::swap(t1, t2);
   auto is = [](int t, int a) { return t == a; };
-  if (is(t1, MJH_GEOM_HFIELD) || is(t2, MJH_GEOM_HFIELD) || is(t2, MJH_GEOM_MESH)) return false;   // mesh geoms: not yet
+  if (is(t1, MJH_GEOM_HFIELD) || is(t2, MJH_GEOM_HFIELD)) return false;
   if (is(t1, MJH_GEOM_PLANE)) return t2 != MJH_GEOM_PLANE;
-  return true;   // analytic routine, or the generic convex narrow phase (cylinder-x, capsule-box, ellipsoid-x)
+  return true;   // analytic routine, or the generic convex narrow phase (cylinder-x, capsule-box, ellipsoid-x, mesh-x)
 }
 static int pair_maxcon(int t1, int t2) {
   if (t1 > t2) std::swap(t1, t2);
   if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_BOX) return 4;
   if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_CAPSULE) return 2;
   if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_CYLINDER) return 4;
+  if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_MESH) return 4;
   if (t1 == MJH_GEOM_BOX && t2 == MJH_GEOM_BOX) return 8;
   return 1;
 }
@@ -294,13 +438,21 @@ extern "C" mjh_model* mjh_builder_compile(mjh_builder* B) {
   std::vector<double> geom_pos(3*ngeom), geom_quat(4*ngeom), geom_size(3*ngeom), geom_rb(ngeom), geom_friction(3*ngeom),
       geom_solmix(ngeom), geom_solref(2*ngeom), geom_solimp(5*ngeom), geom_margin(ngeom), geom_gap(ngeom);
   std::vector<std::string> geom_names(ngeom);
+  std::vector<int> geom_dataid(ngeom, -1), mesh_vertadr, mesh_vertnum;
+  std::vector<double> mesh_vert;
+  for (const BMesh& Mh : B->meshes) {
+    mesh_vertadr.push_back((int)mesh_vert.size() / 3); mesh_vertnum.push_back((int)Mh.vert.size() / 3);
+    mesh_vert.insert(mesh_vert.end(), Mh.vert.begin(), Mh.vert.end());
+  }
   for (int g = 0; g < ngeom; g++) {
     const BGeom& G = B->geoms[gorder[g]];
+    if (G.type == MJH_GEOM_MESH && G.mesh < 0) { g_err = "mesh geom without a mesh (use mjh_builder_add_mesh_geom)"; return nullptr; }
     geom_names[g] = G.name; geom_type[g] = G.type; geom_bodyid[g] = newid[G.body];
     geom_condim[g] = G.condim; geom_contype[g] = G.contype; geom_conaffinity[g] = G.conaffinity; geom_priority[g] = 0;
     for (int k = 0; k < 3; k++) { geom_pos[3*g+k] = G.pos[k]; geom_size[3*g+k] = G.size[k]; geom_friction[3*g+k] = G.friction[k]; }
     for (int k = 0; k < 4; k++) geom_quat[4*g+k] = G.quat[k];
     geom_rb[g] = geom_rbound(G.type, G.size);
+    geom_dataid[g] = G.type == MJH_GEOM_MESH ? G.mesh : -1;
     geom_solmix[g] = 1; geom_solref[2*g] = 0.02; geom_solref[2*g+1] = 1;
     const double si[5] = {0.9, 0.95, 0.001, 0.5, 2};
     for (int k = 0; k < 5; k++) geom_solimp[5*g+k] = si[k];
@@ -318,7 +470,7 @@ extern "C" mjh_model* mjh_builder_compile(mjh_builder* B) {
     }
     double M = 0, com[3] = {0,0,0};
     for (int g = 0; g < ngeom; g++) if (geom_bodyid[g] == i) {
-      double m, I[3]; if (!geom_massprops(B->geoms[gorder[g]], &m, I)) continue;
+      double m, I[3]; if (!geom_massprops(B, B->geoms[gorder[g]], &m, I)) continue;
       M += m; for (int k = 0; k < 3; k++) com[k] += m * geom_pos[3*g+k];
     }
     if (M <= 0) {  // massless (e.g. a frame body): leave zero; dynamics will need armature
@@ -327,7 +479,7 @@ extern "C" mjh_model* mjh_builder_compile(mjh_builder* B) {
     for (int k = 0; k < 3; k++) com[k] /= M;
     double It[9] = {0};
     for (int g = 0; g < ngeom; g++) if (geom_bodyid[g] == i) {
-      double m, I[3]; if (!geom_massprops(B->geoms[gorder[g]], &m, I)) continue;
+      double m, I[3]; if (!geom_massprops(B, B->geoms[gorder[g]], &m, I)) continue;
       double R[9]; hm::quat2mat(R, &geom_quat[4*g]);
       // R diag(I) R^T + m (|d|^2 1 - d d^T)
       double d[3] = {geom_pos[3*g] - com[0], geom_pos[3*g+1] - com[1], geom_pos[3*g+2] - com[2]};
@@ -613,6 +765,8 @@ extern "C" mjh_model* mjh_builder_compile(mjh_builder* B) {
   SETI(geom_solref); SETI(geom_solimp); SETI(geom_margin); SETI(geom_gap);
   SETI(pair_geom1); SETI(pair_geom2);
   SETI(eq_type); SETI(eq_obj1id); SETI(eq_obj2id); SETI(eq_active); SETI(eq_data); SETI(eq_solref); SETI(eq_solimp);
+  m->nmesh = (int)mesh_vertadr.size(); m->nmeshvert = (int)mesh_vert.size() / 3;
+  SETI(geom_dataid); SETI(mesh_vertadr); SETI(mesh_vertnum); SETI(mesh_vert);
 #undef SETI
   m->body_names = dupnames(body_names); m->jnt_names = dupnames(jnt_names); m->geom_names = dupnames(geom_names);
   return m;
@@ -628,7 +782,8 @@ extern "C" void mjh_model_destroy(mjh_model* m) {
     m->dof_frictionloss, m->dof_invweight0, m->dof_solref, m->dof_solimp, m->tree_dofadr, m->tree_dofnum, m->tree_bodyid,
     m->geom_type, m->geom_bodyid, m->geom_condim, m->geom_contype, m->geom_conaffinity, m->geom_priority, m->geom_pos, m->geom_quat,
     m->geom_size, m->geom_rbound, m->geom_friction, m->geom_solmix, m->geom_solref, m->geom_solimp, m->geom_margin, m->geom_gap,
-    m->pair_geom1, m->pair_geom2, m->eq_type, m->eq_obj1id, m->eq_obj2id, m->eq_active, m->eq_data, m->eq_solref, m->eq_solimp};
+    m->pair_geom1, m->pair_geom2, m->eq_type, m->eq_obj1id, m->eq_obj2id, m->eq_active, m->eq_data, m->eq_solref, m->eq_solimp,
+    m->geom_dataid, m->mesh_vertadr, m->mesh_vertnum, m->mesh_vert};
   for (void* p : ptrs) std::free(p);
   auto freen = [](char** n, int c) { if (!n) return; for (int i = 0; i < c; i++) std::free(n[i]); std::free(n); };
   freen(m->body_names, m->nbody); freen(m->jnt_names, m->njnt); freen(m->geom_names, m->ngeom);

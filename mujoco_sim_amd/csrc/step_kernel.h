@@ -439,7 +439,9 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
   return niter;
 }
 
-template <int NROW, bool DIAGM>
+// CONVEX: the model has a pair for the generic convex narrow phase (cylinder-x, capsule-box, ellipsoid-x, mesh geoms);
+// a separate instantiation so that models without one (S24, box piles) keep their code size and register allocation
+template <int NROW, bool DIAGM, bool CONVEX>
 __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restrict__ C, const DState S, int env0, int nsteps, int ph, int xflags) {
   // model descriptor + LDS layout live in device memory (uploaded once): uniform scalar loads on demand instead
   // of a by-value kernarg struct that the lambdas below would force into a private (scratch) copy
@@ -749,9 +751,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           st = s_stage + pair_stageadr[ip] * RAW_STRIDE;
           const int t1 = geom_type[g1], t2 = geom_type[g2];
           margin = fmaxf(geom_margin[g1], geom_margin[g2]); gap = fmaxf(geom_gap[g1], geom_gap[g2]);
-          CvxGeom G1, G2;
-          G1.type = t1; G2.type = t2; G1.vert = G2.vert = nullptr; G1.nvert = G2.nvert = 0;
-          float *p1 = G1.pos, *p2 = G2.pos, *m1 = G1.mat, *m2 = G2.mat, *z1 = G1.size, *z2 = G2.size;
+          float p1[3], p2[3], m1[9], m2[9], z1[3], z2[3];
 #pragma unroll
           for (int k = 0; k < 3; k++) { p1[k] = s_gpos[3*g1+k]; p2[k] = s_gpos[3*g2+k]; z1[k] = s_p_gsize[3*g1+k]; z2[k] = s_p_gsize[3*g2+k]; }
 #pragma unroll
@@ -773,7 +773,24 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             else if (t1 == MJH_GEOM_CAPSULE && t2 == MJH_GEOM_CAPSULE) n = c_capsule_capsule(p1, m1, z1, p2, m2, z2, margin, st);
             else if (t1 == MJH_GEOM_SPHERE && t2 == MJH_GEOM_BOX) n = c_sphere_box(p1, z1[0], p2, m2, z2, margin, st);
             else if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_ELLIPSOID) n = c_plane_ellipsoid(p1, m1, p2, m2, z2, margin, st);
-            else if (M.has_convex && pair_is_convex(t1, t2)) n = c_convex(G1, G2, margin, st);
+            else if (CONVEX && t2 == MJH_GEOM_MESH && t1 == MJH_GEOM_PLANE) {
+              const Tab<int> geom_dataid{M.I, M.o_geom_dataid}, mesh_vertadr{M.I, M.o_mesh_vertadr}, mesh_vertnum{M.I, M.o_mesh_vertnum};
+              const Tab<float> mesh_vert{M.F, M.o_mesh_vert};
+              const int id = geom_dataid[g2];
+              n = c_plane_mesh(p1, m1, p2, m2, mesh_vert + 3 * mesh_vertadr[id], mesh_vertnum[id], margin, st);
+            } else if (CONVEX && pair_is_convex(t1, t2)) {
+              const Tab<int> geom_dataid{M.I, M.o_geom_dataid}, mesh_vertadr{M.I, M.o_mesh_vertadr}, mesh_vertnum{M.I, M.o_mesh_vertnum};
+              const Tab<float> mesh_vert{M.F, M.o_mesh_vert};
+              CvxGeom G1, G2;
+              G1.type = t1; G2.type = t2; G1.vert = G2.vert = nullptr; G1.nvert = G2.nvert = 0;
+              if (t1 == MJH_GEOM_MESH) { const int id = geom_dataid[g1]; G1.vert = mesh_vert + 3 * mesh_vertadr[id]; G1.nvert = mesh_vertnum[id]; }
+              if (t2 == MJH_GEOM_MESH) { const int id = geom_dataid[g2]; G2.vert = mesh_vert + 3 * mesh_vertadr[id]; G2.nvert = mesh_vertnum[id]; }
+#pragma unroll
+              for (int k = 0; k < 3; k++) { G1.pos[k] = p1[k]; G2.pos[k] = p2[k]; G1.size[k] = z1[k]; G2.size[k] = z2[k]; }
+#pragma unroll
+              for (int k = 0; k < 9; k++) { G1.mat[k] = m1[k]; G2.mat[k] = m2[k]; }
+              n = c_convex(G1, G2, margin, st);
+            }
           }
         }
         const int incl = wave_incl_scan_i(n, lane);

@@ -456,6 +456,52 @@ static int c_plane_ellipsoid(const double* pp, const double* pm, const double* c
   for (int k = 0; k < 3; k++) out->pos[k] = pw[k] - n[k] * 0.5 * dist;
   return 1;
 }
+/* plane - convex mesh (this project's definition; [UPSTREAM mjc_PlaneConvex] also returns the support vertex first and
+ * adds up to three more): vertices below the margin; the deepest one, the one farthest from it, the one farthest from
+ * the line through those two, and the one farthest on the other side of that line; at most 4 */
+#define PLANE_MESH_EPS2 1e-8
+static int c_plane_mesh(const double* pp, const double* pm, const double* c, const double* mm, const double* vert, int nvert,
+                        double margin, rawcon* out) {
+  double n[3] = {pm[2], pm[5], pm[8]}, nl[3], t[3] = {c[0]-pp[0], c[1]-pp[1], c[2]-pp[2]};
+  rotvecT(nl, mm, n);
+  const double d0 = dot3(t, n);
+  int pick[4], cnt = 0;
+  double best = 1e300; int bi = -1;
+  for (int i = 0; i < nvert; i++) { double di = d0 + dot3(vert + 3*i, nl); if (di < best) { best = di; bi = i; } }
+  if (bi < 0 || best > margin) return 0;
+  pick[cnt++] = bi;
+  const double* v1 = vert + 3*bi;
+  best = PLANE_MESH_EPS2; bi = -1;
+  for (int i = 0; i < nvert; i++) {
+    if (d0 + dot3(vert + 3*i, nl) > margin) continue;
+    double e[3] = {vert[3*i]-v1[0], vert[3*i+1]-v1[1], vert[3*i+2]-v1[2]}, l2 = dot3(e, e);
+    if (l2 > best) { best = l2; bi = i; }
+  }
+  if (bi >= 0) {
+    pick[cnt++] = bi;
+    const double* v2 = vert + 3*bi;
+    double e12[3] = {v2[0]-v1[0], v2[1]-v1[1], v2[2]-v1[2]}, side[3];
+    cross3(side, e12, nl);                       /* in-plane direction across the line */
+    double bpos = sqrt(PLANE_MESH_EPS2 * dot3(e12, e12)), bneg = bpos; int ipos = -1, ineg = -1;
+    for (int i = 0; i < nvert; i++) {
+      if (d0 + dot3(vert + 3*i, nl) > margin) continue;
+      double e[3] = {vert[3*i]-v1[0], vert[3*i+1]-v1[1], vert[3*i+2]-v1[2]}, sd = dot3(e, side);
+      if (sd > bpos) { bpos = sd; ipos = i; }
+      if (-sd > bneg) { bneg = -sd; ineg = i; }
+    }
+    if (ipos >= 0 && ineg >= 0) { if (bpos >= bneg) { pick[cnt++] = ipos; pick[cnt++] = ineg; } else { pick[cnt++] = ineg; pick[cnt++] = ipos; } }
+    else if (ipos >= 0) pick[cnt++] = ipos;
+    else if (ineg >= 0) pick[cnt++] = ineg;
+  }
+  for (int q = 0; q < cnt; q++) {
+    double w[3];
+    rotvec(w, mm, vert + 3*pick[q]);
+    double di = d0 + dot3(vert + 3*pick[q], nl);
+    out[q].dist = di; copyv(out[q].n, n, 3);
+    for (int k = 0; k < 3; k++) out[q].pos[k] = c[k] + w[k] - n[k] * 0.5 * di;
+  }
+  return cnt;
+}
 static int c_plane_box(const double* pp, const double* pm, const double* c, const double* bm, const double* size, double margin, rawcon* out) {
   double n[3] = {pm[2], pm[5], pm[8]}, t[3] = {c[0]-pp[0], c[1]-pp[1], c[2]-pp[2]};
   double dist = dot3(t, n);
@@ -824,9 +870,10 @@ static int c_convex(const cvx_geom* g1, const cvx_geom* g2, double margin, rawco
   return 1;
 }
 /* test hook: one convex pair */
-int orc_convex_pair(int t1, const double* p1, const double* m1, const double* s1, int t2, const double* p2, const double* m2, const double* s2,
+int orc_convex_pair(int t1, const double* p1, const double* m1, const double* s1, const double* v1, int n1,
+                    int t2, const double* p2, const double* m2, const double* s2, const double* v2, int n2,
                     double margin, double* dist, double* pos, double* normal) {
-  cvx_geom a = {t1, p1, m1, s1, 0, 0, 0}, b = {t2, p2, m2, s2, 0, 0, 0};
+  cvx_geom a = {t1, p1, m1, s1, 0, v1, n1}, b = {t2, p2, m2, s2, 0, v2, n2};
   rawcon rc;
   int n = c_convex(&a, &b, margin, &rc);
   if (n) { *dist = rc.dist; copyv(pos, rc.pos, 3); copyv(normal, rc.n, 3); }
@@ -878,8 +925,14 @@ void orc_collision(orc_data* d) {
       for (int q = 0; q < n; q++) { rc[q].dist = bd[q]; copyv(rc[q].pos, bp + 3*q, 3); copyv(rc[q].n, bn, 3); }
     }
     else if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_ELLIPSOID) n = c_plane_ellipsoid(p1, m1, p2, m2, s2, margin, rc);
+    else if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_MESH) {
+      int id = m->geom_dataid[g2];
+      n = c_plane_mesh(p1, m1, p2, m2, m->mesh_vert + 3*m->mesh_vertadr[id], m->mesh_vertnum[id], margin, rc);
+    }
     else if (pair_is_convex(t1, t2)) {
       cvx_geom a = {t1, p1, m1, s1, 0, 0, 0}, b = {t2, p2, m2, s2, 0, 0, 0};
+      if (t1 == MJH_GEOM_MESH) { int id = m->geom_dataid[g1]; a.vert = m->mesh_vert + 3*m->mesh_vertadr[id]; a.nvert = m->mesh_vertnum[id]; }
+      if (t2 == MJH_GEOM_MESH) { int id = m->geom_dataid[g2]; b.vert = m->mesh_vert + 3*m->mesh_vertadr[id]; b.nvert = m->mesh_vertnum[id]; }
       n = c_convex(&a, &b, margin, rc);
     }
     if (!n) continue;

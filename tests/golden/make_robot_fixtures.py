@@ -4,8 +4,13 @@ that the GPU box — which has no /root/reference — can rebuild the model and 
 
     python tests/golden/make_robot_fixtures.py        (CPU container only; needs /root/reference)
 
-Mesh geoms are skipped by the loader, so these models exercise the articulated-body half of the
-path: 30-50 dof single trees, equality constraints, joint limits, friction loss, damping, gravity compensation."""
+The first six fixtures are compiled with the mesh assets switched off (mjh_load_set_mesh_mode(0)): they exercise the
+articulated-body half of the path — 30-50 dof single trees, equality constraints, joint limits, friction loss, damping,
+gravity compensation — with the primitive collision geometry only.  The *_mesh fixtures are PR2 with its 18 STL meshes
+(37 mesh geoms colliding as convex hulls; pr2.xml carries the 105 <exclude> pairs that make this well-posed — the tiago,
+hsrb4s and ridgeback_panda test files have no exclude list and their hulls overlap permanently at the rest pose, so they
+stay primitive-only here); contacts through the generic convex narrow phase make long horizons chaotic, so those
+trajectories are short."""
 import os
 import sys
 
@@ -16,7 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, os.path.dirname(HERE))
 import mujoco_sim_amd as ms  # noqa: E402
 import orc  # noqa: E402
-from helpers import save_model_tables  # noqa: E402
+from mujoco_sim_amd.tables import save_model_tables  # noqa: E402
 
 REF = "/root/reference/model/test"
 # name -> (file under model/test, contact capacity: LDS budget; the meshes are skipped anyway)
@@ -24,9 +29,12 @@ ROBOTS = {"pr2": ("pr2/pr2.xml", 16), "tiago": ("tiago/tiago.xml", 40), "hsrb4s"
           "ridgeback_panda": ("ridgeback_panda/ridgeback_panda.xml", 32),
           # composed with the reference's world file (floor plane, condim 4) the way MjSim::init composes them: the robot
           # stands on its wheels / casters (plane-cylinder, plane-sphere, plane-box contacts)
-          "pr2_world": ("../world/empty.xml+pr2/pr2.xml", 48), "hsrb4s_world": ("../world/empty.xml+hsrb4s/hsrb4s.xml", 24)}
+          "pr2_world": ("../world/empty.xml+pr2/pr2.xml", 48), "hsrb4s_world": ("../world/empty.xml+hsrb4s/hsrb4s.xml", 24),
+          "pr2_mesh": ("pr2/pr2.xml", 16), "pr2_world_mesh": ("../world/empty.xml+pr2/pr2.xml", 48)}
 STEPS = 300
 KEEP = (1, 10, 50, 100, 200, 300)
+MESH_STEPS = 60
+MESH_KEEP = (1, 5, 20, 60)
 
 
 def command(m, k):
@@ -44,7 +52,12 @@ def main():
     # the reference writes boundmass = boundinertia = 1e-6 into every file before mj_loadXML (mj_sim.cpp:584-590)
     ms.capi.load().mjh_load_set_bounds(1e-6, 1e-6)
     for name, (rel, cap) in ROBOTS.items():
+        mesh = name.endswith("_mesh")
+        ms.capi.load().mjh_load_set_mesh_mode(1 if mesh else 0)
         m = ms.load_mjcf(paths=[os.path.join(REF, r) for r in rel.split("+")])
+        ms.capi.load().mjh_load_set_mesh_mode(1)
+        assert (m.c.nmesh > 0) == mesh
+        steps, keep = (MESH_STEPS, MESH_KEEP) if mesh else (STEPS, KEEP)
         m.c.maxcon = cap; m.c.maxefc = 6 * cap + m.neq + 2 * m.njnt + m.nv
         d = orc.OrcData(m.ptr)
         ctrl = np.zeros(m.nv, dtype=np.int32)
@@ -55,18 +68,18 @@ def main():
         d.ifield("controlled")[:] = ctrl
         out = {}
         maxcon_seen = 0
-        for k in range(1, STEPS + 1):
+        for k in range(1, steps + 1):
             d.f("ddq")[:] = command(m, k)
             d.step(1, 1)
             assert d.i("warn") == 0 and d.i("ncon") < cap, (name, k, d.i("warn"), d.i("ncon"))   # no capacity overflow, no reset
             maxcon_seen = max(maxcon_seen, d.i("ncon"))
-            if k in KEEP:
+            if k in keep:
                 out[f"qpos_{k}"] = d.f("qpos").copy(); out[f"qvel_{k}"] = d.f("qvel").copy()
                 out[f"qfrc_inverse_{k}"] = d.f("qfrc_inverse").copy()
                 out[f"nefc_{k}"] = np.int64(d.i("nefc"))
-        save_model_tables(m, os.path.join(HERE, f"robot_{name}.npz"), controlled=ctrl, **out)
+        save_model_tables(m, os.path.join(HERE, f"robot_{name}.npz"), controlled=ctrl, keep=np.array(keep), **out)
         print(name, "nq", m.nq, "nv", m.nv, "neq", m.neq, "nefc", d.i("nefc"), "|qvel|max %.3f" % np.abs(d.f("qvel")).max(),
-              "max ncon", maxcon_seen, "file %.1f KB" % (os.path.getsize(os.path.join(HERE, f"robot_{name}.npz")) / 1e3))
+              "max ncon", maxcon_seen, "npair", m.c.npair, "mesh vertices", m.c.nmeshvert, "file %.1f KB" % (os.path.getsize(os.path.join(HERE, f"robot_{name}.npz")) / 1e3))
 
 
 if __name__ == "__main__":

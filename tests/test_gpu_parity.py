@@ -540,7 +540,7 @@ def layout_policy(lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("layout", [1, 2], ids=["lds-resident", "global-pools"])
-@pytest.mark.parametrize("name", ["pr2", "tiago", "hsrb4s", "ridgeback_panda", "pr2_world", "hsrb4s_world"])
+@pytest.mark.parametrize("name", ["pr2", "tiago", "hsrb4s", "ridgeback_panda", "pr2_world", "hsrb4s_world", "pr2_mesh", "pr2_world_mesh"])
 def test_reference_robot_models_match_oracle(name, layout, layout_policy):
     """C4-type articulated models (the reference's pr2 / tiago / hsrb4s test assets, compiled to table fixtures by
     tests/golden/make_robot_fixtures.py; meshes skipped): 32-49 dof single trees with equality constraints, joint
@@ -548,14 +548,15 @@ def test_reference_robot_models_match_oracle(name, layout, layout_policy):
     single-block sweep.  The computed-torque wrapper (mj_sim.cpp:1055-1063) and mj_inverse run every step."""
     import mujoco_sim_amd as ms
     from helpers import load_model_tables
-    from test_robot_fixtures import KEEP, robot_command
+    from test_robot_fixtures import robot_command
     m, z = load_model_tables(os.path.join(ROOT, "tests", "golden", f"robot_{name}.npz"))
+    KEEP = [int(k) for k in z["keep"]]     # the *_mesh fixtures (PR2 with its 37 convex-hull mesh geoms) keep a short horizon
     nenv = 4
     layout_policy(layout)     # both memory layouts: pools in LDS (dual / single-block sweeps) and in global memory (three-launch step)
     e = ms.Engine(m, nenv)
     e.set_controlled_dofs(z["controlled"].astype(np.int32))
     d = orc.OrcData(m.ptr); d.ifield("controlled")[:] = z["controlled"]
-    for k in range(1, 301):
+    for k in range(1, KEEP[-1] + 1):
         cmd = robot_command(m, k)
         e.set_cmd(ddq=np.tile(cmd, (nenv, 1)))
         e.step(1, True)
@@ -880,4 +881,114 @@ def test_generic_convex_rollout(lib):
     assert e.get_stats()[0, 3] == 0
     assert np.all(q[0, 2::7] > 0.03) and np.all(q[0, 2::7] < 0.45)          # nothing fell through the floor or flew away
     assert np.abs(v[0]).max() < 30.0                                        # (the round ones keep rolling: no rolling friction at condim 3)
+    e.close()
+
+
+def _random_hull(rng, n, scale):
+    """a random convex polyhedron (vertices + outward-oriented triangles)"""
+    from scipy.spatial import ConvexHull
+    pts = rng.normal(size=(n, 3)); pts /= np.linalg.norm(pts, axis=1)[:, None]; pts *= scale * rng.uniform(0.7, 1.0, size=(n, 1))
+    hull = ConvexHull(pts)
+    faces = []
+    for simplex, eq in zip(hull.simplices, hull.equations):
+        a, b, c = pts[simplex]
+        faces.append(simplex if np.dot(np.cross(b - a, c - a), eq[:3]) > 0 else simplex[::-1])
+    return pts, np.array(faces, dtype=np.int32)
+
+
+def _mesh_zoo(lib, with_floor):
+    """a static block, three free convex-mesh bodies (a box given as a mesh, two random polyhedra) and a free cylinder"""
+    import ctypes as C
+    from test_oracle_collision import CUBE_F, CUBE_V
+    rng = np.random.default_rng(21)
+    b = lib.mjh_builder_create()
+    set_opt(lib, b, timestep=0.004)
+    if with_floor:
+        lib.mjh_builder_add_geom(b, b"floor", 0, 0, D(0, 0, 0.05), None, None, None, -1, -1, -1, -1)
+    lib.mjh_builder_add_geom(b, b"block", 0, 6, D(0.25, 0.2, 0.1), D(0, 0, 0.1), None, None, -1, -1, -1, -1)
+    meshes = [(CUBE_V * np.array([0.08, 0.06, 0.04]), CUBE_F), _random_hull(rng, 40, 0.09), _random_hull(rng, 120, 0.07)]
+    for k, (v, f) in enumerate(meshes):
+        v = np.ascontiguousarray(v, dtype=np.float64); f = np.ascontiguousarray(f, dtype=np.int32)
+        mid = lib.mjh_builder_add_mesh(b, v.ctypes.data_as(C.POINTER(C.c_double)), len(v), f.ctypes.data_as(C.POINTER(C.c_int)), len(f), None)
+        assert mid == k
+        bd = lib.mjh_builder_add_body(b, b"mesh%d" % k, 0, D(0.2 * k - 0.3, 0, 0.6), None, 0.0)
+        lib.mjh_builder_add_joint(b, None, bd, 0, None, None, None, 0, 0, 0, 0, 0)
+        assert lib.mjh_builder_add_mesh_geom(b, None, bd, mid, None, None, None, -1, -1, -1, -1) >= 0
+    bd = lib.mjh_builder_add_body(b, b"cyl", 0, D(0.3, 0, 0.6), None, 0.0)
+    lib.mjh_builder_add_joint(b, None, bd, 0, None, None, None, 0, 0, 0, 0, 0)
+    lib.mjh_builder_add_geom(b, None, bd, 5, D(0.05, 0.08, 0), None, None, None, -1, -1, -1, -1)
+    m = ms.Model(lib.mjh_builder_compile(b), lib)
+    lib.mjh_builder_destroy(b)
+    return m
+
+
+def test_convex_mesh_contacts_match_oracle(lib):
+    """mesh geoms collide as convex hulls through their vertex tables: plane-mesh (up to 4 points) and mesh-x (portal
+    refinement with a vertex-scan support mapping), device against oracle from identical poses"""
+    m = _mesh_zoo(lib, with_floor=True)
+    assert m.c.nmesh == 3 and m.nv == 24 and m.npair == 4 + 4 + 6
+    nenv = 128
+    rng = np.random.default_rng(12)
+    q = np.zeros((nenv, m.nq))
+    for i in range(nenv):
+        for k in range(4):
+            if i % 2 == 0:      # a cluster above the block
+                p = rng.normal(size=3); p *= rng.uniform(0.05, 0.3) / np.linalg.norm(p); p[2] = abs(p[2]) + 0.2 + rng.uniform(0.0, 0.1)
+            else:               # spread out on the floor next to the block
+                p = np.array([0.5 + 0.25 * k, rng.uniform(-0.1, 0.1), rng.uniform(0.02, 0.09)])
+            quat = rng.normal(size=4); quat /= np.linalg.norm(quat)
+            q[i, 7*k:7*k+3] = p; q[i, 7*k+3:7*k+7] = quat
+    e = ms.Engine(m, nenv)
+    e.set_initial_qpos(q); e.reset(); e.forward(); e.synchronize()
+    npairs = nsoft = nmiss = nplane = 0
+    for i in range(nenv):
+        d = orc.OrcData(m.ptr); d.set_qpos(q[i]); d.call("reset"); d.call("forward")
+        oc = {}
+        for x in d.contacts():
+            oc.setdefault(x["geom"], []).append(x)
+        c = e.get_contacts(i)
+        dc = {}
+        for k, g in enumerate(c["geom"]):
+            dc.setdefault(tuple(int(v) for v in g), []).append(k)
+        for key in set(oc) | set(dc):
+            if key not in oc or key not in dc:
+                depth = max(-x["dist"] for x in oc[key]) if key in oc else max(-c["dist"][k] for k in dc[key])
+                assert depth < 2e-4, (i, key, depth)
+                nmiss += 1
+                continue
+            if key[0] == 0:                                       # plane - x: the same points (the order may differ on ties)
+                od = sorted(x["dist"] for x in oc[key]); dd = sorted(c["dist"][k] for k in dc[key])
+                if len(od) == len(dd):
+                    np.testing.assert_allclose(dd, od, atol=2e-5, err_msg=str((i, key)))
+                    nplane += 1
+                else:
+                    assert abs(len(od) - len(dd)) == 1 and max(od[-1], dd[-1]) > -2e-4, (i, key, od, dd)      # a grazing vertex
+                continue
+            o, k = oc[key][0], dc[key][0]
+            assert len(oc[key]) == 1 and len(dc[key]) == 1
+            npairs += 1
+            if o["dist"] < -0.03:
+                continue
+            np.testing.assert_allclose(c["dist"][k], o["dist"], atol=3e-4, err_msg=str((i, key)))
+            if np.abs(c["frame"][k][:3] - o["frame"][:3]).max() > 0.05 or np.abs(c["pos"][k] - o["pos"]).max() > 5e-3:
+                nsoft += 1
+    e.close()
+    assert npairs >= 100 and nplane >= 100 and nsoft <= 0.15 * npairs and nmiss <= 0.05 * (npairs + nplane), (npairs, nplane, nsoft, nmiss)
+
+
+def test_convex_mesh_rollout(lib):
+    """mesh bodies dropped on the block and the floor: short-horizon parity, then rest on the floor / the block"""
+    m = _mesh_zoo(lib, with_floor=True)
+    q0 = m.array("qpos0").copy()
+    rng = np.random.default_rng(4)
+    for k in range(4):
+        q0[7*k:7*k+3] = [0.16 * k - 0.24, 0.02 * (k % 2), 0.30 + 0.03 * k]
+        quat = rng.normal(size=4); q0[7*k+3:7*k+7] = quat / np.linalg.norm(quat)
+    _compare_rollout(m, q0, [1, 10, 25], [1e-5, 2e-4, 3e-3])
+    e = ms.Engine(m, 2)
+    e.set_initial_qpos(np.tile(q0, (2, 1))); e.reset(); e.step(1500)
+    _, q, v, _ = e.get_state()
+    assert e.get_stats()[0, 3] == 0
+    assert np.all(q[0, 2::7] > 0.02) and np.all(q[0, 2::7] < 0.45)
+    assert np.abs(v[0]).max() < 5.0                                           # (a polyhedron on a single contact point keeps rocking a little; the cylinder may roll)
     e.close()

@@ -11,11 +11,12 @@ import orc
 from conftest import ROOT
 from helpers import load_model_tables
 
-ROBOTS = ["pr2", "tiago", "hsrb4s", "ridgeback_panda", "pr2_world", "hsrb4s_world"]
+ROBOTS = ["pr2", "tiago", "hsrb4s", "ridgeback_panda", "pr2_world", "hsrb4s_world", "pr2_mesh", "pr2_world_mesh"]
 FILES = {"pr2": "pr2/pr2.xml", "tiago": "tiago/tiago.xml", "hsrb4s": "hsrb4s/hsrb4s.xml",
          "ridgeback_panda": "ridgeback_panda/ridgeback_panda.xml",
-         "pr2_world": "../world/empty.xml+pr2/pr2.xml", "hsrb4s_world": "../world/empty.xml+hsrb4s/hsrb4s.xml"}
-KEEP = (1, 10, 50, 100, 200, 300)
+         "pr2_world": "../world/empty.xml+pr2/pr2.xml", "hsrb4s_world": "../world/empty.xml+hsrb4s/hsrb4s.xml",
+         # PR2 with its 18 STL meshes (37 mesh geoms colliding as convex hulls); the others are compiled with the meshes off
+         "pr2_mesh": "pr2/pr2.xml", "pr2_world_mesh": "../world/empty.xml+pr2/pr2.xml"}
 REF = "/root/reference/model/test"
 
 
@@ -32,14 +33,17 @@ def robot_command(m, k):
 def test_oracle_reproduces_robot_golden(lib, name):
     m, z = load_model_tables(os.path.join(ROOT, "tests", "golden", f"robot_{name}.npz"))
     assert m.ntree == 1 and m.nv >= 20
-    if name.endswith("_world"):
+    if "_world" in name:
         assert m.array("geom_type")[0] == 0 and m.array("geom_condim")[0] == 4      # the world file's floor plane
     d = orc.OrcData(m.ptr)
     d.ifield("controlled")[:] = z["controlled"]
-    for k in range(1, 101):
+    keep = [int(k) for k in z["keep"]]
+    if name.endswith("_mesh"):
+        assert m.c.nmesh == 18 and (m.array("geom_type") == 7).sum() == 37 and m.c.npair > 1000
+    for k in range(1, min(100, keep[-1]) + 1):
         d.f("ddq")[:] = robot_command(m, k)
         d.step(1, 1)
-        if k in KEEP:
+        if k in keep:
             np.testing.assert_allclose(d.f("qpos"), z[f"qpos_{k}"], rtol=0, atol=1e-9)
             np.testing.assert_allclose(d.f("qfrc_inverse"), z[f"qfrc_inverse_{k}"], rtol=1e-7, atol=1e-7)
             assert d.i("nefc") == int(z[f"nefc_{k}"])
@@ -54,14 +58,16 @@ def test_loader_still_produces_the_fixture_tables(lib, name):
     import mujoco_sim_amd as ms
     from mujoco_sim_amd import capi
     lib.mjh_load_set_bounds(1e-6, 1e-6)      # as the reference does before mj_loadXML (mj_sim.cpp:584-590)
+    lib.mjh_load_set_mesh_mode(1 if name.endswith("_mesh") else 0)
     try:
         m = ms.load_mjcf(paths=[os.path.join(REF, r) for r in FILES[name].split("+")])
     finally:
-        lib.mjh_load_set_bounds(0.0, 0.0)
+        lib.mjh_load_set_bounds(0.0, 0.0); lib.mjh_load_set_mesh_mode(1)
     f, z = load_model_tables(os.path.join(ROOT, "tests", "golden", f"robot_{name}.npz"))
-    for k in ("nq", "nv", "nbody", "njnt", "ngeom", "neq", "npair", "nM", "ntree"):
+    for k in ("nq", "nv", "nbody", "njnt", "ngeom", "neq", "npair", "nM", "ntree", "nmesh", "nmeshvert"):
         assert getattr(m, k) == getattr(f, k), k
     for n, t, _ in capi._ARRAYS:
         np.testing.assert_allclose(m.array(n), f.array(n), rtol=1e-13, atol=1e-13, err_msg=n)
     # working set with the fixture's contact capacity fits one CU's LDS
-    assert lib.mjh_query_lds_bytes(f.ptr) <= 160 * 1024
+    lds = lib.mjh_query_lds_bytes(f.ptr)
+    assert 0 < lds <= 160 * 1024, lds
