@@ -992,3 +992,77 @@ def test_convex_mesh_rollout(lib):
     assert np.all(q[0, 2::7] > 0.02) and np.all(q[0, 2::7] < 0.45)
     assert np.abs(v[0]).max() < 5.0                                           # (a polyhedron on a single contact point keeps rocking a little; the cylinder may roll)
     e.close()
+
+
+def test_spawn_pool_of_cubes_spheres_cylinders_and_meshes(lib):
+    """C4's spawn/destroy service as slot toggling over a mixed pool — the object types the reference's spawn test draws
+    (test/test_spawn_and_destroy.py:13-14: CUBE, SPHERE, CYLINDER, MESH; sizes 0.05 * [2, 5]) dropped onto one spot of the
+    world/empty.xml floor (condim 4, friction 2 / 0.05 / 0.01) so that they pile: every new arrival meets the others
+    through box-box, sphere-x and the generic convex pairs.  Each env has its own schedule; oracle mirrors it."""
+    import ctypes as C
+    from test_oracle_collision import CUBE_F, CUBE_V
+    rng = np.random.default_rng(8)
+    b = lib.mjh_builder_create()
+    set_opt(lib, b, timestep=0.005)
+    lib.mjh_builder_add_geom(b, b"floor", 0, 0, D(0, 0, 0.05), None, None, D(2, 0.05, 0.01), 4, -1, -1, -1)
+    hull_v, hull_f = _random_hull(rng, 60, 0.12)
+    meshes = [(CUBE_V * np.array([0.12, 0.09, 0.06]), CUBE_F), (hull_v, hull_f)]
+    mids = []
+    for v, f in meshes:
+        v = np.ascontiguousarray(v, dtype=np.float64); f = np.ascontiguousarray(f, dtype=np.int32)
+        mids.append(lib.mjh_builder_add_mesh(b, v.ctypes.data_as(C.POINTER(C.c_double)), len(v), f.ctypes.data_as(C.POINTER(C.c_int)), len(f), None))
+    pool = [("cube", 6, (0.10, 0.10, 0.10)), ("sphere", 2, (0.11, 0, 0)), ("cyl", 5, (0.09, 0.12, 0)), ("mesh", 0, None),
+            ("cube", 6, (0.15, 0.08, 0.06)), ("sphere", 2, (0.07, 0, 0)), ("cyl", 5, (0.12, 0.05, 0)), ("mesh", 1, None)]
+    for k, (kind, gt, size) in enumerate(pool):
+        bd = lib.mjh_builder_add_body(b, b"object_%d" % k, 0, D(3.0 + 0.6 * k, 3.0, 0.3), None, 0.0)     # parked out of the way
+        lib.mjh_builder_add_joint(b, None, bd, 0, None, None, None, 0, 0, 0, 0, 0)
+        if kind == "mesh":
+            assert lib.mjh_builder_add_mesh_geom(b, None, bd, mids[gt], None, None, None, -1, -1, -1, -1) >= 0
+        else:
+            lib.mjh_builder_add_geom(b, None, bd, gt, D(*size), None, None, None, -1, -1, -1, -1)
+    lib.mjh_builder_set_capacity(b, 48, 48 * 6)
+    m = ms.Model(lib.mjh_builder_compile(b), lib)
+    lib.mjh_builder_destroy(b)
+    nslot = len(pool)
+    assert m.nv == 6 * nslot and m.npair == nslot + nslot * (nslot - 1) // 2
+    nenv = 6
+    e = ms.Engine(m, nenv)
+    ds = [orc.OrcData(m.ptr) for _ in range(nenv)]
+    e.reset(); [d.call("reset") for d in ds]
+    for k in range(nslot):                         # everything starts destroyed
+        e.set_slot_active(k + 1, False)
+    mask = [(1 << (nslot + 1)) - 2] * nenv
+    for i, d in enumerate(ds):
+        d.L.orc_set_slot_mask(d.d, mask[i])
+    order = [rng.permutation(nslot) for _ in range(nenv)]
+    worst = 0.0
+    for rnd in range(nslot + 2):
+        for i, d in enumerate(ds):
+            if rnd < nslot:                         # spawn the next object of this env's schedule above the pile, with a twist
+                k = int(order[i][rnd])
+                pos = np.array([rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), 0.55 + 0.05 * rnd])
+                quat = rng.normal(size=4); quat /= np.linalg.norm(quat)
+                vel = np.array([0, 0, -0.5, *rng.normal(size=3)])
+                e.set_slot_active(k + 1, True, env0=i, n=1); e.set_body_pose(i, k + 1, pos, quat, vel)
+                mask[i] &= ~(1 << (k + 1)); d.L.orc_set_slot_mask(d.d, mask[i])
+                d.f("qpos")[7*k:7*k+3] = pos; d.f("qpos")[7*k+3:7*k+7] = quat; d.f("qvel")[6*k:6*k+6] = vel
+            else:                                   # destroy the first two arrivals again
+                k = int(order[i][rnd - nslot])
+                e.set_slot_active(k + 1, False, env0=i, n=1)
+                mask[i] |= 1 << (k + 1); d.L.orc_set_slot_mask(d.d, mask[i])
+        e.step(24); [d.step(24) for d in ds]
+        _, q, v, _ = e.get_state()
+        st = e.get_stats()
+        assert (st[:, 3] == 0).all() and all(d.i("warn") == 0 for d in ds)
+        oq = np.array([d.f("qpos") for d in ds])
+        err = np.abs(q - oq).max(axis=1)
+        worst = max(worst, float(np.sort(err)[-3]))          # impacts in a pile of round things are chaotic: an env or two per round may fork
+        assert (err < 2e-2).sum() >= nenv - 2 and err.max() < 0.5, (rnd, err)
+        for i, d in enumerate(ds):                             # destroyed objects stay where they were parked / left
+            for k in range(nslot):
+                if mask[i] >> (k + 1) & 1:
+                    assert (v[i, 6*k:6*k+6] == 0).all()
+        # every segment starts from identical states
+        e.set_state(qpos=oq, qvel=np.array([d.f("qvel") for d in ds]), warmstart=np.array([d.f("qacc_warmstart") for d in ds]))
+    assert max(d.i("ncon") for d in ds) >= 8
+    e.close()
