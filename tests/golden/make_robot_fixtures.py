@@ -30,7 +30,11 @@ ROBOTS = {"pr2": ("pr2/pr2.xml", 16), "tiago": ("tiago/tiago.xml", 40), "hsrb4s"
           # composed with the reference's world file (floor plane, condim 4) the way MjSim::init composes them: the robot
           # stands on its wheels / casters (plane-cylinder, plane-sphere, plane-box contacts)
           "pr2_world": ("../world/empty.xml+pr2/pr2.xml", 48), "hsrb4s_world": ("../world/empty.xml+hsrb4s/hsrb4s.xml", 24),
-          "pr2_mesh": ("pr2/pr2.xml", 16), "pr2_world_mesh": ("../world/empty.xml+pr2/pr2.xml", 48)}
+          "pr2_mesh": ("pr2/pr2.xml", 16), "pr2_world_mesh": ("../world/empty.xml+pr2/pr2.xml", 48),
+          # C5, literally: launch/multi_mujoco_sim.launch:3-4 = world pendulum.xml (three bodies on ball joints, damping 0.5,
+          # gravity -0.1) + "robot" bowl.xml (37 static mesh geoms); started with a spin so that the bodies meet
+          "c5_pendulum_bowl_mesh": ("pendulum.xml+bowl.xml", 16)}
+QVEL0 = {"c5_pendulum_bowl_mesh": [0.0, 0.1, 2.0, 0.1, 0.0, -2.0, 0.2, -0.1, 0.3]}   # sphere and cube circle towards each other
 STEPS = 300
 KEEP = (1, 10, 50, 100, 200, 300)
 MESH_STEPS = 60
@@ -66,7 +70,11 @@ def main():
             if jt[j] in (2, 3):
                 ctrl[da[j]] = 1
         d.ifield("controlled")[:] = ctrl
-        out = {}
+        qvel0 = np.array(QVEL0.get(name, np.zeros(m.nv)), dtype=np.float64)
+        d.f("qvel")[:] = qvel0
+        if name.startswith("c5"):
+            steps, keep = STEPS, KEEP
+        out = {"qvel0": qvel0}
         maxcon_seen = 0
         for k in range(1, steps + 1):
             d.f("ddq")[:] = command(m, k)

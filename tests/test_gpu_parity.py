@@ -540,7 +540,8 @@ def layout_policy(lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("layout", [1, 2], ids=["lds-resident", "global-pools"])
-@pytest.mark.parametrize("name", ["pr2", "tiago", "hsrb4s", "ridgeback_panda", "pr2_world", "hsrb4s_world", "pr2_mesh", "pr2_world_mesh"])
+@pytest.mark.parametrize("name", ["pr2", "tiago", "hsrb4s", "ridgeback_panda", "pr2_world", "hsrb4s_world", "pr2_mesh", "pr2_world_mesh",
+                                  "c5_pendulum_bowl_mesh"])
 def test_reference_robot_models_match_oracle(name, layout, layout_policy):
     """C4-type articulated models (the reference's pr2 / tiago / hsrb4s test assets, compiled to table fixtures by
     tests/golden/make_robot_fixtures.py; meshes skipped): 32-49 dof single trees with equality constraints, joint
@@ -556,6 +557,7 @@ def test_reference_robot_models_match_oracle(name, layout, layout_policy):
     e = ms.Engine(m, nenv)
     e.set_controlled_dofs(z["controlled"].astype(np.int32))
     d = orc.OrcData(m.ptr); d.ifield("controlled")[:] = z["controlled"]
+    d.f("qvel")[:] = z["qvel0"]; e.set_state(qvel=np.tile(z["qvel0"], (nenv, 1)))
     for k in range(1, KEEP[-1] + 1):
         cmd = robot_command(m, k)
         e.set_cmd(ddq=np.tile(cmd, (nenv, 1)))

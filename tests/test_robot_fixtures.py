@@ -11,12 +11,14 @@ import orc
 from conftest import ROOT
 from helpers import load_model_tables
 
-ROBOTS = ["pr2", "tiago", "hsrb4s", "ridgeback_panda", "pr2_world", "hsrb4s_world", "pr2_mesh", "pr2_world_mesh"]
+ROBOTS = ["pr2", "tiago", "hsrb4s", "ridgeback_panda", "pr2_world", "hsrb4s_world", "pr2_mesh", "pr2_world_mesh", "c5_pendulum_bowl_mesh"]
 FILES = {"pr2": "pr2/pr2.xml", "tiago": "tiago/tiago.xml", "hsrb4s": "hsrb4s/hsrb4s.xml",
          "ridgeback_panda": "ridgeback_panda/ridgeback_panda.xml",
          "pr2_world": "../world/empty.xml+pr2/pr2.xml", "hsrb4s_world": "../world/empty.xml+hsrb4s/hsrb4s.xml",
          # PR2 with its 18 STL meshes (37 mesh geoms colliding as convex hulls); the others are compiled with the meshes off
-         "pr2_mesh": "pr2/pr2.xml", "pr2_world_mesh": "../world/empty.xml+pr2/pr2.xml"}
+         "pr2_mesh": "pr2/pr2.xml", "pr2_world_mesh": "../world/empty.xml+pr2/pr2.xml",
+         # C5 as launched (launch/multi_mujoco_sim.launch:3-4): world = pendulum.xml, "robot" = bowl.xml (37 static mesh geoms)
+         "c5_pendulum_bowl_mesh": "pendulum.xml+bowl.xml"}
 REF = "/root/reference/model/test"
 
 
@@ -32,13 +34,17 @@ def robot_command(m, k):
 @pytest.mark.parametrize("name", ROBOTS)
 def test_oracle_reproduces_robot_golden(lib, name):
     m, z = load_model_tables(os.path.join(ROOT, "tests", "golden", f"robot_{name}.npz"))
-    assert m.ntree == 1 and m.nv >= 20
+    if name.startswith("c5"):
+        assert m.ntree == 3 and m.nv == 9 and m.c.nmesh == 2 and (m.array("geom_type") == 7).sum() == 37
+    else:
+        assert m.ntree == 1 and m.nv >= 20
     if "_world" in name:
         assert m.array("geom_type")[0] == 0 and m.array("geom_condim")[0] == 4      # the world file's floor plane
     d = orc.OrcData(m.ptr)
     d.ifield("controlled")[:] = z["controlled"]
     keep = [int(k) for k in z["keep"]]
-    if name.endswith("_mesh"):
+    d.f("qvel")[:] = z["qvel0"]
+    if name.startswith("pr2") and name.endswith("_mesh"):
         assert m.c.nmesh == 18 and (m.array("geom_type") == 7).sum() == 37 and m.c.npair > 1000
     for k in range(1, min(100, keep[-1]) + 1):
         d.f("ddq")[:] = robot_command(m, k)

@@ -1,5 +1,6 @@
 """Throughput of the robot configs (table fixtures of the reference's assets): python tools/robot_bench.py <name> [nenv] [steps]
-   name: pr2_world | hsrb4s_world | ridgeback_panda | tiago | ...   (C3: ridgeback_panda at 8192 envs, C4: pr2_world at 2048)"""
+   name: pr2_world | pr2_world_mesh | hsrb4s_world | ridgeback_panda | tiago | c5_pendulum_bowl_mesh ...
+   (C3: ridgeback_panda at 8192 envs, C4: pr2_world_mesh at 2048, C5: c5_pendulum_bowl_mesh at 4096 per GPU)"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -10,6 +11,9 @@ from robot_common import robot_command
 name = sys.argv[1]; nenv = int(sys.argv[2]) if len(sys.argv) > 2 else 2048; steps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 m, z = load_model_tables(os.path.join(ROOT, "tests", "golden", f"robot_{name}.npz"))
 e = ms.Engine(m, nenv); e.set_controlled_dofs(z["controlled"].astype(np.int32))
+if "qvel0" in z and np.any(z["qvel0"]):          # C5 (pendulum world + bowl): per-env spin so that the envs differ
+    rng = np.random.default_rng(0)
+    e.set_state(qvel=z["qvel0"][None, :] * rng.uniform(0.5, 1.5, size=(nenv, 1)))
 for k in range(1, 101):                       # settle under the commanded accelerations (one command upload per step, all envs)
     e.set_cmd(ddq=np.tile(robot_command(m, k), (nenv, 1))); e.step(1, True)
 e.synchronize()
