@@ -80,8 +80,9 @@ typedef struct mjh_option {
   int iterations;           /* main solver sweeps (MuJoCo default 100)         */
   double tolerance;         /* scaled-improvement threshold (default 1e-8)     */
   double impratio;          /* default 1                                       */
-  int noslip_iterations;    /* model/ontology/scene.xml:2-3 (not implemented)  */
+  int noslip_iterations;    /* model/ontology/scene.xml:2-3; 0 = off (default)  */
   int disableflags;         /* mjh_disable bits                                */
+  double noslip_tolerance;  /* model/ontology/scene.xml:3 (MuJoCo default 1e-6) */
 } mjh_option;
 
 /* Compiled, topology-sorted model: the subset of mjModel this path reads

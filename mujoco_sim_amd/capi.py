@@ -24,6 +24,7 @@ class Option(C.Structure):
         ("impratio", C.c_double),
         ("noslip_iterations", C.c_int),
         ("disableflags", C.c_int),
+        ("noslip_tolerance", C.c_double),
     ]
 
 

@@ -33,6 +33,8 @@ struct DModel {
   float timestep, gravity[3], tolerance, impratio, meaninertia;
   // convex mesh assets (read by the CONVEX kernel instances only)
   int o_geom_dataid, o_mesh_vertadr, o_mesh_vertnum, o_mesh_vert;
+  // noslip post-pass (EXTRA instances)
+  int noslip_iterations; float noslip_tolerance;
 };
 
 // per-env state in HBM (fp32, env-major rows)

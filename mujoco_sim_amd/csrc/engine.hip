@@ -77,10 +77,13 @@ static int ensure_scratch(mjh_engine* e, size_t floats) {
   return MJH_OK;
 }
 
+// models that need the EXTRA kernel instances: generic convex narrow phase (cylinder-x, capsule-box, ellipsoid, mesh) or noslip sweeps
+static bool extra_instance(const DModel& M) { return M.has_convex || M.noslip_iterations > 0; }
+
 static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps, int ph, int xflags) {
   if (n <= 0) return MJH_OK;
 #define MJH_LAUNCH2(NR, DG, CX) hipLaunchKernelGGL((mjh_step_kernel<NR, DG, CX>), dim3(n), dim3(64), (size_t)e->lds_bytes, st, e->dC, e->S, env0, nsteps, ph, xflags)
-#define MJH_LAUNCH(NR, DG) do { if (e->M.has_convex) MJH_LAUNCH2(NR, DG, true); else MJH_LAUNCH2(NR, DG, false); } while (0)
+#define MJH_LAUNCH(NR, DG) do { if (extra_instance(e->M)) MJH_LAUNCH2(NR, DG, true); else MJH_LAUNCH2(NR, DG, false); } while (0)
   const int nr = e->M.big ? 8 : (e->M.nv <= 16 ? 1 : (e->M.nv <= 32 ? 2 : 4));   // 8: many-body layout, running acceleration in LDS
   if (e->M.diagM) { if (nr == 1) MJH_LAUNCH(1, true); else if (nr == 2) MJH_LAUNCH(2, true); else if (nr == 4) MJH_LAUNCH(4, true); else MJH_LAUNCH(8, true); }
   else { if (nr == 1) MJH_LAUNCH(1, false); else if (nr == 2) MJH_LAUNCH(2, false); else if (nr == 4) MJH_LAUNCH(4, false); else MJH_LAUNCH(8, false); }
@@ -224,6 +227,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
   M.iterations = m->opt.iterations; M.disableflags = m->opt.disableflags;
   M.timestep = (float)m->opt.timestep; for (int k = 0; k < 3; k++) M.gravity[k] = (float)m->opt.gravity[k];
   M.tolerance = (float)m->opt.tolerance; M.impratio = (float)m->opt.impratio; M.meaninertia = (float)m->meaninertia;
+  M.noslip_iterations = m->opt.noslip_iterations; M.noslip_tolerance = (float)m->opt.noslip_tolerance;
   // ---- LDS layout (float offsets, 16-byte aligned)
   {
     Lay& L = hp.L; int off = 0; long long goff = 0;
@@ -465,8 +469,11 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
         rc = launch_on(e, st, g0, g1 - g0, 1, ph | PH_PRE, 0);
         if (!rc) {
           const size_t lds = (2 * (size_t)(((e->M.nv + 3) / 4) * 4) + 2 * (size_t)std::max(e->M.maxblk, 1) + 4) * sizeof(float);   // 2 dof vectors + visiting order + group starts
-          if (e->M.diagM) hipLaunchKernelGGL((mjh_solve_kernel<true>), dim3(g1 - g0), dim3(64), lds, st, e->dC, e->S, g0);
-          else hipLaunchKernelGGL((mjh_solve_kernel<false>), dim3(g1 - g0), dim3(64), lds, st, e->dC, e->S, g0);
+          const bool xs = e->M.noslip_iterations > 0;      // (the convex narrow phase is not part of the solve launch)
+          if (e->M.diagM) { if (xs) hipLaunchKernelGGL((mjh_solve_kernel<true, true>), dim3(g1 - g0), dim3(64), lds, st, e->dC, e->S, g0);
+                            else hipLaunchKernelGGL((mjh_solve_kernel<true, false>), dim3(g1 - g0), dim3(64), lds, st, e->dC, e->S, g0); }
+          else { if (xs) hipLaunchKernelGGL((mjh_solve_kernel<false, true>), dim3(g1 - g0), dim3(64), lds, st, e->dC, e->S, g0);
+                 else hipLaunchKernelGGL((mjh_solve_kernel<false, false>), dim3(g1 - g0), dim3(64), lds, st, e->dC, e->S, g0); }
           HIPCHK(hipGetLastError());
           rc = launch_on(e, st, g0, g1 - g0, 1, PH_STEP2 | PH_POST, 0);
         }

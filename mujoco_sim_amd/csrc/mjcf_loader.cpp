@@ -226,7 +226,8 @@ struct Loader {
         if (nums(c->get("impratio"), &v, 1)) o.impratio = v;
         if (nums(c->get("iterations"), &v, 1)) o.iterations = (int)v;
         if (nums(c->get("tolerance"), &v, 1)) o.tolerance = v;
-        if (nums(c->get("noslip_iterations"), &v, 1)) { o.noslip_iterations = (int)v; if (v > 0) note += "noslip_iterations ignored; "; }
+        if (nums(c->get("noslip_iterations"), &v, 1)) o.noslip_iterations = (int)v;
+        if (nums(c->get("noslip_tolerance"), &v, 1)) o.noslip_tolerance = v;
         if (const char* s = c->get("solver")) if (std::string(s) != "PGS") note += std::string("solver=") + s + " -> PGS; ";
         for (auto& f : c->kids) if (f->tag == "flag") {
           if (const char* s = f->get("gravity")) if (std::string(s) == "disable") o.disableflags |= MJH_DSBL_GRAVITY;

@@ -62,7 +62,7 @@ void mjh_set_error(const std::string& s) { g_err = s; }
 
 static void default_option(mjh_option* o) {
   o->timestep = 0.002; o->gravity[0] = 0; o->gravity[1] = 0; o->gravity[2] = -9.81;
-  o->iterations = 100; o->tolerance = 1e-8; o->impratio = 1; o->noslip_iterations = 0; o->disableflags = 0;
+  o->iterations = 100; o->tolerance = 1e-8; o->impratio = 1; o->noslip_iterations = 0; o->noslip_tolerance = 1e-6; o->disableflags = 0;
 }
 
 extern "C" mjh_builder* mjh_builder_create(void) {

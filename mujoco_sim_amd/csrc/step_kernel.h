@@ -180,16 +180,60 @@ DEV float pgs_rows(const float R, const float lo, const float hi, const float* u
   for (int k = 1; k < NB; k++) dphi[k] = dl[2*k - 2] - dl[2*k - 1];
   return imp;
 }
+// The same block in a noslip sweep (mj_solNoSlip; model/ontology/scene.xml:2-3): friction dimensions only, without the
+// regulariser.  u[j] = (J_base a - aref)_j as above (no R f term).  A dof friction-loss row is re-solved with
+// A_rr - R; each opposing pair of pyramid edges (2k-2, 2k-1) is re-solved along f_j - f_q with f_j + f_q held;
+// equality / limit / frictionless rows are left alone (dphi = 0).  Same definition as the oracle.
+template <int NB, int NR>
+DEV float noslip_rows(const float R, const float lo, const float hi, const float* u, float* f, const float* Q, const float* X, float* dphi) {
+  float imp = 0;
+  // (the four-row sweep runs single-row blocks through the widest template of their group: same test there)
+  if (NB == 1 || (lo < 0.0f && lo > -1.0e38f)) {
+#pragma unroll
+    for (int k = 0; k < NB; k++) dphi[k] = 0;
+    const float A = 2.0f * AR_HALF(Q, X, 0) - R;
+    if (lo < 0.0f && lo > -1.0e38f && A > MJ_MINVAL) {      // [-frictionloss, frictionloss]
+      const float fn = __builtin_amdgcn_fmed3f(f[0] - u[0] / A, lo, hi), delta = fn - f[0];
+      imp = -delta * (u[0] + 0.5f * A * delta);
+      f[0] = fn; dphi[0] = delta;
+    }
+    return imp;
+  }
+  float res[NR], dy[NR / 2 + 1];
+#pragma unroll
+  for (int r = 0; r < NR; r++) { const int k = 1 + (r >> 1); res[r] = (r & 1) ? u[0] - u[k] : u[0] + u[k]; }
+#pragma unroll
+  for (int p = 0; p < NR; p += 2) {
+    const float K1 = 2.0f * (AR_HALF(Q, X, p) + AR_HALF(Q, X, p + 1) - R - AR_OFF(Q, X, p, p + 1));
+    const float mid = 0.5f * (f[p] + f[p + 1]), y0 = 0.5f * (f[p] - f[p + 1]), dr = res[p] - res[p + 1];
+    const float y = K1 > MJ_MINVAL ? __builtin_amdgcn_fmed3f(y0 - dr / K1, -mid, mid) : y0;
+    const float d = y - y0;
+    imp -= d * (dr + 0.5f * K1 * d);
+    f[p] = mid + y; f[p + 1] = mid - y; dy[p / 2] = d;
+#pragma unroll
+    for (int q = p + 2; q < NR; q++) res[q] += (AR_OFF(Q, X, p, q) - AR_OFF(Q, X, p + 1, q)) * d;
+  }
+  dphi[0] = 0;
+#pragma unroll
+  for (int k = 1; k < NB; k++) dphi[k] = 2.0f * dy[k - 1];
+  return imp;
+}
+// row math of one block in the current sweep mode (ns: noslip sweep; only the EXTRA kernel instances carry that code)
+template <int NB, int NR, bool EXTRA>
+DEV float solve_rows(const bool ns, const float R, const float lo, const float hi, const float* u, float* f, const float* Q, const float* X, float* dphi) {
+  if (EXTRA && ns) return noslip_rows<NB, NR>(R, lo, hi, u, f, Q, X, dphi);
+  return pgs_rows<NB, NR>(R, lo, hi, u, f, Q, X, dphi);
+}
 // One block of the single-block sweep (nv > 32): NB full-wave reductions, then uniform row math.
-template <int NB, int NR, int NROW>
-DEV void pgs_block(const float R, const float lo, const float hi, const float* ab, float* f, const float* Q, const float* X, const float* Jd, const float* Bd,
+template <int NB, int NR, int NROW, bool EXTRA>
+DEV void pgs_block(const bool ns, const float R, const float lo, const float hi, const float* ab, float* f, const float* Q, const float* X, const float* Jd, const float* Bd,
                    const float bscale, float& a, float& improvement) {
   float u[4] = {Jd[0] * a, NB > 1 ? Jd[1] * a : 0.0f, NB > 2 ? Jd[2] * a : 0.0f, NB > 3 ? Jd[3] * a : 0.0f}, dphi[4];
   constexpr int WR = NROW > 4 ? 4 : NROW;   // NROW 8 (nv > 64): full-wave sums over the block's compact dofs
   if (NB == 1) u[0] = wave_sum<WR>(u[0]); else wave_sum4<WR, NB>(u);
 #pragma unroll
   for (int j = 0; j < NB; j++) u[j] -= ab[j];
-  improvement += pgs_rows<NB, NR>(R, lo, hi, u, f, Q, X, dphi);
+  improvement += solve_rows<NB, NR, EXTRA>(ns, R, lo, hi, u, f, Q, X, dphi);
   float da = Bd[0] * dphi[0];
 #pragma unroll
   for (int j = 1; j < NB; j++) da += Bd[j] * dphi[j];
@@ -244,8 +288,8 @@ template <int N> DEV void half_sum4(float* v, const int lq) {   // sums over eac
   if (N > 3) v[3] = MJH_QBCAST(3);
 #undef MJH_QBCAST
 }
-template <int NB, int NR>
-DEV float pgs_dual(const float R, const float lo, const float hi, const float* ab, float* f, const float* Q, const float* X, const float* Jd, const float* Bd,
+template <int NB, int NR, bool EXTRA>
+DEV float pgs_dual(const bool ns, const float R, const float lo, const float hi, const float* ab, float* f, const float* Q, const float* X, const float* Jd, const float* Bd,
                    const float bscale, const int lq, float& a) {
   float u[4] = {Jd[0] * a, NB > 1 ? Jd[1] * a : 0.0f, NB > 2 ? Jd[2] * a : 0.0f, NB > 3 ? Jd[3] * a : 0.0f}, dphi[4];
   // (opaque products: otherwise u + dpp(u) is contracted to fma(J, a, dpp(u)), which costs an extra v_mov_dpp per base)
@@ -253,7 +297,7 @@ DEV float pgs_dual(const float R, const float lo, const float hi, const float* a
   half_sum4<NB>(u, lq);
 #pragma unroll
   for (int j = 0; j < NB; j++) u[j] -= ab[j];
-  const float imp = pgs_rows<NB, NR>(R, lo, hi, u, f, Q, X, dphi);
+  const float imp = solve_rows<NB, NR, EXTRA>(ns, R, lo, hi, u, f, Q, X, dphi);
   float da = Bd[0] * dphi[0];
 #pragma unroll
   for (int j = 1; j < NB; j++) da += Bd[j] * dphi[j];
@@ -269,10 +313,18 @@ struct ManyCtx {
   int ngrp;
   float* qacc; const float* qLDinv;
   int nblk, nfixblk, rowW, iterations; bool has_dim4; float scale, tolerance;
+  int noslip_iterations; float noslip_tolerance;     // noslip post-pass (EXTRA instances only)
 };
-template <bool DIAGM>
+template <bool DIAGM, bool EXTRA>
 DEV int pgs_many_body(const ManyCtx& c, const int lane) {
-  int niter = 0;
+  int niter = 0, nmain = 0;
+  // sweep mode: the main PGS sweeps, then (EXTRA instances, option noslip_iterations) the noslip sweeps over the same
+  // schedule with the friction-only row math
+  bool ns = false;
+  int itmax = c.iterations; float tol = c.tolerance;
+  const int nmode = (EXTRA && c.noslip_iterations > 0) ? 2 : 1;
+  for (int mode = 0; mode < nmode; mode++) {
+  if (mode == 1) { ns = true; nmain = niter; niter = 0; itmax = c.noslip_iterations; tol = c.noslip_tolerance; __syncthreads(); }
   // operands of one block; every address follows from the block index alone (contact blocks are laid out
   // regularly behind the c.nfixblk non-contact ones), so all loads of block k+1 are in flight while block k is solved
   struct MOp { int4 hd; int b; float4 J, B, p0, r0, r1, r2, A0, A1, A2, A3, X0, X1, X2; };
@@ -311,9 +363,9 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
     const float* Bp = DIAGM ? Jd : Bd;
     const float bs = DIAGM ? (on ? c.qLDinv[d] : 0.0f) : 1.0f;
     const float R = op.p0.x, lo = op.r2.z, hi = op.r2.w;
-    if (kind == BK_PYR4) pgs_block<4, 6, 8>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
-    else if (kind == BK_PYR3) pgs_block<3, 4, 8>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
-    else pgs_block<1, 1, 8>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
+    if (kind == BK_PYR4) pgs_block<4, 6, 8, EXTRA>(ns, R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
+    else if (kind == BK_PYR3) pgs_block<3, 4, 8, EXTRA>(ns, R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
+    else pgs_block<1, 1, 8, EXTRA>(ns, R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
     if (on) c.qacc[d] = ak;                                              // scatter
     if (lane == 0) {
       float* bf = c.blkf + op.b * BLKF_STRIDE + BF_F;
@@ -372,9 +424,9 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
       asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]));
       float imp;
 #define MJH_ROWSUM(N) do { MJH_DPP_BF4(u, N, 0xB1); MJH_DPP_BF4(u, N, 0x4E); MJH_DPP_BF4(u, N, 0x141); MJH_DPP_BF4(u, N, 0x140); } while (0)
-      if (kind == BK_PYR4) { MJH_ROWSUM(4); for (int j = 0; j < 4; j++) u[j] -= aref[j]; imp = pgs_rows<4, 6>(R, lo, hi, u, f, Q, X, dphi); }
-      else if (kind == BK_PYR3) { MJH_ROWSUM(3); for (int j = 0; j < 3; j++) u[j] -= aref[j]; imp = pgs_rows<3, 4>(R, lo, hi, u, f, Q, X, dphi); }
-      else { MJH_ROWSUM(1); u[0] -= aref[0]; imp = pgs_rows<1, 1>(R, lo, hi, u, f, Q, X, dphi); }
+      if (kind == BK_PYR4) { MJH_ROWSUM(4); for (int j = 0; j < 4; j++) u[j] -= aref[j]; imp = solve_rows<4, 6, EXTRA>(ns, R, lo, hi, u, f, Q, X, dphi); }
+      else if (kind == BK_PYR3) { MJH_ROWSUM(3); for (int j = 0; j < 3; j++) u[j] -= aref[j]; imp = solve_rows<3, 4, EXTRA>(ns, R, lo, hi, u, f, Q, X, dphi); }
+      else { MJH_ROWSUM(1); u[0] -= aref[0]; imp = solve_rows<1, 1, EXTRA>(ns, R, lo, hi, u, f, Q, X, dphi); }
 #undef MJH_ROWSUM
       ak += (Bp[0] * dphi[0] + Bp[1] * dphi[1] + Bp[2] * dphi[2] + Bp[3] * dphi[3]) * bs;
       if (on) c.qacc[d] = ak;                                                 // scatter (the group's blocks touch disjoint dofs)
@@ -395,7 +447,7 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
       g = 0; niter++;
       const float improvement = readlane_f(impl, 0) + readlane_f(impl, 16) + readlane_f(impl, 32) + readlane_f(impl, 48);
       impl = 0;
-      done = improvement * c.scale < c.tolerance || niter >= c.iterations;
+      done = improvement * c.scale < tol || niter >= itmax;
     };
     if (c.ngrp >= 3) {
       QOp o0 = nextFetch(), o1 = nextFetch(), o2;
@@ -414,15 +466,15 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
   } else
   if (c.nblk < 3) {
     // (the prefetch would read the forces of a block before its pending update is stored)
-    for (int it = 0; it < c.iterations; it++) {
+    for (int it = 0; it < itmax; it++) {
       float improvement = 0;
       for (int k = 0; k < c.nblk; k++) { MOp op = fetch8(blockAt(k)); process8(op, improvement); __syncthreads(); }
       niter = it + 1;
-      if (improvement * c.scale < c.tolerance) break;
+      if (improvement * c.scale < tol) break;
     }
   } else {
     MOp opA = fetch8(blockAt(0)), opB;
-    for (int it = 0; it < c.iterations; it++) {
+    for (int it = 0; it < itmax; it++) {
       float improvement = 0;
       for (int k = 0; k < c.nblk; k += 2) {
         opB = fetch8(blockAt(k + 1 < c.nblk ? k + 1 : 0));
@@ -433,15 +485,17 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
         } else opA = opB;                  // odd block count: block 0 of the next sweep was loaded into B
       }
       niter = it + 1;
-      if (improvement * c.scale < c.tolerance) break;
+      if (improvement * c.scale < tol) break;
     }
   }
-  return niter;
+  }   // sweep mode
+  return niter + nmain;
 }
 
-// CONVEX: the model has a pair for the generic convex narrow phase (cylinder-x, capsule-box, ellipsoid-x, mesh geoms);
-// a separate instantiation so that models without one (S24, box piles) keep their code size and register allocation
-template <int NROW, bool DIAGM, bool CONVEX>
+// EXTRA: the model has a pair for the generic convex narrow phase (cylinder-x, capsule-box, ellipsoid-x, mesh geoms) or
+// asks for noslip sweeps; a separate instantiation so that models without either (S24, box piles, the robots'
+// primitive geometry) keep their code size and register allocation
+template <int NROW, bool DIAGM, bool EXTRA>
 __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restrict__ C, const DState S, int env0, int nsteps, int ph, int xflags) {
   // model descriptor + LDS layout live in device memory (uploaded once): uniform scalar loads on demand instead
   // of a by-value kernarg struct that the lambdas below would force into a private (scratch) copy
@@ -773,12 +827,12 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             else if (t1 == MJH_GEOM_CAPSULE && t2 == MJH_GEOM_CAPSULE) n = c_capsule_capsule(p1, m1, z1, p2, m2, z2, margin, st);
             else if (t1 == MJH_GEOM_SPHERE && t2 == MJH_GEOM_BOX) n = c_sphere_box(p1, z1[0], p2, m2, z2, margin, st);
             else if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_ELLIPSOID) n = c_plane_ellipsoid(p1, m1, p2, m2, z2, margin, st);
-            else if (CONVEX && t2 == MJH_GEOM_MESH && t1 == MJH_GEOM_PLANE) {
+            else if (EXTRA && t2 == MJH_GEOM_MESH && t1 == MJH_GEOM_PLANE) {
               const Tab<int> geom_dataid{M.I, M.o_geom_dataid}, mesh_vertadr{M.I, M.o_mesh_vertadr}, mesh_vertnum{M.I, M.o_mesh_vertnum};
               const Tab<float> mesh_vert{M.F, M.o_mesh_vert};
               const int id = geom_dataid[g2];
               n = c_plane_mesh(p1, m1, p2, m2, mesh_vert + 3 * mesh_vertadr[id], mesh_vertnum[id], margin, st);
-            } else if (CONVEX && pair_is_convex(t1, t2)) {
+            } else if (EXTRA && pair_is_convex(t1, t2)) {
               const Tab<int> geom_dataid{M.I, M.o_geom_dataid}, mesh_vertadr{M.I, M.o_mesh_vertadr}, mesh_vertnum{M.I, M.o_mesh_vertnum};
               const Tab<float> mesh_vert{M.F, M.o_mesh_vert};
               CvxGeom G1, G2;
@@ -1609,6 +1663,9 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         const float minv0 = (NROW != 8 && d0 < nv) ? s_qLDinv[d0] : 0.0f;
         const int r6 = d0 % 6, dbase6 = d0 < nv ? d0 - r6 : -1;   // DIAGM: dof inside its free body / first dof of that body
         const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
+        // sweep mode (dual / single-block sweeps below; the many-body sweep keeps its own): main PGS, then noslip
+        bool ns = false; int itmax = M.iterations, nmain = 0; float tol = M.tolerance;
+        const int nmode = (EXTRA && M.noslip_iterations > 0) ? 2 : 1;
         const float4* blkf4 = (const float4*)s_blkf;
         const float4* blkq4 = (const float4*)s_blkq;
         const int4* blki4 = (const int4*)s_blki_i;
@@ -1634,7 +1691,8 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             mc.qacc = s_qacc; mc.qLDinv = s_qLDinv;
             mc.nblk = nblk; mc.nfixblk = __builtin_amdgcn_readfirstlane(nfixblk); mc.rowW = rowW; mc.iterations = M.iterations;
             mc.has_dim4 = has_dim4; mc.scale = scale; mc.tolerance = M.tolerance;
-            niter = pgs_many_body<DIAGM>(mc, lane);
+            mc.noslip_iterations = M.noslip_iterations; mc.noslip_tolerance = M.noslip_tolerance;
+            niter = pgs_many_body<DIAGM, EXTRA>(mc, lane);
           }
           WSYNC();
           for (int d = lane; d < nv; d += 64) s_ws[d] = s_qacc[d];
@@ -1698,9 +1756,9 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             const float* Bp = DIAGM ? Jd : Bd;                 // diagonal M: B = J / M_dd, applied as one scale of da
             const float bs = DIAGM ? minv0 : 1.0f;
             float imp;
-            if (kind == BK_PYR4) imp = pgs_dual<4, 6>(op.R, lo, hi, ab, f, Q, X, Jd, Bp, bs, lq, a);
-            else if (kind == BK_PYR3) imp = pgs_dual<3, 4>(op.R, lo, hi, ab, f, Q, X, Jd, Bp, bs, lq, a);
-            else imp = pgs_dual<1, 1>(op.R, lo, hi, ab, f, Q, X, Jd, Bp, bs, lq, a);
+            if (kind == BK_PYR4) imp = pgs_dual<4, 6, EXTRA>(ns, op.R, lo, hi, ab, f, Q, X, Jd, Bp, bs, lq, a);
+            else if (kind == BK_PYR3) imp = pgs_dual<3, 4, EXTRA>(ns, op.R, lo, hi, ab, f, Q, X, Jd, Bp, bs, lq, a);
+            else imp = pgs_dual<1, 1, EXTRA>(ns, op.R, lo, hi, ab, f, Q, X, Jd, Bp, bs, lq, a);
             improvement += op.act * imp;
             if (d0 == 0 && op.act > 0.0f) {
               float* bf = s_blkf + op.b * BLKF_STRIDE + BF_F;
@@ -1708,22 +1766,24 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
               *(float2*)(bf + 4) = make_float2(f[4], f[5]);
             }
           };
+          for (int mode = 0; mode < nmode; mode++) {   // main sweeps, then (EXTRA) the noslip sweeps over the same schedule
+          if (mode == 1) { ns = true; nmain = niter; niter = 0; itmax = M.noslip_iterations; tol = M.noslip_tolerance; gS = 0; WSYNC(); }
           if (ngrp == 1) {
             // a single group: its operands (the forces) change under the prefetch, so no pipeline
-            for (int it = 0; it < M.iterations; it++) {
+            for (int it = 0; it < itmax; it++) {
               float impl = 0;
               DOp op = loadOp(hdrOf(*(const int2*)s_sched_i));
               processD(op, impl);
               niter = it + 1;
               const float improvement = readlane_f(impl, 0) + readlane_f(impl, 32);
-              if (improvement * scale < M.tolerance) break;
+              if (improvement * scale < tol) break;
             }
           } else {
             int2 pqN = nextS();                      // pair of step 0
             DHd hN = hdrOf(pqN); pqN = nextS();      // header of step 0, pair of step 1
             DOp opA = loadOp(hN), opB;               // operands of step 0
             hN = hdrOf(pqN); pqN = nextS();          // header of step 1, pair of step 2
-            for (int it = 0; it < M.iterations; it++) {
+            for (int it = 0; it < itmax; it++) {
               float impl = 0;
               for (int g = 0; g < ngrp; g += 2) {
                 opB = loadOp(hN); hN = hdrOf(pqN); pqN = nextS();
@@ -1735,9 +1795,11 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
               }
               niter = it + 1;
               const float improvement = readlane_f(impl, 0) + readlane_f(impl, 32);
-              if (improvement * scale < M.tolerance) break;
+              if (improvement * scale < tol) break;
             }
           }
+          }   // sweep mode
+          niter += nmain;
         } else {
         // operands of one block: 1 header + 1 (2) Jacobian + 8 parameter ds_read_b128 per lane
         struct BlkOp { int hx; float4 J, B, P, r0, r1, r2, A0, A1, A2, A3, X0, X1, X2; };
@@ -1773,16 +1835,18 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           const float* Bp = DIAGM ? Jd : Bd;
           const float bs = DIAGM ? minv0 : 1.0f;
           const float R = op.P.x, lo = op.r2.z, hi = op.r2.w;
-          if (kind == BK_PYR4) pgs_block<4, 6, NROW>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, a, improvement);
-          else if (kind == BK_PYR3) pgs_block<3, 4, NROW>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, a, improvement);
-          else pgs_block<1, 1, NROW>(R, lo, hi, aref, f, Q, X, Jd, Bp, bs, a, improvement);
+          if (kind == BK_PYR4) pgs_block<4, 6, NROW, EXTRA>(ns, R, lo, hi, aref, f, Q, X, Jd, Bp, bs, a, improvement);
+          else if (kind == BK_PYR3) pgs_block<3, 4, NROW, EXTRA>(ns, R, lo, hi, aref, f, Q, X, Jd, Bp, bs, a, improvement);
+          else pgs_block<1, 1, NROW, EXTRA>(ns, R, lo, hi, aref, f, Q, X, Jd, Bp, bs, a, improvement);
           if (lane == 0) {
             float* bf = s_blkf + b * BLKF_STRIDE + BF_F;
             *(float4*)(bf) = make_float4(f[0], f[1], f[2], f[3]);
             *(float2*)(bf + 4) = make_float2(f[4], f[5]);
           }
         };
-        for (int it = 0; it < M.iterations; it++) {
+        for (int mode = 0; mode < nmode; mode++) {   // main sweeps, then (EXTRA) the noslip sweeps in the same visiting order
+        if (mode == 1) { ns = true; nmain = niter; niter = 0; itmax = M.noslip_iterations; tol = M.noslip_tolerance; WSYNC(); }
+        for (int it = 0; it < itmax; it++) {
           float improvement = 0;
           // two operand buffers in ping-pong: the next block's LDS reads are in flight while this one is solved
           BlkOp opA = fetch(s_order_i[0]), opB;
@@ -1796,9 +1860,11 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             }
           }
           niter = it + 1;
-          if (improvement * scale < M.tolerance) break;
+          if (improvement * scale < tol) break;
           WSYNC();   // the next sweep re-reads the forces from LDS
         }
+        }   // sweep mode
+        niter += nmain;
         }
         WSYNC();
         if (NROW != 8 && d0 < nv && lane < 64 / (NROW <= 2 ? 2 : 1)) { s_qacc[d0] = a; s_ws[d0] = a; }
@@ -1923,7 +1989,7 @@ __global__ __launch_bounds__(1024) void mjh_order_kernel(const int* __restrict__
 // Stand-alone solver of the many-body layout's three-launch step: everything it needs is in the env's scratch slice
 // (pools + hand-over vectors), its LDS footprint is two dof vectors, so many environments are resident per CU while the
 // fused kernel holds ~70 KB per env for the stages around the sweeps.
-template <bool DIAGM>
+template <bool DIAGM, bool EXTRA>
 __global__ __launch_bounds__(64) void mjh_solve_kernel(const DConst* __restrict__ C, const DState S, int env0) {
   const DModel& M = C->M;
   const Lay& L = C->L;
@@ -1948,7 +2014,8 @@ __global__ __launch_bounds__(64) void mjh_solve_kernel(const DConst* __restrict_
   mc.qacc = s_qacc; mc.qLDinv = s_minv;
   mc.nblk = nblk; mc.nfixblk = __builtin_amdgcn_readfirstlane(meta[1]); mc.rowW = M.rowW; mc.iterations = M.iterations;
   mc.has_dim4 = M.has_dim4 != 0; mc.scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1)); mc.tolerance = M.tolerance;
-  const int niter = pgs_many_body<DIAGM>(mc, lane);
+  mc.noslip_iterations = M.noslip_iterations; mc.noslip_tolerance = M.noslip_tolerance;
+  const int niter = pgs_many_body<DIAGM, EXTRA>(mc, lane);
   __syncthreads();
   for (int d = lane; d < nv; d += 64) gs[L.g_qacc + d] = s_qacc[d];
   if (lane == 0) meta[5] = niter;

@@ -8,7 +8,7 @@ import numpy as np
 from . import capi
 from .engine import Model
 
-_OPT_FIELDS = ["timestep", "iterations", "tolerance", "impratio", "noslip_iterations", "disableflags"]
+_OPT_FIELDS = ["timestep", "iterations", "tolerance", "impratio", "noslip_iterations", "disableflags", "noslip_tolerance"]
 
 
 def save_model_tables(m, path, **extra):
@@ -31,6 +31,8 @@ def load_model_tables(path):
         setattr(st, k, int(z["int__" + k]))
     st.meaninertia = float(z["meaninertia"])
     for k in _OPT_FIELDS:
+        if "opt__" + k not in z:       # fixtures written before the field existed keep the struct's default
+            continue
         v = z["opt__" + k]
         setattr(st.opt, k, int(v) if k in ("iterations", "noslip_iterations", "disableflags") else float(v))
     for i in range(3):

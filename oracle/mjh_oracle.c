@@ -1420,6 +1420,45 @@ void orc_fwd_constraint(orc_data* d) {
     iter++;
     if (improvement * scale < m->opt.tolerance) break;
   }
+  /* noslip post-pass [UPSTREAM mj_solNoSlip; option set by model/ontology/scene.xml:2-3]: further Gauss-Seidel sweeps over
+   * the friction dimensions only, WITHOUT the regulariser R (so that resting contacts do not creep): dof friction-loss rows
+   * are re-solved with A_ii - R_i, and each opposing pair of pyramid edges (j, j+1) of a contact is re-solved along
+   * f_j - f_j+1 with f_j + f_j+1 (the normal-force share) held; equality, limit and frictionless rows are untouched. */
+  if (m->opt.noslip_iterations > 0) {
+    int nit = 0;
+    while (nit < m->opt.noslip_iterations) {
+      double improvement = 0;
+      for (int k = 0; k < nefc; k++) {
+        const int i = order[k];
+        if (d->efc_type[i] == MJH_CNSTR_FRICTION_DOF) {
+          double Aii = d->efc_AR[(size_t)i*nefc + i] - d->efc_R[i];
+          if (Aii < MINVAL) continue;
+          double r = d->efc_b[i] + dotn(d->efc_AR + (size_t)i*nefc, d->efc_force, nefc) - d->efc_R[i] * d->efc_force[i];
+          double old = d->efc_force[i], f = old - r / Aii, fl = d->efc_frictionloss[i];
+          if (f < -fl) f = -fl; else if (f > fl) f = fl;
+          double delta = f - old;
+          d->efc_force[i] = f;
+          improvement -= 0.5 * delta*delta * Aii + delta * r;
+        } else if (d->efc_type[i] == MJH_CNSTR_CONTACT_PYRAMIDAL && ((i - d->contact[d->efc_id[i]].efc_address) & 1) == 0) {
+          const int j = i, q = i + 1;       /* the two opposing edges of one friction direction */
+          const double* Aj = d->efc_AR + (size_t)j*nefc; const double* Aq = d->efc_AR + (size_t)q*nefc;
+          double rj = d->efc_b[j] + dotn(Aj, d->efc_force, nefc) - d->efc_R[j] * d->efc_force[j];
+          double rq = d->efc_b[q] + dotn(Aq, d->efc_force, nefc) - d->efc_R[q] * d->efc_force[q];
+          double K1 = (Aj[j] - d->efc_R[j]) + (Aq[q] - d->efc_R[q]) - 2 * Aj[q];
+          if (K1 < MINVAL) continue;
+          double mid = 0.5 * (d->efc_force[j] + d->efc_force[q]), y0 = 0.5 * (d->efc_force[j] - d->efc_force[q]);
+          double y = y0 - (rj - rq) / K1;
+          if (y < -mid) y = -mid; else if (y > mid) y = mid;
+          double dy = y - y0;
+          d->efc_force[j] = mid + y; d->efc_force[q] = mid - y;
+          improvement -= 0.5 * dy*dy * K1 + dy * (rj - rq);
+        }
+      }
+      nit++;
+      if (improvement * scale < m->opt.noslip_tolerance) break;
+    }
+    iter += nit;
+  }
   free(order);
   d->solver_iter = iter;
   /* qfrc_constraint = J^T f ; qacc = qacc_smooth + M^-1 qfrc_constraint */

@@ -1068,3 +1068,58 @@ def test_spawn_pool_of_cubes_spheres_cylinders_and_meshes(lib):
         e.set_state(qpos=oq, qvel=np.array([d.f("qvel") for d in ds]), warmstart=np.array([d.f("qacc_warmstart") for d in ds]))
     assert max(d.i("ncon") for d in ds) >= 8
     e.close()
+
+
+def _noslip_scene(lib, nbox, noslip, floss_joint=False):
+    """boxes resting on a 0.3 rad incline (friction holds them), optionally a slider with friction loss"""
+    b = lib.mjh_builder_create()
+    set_opt(lib, b, timestep=0.005)
+    o = ms.capi.Option(); lib.mjh_builder_get_option(b, o); o.noslip_iterations = noslip; lib.mjh_builder_set_option(b, o)
+    ang = 0.3
+    tilt = D(np.cos(ang / 2), 0, np.sin(ang / 2), 0)
+    lib.mjh_builder_add_geom(b, b"ramp", 0, 0, D(0, 0, 0.05), None, tilt, None, -1, -1, -1, -1)
+    n = np.array([np.sin(ang), 0, np.cos(ang)]); t = np.array([0.0, 1.0, 0.0])
+    for k in range(nbox):
+        h = 0.06 + 0.01 * (k % 3)
+        p = n * (h - 5e-4) + t * (0.3 * k - 0.15 * (nbox - 1))
+        bd = lib.mjh_builder_add_body(b, b"box%d" % k, 0, D(*p), tilt, 0.0)
+        lib.mjh_builder_add_joint(b, None, bd, 0, None, None, None, 0, 0, 0, 0, 0)
+        lib.mjh_builder_add_geom(b, None, bd, 6, D(0.08, 0.1, h), None, None, None, 3 + (k % 2), -1, -1, -1)   # condim 3 and 4
+    if floss_joint:      # a weight on a vertical slider held by dry joint friction (friction-loss row in the noslip pass)
+        bd = lib.mjh_builder_add_body(b, b"slider", 0, D(1.0, 0, 0.5), None, 0.0)
+        lib.mjh_builder_add_joint(b, b"slide", bd, 2, None, D(0, 0, 1), None, 0.0, 0.0, 0.0, 30.0, 0.0)
+        lib.mjh_builder_add_geom(b, None, bd, 2, D(0.05, 0, 0), None, None, None, -1, 0, 0, -1)
+    m = ms.Model(lib.mjh_builder_compile(b), lib)
+    lib.mjh_builder_destroy(b)
+    return m
+
+
+@pytest.mark.parametrize("nbox,policy", [(2, 1), (6, 1), (6, 2), (12, 2), (20, 2)], ids=["dual", "single-block", "global-pools", "many-body", "four-row"])
+def test_noslip_sweeps_stop_the_creep_and_match_oracle(lib, layout_policy, nbox, policy):
+    """option noslip_iterations (model/ontology/scene.xml:2-3): friction-only sweeps without the regulariser after the
+    main PGS.  Boxes held by friction on an incline creep at ~1.5 mm/s with the soft constraint; with noslip they stay.
+    All sweep implementations (dual-block nv <= 32, single-block, many-body in global pools)."""
+    layout_policy(policy)
+    res = {}
+    for noslip in (0, 5):
+        m = _noslip_scene(lib, nbox, noslip, floss_joint=True)
+        assert m.opt.noslip_iterations == noslip
+        e = ms.Engine(m, 2); e.reset()
+        d = orc.OrcData(m.ptr); d.call("reset")
+        e.step(200); d.step(200)
+        _, q1, _, _ = e.get_state()
+        oq1 = d.f("qpos").copy()
+        e.step(200); d.step(200)
+        _, q2, v2, _ = e.get_state()
+        st = e.get_stats()
+        assert st[0, 3] == 0 and d.i("warn") == 0 and st[0, 0] == d.i("ncon") == 4 * nbox
+        np.testing.assert_allclose(q2[0], d.f("qpos"), atol=2e-4)                     # device == oracle (with or without noslip)
+        np.testing.assert_array_equal(q2[0], q2[1])
+        creep = np.abs(q2[0] - q1[0])[:7 * nbox].reshape(nbox, 7)[:, :3].max() / (200 * 0.005)
+        ocreep = np.abs(d.f("qpos") - oq1)[:7 * nbox].reshape(nbox, 7)[:, :3].max() / (200 * 0.005)
+        res[noslip] = (creep, ocreep)
+        # the slider (5 N of weight against 30 N of dry joint friction) sags with the soft friction row, not with noslip
+        assert (abs(q2[0, 7 * nbox]) < 1e-5) if noslip else (q2[0, 7 * nbox] < -5e-3)
+        e.close()
+    assert res[0][0] > 5e-4 and res[0][1] > 5e-4, res        # soft contacts creep down the incline ...
+    assert res[5][0] < 2e-5 and res[5][1] < 2e-5, res        # ... noslip holds them

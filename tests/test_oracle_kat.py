@@ -264,3 +264,32 @@ def test_odom_velocity_rotation(lib):
     d.step(1)
     yaw = d.f("qpos")[2]
     np.testing.assert_allclose(d.f("qvel"), [np.cos(yaw), np.sin(yaw), 0.5], atol=1e-12)
+
+
+def test_noslip_pass_removes_the_creep_of_soft_friction(lib):
+    """option noslip_iterations (model/ontology/scene.xml:2-3): a box held by friction on a 0.3 rad incline creeps at
+    ~1.5 mm/s under the regularised (soft) friction rows; the noslip sweeps (friction dimensions only, no regulariser)
+    stop it, and they leave the normal forces (sum = m g cos) alone"""
+    import mujoco_sim_amd as ms
+    from helpers import D, set_opt
+    out = {}
+    for noslip in (0, 5):
+        b = lib.mjh_builder_create(); set_opt(lib, b, timestep=0.005)
+        o = ms.capi.Option(); lib.mjh_builder_get_option(b, o); o.noslip_iterations = noslip; lib.mjh_builder_set_option(b, o)
+        ang = 0.3; tilt = D(np.cos(ang / 2), 0, np.sin(ang / 2), 0)
+        lib.mjh_builder_add_geom(b, b"ramp", 0, 0, D(0, 0, 0.05), None, tilt, None, -1, -1, -1, -1)
+        n = np.array([np.sin(ang), 0, np.cos(ang)])
+        bd = lib.mjh_builder_add_body(b, b"box", 0, D(*(n * 0.0995)), tilt, 0.0)
+        lib.mjh_builder_add_joint(b, None, bd, 0, None, None, None, 0, 0, 0, 0, 0)
+        lib.mjh_builder_add_geom(b, None, bd, 6, D(0.1, 0.1, 0.1), None, None, None, -1, -1, -1, -1)
+        m = ms.Model(lib.mjh_builder_compile(b), lib); lib.mjh_builder_destroy(b)
+        assert m.opt.noslip_tolerance == 1e-6
+        d = orc.OrcData(m.ptr); d.call("reset")
+        d.step(400); p1 = d.f("qpos")[:3].copy(); d.step(400)
+        f = d.f("efc_force")
+        out[noslip] = (np.linalg.norm(d.f("qpos")[:3] - p1) / 2.0, f.sum(), d.i("ncon"))
+    mg = 1000 * 0.008 * 9.81
+    assert out[0][2] == out[5][2] == 4
+    assert out[0][0] > 1e-3 and out[5][0] < 1e-5, out
+    # pyramid edges: the sum of all edge forces is the normal force share, m g cos(angle) either way
+    np.testing.assert_allclose(out[0][1], mg * np.cos(0.3), rtol=2e-3); np.testing.assert_allclose(out[5][1], mg * np.cos(0.3), rtol=2e-3)
