@@ -1,0 +1,117 @@
+"""Pins the oracle against the reference's third-party engine WHERE THAT ENGINE EXISTS.
+
+MuJoCo 2.3.7 is neither in this image nor on the GPU box, so these tests skip there ("parity unpinned").
+On a machine with `pip install mujoco==2.3.7` they hand MuJoCo the same models as MJCF text (tests/mjcf_emit.py: every
+derived quantity written out explicitly, solver = PGS, pyramidal cones, predefined pair list) and run the reference
+loop's own call sequence mj_step1 -> mj_step2 (src/mj_main.cpp:83,108) beside the oracle.  Smooth dynamics must agree
+to fp64 round-off; contact scenes are compared through what does not depend on the narrow phase's point selection
+(this project's box-box manifold and portal refinement are its own definitions)."""
+import numpy as np
+import pytest
+
+mujoco = pytest.importorskip("mujoco", reason="reference library (mujoco==2.3.7) not installed: parity stays unpinned")
+
+import mujoco_sim_amd as ms  # noqa: E402
+import orc  # noqa: E402
+from mjcf_emit import emit_mjcf  # noqa: E402
+
+
+def _maps(m, mm):
+    """index maps oracle -> MuJoCo for qpos / qvel / bodies (names written by the emitter)"""
+    nq, nv = m.nq, m.nv
+    qmap = np.zeros(nq, dtype=int); vmap = np.zeros(nv, dtype=int)
+    jt, qa, da = m.array("jnt_type"), m.array("jnt_qposadr"), m.array("jnt_dofadr")
+    QN, VN = {0: 7, 1: 4, 2: 1, 3: 1}, {0: 6, 1: 3, 2: 1, 3: 1}
+    for j in range(m.njnt):
+        jid = mujoco.mj_name2id(mm, mujoco.mjtObj.mjOBJ_JOINT, f"j{j}")
+        assert jid >= 0
+        for k in range(QN[int(jt[j])]):
+            qmap[qa[j] + k] = mm.jnt_qposadr[jid] + k
+        for k in range(VN[int(jt[j])]):
+            vmap[da[j] + k] = mm.jnt_dofadr[jid] + k
+    bmap = np.array([0] + [mujoco.mj_name2id(mm, mujoco.mjtObj.mjOBJ_BODY, f"b{b}") for b in range(1, m.c.nbody)])
+    return qmap, vmap, bmap
+
+
+def _pair(m, **over):
+    mm = mujoco.MjModel.from_xml_string(emit_mjcf(m, **over))
+    assert mm.nq == m.nq and mm.nv == m.nv and mm.nbody == m.c.nbody
+    return mm, mujoco.MjData(mm)
+
+
+def test_smooth_dynamics_agree_to_roundoff():
+    """FK, the joint-space inertia, the bias force and one unconstrained step of the C3 arm and the C1 pendulum"""
+    rng = np.random.default_rng(0)
+    for m in (ms.scene("arm7", 0), ms.scene("pendulum")):
+        mm, dd = _pair(m)
+        qmap, vmap, bmap = _maps(m, mm)
+        d = orc.OrcData(m.ptr)
+        q = m.array("qpos0").copy(); v = rng.normal(size=m.nv) * 0.5
+        jt, qa = m.array("jnt_type"), m.array("jnt_qposadr")
+        for j in range(m.njnt):
+            if jt[j] == 1:
+                x = rng.normal(size=4); q[qa[j]:qa[j] + 4] = x / np.linalg.norm(x)
+            elif jt[j] in (2, 3):
+                q[qa[j]] += rng.uniform(-0.3, 0.3)
+        d.set_qpos(q, as_initial=False); d.f("qvel")[:] = v
+        dd.qpos[qmap] = q; dd.qvel[vmap] = v
+        d.call("forward"); mujoco.mj_forward(mm, dd)
+        np.testing.assert_allclose(d.f("xpos").reshape(-1, 3), dd.xpos[bmap], atol=1e-10)
+        np.testing.assert_allclose(d.f("qfrc_bias"), dd.qfrc_bias[vmap], atol=1e-8)
+        M = np.zeros((mm.nv, mm.nv)); mujoco.mj_fullM(mm, M, dd.qM)
+        for k in range(m.nv):
+            e = np.zeros(m.nv); e[k] = 1.0
+            np.testing.assert_allclose(d.mul_m(e), M[np.ix_(vmap, vmap)][:, k], atol=1e-9)
+        if d.i("nefc") == 0 and dd.nefc == 0:
+            np.testing.assert_allclose(d.f("qacc"), dd.qacc[vmap], atol=1e-8)
+
+
+def test_pendulum_c1_trajectory():
+    """C1: 1000 steps of the reference loop body, three damped ball joints under gravity -0.1 (implicit joint damping)"""
+    m = ms.scene("pendulum")
+    mm, dd = _pair(m)
+    qmap, vmap, _ = _maps(m, mm)
+    d = orc.OrcData(m.ptr)
+    v0 = np.tile([0.3, 0.0, 0.0], 3)
+    d.f("qvel")[:] = v0; dd.qvel[vmap] = v0
+    for _ in range(1000):
+        d.step(1)
+        mujoco.mj_step1(mm, dd); mujoco.mj_step2(mm, dd)
+    np.testing.assert_allclose(d.f("qpos"), dd.qpos[qmap], atol=1e-7)
+    np.testing.assert_allclose(d.f("qvel"), dd.qvel[vmap], atol=1e-7)
+
+
+def test_arm_limits_and_equality_free_fall_then_rest():
+    """C3 arm without gravity compensation sags into its joint limits: limit rows, PGS, warm start"""
+    m = ms.scene("arm7", 0)
+    mm, dd = _pair(m)
+    qmap, vmap, _ = _maps(m, mm)
+    d = orc.OrcData(m.ptr)
+    for _ in range(400):
+        d.step(1)
+        mujoco.mj_step1(mm, dd); mujoco.mj_step2(mm, dd)
+    np.testing.assert_allclose(d.f("qpos"), dd.qpos[qmap], atol=1e-4)
+
+
+def test_s24_contact_scene_agrees_where_the_manifold_choice_does_not_matter():
+    """S24 envs: the same per-env boxes.  Before the first box-box touch only plane-box contacts exist (4 corner points on
+    both sides), so the trajectories agree tightly; after the pile has formed, heights and total normal force agree."""
+    from mujoco_sim_amd.engine import EP
+    m = ms.scene("s24")
+    tab = m.s24_randomize(0, 4)
+    for i in range(4):
+        mm, dd = _pair(m, geom_size=tab["geom_size"][i], body_mass=tab["body_mass"][i], body_inertia=tab["body_inertia"][i])
+        qmap, vmap, _ = _maps(m, mm)
+        d = orc.OrcData(m.ptr)
+        for k, w in EP.items():
+            d.set_env_param(w, tab[k][i])
+        d.set_qpos(tab["qpos"][i]); d.call("reset")
+        dd.qpos[qmap] = tab["qpos"][i]
+        for s in range(1, 601):
+            d.step(1)
+            mujoco.mj_step1(mm, dd); mujoco.mj_step2(mm, dd)
+            if s == 30:      # free fall + first plane contacts of the lowest box
+                np.testing.assert_allclose(d.f("qpos"), dd.qpos[qmap], atol=1e-6)
+        z_o = d.f("qpos")[2::7]; z_m = dd.qpos[qmap][2::7]
+        assert np.abs(np.sort(z_o) - np.sort(z_m)).max() < 0.05            # the same pile, up to how the boxes leaned
+        assert np.abs(d.f("qvel")).max() < 0.5 and np.abs(dd.qvel).max() < 0.5
