@@ -5,7 +5,7 @@
  * Every stage cites the reference call site whose arithmetic it restates
  * (paths under /root/reference); [UPSTREAM] marks MuJoCo-internal structure
  * restated from its public documentation.
-  * Where MuJoCo 2.3.7 is installed, tests/test_mujoco_reference.py steps it beside this file on the same models
+ * Where MuJoCo 2.3.7 is installed, tests/test_mujoco_reference.py steps it beside this file on the same models
  * (emitted as MJCF by tests/mjcf_emit.py); it is absent here, so the parity of this file stays UNPINNED.
  */
 #include "mjh_oracle.h"
