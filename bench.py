@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--with-inverse", type=int, default=0, help="also run mj_inverse every step (MjHWInterface::read)")
     ap.add_argument("--fuse", type=int, default=1, help="steps between host hand-offs (one kernel launch per step either way)")
     ap.add_argument("--cohorts", type=int, default=-1, help="env cohorts stepped on separate HIP streams (-1: engine default)")
-    ap.add_argument("--maxcon", type=int, default=0, help="override the scene's contact capacity per env (rows: 6 per contact); 0 = scene default (32)")
+    ap.add_argument("--maxcon", type=int, default=0, help="override the scene's contact capacity per env (rows: 6 per contact); 0 = scene default (40)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the publish all-gather even with one rank (self-test of the multi-GPU path)")
