@@ -269,6 +269,13 @@ int mjh_get_contacts(mjh_engine*, int env, double* dist, double* pos, double* fr
 int mjh_set_env_param(mjh_engine*, int which, int env0, int n, const double* values);
 /* MjRos::reset_robot (mj_ros.cpp:569-609): back to qpos0 (or the per-env initial
  * qpos set by mjh_set_initial_qpos), zero qvel/qacc/warmstart/time */
+/* State transplant after a model change (reference: add_old_state(), mj_sim.cpp:465-558, run when spawn/destroy or a
+ * robot reload recompiles the model): for every body of `from` whose NAME also exists in `to`, copy its joints' state
+ * of envs [0, min(nenv)) — time, qvel, qacc_warmstart, qfrc_applied and qacc per dof if the dof counts match, qpos if the
+ * joint counts match.  qpos_mode 0 is literal: the reference copies body_jntnum scalars of qpos (one per joint, so a free
+ * body keeps only its x and otherwise takes the pose baked into the new model, mj_sim.cpp:613-623); qpos_mode 1 copies
+ * every qpos scalar of the body's joints.  Returns the number of bodies matched, or a negative code. */
+int mjh_transplant_state(mjh_engine* from, mjh_engine* to, int qpos_mode);
 int mjh_set_initial_qpos(mjh_engine*, int env0, int n, const double* qpos);
 int mjh_reset(mjh_engine*, const int* env_ids, int n);
 

@@ -146,6 +146,7 @@ SYMBOLS = [
     ("mjh_get_stats", C.c_int, [_vp, C.c_int, C.c_int, c_int_p]),
     ("mjh_get_contacts", C.c_int, [_vp, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]),
     ("mjh_set_env_param", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, c_double_p]),
+    ("mjh_transplant_state", C.c_int, [_vp, _vp, C.c_int]),
     ("mjh_set_initial_qpos", C.c_int, [_vp, C.c_int, C.c_int, c_double_p]),
     ("mjh_reset", C.c_int, [_vp, c_int_p, C.c_int]),
     ("mjh_set_slot_active", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -607,6 +607,55 @@ extern "C" int mjh_set_state(mjh_engine* e, int env0, int n, const double* time,
   return rc;
 }
 
+// add_old_state() (mj_sim.cpp:465-558) for all environments at once: host-side gather / scatter between two engines
+extern "C" int mjh_transplant_state(mjh_engine* from, mjh_engine* to, int qpos_mode) {
+  if (!from || !to || from == to) { mjh_set_error("mjh_transplant_state: bad engines"); return MJH_ERR_ARG; }
+  const mjh_model *ma = from->model, *mb = to->model;
+  const int n = std::min(from->nenv, to->nenv);
+  static const int QN[4] = {7, 4, 1, 1};
+  const size_t nqa = ma->nq, nva = ma->nv, nqb = mb->nq, nvb = mb->nv;
+  std::vector<double> ta(n), qa(n * nqa), va(n * nva), wa(n * nva), fa(n * nva), aa(n * nva);
+  std::vector<double> tb(n), qb(n * nqb), vb(n * nvb), wb(n * nvb), fb(n * nvb), ab(n * nvb);
+  int rc = mjh_get_state(from, 0, n, ta.data(), qa.data(), va.data(), wa.data());
+  if (!rc) rc = mjh_get_field(from, "qfrc_applied", 0, n, fa.data());
+  if (!rc) rc = mjh_get_field(from, "qacc", 0, n, aa.data());
+  if (!rc) rc = mjh_get_state(to, 0, n, tb.data(), qb.data(), vb.data(), wb.data());
+  if (!rc) rc = mjh_get_field(to, "qfrc_applied", 0, n, fb.data());
+  if (!rc) rc = mjh_get_field(to, "qacc", 0, n, ab.data());
+  if (rc) return rc;
+  int matched = 0;
+  for (int ba = 1; ba < ma->nbody; ba++) {
+    const char* name = ma->body_names ? ma->body_names[ba] : nullptr;
+    if (!name || !*name) continue;
+    const int bb = mjh_name2id(mb, 0, name);
+    if (bb <= 0) continue;
+    matched++;
+    const int ja = ma->body_jntnum[ba], jb = mb->body_jntnum[bb];
+    if (ja == jb && ja > 0) {
+      const int pa = ma->jnt_qposadr[ma->body_jntadr[ba]], pb = mb->jnt_qposadr[mb->body_jntadr[bb]];
+      int cnt = ja;                                   // literal: one scalar per joint (mj_sim.cpp:510-513)
+      if (qpos_mode) { cnt = 0; for (int j = 0; j < ja; j++) cnt += QN[ma->jnt_type[ma->body_jntadr[ba] + j]]; }
+      bool same = true;
+      for (int j = 0; j < ja; j++) same &= ma->jnt_type[ma->body_jntadr[ba] + j] == mb->jnt_type[mb->body_jntadr[bb] + j];
+      if (same || !qpos_mode)
+        for (int i = 0; i < n; i++) for (int k = 0; k < cnt; k++) qb[i * nqb + pb + k] = qa[i * nqa + pa + k];
+    }
+    const int da = ma->body_dofnum[ba], db = mb->body_dofnum[bb];
+    if (da == db && da > 0) {
+      const int oa = ma->body_dofadr[ba], ob = mb->body_dofadr[bb];
+      for (int i = 0; i < n; i++) for (int k = 0; k < da; k++) {
+        vb[i * nvb + ob + k] = va[i * nva + oa + k]; wb[i * nvb + ob + k] = wa[i * nva + oa + k];
+        fb[i * nvb + ob + k] = fa[i * nva + oa + k]; ab[i * nvb + ob + k] = aa[i * nva + oa + k];
+      }
+    }
+  }
+  for (int i = 0; i < n; i++) tb[i] = ta[i];          // d_new->time = d->time
+  rc = mjh_set_state(to, 0, n, tb.data(), qb.data(), vb.data(), wb.data());
+  if (!rc) rc = put_rows(to, to->S.qfrc_applied, to->M.nvp, to->M.nv, 0, n, fb.data());
+  if (!rc) rc = put_rows(to, to->S.qacc, to->M.nvp, to->M.nv, 0, n, ab.data());
+  return rc ? rc : matched;
+}
+
 extern "C" int mjh_get_field(mjh_engine* e, const char* name, int env0, int n, double* out) {
   ENG(e); RANGE(e, env0, n);
   if (!name) return MJH_ERR_ARG;

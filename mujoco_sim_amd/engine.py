@@ -216,6 +216,10 @@ class Engine:
             ids = np.ascontiguousarray(env_ids, dtype=np.int32)
             _chk(self.lib, self.lib.mjh_reset(self.h, capi.iptr(ids), ids.shape[0]), "mjh_reset")
 
+    def transplant_state_from(self, other, full_qpos=True):
+        """add_old_state() (mj_sim.cpp:465-558): name-matched copy of the per-body state of `other` into this engine"""
+        return _chk(self.lib, self.lib.mjh_transplant_state(other.h, self.h, int(bool(full_qpos))), "mjh_transplant_state")
+
     def set_slot_active(self, body, active, env0=0, n=None):
         n = self.nenv - env0 if n is None else n
         _chk(self.lib, self.lib.mjh_set_slot_active(self.h, env0, n, body, int(active)), "mjh_set_slot_active")

@@ -1123,3 +1123,49 @@ def test_noslip_sweeps_stop_the_creep_and_match_oracle(lib, layout_policy, nbox,
         e.close()
     assert res[0][0] > 5e-4 and res[0][1] > 5e-4, res        # soft contacts creep down the incline ...
     assert res[5][0] < 2e-5 and res[5][1] < 2e-5, res        # ... noslip holds them
+
+
+def test_state_transplant_after_a_model_change(lib):
+    """A18: the reference recompiles the model on spawn / destroy and carries the state over by body NAME
+    (add_old_state, mj_sim.cpp:465-558).  Old model: three named boxes mid-fall; new model: one box destroyed, one added,
+    bodies declared in another order.  The survivors continue exactly where they were."""
+    def build(names, z0=0.5):
+        b = lib.mjh_builder_create()
+        set_opt(lib, b, timestep=0.005)
+        lib.mjh_builder_add_geom(b, b"floor", 0, 0, D(0, 0, 0.05), None, None, None, -1, -1, -1, -1)
+        for name, x in names:
+            bd = lib.mjh_builder_add_body(b, name, 0, D(x, 0, z0), None, 0.0)
+            lib.mjh_builder_add_joint(b, None, bd, 0, None, None, None, 0, 0, 0, 0, 0)
+            lib.mjh_builder_add_geom(b, None, bd, 6, D(0.05, 0.06, 0.07), None, None, None, -1, -1, -1, -1)
+        m = ms.Model(lib.mjh_builder_compile(b), lib); lib.mjh_builder_destroy(b)
+        return m
+    old = build([(b"object_0", 0.0), (b"object_1", 0.6), (b"object_2", 1.2)])
+    new = build([(b"object_7", 3.0), (b"object_2", -1.0), (b"object_0", -2.0)], z0=0.9)       # object_1 destroyed, object_7 spawned
+    nenv = 3
+    ea, eb = ms.Engine(old, nenv), ms.Engine(new, nenv)
+    rng = np.random.default_rng(1)
+    q = np.tile(old.array("qpos0"), (nenv, 1)); v = rng.normal(size=(nenv, old.nv)) * 0.3
+    for i in range(nenv):
+        for k in range(3):
+            x = rng.normal(size=4); q[i, 7*k+3:7*k+7] = x / np.linalg.norm(x)
+    ea.set_initial_qpos(q); ea.reset(); ea.set_state(qvel=v); ea.step(40)
+    ta, qa, va, wa = ea.get_state()
+    assert eb.transplant_state_from(ea, full_qpos=True) == 2                       # object_0 and object_2 matched
+    tb, qb, vb, wb = eb.get_state()
+    np.testing.assert_array_equal(tb, ta)
+    # new-model slots: object_7 -> 0, object_2 -> 1, object_0 -> 2
+    np.testing.assert_array_equal(qb[:, 7:14], qa[:, 14:21]); np.testing.assert_array_equal(qb[:, 14:21], qa[:, 0:7])
+    np.testing.assert_array_equal(vb[:, 6:12], va[:, 12:18]); np.testing.assert_array_equal(wb[:, 12:18], wa[:, 0:6])
+    np.testing.assert_allclose(qb[:, 0:3], [[3.0, 0, 0.9]] * nenv)                   # the spawned one keeps its baked pose
+    ea.step(120); eb.step(120)
+    _, qa2, va2, _ = ea.get_state(); _, qb2, vb2, _ = eb.get_state()
+    np.testing.assert_allclose(qb2[:, 7:14], qa2[:, 14:21], atol=2e-4); np.testing.assert_allclose(qb2[:, 14:21], qa2[:, 0:7], atol=2e-4)
+    assert (qb2[:, 2] < 0.2).all()                                                  # and the new box fell to the floor
+    # literal mode: the reference copies body_jntnum qpos scalars, i.e. only x of a free body (mj_sim.cpp:510-513)
+    ec = ms.Engine(new, nenv)
+    assert ec.transplant_state_from(ea, full_qpos=False) == 2
+    _, qc, vc, _ = ec.get_state()
+    np.testing.assert_array_equal(qc[:, 7], qa2[:, 14]); np.testing.assert_allclose(qc[:, 8:14], [[0, 0.9, 1, 0, 0, 0]] * nenv)
+    np.testing.assert_array_equal(vc[:, 6:12], va2[:, 12:18])
+    for e in (ea, eb, ec):
+        e.close()
