@@ -1169,3 +1169,42 @@ def test_state_transplant_after_a_model_change(lib):
     np.testing.assert_array_equal(vc[:, 6:12], va2[:, 12:18])
     for e in (ea, eb, ec):
         e.close()
+
+
+def test_plane_contacts_of_round_geoms_match_oracle(lib):
+    """analytic plane pairs on the device against the oracle from identical random poses: ellipsoid (support point),
+    cylinder (rim points), capsule, sphere — and the rest pose of an ellipsoid on the floor"""
+    m = _convex_zoo(lib, with_floor=True)
+    nenv = 48
+    rng = np.random.default_rng(31)
+    q = np.zeros((nenv, m.nq))
+    for i in range(nenv):
+        for k in range(5):
+            quat = rng.normal(size=4); quat /= np.linalg.norm(quat)
+            q[i, 7*k:7*k+3] = [0.6 + 0.4 * k, rng.uniform(-0.1, 0.1), rng.uniform(0.03, 0.1)]      # next to the block, touching the floor
+            q[i, 7*k+3:7*k+7] = quat
+    e = ms.Engine(m, nenv)
+    e.set_initial_qpos(q); e.reset(); e.forward(); e.synchronize()
+    nsame = npts = 0
+    for i in range(nenv):
+        d = orc.OrcData(m.ptr); d.set_qpos(q[i]); d.call("reset"); d.call("forward")
+        oc = d.contacts(); c = e.get_contacts(i)
+        if len(oc) != len(c["dist"]):
+            assert abs(len(oc) - len(c["dist"])) <= 1            # a grazing rim point
+            continue
+        nsame += 1
+        if oc:
+            assert [tuple(g) for g in c["geom"]] == [x["geom"] for x in oc]
+            np.testing.assert_allclose(c["dist"], [x["dist"] for x in oc], atol=2e-6)
+            np.testing.assert_allclose(c["pos"], [x["pos"] for x in oc], atol=2e-5)
+            npts += len(oc)
+    assert nsame >= nenv - 4 and npts >= 3 * nenv
+    # an ellipsoid dropped flat rests at its smallest half-axis
+    q0 = m.array("qpos0").copy()
+    for k in range(5):
+        q0[7*k:7*k+3] = [0.6 + 0.4 * k, 0, 0.2]
+    q0[7*2:7*2+3] = [1.4, 0, 0.06]
+    e2 = ms.Engine(m, 1); e2.set_initial_qpos(q0[None, :]); e2.reset(); e2.step(600)
+    _, qq, vv, _ = e2.get_state()
+    assert abs(qq[0, 7*2+2] - 0.04) < 2e-3 and np.abs(vv[0, 12:18]).max() < 5e-2
+    e.close(); e2.close()
