@@ -173,6 +173,14 @@ int mjh_builder_add_eq_joint(mjh_builder*, int joint1, int joint2, const double 
 /* compile: derives inertias, qpos0, invweight0, meaninertia, rbound, pair list */
 mjh_model* mjh_builder_compile(mjh_builder*);
 void mjh_model_destroy(mjh_model*);
+/* Sub-wave packing for small models (nv of a few, a handful of bodies: the C1 / C3 / C5 scenes): `copies` independent
+ * instances of every moving body tree in ONE model, sharing the static geometry (world / welded-to-world geoms) and
+ * never colliding with each other.  An engine created from the result steps `copies` environments per wavefront:
+ * row w of every state array holds the qpos / qvel / ... of environments w*copies .. w*copies+copies-1 back to back
+ * (copy c at offset c*nq, c*nv).  What the instances of one wavefront share: the solver's termination test (sweeps
+ * continue until the slowest instance has converged), `time`, the statistics row and the bad-state reset.  Contact
+ * and row capacities scale with `copies`.  Returns a new model (mjh_model_destroy) or NULL. */
+mjh_model* mjh_model_replicate(const mjh_model* m, int copies);
 int mjh_name2id(const mjh_model*, int objtype /*0 body,1 joint,2 geom*/, const char* name);
 const char* mjh_id2name(const mjh_model*, int objtype, int id);
 

@@ -111,6 +111,7 @@ SYMBOLS = [
     ("mjh_builder_add_eq_joint", C.c_int, [_vp, C.c_int, C.c_int, c_double_p]),
     ("mjh_builder_compile", Model_p, [_vp]),
     ("mjh_model_destroy", None, [Model_p]),
+    ("mjh_model_replicate", Model_p, [Model_p, C.c_int]),
     ("mjh_name2id", C.c_int, [Model_p, C.c_int, C.c_char_p]),
     ("mjh_id2name", C.c_char_p, [Model_p, C.c_int, C.c_int]),
     ("mjh_load_mjcf_string", Model_p, [C.c_char_p]),

@@ -772,6 +772,120 @@ extern "C" mjh_model* mjh_builder_compile(mjh_builder* B) {
   return m;
 }
 
+// ---- sub-wave packing: `copies` instances of the moving bodies in one model (include/mjhip.h)
+extern "C" mjh_model* mjh_model_replicate(const mjh_model* a, int G) {
+  if (!a || G < 1) { g_err = "mjh_model_replicate: bad arguments"; return nullptr; }
+  const int nb = a->nbody, nj = a->njnt, nv = a->nv, nq = a->nq, ng = a->ngeom, nt = a->ntree, ne = a->neq, np = a->npair, nM = a->nM;
+  std::vector<int> moving_b, moving_g;
+  for (int b = 1; b < nb; b++) if (a->body_weldid[b] != 0) moving_b.push_back(b);
+  for (int g = 0; g < ng; g++) if (a->body_weldid[a->geom_bodyid[g]] != 0) moving_g.push_back(g);
+  const int mb = (int)moving_b.size(), mg = (int)moving_g.size();
+  const int NB = nb + (G - 1) * mb, NG = ng + (G - 1) * mg;
+  if (NB > 4096 || (long long)G * nv > 4096) { g_err = "mjh_model_replicate: result too large"; return nullptr; }
+  // id maps of copy k
+  auto bmap = [&](int k, int b) { if (k == 0 || a->body_weldid[b] == 0) return b; int r = (int)(std::lower_bound(moving_b.begin(), moving_b.end(), b) - moving_b.begin()); return nb + (k - 1) * mb + r; };
+  auto gmap = [&](int k, int g) { if (k == 0 || a->body_weldid[a->geom_bodyid[g]] == 0) return g; int r = (int)(std::lower_bound(moving_g.begin(), moving_g.end(), g) - moving_g.begin()); return ng + (k - 1) * mg + r; };
+  mjh_model* m = (mjh_model*)std::calloc(1, sizeof(mjh_model));
+  m->nq = G * nq; m->nv = G * nv; m->nbody = NB; m->njnt = G * nj; m->ngeom = NG; m->neq = G * ne; m->npair = G * np; m->nM = G * nM;
+  m->ntree = G * nt; m->nexclude = a->nexclude; m->maxcon = G * a->maxcon; m->maxefc = G * a->maxefc;
+  m->nmesh = a->nmesh; m->nmeshvert = a->nmeshvert; m->opt = a->opt; m->meaninertia = a->meaninertia;
+  auto ialloc = [](size_t n) { return (int*)std::calloc(n + 1, sizeof(int)); };
+  auto dalloc = [](size_t n) { return (double*)std::calloc(n + 1, sizeof(double)); };
+  // ---- bodies
+#define BI(f) m->f = ialloc(NB)
+#define BD(f, w) m->f = dalloc((size_t)(w) * NB)
+  BI(body_parentid); BI(body_rootid); BI(body_weldid); BI(body_jntadr); BI(body_jntnum); BI(body_dofadr); BI(body_dofnum);
+  BI(body_treeid); BI(body_level); BI(body_geomadr); BI(body_geomnum);
+  BD(body_pos, 3); BD(body_quat, 4); BD(body_ipos, 3); BD(body_iquat, 4); BD(body_mass, 1); BD(body_inertia, 3); BD(body_gravcomp, 1); BD(body_invweight0, 2);
+#undef BI
+#undef BD
+  std::vector<std::string> bnames(NB), jnames((size_t)G * nj), gnames(NG);
+  auto nm = [](char** t, int i, int k) { std::string s = (t && t[i]) ? t[i] : ""; if (k > 0 && !s.empty()) s += "#" + std::to_string(k); return s; };
+  for (int k = 0; k < G; k++) for (int b = 0; b < nb; b++) {
+    if (k > 0 && a->body_weldid[b] == 0) continue;
+    const int B2 = bmap(k, b);
+    m->body_parentid[B2] = bmap(k, a->body_parentid[b]); m->body_rootid[B2] = bmap(k, a->body_rootid[b]); m->body_weldid[B2] = bmap(k, a->body_weldid[b]);
+    m->body_jntadr[B2] = a->body_jntadr[b] >= 0 ? a->body_jntadr[b] + k * nj : -1; m->body_jntnum[B2] = a->body_jntnum[b];
+    m->body_dofadr[B2] = a->body_dofadr[b] >= 0 ? a->body_dofadr[b] + k * nv : -1; m->body_dofnum[B2] = a->body_dofnum[b];
+    m->body_treeid[B2] = a->body_treeid[b] >= 0 ? a->body_treeid[b] + k * nt : -1; m->body_level[B2] = a->body_level[b];
+    m->body_geomnum[B2] = a->body_geomnum[b];
+    m->body_geomadr[B2] = a->body_geomadr[b] >= 0 ? gmap(k, a->body_geomadr[b]) : -1;
+    for (int q = 0; q < 3; q++) { m->body_pos[3*B2+q] = a->body_pos[3*b+q]; m->body_ipos[3*B2+q] = a->body_ipos[3*b+q]; m->body_inertia[3*B2+q] = a->body_inertia[3*b+q]; }
+    for (int q = 0; q < 4; q++) { m->body_quat[4*B2+q] = a->body_quat[4*b+q]; m->body_iquat[4*B2+q] = a->body_iquat[4*b+q]; }
+    m->body_mass[B2] = a->body_mass[b]; m->body_gravcomp[B2] = a->body_gravcomp[b];
+    m->body_invweight0[2*B2] = a->body_invweight0[2*b]; m->body_invweight0[2*B2+1] = a->body_invweight0[2*b+1];
+    bnames[B2] = nm(a->body_names, b, k);
+  }
+  // ---- joints, dofs, trees, qpos0: whole blocks per copy
+  m->jnt_type = ialloc((size_t)G*nj); m->jnt_qposadr = ialloc((size_t)G*nj); m->jnt_dofadr = ialloc((size_t)G*nj); m->jnt_bodyid = ialloc((size_t)G*nj); m->jnt_limited = ialloc((size_t)G*nj);
+  m->jnt_pos = dalloc((size_t)3*G*nj); m->jnt_axis = dalloc((size_t)3*G*nj); m->jnt_stiffness = dalloc((size_t)G*nj); m->jnt_range = dalloc((size_t)2*G*nj);
+  m->jnt_margin = dalloc((size_t)G*nj); m->jnt_solref = dalloc((size_t)2*G*nj); m->jnt_solimp = dalloc((size_t)5*G*nj);
+  m->qpos0 = dalloc((size_t)G*nq); m->qpos_spring = dalloc((size_t)G*nq);
+  m->dof_bodyid = ialloc((size_t)G*nv); m->dof_jntid = ialloc((size_t)G*nv); m->dof_parentid = ialloc((size_t)G*nv); m->dof_Madr = ialloc((size_t)G*nv); m->dof_treeid = ialloc((size_t)G*nv);
+  m->dof_armature = dalloc((size_t)G*nv); m->dof_damping = dalloc((size_t)G*nv); m->dof_frictionloss = dalloc((size_t)G*nv); m->dof_invweight0 = dalloc((size_t)G*nv);
+  m->dof_solref = dalloc((size_t)2*G*nv); m->dof_solimp = dalloc((size_t)5*G*nv);
+  m->tree_dofadr = ialloc((size_t)G*nt); m->tree_dofnum = ialloc((size_t)G*nt); m->tree_bodyid = ialloc((size_t)G*nt);
+  auto cpd = [](double* dst, const double* src, size_t n) { if (n) std::memcpy(dst, src, n * sizeof(double)); };
+  for (int k = 0; k < G; k++) {
+    for (int j = 0; j < nj; j++) {
+      const int J2 = j + k * nj;
+      m->jnt_type[J2] = a->jnt_type[j]; m->jnt_qposadr[J2] = a->jnt_qposadr[j] + k * nq; m->jnt_dofadr[J2] = a->jnt_dofadr[j] + k * nv;
+      m->jnt_bodyid[J2] = bmap(k, a->jnt_bodyid[j]); m->jnt_limited[J2] = a->jnt_limited[j];
+      jnames[J2] = nm(a->jnt_names, j, k);
+    }
+    cpd(m->jnt_pos + (size_t)3*k*nj, a->jnt_pos, (size_t)3*nj); cpd(m->jnt_axis + (size_t)3*k*nj, a->jnt_axis, (size_t)3*nj);
+    cpd(m->jnt_stiffness + (size_t)k*nj, a->jnt_stiffness, nj); cpd(m->jnt_range + (size_t)2*k*nj, a->jnt_range, (size_t)2*nj);
+    cpd(m->jnt_margin + (size_t)k*nj, a->jnt_margin, nj); cpd(m->jnt_solref + (size_t)2*k*nj, a->jnt_solref, (size_t)2*nj); cpd(m->jnt_solimp + (size_t)5*k*nj, a->jnt_solimp, (size_t)5*nj);
+    cpd(m->qpos0 + (size_t)k*nq, a->qpos0, nq); cpd(m->qpos_spring + (size_t)k*nq, a->qpos_spring, nq);
+    for (int d = 0; d < nv; d++) {
+      const int D2 = d + k * nv;
+      m->dof_bodyid[D2] = bmap(k, a->dof_bodyid[d]); m->dof_jntid[D2] = a->dof_jntid[d] + k * nj;
+      m->dof_parentid[D2] = a->dof_parentid[d] >= 0 ? a->dof_parentid[d] + k * nv : -1;
+      m->dof_Madr[D2] = a->dof_Madr[d] + k * nM; m->dof_treeid[D2] = a->dof_treeid[d] >= 0 ? a->dof_treeid[d] + k * nt : -1;
+    }
+    cpd(m->dof_armature + (size_t)k*nv, a->dof_armature, nv); cpd(m->dof_damping + (size_t)k*nv, a->dof_damping, nv);
+    cpd(m->dof_frictionloss + (size_t)k*nv, a->dof_frictionloss, nv); cpd(m->dof_invweight0 + (size_t)k*nv, a->dof_invweight0, nv);
+    cpd(m->dof_solref + (size_t)2*k*nv, a->dof_solref, (size_t)2*nv); cpd(m->dof_solimp + (size_t)5*k*nv, a->dof_solimp, (size_t)5*nv);
+    for (int t = 0; t < nt; t++) { m->tree_dofadr[t + k*nt] = a->tree_dofadr[t] + k * nv; m->tree_dofnum[t + k*nt] = a->tree_dofnum[t]; m->tree_bodyid[t + k*nt] = bmap(k, a->tree_bodyid[t]); }
+  }
+  // ---- geoms
+  m->geom_type = ialloc(NG); m->geom_bodyid = ialloc(NG); m->geom_condim = ialloc(NG); m->geom_contype = ialloc(NG); m->geom_conaffinity = ialloc(NG);
+  m->geom_priority = ialloc(NG); m->geom_dataid = ialloc(NG);
+  m->geom_pos = dalloc((size_t)3*NG); m->geom_quat = dalloc((size_t)4*NG); m->geom_size = dalloc((size_t)3*NG); m->geom_rbound = dalloc(NG); m->geom_friction = dalloc((size_t)3*NG);
+  m->geom_solmix = dalloc(NG); m->geom_solref = dalloc((size_t)2*NG); m->geom_solimp = dalloc((size_t)5*NG); m->geom_margin = dalloc(NG); m->geom_gap = dalloc(NG);
+  for (int k = 0; k < G; k++) for (int g = 0; g < ng; g++) {
+    if (k > 0 && a->body_weldid[a->geom_bodyid[g]] == 0) continue;
+    const int G2 = gmap(k, g);
+    m->geom_type[G2] = a->geom_type[g]; m->geom_bodyid[G2] = bmap(k, a->geom_bodyid[g]); m->geom_condim[G2] = a->geom_condim[g];
+    m->geom_contype[G2] = a->geom_contype[g]; m->geom_conaffinity[G2] = a->geom_conaffinity[g]; m->geom_priority[G2] = a->geom_priority[g];
+    m->geom_dataid[G2] = a->geom_dataid ? a->geom_dataid[g] : -1;
+    for (int q = 0; q < 3; q++) { m->geom_pos[3*G2+q] = a->geom_pos[3*g+q]; m->geom_size[3*G2+q] = a->geom_size[3*g+q]; m->geom_friction[3*G2+q] = a->geom_friction[3*g+q]; }
+    for (int q = 0; q < 4; q++) m->geom_quat[4*G2+q] = a->geom_quat[4*g+q];
+    m->geom_rbound[G2] = a->geom_rbound[g]; m->geom_solmix[G2] = a->geom_solmix[g]; m->geom_margin[G2] = a->geom_margin[g]; m->geom_gap[G2] = a->geom_gap[g];
+    for (int q = 0; q < 2; q++) m->geom_solref[2*G2+q] = a->geom_solref[2*g+q];
+    for (int q = 0; q < 5; q++) m->geom_solimp[5*G2+q] = a->geom_solimp[5*g+q];
+    gnames[G2] = nm(a->geom_names, g, k);
+  }
+  // ---- candidate pairs (instances never meet), equalities
+  m->pair_geom1 = ialloc((size_t)G*np); m->pair_geom2 = ialloc((size_t)G*np);
+  for (int k = 0; k < G; k++) for (int i = 0; i < np; i++) { m->pair_geom1[i + k*np] = gmap(k, a->pair_geom1[i]); m->pair_geom2[i + k*np] = gmap(k, a->pair_geom2[i]); }
+  m->eq_type = ialloc((size_t)G*ne); m->eq_obj1id = ialloc((size_t)G*ne); m->eq_obj2id = ialloc((size_t)G*ne); m->eq_active = ialloc((size_t)G*ne);
+  m->eq_data = dalloc((size_t)11*G*ne); m->eq_solref = dalloc((size_t)2*G*ne); m->eq_solimp = dalloc((size_t)5*G*ne);
+  for (int k = 0; k < G; k++) {
+    for (int e = 0; e < ne; e++) {
+      m->eq_type[e + k*ne] = a->eq_type[e]; m->eq_active[e + k*ne] = a->eq_active[e];
+      m->eq_obj1id[e + k*ne] = a->eq_obj1id[e] + k * nj; m->eq_obj2id[e + k*ne] = a->eq_obj2id[e] >= 0 ? a->eq_obj2id[e] + k * nj : -1;
+    }
+    cpd(m->eq_data + (size_t)11*k*ne, a->eq_data, (size_t)11*ne); cpd(m->eq_solref + (size_t)2*k*ne, a->eq_solref, (size_t)2*ne); cpd(m->eq_solimp + (size_t)5*k*ne, a->eq_solimp, (size_t)5*ne);
+  }
+  // ---- mesh assets: shared
+  m->mesh_vertadr = ialloc(a->nmesh); m->mesh_vertnum = ialloc(a->nmesh); m->mesh_vert = dalloc((size_t)3 * a->nmeshvert);
+  for (int i = 0; i < a->nmesh; i++) { m->mesh_vertadr[i] = a->mesh_vertadr[i]; m->mesh_vertnum[i] = a->mesh_vertnum[i]; }
+  cpd(m->mesh_vert, a->mesh_vert, (size_t)3 * a->nmeshvert);
+  m->body_names = dupnames(bnames); m->jnt_names = dupnames(jnames); m->geom_names = dupnames(gnames);
+  return m;
+}
+
 extern "C" void mjh_model_destroy(mjh_model* m) {
   if (!m) return;
   void* ptrs[] = {m->body_parentid, m->body_rootid, m->body_weldid, m->body_jntadr, m->body_jntnum, m->body_dofadr, m->body_dofnum,

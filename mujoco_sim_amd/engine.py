@@ -41,6 +41,10 @@ class Model:
     def name2id(self, objtype, name):
         return self.lib.mjh_name2id(self.ptr, objtype, name.encode())
 
+    def replicate(self, copies):
+        """sub-wave packing: `copies` instances of the moving bodies in one model (mjh_model_replicate)"""
+        return Model(self.lib.mjh_model_replicate(self.ptr, int(copies)), self.lib)
+
     def s24_randomize(self, env0, nenv, seed_base=0x5EED0000):
         """Per-env S24 tables: dict of float64 arrays."""
         c = self.c

@@ -134,3 +134,21 @@ def test_s24_working_set_fits_nine_envs_per_cu(lib):
     assert m.maxcon == 40
     nbytes = lib.mjh_query_lds_bytes(m.ptr)
     assert 0 < nbytes <= 14 * 1280, nbytes
+
+
+def test_model_replicate_keeps_instances_apart(lib):
+    """mjh_model_replicate (sub-wave packing): moving trees are copied, static geometry is shared, no pair joins two instances"""
+    import mujoco_sim_amd as ms
+    m = ms.scene("s24")
+    r = m.replicate(3)
+    nstatic = int((m.array("body_weldid")[m.array("geom_bodyid")] == 0).sum())
+    assert r.nv == 3 * m.nv and r.nq == 3 * m.nq and r.c.nbody == 1 + 3 * (m.c.nbody - 1) and r.c.ngeom == nstatic + 3 * (m.c.ngeom - nstatic)
+    assert r.npair == 3 * m.npair and r.c.maxcon == 3 * m.c.maxcon
+    gb = r.array("geom_bodyid"); root = r.array("body_rootid")
+    inst = lambda b: 0 if b < m.c.nbody else 1 + (b - m.c.nbody) // (m.c.nbody - 1)
+    for g1, g2 in zip(r.array("pair_geom1"), r.array("pair_geom2")):
+        b1, b2 = gb[g1], gb[g2]
+        assert b1 == 0 or b2 == 0 or inst(b1) == inst(b2)
+    np.testing.assert_array_equal(r.array("qpos0").reshape(3, -1), np.tile(m.array("qpos0"), (3, 1)))
+    assert lib.mjh_id2name(r.ptr, 0, m.c.nbody).endswith(b"#1")
+    assert not lib.mjh_model_replicate(m.ptr, 0)

@@ -1208,3 +1208,35 @@ def test_plane_contacts_of_round_geoms_match_oracle(lib):
     _, qq, vv, _ = e2.get_state()
     assert abs(qq[0, 7*2+2] - 0.04) < 2e-3 and np.abs(vv[0, 12:18]).max() < 5e-2
     e.close(); e2.close()
+
+
+@pytest.mark.parametrize("scene,copies", [("arm7", 4), ("pendulum", 3)])
+def test_sub_wave_packing_matches_the_oracle_per_instance(scene, copies):
+    """mjh_model_replicate: `copies` environments per wavefront (instances of the moving trees in one model, sharing the
+    static geometry, never colliding with each other).  Every instance must follow ITS oracle."""
+    m = ms.scene(scene, 0) if scene == "arm7" else ms.scene(scene)
+    r = m.replicate(copies)
+    assert r.nv == copies * m.nv and r.ntree == copies * m.ntree and r.npair == copies * m.npair
+    nw = 3                                    # wavefronts
+    rng = np.random.default_rng(5)
+    q0 = np.tile(m.array("qpos0"), (nw * copies, 1)); v0 = rng.normal(size=(nw * copies, m.nv)) * 0.4
+    if scene == "arm7":
+        q0 += rng.uniform(-0.2, 0.2, size=q0.shape)
+    e = ms.Engine(r, nw)
+    e.set_initial_qpos(q0.reshape(nw, -1)); e.reset(); e.set_state(qvel=v0.reshape(nw, -1))
+    ds = []
+    for i in range(nw * copies):
+        d = orc.OrcData(m.ptr); d.set_qpos(q0[i]); d.call("reset"); d.f("qvel")[:] = v0[i]; ds.append(d)
+    for n in (1, 100, 400):
+        done = int(round(ds[0].f("time")[0] / m.opt.timestep))
+        e.step(n - done, True); [d.step(n - done, 1) for d in ds]
+        _, q, v, _ = e.get_state()
+        q = q.reshape(nw * copies, m.nq); v = v.reshape(nw * copies, m.nv)
+        tol = {1: 1e-5, 100: 2e-3, 400: 2e-2}[n]     # (the arm sags into its limits: when a limit row switches on is a rounding matter)
+        np.testing.assert_allclose(q, [d.f("qpos") for d in ds], atol=tol, err_msg=f"step {n}")
+        np.testing.assert_allclose(v, [d.f("qvel") for d in ds], atol=10 * tol, err_msg=f"step {n}")
+    fi = e.get_field("qfrc_inverse").reshape(nw * copies, m.nv)
+    ref = np.array([d.f("qfrc_inverse") for d in ds])
+    np.testing.assert_allclose(fi, ref, atol=2e-2 * max(1.0, np.abs(ref).max()))
+    assert (e.get_stats()[:, 3] == 0).all()
+    e.close()
