@@ -288,7 +288,9 @@ int mjh_set_initial_qpos(mjh_engine*, int env0, int n, const double* qpos);
 int mjh_reset(mjh_engine*, const int* env_ids, int n);
 
 /* spawn / destroy as per-env slot toggling (reference: spawn_objects / destroy_objects services,
- * mj_ros.cpp:859-1507, which re-compile the whole model): an inactive slot does not collide and is frozen */
+ * mj_ros.cpp:859-1507, which re-compile the whole model): an inactive slot does not collide and is frozen.
+ * Toggleable are the last 32 bodies of the model (all of them, except the world, in a model of up to 32 bodies):
+ * declare the object pool after the robot. */
 int mjh_set_slot_active(mjh_engine*, int env0, int n, int body, int active);
 /* initial pose / twist of a spawned free body (mj_ros.cpp:1406-1412) */
 int mjh_set_body_pose(mjh_engine*, int env, int body, const double pos[3], const double quat[4], const double vel[6]);

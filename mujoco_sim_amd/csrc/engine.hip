@@ -768,12 +768,17 @@ extern "C" int mjh_reset(mjh_engine* e, const int* env_ids, int n) {
 // mj_ros.cpp:906-1507 -> full XML round trip + recompile): a pre-allocated free body is toggled per env.
 extern "C" int mjh_set_slot_active(mjh_engine* e, int env0, int n, int body, int active) {
   ENG(e); RANGE(e, env0, n);
-  if (body <= 0 || body >= e->M.nbody || body >= 32) { mjh_set_error("mjh_set_slot_active: body must be in [1, 32)"); return MJH_ERR_ARG; }
+  const int sbase = e->M.nbody > 32 ? e->M.nbody - 32 : 0;     // the last 32 bodies of a big model are the toggleable slots
+  if (body <= 0 || body >= e->M.nbody || body < sbase) {
+    mjh_set_error("mjh_set_slot_active: body must be one of the last 32 bodies, [" + std::to_string(std::max(1, sbase)) + ", " + std::to_string(e->M.nbody) + ")");
+    return MJH_ERR_ARG;
+  }
+  const int bit = body - sbase;
   if (!e->S.slot_mask) { int rc = dev_alloc(e, &e->S.slot_mask, (size_t)e->nenv); if (rc) return rc; }
   std::vector<unsigned> h(n);
   HIPCHK(hipMemcpyAsync(h.data(), e->S.slot_mask + env0, n * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
-  for (int i = 0; i < n; i++) h[i] = active ? (h[i] & ~(1u << body)) : (h[i] | (1u << body));
+  for (int i = 0; i < n; i++) h[i] = active ? (h[i] & ~(1u << bit)) : (h[i] | (1u << bit));
   HIPCHK(hipMemcpyAsync(e->S.slot_mask + env0, h.data(), n * sizeof(unsigned), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   return MJH_OK;

@@ -908,6 +908,7 @@ extern "C" int mjh_name2id(const mjh_model* m, int objtype, const char* name) {
   if (!m || !name) return -1;
   char** t = objtype == 0 ? m->body_names : objtype == 1 ? m->jnt_names : m->geom_names;
   int n = objtype == 0 ? m->nbody : objtype == 1 ? m->njnt : m->ngeom;
+  if (!t) return -1;                                   // a model assembled without name tables
   for (int i = 0; i < n; i++) if (t[i] && std::strcmp(t[i], name) == 0) return i;
   return -1;
 }
@@ -915,6 +916,6 @@ extern "C" const char* mjh_id2name(const mjh_model* m, int objtype, int id) {
   if (!m) return nullptr;
   char** t = objtype == 0 ? m->body_names : objtype == 1 ? m->jnt_names : m->geom_names;
   int n = objtype == 0 ? m->nbody : objtype == 1 ? m->njnt : m->ngeom;
-  if (id < 0 || id >= n) return nullptr;
+  if (!t || id < 0 || id >= n) return nullptr;
   return t[id];
 }

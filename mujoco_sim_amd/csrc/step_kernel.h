@@ -573,6 +573,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   float time = S.time[env];
   // spawn/destroy as slot toggling: bit b set = body b is an INACTIVE slot in this env
   const unsigned slotmask = S.slot_mask ? (unsigned)__builtin_amdgcn_readfirstlane((int)S.slot_mask[env]) : 0u;
+  const int sbase = nbody > 32 ? nbody - 32 : 0;   // mask bit i = body sbase + i: the LAST 32 bodies of a big model are the toggleable slots
   int flags = 0, ncon = 0, nefc = 0, niter = 0;
   PROF(0);
   if ((xflags & XF_PROF) && lane == 0) {   // 100 MHz wall clock (comparable across CUs) and where this env ran: HW_ID | XCC_ID << 32
@@ -812,7 +813,8 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           for (int k = 0; k < 9; k++) { m1[k] = s_gmat[9*g1+k]; m2[k] = s_gmat[9*g2+k]; }
           bool cull;
           const int sb1 = geom_bodyid[g1], sb2 = geom_bodyid[g2];
-          const bool parked = ((sb1 < 32 && ((slotmask >> sb1) & 1u)) || (sb2 < 32 && ((slotmask >> sb2) & 1u)));
+          const unsigned r1 = (unsigned)(sb1 - sbase), r2 = (unsigned)(sb2 - sbase);
+          const bool parked = ((r1 < 32u && ((slotmask >> r1) & 1u)) || (r2 < 32u && ((slotmask >> r2) & 1u)));
           float tt[3] = {p2[0]-p1[0], p2[1]-p1[1], p2[2]-p1[2]};
           if (t1 == MJH_GEOM_PLANE) { float nn[3] = {m1[2], m1[5], m1[8]}; cull = dot3(tt, nn) > s_p_rbound[g2] + margin; }
           else { float bound = s_p_rbound[g1] + s_p_rbound[g2] + margin; cull = dot3(tt, tt) > bound * bound; }
@@ -869,7 +871,8 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         const int g1 = pair_geom1[ip], g2 = pair_geom2[ip];
         const float margin = fmaxf(geom_margin[g1], geom_margin[g2]);
         const int sb1 = geom_bodyid[g1], sb2 = geom_bodyid[g2];
-        if ((sb1 < 32 && ((slotmask >> sb1) & 1u)) || (sb2 < 32 && ((slotmask >> sb2) & 1u))) return false;
+        const unsigned r1 = (unsigned)(sb1 - sbase), r2 = (unsigned)(sb2 - sbase);
+        if ((r1 < 32u && ((slotmask >> r1) & 1u)) || (r2 < 32u && ((slotmask >> r2) & 1u))) return false;
         const float tt[3] = {s_gpos[3*g2] - s_gpos[3*g1], s_gpos[3*g2+1] - s_gpos[3*g1+1], s_gpos[3*g2+2] - s_gpos[3*g1+2]};
         if (geom_type[g1] == MJH_GEOM_PLANE) { const float nn[3] = {s_gmat[9*g1+2], s_gmat[9*g1+5], s_gmat[9*g1+8]}; return !(dot3(tt, nn) > s_p_rbound[g2] + margin); }
         const float bound = s_p_rbound[g1] + s_p_rbound[g2] + margin;
@@ -1909,7 +1912,8 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         }
         for (int d = lane; d < nv; d += 64) {
           const int bd = dof_bodyid[d];
-          const bool parked = bd < 32 && ((slotmask >> bd) & 1u);      // inactive slot: frozen in place
+          const unsigned rb = (unsigned)(bd - sbase);
+          const bool parked = rb < 32u && ((slotmask >> rb) & 1u);      // inactive slot: frozen in place
           s_qvel[d] = parked ? 0.0f : s_qvel[d] + h * qint[d];
           if (parked) { s_qacc[d] = 0; s_ws[d] = 0; }
         }

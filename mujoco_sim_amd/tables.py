@@ -19,6 +19,8 @@ def save_model_tables(m, path, **extra):
     d["opt__gravity"] = np.array(list(m.c.opt.gravity), dtype=np.float64)
     for n, t, _ in capi._ARRAYS:
         d["arr__" + n] = m.array(n)
+    for kind, objtype, n in (("body", 0, m.c.nbody), ("jnt", 1, m.c.njnt), ("geom", 2, m.c.ngeom)):
+        d["names__" + kind] = np.array([(m.lib.mjh_id2name(m.ptr, objtype, i) or b"").decode() for i in range(n)], dtype=str)
     d.update(extra)
     np.savez_compressed(path, **d)
 
@@ -44,6 +46,12 @@ def load_model_tables(path):
             a = np.zeros(1, dtype=a.dtype)
         keep.append(a)
         setattr(st, n, a.ctypes.data_as(capi.c_int_p if t == "i" else capi.c_double_p))
+    for kind in ("body", "jnt", "geom"):          # name tables (mjh_name2id / mjh_id2name), if the file has them
+        if "names__" + kind in z:
+            bufs = [C.create_string_buffer(str(x).encode()) for x in z["names__" + kind]]
+            arr = (C.c_char_p * max(1, len(bufs)))(*[C.cast(b, C.c_char_p) for b in bufs])
+            keep.append((bufs, arr))
+            setattr(st, kind + "_names", C.cast(arr, C.POINTER(C.c_char_p)))
     m = Model(C.pointer(st))
     m._keep = (st, keep)
     m.note = "rebuilt from compiled tables"

@@ -939,7 +939,8 @@ void orc_collision(orc_data* d) {
     }
     if (!n) continue;
     { int sb1 = m->geom_bodyid[g1], sb2 = m->geom_bodyid[g2];   /* inactive spawn/destroy slots do not collide */
-      if ((sb1 < 32 && ((d->slot_mask >> sb1) & 1u)) || (sb2 < 32 && ((d->slot_mask >> sb2) & 1u))) continue; }
+      unsigned sbase = m->nbody > 32 ? (unsigned)(m->nbody - 32) : 0u, r1 = (unsigned)sb1 - sbase, r2 = (unsigned)sb2 - sbase;   /* bit i = body sbase + i */
+      if ((r1 < 32u && ((d->slot_mask >> r1) & 1u)) || (r2 < 32u && ((d->slot_mask >> r2) & 1u))) continue; }
     /* contact parameters [UPSTREAM mj_contactParam]: max condim, max friction, solmix-weighted solref/solimp */
     int dim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
     double fr[3], mix;
@@ -1491,7 +1492,8 @@ void orc_euler(orc_data* d) {
   double h = m->opt.timestep;
   for (int i = 0; i < nv; i++) {
     int bd = m->dof_bodyid[i];
-    if (bd < 32 && ((d->slot_mask >> bd) & 1u)) { d->qvel[i] = 0; d->qacc[i] = 0; d->qacc_warmstart[i] = 0; }  /* parked slot */
+    unsigned rb = (unsigned)bd - (m->nbody > 32 ? (unsigned)(m->nbody - 32) : 0u);
+    if (rb < 32u && ((d->slot_mask >> rb) & 1u)) { d->qvel[i] = 0; d->qacc[i] = 0; d->qacc_warmstart[i] = 0; }  /* parked slot */
     else d->qvel[i] += h * qacc[i];
   }
   for (int j = 0; j < m->njnt; j++) {

@@ -33,7 +33,16 @@ ROBOTS = {"pr2": ("pr2/pr2.xml", 16), "tiago": ("tiago/tiago.xml", 40), "hsrb4s"
           "pr2_mesh": ("pr2/pr2.xml", 16), "pr2_world_mesh": ("../world/empty.xml+pr2/pr2.xml", 48),
           # C5, literally: launch/multi_mujoco_sim.launch:3-4 = world pendulum.xml (three bodies on ball joints, damping 0.5,
           # gravity -0.1) + "robot" bowl.xml (37 static mesh geoms); started with a spin so that the bodies meet
-          "c5_pendulum_bowl_mesh": ("pendulum.xml+bowl.xml", 16)}
+          "c5_pendulum_bowl_mesh": ("pendulum.xml+bowl.xml", 16),
+          "c4_pr2_world_objects_mesh": ("../world/empty.xml+pr2/pr2.xml+@objects", 72)}
+# C4 as SURVEY.md §8-d D3 states it: PR2 on the world floor + a pool of spawnable objects of the types the reference's spawn
+# test draws (test/test_spawn_and_destroy.py:13-14,32-41: cubes / spheres / cylinders of size 0.05 * [2, 5]); the pool is
+# this repo's own MJCF text, parked beside the robot (slots are toggled at run time: tools/c4_bench.py)
+OBJECT_POOL = """<mujoco><worldbody>
+""" + "".join(
+    f'<body name="object_{k}" pos="{4 + 0.6 * k} 4 0.3"><freejoint/><geom type="{t}" size="{sz}"/></body>\n'
+    for k, (t, sz) in enumerate([("box", "0.10 0.10 0.10"), ("sphere", "0.15"), ("cylinder", "0.12 0.12"), ("box", "0.20 0.20 0.20"),
+                                 ("sphere", "0.25"), ("cylinder", "0.20 0.20"), ("box", "0.15 0.15 0.15"), ("sphere", "0.10")])) + """</worldbody></mujoco>"""
 QVEL0 = {"c5_pendulum_bowl_mesh": [0.0, 0.1, 2.0, 0.1, 0.0, -2.0, 0.2, -0.1, 0.3]}   # sphere and cube circle towards each other
 STEPS = 300
 KEEP = (1, 10, 50, 100, 200, 300)
@@ -58,7 +67,15 @@ def main():
     for name, (rel, cap) in ROBOTS.items():
         mesh = name.endswith("_mesh")
         ms.capi.load().mjh_load_set_mesh_mode(1 if mesh else 0)
-        m = ms.load_mjcf(paths=[os.path.join(REF, r) for r in rel.split("+")])
+        paths = []
+        for r in rel.split("+"):
+            if r == "@objects":
+                import tempfile
+                tf = tempfile.NamedTemporaryFile("w", suffix=".xml", delete=False); tf.write(OBJECT_POOL); tf.close()
+                paths.append(tf.name)
+            else:
+                paths.append(os.path.join(REF, r))
+        m = ms.load_mjcf(paths=paths)
         ms.capi.load().mjh_load_set_mesh_mode(1)
         assert (m.c.nmesh > 0) == mesh
         steps, keep = (MESH_STEPS, MESH_KEEP) if mesh else (STEPS, KEEP)

@@ -541,7 +541,7 @@ def layout_policy(lib):
 @pytest.mark.gpu
 @pytest.mark.parametrize("layout", [1, 2], ids=["lds-resident", "global-pools"])
 @pytest.mark.parametrize("name", ["pr2", "tiago", "hsrb4s", "ridgeback_panda", "pr2_world", "hsrb4s_world", "pr2_mesh", "pr2_world_mesh",
-                                  "c5_pendulum_bowl_mesh"])
+                                  "c5_pendulum_bowl_mesh", "c4_pr2_world_objects_mesh"])
 def test_reference_robot_models_match_oracle(name, layout, layout_policy):
     """C4-type articulated models (the reference's pr2 / tiago / hsrb4s test assets, compiled to table fixtures by
     tests/golden/make_robot_fixtures.py; meshes skipped): 32-49 dof single trees with equality constraints, joint

@@ -11,14 +11,17 @@ import orc
 from conftest import ROOT
 from helpers import load_model_tables
 
-ROBOTS = ["pr2", "tiago", "hsrb4s", "ridgeback_panda", "pr2_world", "hsrb4s_world", "pr2_mesh", "pr2_world_mesh", "c5_pendulum_bowl_mesh"]
+ROBOTS = ["pr2", "tiago", "hsrb4s", "ridgeback_panda", "pr2_world", "hsrb4s_world", "pr2_mesh", "pr2_world_mesh", "c5_pendulum_bowl_mesh",
+          "c4_pr2_world_objects_mesh"]
 FILES = {"pr2": "pr2/pr2.xml", "tiago": "tiago/tiago.xml", "hsrb4s": "hsrb4s/hsrb4s.xml",
          "ridgeback_panda": "ridgeback_panda/ridgeback_panda.xml",
          "pr2_world": "../world/empty.xml+pr2/pr2.xml", "hsrb4s_world": "../world/empty.xml+hsrb4s/hsrb4s.xml",
          # PR2 with its 18 STL meshes (37 mesh geoms colliding as convex hulls); the others are compiled with the meshes off
          "pr2_mesh": "pr2/pr2.xml", "pr2_world_mesh": "../world/empty.xml+pr2/pr2.xml",
          # C5 as launched (launch/multi_mujoco_sim.launch:3-4): world = pendulum.xml, "robot" = bowl.xml (37 static mesh geoms)
-         "c5_pendulum_bowl_mesh": "pendulum.xml+bowl.xml"}
+         "c5_pendulum_bowl_mesh": "pendulum.xml+bowl.xml",
+         # C4: PR2 on the world floor + 8 spawnable objects (cubes / spheres / cylinders; the pool text lives in the generator)
+         "c4_pr2_world_objects_mesh": None}
 REF = "/root/reference/model/test"
 
 
@@ -34,7 +37,9 @@ def robot_command(m, k):
 @pytest.mark.parametrize("name", ROBOTS)
 def test_oracle_reproduces_robot_golden(lib, name):
     m, z = load_model_tables(os.path.join(ROOT, "tests", "golden", f"robot_{name}.npz"))
-    if name.startswith("c5"):
+    if name.startswith("c4"):
+        assert m.ntree == 9 and m.nv == 49 + 8 * 6 and m.c.nmesh == 18
+    elif name.startswith("c5"):
         assert m.ntree == 3 and m.nv == 9 and m.c.nmesh == 2 and (m.array("geom_type") == 7).sum() == 37
     else:
         assert m.ntree == 1 and m.nv >= 20
@@ -61,6 +66,8 @@ def test_oracle_reproduces_robot_golden(lib, name):
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
 @pytest.mark.parametrize("name", ROBOTS)
 def test_loader_still_produces_the_fixture_tables(lib, name):
+    if FILES[name] is None:
+        pytest.skip("composed with generator-side text")
     import mujoco_sim_amd as ms
     from mujoco_sim_amd import capi
     lib.mjh_load_set_bounds(1e-6, 1e-6)      # as the reference does before mj_loadXML (mj_sim.cpp:584-590)
