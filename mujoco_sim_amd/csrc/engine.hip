@@ -408,7 +408,10 @@ extern "C" void mjh_destroy(mjh_engine* e) {
   delete e;
 }
 
-#define ENG_NOJOIN(e) if (!(e)) { mjh_set_error("null engine"); return MJH_ERR_ARG; }
+// (every entry point re-selects the engine's device: one process may hold engines on several GPUs, and the caller's
+// current device is whatever its framework left it at)
+#define ENG_NOJOIN(e) if (!(e)) { mjh_set_error("null engine"); return MJH_ERR_ARG; } \
+                      if (hipSetDevice((e)->device) != hipSuccess) { mjh_set_error("hipSetDevice failed"); return MJH_ERR_NO_DEVICE; }
 // every entry point except mjh_step first joins the cohort streams back into the caller's stream
 #define ENG(e) ENG_NOJOIN(e) { int rcj_ = join_cohorts(e); if (rcj_) return rcj_; }
 #define RANGE(e, env0, n) if ((env0) < 0 || (n) < 0 || (env0) + (n) > (e)->nenv) { mjh_set_error("env range out of bounds"); return MJH_ERR_ARG; }
