@@ -164,7 +164,7 @@ int mjh_builder_add_geom(mjh_builder*, const char* name, int body, int type, con
  * bounding box otherwise).  Collides as its convex hull, like MuJoCo: the builder keeps the vertices that are
  * extreme along a dense set of directions.  scale may be NULL.  Returns the mesh id (>= 0) or a negative code. */
 int mjh_builder_add_mesh(mjh_builder*, const double* vert, int nvert, const int* face, int nface, const double scale[3]);
-int mjh_builder_add_mesh_stl(mjh_builder*, const char* path, const double scale[3]);   /* binary STL */
+int mjh_builder_add_mesh_stl(mjh_builder*, const char* path, const double scale[3]);   /* binary or ASCII STL, Wavefront OBJ (by extension) */
 /* mesh geom: pos/quat place the MESH FILE's frame in the body, as <geom type="mesh" pos quat> does */
 int mjh_builder_add_mesh_geom(mjh_builder*, const char* name, int body, int mesh, const double pos[3], const double quat[4],
                               const double friction[3], int condim, int contype, int conaffinity, double density);

@@ -218,11 +218,68 @@ extern "C" int mjh_builder_add_mesh(mjh_builder* b, const double* vert, int nver
   if (!b || !vert || nvert < 4 || (nface > 0 && !face)) { g_err = "add_mesh: bad arguments"; return MJH_ERR_ARG; }
   return add_mesh_impl(b, std::vector<double>(vert, vert + 3 * (size_t)nvert), face, nface, scale);
 }
-// binary STL: 80-byte header, uint32 triangle count, 50 bytes per triangle (normal, 3 vertices, attribute)
+// text formats: ASCII STL ("vertex x y z", three per facet) and Wavefront OBJ ("v x y z", "f a b c ..." with a/b/c and
+// negative indices; polygons are fanned into triangles)
+static int add_mesh_text(mjh_builder* b, const std::string& text, bool obj, const char* path, const double scale[3]) {
+  std::vector<double> v; std::vector<int> face;
+  size_t pos = 0;
+  while (pos < text.size()) {
+    size_t eol = text.find('\n', pos); if (eol == std::string::npos) eol = text.size();
+    std::string line = text.substr(pos, eol - pos); pos = eol + 1;
+    size_t s0 = line.find_first_not_of(" \t\r");
+    if (s0 == std::string::npos) continue;
+    if (!obj) {
+      if (line.compare(s0, 6, "vertex") == 0) {
+        double x, y, z;
+        if (std::sscanf(line.c_str() + s0 + 6, "%lf %lf %lf", &x, &y, &z) == 3) { v.push_back(x); v.push_back(y); v.push_back(z); }
+      }
+    } else if (line.compare(s0, 2, "v ") == 0) {
+      double x, y, z;
+      if (std::sscanf(line.c_str() + s0 + 2, "%lf %lf %lf", &x, &y, &z) == 3) { v.push_back(x); v.push_back(y); v.push_back(z); }
+    } else if (line.compare(s0, 2, "f ") == 0) {
+      std::vector<int> idx; const char* p = line.c_str() + s0 + 2;
+      while (*p) {
+        while (*p == ' ' || *p == '\t' || *p == '\r') p++;
+        if (!*p) break;
+        char* end; long k = std::strtol(p, &end, 10);
+        if (end == p) break;
+        const int nvert = (int)v.size() / 3;
+        idx.push_back(k > 0 ? (int)k - 1 : nvert + (int)k);
+        p = end; while (*p && *p != ' ' && *p != '\t') p++;      // skip /vt/vn
+      }
+      for (size_t k = 2; k < idx.size(); k++) { face.push_back(idx[0]); face.push_back(idx[k-1]); face.push_back(idx[k]); }
+    }
+  }
+  if (!obj) for (int t = 0; t + 2 < (int)v.size() / 3; t += 3) { face.push_back(t); face.push_back(t + 1); face.push_back(t + 2); }
+  if (v.size() < 12) { g_err = std::string("add_mesh: no vertices found in ") + path; return MJH_ERR_ARG; }
+  const int nvert = (int)v.size() / 3;
+  for (int i : face) if (i < 0 || i >= nvert) { g_err = std::string("add_mesh: face index out of range in ") + path; return MJH_ERR_ARG; }
+  return add_mesh_impl(b, std::move(v), face.data(), (int)face.size() / 3, scale);
+}
+// mesh file: binary STL (80-byte header, uint32 triangle count, 50 bytes per triangle: normal, 3 vertices, attribute),
+// ASCII STL, or Wavefront OBJ (by extension)
 extern "C" int mjh_builder_add_mesh_stl(mjh_builder* b, const char* path, const double scale[3]) {
   if (!b || !path) { g_err = "add_mesh_stl: bad arguments"; return MJH_ERR_ARG; }
   FILE* f = std::fopen(path, "rb");
   if (!f) { g_err = std::string("add_mesh_stl: cannot open ") + path; return MJH_ERR_ARG; }
+  {
+    const std::string ps = path;
+    const bool obj = ps.size() > 4 && (ps.compare(ps.size() - 4, 4, ".obj") == 0 || ps.compare(ps.size() - 4, 4, ".OBJ") == 0);
+    char head5[6] = {0}; const size_t got5 = std::fread(head5, 1, 5, f);
+    bool ascii = false;
+    if (!obj && got5 == 5 && std::strncmp(head5, "solid", 5) == 0) {      // "solid" + a facet keyword further on = ASCII STL
+      std::vector<char> probe(1024); const size_t n = std::fread(probe.data(), 1, probe.size(), f);
+      ascii = std::string(probe.data(), n).find("facet") != std::string::npos;
+    }
+    if (obj || ascii) {
+      std::fseek(f, 0, SEEK_END); const long sz = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+      std::string text((size_t)std::max(0L, sz), '\0');
+      const size_t got = std::fread(&text[0], 1, text.size(), f); std::fclose(f);
+      text.resize(got);
+      return add_mesh_text(b, text, obj, path, scale);
+    }
+    std::fseek(f, 0, SEEK_SET);
+  }
   unsigned char head[84];
   unsigned ntri = 0;
   if (std::fread(head, 1, 84, f) != 84) { std::fclose(f); g_err = std::string("add_mesh_stl: short file ") + path; return MJH_ERR_ARG; }

@@ -395,3 +395,25 @@ def test_binary_stl_through_the_mjcf_loader(tmp_path, lib):
     # the same text without a directory: the mesh cannot be found, the geom is reported and skipped
     m2 = ms.load_mjcf(xml.replace("<freejoint/>", '<freejoint/><geom type="sphere" size="0.01"/>'))
     assert m2.c.nmesh == 0 and m2.c.ngeom == 2 and b"not loaded" in lib.mjh_load_note()
+
+
+def test_ascii_stl_and_obj_meshes(tmp_path, lib):
+    """text mesh formats next to the binary STL of the reference's assets: ASCII STL and Wavefront OBJ (quads, a/b/c indices)"""
+    tris = (CUBE_V * np.array([0.1, 0.05, 0.05]))[CUBE_F]
+    with open(tmp_path / "a.stl", "w") as f:
+        f.write("solid cube\n")
+        for t in tris:
+            f.write(" facet normal 0 0 0\n  outer loop\n" + "".join("   vertex %.17g %.17g %.17g\n" % tuple(p) for p in t) + "  endloop\n endfacet\n")
+        f.write("endsolid cube\n")
+    V = CUBE_V * np.array([0.1, 0.05, 0.05])
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    with open(tmp_path / "o.obj", "w") as f:
+        f.write("# cube\n" + "".join("v %.17g %.17g %.17g\n" % tuple(p) for p in V) + "vn 0 0 1\n" + "".join("f " + " ".join(f"{i+1}//1" for i in q) + "\n" for q in quads))
+    for fn in ("a.stl", "o.obj"):
+        xml = f"""<mujoco><asset><mesh name="m" file="{fn}"/></asset><worldbody><geom type="plane" size="0 0 0.05"/>
+          <body pos="0 0 0.2"><freejoint/><geom type="mesh" mesh="m"/></body></worldbody></mujoco>"""
+        (tmp_path / "m.xml").write_text(xml)
+        m = ms.load_mjcf(path=str(tmp_path / "m.xml"))
+        assert m.c.nmesh == 1 and m.c.nmeshvert == 8, (fn, lib.mjh_load_note())
+        np.testing.assert_allclose(m.array("body_mass")[1], 1000 * 0.2 * 0.1 * 0.1, rtol=1e-9)
+        np.testing.assert_allclose(sorted(np.abs(m.array("mesh_vert").reshape(-1, 3)).max(axis=0)), [0.05, 0.05, 0.1], rtol=1e-9)
