@@ -5,7 +5,7 @@
 // <freejoint>, <geom> (plane, sphere, capsule, cylinder, box; mesh geoms are skipped with a note), gravcomp,
 // <contact><exclude>, <equality><joint polycoef>.  Everything is translated into mjh_builder_* calls; physics
 // defaults follow MuJoCo's documented defaults (angle = degree, hinge axis 0 0 1, geom type sphere, ...).
-// Not handled (reported in the returned note): <include>, default classes, tendons, actuators, sensors, mocap, fromto.
+// Not handled (reported in the returned note): <include>, default classes, tendons, actuators, sensors.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -132,9 +132,25 @@ struct Loader {
       else if (t == "mesh") gt = MJH_GEOM_MESH;
       else { note += "skipped <geom type=\"" + t + "\">; "; return; }
     } else if (n.get("mesh")) gt = MJH_GEOM_MESH;
-    if (n.get("fromto")) { note += "skipped <geom fromto>; "; return; }
     double size[3] = {0, 0, 0}, pos[3] = {0, 0, 0}, quat[4] = {1, 0, 0, 0}, fr[3];
     nums(n.get("size"), size, 3); nums(n.get("pos"), pos, 3); orientation(n, quat);
+    double ft[6];
+    if (nums(n.get("fromto"), ft, 6) == 6) {
+      // fromto: the geom's z axis runs from the first point to the second; size = radius (capsule, cylinder) or the two
+      // lateral half-sizes (box, ellipsoid), the half-length comes from the distance
+      if (gt != MJH_GEOM_CAPSULE && gt != MJH_GEOM_CYLINDER && gt != MJH_GEOM_BOX && gt != MJH_GEOM_ELLIPSOID) { note += "skipped <geom fromto> of this type; "; return; }
+      double d[3] = {ft[3] - ft[0], ft[4] - ft[1], ft[5] - ft[2]};
+      const double len = hm::norm3(d);
+      for (int k = 0; k < 3; k++) pos[k] = 0.5 * (ft[k] + ft[3 + k]);
+      if (len > 1e-12) {
+        for (int k = 0; k < 3; k++) d[k] /= len;
+        const double zax[3] = {0, 0, 1}; double ax[3]; hm::cross(ax, zax, d);
+        const double sn = hm::norm3(ax), cs = d[2];
+        if (sn < 1e-12) { quat[0] = cs > 0 ? 1 : 0; quat[1] = cs > 0 ? 0 : 1; quat[2] = quat[3] = 0; }
+        else { for (int k = 0; k < 3; k++) ax[k] /= sn; hm::axisangle2quat(quat, ax, std::atan2(sn, cs)); }
+      }
+      if (gt == MJH_GEOM_CAPSULE || gt == MJH_GEOM_CYLINDER) size[1] = 0.5 * len; else { size[1] = size[1] > 0 ? size[1] : size[0]; size[2] = 0.5 * len; }
+    }
     std::memcpy(fr, def.geom_friction, sizeof fr);
     double t3[3]; int nf = nums(n.get("friction"), t3, 3); for (int i = 0; i < nf; i++) fr[i] = t3[i];
     double v; int condim = def.geom_condim, contype = def.geom_contype, conaff = def.geom_conaffinity; double density = def.geom_density;

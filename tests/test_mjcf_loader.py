@@ -157,3 +157,19 @@ def test_world_plus_robot_composition_and_bounds(lib, tmp_path):
     d = orc.OrcData(m.ptr)
     d.step(600)
     assert d.i("ncon") >= 4 and np.abs(d.f("qvel")).max() < 0.05 and abs(d.f("qpos")[2] - 0.06) < 5e-3
+
+
+def test_geom_fromto():
+    """<geom fromto>: position = midpoint, z axis along the segment, half-length from the distance"""
+    import mujoco_sim_amd as ms
+    m = ms.load_mjcf("""<mujoco><worldbody><body pos="0 0 1"><freejoint/>
+        <geom type="capsule" size="0.05" fromto="0 0 0 0.3 0 0.4"/>
+        <geom type="cylinder" size="0.02" fromto="0 0 0 0 0 -0.2"/></body></worldbody></mujoco>""")
+    assert m.c.ngeom == 2 and ms.capi.load().mjh_load_note() == b""
+    np.testing.assert_allclose(m.array("geom_size").reshape(-1, 3), [[0.05, 0.25, 0], [0.02, 0.1, 0]], atol=1e-12)
+    np.testing.assert_allclose(m.array("geom_pos").reshape(-1, 3), [[0.15, 0, 0.2], [0, 0, -0.1]], atol=1e-12)
+    q = m.array("geom_quat").reshape(-1, 4)
+    w, x, y, z = q[0]
+    zax = np.array([2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)])
+    np.testing.assert_allclose(zax, [0.6, 0, 0.8], atol=1e-12)
+    np.testing.assert_allclose(np.abs(q[1]), [0, 1, 0, 0], atol=1e-12)          # pointing down: half a turn about x
