@@ -12,7 +12,7 @@ from conftest import ROOT
 from helpers import load_model_tables
 
 ROBOTS = ["pr2", "tiago", "hsrb4s", "ridgeback_panda", "pr2_world", "hsrb4s_world", "pr2_mesh", "pr2_world_mesh", "c5_pendulum_bowl_mesh",
-          "c4_pr2_world_objects_mesh"]
+          "c4_pr2_world_objects_mesh", "tiago_mesh", "hsrb4s_mesh"]
 FILES = {"pr2": "pr2/pr2.xml", "tiago": "tiago/tiago.xml", "hsrb4s": "hsrb4s/hsrb4s.xml",
          "ridgeback_panda": "ridgeback_panda/ridgeback_panda.xml",
          "pr2_world": "../world/empty.xml+pr2/pr2.xml", "hsrb4s_world": "../world/empty.xml+hsrb4s/hsrb4s.xml",
@@ -21,7 +21,8 @@ FILES = {"pr2": "pr2/pr2.xml", "tiago": "tiago/tiago.xml", "hsrb4s": "hsrb4s/hsr
          # C5 as launched (launch/multi_mujoco_sim.launch:3-4): world = pendulum.xml, "robot" = bowl.xml (37 static mesh geoms)
          "c5_pendulum_bowl_mesh": "pendulum.xml+bowl.xml",
          # C4: PR2 on the world floor + 8 spawnable objects (cubes / spheres / cylinders; the pool text lives in the generator)
-         "c4_pr2_world_objects_mesh": None}
+         "c4_pr2_world_objects_mesh": None,
+         "tiago_mesh": "tiago/tiago.xml", "hsrb4s_mesh": "hsrb4s/hsrb4s.xml"}
 REF = "/root/reference/model/test"
 
 
