@@ -5,7 +5,7 @@
 // <freejoint>, <geom> (plane, sphere, capsule, cylinder, box; mesh geoms are skipped with a note), gravcomp,
 // <contact><exclude>, <equality><joint polycoef>.  Everything is translated into mjh_builder_* calls; physics
 // defaults follow MuJoCo's documented defaults (angle = degree, hinge axis 0 0 1, geom type sphere, ...).
-// Not handled (reported in the returned note): <include>, default classes, tendons, actuators, sensors.
+// Not handled (reported in the returned note): tendons, actuators, sensors, <weld> / <connect> equalities.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -108,6 +108,35 @@ struct Loader {
   double bmass = 0, binertia = 0;   // <compiler boundmass boundinertia>, raised to the process-wide floor of mjh_load_set_bounds
   Defaults def;
   std::map<std::string, int> body_id, joint_id, mesh_id;
+  // <default class="..."> tables: class -> element tag -> attributes (a nested class starts from its parent's); the
+  // unnamed top-level <default> is class "main".  An element takes the attributes it does not set itself from its class
+  // (its own class="" attribute, else the nearest enclosing body's childclass, else "main").
+  typedef std::vector<std::pair<std::string, std::string>> Attrs;
+  std::map<std::string, std::map<std::string, Attrs>> classes;
+  std::string childclass;
+  void read_defaults(const Node& d, const std::string& parent) {
+    const std::string cls = d.get("class") ? d.get("class") : (parent.empty() ? "main" : parent);
+    if (!parent.empty() && cls != parent) classes[cls] = classes[parent];
+    for (auto& k : d.kids) {
+      if (k->tag == "default") { read_defaults(*k, cls); continue; }
+      Attrs& dst = classes[cls][k->tag];
+      for (auto& a : k->attr) {
+        bool found = false;
+        for (auto& e : dst) if (e.first == a.first) { e.second = a.second; found = true; }
+        if (!found) dst.push_back(a);
+      }
+    }
+  }
+  Node with_defaults(const Node& n) const {
+    Node m; m.tag = n.tag; m.attr = n.attr;
+    const std::string cls = n.get("class") ? n.get("class") : (childclass.empty() ? "main" : childclass);
+    auto ci = classes.find(cls);
+    if (ci == classes.end()) return m;
+    auto ti = ci->second.find(n.tag);
+    if (ti == ci->second.end()) return m;
+    for (auto& a : ti->second) if (!n.get(a.first.c_str())) m.attr.push_back(a);
+    return m;
+  }
   std::string note, basedir, meshdir;   // directory of the file being read (empty for a string), <compiler meshdir>
   int nameless = 0;
 
@@ -122,7 +151,8 @@ struct Loader {
     }
     return false;
   }
-  void geom(const Node& n, int body) {
+  void geom(const Node& n0, int body) {
+    const Node n = with_defaults(n0);
     const char* type = n.get("type");
     int gt = MJH_GEOM_SPHERE;
     if (type) {
@@ -166,7 +196,8 @@ struct Loader {
     }
     mjh_builder_add_geom(b, n.get("name"), body, gt, size, pos, quat, fr, condim, contype, conaff, density);
   }
-  bool joint(const Node& n, int body, bool freejoint) {
+  bool joint(const Node& n0, int body, bool freejoint) {
+    const Node n = freejoint ? with_defaults(Node()) : with_defaults(n0);
     int type = MJH_JNT_HINGE;
     if (freejoint) type = MJH_JNT_FREE;
     else if (const char* t = n.get("type")) {
@@ -187,7 +218,7 @@ struct Loader {
     if (nums(n.get("armature"), &v, 1)) armature = v;
     if (nums(n.get("frictionloss"), &v, 1)) floss = v;
     if (nums(n.get("ref"), &v, 1)) ref = type == MJH_JNT_HINGE ? ang(v) : v;
-    std::string name = n.get("name") ? n.get("name") : ("joint" + std::to_string(nameless++));
+    std::string name = n0.get("name") ? n0.get("name") : ("joint" + std::to_string(nameless++));
     int id = mjh_builder_add_joint(b, name.c_str(), body, type, pos, axis, limited ? range : nullptr, damping, stiffness, armature, floss, ref);
     if (id < 0) return false;
     joint_id[name] = id;
@@ -200,7 +231,11 @@ struct Loader {
     int id = mjh_builder_add_body(b, name.c_str(), parent, pos, quat, gc);
     if (id < 0) return false;
     body_id[name] = id;
-    return children(n, id);
+    const std::string saved = childclass;
+    if (n.get("childclass")) childclass = n.get("childclass");
+    const bool ok = children(n, id);
+    childclass = saved;
+    return ok;
   }
   bool children(const Node& n, int body) {
     for (auto& c : n.kids) {
@@ -224,7 +259,7 @@ struct Loader {
   bool add(const Node& root, bool first, const std::string& dir = std::string()) {
     if (root.tag != "mujoco") { mjh_set_error("root element must be <mujoco>"); return false; }
     if (first) b = mjh_builder_create();
-    degree = true; autolimits = false; def = Defaults(); basedir = dir; meshdir.clear(); mesh_id.clear();
+    degree = true; autolimits = false; def = Defaults(); basedir = dir; meshdir.clear(); mesh_id.clear(); classes.clear(); childclass.clear();
     mjh_option o; mjh_builder_get_option(b, &o);
     // first pass: compiler / option / default (they may appear after worldbody in a file)
     for (auto& c : root.kids) {
@@ -252,6 +287,7 @@ struct Loader {
           if (const char* s = f->get("warmstart")) if (std::string(s) == "disable") o.disableflags |= MJH_DSBL_WARMSTART;
         }
       } else if (c->tag == "default") {
+        read_defaults(*c, "");
         for (auto& dflt : c->kids) {
           double v, t3[3];
           if (dflt->tag == "geom") {
@@ -265,7 +301,7 @@ struct Loader {
             if (nums(dflt->get("stiffness"), &v, 1)) def.jnt_stiffness = v;
             if (nums(dflt->get("armature"), &v, 1)) def.jnt_armature = v;
             if (nums(dflt->get("frictionloss"), &v, 1)) def.jnt_frictionloss = v;
-          } else if (dflt->tag == "default") note += "default classes ignored; ";
+          }
         }
       }
     }
@@ -338,6 +374,33 @@ extern "C" mjh_model* mjh_load_mjcf_string(const char* xml) {
   g_note = L.note;
   return m;
 }
+// <include file="..."/>: the children of the included file's <mujoco> root take the place of the element (any depth; paths
+// relative to the including file)
+static bool expand_includes(Node& n, const std::string& dir, int depth, std::string& err) {
+  if (depth > 16) { err = "<include> nesting too deep"; return false; }
+  for (size_t i = 0; i < n.kids.size();) {
+    Node& c = *n.kids[i];
+    if (c.tag != "include") { if (!expand_includes(c, dir, depth, err)) return false; i++; continue; }
+    const char* file = c.get("file");
+    if (!file) { err = "<include> without file"; return false; }
+    const std::string path = file[0] == '/' ? std::string(file) : dir + file;
+    std::ifstream f(path);
+    if (!f) { err = "cannot open included file " + path; return false; }
+    std::stringstream ss; ss << f.rdbuf();
+    const std::string text = ss.str();
+    Xml x{text.c_str(), text.c_str() + text.size(), {}};
+    auto root = x.element();
+    if (!root) { err = "parse error in included file " + path + ": " + x.err; return false; }
+    size_t sl = path.find_last_of('/');
+    if (!expand_includes(*root, sl == std::string::npos ? std::string("./") : path.substr(0, sl + 1), depth + 1, err)) return false;
+    std::vector<std::unique_ptr<Node>> repl;
+    for (auto& k : root->kids) repl.push_back(std::move(k));
+    n.kids.erase(n.kids.begin() + (long)i);
+    for (size_t k = 0; k < repl.size(); k++) n.kids.insert(n.kids.begin() + (long)(i + k), std::move(repl[k]));
+    i += repl.size();
+  }
+  return true;
+}
 static std::string dir_of(const char* path) {
   std::string p = path ? path : "";
   size_t sl = p.find_last_of('/');
@@ -356,6 +419,8 @@ extern "C" mjh_model* mjh_load_mjcf_files(const char* const* paths, int n) {
     Xml x{text.c_str(), text.c_str() + text.size(), {}};
     auto root = x.element();
     if (!root) { mjh_set_error(std::string("MJCF parse error in ") + paths[i] + ": " + (x.err.empty() ? std::string("no root element") : x.err)); L.abort(); return nullptr; }
+    { std::string ierr;
+      if (!expand_includes(*root, dir_of(paths[i]), 0, ierr)) { mjh_set_error(ierr); L.abort(); return nullptr; } }
     if (!L.add(*root, i == 0, dir_of(paths[i]))) { L.abort(); return nullptr; }
   }
   mjh_model* m = L.finish();

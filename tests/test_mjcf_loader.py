@@ -173,3 +173,31 @@ def test_geom_fromto():
     zax = np.array([2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)])
     np.testing.assert_allclose(zax, [0.6, 0, 0.8], atol=1e-12)
     np.testing.assert_allclose(np.abs(q[1]), [0, 1, 0, 0], atol=1e-12)          # pointing down: half a turn about x
+
+
+def test_default_classes_childclass_and_include(tmp_path):
+    """<default class> (nested, inherited), class= / childclass= on elements, and <include file> spliced in place"""
+    import mujoco_sim_amd as ms
+    (tmp_path / "parts").mkdir()
+    (tmp_path / "parts" / "arm.xml").write_text("""<mujoco><body name="link2" pos="0 0 0.3">
+        <joint name="j2" class="stiff"/><geom class="thin" fromto="0 0 0 0 0 0.3"/></body></mujoco>""")
+    (tmp_path / "defs.xml").write_text("""<mujoco><default>
+        <geom type="capsule" size="0.04" friction="0.7 0.005 0.0001"/><joint damping="0.2" axis="0 1 0"/>
+        <default class="thin"><geom size="0.01"/></default>
+        <default class="stiff"><joint stiffness="5" damping="1.5"/>
+          <default class="stiffer"><joint stiffness="50"/></default></default>
+      </default></mujoco>""")
+    (tmp_path / "m.xml").write_text("""<mujoco><compiler angle="radian"/><include file="defs.xml"/>
+      <worldbody><body name="link1" pos="0 0 1" childclass="stiffer">
+          <joint name="j1"/><geom fromto="0 0 0 0 0 0.3"/><geom class="main" type="sphere" size="0.06" pos="0 0 0.3"/>
+          <include file="parts/arm.xml"/>
+      </body></worldbody></mujoco>""")
+    m = ms.load_mjcf(path=str(tmp_path / "m.xml"))
+    assert ms.capi.load().mjh_load_note() == b"" and m.c.nbody == 3 and m.njnt == 2 and m.c.ngeom == 3
+    # j1: childclass "stiffer" = stiff (damping 1.5) + stiffness 50, axis from the top-level default; j2: explicit class "stiff"
+    np.testing.assert_allclose(m.array("jnt_stiffness"), [50, 5]); np.testing.assert_allclose(m.array("dof_damping"), [1.5, 1.5])
+    np.testing.assert_allclose(m.array("jnt_axis").reshape(-1, 3), [[0, 1, 0], [0, 1, 0]])
+    # geoms: capsule from "main" via the class chain (size 0.04), the sphere with its own size, the included one "thin"
+    np.testing.assert_array_equal(m.array("geom_type"), [3, 2, 3])
+    np.testing.assert_allclose(m.array("geom_size").reshape(-1, 3)[:, 0], [0.04, 0.06, 0.01])
+    np.testing.assert_allclose(m.array("geom_friction").reshape(-1, 3)[:, 0], [0.7, 0.7, 0.7])
