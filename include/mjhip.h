@@ -147,6 +147,7 @@ void mjh_builder_get_option(const mjh_builder*, mjh_option*);
 void mjh_builder_set_capacity(mjh_builder*, int maxcon, int maxefc);
 /* <compiler boundmass boundinertia>: lower bounds on the mass / principal inertias of every body except the world */
 void mjh_builder_set_bounds(mjh_builder*, double boundmass, double boundinertia);
+void mjh_builder_set_balanceinertia(mjh_builder*, int on);   /* <compiler balanceinertia> (mujoco_compile.cpp:157-160) */
 /* returns body id (>0) ; parent 0 = world.  mass<=0 -> inertia inferred from geoms (density 1000) */
 int mjh_builder_add_body(mjh_builder*, const char* name, int parent, const double pos[3],
                          const double quat[4], double gravcomp);

@@ -97,6 +97,7 @@ SYMBOLS = [
     ("mjh_builder_get_option", None, [_vp, C.POINTER(Option)]),
     ("mjh_builder_set_capacity", None, [_vp, C.c_int, C.c_int]),
     ("mjh_builder_set_bounds", None, [_vp, C.c_double, C.c_double]),
+    ("mjh_builder_set_balanceinertia", None, [_vp, C.c_int]),
     ("mjh_builder_add_body", C.c_int, [_vp, C.c_char_p, C.c_int, c_double_p, c_double_p, C.c_double]),
     ("mjh_builder_set_inertial", C.c_int, [_vp, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p]),
     ("mjh_builder_add_joint", C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p,

@@ -104,7 +104,7 @@ static int g_load_meshes = 1;   // mjh_load_set_mesh_mode: 0 = skip mesh assets 
 
 struct Loader {
   mjh_builder* b = nullptr;
-  bool degree = true, autolimits = false;
+  bool degree = true, autolimits = false, balance = false;
   double bmass = 0, binertia = 0;   // <compiler boundmass boundinertia>, raised to the process-wide floor of mjh_load_set_bounds
   Defaults def;
   std::map<std::string, int> body_id, joint_id, mesh_id;
@@ -266,6 +266,7 @@ struct Loader {
       if (c->tag == "compiler") {
         if (const char* a = c->get("angle")) degree = std::string(a) != "radian";
         if (const char* a = c->get("autolimits")) autolimits = std::string(a) == "true";
+        if (const char* a = c->get("balanceinertia")) if (std::string(a) == "true") balance = true;
         if (const char* a = c->get("meshdir")) { meshdir = a; if (!meshdir.empty() && meshdir.back() != '/') meshdir += '/'; }
         double v;
         if (nums(c->get("boundmass"), &v, 1)) bmass = std::max(bmass, v);
@@ -348,6 +349,7 @@ struct Loader {
   }
   mjh_model* finish() {
     mjh_builder_set_bounds(b, std::max(bmass, g_boundmass), std::max(binertia, g_boundinertia));
+    mjh_builder_set_balanceinertia(b, balance ? 1 : 0);
     mjh_model* m = mjh_builder_compile(b);
     mjh_builder_destroy(b); b = nullptr;
     return m;

@@ -48,6 +48,7 @@ struct mjh_builder {
   mjh_option opt;
   int maxcon = 0, maxefc = 0;
   double boundmass = 0, boundinertia = 0;   // <compiler boundmass boundinertia> (the reference forces 1e-6, mj_sim.cpp:584-590)
+  bool balanceinertia = false;              // <compiler balanceinertia> (mujoco_compile.cpp:157-160 sets it for URDF-derived models)
   std::vector<BBody> bodies;
   std::vector<BJoint> joints;
   std::vector<BGeom> geoms;
@@ -78,6 +79,7 @@ extern "C" void mjh_builder_set_option(mjh_builder* b, const mjh_option* o) { b-
 extern "C" void mjh_builder_get_option(const mjh_builder* b, mjh_option* o) { *o = b->opt; }
 extern "C" void mjh_builder_set_capacity(mjh_builder* b, int maxcon, int maxefc) { b->maxcon = maxcon; b->maxefc = maxefc; }
 extern "C" void mjh_builder_set_bounds(mjh_builder* b, double boundmass, double boundinertia) { b->boundmass = boundmass; b->boundinertia = boundinertia; }
+extern "C" void mjh_builder_set_balanceinertia(mjh_builder* b, int on) { b->balanceinertia = on != 0; }
 
 extern "C" int mjh_builder_add_body(mjh_builder* b, const char* name, int parent, const double pos[3],
                                     const double quat[4], double gravcomp) {
@@ -564,6 +566,12 @@ extern "C" mjh_model* mjh_builder_compile(mjh_builder* B) {
   }
   body_iquat[0] = 1;
 
+  // <compiler balanceinertia>: a diagonal inertia that violates the triangle inequality A + B >= C (URDF exports do) is
+  // replaced by its mean on all three axes [UPSTREAM mjCompiler]
+  if (B->balanceinertia) for (int i = 1; i < nbody; i++) {
+    double* I = &body_inertia[3*i];
+    if (I[0] + I[1] < I[2] || I[0] + I[2] < I[1] || I[1] + I[2] < I[0]) I[0] = I[1] = I[2] = (I[0] + I[1] + I[2]) / 3.0;
+  }
   // lower bounds on mass / inertia of every body except the world (mjCompiler boundmass / boundinertia)
   for (int i = 1; i < nbody; i++) {
     if (B->boundmass > 0 && body_mass[i] < B->boundmass) body_mass[i] = B->boundmass;

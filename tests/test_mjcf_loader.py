@@ -201,3 +201,12 @@ def test_default_classes_childclass_and_include(tmp_path):
     np.testing.assert_array_equal(m.array("geom_type"), [3, 2, 3])
     np.testing.assert_allclose(m.array("geom_size").reshape(-1, 3)[:, 0], [0.04, 0.06, 0.01])
     np.testing.assert_allclose(m.array("geom_friction").reshape(-1, 3)[:, 0], [0.7, 0.7, 0.7])
+
+
+def test_compiler_balanceinertia():
+    """<compiler balanceinertia="true"> (mujoco_compile.cpp:157-160): an inertia violating A + B >= C becomes its mean"""
+    import mujoco_sim_amd as ms
+    xml = """<mujoco><compiler balanceinertia="%s"/><worldbody><body pos="0 0 1"><freejoint/>
+        <inertial pos="0 0 0" mass="1" diaginertia="0.1 0.2 0.5"/><geom type="sphere" size="0.1"/></body></worldbody></mujoco>"""
+    np.testing.assert_allclose(ms.load_mjcf(xml % "false").array("body_inertia")[3:6], [0.1, 0.2, 0.5])
+    np.testing.assert_allclose(ms.load_mjcf(xml % "true").array("body_inertia")[3:6], [0.8 / 3] * 3)
