@@ -197,6 +197,10 @@ const char* mjh_load_note(void);
 /* 1 (default): <asset><mesh> files are read and mesh geoms collide as convex hulls; 0: mesh geoms are dropped (and
  * listed in mjh_load_note), which leaves the primitive collision geometry only */
 void mjh_load_set_mesh_mode(int mode);
+/* rosparam ~disable_gravity of the reference (robot.yaml:19, default true): MjSim::init_tmp rewrites gravcomp on EVERY
+ * body of a robot file — 1 if set, 0 otherwise (mj_sim.cpp:301-310).  mode 1 / 0 does the same to the bodies of the files
+ * after the first one in mjh_load_mjcf_files; -1 (default) keeps what the files say. */
+void mjh_load_set_robot_gravcomp(int mode);
 /* process-wide floor for <compiler boundmass boundinertia> of every file loaded afterwards: the reference writes
  * 1e-6 / 1e-6 into each file before mj_loadXML (mj_sim.cpp:584-590) */
 void mjh_load_set_bounds(double boundmass, double boundinertia);

@@ -100,11 +100,12 @@ struct Defaults {
 // floor applied to every file loaded afterwards: MjSim::init() writes boundmass = boundinertia = 1e-6 into the <compiler>
 // element of whatever it loads (mj_sim.cpp:584-590)
 static double g_boundmass = 0, g_boundinertia = 0;
+static int g_robot_gravcomp = -1;   // mjh_load_set_robot_gravcomp: -1 keep the files' values, 0 / 1 force it on every robot body
 static int g_load_meshes = 1;   // mjh_load_set_mesh_mode: 0 = skip mesh assets (their geoms are reported and dropped)
 
 struct Loader {
   mjh_builder* b = nullptr;
-  bool degree = true, autolimits = false, balance = false;
+  bool degree = true, autolimits = false, balance = false, robot_file = false;
   double bmass = 0, binertia = 0;   // <compiler boundmass boundinertia>, raised to the process-wide floor of mjh_load_set_bounds
   Defaults def;
   std::map<std::string, int> body_id, joint_id, mesh_id;
@@ -227,6 +228,7 @@ struct Loader {
   bool body(const Node& n, int parent) {
     double pos[3] = {0, 0, 0}, quat[4] = {1, 0, 0, 0}, gc = 0;
     nums(n.get("pos"), pos, 3); orientation(n, quat); nums(n.get("gravcomp"), &gc, 1);
+    if (robot_file && g_robot_gravcomp >= 0) gc = g_robot_gravcomp;   // MjSim::init_tmp overwrites it on every robot body (mj_sim.cpp:301-310)
     std::string name = n.get("name") ? n.get("name") : ("body" + std::to_string(nameless++));
     int id = mjh_builder_add_body(b, name.c_str(), parent, pos, quat, gc);
     if (id < 0) return false;
@@ -259,6 +261,7 @@ struct Loader {
   bool add(const Node& root, bool first, const std::string& dir = std::string()) {
     if (root.tag != "mujoco") { mjh_set_error("root element must be <mujoco>"); return false; }
     if (first) b = mjh_builder_create();
+    robot_file = !first;      // files after the world file are robots (MjSim::init composition)
     degree = true; autolimits = false; def = Defaults(); basedir = dir; meshdir.clear(); mesh_id.clear(); classes.clear(); childclass.clear();
     mjh_option o; mjh_builder_get_option(b, &o);
     // first pass: compiler / option / default (they may appear after worldbody in a file)
@@ -432,3 +435,4 @@ extern "C" mjh_model* mjh_load_mjcf_files(const char* const* paths, int n) {
 extern "C" const char* mjh_load_note(void) { return g_note.c_str(); }
 extern "C" void mjh_load_set_bounds(double boundmass, double boundinertia) { g_boundmass = boundmass; g_boundinertia = boundinertia; }
 extern "C" void mjh_load_set_mesh_mode(int mode) { g_load_meshes = mode != 0; }
+extern "C" void mjh_load_set_robot_gravcomp(int mode) { g_robot_gravcomp = mode < 0 ? -1 : (mode ? 1 : 0); }

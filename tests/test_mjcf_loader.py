@@ -210,3 +210,23 @@ def test_compiler_balanceinertia():
         <inertial pos="0 0 0" mass="1" diaginertia="0.1 0.2 0.5"/><geom type="sphere" size="0.1"/></body></worldbody></mujoco>"""
     np.testing.assert_allclose(ms.load_mjcf(xml % "false").array("body_inertia")[3:6], [0.1, 0.2, 0.5])
     np.testing.assert_allclose(ms.load_mjcf(xml % "true").array("body_inertia")[3:6], [0.8 / 3] * 3)
+
+
+def test_robot_gravcomp_override(tmp_path, lib):
+    """~disable_gravity: every body of a robot file gets gravcomp 1 (or 0), whatever the file says (mj_sim.cpp:301-310)"""
+    import mujoco_sim_amd as ms
+    (tmp_path / "world.xml").write_text('<mujoco><worldbody><geom type="plane" size="0 0 0.05"/><body name="crate" pos="1 0 0.2" gravcomp="0.5"><freejoint/><geom type="box" size="0.1 0.1 0.1"/></body></worldbody></mujoco>')
+    (tmp_path / "robot.xml").write_text('<mujoco><worldbody><body name="base" pos="0 0 0.5" gravcomp="0"><freejoint/><geom type="box" size="0.2 0.2 0.1"/>'
+                                        '<body name="arm" pos="0 0 0.2"><joint axis="0 1 0"/><geom type="capsule" size="0.03 0.2"/></body></body></worldbody></mujoco>')
+    paths = [str(tmp_path / "world.xml"), str(tmp_path / "robot.xml")]
+    try:
+        np.testing.assert_allclose(ms.load_mjcf(paths=paths).array("body_gravcomp"), [0, 0.5, 0, 0])
+        lib.mjh_load_set_robot_gravcomp(1)
+        m = ms.load_mjcf(paths=paths)
+        np.testing.assert_allclose(m.array("body_gravcomp"), [0, 0.5, 1, 1])          # world-file bodies keep theirs
+        d = orc.OrcData(m.ptr); d.step(200)
+        assert abs(d.f("qpos")[7 + 2] - 0.5) < 1e-6 and d.f("qpos")[2] < 0.2          # the robot floats, the crate fell
+        lib.mjh_load_set_robot_gravcomp(0)
+        np.testing.assert_allclose(ms.load_mjcf(paths=paths).array("body_gravcomp"), [0, 0.5, 0, 0])
+    finally:
+        lib.mjh_load_set_robot_gravcomp(-1)
