@@ -201,6 +201,11 @@ void mjh_load_set_mesh_mode(int mode);
  * body of a robot file — 1 if set, 0 otherwise (mj_sim.cpp:301-310).  mode 1 / 0 does the same to the bodies of the files
  * after the first one in mjh_load_mjcf_files; -1 (default) keeps what the files say. */
 void mjh_load_set_robot_gravcomp(int mode);
+/* rosparam ~add_odom_joints (robot.yaml; mj_sim.cpp:337-415): the root body of every robot file gets the joints
+ * "<root>_lin_odom_{x,y,z}_joint" (slide) / "<root>_ang_odom_{x,y,z}_joint" (hinge) selected by mask bits 0..5
+ * (lin x y z, ang x y z), with the reference's rule that a planar linear axis comes along when the other one and the yaw
+ * (or, for z, the pitch) are selected.  Resolve their dofs with mjh_name2id and pass them to mjh_set_odom_dofs. */
+void mjh_load_set_odom_joints(unsigned mask);
 /* process-wide floor for <compiler boundmass boundinertia> of every file loaded afterwards: the reference writes
  * 1e-6 / 1e-6 into each file before mj_loadXML (mj_sim.cpp:584-590) */
 void mjh_load_set_bounds(double boundmass, double boundinertia);

@@ -101,6 +101,7 @@ struct Defaults {
 // element of whatever it loads (mj_sim.cpp:584-590)
 static double g_boundmass = 0, g_boundinertia = 0;
 static int g_robot_gravcomp = -1;   // mjh_load_set_robot_gravcomp: -1 keep the files' values, 0 / 1 force it on every robot body
+static unsigned g_odom_mask = 0;      // mjh_load_set_odom_joints: bits 0..5 = lin x y z, ang x y z
 static int g_load_meshes = 1;   // mjh_load_set_mesh_mode: 0 = skip mesh assets (their geoms are reported and dropped)
 
 struct Loader {
@@ -236,6 +237,22 @@ struct Loader {
     const std::string saved = childclass;
     if (n.get("childclass")) childclass = n.get("childclass");
     const bool ok = children(n, id);
+    // rosparam ~add_odom_joints (mj_sim.cpp:337-415): slide / hinge joints "<robot>_lin_odom_x_joint" ... appended to the
+    // root body of a robot file, after the body's own children as InsertEndChild does; a linear axis is also added when
+    // the other planar axis and the matching rotation are asked for (the reference's rule, :355,:365,:375)
+    if (ok && robot_file && parent == 0 && g_odom_mask) {
+      const unsigned m = g_odom_mask;
+      const bool lx = (m & 1) || ((m & 2) && (m & 32)), ly = (m & 2) || ((m & 1) && (m & 32)), lz = (m & 4) || ((m & 1) && (m & 16));
+      const bool on[6] = {lx, ly, lz, (m & 8) != 0, (m & 16) != 0, (m & 32) != 0};
+      static const char* nm[6] = {"_lin_odom_x_joint", "_lin_odom_y_joint", "_lin_odom_z_joint", "_ang_odom_x_joint", "_ang_odom_y_joint", "_ang_odom_z_joint"};
+      for (int k = 0; k < 6; k++) if (on[k]) {
+        double axis[3] = {0, 0, 0}; axis[k % 3] = 1;
+        const std::string jn = name + nm[k];
+        const int jid = mjh_builder_add_joint(b, jn.c_str(), id, k < 3 ? MJH_JNT_SLIDE : MJH_JNT_HINGE, nullptr, axis, nullptr, 0, 0, 0, 0, 0);
+        if (jid < 0) return false;
+        joint_id[jn] = jid;
+      }
+    }
     childclass = saved;
     return ok;
   }
@@ -435,4 +452,5 @@ extern "C" mjh_model* mjh_load_mjcf_files(const char* const* paths, int n) {
 extern "C" const char* mjh_load_note(void) { return g_note.c_str(); }
 extern "C" void mjh_load_set_bounds(double boundmass, double boundinertia) { g_boundmass = boundmass; g_boundinertia = boundinertia; }
 extern "C" void mjh_load_set_mesh_mode(int mode) { g_load_meshes = mode != 0; }
+extern "C" void mjh_load_set_odom_joints(unsigned mask) { g_odom_mask = mask & 63u; }
 extern "C" void mjh_load_set_robot_gravcomp(int mode) { g_robot_gravcomp = mode < 0 ? -1 : (mode ? 1 : 0); }

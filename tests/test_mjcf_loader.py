@@ -230,3 +230,24 @@ def test_robot_gravcomp_override(tmp_path, lib):
         np.testing.assert_allclose(ms.load_mjcf(paths=paths).array("body_gravcomp"), [0, 0.5, 0, 0])
     finally:
         lib.mjh_load_set_robot_gravcomp(-1)
+
+
+def test_odom_joints_added_to_robot_roots(tmp_path, lib):
+    """~add_odom_joints (mj_sim.cpp:337-415): slide / hinge joints named after the robot's root body, appended to it"""
+    import mujoco_sim_amd as ms
+    (tmp_path / "world.xml").write_text('<mujoco><option gravity="0 0 0"/><worldbody><geom type="plane" size="0 0 0.05"/></worldbody></mujoco>')
+    (tmp_path / "robot.xml").write_text('<mujoco><worldbody><body name="ridgeback" pos="0 0 0.3"><geom type="box" size="0.3 0.2 0.1"/>'
+                                        '<body name="arm" pos="0 0 0.2"><joint name="shoulder" axis="0 1 0"/><geom type="capsule" size="0.03 0.2"/></body></body></worldbody></mujoco>')
+    paths = [str(tmp_path / "world.xml"), str(tmp_path / "robot.xml")]
+    try:
+        lib.mjh_load_set_odom_joints(1 | 32)                      # lin x + ang z  ->  lin y comes along
+        m = ms.load_mjcf(paths=paths)
+    finally:
+        lib.mjh_load_set_odom_joints(0)
+    names = [lib.mjh_id2name(m.ptr, 1, j).decode() for j in range(m.njnt)]
+    assert names == ["ridgeback_lin_odom_x_joint", "ridgeback_lin_odom_y_joint", "ridgeback_ang_odom_z_joint", "shoulder"]
+    np.testing.assert_array_equal(m.array("jnt_type"), [2, 2, 3, 3])
+    np.testing.assert_allclose(m.array("jnt_axis").reshape(-1, 3), [[1, 0, 0], [0, 1, 0], [0, 0, 1], [0, 1, 0]])
+    assert m.nv == 4 and ms.load_mjcf(paths=paths).nv == 1      # and nothing is added without the option
+    d = orc.OrcData(m.ptr); d.f("qvel")[:] = [0.5, 0, 1.0, 0]; d.step(100)
+    np.testing.assert_allclose(d.f("qpos")[[0, 2]], [0.1, 0.2], atol=1e-2)       # 100 steps of 2 ms: the base drives and turns on its odom joints
