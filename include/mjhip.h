@@ -206,6 +206,9 @@ void mjh_load_set_robot_gravcomp(int mode);
  * (lin x y z, ang x y z), with the reference's rule that a planar linear axis comes along when the other one and the yaw
  * (or, for z, the pitch) are selected.  Resolve their dofs with mjh_name2id and pass them to mjh_set_odom_dofs. */
 void mjh_load_set_odom_joints(unsigned mask);
+/* rosparam ~pose_init (mj_sim.cpp:312-335): position and roll / pitch / yaw (radians, tf2 setRPY) written onto the root body
+ * of a robot file, by body name; pose NULL removes the entry, root_body NULL removes all */
+void mjh_load_set_robot_pose(const char* root_body, const double pose[6]);
 /* process-wide floor for <compiler boundmass boundinertia> of every file loaded afterwards: the reference writes
  * 1e-6 / 1e-6 into each file before mj_loadXML (mj_sim.cpp:584-590) */
 void mjh_load_set_bounds(double boundmass, double boundinertia);

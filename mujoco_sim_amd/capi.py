@@ -123,6 +123,7 @@ SYMBOLS = [
     ("mjh_load_set_mesh_mode", None, [C.c_int]),
     ("mjh_load_set_robot_gravcomp", None, [C.c_int]),
     ("mjh_load_set_odom_joints", None, [C.c_uint]),
+    ("mjh_load_set_robot_pose", None, [C.c_char_p, c_double_p]),
     ("mjh_scene_s24", Model_p, []),
     ("mjh_scene_s24_randomize", C.c_int, [Model_p, C.c_int, C.c_int, C.c_uint] + [c_double_p] * 7),
     ("mjh_scene_pendulum", Model_p, []),

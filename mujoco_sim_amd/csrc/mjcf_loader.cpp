@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <array>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -101,6 +102,7 @@ struct Defaults {
 // element of whatever it loads (mj_sim.cpp:584-590)
 static double g_boundmass = 0, g_boundinertia = 0;
 static int g_robot_gravcomp = -1;   // mjh_load_set_robot_gravcomp: -1 keep the files' values, 0 / 1 force it on every robot body
+static std::map<std::string, std::array<double, 6>> g_robot_pose;   // mjh_load_set_robot_pose: root body name -> x y z roll pitch yaw
 static unsigned g_odom_mask = 0;      // mjh_load_set_odom_joints: bits 0..5 = lin x y z, ang x y z
 static int g_load_meshes = 1;   // mjh_load_set_mesh_mode: 0 = skip mesh assets (their geoms are reported and dropped)
 
@@ -231,6 +233,15 @@ struct Loader {
     nums(n.get("pos"), pos, 3); orientation(n, quat); nums(n.get("gravcomp"), &gc, 1);
     if (robot_file && g_robot_gravcomp >= 0) gc = g_robot_gravcomp;   // MjSim::init_tmp overwrites it on every robot body (mj_sim.cpp:301-310)
     std::string name = n.get("name") ? n.get("name") : ("body" + std::to_string(nameless++));
+    if (robot_file && parent == 0) {          // rosparam ~pose_init: position + roll / pitch / yaw of the robot's root body (mj_sim.cpp:312-335)
+      auto it = g_robot_pose.find(name);
+      if (it != g_robot_pose.end()) {
+        for (int k = 0; k < 3; k++) pos[k] = it->second[k];
+        double q[4] = {1, 0, 0, 0};          // tf2::Quaternion::setRPY: q = Rz(yaw) Ry(pitch) Rx(roll)
+        for (int k = 2; k >= 0; k--) { double ax[3] = {0, 0, 0}; ax[k] = 1; double r[4], t[4]; hm::axisangle2quat(r, ax, it->second[3 + k]); hm::mulquat(t, q, r); std::memcpy(q, t, sizeof q); }
+        std::memcpy(quat, q, sizeof q);
+      }
+    }
     int id = mjh_builder_add_body(b, name.c_str(), parent, pos, quat, gc);
     if (id < 0) return false;
     body_id[name] = id;
@@ -452,5 +463,11 @@ extern "C" mjh_model* mjh_load_mjcf_files(const char* const* paths, int n) {
 extern "C" const char* mjh_load_note(void) { return g_note.c_str(); }
 extern "C" void mjh_load_set_bounds(double boundmass, double boundinertia) { g_boundmass = boundmass; g_boundinertia = boundinertia; }
 extern "C" void mjh_load_set_mesh_mode(int mode) { g_load_meshes = mode != 0; }
+extern "C" void mjh_load_set_robot_pose(const char* root_body, const double pose[6]) {
+  if (!root_body) { g_robot_pose.clear(); return; }
+  if (!pose) { g_robot_pose.erase(root_body); return; }
+  std::array<double, 6> a; for (int k = 0; k < 6; k++) a[k] = pose[k];
+  g_robot_pose[root_body] = a;
+}
 extern "C" void mjh_load_set_odom_joints(unsigned mask) { g_odom_mask = mask & 63u; }
 extern "C" void mjh_load_set_robot_gravcomp(int mode) { g_robot_gravcomp = mode < 0 ? -1 : (mode ? 1 : 0); }

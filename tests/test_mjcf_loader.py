@@ -251,3 +251,27 @@ def test_odom_joints_added_to_robot_roots(tmp_path, lib):
     assert m.nv == 4 and ms.load_mjcf(paths=paths).nv == 1      # and nothing is added without the option
     d = orc.OrcData(m.ptr); d.f("qvel")[:] = [0.5, 0, 1.0, 0]; d.step(100)
     np.testing.assert_allclose(d.f("qpos")[[0, 2]], [0.1, 0.2], atol=1e-2)       # 100 steps of 2 ms: the base drives and turns on its odom joints
+
+
+def test_robot_pose_init(tmp_path, lib):
+    """~pose_init (mj_sim.cpp:312-335): pos + euler of a robot's root body, by name"""
+    import mujoco_sim_amd as ms
+    (tmp_path / "world.xml").write_text('<mujoco><worldbody><geom type="plane" size="0 0 0.05"/></worldbody></mujoco>')
+    (tmp_path / "robot.xml").write_text('<mujoco><worldbody><body name="tiago" pos="9 9 9"><freejoint/><geom type="box" size="0.2 0.2 0.1"/></body></worldbody></mujoco>')
+    paths = [str(tmp_path / "world.xml"), str(tmp_path / "robot.xml")]
+    try:
+        lib.mjh_load_set_robot_pose(b"tiago", D(1.0, 2.0, 0.5, 0, 0, np.pi / 2))
+        m = ms.load_mjcf(paths=paths)
+    finally:
+        lib.mjh_load_set_robot_pose(None, None)
+    np.testing.assert_allclose(m.array("qpos0"), [1, 2, 0.5, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)], atol=1e-12)
+    # roll, pitch, yaw as tf2's setRPY composes them: R = Rz(yaw) Ry(pitch) Rx(roll)
+    from scipy.spatial.transform import Rotation
+    rpy = (0.3, -0.4, 1.1)
+    lib.mjh_load_set_robot_pose(b"tiago", D(0, 0, 1, *rpy))
+    try:
+        w, x, y, z = ms.load_mjcf(paths=paths).array("qpos0")[3:7]
+    finally:
+        lib.mjh_load_set_robot_pose(None, None)
+    np.testing.assert_allclose(Rotation.from_quat([x, y, z, w]).as_matrix(), Rotation.from_euler("xyz", rpy).as_matrix(), atol=1e-12)   # extrinsic xyz = fixed-axis RPY
+    np.testing.assert_allclose(ms.load_mjcf(paths=paths).array("qpos0")[:3], [9, 9, 9])
