@@ -277,7 +277,9 @@ int mjh_get_state(mjh_engine*, int env0, int n, double* time, double* qpos, doub
                   double* qacc_warmstart);
 int mjh_set_state(mjh_engine*, int env0, int n, const double* time, const double* qpos,
                   const double* qvel, const double* qacc_warmstart);
-/* other per-env vectors by name: "qacc","qfrc_bias","qfrc_applied","qfrc_passive",
+/* (qacc and qacc_warmstart are one array on the device: after every solve qacc_warmstart = qacc, as mj_advance leaves them;
+ * writing a warm start through mjh_set_state therefore also sets the qacc a following mjh_inverse reads)
+ * other per-env vectors by name: "qacc","qfrc_bias","qfrc_applied","qfrc_passive",
  * "qfrc_constraint","qfrc_inverse","qacc_smooth","energy"(2) */
 int mjh_get_field(mjh_engine*, const char* name, int env0, int n, double* out);
 /* per-env solver statistics: ncon, nefc, solver iterations, flags (bit0 contact overflow,

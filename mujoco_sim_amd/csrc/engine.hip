@@ -373,7 +373,8 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   const size_t nq_all = (size_t)nenv * M.nqp, nv_all = (size_t)nenv * M.nvp;
   int rc = 0;
   rc |= dev_alloc(e, &S.qpos, nq_all); rc |= dev_alloc(e, &S.initial_qpos, nq_all);
-  rc |= dev_alloc(e, &S.qvel, nv_all); rc |= dev_alloc(e, &S.qacc, nv_all); rc |= dev_alloc(e, &S.qacc_ws, nv_all);
+  rc |= dev_alloc(e, &S.qvel, nv_all); rc |= dev_alloc(e, &S.qacc_ws, nv_all);
+  S.qacc = S.qacc_ws;   // one array: after every solve qacc_warmstart = qacc (step_kernel.h, store), so the second row would only double the traffic
   rc |= dev_alloc(e, &S.qvel_ref, nv_all); rc |= dev_alloc(e, &S.qfrc_applied, nv_all); rc |= dev_alloc(e, &S.ddq, nv_all);
   rc |= dev_alloc(e, &S.dq, nv_all); rc |= dev_alloc(e, &S.qfrc_inverse, nv_all);
   S.gscratch = nullptr; S.gstride = hp.gstride;
@@ -653,9 +654,9 @@ extern "C" int mjh_transplant_state(mjh_engine* from, mjh_engine* to, int qpos_m
     }
   }
   for (int i = 0; i < n; i++) tb[i] = ta[i];          // d_new->time = d->time
-  rc = mjh_set_state(to, 0, n, tb.data(), qb.data(), vb.data(), wb.data());
+  rc = put_rows(to, to->S.qacc, to->M.nvp, to->M.nv, 0, n, ab.data());      // (qacc shares its array with qacc_warmstart, which is written next)
+  if (!rc) rc = mjh_set_state(to, 0, n, tb.data(), qb.data(), vb.data(), wb.data());
   if (!rc) rc = put_rows(to, to->S.qfrc_applied, to->M.nvp, to->M.nv, 0, n, fb.data());
-  if (!rc) rc = put_rows(to, to->S.qacc, to->M.nvp, to->M.nv, 0, n, ab.data());
   return rc ? rc : matched;
 }
 

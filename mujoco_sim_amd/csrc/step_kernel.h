@@ -541,7 +541,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   // ------------------------------------------------------------------ load state
   if (ph & PH_RESET) {
     for (int i = lane; i < nq; i += 64) S.qpos[qrow + i] = S.initial_qpos[qrow + i];
-    for (int i = lane; i < nv; i += 64) { S.qvel[vrow+i] = 0; S.qacc[vrow+i] = 0; S.qacc_ws[vrow+i] = 0; S.qvel_ref[vrow+i] = 0; S.qfrc_applied[vrow+i] = 0; S.ddq[vrow+i] = 0; S.dq[vrow+i] = 0; }
+    for (int i = lane; i < nv; i += 64) { S.qvel[vrow+i] = 0; S.qacc_ws[vrow+i] = 0; S.qvel_ref[vrow+i] = 0; S.qfrc_applied[vrow+i] = 0; S.ddq[vrow+i] = 0; S.dq[vrow+i] = 0; }
     if (lane == 0) { S.time[env] = 0; S.stats[4*env] = 0; S.stats[4*env+1] = 0; S.stats[4*env+2] = 0; S.stats[4*env+3] = 0; }
     return;
   }
@@ -1953,7 +1953,9 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   // ------------------------------------------------------------------ store state
   for (int i = lane; i < nq; i += 64) S.qpos[qrow + i] = s_qpos[i];
   for (int i = lane; i < nv; i += 64) {
-    S.qvel[vrow + i] = s_qvel[i]; S.qacc_ws[vrow + i] = s_ws[i]; S.qacc[vrow + i] = s_qacc[i];
+    // qacc and qacc_warmstart are ONE array in HBM (S.qacc aliases S.qacc_ws): every path that solves for qacc also stores
+    // it as the next warm start (mj_advance: qacc_warmstart = qacc), and no path changes one without the other
+    S.qvel[vrow + i] = s_qvel[i]; S.qacc_ws[vrow + i] = s_ws[i];
     if (!((ph & PH_STEP1) && (ph & PH_STEP2))) { S.qvel_ref[vrow + i] = s_qvref[i]; S.qfrc_applied[vrow + i] = s_applied[i]; }
   }
   if (lane == 0) {
