@@ -52,7 +52,9 @@ struct DState {
   float *x_vec, *x_res;  // mulM in/out [n*nvp]
   long long* x_prof;     // [n*16] s_memtime stamps at stage boundaries (debug)
   // per-env model parameter tables (null -> shared model)
+  // (one row of p_stride floats per env holds all six, so that an env's parameters cost whole sectors once, not six times)
   const float *p_geom_size, *p_geom_rbound, *p_body_mass, *p_body_inertia, *p_body_invweight0, *p_dof_invweight0;
+  int p_stride;
   // many-body models (nv > 64): per-env pools that do not fit LDS (contacts, blocks, Jacobians) live here; a negative
   // Lay offset -1-k addresses float k of the env's slice
   float* gscratch; long long gstride;

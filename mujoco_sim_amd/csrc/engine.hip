@@ -525,6 +525,16 @@ static int put_rows(mjh_engine* e, float* dst, int stride, int width, int env0, 
   HIPCHK(hipStreamSynchronize(e->stream));
   return MJH_OK;
 }
+// a column block of wider rows: only `width` floats of every row are written (the rest belongs to other tables)
+static int put_cols(mjh_engine* e, float* dst, int stride, int width, int env0, int n, const double* src) {
+  if (!src || n == 0) return MJH_OK;
+  std::vector<float> tmp((size_t)n * width);
+  for (size_t i = 0; i < tmp.size(); i++) tmp[i] = (float)src[i];
+  HIPCHK(hipMemcpy2DAsync(dst + (size_t)env0 * stride, (size_t)stride * sizeof(float), tmp.data(), (size_t)width * sizeof(float),
+                          (size_t)width * sizeof(float), (size_t)n, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return MJH_OK;
+}
 static int get_rows(mjh_engine* e, const float* src, int stride, int width, int env0, int n, double* dst) {
   if (!dst || n == 0) return MJH_OK;
   std::vector<float> tmp((size_t)n * stride);
@@ -737,19 +747,24 @@ extern "C" int mjh_set_env_param(mjh_engine* e, int which, int env0, int n, cons
   const int widths[MJH_EP_COUNT] = {3 * m->ngeom, m->ngeom, m->nbody, 3 * m->nbody, 2 * m->nbody, m->nv};
   const double* defaults[MJH_EP_COUNT] = {m->geom_size, m->geom_rbound, m->body_mass, m->body_inertia, m->body_invweight0, m->dof_invweight0};
   const int w = widths[which];
-  if (!e->p_tables[which]) {
+  if (!e->p_tables[0]) {
+    // first use: ONE array with a row per env holding all six tables back to back (rows padded to 64 B), every table
+    // initialised with the shared model's values; the six device pointers address their column of it
+    int off[MJH_EP_COUNT], total = 0;
+    for (int k = 0; k < MJH_EP_COUNT; k++) { off[k] = total; total += widths[k]; }
+    const int P = ((total + 15) / 16) * 16;
     float* p = nullptr;
-    int rc = dev_alloc(e, &p, (size_t)e->nenv * w, false);
+    int rc = dev_alloc(e, &p, (size_t)e->nenv * P, false);
     if (rc) return rc;
-    std::vector<float> init((size_t)e->nenv * w);
-    for (int en = 0; en < e->nenv; en++) for (int k = 0; k < w; k++) init[(size_t)en * w + k] = (float)defaults[which][k];
+    std::vector<float> init((size_t)e->nenv * P, 0.0f);
+    for (int en = 0; en < e->nenv; en++) for (int k = 0; k < MJH_EP_COUNT; k++) for (int i = 0; i < widths[k]; i++) init[(size_t)en * P + off[k] + i] = (float)defaults[k][i];
     HIPCHK(hipMemcpyAsync(p, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    e->p_tables[which] = p;
     const float** slots[MJH_EP_COUNT] = {&e->S.p_geom_size, &e->S.p_geom_rbound, &e->S.p_body_mass, &e->S.p_body_inertia, &e->S.p_body_invweight0, &e->S.p_dof_invweight0};
-    *slots[which] = p;
+    for (int k = 0; k < MJH_EP_COUNT; k++) { e->p_tables[k] = p + off[k]; *slots[k] = p + off[k]; }
+    e->S.p_stride = P;
   }
-  return put_rows(e, e->p_tables[which], w, w, env0, n, values);
+  return put_cols(e, e->p_tables[which], e->S.p_stride, w, env0, n, values);
 }
 
 extern "C" int mjh_set_initial_qpos(mjh_engine* e, int env0, int n, const double* qpos) {

@@ -562,10 +562,10 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       for (int j = dof_parentid[i]; j >= 0; j = dof_parentid[j]) s_anc_i[++a] = j;
     }
   }
-  for (int i = lane; i < 3 * ngeom; i += 64) s_p_gsize[i] = S.p_geom_size ? S.p_geom_size[(size_t)env * 3 * ngeom + i] : geom_size[i];
-  for (int i = lane; i < ngeom; i += 64) s_p_rbound[i] = S.p_geom_rbound ? S.p_geom_rbound[(size_t)env * ngeom + i] : geom_rbound[i];
-  for (int i = lane; i < nbody; i += 64) s_p_mass[i] = S.p_body_mass ? S.p_body_mass[(size_t)env * nbody + i] : body_mass[i];
-  for (int i = lane; i < 3 * nbody; i += 64) s_p_inertia[i] = S.p_body_inertia ? S.p_body_inertia[(size_t)env * 3 * nbody + i] : body_inertia[i];
+  for (int i = lane; i < 3 * ngeom; i += 64) s_p_gsize[i] = S.p_geom_size ? S.p_geom_size[(size_t)env * S.p_stride + i] : geom_size[i];
+  for (int i = lane; i < ngeom; i += 64) s_p_rbound[i] = S.p_geom_rbound ? S.p_geom_rbound[(size_t)env * S.p_stride + i] : geom_rbound[i];
+  for (int i = lane; i < nbody; i += 64) s_p_mass[i] = S.p_body_mass ? S.p_body_mass[(size_t)env * S.p_stride + i] : body_mass[i];
+  for (int i = lane; i < 3 * nbody; i += 64) s_p_inertia[i] = S.p_body_inertia ? S.p_body_inertia[(size_t)env * S.p_stride + i] : body_inertia[i];
   // many-body layout, three-launch step (engine.hip): PH_PRE stops in front of the solver sweeps and hands over through the
   // env's scratch slice; PH_POST skips everything between the factorisation and the end of the sweeps
   const bool pre = NROW == 8 && (ph & PH_PRE), post = NROW == 8 && (ph & PH_POST);
@@ -1031,8 +1031,8 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       if (jb == 0) { hd[2] = tree_dofadr[t1] | (tree_dofnum[t1] << 16); hd[3] = t2 >= 0 ? (tree_dofadr[t2] | (tree_dofnum[t2] << 16)) : 0xffff; }   // no second tree: n2 = 0, a2 matches no dof
     }
     // ---- block parameters: impedance, regulariser R, reference gains (lanes = blocks)
-    auto p_dinv = [&](int d) __attribute__((always_inline)) { return S.p_dof_invweight0 ? S.p_dof_invweight0[(size_t)env * nv + d] : dof_invweight0[d]; };
-    auto p_binv = [&](int i) __attribute__((always_inline)) { return S.p_body_invweight0 ? S.p_body_invweight0[(size_t)env * 2 * nbody + i] : body_invweight0[i]; };
+    auto p_dinv = [&](int d) __attribute__((always_inline)) { return S.p_dof_invweight0 ? S.p_dof_invweight0[(size_t)env * S.p_stride + d] : dof_invweight0[d]; };
+    auto p_binv = [&](int i) __attribute__((always_inline)) { return S.p_body_invweight0 ? S.p_body_invweight0[(size_t)env * S.p_stride + i] : body_invweight0[i]; };
     for (int b = lane; b < nblk; b += 64) {
       const int* hd = s_blki_i + b * BLKI_STRIDE;
       const int id = hd[1] & 0xffffff, rtype = (hd[1] >> 24) & 15, side = (hd[1] >> 28) & 1;
