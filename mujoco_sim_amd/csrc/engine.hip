@@ -206,7 +206,10 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
 #undef PF
   M.nq = m->nq; M.nv = nv; M.nbody = nb; M.njnt = nj; M.ngeom = ng; M.neq = m->neq; M.npair = m->npair; M.nM = m->nM; M.ntree = m->ntree;
   M.maxcon = std::max(m->maxcon, 1); M.maxefc = std::max(m->maxefc, 1);
-  M.nqp = pad32(m->nq); M.nvp = pad32(std::max(nv, 1));
+  // per-env state record: the rows a step reads (qpos, qvel, qacc_warmstart, ddq, dq) lie back to back in one record per
+  // env, padded to whole 128-byte lines (S24: 28 + 4 x 24 floats = 496 B -> 4 lines; as five separately padded rows it
+  // was 5 lines), and every per-env array uses the record stride (the kernel knows only (pointer, stride) pairs)
+  M.nqp = M.nvp = pad32(m->nq + 4 * std::max(nv, 1));
   M.maxlevel = maxlevel; M.nfl = (int)fl_dof.size(); M.ngc = (int)gc_body.size(); M.rowW = rowW; M.nstage = nstage;
   M.has_damping = has_damping; M.has_limits = has_limits; M.diagM = diagM;
   M.has_dim4 = 0;
@@ -373,10 +376,13 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   const size_t nq_all = (size_t)nenv * M.nqp, nv_all = (size_t)nenv * M.nvp;
   int rc = 0;
   rc |= dev_alloc(e, &S.qpos, nq_all); rc |= dev_alloc(e, &S.initial_qpos, nq_all);
-  rc |= dev_alloc(e, &S.qvel, nv_all); rc |= dev_alloc(e, &S.qacc_ws, nv_all);
+  {   // columns of the per-env record (derive_device_model): qpos | qvel | qacc_warmstart | ddq | dq
+    const int nvc = std::max(M.nv, 1);
+    S.qvel = S.qpos + M.nq; S.qacc_ws = S.qvel + nvc; S.ddq = S.qacc_ws + nvc; S.dq = S.ddq + nvc;
+  }
   S.qacc = S.qacc_ws;   // one array: after every solve qacc_warmstart = qacc (step_kernel.h, store), so the second row would only double the traffic
-  rc |= dev_alloc(e, &S.qvel_ref, nv_all); rc |= dev_alloc(e, &S.qfrc_applied, nv_all); rc |= dev_alloc(e, &S.ddq, nv_all);
-  rc |= dev_alloc(e, &S.dq, nv_all); rc |= dev_alloc(e, &S.qfrc_inverse, nv_all);
+  rc |= dev_alloc(e, &S.qvel_ref, nv_all); rc |= dev_alloc(e, &S.qfrc_applied, nv_all);
+  rc |= dev_alloc(e, &S.qfrc_inverse, nv_all);
   S.gscratch = nullptr; S.gstride = hp.gstride;
   if (M.big) rc |= dev_alloc(e, &S.gscratch, (size_t)nenv * (size_t)hp.gstride, false);   // many-body models: contact / block / Jacobian pools
   rc |= dev_alloc(e, &S.time, (size_t)nenv); rc |= dev_alloc(e, &S.odom_vel, (size_t)nenv * 6); rc |= dev_alloc(e, &S.stats, (size_t)nenv * 4);
@@ -517,16 +523,9 @@ extern "C" int mjh_get_cohorts(const mjh_engine* e) { return e ? e->ncohort : 0;
 extern "C" int mjh_synchronize(mjh_engine* e) { ENG(e); HIPCHK(hipStreamSynchronize(e->stream)); return MJH_OK; }
 
 // ---- host <-> device marshalling helpers (double on the host side, padded fp32 rows on the device)
+// rows of `width` floats at `stride` floats apart; only the `width` floats are touched (rows may be columns of a wider
+// per-env record, see the state layout in mjh_create)
 static int put_rows(mjh_engine* e, float* dst, int stride, int width, int env0, int n, const double* src) {
-  if (!src || n == 0) return MJH_OK;
-  std::vector<float> tmp((size_t)n * stride, 0.0f);
-  for (int i = 0; i < n; i++) for (int k = 0; k < width; k++) tmp[(size_t)i * stride + k] = (float)src[(size_t)i * width + k];
-  HIPCHK(hipMemcpyAsync(dst + (size_t)env0 * stride, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  return MJH_OK;
-}
-// a column block of wider rows: only `width` floats of every row are written (the rest belongs to other tables)
-static int put_cols(mjh_engine* e, float* dst, int stride, int width, int env0, int n, const double* src) {
   if (!src || n == 0) return MJH_OK;
   std::vector<float> tmp((size_t)n * width);
   for (size_t i = 0; i < tmp.size(); i++) tmp[i] = (float)src[i];
@@ -535,12 +534,15 @@ static int put_cols(mjh_engine* e, float* dst, int stride, int width, int env0, 
   HIPCHK(hipStreamSynchronize(e->stream));
   return MJH_OK;
 }
+// a column block of wider rows: only `width` floats of every row are written (the rest belongs to other tables)
+static int put_cols(mjh_engine* e, float* dst, int stride, int width, int env0, int n, const double* src) { return put_rows(e, dst, stride, width, env0, n, src); }
 static int get_rows(mjh_engine* e, const float* src, int stride, int width, int env0, int n, double* dst) {
   if (!dst || n == 0) return MJH_OK;
-  std::vector<float> tmp((size_t)n * stride);
-  HIPCHK(hipMemcpyAsync(tmp.data(), src + (size_t)env0 * stride, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  std::vector<float> tmp((size_t)n * width);
+  HIPCHK(hipMemcpy2DAsync(tmp.data(), (size_t)width * sizeof(float), src + (size_t)env0 * stride, (size_t)stride * sizeof(float),
+                          (size_t)width * sizeof(float), (size_t)n, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
-  for (int i = 0; i < n; i++) for (int k = 0; k < width; k++) dst[(size_t)i * width + k] = (double)tmp[(size_t)i * stride + k];
+  for (size_t i = 0; i < tmp.size(); i++) dst[i] = (double)tmp[i];
   return MJH_OK;
 }
 
