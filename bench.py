@@ -1,18 +1,18 @@
 #!/usr/bin/env python
-"""bench.py — env-steps/sec of the S24 scene (BASELINE.json metric) on N MI355X.
+"""bench.py — env-steps/sec of the BASELINE.json configs on N MI355X (default: S24, the metric's scene).
 
-A "step" is one pass of the hot path — mj_step1 + controller + mj_step2
-(reference loop body, src/mj_main.cpp:82-112) — over one batch of 4096 environments
-per GPU, ONE kernel launch per step (the drop-in keeps the reference's per-step host
-hand-off to ros_control).  Inputs are resident in HBM when the timed region starts.
+A "step" is one pass of the hot path — mj_step1 + controller + [mj_inverse] + mj_step2 (reference loop body,
+src/mj_main.cpp:82-112) — over one batch of environments per GPU, one launch per step and cohort (the drop-in keeps the
+reference's per-step host hand-off to ros_control).  Inputs are resident in HBM when the timed region starts.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config s24|c2|c3|c4|c5]
 
-N > 1: launched by torch.distributed.run, one rank per GPU; environments are sharded
-(rank r owns envs [r*4096, (r+1)*4096)), no data-path collective; the only collective is the
-RCCL all-gather of the published state slice at 60 Hz of simulated time.  The slice is packed
-(mjh_export_state_device) at that rate at every N, so that per-GPU work does not depend on N.
-Prints ONE JSON line on rank 0.
+Every config first runs its FIXED, untimed settle phase (S24 400 steps, C2 200, ...) — independent
+of --warmup — so that the timed window always steps the scene the metric names; then W untimed warm-up steps, then EXACTLY K
+timed steps bracketed by barrier + synchronize.  N > 1: launched by torch.distributed.run, one rank per GPU; environments
+are sharded (rank r owns envs [r*n, (r+1)*n)), no data-path collective; the only collective is the RCCL all-gather of the
+published state slice at 60 Hz of simulated time, packed (mjh_export_state_device) at that rate at every N
+so that per-GPU work does not depend on N.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -29,8 +29,9 @@ sys.path.insert(0, ROOT)
 # publish path).  Must be set before the HIP runtime initialises, i.e. before torch is imported.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-ENVS_PER_GPU = 4096
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (~6.3 TB/s achievable)
+METRIC = "env-steps/sec (whole node) at 4096 envs, 24-DoF/30-contact scene; 1/2/4/8 GPUs"
+GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 def algorithmic_bytes_per_env_step(nq, nv):
@@ -38,39 +39,234 @@ def algorithmic_bytes_per_env_step(nq, nv):
     return 4 * (2 * nq + 6 * nv)
 
 
-def cpu_baseline(model, eng, tab, env_offset, sample_envs, sample_steps, with_inverse=0):
-    """Oracle (fp64 C restatement, test infrastructure) timed on the host cores on a bounded
-    sample of the SAME workload: the first `sample_envs` envs, started from the GPU's settled state."""
+def robot_command(m, k):
+    """commanded joint accelerations of the robot fixtures (same generator as tests/test_robot_fixtures.py)"""
+    jt = m.array("jnt_type"); da = m.array("jnt_dofadr")
+    ddq = np.zeros(m.nv)
+    for j in range(m.njnt):
+        if jt[j] in (2, 3):
+            ddq[da[j]] = 0.8 * np.sin(0.05 * k + 0.37 * j)
+    return ddq
+
+
+class Workload:
+    """One BASELINE.json config as concrete inputs.  `inverse` = the ros_control read path
+    (mj_inverse every step, mj_hw_interface.cpp:61): the robot configs always pay it, as the reference does."""
+    name = ""; label = ""; envs_per_gpu = 4096; settle_steps = 0; inverse = False; min_ncon = None
+
+    def __init__(self, ms, args, rank, device, stream):
+        self.ms = ms; self.args = args; self.rank = rank
+        self.nenv = args.envs_per_gpu or self.envs_per_gpu
+        self.env_offset = rank * self.nenv
+        self.tab = None; self.step_count = 0
+        self.build(device, stream)
+
+    # -- hooks
+    def build(self, device, stream): raise NotImplementedError
+    def before_step(self, k): pass                     # host-side work of step k of the run (service calls, new targets)
+    def oracle_data(self, orc, i, state): raise NotImplementedError
+    def extra_config(self): return {}
+
+    def step(self, n, inverse):
+        for _ in range(n):
+            self.before_step(self.step_count)
+            self.eng.step(1, inverse)
+            self.step_count += 1
+
+
+class S24(Workload):
+    name = "s24"; settle_steps = 400; min_ncon = 8.0
+    label = "S24: 4 free boxes (24 DoF) in a walled pen on the empty.xml floor, PGS 100 it / tol 1e-8"
+
+    def build(self, device, stream):
+        self.model = self.ms.scene("s24")
+        if self.args.maxcon > 0:
+            self.model.c.maxcon = self.args.maxcon; self.model.c.maxefc = 6 * self.args.maxcon
+        self.eng = self.ms.Engine(self.model, self.nenv, device=device, stream=stream)
+        self.tab = self.eng.load_s24(env_offset=self.env_offset)
+
+    def oracle_data(self, orc, i, state):
+        from mujoco_sim_amd.engine import EP
+        d = orc.OrcData(self.model.ptr)
+        for k, wh in EP.items():
+            d.set_env_param(wh, self.tab[k][i])
+        return d
+
+
+class C2(S24):
+    name = "c2"; settle_steps = 200; min_ncon = None
+    label = ("C2: 64 free boxes (nv 384), half-extents U[0.05,0.125]^3, 4x4x4 lattice (pitch 0.3 m, z0 0.5..1.4) with +-0.01 m jitter and "
+             "random orientation, on the empty.xml floor")
+
+    def build(self, device, stream):
+        self.model = self.ms.scene("boxpile", 64)
+        mc = self.args.maxcon if self.args.maxcon > 0 else 600
+        self.model.c.maxcon = mc; self.model.c.maxefc = 4 * mc
+        self.eng = self.ms.Engine(self.model, self.nenv, device=device, stream=stream)
+        self.tab = self.eng.load_tables(self.ms.boxes_randomize(self.model, self.env_offset, self.nenv, jitter=0.01))
+
+    def extra_config(self):
+        st = self.eng.get_stats()
+        hist, edges = np.histogram(st[:, 0], bins=[0, 64, 128, 192, 256, 320, 384, 448, 512, 100000])
+        return {"ncon_histogram": {f"{int(edges[i])}-{int(edges[i + 1]) - 1}" if i < 8 else "512+": int(hist[i]) for i in range(9)}}
+
+
+class C3(Workload):
+    name = "c3"; envs_per_gpu = 8192; settle_steps = 200; inverse = True
+    label = ("C3: 7-hinge Panda chain (limits of ridgeback_panda.xml:53-87), fixed base, gravcomp 1, computed-torque wrapper + mj_inverse, "
+             "PD ddq = 200 (q* - q) - 50 qd in the engine, targets U[limits] re-drawn every 200 steps")
+
+    def build(self, device, stream):
+        self.model = self.ms.scene("arm7", 1)
+        self.eng = self.ms.Engine(self.model, self.nenv, device=device, stream=stream)
+        self.eng.set_controlled_dofs(np.ones(self.model.nv, dtype=np.int32))
+        self.rng = np.random.default_rng(0xC3 + self.rank)
+        self.lo, self.hi = self.model.array("jnt_range").reshape(-1, 2).T
+        self.eng.set_pd_controller(200.0, 50.0)          # box.yaml:8 (integral term dropped, as SURVEY §8-d D3 states)
+        self.target = None
+
+    def before_step(self, k):
+        if k % 200 == 0:
+            self.target = self.rng.uniform(self.lo, self.hi, size=(self.nenv, self.model.nv))
+            self.eng.set_pd_target(self.target)
+
+    def oracle_data(self, orc, i, state):
+        d = orc.OrcData(self.model.ptr)
+        d.ifield("controlled")[:] = 1
+        d.set_pd(self.target[i], 200.0, 50.0)
+        return d
+
+
+class RobotFixture(Workload):
+    fixture = ""; inverse = True
+
+    def build(self, device, stream):
+        from mujoco_sim_amd.tables import load_model_tables
+        self.model, self.z = load_model_tables(os.path.join(GOLD, f"robot_{self.fixture}.npz"))
+        self.eng = self.ms.Engine(self.model, self.nenv, device=device, stream=stream)
+        self.controlled = self.z["controlled"].astype(np.int32)
+        self.eng.set_controlled_dofs(self.controlled)
+
+    def oracle_data(self, orc, i, state):
+        d = orc.OrcData(self.model.ptr)
+        d.ifield("controlled")[:] = self.controlled
+        return d
+
+
+class C4(RobotFixture):
+    name = "c4"; envs_per_gpu = 2048; settle_steps = 200; fixture = "c4_pr2_world_objects_mesh"
+    label = ("C4: PR2 (nv 49, 6 joint equalities, 37 mesh geoms as convex hulls) on the reference floor + pool of 8 spawnable objects in one "
+             "model, computed-torque wrapper + mj_inverse, every 100 steps 1/16 of the envs get one object spawned and one destroyed")
+
+    def build(self, device, stream):
+        super().build(device, stream)
+        lib = self.ms.capi.load()
+        names = [lib.mjh_id2name(self.model.ptr, 0, b).decode() for b in range(self.model.c.nbody)]
+        self.slots = [b for b, n in enumerate(names) if n.startswith("object_")]
+        for b in self.slots:
+            self.eng.set_slot_active(b, False)                      # the pool starts empty
+        self.active = np.zeros((self.nenv, len(self.slots)), dtype=bool)
+        self.rng = np.random.default_rng(0xC4 + self.rank)
+        self.service_s = 0.0; self.service_calls = 0
+
+    def churn(self):
+        """spawn_objects / destroy_objects (mj_ros.cpp:859-1507) as slot toggles + initial pose and twist (mj_ros.cpp:1406-1412)"""
+        e = self.eng
+        t0 = time.perf_counter()
+        for i in self.rng.choice(self.nenv, max(1, self.nenv // 16), replace=False):
+            off = np.nonzero(~self.active[i])[0]; on = np.nonzero(self.active[i])[0]
+            if len(on) > 2:
+                k = int(self.rng.choice(on)); e.set_slot_active(self.slots[k], False, env0=int(i), n=1); self.active[i, k] = False
+            if len(off):
+                k = int(self.rng.choice(off)); a = self.rng.uniform(-np.pi, np.pi); r = self.rng.uniform(0.8, 1.5)
+                e.set_slot_active(self.slots[k], True, env0=int(i), n=1)
+                e.set_body_pose(int(i), self.slots[k], [r * np.sin(a), r * np.cos(a), 2.0], [1, 0, 0, 0], [0, 0, 0, 0, 0, 0])
+                self.active[i, k] = True
+        self.service_s += time.perf_counter() - t0; self.service_calls += 1
+
+    def before_step(self, k):
+        if k < self.settle_steps:
+            if k % 25 == 24:
+                self.churn()                                        # fill the pools a little while settling
+            if k % 10 == 0:
+                self.eng.set_cmd(ddq=np.tile(robot_command(self.model, k), (self.nenv, 1)))
+        elif (k - self.settle_steps) % 100 == 0:
+            self.churn()
+
+    def oracle_data(self, orc, i, state):
+        d = super().oracle_data(orc, i, state)
+        sbase = self.model.c.nbody - 32 if self.model.c.nbody > 32 else 0
+        mask = 0
+        for k, b in enumerate(self.slots):
+            if not self.active[i, k]:
+                mask |= 1 << (b - sbase)
+        orc.lib().orc_set_slot_mask(d.d, mask)
+        return d
+
+    def extra_config(self):
+        return {"objects_alive_per_env": float(self.active.sum(1).mean()),
+                "service_ms_per_churn": 1e3 * self.service_s / max(self.service_calls, 1), "churns": self.service_calls}
+
+
+class C5(RobotFixture):
+    name = "c5"; envs_per_gpu = 4096; settle_steps = 100; fixture = "c5_pendulum_bowl_mesh"
+    label = ("C5: multi_mujoco_sim.launch scene (pendulum.xml world + static bowl.xml, 37 mesh geoms), 32768 envs over 8 GPUs = 4096 per GPU, "
+             "mj_inverse every step, state all-gather at 60 Hz")
+
+    def build(self, device, stream):
+        super().build(device, stream)
+        rng = np.random.default_rng(0xC5 + self.rank)
+        if "qvel0" in self.z and np.any(self.z["qvel0"]):      # per-env spin so that the envs differ
+            self.eng.set_state(qvel=self.z["qvel0"][None, :] * rng.uniform(0.5, 1.5, size=(self.nenv, 1)))
+
+
+WORKLOADS = {w.name: w for w in (S24, C2, C3, C4, C5)}
+
+
+def cpu_baseline(w, sample_envs, budget_s, with_inverse):
+    """Oracle (fp64 C restatement, test infrastructure) timed on the host cores on a bounded sample of the SAME workload:
+    the first `sample_envs` envs, started from the state the GPU holds when the timed window ends."""
     import ctypes as C
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
-    from mujoco_sim_amd.engine import EP
 
     L = orc.lib()
-    t, q, v, w = eng.get_state(0, sample_envs)
+    eng = w.eng
+    sample_envs = min(sample_envs, w.nenv)
+    t, q, v, ws = eng.get_state(0, sample_envs)
+    st = eng.get_stats(0, sample_envs)
     ds = []
     for i in range(sample_envs):
-        d = orc.OrcData(model.ptr)
-        for k, wh in EP.items():
-            d.set_env_param(wh, tab[k][i])
-        d.set_qpos(q[i]); d.f("qvel")[:] = v[i]; d.f("qacc_warmstart")[:] = w[i]
+        d = w.oracle_data(orc, i, None)
+        d.set_qpos(q[i]); d.f("qvel")[:] = v[i]; d.f("qacc_warmstart")[:] = ws[i]; d.f("qacc")[:] = ws[i]
         ds.append(d)
     arr = (C.c_void_p * sample_envs)(*[d.d for d in ds])
     ncores = os.cpu_count() or 1
+    # calibration pass (2 steps of up to one env per core), then a sample sized for the time budget
+    L.orc_set_threads(ncores)
+    ncal = min(sample_envs, ncores)
+    t0 = time.perf_counter(); L.orc_step_many(arr, ncal, 2, int(with_inverse)); cal = time.perf_counter() - t0
+    rate = 2 * ncal / max(cal, 1e-6)
+    steps = int(max(2, min(200, budget_s * rate / sample_envs)))
     out = {}
     for label, threads in (("mt", ncores), ("st", 1)):
-        n_envs = sample_envs if threads > 1 else max(1, min(sample_envs, 8))
+        n_envs = sample_envs if threads > 1 else max(1, min(sample_envs, 4))
+        n_steps = steps if threads > 1 else int(max(2, min(steps, budget_s * 0.25 * (rate / ncal) / n_envs)))
         L.orc_set_threads(threads)
         t0 = time.perf_counter()
-        L.orc_step_many(arr, n_envs, sample_steps, with_inverse)
+        L.orc_step_many(arr, n_envs, n_steps, int(with_inverse))
         dt = time.perf_counter() - t0
-        out[label] = n_envs * sample_steps / dt
-    rows = float(np.mean([d.i("nefc") for d in ds]))
+        out[label] = n_envs * n_steps / dt
+        out[label + "_steps"] = n_steps
+    nefc = float(np.mean([d.i("nefc") for d in ds])); ncon = float(np.mean([d.i("ncon") for d in ds]))
     return {
         "value": out["mt"], "unit": "env-steps/s", "cores": ncores, "kind": "port",
-        "value_1thread": out["st"],
-        "sample": f"oracle/ fp64 C restatement (PGS, dense AR), first {sample_envs} S24 envs from the GPU's settled state, "
-                  f"{sample_steps} steps, OpenMP over envs; mean nefc {rows:.0f}; reference library (libmujoco 2.3.7) absent",
+        "value_1thread": out["st"], "mean_nefc": nefc, "mean_ncon": ncon,
+        "gpu_mean_nefc_same_envs": float(st[:, 1].mean()), "gpu_mean_ncon_same_envs": float(st[:, 0].mean()),
+        "with_inverse": bool(with_inverse),
+        "sample": f"oracle/ fp64 C restatement (PGS in MuJoCo's dense-AR form), first {sample_envs} {w.name} envs started from the GPU's state at the end "
+                  f"of the timed window, {out['mt_steps']} steps, OpenMP over envs ({ncores} threads; 1-thread figure: {out['st_steps']} steps of "
+                  f"{max(1, min(sample_envs, 4))} envs); reference library (libmujoco 2.3.7) absent from this image",
     }
 
 
@@ -78,17 +274,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=400)
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
-    ap.add_argument("--with-inverse", type=int, default=0, help="also run mj_inverse every step (MjHWInterface::read)")
-    ap.add_argument("--fuse", type=int, default=1, help="steps between host hand-offs (one kernel launch per step either way)")
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="s24", help="BASELINE.json config (default: the metric's scene, S24)")
+    ap.add_argument("--envs-per-gpu", type=int, default=0, help="0 = the config's size (S24/C2/C5 4096, C3 8192, C4 2048)")
+    ap.add_argument("--with-inverse", type=int, default=-1, help="mj_inverse every step in the MAIN timed window (-1: the config's default; the other variant is timed in a second window)")
     ap.add_argument("--cohorts", type=int, default=-1, help="env cohorts stepped on separate HIP streams (-1: engine default)")
-    ap.add_argument("--maxcon", type=int, default=0, help="override the scene's contact capacity per env (rows: 6 per contact); 0 = scene default (40)")
+    ap.add_argument("--maxcon", type=int, default=0, help="override the scene's contact capacity per env; 0 = scene default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-second-window", action="store_true", help="skip the second timed window (the other mj_inverse variant)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the publish all-gather even with one rank (self-test of the multi-GPU path)")
     ap.add_argument("--cpu-envs", type=int, default=1024)
-    ap.add_argument("--cpu-steps", type=int, default=100)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time budget of the CPU baseline sample")
     args = ap.parse_args()
 
     import torch
@@ -111,92 +308,110 @@ def main():
 
     import mujoco_sim_amd as ms
 
-    model = ms.scene("s24")
-    if args.maxcon > 0:
-        model.c.maxcon = args.maxcon; model.c.maxefc = 6 * args.maxcon
-    nenv = args.envs_per_gpu
     stream = torch.cuda.current_stream()
-    eng = ms.Engine(model, nenv, device=local_rank, stream=stream.cuda_stream)
-    tab = eng.load_s24(env_offset=rank * nenv)
+    w = WORKLOADS[args.config](ms, args, rank, local_rank, stream.cuda_stream)
+    eng, model, nenv = w.eng, w.model, w.nenv
     if args.cohorts > 0:
         eng.set_cohorts(args.cohorts)
+    main_inverse = w.inverse if args.with_inverse < 0 else bool(args.with_inverse)
     stride = eng.state_stride
     pub = torch.empty(nenv * stride, dtype=torch.float32, device="cuda")
     gathered = torch.empty(world * nenv * stride, dtype=torch.float32, device="cuda") if use_dist else None
     publish_every = max(1, int(round(1.0 / (60.0 * model.opt.timestep))))  # 60 Hz of simulated time
 
-    def run(nsteps):
-        s = 0
-        while s < nsteps:
-            k = min(args.fuse, nsteps - s)
-            eng.step(k, args.with_inverse)
-            s += k
-            if not args.no_gather and (s % publish_every) < k:   # 60 Hz publish: packed state slice (+ RCCL all-gather)
+    def run(nsteps, inverse):
+        for _ in range(nsteps):
+            w.step(1, inverse)
+            if not args.no_gather and w.step_count % publish_every == 0:   # 60 Hz publish: packed state slice (+ RCCL all-gather)
                 eng.export_state_device(pub.data_ptr())
                 if use_dist:
                     dist.all_gather_into_tensor(gathered, pub)
 
-    run(args.warmup)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # the engine brackets every step-kernel launch with HIP events on the stream it is launched on (cohort streams)
-    eng.set_launch_timing(True)
-    t0 = time.perf_counter()
-    run(args.steps)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    kernel_ms, n_launches = eng.get_launch_timing()
-    eng.set_launch_timing(False)
-    cohorts = eng.cohorts
+    def timed(nsteps, inverse):
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.set_launch_timing(True)   # HIP events around every step launch on the stream it is launched on (cohort streams)
+        t0 = time.perf_counter()
+        run(nsteps, inverse)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        kernel_ms, n_launches = eng.get_launch_timing()
+        eng.set_launch_timing(False)
+        return elapsed, kernel_ms, n_launches
 
+    # 1. the config's fixed settle phase — NOT --warmup: whatever the driver passes, the timed window steps the settled scene
+    run(w.settle_steps, main_inverse)
+    # 2. warm-up, 3. the timed window
+    run(args.warmup, main_inverse)
+    elapsed, kernel_ms, n_launches = timed(args.steps, main_inverse)
     st = eng.get_stats()
     total_envs = nenv * world
     value = total_envs * args.steps / elapsed
+    cohorts = eng.cohorts
     bytes_step = algorithmic_bytes_per_env_step(model.nq, model.nv)
     envs_per_launch = nenv * args.steps / max(n_launches, 1)   # one launch = one step of one cohort
     achieved = bytes_step * envs_per_launch / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    valu_busy = None
+
+    # 4. the other mj_inverse variant, same K steps (the reference always pays mj_inverse,
+    # mj_hw_interface.cpp:61 — report both)
+    other = None
+    if not args.no_second_window:
+        e2, k2, n2 = timed(args.steps, not main_inverse)
+        other = {"value": total_envs * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3, "kernel_ms": k2}
+
+    # committed rocprofv3 PMC measurement of this config (profiles/), per launch: provenance stated, never re-measured here
+    traffic = traffic_src = valu_busy = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
-            tj = json.load(open(tpath))   # rocprofv3 PMC measurement of the committed profile run, per launch
-            traffic = tj.get("bytes_per_launch")
-            valu_busy = tj.get("valu_issue_busy")
-            if traffic is not None and tj.get("envs_per_launch"):
-                traffic = traffic * envs_per_launch / tj["envs_per_launch"]
+            tj = json.load(open(tpath))
+            tj = tj.get(w.name, tj if (w.name == "s24" and "bytes_per_launch" in tj) else None)
+            if tj and tj.get("bytes_per_launch") and tj.get("envs_per_launch"):
+                traffic = tj["bytes_per_launch"] * envs_per_launch / tj["envs_per_launch"]
+                valu_busy = tj.get("valu_issue_busy")
+                traffic_src = f"profiles/{tj.get('tag', '?')} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this config, scaled to this run's envs per launch; not measured in this run)"
         except Exception:
             traffic = None
+    mean_ncon = float(st[:, 0].mean())
+    unsettled = w.min_ncon is not None and mean_ncon < w.min_ncon
+    key_inv, key_no = ("value", "value_without_inverse") if main_inverse else ("value_with_inverse", "value")
     out = {
-        "metric": "env-steps/sec (whole node) at 4096 envs, 24-DoF/30-contact scene; 1/2/4/8 GPUs",
+        "metric": METRIC if w.name == "s24" else f"env-steps/sec (whole node), BASELINE config {w.name.upper()}",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "S24: 4 free boxes (24 DoF) in a walled pen on the empty.xml floor, PGS 100 it / tol 1e-8",
-                   "envs_per_gpu": nenv, "envs_total": total_envs, "steps_per_launch": 1, "steps_per_call": args.fuse, "cohorts": cohorts,
-                   "with_inverse": bool(args.with_inverse), "parallelism": f"env-sharded x{world}",
-                   "mean_ncon": float(st[:, 0].mean()), "max_ncon": int(st[:, 0].max()), "mean_nefc": float(st[:, 1].mean()),
+        "config": {"workload": w.label, "name": w.name, "settle_steps": w.settle_steps, "envs_per_gpu": nenv, "envs_total": total_envs,
+                   "steps_per_launch": 1, "cohorts": cohorts, "with_inverse": bool(main_inverse), "parallelism": f"env-sharded x{world}",
+                   "nq": int(model.nq), "nv": int(model.nv),
+                   "mean_ncon": mean_ncon, "max_ncon": int(st[:, 0].max()), "mean_nefc": float(st[:, 1].mean()),
                    "max_nefc": int(st[:, 1].max()), "mean_solver_iter": float(st[:, 2].mean()),
                    "overflow_envs": int((st[:, 3] & 3 != 0).sum()), "reset_envs": int((st[:, 3] & 4 != 0).sum()),
-                   "lds_bytes_per_env": eng.lds_bytes, "contact_capacity": int(model.maxcon)},
+                   "lds_bytes_per_env": eng.lds_bytes, "contact_capacity": int(model.maxcon), **w.extra_config()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": "mjh_step_kernel", "kernel_ms": kernel_ms,
-                     "launches": n_launches, "envs_per_launch": envs_per_launch, "concurrent_launches": cohorts,
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "mjh_step_kernel" + (" (+ mjh_solve_kernel: three-launch step of the many-body layout)" if eng.lds_bytes > 24 * 1024 or model.nv > 64 else ""),
+                     "kernel_ms": kernel_ms, "launches": n_launches, "envs_per_launch": envs_per_launch, "concurrent_launches": cohorts,
                      "algorithmic_bytes_per_env_step": bytes_step,
-                     "valu_issue_busy": valu_busy,   # SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x resident waves per SIMD (profiles/): the binding resource
-                     "note": "fused per-env pipeline keeps intermediates in LDS: the path is VALU-issue bound, far below the HBM roofline by design (DESIGN.md)"},
+                     "valu_issue_busy": valu_busy, "valu_issue_busy_source": traffic_src,
+                     "note": "fused per-env pipeline keeps intermediates in LDS: the path is issue/latency bound, far below the HBM roofline by design (DESIGN.md §4)"},
     }
+    if other is not None:
+        out[key_inv if not main_inverse else key_no] = other["value"]
+        out["second_window"] = {"with_inverse": not main_inverse, **other}
+    if unsettled:
+        out["unsettled"] = True; out["valid"] = False
+        out["note"] = f"mean_ncon {mean_ncon:.1f} < {w.min_ncon}: the scene is not in the state the metric names — do not use `value`"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is timed at N = 1 only
-        out["cpu_baseline"] = cpu_baseline(model, eng, tab, 0, min(args.cpu_envs, nenv), args.cpu_steps, args.with_inverse)
+        out["cpu_baseline"] = cpu_baseline(w, args.cpu_envs, args.cpu_seconds, main_inverse)
     if use_dist:
         dist.barrier()
     eng.close()

@@ -222,6 +222,13 @@ int mjh_scene_s24_randomize(const mjh_model*, int env0, int nenv, unsigned seed_
                             double* qpos, double* geom_size, double* geom_rbound,
                             double* body_mass, double* body_inertia,
                             double* body_invweight0, double* dof_invweight0);
+/* per-env randomisation of any scene of free boxes (C2): half-extents U[0.05,0.125]^3 with the mass /
+ * inertia / inverse weights that follow, lattice position = the model's qpos0 + U[-jitter,jitter]^3, uniformly random
+ * orientation; same table layout and seeding as mjh_scene_s24_randomize */
+int mjh_scene_boxes_randomize(const mjh_model*, int env0, int nenv, unsigned seed_base, double jitter,
+                              double* qpos, double* geom_size, double* geom_rbound,
+                              double* body_mass, double* body_inertia,
+                              double* body_invweight0, double* dof_invweight0);
 mjh_model* mjh_scene_pendulum(void);          /* model/test/pendulum.xml restated (C1/C5) */
 mjh_model* mjh_scene_arm7(int gravcomp);      /* 7-hinge Panda-like chain with limits (C3) */
 mjh_model* mjh_scene_boxpile(int nbox);       /* nbox free boxes over the floor (C2 family) */
@@ -257,6 +264,15 @@ int mjh_synchronize(mjh_engine*);
  * (interpreted as desired acceleration), dq = velocity command; [n*nv] each,
  * either may be NULL.  Consumed (and zeroed, mj_sim.cpp:1075-1076) by the next step1. */
 int mjh_set_cmd(mjh_engine*, int env0, int n, const double* ddq, const double* dq);
+/* In-engine joint-space PD effort controller for ALL environments.  The reference closes this loop on the host for its one
+ * environment: read() -> controller_manager->update() -> write() (mj_main.cpp:86-106) with ros_control effort controllers
+ * (PID p 200 d 50: model/ontology/box/box.yaml:5-13) whose output MjSim::controller treats as a desired acceleration
+ * (mj_sim.cpp:1057).  With thousands of environments the same law runs on the device in front of every step:
+ * ddq[d] = kp (target[d] - qpos[d]) - kd qvel[d] on every hinge / slide dof (other dofs untouched), consumed by the controller
+ * stage of mj_step1 exactly like a command written with mjh_set_cmd.  kp = kd = 0 switches it off.  Targets default to qpos0;
+ * mjh_set_pd_target takes [n*nv] values indexed by dof. */
+int mjh_set_pd_controller(mjh_engine*, double kp, double kd);
+int mjh_set_pd_target(mjh_engine*, int env0, int n, const double* target);
 /* which dofs are "controlled" (MjSim::controlled_joints, mj_sim.cpp:1058-1063): mask[nv] */
 int mjh_set_controlled_dofs(mjh_engine*, const int* mask);
 /* MjSim::set_odom_vels (mj_sim.cpp:1079-1153): dof ids of the 6 odom joints of one
@@ -272,7 +288,10 @@ int mjh_get_joint_state(mjh_engine*, int env0, int n, double* qpos, double* qvel
 int mjh_get_body_state(mjh_engine*, int env0, int n, double* xpos, double* xquat);
 /* d->geom_xpos / geom_xmat readers (mj_ros.cpp:1968-2094) */
 int mjh_get_geom_state(mjh_engine*, int env0, int n, double* geom_xpos, double* geom_xmat);
-/* full state: time, qpos, qvel, qacc_warmstart (add_old_state, mj_sim.cpp:465-558) */
+/* full state: time, qpos, qvel, qacc_warmstart (add_old_state, mj_sim.cpp:465-558).  `time` is kept in fp64 on the device
+ * (d->time is mjtNum: the ROS stamps, the 10 kHz controller gate and the real-time factor of mj_main.cpp:85,115-163 read
+ * it): after n steps it equals n * opt.timestep to fp64 round-off, however long the simulation runs; only the packed
+ * fp32 publish slice (mjh_export_state_device) rounds it */
 int mjh_get_state(mjh_engine*, int env0, int n, double* time, double* qpos, double* qvel,
                   double* qacc_warmstart);
 int mjh_set_state(mjh_engine*, int env0, int n, const double* time, const double* qpos,
@@ -285,7 +304,9 @@ int mjh_get_field(mjh_engine*, const char* name, int env0, int n, double* out);
 /* per-env solver statistics: ncon, nefc, solver iterations, flags (bit0 contact overflow,
  * bit1 row overflow, bit2 NaN reset) — int[n*4] */
 int mjh_get_stats(mjh_engine*, int env0, int n, int* out);
-/* contacts of ONE env (debug/parity): dist[maxcon], pos[3*maxcon], frame[9*maxcon], geom[2*maxcon]; returns ncon or <0 */
+/* contacts of ONE env (debug/parity): dist[maxcon], pos[3*maxcon], frame[9*maxcon], geom[2*maxcon]; returns ncon or <0.
+ * Read-only: runs the position stage of that env into a scratch buffer; state, statistics, warm start and time are untouched
+ * (it may be called between mjh_step1 and mjh_step2) */
 int mjh_get_contacts(mjh_engine*, int env, double* dist, double* pos, double* frame, int* geom);
 
 /* per-env model parameters (enum mjh_env_param) */
@@ -331,6 +352,8 @@ void mjh_mirror_destroy(mjh_mirror*);
 int mjh_mirror_update(mjh_mirror*, int what);
 int mjh_mirror_wait(mjh_mirror*);
 const float* mjh_mirror_field(const mjh_mirror*, int which, int* row_width);
+/* the mirrored simulation time of the n environments in fp64 (field MJH_MIRROR_TIME holds the same doubles: row_width 2 floats) */
+const double* mjh_mirror_time(const mjh_mirror*);
 
 /* debug: mean shader-clock ticks from kernel start to each of the 16 stage boundaries of one fused step */
 int mjh_debug_stage_cycles(mjh_engine*, int with_inverse, double* out16);

@@ -126,6 +126,7 @@ SYMBOLS = [
     ("mjh_load_set_robot_pose", None, [C.c_char_p, c_double_p]),
     ("mjh_scene_s24", Model_p, []),
     ("mjh_scene_s24_randomize", C.c_int, [Model_p, C.c_int, C.c_int, C.c_uint] + [c_double_p] * 7),
+    ("mjh_scene_boxes_randomize", C.c_int, [Model_p, C.c_int, C.c_int, C.c_uint, C.c_double] + [c_double_p] * 7),
     ("mjh_scene_pendulum", Model_p, []),
     ("mjh_scene_arm7", Model_p, [C.c_int]),
     ("mjh_scene_boxpile", Model_p, [C.c_int]),
@@ -139,6 +140,8 @@ SYMBOLS = [
     ("mjh_mulM", C.c_int, [_vp, C.c_int, C.c_int, c_double_p, c_double_p]),
     ("mjh_synchronize", C.c_int, [_vp]),
     ("mjh_set_cmd", C.c_int, [_vp, C.c_int, C.c_int, c_double_p, c_double_p]),
+    ("mjh_set_pd_controller", C.c_int, [_vp, C.c_double, C.c_double]),
+    ("mjh_set_pd_target", C.c_int, [_vp, C.c_int, C.c_int, c_double_p]),
     ("mjh_set_controlled_dofs", C.c_int, [_vp, c_int_p]),
     ("mjh_set_odom_dofs", C.c_int, [_vp, c_int_p, c_int_p, c_int_p]),
     ("mjh_set_odom_vel", C.c_int, [_vp, C.c_int, C.c_int, c_double_p]),
@@ -163,6 +166,7 @@ SYMBOLS = [
     ("mjh_mirror_update", C.c_int, [_vp, C.c_int]),
     ("mjh_mirror_wait", C.c_int, [_vp]),
     ("mjh_mirror_field", C.POINTER(C.c_float), [_vp, C.c_int, C.POINTER(C.c_int)]),
+    ("mjh_mirror_time", c_double_p, [_vp]),
     ("mjh_debug_stage_cycles", C.c_int, [_vp, C.c_int, c_double_p]),
     ("mjh_debug_stage_raw", C.c_int, [_vp, C.c_int, _vp]),
     ("mjh_debug_stop_at", C.c_int, [_vp, C.c_int, C.c_int]),

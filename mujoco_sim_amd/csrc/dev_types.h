@@ -35,12 +35,14 @@ struct DModel {
   int o_geom_dataid, o_mesh_vertadr, o_mesh_vertnum, o_mesh_vert;
   // noslip post-pass (EXTRA instances)
   int noslip_iterations; float noslip_tolerance;
+  double timestep_d;   // opt.timestep in fp64: per-env time advances by exactly this (time == n * dt after n steps)
 };
 
 // per-env state in HBM (fp32, env-major rows)
 #define PROF_STRIDE 20   // x_prof: 16 stage stamps (shader clock), [16],[17] wall clock start/end, [18] HW_ID|XCC_ID<<32
 struct DState {
-  float *qpos, *qvel, *qacc, *qacc_ws, *qvel_ref, *qfrc_applied, *ddq, *dq, *qfrc_inverse, *time;
+  float *qpos, *qvel, *qacc, *qacc_ws, *qvel_ref, *qfrc_applied, *ddq, *dq, *qfrc_inverse;
+  double* time;  // [nenv] simulation time in fp64 (d->time is mjtNum: ROS stamps, the 10 kHz gate and the RTF logic read it)
   float *initial_qpos, *odom_vel;
   int* stats;  // [nenv*4]: ncon, nefc, solver iterations, flags
   const int* env_order;  // launch order of the envs (longest job first) or null
@@ -89,7 +91,8 @@ enum { PH_STEP1 = 1, PH_INV = 2, PH_STEP2 = 4, PH_NOINT = 8, PH_FKONLY = 16, PH_
        // many-body layout only: the fused step as three launches  assemble (PH_PRE) -> mjh_solve_kernel -> integrate (PH_POST)
        PH_PRE = 128, PH_POST = 256 };
 // export flags
-enum { XF_BODY = 1, XF_GEOM = 2, XF_CON = 4, XF_FORCE = 8, XF_PROF = 16 };
+enum { XF_BODY = 1, XF_GEOM = 2, XF_CON = 4, XF_FORCE = 8, XF_PROF = 16,
+       XF_NOSTORE = 32 };   // read-only launch: nothing of the env's state, statistics or time is written back
 
 #define CON_STRIDE 16  // dist, pos3, frame9, [13] geom1 | geom2 << 12 | dim << 24, [14] includemargin, [15] pad
 #define CON_GEOMS 13

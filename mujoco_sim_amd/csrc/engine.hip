@@ -26,6 +26,19 @@ void mjh_set_error(const std::string& s);  // model_builder.cpp
     }                                                                                            \
   } while (0)
 
+// restores the engine's device-state descriptor when a scope that patched it (export pointers, launch order) is left on
+// ANY path, early error returns included
+struct StateGuard {
+  DState* where; DState saved;
+  explicit StateGuard(DState* w) : where(w), saved(*w) {}
+  ~StateGuard() { *where = saved; }
+  StateGuard(const StateGuard&) = delete; StateGuard& operator=(const StateGuard&) = delete;
+};
+struct DevBuf {   // temporary device allocation freed on every path
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
 #define MJH_MAX_COHORTS 8
 struct mjh_engine {
   const mjh_model* model = nullptr;
@@ -56,6 +69,8 @@ struct mjh_engine {
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> tev; size_t tev_used = 0;
   bool step1_done = false;
+  // in-engine joint-space PD effort controller (mjh_set_pd_controller): ddq written on the device in front of every step
+  float pd_kp = 0, pd_kd = 0; float* pd_target = nullptr; bool pd_on = false;
 };
 
 static int pad32(int n) { return ((n + 31) / 32) * 32; }
@@ -228,7 +243,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     M.maxblk = nfix + M.maxcon; M.maxbrow = nfix + 4 * M.maxcon;
   }
   M.iterations = m->opt.iterations; M.disableflags = m->opt.disableflags;
-  M.timestep = (float)m->opt.timestep; for (int k = 0; k < 3; k++) M.gravity[k] = (float)m->opt.gravity[k];
+  M.timestep = (float)m->opt.timestep; M.timestep_d = m->opt.timestep; for (int k = 0; k < 3; k++) M.gravity[k] = (float)m->opt.gravity[k];
   M.tolerance = (float)m->opt.tolerance; M.impratio = (float)m->opt.impratio; M.meaninertia = (float)m->meaninertia;
   M.noslip_iterations = m->opt.noslip_iterations; M.noslip_tolerance = (float)m->opt.noslip_tolerance;
   // ---- LDS layout (float offsets, 16-byte aligned)
@@ -334,6 +349,9 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     mjh_set_error("mjh_create: condim must be 1, 3 or 4 (rolling friction, condim 6, is not implemented)"); return MJH_ERR_UNSUPPORTED; }
   HIPCHK(hipSetDevice(device));
   mjh_engine* e = new mjh_engine();
+  // from here on every failure path releases the engine and whatever it has allocated so far
+#undef HIPCHK
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { mjh_set_error(std::string(#call) + ": " + hipGetErrorString(e_)); mjh_destroy(e); return MJH_ERR_NO_DEVICE; } } while (0)
   if (const char* v = getenv("MJH_LPT")) e->lpt = atoi(v) != 0;
   if (const char* v = getenv("MJH_SPLIT3")) e->split3 = atoi(v) != 0;
   e->model = m; e->nenv = nenv; e->device = device; e->stream = (hipStream_t)stream;
@@ -401,6 +419,8 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     if (const char* v = getenv("MJH_COHORTS")) nc = atoi(v); if (set_cohorts(e, nc)) { mjh_destroy(e); return MJH_ERR_NO_DEVICE; } }
   *out = e;
   return MJH_OK;
+#undef HIPCHK
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { mjh_set_error(std::string(#call) + ": " + hipGetErrorString(e_)); return MJH_ERR_NO_DEVICE; } } while (0)
 }
 
 extern "C" void mjh_destroy(mjh_engine* e) {
@@ -433,13 +453,16 @@ static int launch_lpt(mjh_engine* e, int ph, int xflags, bool resort) {
       e->order_valid = true;
     }
   }
-  DState saved = e->S;
+  StateGuard guard(&e->S);
   if (e->lpt && e->d_order && e->order_valid) e->S.env_order = e->d_order;
-  int rc = launch(e, 0, e->nenv, 1, ph, xflags);
-  e->S = saved;
-  return rc;
+  return launch(e, 0, e->nenv, 1, ph, xflags);
 }
-extern "C" int mjh_step1(mjh_engine* e) { ENG(e); e->step1_done = true; return launch_lpt(e, PH_STEP1, XF_FORCE, true); }
+static int launch_pd(mjh_engine* e, hipStream_t st, int env0, int n);
+extern "C" int mjh_step1(mjh_engine* e) {
+  ENG(e); e->step1_done = true;
+  if (e->pd_on) { int rc = launch_pd(e, e->stream, 0, e->nenv); if (rc) return rc; }
+  return launch_lpt(e, PH_STEP1, XF_FORCE, true);
+}
 extern "C" int mjh_inverse(mjh_engine* e) { ENG(e); return launch_lpt(e, PH_INV, XF_FORCE, false); }
 extern "C" int mjh_step2(mjh_engine* e) {
   ENG(e);
@@ -459,7 +482,7 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
   int rc = G > 1 ? fork_cohorts(e) : join_cohorts(e);
   if (rc) return rc;
   const int ph = PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0);
-  DState saved = e->S;
+  StateGuard guard(&e->S);
   if (e->lpt && e->d_order) e->S.env_order = e->d_order;
   for (int s = 0; s < nsteps && !rc; s++) {   // one launch per step and cohort (commands are consumed by the first one)
     for (int g = 0; g < G && !rc; g++) {
@@ -467,6 +490,7 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
       hipStream_t st = G > 1 ? e->cstream[g] : e->stream;
       if (e->S.env_order)   // dispatch the envs with the most solver work first (shorter kernel tail)
         hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, st, (const int*)e->S.stats, e->d_order, g0, g1 - g0);
+      if (e->pd_on) { rc = launch_pd(e, st, g0, g1 - g0); if (rc) break; }
       hipEvent_t ta = nullptr, tb = nullptr;
       if (e->timing) {
         if (e->tev_used == e->tev.size()) { hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); e->tev.push_back({a, b}); }
@@ -491,8 +515,7 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
       if (ta && !rc) HIPCHK(hipEventRecord(tb, st));
     }
   }
-  e->S = saved;
-  if (e->lpt && e->d_order) e->order_valid = true;   // the per-cohort sorts tile a full permutation
+  if (e->lpt && e->d_order && nsteps > 0 && !rc) e->order_valid = true;   // the per-cohort sorts tile a full permutation
   return rc;
 }
 // Per-launch timing of the step kernels with HIP events on the streams they are launched on (bench.py's roofline leg).
@@ -512,12 +535,13 @@ extern "C" int mjh_get_launch_timing(mjh_engine* e, double* mean_ms, int* count)
 extern "C" int mjh_set_timestep(mjh_engine* e, double dt) {
   ENG(e);
   if (!(dt > 0)) { mjh_set_error("mjh_set_timestep: dt must be positive"); return MJH_ERR_ARG; }
-  e->M.timestep = (float)dt;
+  e->M.timestep = (float)dt; e->M.timestep_d = dt;
   HIPCHK(hipMemcpyAsync((char*)e->dC + offsetof(DConst, M) + offsetof(DModel, timestep), &e->M.timestep, sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync((char*)e->dC + offsetof(DConst, M) + offsetof(DModel, timestep_d), &e->M.timestep_d, sizeof(double), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   return MJH_OK;
 }
-extern "C" double mjh_get_timestep(const mjh_engine* e) { return e ? (double)e->M.timestep : 0.0; }
+extern "C" double mjh_get_timestep(const mjh_engine* e) { return e ? e->M.timestep_d : 0.0; }
 extern "C" int mjh_set_cohorts(mjh_engine* e, int n) { ENG(e); return set_cohorts(e, n); }
 extern "C" int mjh_get_cohorts(const mjh_engine* e) { return e ? e->ncohort : 0; }
 extern "C" int mjh_synchronize(mjh_engine* e) { ENG(e); HIPCHK(hipStreamSynchronize(e->stream)); return MJH_OK; }
@@ -551,6 +575,55 @@ extern "C" int mjh_set_cmd(mjh_engine* e, int env0, int n, const double* ddq, co
   int rc = put_rows(e, e->S.ddq, e->M.nvp, e->M.nv, env0, n, ddq);
   if (rc) return rc;
   return put_rows(e, e->S.dq, e->M.nvp, e->M.nv, env0, n, dq);
+}
+
+// ---- in-engine PD effort controller.  The reference runs ros_control effort controllers on the host between read() and
+// write() (mj_main.cpp:86-106; gains e.g. PID p 200 d 50, model/ontology/box/box.yaml:5-13) for its ONE environment; with
+// thousands of environments that hand-off is a PCIe round trip per step, so the same law can run on the device: in front of
+// every step, ddq[d] = kp (target[d] - q[d]) - kd qvel[d] on every hinge / slide dof, consumed by the controller stage of
+// step1 exactly like a command written through mjh_set_cmd.
+__global__ void mjh_pd_kernel(const DConst* __restrict__ C, const DState S, const float* __restrict__ target, float kp, float kd, int env0, int n) {
+  const DModel& M = C->M;
+  const int nv = M.nv;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n * nv; i += (size_t)gridDim.x * blockDim.x) {
+    const int env = env0 + (int)(i / nv), d = (int)(i % nv);
+    const int j = M.I[M.o_dof_jntid + d], jt = M.I[M.o_jnt_type + j];
+    if (jt != MJH_JNT_HINGE && jt != MJH_JNT_SLIDE) continue;
+    const float q = S.qpos[(size_t)env * M.nqp + M.I[M.o_jnt_qposadr + j]], v = S.qvel[(size_t)env * M.nvp + d];
+    S.ddq[(size_t)env * M.nvp + d] = kp * (target[(size_t)env * nv + d] - q) - kd * v;
+  }
+}
+static int launch_pd(mjh_engine* e, hipStream_t st, int env0, int n) {
+  if (!e->pd_on || !e->pd_target || n <= 0) return MJH_OK;
+  const size_t total = (size_t)n * e->M.nv;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(mjh_pd_kernel, dim3(blocks), dim3(256), 0, st, e->dC, e->S, (const float*)e->pd_target, e->pd_kp, e->pd_kd, env0, n);
+  HIPCHK(hipGetLastError());
+  return MJH_OK;
+}
+extern "C" int mjh_set_pd_controller(mjh_engine* e, double kp, double kd) {
+  ENG(e);
+  if (kp < 0 || kd < 0) { mjh_set_error("mjh_set_pd_controller: gains must be non-negative"); return MJH_ERR_ARG; }
+  if ((kp > 0 || kd > 0) && !e->pd_target) {    // targets start at qpos0 of every dof's joint
+    int rc = dev_alloc(e, &e->pd_target, (size_t)e->nenv * std::max(e->M.nv, 1));
+    if (rc) return rc;
+    const mjh_model* m = e->model;
+    std::vector<float> t((size_t)e->nenv * std::max(m->nv, 1), 0.0f);
+    for (int en = 0; en < e->nenv; en++) for (int d = 0; d < m->nv; d++) {
+      const int j = m->dof_jntid[d];
+      if (m->jnt_type[j] == MJH_JNT_HINGE || m->jnt_type[j] == MJH_JNT_SLIDE) t[(size_t)en * m->nv + d] = (float)m->qpos0[m->jnt_qposadr[j]];
+    }
+    HIPCHK(hipMemcpyAsync(e->pd_target, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  e->pd_kp = (float)kp; e->pd_kd = (float)kd; e->pd_on = kp > 0 || kd > 0;
+  return MJH_OK;
+}
+extern "C" int mjh_set_pd_target(mjh_engine* e, int env0, int n, const double* target) {
+  ENG(e); RANGE(e, env0, n);
+  if (!target) return MJH_ERR_ARG;
+  if (!e->pd_target) { mjh_set_error("mjh_set_pd_target: enable the controller first (mjh_set_pd_controller)"); return MJH_ERR_STATE; }
+  return put_rows(e, e->pd_target, e->M.nv, e->M.nv, env0, n, target);
 }
 
 static int patch_int_table(mjh_engine* e, int off, const int* vals, int n) {
@@ -588,10 +661,11 @@ static int fk_export(mjh_engine* e, int env0, int n, double* a, int wa, double* 
   const size_t fa = (size_t)n * wa, fb = (size_t)n * wb;
   int rc = ensure_scratch(e, fa + fb);
   if (rc) return rc;
-  DState saved = e->S;
-  if (geoms) { e->S.x_gpos = e->scratch; e->S.x_gmat = e->scratch + fa; } else { e->S.x_xpos = e->scratch; e->S.x_xquat = e->scratch + fa; }
-  rc = launch(e, env0, n, 1, PH_FKONLY, geoms ? XF_GEOM : XF_BODY);
-  e->S = saved;
+  {
+    StateGuard guard(&e->S);
+    if (geoms) { e->S.x_gpos = e->scratch; e->S.x_gmat = e->scratch + fa; } else { e->S.x_xpos = e->scratch; e->S.x_xquat = e->scratch + fa; }
+    rc = launch(e, env0, n, 1, PH_FKONLY, geoms ? XF_GEOM : XF_BODY);
+  }
   if (rc) return rc;
   if (!rc) rc = get_rows(e, e->scratch, wa, wa, 0, n, a);
   if (!rc) rc = get_rows(e, e->scratch + fa, wb, wb, 0, n, b);
@@ -608,7 +682,8 @@ extern "C" int mjh_get_geom_state(mjh_engine* e, int env0, int n, double* gpos, 
 
 extern "C" int mjh_get_state(mjh_engine* e, int env0, int n, double* time, double* qpos, double* qvel, double* ws) {
   ENG(e); RANGE(e, env0, n);
-  int rc = get_rows(e, e->S.time, 1, 1, env0, n, time);
+  int rc = MJH_OK;
+  if (time && n) { HIPCHK(hipMemcpyAsync(time, e->S.time + env0, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }
   if (!rc) rc = get_rows(e, e->S.qpos, e->M.nqp, e->M.nq, env0, n, qpos);
   if (!rc) rc = get_rows(e, e->S.qvel, e->M.nvp, e->M.nv, env0, n, qvel);
   if (!rc) rc = get_rows(e, e->S.qacc_ws, e->M.nvp, e->M.nv, env0, n, ws);
@@ -616,7 +691,8 @@ extern "C" int mjh_get_state(mjh_engine* e, int env0, int n, double* time, doubl
 }
 extern "C" int mjh_set_state(mjh_engine* e, int env0, int n, const double* time, const double* qpos, const double* qvel, const double* ws) {
   ENG(e); RANGE(e, env0, n);
-  int rc = put_rows(e, e->S.time, 1, 1, env0, n, time);
+  int rc = MJH_OK;
+  if (time && n) { HIPCHK(hipMemcpyAsync(e->S.time + env0, time, (size_t)n * sizeof(double), hipMemcpyHostToDevice, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }
   if (!rc) rc = put_rows(e, e->S.qpos, e->M.nqp, e->M.nq, env0, n, qpos);
   if (!rc) rc = put_rows(e, e->S.qvel, e->M.nvp, e->M.nv, env0, n, qvel);
   if (!rc) rc = put_rows(e, e->S.qacc_ws, e->M.nvp, e->M.nv, env0, n, ws);
@@ -700,22 +776,20 @@ extern "C" int mjh_get_stats(mjh_engine* e, int env0, int n, int* out) {
 extern "C" int mjh_get_contacts(mjh_engine* e, int env, double* dist, double* pos, double* frame, int* geom) {
   ENG(e); RANGE(e, env, 1);
   const int mc = e->M.maxcon;
-  int rc = ensure_scratch(e, (size_t)mc * CON_STRIDE);
+  int rc = ensure_scratch(e, (size_t)mc * CON_STRIDE + 4);
   if (rc) return rc;
-  // snapshot the rows the kernel would overwrite, run the position stage only, restore
-  DState saved = e->S;
-  e->S.x_contacts = e->scratch;
-  // PH_STEP1 without state change is not available; use a dedicated read-only pass: phases = 0 runs
-  // position stage + velocity stage on qvel_ref and stores the same state back.
-  rc = launch(e, env, 1, 1, 0, XF_CON);
-  e->S = saved;
+  {
+    // read-only snapshot: position stage up to the collision stage, the records and their count go to the scratch buffer
+    // and the launch ends there (XF_NOSTORE): state, statistics, time and warm start of the env are not touched
+    StateGuard guard(&e->S);
+    e->S.x_contacts = e->scratch;
+    rc = launch(e, env, 1, 1, 0, XF_CON | XF_NOSTORE);
+  }
   if (rc) return rc;
-  std::vector<float> tmp((size_t)mc * CON_STRIDE);
-  int st[4];
+  std::vector<float> tmp((size_t)mc * CON_STRIDE + 4);
   HIPCHK(hipMemcpyAsync(tmp.data(), e->scratch, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipMemcpyAsync(st, e->S.stats + (size_t)env * 4, sizeof st, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
-  const int ncon = st[0];
+  int ncon; std::memcpy(&ncon, tmp.data() + (size_t)mc * CON_STRIDE, 4);
   for (int c = 0; c < ncon; c++) {
     const float* r = tmp.data() + (size_t)c * CON_STRIDE;
     if (dist) dist[c] = r[0];
@@ -734,10 +808,11 @@ extern "C" int mjh_mulM(mjh_engine* e, int env0, int n, const double* vec, doubl
   if (rc) return rc;
   rc = put_rows(e, e->scratch, nvp, e->M.nv, 0, n, vec);
   if (rc) return rc;
-  DState saved = e->S;
-  e->S.x_vec = e->scratch; e->S.x_res = e->scratch + (size_t)n * nvp;
-  rc = launch(e, env0, n, 1, PH_MULM, 0);
-  e->S = saved;
+  {
+    StateGuard guard(&e->S);
+    e->S.x_vec = e->scratch; e->S.x_res = e->scratch + (size_t)n * nvp;
+    rc = launch(e, env0, n, 1, PH_MULM, 0);
+  }
   if (rc) return rc;
   return get_rows(e, e->scratch + (size_t)n * nvp, nvp, e->M.nv, 0, n, res);
 }
@@ -834,7 +909,8 @@ extern "C" int mjh_mirror_create(mjh_engine* e, int env0, int n, mjh_mirror** ou
   ENG(e); RANGE(e, env0, n);
   if (!out || n <= 0) { mjh_set_error("mjh_mirror_create: bad argument"); return MJH_ERR_ARG; }
   mjh_mirror* m = new mjh_mirror(); m->e = e; m->env0 = env0; m->n = n;
-  const int w[8] = {1, e->M.nq, e->M.nv, e->M.nv, 3 * e->M.nbody, 4 * e->M.nbody, 3 * e->M.ngeom, 9 * e->M.ngeom};
+  // (field 0, time, is one DOUBLE per env = two floats of row width: mjh_mirror_time)
+  const int w[8] = {2, e->M.nq, e->M.nv, e->M.nv, 3 * e->M.nbody, 4 * e->M.nbody, 3 * e->M.ngeom, 9 * e->M.ngeom};
   for (int k = 0; k < 8; k++) { m->width[k] = w[k]; m->off[k] = m->total; m->total += (size_t)n * w[k]; }
   m->fk_floats = m->total - m->off[4];
   if (hipHostMalloc((void**)&m->host, m->total * sizeof(float), hipHostMallocDefault) != hipSuccess ||
@@ -864,15 +940,18 @@ extern "C" int mjh_mirror_update(mjh_mirror* m, int what) {
                             (size_t)m->width[k] * sizeof(float), (size_t)n, hipMemcpyDeviceToHost, e->stream);
   };
   if (what & MJH_MIRROR_JOINTS) {
-    HIPCHK(rows(0, e->S.time, 1)); HIPCHK(rows(1, e->S.qpos, e->M.nqp)); HIPCHK(rows(2, e->S.qvel, e->M.nvp)); HIPCHK(rows(3, e->S.qfrc_inverse, e->M.nvp));
+    HIPCHK(hipMemcpyAsync(m->host + m->off[0], e->S.time + env0, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));   // time: fp64
+    HIPCHK(rows(1, e->S.qpos, e->M.nqp)); HIPCHK(rows(2, e->S.qvel, e->M.nvp)); HIPCHK(rows(3, e->S.qfrc_inverse, e->M.nvp));
   }
   if (what & (MJH_MIRROR_BODIES | MJH_MIRROR_GEOMS)) {
-    DState saved = e->S;
     float* d = m->dev;
-    e->S.x_xpos = d; e->S.x_xquat = d + (m->off[5] - m->off[4]); e->S.x_gpos = d + (m->off[6] - m->off[4]); e->S.x_gmat = d + (m->off[7] - m->off[4]);
-    const int xf = ((what & MJH_MIRROR_BODIES) ? XF_BODY : 0) | ((what & MJH_MIRROR_GEOMS) ? XF_GEOM : 0);
-    int rc = launch(e, env0, n, 1, PH_FKONLY, xf);
-    e->S = saved;
+    int rc;
+    {
+      StateGuard guard(&e->S);
+      e->S.x_xpos = d; e->S.x_xquat = d + (m->off[5] - m->off[4]); e->S.x_gpos = d + (m->off[6] - m->off[4]); e->S.x_gmat = d + (m->off[7] - m->off[4]);
+      const int xf = ((what & MJH_MIRROR_BODIES) ? XF_BODY : 0) | ((what & MJH_MIRROR_GEOMS) ? XF_GEOM : 0);
+      rc = launch(e, env0, n, 1, PH_FKONLY, xf);
+    }
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(m->host + m->off[4], d, m->fk_floats * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   }
@@ -884,6 +963,7 @@ extern "C" int mjh_mirror_wait(mjh_mirror* m) {
   HIPCHK(hipEventSynchronize(m->ev));
   return MJH_OK;
 }
+extern "C" const double* mjh_mirror_time(const mjh_mirror* m) { return m ? (const double*)(m->host + m->off[0]) : nullptr; }
 extern "C" const float* mjh_mirror_field(const mjh_mirror* m, int which, int* row_width) {
   if (!m || which < 0 || which > 7) return nullptr;
   if (row_width) *row_width = m->width[which];
@@ -919,16 +999,18 @@ extern "C" int mjh_export_state_device(mjh_engine* e, void* d_out) {
 // out[16] = mean over envs of (stamp[k] - stamp[0]) in shader-clock ticks
 extern "C" int mjh_debug_stage_cycles(mjh_engine* e, int with_inverse, double* out) {
   ENG(e);
-  long long* buf = nullptr;
-  HIPCHK(hipMalloc((void**)&buf, (size_t)e->nenv * PROF_STRIDE * sizeof(long long)));
+  DevBuf db;
+  HIPCHK(hipMalloc(&db.p, (size_t)e->nenv * PROF_STRIDE * sizeof(long long)));
+  long long* buf = (long long*)db.p;
   HIPCHK(hipMemsetAsync(buf, 0, (size_t)e->nenv * PROF_STRIDE * sizeof(long long), e->stream));
-  DState saved = e->S;
-  e->S.x_prof = buf;
-  int rc = launch(e, 0, e->nenv, 1, PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0), XF_PROF);
-  e->S = saved;
+  int rc;
+  {
+    StateGuard guard(&e->S);
+    e->S.x_prof = buf;
+    rc = launch(e, 0, e->nenv, 1, PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0), XF_PROF);
+  }
   std::vector<long long> h((size_t)e->nenv * PROF_STRIDE);
   if (!rc) { HIPCHK(hipMemcpyAsync(h.data(), buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }
-  (void)hipFree(buf);
   if (rc) return rc;
   for (int k = 0; k < 16; k++) out[k] = 0;
   for (int en = 0; en < e->nenv; en++) for (int k = 0; k < 16; k++) { long long v = h[(size_t)en*PROF_STRIDE+k]; out[k] += v ? (double)(v - h[(size_t)en*PROF_STRIDE]) : 0.0; }
@@ -939,19 +1021,21 @@ extern "C" int mjh_debug_stage_cycles(mjh_engine* e, int with_inverse, double* o
 // raw per-env stamps of one LPT-ordered step launch (debug timeline tool): out[nenv*PROF_STRIDE]
 extern "C" int mjh_debug_stage_raw(mjh_engine* e, int with_inverse, long long* out) {
   ENG(e);
-  long long* buf = nullptr;
-  HIPCHK(hipMalloc((void**)&buf, (size_t)e->nenv * PROF_STRIDE * sizeof(long long)));
+  DevBuf db;
+  HIPCHK(hipMalloc(&db.p, (size_t)e->nenv * PROF_STRIDE * sizeof(long long)));
+  long long* buf = (long long*)db.p;
   HIPCHK(hipMemsetAsync(buf, 0, (size_t)e->nenv * PROF_STRIDE * sizeof(long long), e->stream));
-  DState saved = e->S;
-  e->S.x_prof = buf;
-  if (e->lpt && e->d_order) {
-    hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, e->stream, (const int*)e->S.stats, e->d_order, 0, e->nenv);
-    e->S.env_order = e->d_order;
+  int rc;
+  {
+    StateGuard guard(&e->S);
+    e->S.x_prof = buf;
+    if (e->lpt && e->d_order) {
+      hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, e->stream, (const int*)e->S.stats, e->d_order, 0, e->nenv);
+      e->S.env_order = e->d_order; e->order_valid = true;
+    }
+    rc = launch(e, 0, e->nenv, 1, PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0), XF_PROF);
   }
-  int rc = launch(e, 0, e->nenv, 1, PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0), XF_PROF);
-  e->S = saved;
   if (!rc) { HIPCHK(hipMemcpyAsync(out, buf, (size_t)e->nenv * PROF_STRIDE * sizeof(long long), hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }
-  (void)hipFree(buf);
   return rc;
 }
 

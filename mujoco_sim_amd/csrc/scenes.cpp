@@ -123,6 +123,53 @@ extern "C" int mjh_scene_s24_randomize(const mjh_model* m, int env0, int nenv, u
   return MJH_OK;
 }
 
+// Per-env randomisation of a scene of free boxes (BASELINE config C2, SURVEY.md §8-d D3: "64 boxes, half-extents
+// U[0.05,0.125]^3, released from a 4x4x4 lattice (pitch 0.3 m, z0 in [0.5, 1.4]) with +-0.01 m jitter and random
+// orientation"): every body that carries one free joint and one box geom gets its own half-extents (and the mass, inertia and
+// inverse weights that follow at density 1000), its lattice position from the model's qpos0 plus U[-jitter, jitter]^3 and a
+// uniformly random orientation.  PCG32 seeded `seed_base + env`, like S24.  Every out pointer may be NULL.
+extern "C" int mjh_scene_boxes_randomize(const mjh_model* m, int env0, int nenv, unsigned seed_base, double jitter,
+                                         double* qpos, double* geom_size, double* geom_rbound,
+                                         double* body_mass, double* body_inertia,
+                                         double* body_invweight0, double* dof_invweight0) {
+  if (!m || nenv < 0) return MJH_ERR_ARG;
+  const int nq = m->nq, nv = m->nv, nb = m->nbody, ng = m->ngeom;
+  for (int e = 0; e < nenv; e++) {
+    Pcg32 rng((uint64_t)seed_base + (uint64_t)(env0 + e));
+    if (qpos) for (int i = 0; i < nq; i++) qpos[(size_t)e * nq + i] = m->qpos0[i];
+    if (geom_size) for (int i = 0; i < 3 * ng; i++) geom_size[(size_t)e * 3 * ng + i] = m->geom_size[i];
+    if (geom_rbound) for (int i = 0; i < ng; i++) geom_rbound[(size_t)e * ng + i] = m->geom_rbound[i];
+    if (body_mass) for (int i = 0; i < nb; i++) body_mass[(size_t)e * nb + i] = m->body_mass[i];
+    if (body_inertia) for (int i = 0; i < 3 * nb; i++) body_inertia[(size_t)e * 3 * nb + i] = m->body_inertia[i];
+    if (body_invweight0) for (int i = 0; i < 2 * nb; i++) body_invweight0[(size_t)e * 2 * nb + i] = m->body_invweight0[i];
+    if (dof_invweight0) for (int i = 0; i < nv; i++) dof_invweight0[(size_t)e * nv + i] = m->dof_invweight0[i];
+    for (int body = 1; body < nb; body++) {
+      if (m->body_jntnum[body] != 1 || m->jnt_type[m->body_jntadr[body]] != MJH_JNT_FREE || m->body_geomnum[body] != 1) continue;
+      const int geom = m->body_geomadr[body];
+      if (m->geom_type[geom] != MJH_GEOM_BOX) continue;
+      const int da = m->body_dofadr[body], qa = m->jnt_qposadr[m->body_jntadr[body]];
+      const double hx = rng.uniform(0.05, 0.125), hy = rng.uniform(0.05, 0.125), hz = rng.uniform(0.05, 0.125);
+      const double jx = rng.uniform(-jitter, jitter), jy = rng.uniform(-jitter, jitter), jz = rng.uniform(-jitter, jitter);
+      const double u1 = rng.uniform(), u2 = rng.uniform(), u3 = rng.uniform();
+      const double twopi = 6.283185307179586476925;
+      const double a = std::sqrt(1 - u1), bq = std::sqrt(u1);
+      double quat[4] = {a * std::sin(twopi * u2), a * std::cos(twopi * u2), bq * std::sin(twopi * u3), bq * std::cos(twopi * u3)};
+      hm::normalize4(quat);
+      if (qpos) { double* q = qpos + (size_t)e * nq + qa; q[0] += jx; q[1] += jy; q[2] += jz; for (int i = 0; i < 4; i++) q[3 + i] = quat[i]; }
+      const double mass = 1000.0 * 8 * hx * hy * hz;
+      const double I[3] = {mass / 3 * (hy*hy + hz*hz), mass / 3 * (hx*hx + hz*hz), mass / 3 * (hx*hx + hy*hy)};
+      if (geom_size) { double* sz = geom_size + (size_t)e * 3 * ng + 3 * geom; sz[0] = hx; sz[1] = hy; sz[2] = hz; }
+      if (geom_rbound) geom_rbound[(size_t)e * ng + geom] = std::sqrt(hx*hx + hy*hy + hz*hz);
+      if (body_mass) body_mass[(size_t)e * nb + body] = mass;
+      if (body_inertia) for (int i = 0; i < 3; i++) body_inertia[(size_t)e * 3 * nb + 3 * body + i] = I[i];
+      const double tr = 1 / mass, rr = (1 / I[0] + 1 / I[1] + 1 / I[2]) / 3;
+      if (body_invweight0) { body_invweight0[(size_t)e * 2 * nb + 2 * body] = tr; body_invweight0[(size_t)e * 2 * nb + 2 * body + 1] = rr; }
+      if (dof_invweight0) for (int i = 0; i < 3; i++) { dof_invweight0[(size_t)e * nv + da + i] = tr; dof_invweight0[(size_t)e * nv + da + 3 + i] = rr; }
+    }
+  }
+  return MJH_OK;
+}
+
 // model/test/pendulum.xml:18-29 — three bodies on ball joints (damping 0.5) sharing the anchor (0,0,2),
 // gravity -0.1; geoms sphere / box / cylinder of "size .1 .1 .1".
 extern "C" mjh_model* mjh_scene_pendulum(void) {

@@ -570,7 +570,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   // env's scratch slice; PH_POST skips everything between the factorisation and the end of the sweeps
   const bool pre = NROW == 8 && (ph & PH_PRE), post = NROW == 8 && (ph & PH_POST);
   if (post) for (int i = lane; i < nv; i += 64) s_qvel[i] = gs[L.g_qvel + i];     // (the controller may have overridden velocities)
-  float time = S.time[env];
+  double time = S.time[env];
   // spawn/destroy as slot toggling: bit b set = body b is an INACTIVE slot in this env
   const unsigned slotmask = S.slot_mask ? (unsigned)__builtin_amdgcn_readfirstlane((int)S.slot_mask[env]) : 0u;
   const int sbase = nbody > 32 ? nbody - 32 : 0;   // mask bit i = body sbase + i: the LAST 32 bodies of a big model are the toggleable slots
@@ -906,9 +906,11 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       ncon = __builtin_amdgcn_readfirstlane(conbase);
     }
     WSYNC();
-    if ((xflags & XF_CON) && S.x_contacts) {
-      float* o = S.x_contacts + (size_t)blockIdx.x * M.maxcon * CON_STRIDE;
+    if ((xflags & XF_CON) && S.x_contacts) {   // contact snapshot (mjh_get_contacts): records + count, nothing else is written
+      float* o = S.x_contacts + (size_t)blockIdx.x * ((size_t)M.maxcon * CON_STRIDE + 4);
       for (int i = lane; i < ncon * CON_STRIDE; i += 64) o[i] = s_con[i];
+      if (lane == 0) { o[(size_t)M.maxcon * CON_STRIDE] = __int_as_float(ncon); o[(size_t)M.maxcon * CON_STRIDE + 1] = __int_as_float(flags); }
+      if (xflags & XF_NOSTORE) return;
       WSYNC();
     }
 
@@ -1931,7 +1933,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             s_qpos[qa] = q[0]; s_qpos[qa+1] = q[1]; s_qpos[qa+2] = q[2]; s_qpos[qa+3] = q[3];
           } else s_qpos[qa] += h * s_qvel[da];
         }
-        time += h;
+        time += M.timestep_d;
         WSYNC();
         // ---- odom velocities (MjSim::set_odom_vels, mj_sim.cpp:1079-1153)
         if (lane == 0 && odom[9]) {
@@ -1949,7 +1951,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   }  // steps
 
   PROF(14);
-  if (ph & (PH_FKONLY | PH_MULM)) return;
+  if ((ph & (PH_FKONLY | PH_MULM)) || (xflags & XF_NOSTORE)) return;
   // ------------------------------------------------------------------ store state
   for (int i = lane; i < nq; i += 64) S.qpos[qrow + i] = s_qpos[i];
   for (int i = lane; i < nv; i += 64) {
@@ -1972,7 +1974,7 @@ __global__ void mjh_export_kernel(const DState S, float* out, int env0, int nenv
   out += (size_t)env0 * stride;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)nenv * stride; i += (size_t)gridDim.x * blockDim.x) {
     const int e = env0 + (int)(i / stride), k = (int)(i % stride);
-    out[i] = (k == 0) ? S.time[e] : (k <= nq ? S.qpos[(size_t)e * nqp + k - 1] : S.qvel[(size_t)e * nvp + k - 1 - nq]);
+    out[i] = (k == 0) ? (float)S.time[e] : (k <= nq ? S.qpos[(size_t)e * nqp + k - 1] : S.qvel[(size_t)e * nvp + k - 1 - nq]);
   }
 }
 

@@ -59,6 +59,20 @@ class Model:
         return out
 
 
+def boxes_randomize(model, env0, nenv, seed_base=0x5EED0000, jitter=0.01):
+    """Per-env tables of a free-box scene (C2): dict of float64 arrays like Model.s24_randomize."""
+    c = model.c
+    out = dict(
+        qpos=np.zeros((nenv, c.nq)), geom_size=np.zeros((nenv, 3 * c.ngeom)), geom_rbound=np.zeros((nenv, c.ngeom)),
+        body_mass=np.zeros((nenv, c.nbody)), body_inertia=np.zeros((nenv, 3 * c.nbody)),
+        body_invweight0=np.zeros((nenv, 2 * c.nbody)), dof_invweight0=np.zeros((nenv, c.nv)))
+    rc = model.lib.mjh_scene_boxes_randomize(model.ptr, env0, nenv, seed_base, float(jitter), *[capi.dptr(out[k]) for k in
+                                             ["qpos", "geom_size", "geom_rbound", "body_mass", "body_inertia",
+                                              "body_invweight0", "dof_invweight0"]])
+    _chk(model.lib, rc, "mjh_scene_boxes_randomize")
+    return out
+
+
 def load_mjcf(xml=None, path=None, paths=None):
     """MJCF-subset loader (mj_loadXML boundary, mj_util.h:185-193); `paths`: world file + robot files composed into one model"""
     lib = capi.load()
@@ -132,6 +146,14 @@ class Engine:
         b = None if dq is None else np.ascontiguousarray(dq, dtype=np.float64).reshape(-1, self.nv)
         n = (a if a is not None else b).shape[0]
         _chk(self.lib, self.lib.mjh_set_cmd(self.h, env0, n, capi.dptr(a), capi.dptr(b)), "mjh_set_cmd")
+
+    def set_pd_controller(self, kp, kd):
+        """in-engine joint-space PD effort controller (ros_control's effort controllers for all envs at once)"""
+        _chk(self.lib, self.lib.mjh_set_pd_controller(self.h, float(kp), float(kd)), "mjh_set_pd_controller")
+
+    def set_pd_target(self, target, env0=0):
+        t = np.ascontiguousarray(target, dtype=np.float64).reshape(-1, self.nv)
+        _chk(self.lib, self.lib.mjh_set_pd_target(self.h, env0, t.shape[0], capi.dptr(t)), "mjh_set_pd_target")
 
     def set_controlled_dofs(self, mask):
         m = np.ascontiguousarray(mask, dtype=np.int32)
@@ -242,6 +264,14 @@ class Engine:
     @property
     def lds_bytes(self):
         return self.lib.mjh_lds_bytes(self.h)
+
+    def load_tables(self, t):
+        """apply per-env parameter tables + initial poses (dict as returned by *_randomize) and reset"""
+        for k in ["geom_size", "geom_rbound", "body_mass", "body_inertia", "body_invweight0", "dof_invweight0"]:
+            self.set_env_param(k, t[k])
+        self.set_initial_qpos(t["qpos"])
+        self.reset()
+        return t
 
     def load_s24(self, seed_base=0x5EED0000, env_offset=0):
         """Apply the per-env S24 randomisation (sizes, masses, initial poses) and reset."""

@@ -159,7 +159,7 @@ void orc_free_data(orc_data* d) {
   for (size_t i = 0; i < sizeof(ps)/sizeof(ps[0]); i++) free(ps[i]);
   for (int i = 0; i < 6; i++) free(d->scr_nv[i]);
   for (int i = 0; i < 3; i++) { free(d->scr_efc[i]); free(d->scr_body6[i]); }
-  free(d->contact); free(d->efc_type); free(d->efc_id); free(d->controlled);
+  free(d->contact); free(d->efc_type); free(d->efc_id); free(d->controlled); free(d->pd_target);
   free(d);
 }
 
@@ -1561,8 +1561,21 @@ void orc_inverse(orc_data* d) {
 }
 
 /* loop body of simulate(), mj_main.cpp:82-112, without ROS: step1 -> read() -> write() -> step2 */
+void orc_set_pd(orc_data* d, const double* target, double kp, double kd) {
+  const int nv = d->m->nv;
+  if (!d->pd_target) d->pd_target = dalloc((size_t)nv);
+  if (target) copyv(d->pd_target, target, nv);
+  d->pd_kp = kp; d->pd_kd = kd;
+}
 void orc_step(orc_data* d, int nsteps, int with_inverse) {
+  const mjh_model* m = d->m;
   for (int s = 0; s < nsteps; s++) {
+    if (d->pd_target && (d->pd_kp > 0 || d->pd_kd > 0))      /* controller_manager->update() + write(), mj_main.cpp:99-106 */
+      for (int i = 0; i < m->nv; i++) {
+        const int j = m->dof_jntid[i];
+        if (m->jnt_type[j] == MJH_JNT_HINGE || m->jnt_type[j] == MJH_JNT_SLIDE)
+          d->ddq[i] = d->pd_kp * (d->pd_target[i] - d->qpos[m->jnt_qposadr[j]]) - d->pd_kd * d->qvel[i];
+      }
     orc_step1(d);
     if (with_inverse) orc_inverse(d);
     orc_step2(d);

@@ -55,6 +55,9 @@ typedef struct orc_data {
   int odom_lin[3], odom_ang[3], odom_angq[3]; double odom_vel[6];
   double* initial_qpos;
   unsigned slot_mask; /* bit b = body b is an inactive spawn/destroy slot */
+  /* joint-space PD effort controller evaluated in front of every step of orc_step (what ros_control's effort controllers do
+   * between read() and write(), mj_main.cpp:86-106): ddq = kp (target - q) - kd qvel on hinge / slide dofs */
+  double *pd_target, pd_kp, pd_kd;
   /* scratch */
   double *scr_nv[6], *scr_nM, *scr_efc[3], *scr_B, *scr_body6[3];
 } orc_data;
@@ -109,6 +112,7 @@ int orc_get_contact(orc_data* d, int k, double* dist, double* pos, double* frame
 void orc_step_many(orc_data** ds, int nenv, int nsteps, int with_inverse);
 void orc_set_threads(int n);
 void orc_set_slot_mask(orc_data* d, unsigned mask);
+void orc_set_pd(orc_data* d, const double* target /* [nv], may be NULL with kp = kd = 0 */, double kp, double kd);
 
 #ifdef __cplusplus
 }

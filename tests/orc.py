@@ -40,6 +40,7 @@ def lib():
         L.orc_step_many.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int]
         L.orc_set_threads.argtypes = [C.c_int]
         L.orc_set_slot_mask.argtypes = [vp, C.c_uint]
+        L.orc_set_pd.argtypes = [vp, dp, C.c_double, C.c_double]
         _lib = L
     return _lib
 
@@ -90,6 +91,10 @@ class OrcData:
         self.f("qpos")[:] = q
         if as_initial:
             self.f("initial_qpos")[:] = q
+
+    def set_pd(self, target, kp, kd):
+        t = np.ascontiguousarray(target, dtype=np.float64)
+        self.L.orc_set_pd(self.d, t.ctypes.data_as(C.POINTER(C.c_double)), float(kp), float(kd))
 
     def contacts(self):
         out = []

@@ -787,7 +787,7 @@ def test_pinned_host_mirror_matches_getters(s24, lib):
     t, q, v, w = f.get_state(env0, n); qj, vj, fi = f.get_joint_state(env0, n)
     xp, xq = f.get_body_state(env0, n); gp, gm = f.get_geom_state(env0, n)
     f.close()
-    np.testing.assert_allclose(got[0][:, 0], t, rtol=1e-6)
+    assert np.array_equal(got[0].view(np.float64)[:, 0], t)          # field 0: one fp64 per env (also mjh_mirror_time)
     assert np.array_equal(got[1], q.astype(np.float32)) and np.array_equal(got[2], v.astype(np.float32))
     assert np.array_equal(got[3], fi.astype(np.float32))
     np.testing.assert_allclose(got[4], xp.reshape(n, -1), atol=1e-6); np.testing.assert_allclose(got[5], xq.reshape(n, -1), atol=1e-6)
