@@ -1,33 +1,74 @@
-"""Build the C-ABI shared library (HIP kernels + host C++) in-tree for gfx950."""
+"""Build the C-ABI shared library (HIP kernels + host C++) in-tree for gfx950.
+
+One object per source under mujoco_sim_amd/build/ (re-made only when the source or one of its headers is newer), then one link:
+the kernel translation unit (engine.hip, every mjh_step_kernel instance) takes about two minutes, the host files seconds."""
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libmjhip.so")
-SOURCES = ["engine.hip", "model_builder.cpp", "scenes.cpp", "host_sim.cpp", "mjcf_loader.cpp"]
-DEPS = SOURCES + ["step_kernel.h", "dev_math.h", "dev_collide.h", "dev_convex.h", "dev_types.h", "hmath.h", "host_sim.h",
-                  os.path.join("..", "..", "include", "mjhip.h")]
+API = os.path.join("..", "..", "include", "mjhip.h")
+KERNEL_HEADERS = ["step_kernel.h", "dev_math.h", "dev_collide.h", "dev_convex.h", "dev_types.h"]
+# source -> headers it includes (besides itself)
+SOURCES = {
+    "engine.hip": KERNEL_HEADERS + [API],
+    "group.hip": [API],
+    "model_builder.cpp": ["hmath.h", API],
+    "scenes.cpp": ["hmath.h", API],
+    "host_sim.cpp": ["host_sim.h", API],
+    "mjcf_loader.cpp": ["hmath.h", API],
+}
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-Wno-unused-result"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.exists(os.path.join(CSRC, d)) and os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+def _digest(paths, extra=""):
+    """content hash of a source and its headers: staleness does not depend on file times (a snapshot copied to the GPU box
+    keeps contents, not necessarily mtimes)"""
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        if os.path.exists(p):
+            with open(p, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
 
 
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950: cross-compiles without a GPU."""
-    if not force and not _stale():
-        return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-fno-slp-vectorize",
-           "-Wno-unused-result"] + [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ, exist_ok=True)
+    objs, digests = [], []
+    for src, deps in SOURCES.items():
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        op = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        dg = _digest([sp] + [os.path.join(CSRC, d) for d in deps], " ".join(FLAGS))
+        stamp = op + ".sha256"
+        have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+        if force or not os.path.exists(op) or have != dg:
+            cmd = [hipcc] + FLAGS + ["-c", sp, "-o", op]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+            with open(stamp, "w") as f:
+                f.write(dg)
+        objs.append(op); digests.append(dg)
+    link_dg = _digest([], " ".join(digests))
+    link_stamp = os.path.join(OBJ, "libmjhip.sha256")
+    have = open(link_stamp).read().strip() if os.path.exists(link_stamp) else ""
+    if force or not os.path.exists(LIB) or have != link_dg:
+        # RCCL (mjh_group_*: the all-gather of the published state slice across the GPUs of a node) is resolved at run time
+        # with dlopen, so the library loads on boxes without it
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", LIB]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        with open(link_stamp, "w") as f:
+            f.write(link_dg)
     return LIB
 
 

@@ -195,18 +195,57 @@ static int add_mesh_impl(mjh_builder* b, std::vector<double> v, const int* face,
   // The mesh collides as its convex hull, and the hull's support mapping only ever returns hull vertices: keep the
   // vertices that are extreme along a dense direction set (Fibonacci sphere + the 26 axis/diagonal directions).  An
   // inner approximation of the hull: a hull vertex that is never selected is within a fraction of a degree of one.
+  {   // STL repeats every vertex once per facet: scan each distinct point once
+    std::vector<int> idx(nv);
+    for (int i = 0; i < nv; i++) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](int a, int c) { return std::lexicographical_compare(&v[3*a], &v[3*a] + 3, &v[3*c], &v[3*c] + 3); });
+    std::vector<double> u; u.reserve(v.size());
+    for (int k = 0; k < nv; k++) {
+      const int i = idx[k];
+      if (k > 0 && v[3*i] == v[3*idx[k-1]] && v[3*i+1] == v[3*idx[k-1]+1] && v[3*i+2] == v[3*idx[k-1]+2]) continue;
+      u.push_back(v[3*i]); u.push_back(v[3*i+1]); u.push_back(v[3*i+2]);
+    }
+    v.swap(u); nv = (int)v.size() / 3;
+  }
   std::vector<char> keep(nv, 0);
-  auto take = [&](const double* dir) {
-    double best = -1e300; int bi = 0;
-    for (int i = 0; i < nv; i++) { const double dp = v[3*i]*dir[0] + v[3*i+1]*dir[1] + v[3*i+2]*dir[2]; if (dp > best) { best = dp; bi = i; } }
-    keep[bi] = 1;
+  auto support = [&](const double* dir, bool kept_only, int* arg) {
+    double best = -1e300; int bi = -1;
+    for (int i = 0; i < nv; i++) {
+      if (kept_only && !keep[i]) continue;
+      const double dp = v[3*i]*dir[0] + v[3*i+1]*dir[1] + v[3*i+2]*dir[2];
+      if (dp > best) { best = dp; bi = i; }
+    }
+    if (arg) *arg = bi;
+    return best;
   };
+  auto take = [&](const double* dir) { int bi; support(dir, false, &bi); if (bi >= 0) keep[bi] = 1; };
   for (int x = -1; x <= 1; x++) for (int y = -1; y <= 1; y++) for (int z = -1; z <= 1; z++) if (x || y || z) { const double d[3] = {(double)x, (double)y, (double)z}; take(d); }
+  auto fib = [](int i, int n, double phase, double* d) {
+    const double z = 1.0 - 2.0 * (i + 0.5) / n, r = std::sqrt(std::max(0.0, 1.0 - z*z)), ph = i * 2.399963229728653 + phase;   // golden angle
+    d[0] = r * std::cos(ph); d[1] = r * std::sin(ph); d[2] = z;
+  };
   const int NDIR = 1500;
-  for (int i = 0; i < NDIR; i++) {
-    const double z = 1.0 - 2.0 * (i + 0.5) / NDIR, r = std::sqrt(std::max(0.0, 1.0 - z*z)), ph = i * 2.399963229728653;   // golden angle
-    const double d[3] = {r * std::cos(ph), r * std::sin(ph), z};
-    take(d);
+  for (int i = 0; i < NDIR; i++) { double d[3]; fib(i, NDIR, 0.0, d); take(d); }
+  // ... then refined against a second, denser direction set until the kept set's support function is within 2e-4 of the
+  // mesh size of the full one everywhere on it (tests/test_oracle_pinning.py checks this against the raw STL files: the
+  // first set alone left 8e-3 on PR2's head_pan_L)
+  {
+    const double size = std::sqrt(ext[0]*ext[0] + ext[1]*ext[1] + ext[2]*ext[2]), tol = 2e-4 * size;
+    const int NREF = 6000;
+    std::vector<double> kv;     // kept vertices, contiguous (the inner loop of the refinement)
+    for (int pass = 0; pass < 4; pass++) {
+      kv.clear();
+      for (int i = 0; i < nv; i++) if (keep[i]) { kv.push_back(v[3*i]); kv.push_back(v[3*i+1]); kv.push_back(v[3*i+2]); }
+      int added = 0;
+      for (int i = 0; i < NREF; i++) {
+        double d[3]; fib(i, NREF, 1.0 + pass, d);
+        double hk = -1e300;
+        for (size_t k = 0; k < kv.size(); k += 3) hk = std::max(hk, kv[k]*d[0] + kv[k+1]*d[1] + kv[k+2]*d[2]);
+        int bi; const double hf = support(d, false, &bi);
+        if (hf - hk > tol && !keep[bi]) { keep[bi] = 1; added++; kv.push_back(v[3*bi]); kv.push_back(v[3*bi+1]); kv.push_back(v[3*bi+2]); }
+      }
+      if (!added) break;
+    }
   }
   M.rbound = 0;
   for (int i = 0; i < nv; i++) if (keep[i]) {

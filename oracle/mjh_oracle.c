@@ -1302,8 +1302,15 @@ static void block_trees(const orc_data* d, int row, int* t1, int* t2) {
       *t2 = m->body_treeid[m->geom_bodyid[d->contact[id].geom2]];
   }
 }
+/* 0 (default): the independent-pair / independent-group order above, shared with the device;
+ * 1: plain constraint-row order, the order mj_solPGS visits the rows in [UPSTREAM].  Both are Gauss-Seidel on the same dual
+ * problem: they agree at convergence; where the sweep cap ends the iteration first (settled S24 piles run into the default
+ * 100 sweeps at tolerance 1e-8) the iterates differ, and tests/test_oracle_pinning.py measures by how much. */
+static int g_pgs_row_order = 0;
+void orc_set_pgs_row_order(int plain) { g_pgs_row_order = plain != 0; }
 static int pgs_order(const orc_data* d, int* order) {
   int nefc = d->nefc, nblk = 0;
+  if (g_pgs_row_order) { for (int i = 0; i < nefc; i++) order[i] = i; return nefc; }
   int* bstart = (int*)malloc(sizeof(int) * (size_t)(nefc + 1) * 5);
   int *bnum = bstart + nefc + 1, *bt1 = bnum + nefc + 1, *bt2 = bt1 + nefc + 1, *used = bt2 + nefc + 1;
   for (int i = 0; i < nefc;) {

@@ -112,6 +112,9 @@ int orc_get_contact(orc_data* d, int k, double* dist, double* pos, double* frame
 void orc_step_many(orc_data** ds, int nenv, int nsteps, int with_inverse);
 void orc_set_threads(int n);
 void orc_set_slot_mask(orc_data* d, unsigned mask);
+/* Gauss-Seidel visiting order of orc_fwd_constraint (process-wide): 0 = the device's independent-pair order (default),
+ * 1 = plain constraint-row order as mj_solPGS [UPSTREAM] */
+void orc_set_pgs_row_order(int plain);
 void orc_set_pd(orc_data* d, const double* target /* [nv], may be NULL with kp = kd = 0 */, double kp, double kd);
 
 #ifdef __cplusplus
