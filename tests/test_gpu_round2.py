@@ -121,3 +121,183 @@ def test_in_engine_pd_controller_equals_host_pd_and_the_oracle():
     assert np.abs(qd - target).mean() < 0.1           # the arms are converging on their (in-range) targets
     dev.set_pd_controller(0.0, 0.0)
     dev.close(); host.close()
+
+
+# ------------------------------------------------------------------ BASELINE-size runs of C2 / C3 / C4 with invariants
+def _robot(name):
+    from mujoco_sim_amd.tables import load_model_tables
+    return load_model_tables(os.path.join(G, f"robot_{name}.npz"))
+
+
+def test_c2_full_size_invariants():
+    """C2 as SURVEY.md §8-d D3 states it — 64 boxes with per-env random sizes / orientations / jitter, 4096 envs — settled
+    200 steps + 60 more: finite, no capacity overflow, no bad-state reset, unit quaternions, nothing below the floor,
+    Newton's second law on the vertical axis of every env (ties qacc, qfrc_constraint and the per-env masses together),
+    total energy not increasing once the boxes have landed"""
+    m = ms.scene("boxpile", 64); m.c.maxcon = 600; m.c.maxefc = 2400
+    nenv = 4096
+    e = ms.Engine(m, nenv)
+    tab = e.load_tables(ms.boxes_randomize(m, 0, nenv, jitter=0.01))
+    assert np.abs(tab["geom_size"][0] - tab["geom_size"][1]).max() > 1e-3          # per-env sizes really differ
+    e.step(200)
+    e.forward(); E0 = e.get_field("energy").sum(axis=1)
+    e.step(60)
+    e.forward(); E1 = e.get_field("energy").sum(axis=1)
+    t, q, v, _ = e.get_state(); st = e.get_stats()
+    assert np.isfinite(q).all() and np.isfinite(v).all()
+    assert (st[:, 3] == 0).all(), f"flags {np.unique(st[:, 3])}: overflow / reset at capacity 600"
+    pos = q.reshape(nenv, 64, 7)
+    np.testing.assert_allclose(np.linalg.norm(pos[:, :, 3:], axis=-1), 1, atol=1e-5)
+    assert pos[:, :, 2].min() > 0.02                                           # smallest half-extent 0.05, penetration of millimetres
+    assert np.mean(E1 <= E0 + 1e-3 * np.abs(E0)) > 0.98
+    fz = e.get_field("qfrc_constraint").reshape(nenv, 64, 6)[:, :, 2]; az = e.get_field("qacc").reshape(nenv, 64, 6)[:, :, 2]
+    mb = tab["body_mass"][:, 1:]
+    lhs, rhs = fz.sum(axis=1), (mb * (az + 9.81)).sum(axis=1); wtot = 9.81 * mb.sum(axis=1)
+    rel = np.abs(lhs - rhs) / wtot
+    assert np.median(rel) < 2e-4 and np.quantile(rel, 0.99) < 2e-2, (np.median(rel), np.quantile(rel, 0.99))
+    print(f"C2 4096 envs: mean ncon {st[:, 0].mean():.0f} max {st[:, 0].max()}, mean nefc {st[:, 1].mean():.0f} max {st[:, 1].max()}, mean sweeps {st[:, 2].mean():.0f}")
+    assert 100 < st[:, 0].mean() < 600
+    e.close()
+
+
+def test_c3_full_size_invariants():
+    """C3 at 8192 envs: the in-engine PD law drives every arm to its own random in-range target; afterwards every joint is
+    inside its limits (up to the solref penetration), velocities are small, qfrc_inverse is finite and — the arms being at
+    rest under gravity compensation + computed torque — close to the applied torque"""
+    m = ms.scene("arm7", 1)
+    nenv = 8192
+    e = ms.Engine(m, nenv)
+    e.set_controlled_dofs(np.ones(m.nv, dtype=np.int32))
+    rng = np.random.default_rng(11)
+    lo, hi = m.array("jnt_range").reshape(-1, 2).T
+    target = rng.uniform(lo + 0.05, hi - 0.05, size=(nenv, m.nv))
+    e.set_pd_controller(200.0, 50.0); e.set_pd_target(target)
+    e.step(600, True)
+    q, v, f = e.get_joint_state(); st = e.get_stats()
+    assert np.isfinite(q).all() and np.isfinite(v).all() and np.isfinite(f).all()
+    assert (st[:, 3] == 0).all()
+    assert (q > lo - 2e-2).all() and (q < hi + 2e-2).all()
+    err = np.abs(q - target)
+    assert np.quantile(err, 0.99) < 2e-2 and np.abs(v).max() < 0.2, (np.quantile(err, 0.99), np.abs(v).max())
+    # at rest: qfrc_inverse = qfrc_applied (= M ddq + bias on the controlled dofs) up to the residual PD acceleration
+    fa = e.get_field("qfrc_applied")
+    assert np.quantile(np.abs(f - fa), 0.99) < 0.05 * max(1.0, np.abs(fa).max())
+    e.close()
+
+
+def test_c4_full_size_invariants_with_runtime_spawn_and_destroy():
+    """C4 at 2048 envs: PR2 (37 mesh geoms as hulls) on the reference floor + the object pool, slots spawned / destroyed at
+    run time in a different pattern per env (reference shape: test/test_spawn_and_destroy_pr2.py:25-42,69-80): finite, no
+    overflow / reset, the robot keeps standing (base height), destroyed slots stay frozen, spawned objects end on the floor"""
+    m, z = _robot("c4_pr2_world_objects_mesh")
+    lib = ms.capi.load()
+    names = [lib.mjh_id2name(m.ptr, 0, b).decode() for b in range(m.c.nbody)]
+    slots = [b for b, n in enumerate(names) if n.startswith("object_")]
+    nenv = 2048
+    e = ms.Engine(m, nenv)
+    e.set_controlled_dofs(z["controlled"].astype(np.int32))
+    for b in slots:
+        e.set_slot_active(b, False)
+    rng = np.random.default_rng(4)
+    alive = np.zeros((nenv, len(slots)), dtype=bool)
+    base_z0 = None
+    jq = m.array("jnt_qposadr"); bj = m.array("body_jntadr")
+    for rnd in range(6):
+        for i in rng.choice(nenv, nenv // 16, replace=False):
+            k = int(rng.integers(len(slots)))
+            if alive[i, k]:
+                e.set_slot_active(slots[k], False, env0=int(i), n=1); alive[i, k] = False
+            else:
+                a, r = rng.uniform(-np.pi, np.pi), rng.uniform(0.9, 1.5)
+                e.set_slot_active(slots[k], True, env0=int(i), n=1)
+                e.set_body_pose(int(i), slots[k], [r * np.sin(a), r * np.cos(a), 1.0], [1, 0, 0, 0], [0, 0, -0.5, 0.3, 0.2, 0.1])
+                alive[i, k] = True
+        e.step(100, True)
+        t, q, v, _ = e.get_state(); st = e.get_stats()
+        assert np.isfinite(q).all() and np.isfinite(v).all(), rnd
+        assert (st[:, 3] == 0).all(), (rnd, np.unique(st[:, 3]))
+        if base_z0 is None:
+            base_z0 = q[:, 2].copy()
+        assert np.abs(q[:, 2] - base_z0).max() < 0.02                       # the PR2 keeps standing on its casters
+        for k, b in enumerate(slots):
+            qa = jq[bj[b]]; da = m.array("body_dofadr")[b]
+            dead = ~alive[:, k]
+            assert (v[dead][:, da:da + 6] == 0).all()                        # destroyed slots are frozen
+            if rnd >= 2 and alive[:, k].any():
+                zs = q[alive[:, k], qa + 2]
+                assert zs.min() > 0.0 and np.median(zs) < 0.5                 # spawned objects fell onto the floor, none through it
+    print(f"C4 2048 envs: objects alive per env {alive.sum(1).mean():.2f}, mean ncon {st[:, 0].mean():.1f} max {st[:, 0].max()}, mean nefc {st[:, 1].mean():.1f}")
+    e.close()
+
+
+@pytest.mark.parametrize("layout", [1, 2], ids=["lds-resident", "global-pools"])
+def test_c4_pr2_spawn_destroy_schedule_matches_the_oracle(layout, lib):
+    """C4 under the oracle: on the PR2 + world + object-pool fixture, objects are spawned (pose + twist, mj_ros.cpp:1406-1412)
+    and destroyed per env on a schedule (reference shape: test/test_spawn_and_destroy_pr2.py:25-42,69-80), mirrored in the
+    oracle through orc_set_slot_mask; segments of 25 steps, each starting from identical states (contacts of round objects
+    dropped beside a 49-dof robot fork over long horizons).  Both memory layouts."""
+    from test_robot_fixtures import robot_command
+    m, z = _robot("c4_pr2_world_objects_mesh")
+    lib.mjh_set_layout_policy(layout)
+    try:
+        names = [lib.mjh_id2name(m.ptr, 0, b).decode() for b in range(m.c.nbody)]
+        slots = [b for b, n in enumerate(names) if n.startswith("object_")]
+        sbase = m.c.nbody - 32 if m.c.nbody > 32 else 0
+        nenv = 4
+        e = ms.Engine(m, nenv)
+        e.set_controlled_dofs(z["controlled"].astype(np.int32))
+        ds = [orc.OrcData(m.ptr) for _ in range(nenv)]
+        for d in ds:
+            d.ifield("controlled")[:] = z["controlled"]
+        mask = [0] * nenv
+        for b in slots:
+            e.set_slot_active(b, False)
+            for i in range(nenv):
+                mask[i] |= 1 << (b - sbase)
+        for i, d in enumerate(ds):
+            d.L.orc_set_slot_mask(d.d, mask[i])
+        rng = np.random.default_rng(21)
+        jq, bj, bd = m.array("jnt_qposadr"), m.array("body_jntadr"), m.array("body_dofadr")
+        order = [rng.permutation(len(slots)) for _ in range(nenv)]
+        worst = 0.0; step = 0
+        for rnd in range(7):
+            for i, d in enumerate(ds):
+                if rnd < 5:                                           # spawn next to the robot, with a twist
+                    b = slots[int(order[i][rnd])]
+                    a, r = rng.uniform(-np.pi, np.pi), rng.uniform(0.9, 1.3)
+                    pos = np.array([r * np.sin(a), r * np.cos(a), 0.6]); quat = rng.normal(size=4); quat /= np.linalg.norm(quat)
+                    vel = np.array([0.1, -0.1, -0.3, *(0.5 * rng.normal(size=3))])
+                    e.set_slot_active(b, True, env0=i, n=1); e.set_body_pose(i, b, pos, quat, vel)
+                    mask[i] &= ~(1 << (b - sbase)); d.L.orc_set_slot_mask(d.d, mask[i])
+                    qa, da = jq[bj[b]], bd[b]
+                    d.f("qpos")[qa:qa + 3] = pos; d.f("qpos")[qa + 3:qa + 7] = quat; d.f("qvel")[da:da + 6] = vel
+                else:                                                 # destroy the first arrivals again
+                    b = slots[int(order[i][rnd - 5])]
+                    e.set_slot_active(b, False, env0=i, n=1)
+                    mask[i] |= 1 << (b - sbase); d.L.orc_set_slot_mask(d.d, mask[i])
+            for k in range(25):
+                step += 1
+                cmd = robot_command(m, step)
+                e.set_cmd(ddq=np.tile(cmd, (nenv, 1))); e.step(1, True)
+                for d in ds:
+                    d.f("ddq")[:] = cmd; d.step(1, 1)
+            _, q, v, _ = e.get_state(); st = e.get_stats()
+            assert (st[:, 3] == 0).all() and all(d.i("warn") == 0 for d in ds), (rnd, st[:, 3])
+            oq = np.array([d.f("qpos") for d in ds]); ov = np.array([d.f("qvel") for d in ds])
+            err = np.abs(q - oq).max(axis=1)
+            worst = max(worst, float(err.max()))
+            assert (err < 5e-3).sum() >= nenv - 1 and err.max() < 0.2, (rnd, err)
+            fi = e.get_field("qfrc_inverse")
+            for i, d in enumerate(ds):
+                if err[i] < 5e-3:
+                    ref = d.f("qfrc_inverse")
+                    np.testing.assert_allclose(fi[i], ref, rtol=0, atol=2e-2 * max(1.0, np.abs(ref).max()))
+                for b in slots:                                       # destroyed slots: frozen on both sides
+                    if mask[i] >> (b - sbase) & 1:
+                        assert (v[i, bd[b]:bd[b] + 6] == 0).all() and (ov[i, bd[b]:bd[b] + 6] == 0).all()
+            e.set_state(qpos=oq, qvel=ov, warmstart=np.array([d.f("qacc_warmstart") for d in ds]))
+        assert max(d.i("ncon") for d in ds) >= 16
+        print(f"C4 spawn/destroy schedule vs oracle (layout {layout}): worst |dqpos| over 7 segments {worst:.2e}")
+        e.close()
+    finally:
+        lib.mjh_set_layout_policy(0)
