@@ -388,11 +388,52 @@ int mjh_get_cohorts(const mjh_engine*);
 int mjh_set_launch_timing(mjh_engine*, int on);
 int mjh_get_launch_timing(mjh_engine*, double* mean_ms, int* count);
 
+/* ---- multi-GPU: the environments of ONE simulation sharded over the GPUs of a node, driven by ONE host thread.
+ * The reference is a single C++ node with a single publisher set (src/mj_main.cpp:167-236, src/mujoco_sim/mj_ros.cpp:554-564).
+ * Environments are independent, so a group is one engine + one stream per device over contiguous env ranges
+ * [k*N/G + min(k, N%G), ...) (shares differ by at most one), model tables replicated and NO collective in the step; the only
+ * exchange is mjh_group_publish(): every device packs its slice (time | qpos | qvel per env, fp32, mjh_export_state_device)
+ * and one RCCL ncclAllGather over xGMI leaves the full env-ordered state on EVERY device — issued at the state topic's rate,
+ * not per step.  RCCL is resolved at run time (dlopen); without it, or when a device is listed twice, the
+ * gather uses peer copies.  Everything else (commands, getters, slots, mirrors) goes through the per-device engines with
+ * LOCAL env ids: mjh_group_engine() / mjh_group_locate().  All calls are asynchronous like their mjh_* counterparts. */
+typedef struct mjh_group mjh_group;
+int mjh_group_create(const mjh_model* model, int nenv_total, const int* devices /* NULL: 0..ndev-1 */, int ndev, mjh_group** out);
+void mjh_group_destroy(mjh_group*);
+int mjh_group_ndev(const mjh_group*);
+int mjh_group_nenv(const mjh_group*);
+mjh_engine* mjh_group_engine(mjh_group*, int rank);
+int mjh_group_env_range(const mjh_group*, int rank, int* env0, int* n);
+int mjh_group_locate(const mjh_group*, int env, int* rank, int* local_env);
+int mjh_group_step(mjh_group*, int nsteps, int with_inverse);   /* mjh_step on every device */
+int mjh_group_step1(mjh_group*);                                /* mj_main.cpp:83 on every device */
+int mjh_group_inverse(mjh_group*);
+int mjh_group_step2(mjh_group*);                                /* mj_main.cpp:108 */
+int mjh_group_reset(mjh_group*);
+int mjh_group_synchronize(mjh_group*);
+/* pack + all-gather; host_out (may be NULL) receives device 0's copy: [nenv_total * mjh_group_state_stride()] floats, env order */
+int mjh_group_publish(mjh_group*, float* host_out);
+const float* mjh_group_state_device(const mjh_group*, int rank);   /* the gathered state on device `rank` (valid after publish, in stream order) */
+int mjh_group_state_stride(const mjh_group*);
+int mjh_group_uses_rccl(const mjh_group*);
+void mjh_group_set_transport(int mode);   /* groups created afterwards: 0 = RCCL when available (default), 1 = peer copies */
+
 /* ROS-free harness of the host loop (csrc/host_sim.cpp: simulate() + MjhHWInterface, mirrors of
  * mj_main.cpp:76-164 and mj_hw_interface.cpp:59-110) with an in-process PD effort controller on
  * every hinge/slide joint of env `env`; returns final joint positions / efforts and the real-time factor */
 int mjh_host_run_pd(mjh_engine*, int env, const double* target, double kp, double kd, long nsteps,
                     double* out_qpos, double* out_effort, double* out_rtf);
+
+/* the same harness over a multi-GPU group: the ROS surface attached to GLOBAL env `env`, every shard stepped each step
+ * (mjh_group_step1 / inverse / step2), the state slice of all environments all-gathered every `publish_every` steps; out_state
+ * (may be NULL, [nenv_total * stride] floats) receives the last published slice */
+int mjh_host_run_pd_group(mjh_group*, int env, const double* target, double kp, double kd, long nsteps, int publish_every,
+                          double* out_qpos, double* out_effort, float* out_state);
+/* simulate() with its real-time pacing switched ON (mj_main.cpp:115-163): the wall-clock spin that holds the real-time factor
+ * at <= 1 and the adaptive timestep (doubled while the simulation lags the wall clock by > 1 ms, up to max_time_step; halved
+ * back otherwise).  out_stats6 = {sim_time, wall_time, rtf, final_dt, steps, dt_changes} */
+int mjh_host_run_realtime(mjh_engine*, int env, const double* target, double kp, double kd, long nsteps, double max_time_step,
+                          double* out_stats6);
 
 /* introspection */
 int mjh_nenv(const mjh_engine*);

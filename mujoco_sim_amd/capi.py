@@ -177,11 +177,31 @@ SYMBOLS = [
     ("mjh_get_cohorts", C.c_int, [_vp]),
     ("mjh_set_launch_timing", C.c_int, [_vp, C.c_int]),
     ("mjh_get_launch_timing", C.c_int, [_vp, c_double_p, C.POINTER(C.c_int)]),
+    ("mjh_group_create", C.c_int, [Model_p, C.c_int, c_int_p, C.c_int, C.POINTER(_vp)]),
+    ("mjh_group_destroy", None, [_vp]),
+    ("mjh_group_ndev", C.c_int, [_vp]),
+    ("mjh_group_nenv", C.c_int, [_vp]),
+    ("mjh_group_engine", _vp, [_vp, C.c_int]),
+    ("mjh_group_env_range", C.c_int, [_vp, C.c_int, c_int_p, c_int_p]),
+    ("mjh_group_locate", C.c_int, [_vp, C.c_int, c_int_p, c_int_p]),
+    ("mjh_group_step", C.c_int, [_vp, C.c_int, C.c_int]),
+    ("mjh_group_step1", C.c_int, [_vp]),
+    ("mjh_group_inverse", C.c_int, [_vp]),
+    ("mjh_group_step2", C.c_int, [_vp]),
+    ("mjh_group_reset", C.c_int, [_vp]),
+    ("mjh_group_synchronize", C.c_int, [_vp]),
+    ("mjh_group_publish", C.c_int, [_vp, C.POINTER(C.c_float)]),
+    ("mjh_group_state_device", C.POINTER(C.c_float), [_vp, C.c_int]),
+    ("mjh_group_state_stride", C.c_int, [_vp]),
+    ("mjh_group_uses_rccl", C.c_int, [_vp]),
+    ("mjh_group_set_transport", None, [C.c_int]),
     ("mjh_nenv", C.c_int, [_vp]),
     ("mjh_engine_model", Model_p, [_vp]),
     ("mjh_lds_bytes", C.c_int, [_vp]),
     ("mjh_query_lds_bytes", C.c_int, [Model_p]),
     ("mjh_host_run_pd", C.c_int, [_vp, C.c_int, c_double_p, C.c_double, C.c_double, C.c_long, c_double_p, c_double_p, c_double_p]),
+    ("mjh_host_run_pd_group", C.c_int, [_vp, C.c_int, c_double_p, C.c_double, C.c_double, C.c_long, C.c_int, c_double_p, c_double_p, C.POINTER(C.c_float)]),
+    ("mjh_host_run_realtime", C.c_int, [_vp, C.c_int, c_double_p, C.c_double, C.c_double, C.c_long, C.c_double, c_double_p]),
     ("mjh_last_error", C.c_char_p, []),
     ("mjh_version", C.c_char_p, []),
 ]

@@ -1,0 +1,219 @@
+// group.hip — the environments of ONE simulation sharded over the GPUs of a node, driven by ONE host thread through the C ABI
+// (include/mjhip.h "multi-GPU").  The reference is one C++ node with one publisher set (src/mj_main.cpp:167-236,
+// src/mujoco_sim/mj_ros.cpp:554-564); with many environments the stepper shards them — contiguous env ranges, one engine and one
+// stream per device, model tables replicated, NO collective in the step (environments are independent) — and the only exchange
+// is the all-gather of the published state slice (time | qpos | qvel per env, fp32) that feeds the single state / clock
+// publisher: RCCL ncclAllGather over xGMI, issued at the publish rate, not per step.
+// RCCL is resolved with dlopen (no link-time dependency: the library loads on hosts without it); without it the gather falls
+// back to peer copies (hipMemcpyPeerAsync), which is also what a gather to ONE consumer would use.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mjhip.h"
+
+void mjh_set_error(const std::string& s);  // model_builder.cpp
+
+#define GCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { mjh_set_error(std::string(#call) + ": " + hipGetErrorString(e_)); return MJH_ERR_NO_DEVICE; } } while (0)
+
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok() const { return lib && CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd; }
+};
+Rccl* load_rccl() {
+  static Rccl r; static bool tried = false;
+  if (tried) return r.ok() ? &r : nullptr;
+  tried = true;
+  // a process that already holds RCCL (torch bundles its own) must not get a second copy: look the symbols up globally first
+  const char* names[] = {nullptr, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char* n : names) {
+    void* h = n ? dlopen(n, RTLD_NOW | RTLD_GLOBAL) : dlopen(nullptr, RTLD_NOW);
+    if (!h) continue;
+    if (!dlsym(h, "ncclAllGather")) { if (n) dlclose(h); continue; }
+    r.lib = h;
+    r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (r.ok()) return &r;
+  }
+  return nullptr;
+}
+int g_transport = 0;   // 0: RCCL when it can be loaded (and the devices are distinct), 1: peer copies
+}  // namespace
+
+struct mjh_group {
+  const mjh_model* model = nullptr;
+  int nenv = 0, ndev = 0, stride = 0;
+  size_t slot = 0;                                   // floats per rank in the gathered buffer: max_k n_k * stride
+  std::vector<int> dev, env0, n;
+  std::vector<mjh_engine*> eng;
+  std::vector<hipStream_t> stream;
+  std::vector<hipEvent_t> ready;                     // send buffer of device k packed (peer-copy transport)
+  std::vector<float*> send, recv, packed;            // per device: own slice | every rank's slot | env-ordered, contiguous
+  float* host = nullptr;                             // pinned staging of the gathered state (rank 0's copy)
+  Rccl* rccl = nullptr; std::vector<ncclComm_t> comm;
+  bool padded = false;
+};
+
+extern "C" void mjh_group_set_transport(int mode) { g_transport = mode == 1 ? 1 : 0; }
+
+extern "C" void mjh_group_destroy(mjh_group* g) {
+  if (!g) return;
+  for (int k = 0; k < (int)g->eng.size(); k++) {
+    (void)hipSetDevice(g->dev[k]);
+    if (g->eng[k]) mjh_destroy(g->eng[k]);
+    if (k < (int)g->comm.size() && g->comm[k] && g->rccl) (void)g->rccl->CommDestroy(g->comm[k]);
+    if (k < (int)g->send.size() && g->send[k]) (void)hipFree(g->send[k]);
+    if (k < (int)g->recv.size() && g->recv[k]) (void)hipFree(g->recv[k]);
+    if (g->padded && k < (int)g->packed.size() && g->packed[k]) (void)hipFree(g->packed[k]);
+    if (k < (int)g->ready.size() && g->ready[k]) (void)hipEventDestroy(g->ready[k]);
+    if (k < (int)g->stream.size() && g->stream[k]) (void)hipStreamDestroy(g->stream[k]);
+  }
+  if (g->host) (void)hipHostFree(g->host);
+  delete g;
+}
+
+extern "C" int mjh_group_create(const mjh_model* model, int nenv_total, const int* devices, int ndev, mjh_group** out) {
+  if (!model || nenv_total <= 0 || ndev <= 0 || ndev > nenv_total || !out) { mjh_set_error("mjh_group_create: bad argument"); return MJH_ERR_ARG; }
+  int have = 0;
+  if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) { mjh_set_error("mjh_group_create: no HIP device visible (no CPU fallback)"); return MJH_ERR_NO_DEVICE; }
+  mjh_group* g = new mjh_group();
+  g->model = model; g->nenv = nenv_total; g->ndev = ndev;
+  g->dev.resize(ndev); g->env0.resize(ndev); g->n.resize(ndev);
+  g->eng.assign(ndev, nullptr); g->stream.assign(ndev, nullptr); g->ready.assign(ndev, nullptr);
+  g->send.assign(ndev, nullptr); g->recv.assign(ndev, nullptr); g->packed.assign(ndev, nullptr);
+  bool distinct = true;
+  for (int k = 0; k < ndev; k++) {
+    g->dev[k] = devices ? devices[k] : k;
+    if (g->dev[k] < 0 || g->dev[k] >= have) { mjh_set_error("mjh_group_create: bad device index"); mjh_group_destroy(g); return MJH_ERR_ARG; }
+    for (int j = 0; j < k; j++) distinct &= g->dev[j] != g->dev[k];
+    // contiguous env ranges, sizes differ by at most one (same rule as mujoco_sim_amd/shard.py: env_range)
+    const int base = nenv_total / ndev, rem = nenv_total % ndev;
+    g->env0[k] = k * base + std::min(k, rem); g->n[k] = base + (k < rem ? 1 : 0);
+  }
+  g->padded = nenv_total % ndev != 0;
+#define GFAIL(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { mjh_set_error(std::string(#call) + ": " + hipGetErrorString(e_)); mjh_group_destroy(g); return MJH_ERR_NO_DEVICE; } } while (0)
+  for (int k = 0; k < ndev; k++) {
+    GFAIL(hipSetDevice(g->dev[k]));
+    GFAIL(hipStreamCreateWithFlags(&g->stream[k], hipStreamNonBlocking));
+    GFAIL(hipEventCreateWithFlags(&g->ready[k], hipEventDisableTiming));
+    const int rc = mjh_create(model, g->n[k], g->dev[k], g->stream[k], &g->eng[k]);
+    if (rc) { mjh_group_destroy(g); return rc; }
+  }
+  g->stride = mjh_state_stride(g->eng[0]);
+  g->slot = (size_t)g->n[0] * g->stride;             // n[0] is the largest share
+  for (int k = 0; k < ndev; k++) {
+    GFAIL(hipSetDevice(g->dev[k]));
+    GFAIL(hipMalloc((void**)&g->send[k], g->slot * sizeof(float)));
+    GFAIL(hipMemsetAsync(g->send[k], 0, g->slot * sizeof(float), g->stream[k]));
+    GFAIL(hipMalloc((void**)&g->recv[k], g->slot * ndev * sizeof(float)));
+    if (g->padded) GFAIL(hipMalloc((void**)&g->packed[k], (size_t)nenv_total * g->stride * sizeof(float)));
+    else g->packed[k] = g->recv[k];
+    GFAIL(hipStreamSynchronize(g->stream[k]));
+  }
+  GFAIL(hipHostMalloc((void**)&g->host, (size_t)nenv_total * g->stride * sizeof(float), hipHostMallocDefault));
+#undef GFAIL
+  if (g_transport == 0 && distinct) {
+    g->rccl = load_rccl();
+    if (g->rccl) {
+      g->comm.assign(ndev, nullptr);
+      const ncclResult_t r = g->rccl->CommInitAll(g->comm.data(), ndev, g->dev.data());
+      if (r != ncclSuccess) {
+        mjh_set_error(std::string("ncclCommInitAll: ") + (g->rccl->GetErrorString ? g->rccl->GetErrorString(r) : "failed"));
+        g->comm.clear(); g->rccl = nullptr;           // keep going on peer copies; mjh_group_uses_rccl() says so
+      }
+    }
+  }
+  *out = g;
+  return MJH_OK;
+}
+
+extern "C" int mjh_group_ndev(const mjh_group* g) { return g ? g->ndev : 0; }
+extern "C" int mjh_group_nenv(const mjh_group* g) { return g ? g->nenv : 0; }
+extern "C" int mjh_group_uses_rccl(const mjh_group* g) { return g && g->rccl ? 1 : 0; }
+extern "C" mjh_engine* mjh_group_engine(mjh_group* g, int k) { return g && k >= 0 && k < g->ndev ? g->eng[k] : nullptr; }
+extern "C" int mjh_group_env_range(const mjh_group* g, int k, int* env0, int* n) {
+  if (!g || k < 0 || k >= g->ndev) { mjh_set_error("mjh_group_env_range: bad rank"); return MJH_ERR_ARG; }
+  if (env0) *env0 = g->env0[k];
+  if (n) *n = g->n[k];
+  return MJH_OK;
+}
+extern "C" int mjh_group_locate(const mjh_group* g, int env, int* rank, int* local) {
+  if (!g || env < 0 || env >= g->nenv) { mjh_set_error("mjh_group_locate: env out of range"); return MJH_ERR_ARG; }
+  for (int k = 0; k < g->ndev; k++) if (env < g->env0[k] + g->n[k]) { if (rank) *rank = k; if (local) *local = env - g->env0[k]; return MJH_OK; }
+  return MJH_ERR_ARG;
+}
+
+// one call per device, all asynchronous: the devices step concurrently, the host thread never waits here
+#define FOR_ALL(expr) do { for (int k = 0; k < g->ndev; k++) { mjh_engine* e = g->eng[k]; const int rc_ = (expr); if (rc_) return rc_; } return MJH_OK; } while (0)
+extern "C" int mjh_group_step(mjh_group* g, int nsteps, int with_inverse) { if (!g) return MJH_ERR_ARG; FOR_ALL(mjh_step(e, nsteps, with_inverse)); }
+extern "C" int mjh_group_step1(mjh_group* g) { if (!g) return MJH_ERR_ARG; FOR_ALL(mjh_step1(e)); }
+extern "C" int mjh_group_step2(mjh_group* g) { if (!g) return MJH_ERR_ARG; FOR_ALL(mjh_step2(e)); }
+extern "C" int mjh_group_inverse(mjh_group* g) { if (!g) return MJH_ERR_ARG; FOR_ALL(mjh_inverse(e)); }
+extern "C" int mjh_group_reset(mjh_group* g) { if (!g) return MJH_ERR_ARG; FOR_ALL(mjh_reset(e, nullptr, 0)); }
+extern "C" int mjh_group_synchronize(mjh_group* g) { if (!g) return MJH_ERR_ARG; FOR_ALL(mjh_synchronize(e)); }
+#undef FOR_ALL
+
+// Publish: every device packs its slice (time | qpos | qvel per env) behind the steps queued so far, then ONE all-gather
+// leaves the full, env-ordered state on every device; host_out (optional, [nenv * stride] floats) receives device 0's copy.
+extern "C" int mjh_group_publish(mjh_group* g, float* host_out) {
+  if (!g) { mjh_set_error("null group"); return MJH_ERR_ARG; }
+  const size_t slot_bytes = g->slot * sizeof(float);
+  for (int k = 0; k < g->ndev; k++) {
+    const int rc = mjh_export_state_device(g->eng[k], g->send[k]);      // (re-selects device k)
+    if (rc) return rc;
+    if (!g->rccl) GCHK(hipEventRecord(g->ready[k], g->stream[k]));
+  }
+  if (g->rccl) {
+    ncclResult_t r = g->rccl->GroupStart();
+    for (int k = 0; k < g->ndev && r == ncclSuccess; k++) {
+      GCHK(hipSetDevice(g->dev[k]));
+      r = g->rccl->AllGather(g->send[k], g->recv[k], g->slot, ncclFloat, g->comm[k], g->stream[k]);
+    }
+    const ncclResult_t r2 = g->rccl->GroupEnd();
+    if (r != ncclSuccess || r2 != ncclSuccess) {
+      mjh_set_error(std::string("ncclAllGather: ") + (g->rccl->GetErrorString ? g->rccl->GetErrorString(r != ncclSuccess ? r : r2) : "failed"));
+      return MJH_ERR_NO_DEVICE;
+    }
+  } else {
+    for (int k = 0; k < g->ndev; k++) {
+      GCHK(hipSetDevice(g->dev[k]));
+      for (int r = 0; r < g->ndev; r++) {
+        GCHK(hipStreamWaitEvent(g->stream[k], g->ready[r], 0));
+        GCHK(hipMemcpyPeerAsync(g->recv[k] + (size_t)r * g->slot, g->dev[k], g->send[r], g->dev[r], slot_bytes, g->stream[k]));
+      }
+    }
+  }
+  if (g->padded)     // uneven shares: the ranks' slots carry padding behind the smaller shares; close the gaps
+    for (int k = 0; k < g->ndev; k++) {
+      GCHK(hipSetDevice(g->dev[k]));
+      for (int r = 0; r < g->ndev; r++)
+        GCHK(hipMemcpyAsync(g->packed[k] + (size_t)g->env0[r] * g->stride, g->recv[k] + (size_t)r * g->slot, (size_t)g->n[r] * g->stride * sizeof(float),
+                            hipMemcpyDeviceToDevice, g->stream[k]));
+    }
+  if (host_out) {
+    GCHK(hipSetDevice(g->dev[0]));
+    const size_t bytes = (size_t)g->nenv * g->stride * sizeof(float);
+    GCHK(hipMemcpyAsync(g->host, g->packed[0], bytes, hipMemcpyDeviceToHost, g->stream[0]));
+    GCHK(hipStreamSynchronize(g->stream[0]));
+    std::memcpy(host_out, g->host, bytes);
+  }
+  return MJH_OK;
+}
+extern "C" const float* mjh_group_state_device(const mjh_group* g, int k) { return g && k >= 0 && k < g->ndev ? g->packed[k] : nullptr; }
+extern "C" int mjh_group_state_stride(const mjh_group* g) { return g ? g->stride : 0; }

@@ -27,7 +27,14 @@ struct MjhSim {
 
   mjh_engine* engine = nullptr;
   const mjh_model* model = nullptr;
-  int env = 0;  // which environment the single ROS surface is attached to
+  int env = 0;  // which environment the single ROS surface is attached to (LOCAL id on `engine`)
+  // multi-GPU (include/mjhip.h "multi-GPU"): when set, simulate() steps every device of the group; `engine` / `env` are the
+  // shard and local id of the attached environment (attach_group), and every `publish_every` steps the state slice of ALL
+  // environments is all-gathered (RCCL) into `published` — what the single state / clock publisher set reads (mj_ros.cpp:554-564)
+  mjh_group* group = nullptr;
+  int publish_every = 0;
+  std::vector<float> published;
+  int attach_group(mjh_group* g, int global_env);
 
   // push controlled_joints / odom joints to the engine (name -> id resolved ONCE, not per step)
   int sync_controlled();

@@ -106,9 +106,18 @@ class Engine:
         self.h = h
         self.nq, self.nv, self.nbody, self.ngeom = model.nq, model.nv, model.nbody, model.ngeom
 
+    @classmethod
+    def from_handle(cls, model, handle, nenv):
+        """view of an engine owned by someone else (a device of an mjh_group): close() does not destroy it"""
+        self = cls.__new__(cls)
+        self.lib = model.lib; self.model = model; self.nenv = nenv; self.h = C.c_void_p(handle); self._borrowed = True
+        self.nq, self.nv, self.nbody, self.ngeom = model.nq, model.nv, model.nbody, model.ngeom
+        return self
+
     def close(self):
         if getattr(self, "h", None):
-            self.lib.mjh_destroy(self.h)
+            if not getattr(self, "_borrowed", False):
+                self.lib.mjh_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -281,3 +290,56 @@ class Engine:
         self.set_initial_qpos(t["qpos"])
         self.reset()
         return t
+
+
+class Group:
+    """mjh_group: the environments of one simulation sharded over the GPUs of a node (one engine + stream per device, env ranges
+    contiguous); the only exchange is publish() = pack + RCCL all-gather of the state slice (include/mjhip.h "multi-GPU")."""
+
+    def __init__(self, model, nenv_total, devices):
+        self.lib = model.lib; self.model = model; self.nenv = nenv_total
+        dv = np.ascontiguousarray(devices, dtype=np.int32)
+        h = C.c_void_p()
+        _chk(self.lib, self.lib.mjh_group_create(model.ptr, nenv_total, capi.iptr(dv), len(dv), C.byref(h)), "mjh_group_create")
+        self.h = h
+        self.ndev = self.lib.mjh_group_ndev(h)
+        self.ranges = []
+        self.engines = []
+        for k in range(self.ndev):
+            a, b = C.c_int(0), C.c_int(0)
+            _chk(self.lib, self.lib.mjh_group_env_range(h, k, C.byref(a), C.byref(b)), "mjh_group_env_range")
+            self.ranges.append((a.value, b.value))
+            self.engines.append(Engine.from_handle(model, self.lib.mjh_group_engine(h, k), b.value))
+        self.stride = self.lib.mjh_group_state_stride(h)
+
+    @property
+    def uses_rccl(self): return bool(self.lib.mjh_group_uses_rccl(self.h))
+    def step(self, n=1, with_inverse=False): _chk(self.lib, self.lib.mjh_group_step(self.h, n, int(with_inverse)), "mjh_group_step")
+    def step1(self): _chk(self.lib, self.lib.mjh_group_step1(self.h), "mjh_group_step1")
+    def inverse(self): _chk(self.lib, self.lib.mjh_group_inverse(self.h), "mjh_group_inverse")
+    def step2(self): _chk(self.lib, self.lib.mjh_group_step2(self.h), "mjh_group_step2")
+    def synchronize(self): _chk(self.lib, self.lib.mjh_group_synchronize(self.h), "mjh_group_synchronize")
+
+    def publish(self):
+        """-> [nenv, 1 + nq + nv] float32: time | qpos | qvel of every env in env order (device 0's copy of the all-gather)"""
+        out = np.zeros((self.nenv, self.stride), dtype=np.float32)
+        _chk(self.lib, self.lib.mjh_group_publish(self.h, out.ctypes.data_as(C.POINTER(C.c_float))), "mjh_group_publish")
+        return out
+
+    def locate(self, env):
+        r, l = C.c_int(0), C.c_int(0)
+        _chk(self.lib, self.lib.mjh_group_locate(self.h, env, C.byref(r), C.byref(l)), "mjh_group_locate")
+        return r.value, l.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            for e in self.engines:
+                e.close()
+            self.lib.mjh_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
