@@ -16,6 +16,10 @@ int MjhSim::sync_controlled() {
     if (id < 0) continue;
     mask[model->jnt_dofadr[id]] = 1;  // hinge / slide joints: one dof (the reference indexes jnt_dofadr the same way)
   }
+  if (group) {   // the controlled-joint set is a property of the model, not of one environment: every shard gets it
+    for (int k = 0; k < mjh_group_ndev(group); k++) { const int rc = mjh_set_controlled_dofs(mjh_group_engine(group, k), mask.data()); if (rc) return rc; }
+    return MJH_OK;
+  }
   return mjh_set_controlled_dofs(engine, mask.data());
 }
 
@@ -37,6 +41,10 @@ int MjhSim::sync_odom(const std::string& robot) {
     l[k] = jl >= 0 ? model->jnt_dofadr[jl] : -1;
     a[k] = ja >= 0 ? model->jnt_dofadr[ja] : -1;
     aq[k] = ja >= 0 ? model->jnt_qposadr[ja] : -1;
+  }
+  if (group) {
+    for (int k = 0; k < mjh_group_ndev(group); k++) { const int rc = mjh_set_odom_dofs(mjh_group_engine(group, k), l, a, aq); if (rc) return rc; }
+    return MJH_OK;
   }
   return mjh_set_odom_dofs(engine, l, a, aq);
 }

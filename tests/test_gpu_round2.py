@@ -178,6 +178,7 @@ def test_c3_full_size_invariants():
     assert (st[:, 3] == 0).all()
     assert (q > lo - 2e-2).all() and (q < hi + 2e-2).all()
     assert np.abs(v).max() < 0.2, np.abs(v).max()
+    e.step1(); e.inverse()                       # split API: qfrc_passive / qfrc_applied / qfrc_inverse of THIS step are readable
     # Where the arms come to rest: the wrapper compensates gravity twice (gravcomp = 1 in qfrc_passive AND qfrc_bias added on
     # the controlled dofs, mj_sim.cpp:301-310,1058-1063 — reproduced literally), so the PD law settles at the offset where
     # M ddq = -qfrc_passive, not at the target.  Checked with the engine's own mj_mulM and qfrc_passive on every env.
@@ -188,7 +189,6 @@ def test_c3_full_size_invariants():
     assert np.quantile(np.abs(q - target), 0.99) < 0.6
     # mj_inverse's contract (mj_hw_interface.cpp:61-69) on every env: with the limits inactive, qfrc_inverse of the step equals
     # the torque the controller applied, qfrc_applied = M ddq + bias (split API: the hand-over vectors are then readable)
-    e.step1(); e.inverse()
     fa, fi = e.get_field("qfrc_applied"), e.get_field("qfrc_inverse")
     e.step2()
     free = (st[:, 1] == 0)
