@@ -22,9 +22,15 @@ def gather_state(local, total, world, rank):
         out = torch.empty(total * stride, dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.reshape(-1).contiguous())
         return out.reshape(total, stride)
-    parts = [torch.empty(s, stride, dtype=local.dtype, device=local.device) for s in sizes]
-    dist.all_gather(parts, local.contiguous())
-    return torch.cat(parts, 0)
+    # uneven shares (they differ by at most one env): every rank pads its slice to the largest share, one all-gather of equal
+    # slots, then the padding rows are dropped — the same scheme as mjh_group_publish (csrc/group.hip)
+    slot = max(sizes)
+    padded = torch.zeros(slot, stride, dtype=local.dtype, device=local.device)
+    padded[:local.shape[0]] = local
+    out = torch.empty(world * slot * stride, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded.reshape(-1).contiguous())
+    out = out.reshape(world, slot, stride)
+    return torch.cat([out[r, :sizes[r]] for r in range(world)], 0)
 
 
 def max_over_ranks(x):

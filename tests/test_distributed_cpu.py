@@ -14,15 +14,37 @@ WORKER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1])
 import numpy as np, torch, torch.distributed as dist
+import mujoco_sim_amd as ms
 from mujoco_sim_amd import shard
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-total, stride = 10, 5
-lo, hi = shard.env_range(total, world, rank)
-# fake "exported state": row e = [time, e, e, e, e]
-local = torch.tensor([[0.005 * (e + 1)] + [float(e)] * (stride - 1) for e in range(lo, hi)], dtype=torch.float32)
-full = shard.gather_state(local, total, world, rank)
-ok = full.shape == (total, stride) and bool((full[:, 1] == torch.arange(total)).all())
+ok = True
+for total in (10, 7):                       # even and uneven shares
+    lo, hi = shard.env_range(total, world, rank)
+    n = hi - lo
+    # this rank's shard as the engine lays it out in HBM (csrc/engine.hip: one padded record per env, qpos | qvel | ...):
+    # the S24 model's sizes, per-env content drawn by the scene's own randomiser with GLOBAL env ids
+    m = ms.scene("s24")
+    nq, nv = m.nq, m.nv
+    nqp = ((nq + 4 * nv + 31) // 32) * 32
+    tab = m.s24_randomize(lo, n)            # env_offset = lo: rank r owns the global envs [lo, hi)
+    rec = np.zeros((n, nqp), dtype=np.float32)
+    rec[:, :nq] = tab["qpos"]
+    rec[:, nq:nq + nv] = (np.arange(lo, hi)[:, None] * 100 + np.arange(nv)[None, :]).astype(np.float32)   # qvel: env id + dof id
+    time = (0.005 * (np.arange(lo, hi) + 1)).astype(np.float32)
+    # mjh_export_kernel's packing (csrc/step_kernel.h): out[i] with e = i // stride, k = i % stride:
+    #   k == 0 -> time[e];  k <= nq -> qpos[e * nqp + k - 1];  else qvel[e * nvp + k - 1 - nq]  (qvel = column nq of the record)
+    stride = 1 + nq + nv
+    flat = np.empty(n * stride, dtype=np.float32)
+    for i in range(n * stride):
+        e, k = divmod(i, stride)
+        flat[i] = time[e] if k == 0 else (rec[e, k - 1] if k <= nq else rec[e, nq + (k - 1 - nq)])
+    full = shard.gather_state(torch.from_numpy(flat.reshape(n, stride)), total, world, rank).numpy()
+    ref = ms.scene("s24").s24_randomize(0, total)["qpos"].astype(np.float32)      # what ONE engine over all envs would hold
+    ok &= full.shape == (total, stride)
+    ok &= bool(np.array_equal(full[:, 0], (0.005 * (np.arange(total) + 1)).astype(np.float32)))
+    ok &= bool(np.array_equal(full[:, 1:1 + nq], ref))                             # env order across the ranks, row by row
+    ok &= bool(np.array_equal(full[:, 1 + nq:], (np.arange(total)[:, None] * 100 + np.arange(nv)[None, :]).astype(np.float32)))
 tmax = shard.max_over_ranks(float(rank + 1))
 print("RESULT", rank, int(ok), tmax)
 dist.destroy_process_group()
