@@ -45,6 +45,8 @@ enum mjh_geom {
 };
 
 enum mjh_eq { MJH_EQ_CONNECT = 0, MJH_EQ_WELD = 1, MJH_EQ_JOINT = 2 };
+/* sensor types: values follow mjtSensor; the reference publishes exactly these two (MjSim::init_sensors, mj_sim.cpp:973-1014) */
+enum mjh_sensor { MJH_SENS_FORCE = 4, MJH_SENS_TORQUE = 5 };
 
 /* constraint row types (order of assembly: equality, friction loss, limit, contact) */
 enum mjh_cnstr {
@@ -133,6 +135,21 @@ typedef struct mjh_model {
   /* name tables: resolved ONCE on the host (the reference calls mj_name2id per
    * joint per step: mj_hw_interface.cpp:64,79; mj_sim.cpp:1060,1083-1146) */
   char **body_names, **jnt_names, **geom_names;
+  /* ---- appended in round 2 (older fields keep their offsets) ----
+   * sites and force / torque sensors (m->nsensor, sensor_type, sensor_objid, sensor_adr, nsensordata: mj_sim.cpp:973-1014,
+   * mj_ros.cpp:1933-1966); a sensor measures the interaction force (torque) between its site's body and that body's parent,
+   * in the site frame, 3 numbers each */
+  int nsite, nsensor, nsensordata, nmocap;
+  int* site_bodyid; double *site_pos, *site_quat;      /* [nsite], [3*nsite], [4*nsite]: site frame in its body */
+  int *sensor_type, *sensor_objid, *sensor_adr;        /* [nsensor]: mjh_sensor, site id, first index in sensordata */
+  char **site_names, **sensor_names;
+  /* mocap bodies (the `_ref` bodies MjSim::init_references welds robot links to, mj_sim.cpp:847-960): static children of the
+   * world whose pose is an INPUT per environment (mjh_set_mocap_pose); body_mocapid[b] = index or -1; their initial pose is
+   * body_pos / body_quat.  eq_type CONNECT / WELD: eq_obj1id / eq_obj2id are BODY ids (0 = world) and eq_data holds
+   *   connect: [0..2] anchor in body1's frame, [3..5] the same point in body2's frame at qpos0
+   *   weld:    [0..2] anchor in body2's frame, [3..5] the same point in body1's frame at qpos0,
+   *            [6..9] relative orientation quat(body2)^-1 * quat(body1) at qpos0, [10] torquescale */
+  int* body_mocapid;
 } mjh_model;
 
 /* ------------------------------------------------- model builder (host) */
@@ -171,6 +188,16 @@ int mjh_builder_add_mesh_geom(mjh_builder*, const char* name, int body, int mesh
                               const double friction[3], int condim, int contype, int conaffinity, double density);
 int mjh_builder_add_exclude(mjh_builder*, int body1, int body2);
 int mjh_builder_add_eq_joint(mjh_builder*, int joint1, int joint2, const double polycoef[5]);
+/* <equality><connect body1 body2 anchor> / <weld body1 body2 anchor torquescale> (body2 = 0: the world).  connect: `anchor`
+ * in body1's frame; weld: in body2's frame (NULL = its origin), the relative pose is the one at qpos0.  MjSim::init_references
+ * emits <weld body1="X" body2="X_ref" torquescale="0.9"/> against a mocap clone of X (mj_sim.cpp:933-938). */
+int mjh_builder_add_eq_connect(mjh_builder*, int body1, int body2, const double anchor[3]);
+int mjh_builder_add_eq_weld(mjh_builder*, int body1, int body2, const double anchor[3], double torquescale);
+/* <body mocap="true">: a child of the world without joints whose pose is set per environment at run time */
+int mjh_builder_set_mocap(mjh_builder*, int body);
+/* <site> and <sensor><force site=.../><torque site=.../> */
+int mjh_builder_add_site(mjh_builder*, const char* name, int body, const double pos[3], const double quat[4]);
+int mjh_builder_add_sensor(mjh_builder*, const char* name, int type /* mjh_sensor */, int site);
 /* compile: derives inertias, qpos0, invweight0, meaninertia, rbound, pair list */
 mjh_model* mjh_builder_compile(mjh_builder*);
 void mjh_model_destroy(mjh_model*);
@@ -182,7 +209,7 @@ void mjh_model_destroy(mjh_model*);
  * continue until the slowest instance has converged), `time`, the statistics row and the bad-state reset.  Contact
  * and row capacities scale with `copies`.  Returns a new model (mjh_model_destroy) or NULL. */
 mjh_model* mjh_model_replicate(const mjh_model* m, int copies);
-int mjh_name2id(const mjh_model*, int objtype /*0 body,1 joint,2 geom*/, const char* name);
+int mjh_name2id(const mjh_model*, int objtype /*0 body,1 joint,2 geom,3 site,4 sensor*/, const char* name);
 const char* mjh_id2name(const mjh_model*, int objtype, int id);
 
 /* MJCF-subset loader: replaces load_XML -> mj_loadXML (include/mujoco_sim/mj_util.h:185-193) for the element
@@ -309,6 +336,16 @@ int mjh_get_stats(mjh_engine*, int env0, int n, int* out);
  * (it may be called between mjh_step1 and mjh_step2) */
 int mjh_get_contacts(mjh_engine*, int env, double* dist, double* pos, double* frame, int* geom);
 
+/* d->xfrc_applied (mj_sim.cpp:499 carries it across a model change): Cartesian force (3) and torque (3) per body, world
+ * frame, applied at the body's centre of mass; [n * 6*nbody].  Enters qfrc_smooth of every step until changed. */
+int mjh_set_xfrc_applied(mjh_engine*, int env0, int n, const double* xfrc);
+int mjh_get_xfrc_applied(mjh_engine*, int env0, int n, double* xfrc);
+/* d->sensordata (mj_ros.cpp:1933-1966 reads sensordata[sensor_adr[i] .. +3] of every force / torque sensor): [n * nsensordata],
+ * computed at the end of mj_step2's forward part (mj_sensorAcc), i.e. the values of the LAST step */
+int mjh_get_sensordata(mjh_engine*, int env0, int n, double* sensordata);
+/* pose of mocap body `mocapid` in envs [env0, env0+n): pos[n*3], quat[n*4] (either may be NULL) — d->mocap_pos / mocap_quat,
+ * what the reference's `~receive` mode drives (mj_sim.cpp:847-960) */
+int mjh_set_mocap_pose(mjh_engine*, int env0, int n, int mocapid, const double* pos, const double* quat);
 /* per-env model parameters (enum mjh_env_param) */
 int mjh_set_env_param(mjh_engine*, int which, int env0, int n, const double* values);
 /* MjRos::reset_robot (mj_ros.cpp:569-609): back to qpos0 (or the per-env initial

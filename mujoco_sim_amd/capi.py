@@ -63,6 +63,15 @@ _ARRAYS = [
 ]
 
 
+# appended to struct mjh_model in round 2 (behind the name tables): sites, sensors, mocap bodies
+_INT_SIZES2 = ["nsite", "nsensor", "nsensordata", "nmocap"]
+_ARRAYS2 = [
+    ("site_bodyid", "i", "nsite"), ("site_pos", "d", "3*nsite"), ("site_quat", "d", "4*nsite"),
+    ("sensor_type", "i", "nsensor"), ("sensor_objid", "i", "nsensor"), ("sensor_adr", "i", "nsensor"),
+]
+_ARRAYS3 = [("body_mocapid", "i", "nbody")]
+
+
 class Model(C.Structure):
     _fields_ = (
         [(n, C.c_int) for n in _INT_SIZES]
@@ -70,17 +79,21 @@ class Model(C.Structure):
         + [(n, c_int_p if t == "i" else c_double_p) for n, t, _ in _ARRAYS]
         + [("body_names", C.POINTER(C.c_char_p)), ("jnt_names", C.POINTER(C.c_char_p)),
            ("geom_names", C.POINTER(C.c_char_p))]
+        + [(n, C.c_int) for n in _INT_SIZES2]
+        + [(n, c_int_p if t == "i" else c_double_p) for n, t, _ in _ARRAYS2]
+        + [("site_names", C.POINTER(C.c_char_p)), ("sensor_names", C.POINTER(C.c_char_p))]
+        + [(n, c_int_p if t == "i" else c_double_p) for n, t, _ in _ARRAYS3]
     )
 
     def array(self, name):
         """numpy copy of a model array."""
         import numpy as np
 
-        for n, t, expr in _ARRAYS:
+        for n, t, expr in _ARRAYS + _ARRAYS2 + _ARRAYS3:
             if n == name:
-                ln = eval(expr, {}, {k: getattr(self, k) for k in _INT_SIZES})
+                ln = eval(expr, {}, {k: getattr(self, k) for k in _INT_SIZES + _INT_SIZES2})
                 ptr = getattr(self, n)
-                if ln == 0:
+                if ln == 0 or not ptr:
                     return np.zeros(0, dtype=np.int32 if t == "i" else np.float64)
                 return np.ctypeslib.as_array(ptr, shape=(ln,)).copy()
         raise KeyError(name)
@@ -110,6 +123,11 @@ SYMBOLS = [
                                            C.c_int, C.c_int, C.c_int, C.c_double]),
     ("mjh_builder_add_exclude", C.c_int, [_vp, C.c_int, C.c_int]),
     ("mjh_builder_add_eq_joint", C.c_int, [_vp, C.c_int, C.c_int, c_double_p]),
+    ("mjh_builder_add_eq_connect", C.c_int, [_vp, C.c_int, C.c_int, c_double_p]),
+    ("mjh_builder_add_eq_weld", C.c_int, [_vp, C.c_int, C.c_int, c_double_p, C.c_double]),
+    ("mjh_builder_set_mocap", C.c_int, [_vp, C.c_int]),
+    ("mjh_builder_add_site", C.c_int, [_vp, C.c_char_p, C.c_int, c_double_p, c_double_p]),
+    ("mjh_builder_add_sensor", C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
     ("mjh_builder_compile", Model_p, [_vp]),
     ("mjh_model_destroy", None, [Model_p]),
     ("mjh_model_replicate", Model_p, [Model_p, C.c_int]),
@@ -153,6 +171,10 @@ SYMBOLS = [
     ("mjh_get_field", C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, c_double_p]),
     ("mjh_get_stats", C.c_int, [_vp, C.c_int, C.c_int, c_int_p]),
     ("mjh_get_contacts", C.c_int, [_vp, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]),
+    ("mjh_set_xfrc_applied", C.c_int, [_vp, C.c_int, C.c_int, c_double_p]),
+    ("mjh_get_xfrc_applied", C.c_int, [_vp, C.c_int, C.c_int, c_double_p]),
+    ("mjh_get_sensordata", C.c_int, [_vp, C.c_int, C.c_int, c_double_p]),
+    ("mjh_set_mocap_pose", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p]),
     ("mjh_set_env_param", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, c_double_p]),
     ("mjh_transplant_state", C.c_int, [_vp, _vp, C.c_int]),
     ("mjh_set_initial_qpos", C.c_int, [_vp, C.c_int, C.c_int, c_double_p]),

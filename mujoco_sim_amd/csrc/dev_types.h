@@ -36,6 +36,10 @@ struct DModel {
   // noslip post-pass (EXTRA instances)
   int noslip_iterations; float noslip_tolerance;
   double timestep_d;   // opt.timestep in fp64: per-env time advances by exactly this (time == n * dt after n steps)
+  // sites, force / torque sensors, mocap bodies, connect / weld equalities (EXTRA kernel instances only)
+  int nsite, nsensor, nmocap, has_weld;
+  int scratch_off;   // many-body layout: LDS scratch of k1_floats floats (the dead position-stage arrays; an own region when sensors keep them alive)
+  int o_site_bodyid, o_site_pos, o_site_quat, o_sensor_type, o_sensor_objid, o_body_mocapid, o_eq_type;
 };
 
 // per-env state in HBM (fp32, env-major rows)
@@ -57,6 +61,9 @@ struct DState {
   // (one row of p_stride floats per env holds all six, so that an env's parameters cost whole sectors once, not six times)
   const float *p_geom_size, *p_geom_rbound, *p_body_mass, *p_body_inertia, *p_body_invweight0, *p_dof_invweight0;
   int p_stride;
+  // optional per-env inputs / outputs of the EXTRA instances (null until used): Cartesian forces on bodies [nenv][xfrc_stride],
+  // mocap poses [nenv][7*nmocap] (pos3 quat4), sensor outputs [nenv][3*nsensor]
+  float *xfrc_applied, *mocap, *sensordata; int xfrc_stride;
   // many-body models (nv > 64): per-env pools that do not fit LDS (contacts, blocks, Jacobians) live here; a negative
   // Lay offset -1-k addresses float k of the env's slice
   float* gscratch; long long gstride;
@@ -68,7 +75,7 @@ struct DState {
   X(qpos) X(qvel) X(qvref) X(ws) X(qacc) X(smooth) X(asmooth) X(passive) X(bias) X(applied)        \
   X(tmpv) X(tmpv2) X(xpos) X(xquat) X(xmat) X(xipos) X(ximat) X(com) X(cinert) X(crb) X(cvel)      \
   X(cacc) X(cfrc) X(cfrcsub) X(xanchor) X(xaxis) X(cdof) X(cdofdot) X(qM) X(qLD) X(qLDinv)          \
-  X(gpos) X(gmat) X(zero) X(dofpar) X(dofMadr) X(anc) X(p_gsize) X(p_rbound) X(p_mass) X(p_inertia)
+  X(gpos) X(gmat) X(zero) X(dofpar) X(dofMadr) X(anc) X(p_gsize) X(p_rbound) X(p_mass) X(p_inertia) X(site) X(fext)
 // contact / block / Jacobian pools: LDS, or (many-body layout, NROW = 8 kernels) the env's slice of global memory
 #define MJH_LDS_POOLS(X) X(con) X(blki) X(blkf) X(blkq) X(bv) X(phi) X(sched) X(order) X(J) X(B) X(ext)
 #define MJH_LDS_ARRAYS(X) MJH_LDS_SMALL(X) MJH_LDS_POOLS(X)
@@ -112,4 +119,4 @@ enum { XF_BODY = 1, XF_GEOM = 2, XF_CON = 4, XF_FORCE = 8, XF_PROF = 16,
 #define BF_F 8
 #define BF_LO 14   // [14],[15]: projection interval lo, hi of the block's rows
 enum { BK_SINGLE = 0, BK_PYR3 = 3, BK_PYR4 = 4 };
-enum { RT_EQ = 0, RT_FL = 1, RT_LIMIT = 2, RT_CONTACT = 3 };
+enum { RT_EQ = 0, RT_FL = 1, RT_LIMIT = 2, RT_CONTACT = 3, RT_WELD = 4 };   // RT_WELD: one row of a connect / weld equality, id = eq | row << 16

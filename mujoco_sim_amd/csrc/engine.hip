@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -93,12 +94,13 @@ static int ensure_scratch(mjh_engine* e, size_t floats) {
 }
 
 // models that need the EXTRA kernel instances: generic convex narrow phase (cylinder-x, capsule-box, ellipsoid, mesh) or noslip sweeps
-static bool extra_instance(const DModel& M) { return M.has_convex || M.noslip_iterations > 0; }
+// ... or sites / sensors / mocap bodies / connect-weld equalities; and (engine state) Cartesian forces on bodies in use
+static bool extra_instance(const DModel& M) { return M.has_convex || M.noslip_iterations > 0 || M.nsensor > 0 || M.nmocap > 0 || M.has_weld; }
 
 static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps, int ph, int xflags) {
   if (n <= 0) return MJH_OK;
 #define MJH_LAUNCH2(NR, DG, CX) hipLaunchKernelGGL((mjh_step_kernel<NR, DG, CX>), dim3(n), dim3(64), (size_t)e->lds_bytes, st, e->dC, e->S, env0, nsteps, ph, xflags)
-#define MJH_LAUNCH(NR, DG) do { if (extra_instance(e->M)) MJH_LAUNCH2(NR, DG, true); else MJH_LAUNCH2(NR, DG, false); } while (0)
+#define MJH_LAUNCH(NR, DG) do { if (extra_instance(e->M) || e->S.xfrc_applied) MJH_LAUNCH2(NR, DG, true); else MJH_LAUNCH2(NR, DG, false); } while (0)
   const int nr = e->M.big ? 8 : (e->M.nv <= 16 ? 1 : (e->M.nv <= 32 ? 2 : 4));   // 8: many-body layout, running acceleration in LDS
   if (e->M.diagM) { if (nr == 1) MJH_LAUNCH(1, true); else if (nr == 2) MJH_LAUNCH(2, true); else if (nr == 4) MJH_LAUNCH(4, true); else MJH_LAUNCH(8, true); }
   else { if (nr == 1) MJH_LAUNCH(1, false); else if (nr == 2) MJH_LAUNCH(2, false); else if (nr == 4) MJH_LAUNCH(4, false); else MJH_LAUNCH(8, false); }
@@ -173,7 +175,14 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     rowW = std::max(rowW, w);
   }
   for (int t = 0; t < m->ntree; t++) rowW = std::max(rowW, m->tree_dofnum[t]);
+  int neqrow = 0; bool has_weld = false;
   for (int q = 0; q < m->neq; q++) {
+    if (m->eq_type[q] != MJH_EQ_JOINT) {      // connect / weld between bodies: 3 / 6 single-row blocks over the bodies' trees
+      has_weld = true; neqrow += m->eq_type[q] == MJH_EQ_WELD ? 6 : 3;
+      rowW = std::max(rowW, treenum(m->eq_obj1id[q]) + ((m->body_treeid[m->eq_obj1id[q]] != m->body_treeid[m->eq_obj2id[q]]) ? treenum(m->eq_obj2id[q]) : 0));
+      continue;
+    }
+    neqrow++;
     int j1 = m->eq_obj1id[q], j2 = m->eq_obj2id[q];
     int t1 = m->dof_treeid[m->jnt_dofadr[j1]], w = m->tree_dofnum[t1];
     if (j2 >= 0) { int t2 = m->dof_treeid[m->jnt_dofadr[j2]]; if (t2 != t1) w += m->tree_dofnum[t2]; }
@@ -181,7 +190,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
   }
   rowW = ((rowW + 3) / 4) * 4;
   // every tree a single free body about its own COM with principal axes = body axes  =>  M is diagonal
-  bool diagM = m->ntree > 0 && m->neq == 0;   // (also implies: no limit / equality rows, every block is a contact)
+  bool diagM = m->ntree > 0 && m->neq == 0 && m->nsensor == 0 && m->nmocap == 0;   // (also implies: no limit / equality rows, every block is a contact)
   for (int t = 0; t < m->ntree && diagM; t++) {
     const int b = m->tree_bodyid[t];
     diagM = m->tree_dofnum[t] == 6 && m->body_jntnum[b] == 1 && m->jnt_type[m->body_jntadr[b]] == MJH_JNT_FREE && subtreesize[b] == 1 &&
@@ -217,6 +226,15 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
   PF(geom_solref, 2*ng); PF(geom_solimp, 5*ng); PF(geom_margin, ng); PF(geom_gap, ng);
   PF(eq_data, 11*m->neq); PF(eq_solref, 2*m->neq); PF(eq_solimp, 5*m->neq);
   PI(geom_dataid, ng); PI(mesh_vertadr, m->nmesh); PI(mesh_vertnum, m->nmesh); PF(mesh_vert, 3 * (size_t)m->nmeshvert);
+  PI(eq_type, m->neq);
+  if (m->nsite > 0) { PI(site_bodyid, m->nsite); PF(site_pos, 3 * (size_t)m->nsite); PF(site_quat, 4 * (size_t)m->nsite); }
+  if (m->nsensor > 0) { PI(sensor_type, m->nsensor); PI(sensor_objid, m->nsensor); }
+  {
+    std::vector<int> mocapid(nb, -1);
+    if (m->body_mocapid) for (int b = 0; b < nb; b++) mocapid[b] = m->body_mocapid[b];
+    M.o_body_mocapid = addI(mocapid.data(), nb);
+  }
+  M.nsite = m->nsite; M.nsensor = m->nsensor; M.nmocap = m->nmocap; M.has_weld = has_weld ? 1 : 0;
 #undef PI
 #undef PF
   M.nq = m->nq; M.nv = nv; M.nbody = nb; M.njnt = nj; M.ngeom = ng; M.neq = m->neq; M.npair = m->npair; M.nM = m->nM; M.ntree = m->ntree;
@@ -239,7 +257,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
   {
     // a limited joint can have both sides active only if its margins overlap (range narrower than 2 margins)
     int nlim = 0; for (int j = 0; j < nj; j++) if (m->jnt_limited[j]) nlim += (m->jnt_range[2*j+1] - m->jnt_range[2*j] <= 2 * m->jnt_margin[j]) ? 2 : 1;
-    const int nfix = m->neq + (int)fl_dof.size() + nlim;
+    const int nfix = neqrow + (int)fl_dof.size() + nlim;
     M.maxblk = nfix + M.maxcon; M.maxbrow = nfix + 4 * M.maxcon;
   }
   M.iterations = m->opt.iterations; M.disableflags = m->opt.disableflags;
@@ -254,6 +272,9 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     // memory (negative offsets), only the per-body / per-dof arrays stay in LDS
     const bool big = force_big || nv > 64;
     M.big = big;
+    // models with sensors read the position-stage arrays, the contact records and the velocity-stage vectors again AFTER the
+    // solver (mj_sensorAcc): nothing of those is aliased then
+    const bool keep = m->nsensor > 0;
     auto gput = [&](long long n) { long long o = goff; goff += ((std::max<long long>(n, 1) + 3) / 4) * 4; return (int)(-1 - o); };
     const int nblkcap = std::max(M.maxblk, 1);   // exact: the block builder never creates more than maxblk blocks
     // J / B pools: one row per non-contact block (equality, friction loss, limits), four interleaved rows per contact
@@ -270,6 +291,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     L.xanchor = put(3*nj); L.xaxis = put(3*nj); L.gpos = put(3*ng); L.gmat = put(9*ng);
     const int k1_size = off - k1;
     M.k1_floats = k1_size;
+    M.scratch_off = (big && keep) ? put(k1_size) : k1;
     L.xipos = put(3*nb); L.com = put(3*nb); L.cinert = put(10*nb); L.cdof = put(6*nv);
     const int k2_size = off - k1;   // ... and all of these are dead when the solver sweeps run: the X extension of condim-4 models
     L.qM = put(m->nM); L.qLD = diagM ? L.qM : put(m->nM); L.qLDinv = put(nv);   // diagonal M: no factor storage
@@ -281,6 +303,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       const int velsz = 4 * a4 + ((6*nv + 3) / 4) * 4;
       int vel;
       if (big) { L.con = gput((long long)M.maxcon * CON_STRIDE); L.blkq = gput((long long)nblkcap * BLKQ_STRIDE); vel = put(velsz); }
+      else if (keep) { L.con = put(M.maxcon * CON_STRIDE); L.blkq = put(nblkcap * BLKQ_STRIDE); vel = put(velsz); }
       else {
         // (and, once those are dead too, the per-block solver matrices A_c / Q, built when the solver starts)
         L.con = put(std::max(std::max(M.maxcon * CON_STRIDE, velsz), nblkcap * BLKQ_STRIDE));
@@ -295,15 +318,17 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       L.ext = gput(extsz); L.J = gput(jsz); L.B = diagM ? L.J : gput(jsz);
     } else {
       L.blki = put(nblkcap * BLKI_STRIDE); L.blkf = put(nblkcap * BLKF_STRIDE);
-      if (2 * nblkcap * 4 <= k1_size) { L.bv = k1; L.phi = k1 + nblkcap * 4; }
+      if (2 * nblkcap * 4 <= k1_size && !keep) { L.bv = k1; L.phi = k1 + nblkcap * 4; }
       else { L.bv = put(nblkcap * 4); L.phi = put(nblkcap * 4); }
       L.sched = put(nblkcap * 2);
       // the dual-block sweep (nv <= 32) reads the pair schedule only; `order` is then just scratch of the schedule builder
-      L.order = (nv <= 32 && nblkcap <= k1_size) ? L.bv : put(nblkcap);
-      L.ext = extsz <= k2_size ? k1 : put(extsz);
+      L.order = (nv <= 32 && nblkcap <= k1_size && !keep) ? L.bv : put(nblkcap);
+      L.ext = (extsz <= k2_size && !keep) ? k1 : put(extsz);
       L.J = put((int)jsz); L.B = diagM ? L.J : put((int)jsz);
     }
     L.zero = put(4);
+    L.site = m->nsite > 0 ? put(12 * m->nsite) : 0;        // world frame of every site: pos(3) + rotation(9)
+    L.fext = m->nsensor > 0 ? put(6 * nb) : 0;             // external spatial force per body (mj_rnePostConstraint)
     if (big) {   // hand-over vectors of the three-launch step (non-negative offsets into the scratch slice)
       auto graw = [&](int n) { long long o = goff; goff += ((std::max(n, 1) + 3) / 4) * 4; return (int)o; };
       L.g_a0 = graw(nv); L.g_minv = graw(nv); L.g_qvel = graw(nv); L.g_smooth = graw(nv); L.g_qacc = graw(nv); L.g_meta = graw(8); L.g_qM = graw(m->nM);
@@ -406,7 +431,20 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   rc |= dev_alloc(e, &S.time, (size_t)nenv); rc |= dev_alloc(e, &S.odom_vel, (size_t)nenv * 6); rc |= dev_alloc(e, &S.stats, (size_t)nenv * 4);
   rc |= dev_alloc(e, &S.x_bias, nv_all); rc |= dev_alloc(e, &S.x_passive, nv_all); rc |= dev_alloc(e, &S.x_smooth, nv_all);
   rc |= dev_alloc(e, &S.x_constraint, nv_all); rc |= dev_alloc(e, &S.x_energy, (size_t)nenv * 2);
+  if (M.nsensor > 0) { rc |= dev_alloc(e, &S.sensordata, (size_t)nenv * 3 * M.nsensor); e->split3 = false; }   // (sensors read the position stage after the solve: one fused launch)
+  if (M.nmocap > 0) rc |= dev_alloc(e, &S.mocap, (size_t)nenv * 7 * M.nmocap, false);
   if (rc) { mjh_destroy(e); return MJH_ERR_NO_DEVICE; }
+  if (M.nmocap > 0) {   // mocap poses start at the bodies' model poses (d->mocap_pos / mocap_quat after mj_makeData)
+    std::vector<float> mp((size_t)nenv * 7 * M.nmocap);
+    for (int b = 0; b < m->nbody; b++) if (m->body_mocapid && m->body_mocapid[b] >= 0)
+      for (int en = 0; en < nenv; en++) {
+        float* p = &mp[((size_t)en * M.nmocap + m->body_mocapid[b]) * 7];
+        for (int k = 0; k < 3; k++) p[k] = (float)m->body_pos[3*b+k];
+        for (int k = 0; k < 4; k++) p[3+k] = (float)m->body_quat[4*b+k];
+      }
+    HIPCHK(hipMemcpyAsync(S.mocap, mp.data(), mp.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
   // initial state = qpos0 for every env
   {
     std::vector<float> q0(nq_all, 0.0f);
@@ -715,6 +753,15 @@ extern "C" int mjh_transplant_state(mjh_engine* from, mjh_engine* to, int qpos_m
   if (!rc) rc = mjh_get_field(to, "qfrc_applied", 0, n, fb.data());
   if (!rc) rc = mjh_get_field(to, "qacc", 0, n, ab.data());
   if (rc) return rc;
+  // d_new->xfrc_applied[body] = d->xfrc_applied[body] (mj_sim.cpp:496-500), if the old engine carries any
+  std::vector<double> xa, xb;
+  const bool has_x = from->S.xfrc_applied != nullptr;
+  if (has_x) {
+    xa.resize((size_t)n * 6 * ma->nbody); xb.assign((size_t)n * 6 * mb->nbody, 0.0);
+    rc = mjh_get_xfrc_applied(from, 0, n, xa.data());
+    if (!rc) rc = mjh_get_xfrc_applied(to, 0, n, xb.data());
+    if (rc) return rc;
+  }
   int matched = 0;
   for (int ba = 1; ba < ma->nbody; ba++) {
     const char* name = ma->body_names ? ma->body_names[ba] : nullptr;
@@ -722,6 +769,7 @@ extern "C" int mjh_transplant_state(mjh_engine* from, mjh_engine* to, int qpos_m
     const int bb = mjh_name2id(mb, 0, name);
     if (bb <= 0) continue;
     matched++;
+    if (has_x) for (int i = 0; i < n; i++) for (int k = 0; k < 6; k++) xb[((size_t)i * mb->nbody + bb) * 6 + k] = xa[((size_t)i * ma->nbody + ba) * 6 + k];
     const int ja = ma->body_jntnum[ba], jb = mb->body_jntnum[bb];
     if (ja == jb && ja > 0) {
       const int pa = ma->jnt_qposadr[ma->body_jntadr[ba]], pb = mb->jnt_qposadr[mb->body_jntadr[bb]];
@@ -745,6 +793,7 @@ extern "C" int mjh_transplant_state(mjh_engine* from, mjh_engine* to, int qpos_m
   rc = put_rows(to, to->S.qacc, to->M.nvp, to->M.nv, 0, n, ab.data());      // (qacc shares its array with qacc_warmstart, which is written next)
   if (!rc) rc = mjh_set_state(to, 0, n, tb.data(), qb.data(), vb.data(), wb.data());
   if (!rc) rc = put_rows(to, to->S.qfrc_applied, to->M.nvp, to->M.nv, 0, n, fb.data());
+  if (!rc && has_x) rc = mjh_set_xfrc_applied(to, 0, n, xb.data());
   return rc ? rc : matched;
 }
 
@@ -842,6 +891,52 @@ extern "C" int mjh_set_env_param(mjh_engine* e, int which, int env0, int n, cons
     e->S.p_stride = P;
   }
   return put_cols(e, e->p_tables[which], e->S.p_stride, w, env0, n, values);
+}
+
+// d->xfrc_applied (mj_sim.cpp:499): force + torque per body at its centre of mass, world frame
+extern "C" int mjh_set_xfrc_applied(mjh_engine* e, int env0, int n, const double* xfrc) {
+  ENG(e); RANGE(e, env0, n);
+  if (!xfrc) return MJH_ERR_ARG;
+  const int w = 6 * e->M.nbody;
+  if (!e->S.xfrc_applied) {
+    const int stride = ((w + 3) / 4) * 4;
+    int rc = dev_alloc(e, &e->S.xfrc_applied, (size_t)e->nenv * stride);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->S.xfrc_stride = stride;
+  }
+  return put_rows(e, e->S.xfrc_applied, e->S.xfrc_stride, w, env0, n, xfrc);
+}
+extern "C" int mjh_get_xfrc_applied(mjh_engine* e, int env0, int n, double* xfrc) {
+  ENG(e); RANGE(e, env0, n);
+  if (!xfrc) return MJH_ERR_ARG;
+  const int w = 6 * e->M.nbody;
+  if (!e->S.xfrc_applied) { std::memset(xfrc, 0, (size_t)n * w * sizeof(double)); return MJH_OK; }
+  return get_rows(e, e->S.xfrc_applied, e->S.xfrc_stride, w, env0, n, xfrc);
+}
+// d->sensordata as mj_step2's mj_sensorAcc left it (the reference's publisher reads it unlocked at its own rate, mj_ros.cpp:1933-1966)
+extern "C" int mjh_get_sensordata(mjh_engine* e, int env0, int n, double* out) {
+  ENG(e); RANGE(e, env0, n);
+  if (!out) return MJH_ERR_ARG;
+  if (e->M.nsensor == 0) return MJH_OK;
+  return get_rows(e, e->S.sensordata, 3 * e->M.nsensor, 3 * e->M.nsensor, env0, n, out);
+}
+// d->mocap_pos / d->mocap_quat of one mocap body for a range of environments
+extern "C" int mjh_set_mocap_pose(mjh_engine* e, int env0, int n, int mocapid, const double* pos, const double* quat) {
+  ENG(e); RANGE(e, env0, n);
+  if (mocapid < 0 || mocapid >= e->M.nmocap) { mjh_set_error("mjh_set_mocap_pose: no such mocap body"); return MJH_ERR_ARG; }
+  const int stride = 7 * e->M.nmocap;
+  if (pos) { int rc = put_rows(e, e->S.mocap + 7 * mocapid, stride, 3, env0, n, pos); if (rc) return rc; }
+  if (quat) {
+    std::vector<double> q((size_t)n * 4);
+    for (int i = 0; i < n; i++) {       // stored normalised (mj_kinematics normalises mocap_quat on use)
+      const double* s = quat + 4 * (size_t)i; double nn = std::sqrt(s[0]*s[0] + s[1]*s[1] + s[2]*s[2] + s[3]*s[3]);
+      if (!(nn > 1e-12)) { mjh_set_error("mjh_set_mocap_pose: zero quaternion"); return MJH_ERR_ARG; }
+      for (int k = 0; k < 4; k++) q[4 * (size_t)i + k] = s[k] / nn;
+    }
+    return put_rows(e, e->S.mocap + 7 * mocapid + 3, stride, 4, env0, n, q.data());
+  }
+  return MJH_OK;
 }
 
 extern "C" int mjh_set_initial_qpos(mjh_engine* e, int env0, int n, const double* qpos) {

@@ -3,7 +3,7 @@
 // the step path: <compiler angle autolimits>, <option timestep gravity impratio iterations tolerance>,
 // root <default> (<geom>, <joint>), <worldbody>/<body> trees with <inertial>, <joint> (free, ball, hinge, slide),
 // <freejoint>, <geom> (plane, sphere, capsule, cylinder, box; mesh geoms are skipped with a note), gravcomp,
-// <contact><exclude>, <equality><joint polycoef>.  Everything is translated into mjh_builder_* calls; physics
+// <contact><exclude>, <equality><joint polycoef> / <weld> / <connect>, <body mocap>, <site>, <sensor><force> / <torque>.  Everything is translated into mjh_builder_* calls; physics
 // defaults follow MuJoCo's documented defaults (angle = degree, hinge axis 0 0 1, geom type sphere, ...).
 // Not handled (reported in the returned note): tendons, actuators, sensors, <weld> / <connect> equalities.
 #include <cmath>
@@ -111,7 +111,7 @@ struct Loader {
   bool degree = true, autolimits = false, balance = false, robot_file = false;
   double bmass = 0, binertia = 0;   // <compiler boundmass boundinertia>, raised to the process-wide floor of mjh_load_set_bounds
   Defaults def;
-  std::map<std::string, int> body_id, joint_id, mesh_id;
+  std::map<std::string, int> body_id, joint_id, mesh_id, site_id;
   // <default class="..."> tables: class -> element tag -> attributes (a nested class starts from its parent's); the
   // unnamed top-level <default> is class "main".  An element takes the attributes it does not set itself from its class
   // (its own class="" attribute, else the nearest enclosing body's childclass, else "main").
@@ -245,9 +245,11 @@ struct Loader {
     int id = mjh_builder_add_body(b, name.c_str(), parent, pos, quat, gc);
     if (id < 0) return false;
     body_id[name] = id;
+    const bool is_mocap = n.get("mocap") && std::string(n.get("mocap")) == "true";   // MjSim::init_references: the *_ref clones (mj_sim.cpp:903)
     const std::string saved = childclass;
     if (n.get("childclass")) childclass = n.get("childclass");
     const bool ok = children(n, id);
+    if (ok && is_mocap && mjh_builder_set_mocap(b, id) < 0) return false;
     // rosparam ~add_odom_joints (mj_sim.cpp:337-415): slide / hinge joints "<robot>_lin_odom_x_joint" ... appended to the
     // root body of a robot file, after the body's own children as InsertEndChild does; a linear axis is also added when
     // the other planar axis and the matching rotation are asked for (the reference's rule, :355,:365,:375)
@@ -279,7 +281,14 @@ struct Loader {
         nums(c->get("pos"), ipos, 3); orientation(*c, iq); nums(c->get("mass"), &mass, 1);
         if (nums(c->get("diaginertia"), di, 3) != 3) { mjh_set_error("<inertial> needs diaginertia (fullinertia is not supported)"); return false; }
         mjh_builder_set_inertial(b, body, mass, ipos, iq, di);
-      } else if (c->tag != "light" && c->tag != "camera" && c->tag != "site") note += "ignored <" + c->tag + ">; ";
+      } else if (c->tag == "site") {
+        double pos[3] = {0, 0, 0}, quat[4] = {1, 0, 0, 0};
+        nums(c->get("pos"), pos, 3); orientation(*c, quat);
+        std::string name = c->get("name") ? c->get("name") : ("site" + std::to_string(nameless++));
+        const int id = mjh_builder_add_site(b, name.c_str(), body, pos, quat);
+        if (id < 0) return false;
+        site_id[name] = id;
+      } else if (c->tag != "light" && c->tag != "camera") note += "ignored <" + c->tag + ">; ";
     }
     return true;
   }
@@ -365,6 +374,18 @@ struct Loader {
         }
       } else if (c->tag == "equality") {
         for (auto& e : c->kids) {
+          if (e->tag == "weld" || e->tag == "connect") {
+            auto i1 = body_id.find(e->get("body1") ? e->get("body1") : "");
+            if (i1 == body_id.end()) { mjh_set_error("<equality><" + e->tag + "> names an unknown body1"); return false; }
+            int b2 = 0;                                      // body2 omitted: the world
+            if (e->get("body2")) { auto i2 = body_id.find(e->get("body2")); if (i2 == body_id.end()) { mjh_set_error("<equality><" + e->tag + "> names an unknown body2"); return false; } b2 = i2->second; }
+            double anchor[3] = {0, 0, 0}, ts = 1.0;
+            nums(e->get("anchor"), anchor, 3); nums(e->get("torquescale"), &ts, 1);
+            if (e->get("relpose")) note += "<weld relpose> ignored (the relative pose of the reference configuration is used); ";
+            const int rc = e->tag == "weld" ? mjh_builder_add_eq_weld(b, i1->second, b2, anchor, ts) : mjh_builder_add_eq_connect(b, i1->second, b2, anchor);
+            if (rc < 0) return false;
+            continue;
+          }
           if (e->tag != "joint") { note += "ignored <equality><" + e->tag + ">; "; continue; }
           auto j1 = joint_id.find(e->get("joint1") ? e->get("joint1") : "");
           if (j1 == joint_id.end()) { mjh_set_error("<equality><joint> names an unknown joint1"); return false; }
@@ -372,6 +393,13 @@ struct Loader {
           if (e->get("joint2")) { auto it = joint_id.find(e->get("joint2")); if (it == joint_id.end()) { mjh_set_error("unknown joint2"); return false; } j2 = it->second; }
           double poly[5] = {0, 1, 0, 0, 0}, t5[5]; int np = nums(e->get("polycoef"), t5, 5); for (int i = 0; i < np; i++) poly[i] = t5[i];
           mjh_builder_add_eq_joint(b, j1->second, j2, poly);
+        }
+      } else if (c->tag == "sensor") {
+        for (auto& e : c->kids) {
+          if (e->tag != "force" && e->tag != "torque") { note += "ignored <sensor><" + e->tag + "> (the reference publishes force and torque sensors only, mj_sim.cpp:973-1014); "; continue; }
+          auto it = site_id.find(e->get("site") ? e->get("site") : "");
+          if (it == site_id.end()) { mjh_set_error("<sensor><" + e->tag + "> names an unknown site"); return false; }
+          if (mjh_builder_add_sensor(b, e->get("name"), e->tag == "force" ? MJH_SENS_FORCE : MJH_SENS_TORQUE, it->second) < 0) return false;
         }
       } else if (c->tag != "compiler" && c->tag != "option" && c->tag != "default" && c->tag != "worldbody" && c->tag != "asset" && c->tag != "visual" && c->tag != "size" && c->tag != "statistic")
         note += "ignored <" + c->tag + ">; ";

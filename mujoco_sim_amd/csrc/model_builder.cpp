@@ -40,7 +40,10 @@ struct BMesh {
   double volume, inertia[3];       // unit density
   double rbound;
 };
-struct BEq { int j1, j2; double poly[5]; };
+struct BEq { int type = MJH_EQ_JOINT; int j1 = -1, j2 = -1; double poly[5] = {0, 0, 0, 0, 0};        // joint coupling: joints j1, j2
+              int b1 = 0, b2 = 0; double anchor[3] = {0, 0, 0}; double torquescale = 1; };       // connect / weld: bodies b1, b2
+struct BSite { std::string name; int body; double pos[3], quat[4]; };
+struct BSensor { std::string name; int type, site; };
 
 }  // namespace
 
@@ -55,6 +58,9 @@ struct mjh_builder {
   std::vector<BMesh> meshes;
   std::vector<std::pair<int,int>> excludes;
   std::vector<BEq> eqs;
+  std::vector<BSite> sites;
+  std::vector<BSensor> sensors;
+  std::vector<int> mocap;       // builder body ids flagged <body mocap="true">
 };
 
 static thread_local std::string g_err;
@@ -360,6 +366,39 @@ extern "C" int mjh_builder_add_exclude(mjh_builder* b, int b1, int b2) { b->excl
 extern "C" int mjh_builder_add_eq_joint(mjh_builder* b, int j1, int j2, const double poly[5]) {
   BEq e; e.j1 = j1; e.j2 = j2; for (int i = 0; i < 5; i++) e.poly[i] = poly[i];
   b->eqs.push_back(e); return (int)b->eqs.size() - 1;
+}
+
+extern "C" int mjh_builder_add_eq_connect(mjh_builder* b, int body1, int body2, const double anchor[3]) {
+  if (body1 <= 0 || body1 >= (int)b->bodies.size() || body2 < 0 || body2 >= (int)b->bodies.size() || body1 == body2) { g_err = "add_eq_connect: bad body"; return MJH_ERR_ARG; }
+  BEq e; e.type = MJH_EQ_CONNECT; e.b1 = body1; e.b2 = body2;
+  for (int i = 0; i < 3; i++) e.anchor[i] = anchor ? anchor[i] : 0;
+  b->eqs.push_back(e); return (int)b->eqs.size() - 1;
+}
+extern "C" int mjh_builder_add_eq_weld(mjh_builder* b, int body1, int body2, const double anchor[3], double torquescale) {
+  if (body1 <= 0 || body1 >= (int)b->bodies.size() || body2 < 0 || body2 >= (int)b->bodies.size() || body1 == body2) { g_err = "add_eq_weld: bad body"; return MJH_ERR_ARG; }
+  BEq e; e.type = MJH_EQ_WELD; e.b1 = body1; e.b2 = body2; e.torquescale = torquescale;
+  for (int i = 0; i < 3; i++) e.anchor[i] = anchor ? anchor[i] : 0;
+  b->eqs.push_back(e); return (int)b->eqs.size() - 1;
+}
+extern "C" int mjh_builder_set_mocap(mjh_builder* b, int body) {
+  if (body <= 0 || body >= (int)b->bodies.size() || b->bodies[body].parent != 0) { g_err = "set_mocap: a mocap body must be a child of the world"; return MJH_ERR_ARG; }
+  for (const BJoint& j : b->joints) if (j.body == body) { g_err = "set_mocap: a mocap body cannot have joints"; return MJH_ERR_ARG; }
+  for (int x : b->mocap) if (x == body) return MJH_OK;
+  b->mocap.push_back(body);
+  return MJH_OK;
+}
+extern "C" int mjh_builder_add_site(mjh_builder* b, const char* name, int body, const double pos[3], const double quat[4]) {
+  if (body < 0 || body >= (int)b->bodies.size()) { g_err = "add_site: bad body"; return MJH_ERR_ARG; }
+  BSite x; x.name = name ? name : ""; x.body = body;
+  for (int i = 0; i < 3; i++) x.pos[i] = pos ? pos[i] : 0;
+  if (quat) { for (int i = 0; i < 4; i++) x.quat[i] = quat[i]; hm::normalize4(x.quat); } else { x.quat[0] = 1; x.quat[1] = x.quat[2] = x.quat[3] = 0; }
+  b->sites.push_back(x); return (int)b->sites.size() - 1;
+}
+extern "C" int mjh_builder_add_sensor(mjh_builder* b, const char* name, int type, int site) {
+  if (site < 0 || site >= (int)b->sites.size()) { g_err = "add_sensor: bad site"; return MJH_ERR_ARG; }
+  if (type != MJH_SENS_FORCE && type != MJH_SENS_TORQUE) { g_err = "add_sensor: only force and torque sensors are implemented (the types MjSim::init_sensors accepts)"; return MJH_ERR_UNSUPPORTED; }
+  BSensor x; x.name = name ? name : ""; x.type = type; x.site = site;
+  b->sensors.push_back(x); return (int)b->sensors.size() - 1;
 }
 
 // ---- geom mass properties (density * volume; inertia about geom centre, geom frame)
@@ -831,14 +870,31 @@ extern "C" mjh_model* mjh_builder_compile(mjh_builder* B) {
   std::vector<int> eq_type(neq), eq_obj1id(neq), eq_obj2id(neq), eq_active(neq);
   std::vector<double> eq_data(11*neq), eq_solref(2*neq), eq_solimp(5*neq);
   for (int e = 0; e < neq; e++) {
-    eq_type[e] = MJH_EQ_JOINT; eq_obj1id[e] = jnewid[B->eqs[e].j1]; eq_obj2id[e] = B->eqs[e].j2 >= 0 ? jnewid[B->eqs[e].j2] : -1;
-    eq_active[e] = 1;
-    for (int k = 0; k < 5; k++) eq_data[11*e+k] = B->eqs[e].poly[k];
+    const BEq& E = B->eqs[e];
+    eq_type[e] = E.type; eq_active[e] = 1;
+    if (E.type == MJH_EQ_JOINT) {
+      eq_obj1id[e] = jnewid[E.j1]; eq_obj2id[e] = E.j2 >= 0 ? jnewid[E.j2] : -1;
+      for (int k = 0; k < 5; k++) eq_data[11*e+k] = E.poly[k];
+    } else {
+      // connect / weld between bodies: the second anchor and the relative orientation are those of the reference configuration
+      const int b1 = newid[E.b1], b2 = newid[E.b2];
+      eq_obj1id[e] = b1; eq_obj2id[e] = b2;
+      const int ba = E.type == MJH_EQ_CONNECT ? b1 : b2, bo = E.type == MJH_EQ_CONNECT ? b2 : b1;   // body the anchor is given in / the other one
+      double w[3], t[3], o[3];
+      hm::rotvec(t, &xmat[9*ba], E.anchor);
+      for (int k = 0; k < 3; k++) w[k] = xpos[3*ba+k] + t[k] - xpos[3*bo+k];
+      hm::rotvecT(o, &xmat[9*bo], w);
+      for (int k = 0; k < 3; k++) { eq_data[11*e+k] = E.anchor[k]; eq_data[11*e+3+k] = o[k]; }
+      double qi[4] = {xquat[4*b2], -xquat[4*b2+1], -xquat[4*b2+2], -xquat[4*b2+3]};
+      hm::mulquat(&eq_data[11*e+6], qi, &xquat[4*b1]);
+      eq_data[11*e+10] = E.torquescale;
+    }
     eq_solref[2*e] = 0.02; eq_solref[2*e+1] = 1;
     const double si[5] = {0.9, 0.95, 0.001, 0.5, 2};
     for (int k = 0; k < 5; k++) eq_solimp[5*e+k] = si[k];
   }
-  int nlimit = 0, nfl = 0;
+  int nlimit = 0, nfl = 0, neqrow = 0;
+  for (int e = 0; e < neq; e++) neqrow += eq_type[e] == MJH_EQ_WELD ? 6 : (eq_type[e] == MJH_EQ_CONNECT ? 3 : 1);
   for (int j = 0; j < njnt; j++) if (jnt_limited[j]) nlimit++;
   for (int d = 0; d < nv; d++) if (dof_frictionloss[d] > 0) nfl++;
 
@@ -846,12 +902,12 @@ extern "C" mjh_model* mjh_builder_compile(mjh_builder* B) {
   m->nq = nq; m->nv = nv; m->nbody = nbody; m->njnt = njnt; m->ngeom = ngeom; m->neq = neq; m->npair = npair;
   m->nM = nM; m->ntree = ntree; m->nexclude = (int)B->excludes.size();
   m->maxcon = B->maxcon > 0 ? B->maxcon : capcon;
-  m->maxefc = B->maxefc > 0 ? B->maxefc : (caprow + neq + nlimit + nfl);
+  m->maxefc = B->maxefc > 0 ? B->maxefc : (caprow + neqrow + nlimit + nfl);
   if (B->maxcon > 0 && B->maxefc <= 0) {
     // rows for the capped contact count at the worst-case dim present in the pair list
     int maxrows_per_con = 1;
     for (int i = 0; i < npair; i++) { int dim = std::max(geom_condim[pair_geom1[i]], geom_condim[pair_geom2[i]]); maxrows_per_con = std::max(maxrows_per_con, dim == 1 ? 1 : 2*(dim-1)); }
-    m->maxefc = std::min(caprow, B->maxcon * maxrows_per_con) + neq + nlimit + nfl;
+    m->maxefc = std::min(caprow, B->maxcon * maxrows_per_con) + neqrow + nlimit + nfl;
   }
   m->opt = B->opt; m->meaninertia = meaninertia;
 #define SETI(f) m->f = dup(f)
@@ -873,12 +929,34 @@ extern "C" mjh_model* mjh_builder_compile(mjh_builder* B) {
   SETI(geom_dataid); SETI(mesh_vertadr); SETI(mesh_vertnum); SETI(mesh_vert);
 #undef SETI
   m->body_names = dupnames(body_names); m->jnt_names = dupnames(jnt_names); m->geom_names = dupnames(geom_names);
+  {   // sites, force / torque sensors, mocap bodies
+    const int nsite = (int)B->sites.size(), nsensor = (int)B->sensors.size();
+    std::vector<int> site_bodyid(nsite), sensor_type(nsensor), sensor_objid(nsensor), sensor_adr(nsensor), body_mocapid(nbody, -1);
+    std::vector<double> site_pos(3*nsite), site_quat(4*nsite);
+    std::vector<std::string> site_names(nsite), sensor_names(nsensor);
+    for (int i = 0; i < nsite; i++) {
+      const BSite& S = B->sites[i];
+      site_bodyid[i] = newid[S.body]; site_names[i] = S.name;
+      for (int k = 0; k < 3; k++) site_pos[3*i+k] = S.pos[k];
+      for (int k = 0; k < 4; k++) site_quat[4*i+k] = S.quat[k];
+    }
+    for (int i = 0; i < nsensor; i++) { sensor_type[i] = B->sensors[i].type; sensor_objid[i] = B->sensors[i].site; sensor_adr[i] = 3 * i; sensor_names[i] = B->sensors[i].name; }
+    int nmocap = 0;
+    for (int i = 1; i < nbody; i++) for (int ob : B->mocap) if (newid[ob] == i) body_mocapid[i] = nmocap++;   // numbered in body order
+    m->nsite = nsite; m->nsensor = nsensor; m->nsensordata = 3 * nsensor; m->nmocap = nmocap;
+    m->site_bodyid = dup(site_bodyid); m->site_pos = dup(site_pos); m->site_quat = dup(site_quat);
+    m->sensor_type = dup(sensor_type); m->sensor_objid = dup(sensor_objid); m->sensor_adr = dup(sensor_adr);
+    m->body_mocapid = dup(body_mocapid);
+    m->site_names = dupnames(site_names); m->sensor_names = dupnames(sensor_names);
+  }
   return m;
 }
 
 // ---- sub-wave packing: `copies` instances of the moving bodies in one model (include/mjhip.h)
 extern "C" mjh_model* mjh_model_replicate(const mjh_model* a, int G) {
   if (!a || G < 1) { g_err = "mjh_model_replicate: bad arguments"; return nullptr; }
+  if (a->nsite || a->nsensor || a->nmocap) { g_err = "mjh_model_replicate: models with sites, sensors or mocap bodies are not packed"; return nullptr; }
+  for (int e = 0; e < a->neq; e++) if (a->eq_type[e] != MJH_EQ_JOINT) { g_err = "mjh_model_replicate: connect / weld equalities are not packed"; return nullptr; }
   const int nb = a->nbody, nj = a->njnt, nv = a->nv, nq = a->nq, ng = a->ngeom, nt = a->ntree, ne = a->neq, np = a->npair, nM = a->nM;
   std::vector<int> moving_b, moving_g;
   for (int b = 1; b < nb; b++) if (a->body_weldid[b] != 0) moving_b.push_back(b);
@@ -987,6 +1065,8 @@ extern "C" mjh_model* mjh_model_replicate(const mjh_model* a, int G) {
   for (int i = 0; i < a->nmesh; i++) { m->mesh_vertadr[i] = a->mesh_vertadr[i]; m->mesh_vertnum[i] = a->mesh_vertnum[i]; }
   cpd(m->mesh_vert, a->mesh_vert, (size_t)3 * a->nmeshvert);
   m->body_names = dupnames(bnames); m->jnt_names = dupnames(jnames); m->geom_names = dupnames(gnames);
+  m->body_mocapid = ialloc(NB);
+  for (int b = 0; b < NB; b++) m->body_mocapid[b] = -1;
   return m;
 }
 
@@ -1001,25 +1081,27 @@ extern "C" void mjh_model_destroy(mjh_model* m) {
     m->geom_type, m->geom_bodyid, m->geom_condim, m->geom_contype, m->geom_conaffinity, m->geom_priority, m->geom_pos, m->geom_quat,
     m->geom_size, m->geom_rbound, m->geom_friction, m->geom_solmix, m->geom_solref, m->geom_solimp, m->geom_margin, m->geom_gap,
     m->pair_geom1, m->pair_geom2, m->eq_type, m->eq_obj1id, m->eq_obj2id, m->eq_active, m->eq_data, m->eq_solref, m->eq_solimp,
-    m->geom_dataid, m->mesh_vertadr, m->mesh_vertnum, m->mesh_vert};
+    m->geom_dataid, m->mesh_vertadr, m->mesh_vertnum, m->mesh_vert,
+    m->site_bodyid, m->site_pos, m->site_quat, m->sensor_type, m->sensor_objid, m->sensor_adr, m->body_mocapid};
   for (void* p : ptrs) std::free(p);
   auto freen = [](char** n, int c) { if (!n) return; for (int i = 0; i < c; i++) std::free(n[i]); std::free(n); };
   freen(m->body_names, m->nbody); freen(m->jnt_names, m->njnt); freen(m->geom_names, m->ngeom);
+  freen(m->site_names, m->nsite); freen(m->sensor_names, m->nsensor);
   std::free(m);
 }
 
 extern "C" int mjh_name2id(const mjh_model* m, int objtype, const char* name) {
   if (!m || !name) return -1;
-  char** t = objtype == 0 ? m->body_names : objtype == 1 ? m->jnt_names : m->geom_names;
-  int n = objtype == 0 ? m->nbody : objtype == 1 ? m->njnt : m->ngeom;
-  if (!t) return -1;                                   // a model assembled without name tables
+  char** t = objtype == 0 ? m->body_names : objtype == 1 ? m->jnt_names : objtype == 2 ? m->geom_names : objtype == 3 ? m->site_names : m->sensor_names;
+  int n = objtype == 0 ? m->nbody : objtype == 1 ? m->njnt : objtype == 2 ? m->ngeom : objtype == 3 ? m->nsite : m->nsensor;
+  if (!t || objtype < 0 || objtype > 4) return -1;     // a model assembled without name tables
   for (int i = 0; i < n; i++) if (t[i] && std::strcmp(t[i], name) == 0) return i;
   return -1;
 }
 extern "C" const char* mjh_id2name(const mjh_model* m, int objtype, int id) {
   if (!m) return nullptr;
-  char** t = objtype == 0 ? m->body_names : objtype == 1 ? m->jnt_names : m->geom_names;
-  int n = objtype == 0 ? m->nbody : objtype == 1 ? m->njnt : m->ngeom;
-  if (!t || id < 0 || id >= n) return nullptr;
+  char** t = objtype == 0 ? m->body_names : objtype == 1 ? m->jnt_names : objtype == 2 ? m->geom_names : objtype == 3 ? m->site_names : m->sensor_names;
+  int n = objtype == 0 ? m->nbody : objtype == 1 ? m->njnt : objtype == 2 ? m->ngeom : objtype == 3 ? m->nsite : m->nsensor;
+  if (!t || objtype < 0 || objtype > 4 || id < 0 || id >= n) return nullptr;
   return t[id];
 }

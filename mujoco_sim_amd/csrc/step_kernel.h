@@ -636,6 +636,10 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           s_qpos[qa+3] = xquat[0]; s_qpos[qa+4] = xquat[1]; s_qpos[qa+5] = xquat[2]; s_qpos[qa+6] = xquat[3];
           s_xanchor[3*ja] = xpos[0]; s_xanchor[3*ja+1] = xpos[1]; s_xanchor[3*ja+2] = xpos[2];
           s_xaxis[3*ja] = 0; s_xaxis[3*ja+1] = 0; s_xaxis[3*ja+2] = 1;
+        } else if (EXTRA && M.nmocap > 0 && M.I[M.o_body_mocapid + b] >= 0) {
+          // mocap body (mj_kinematics: xpos / xquat = d->mocap_pos / mocap_quat; the *_ref bodies of mj_sim.cpp:903)
+          const float* mp = S.mocap + ((size_t)env * M.nmocap + M.I[M.o_body_mocapid + b]) * 7;
+          xpos[0] = mp[0]; xpos[1] = mp[1]; xpos[2] = mp[2]; xquat[0] = mp[3]; xquat[1] = mp[4]; xquat[2] = mp[5]; xquat[3] = mp[6];
         } else {
           const int p = body_parentid[b];
           float t[3]; rotvec(t, s_xmat + 9*p, body_pos + 3*b);
@@ -690,6 +694,18 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       for (int k = 0; k < 3; k++) s_gpos[3*g+k] = s_xpos[3*b+k] + t[k];
 #pragma unroll
       for (int k = 0; k < 9; k++) s_gmat[9*g+k] = mat[k];
+    }
+    if (EXTRA && M.nsite > 0) {          // site frames in the world (read by the force / torque sensors after the solve)
+      for (int si = lane; si < M.nsite; si += 64) {
+        const int b = M.I[M.o_site_bodyid + si];
+        float t[3], q[4], mat[9];
+        rotvec(t, s_xmat + 9*b, M.F + M.o_site_pos + 3*si);
+        mulquat(q, s_xquat + 4*b, M.F + M.o_site_quat + 4*si); quat2mat(mat, q);
+#pragma unroll
+        for (int k = 0; k < 3; k++) s_site[12*si+k] = s_xpos[3*b+k] + t[k];
+#pragma unroll
+        for (int k = 0; k < 9; k++) s_site[12*si+3+k] = mat[k];
+      }
     }
     if (xflags & (XF_BODY | XF_GEOM)) {
       WSYNC();
@@ -928,7 +944,13 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       };
       const int w4 = rowW >> 2;
       if (!(M.disableflags & MJH_DSBL_EQUALITY))
-        for (int e = 0; e < M.neq; e++) if (eq_active[e]) { if (lane == 0) put_block(nblk, BK_SINGLE, 1, 1, 0, nblk * w4, e, RT_EQ, 0); nblk++; nbrow++; nefc++; }
+        for (int e = 0; e < M.neq; e++) if (eq_active[e]) {
+          // joint coupling: one row; connect / weld between bodies (EXTRA instances): 3 / 6 rows, one single-row block each
+          const int et = (EXTRA && M.has_weld) ? M.I[M.o_eq_type + e] : MJH_EQ_JOINT;
+          const int nr = et == MJH_EQ_WELD ? 6 : (et == MJH_EQ_CONNECT ? 3 : 1);
+          if (lane < nr) put_block(nblk + lane, BK_SINGLE, 1, 1, 0, (nblk + lane) * w4, et == MJH_EQ_JOINT ? e : (e | (lane << 16)), et == MJH_EQ_JOINT ? RT_EQ : RT_WELD, 0);
+          nblk += nr; nbrow += nr; nefc += nr;
+        }
       if (!(M.disableflags & MJH_DSBL_FRICTIONLOSS)) {
         for (int f = lane; f < M.nfl; f += 64) put_block(nblk + f, BK_SINGLE, 1, 1, 2, (nblk + f) * w4, fl_dof[f], RT_FL, 0);
         nblk += M.nfl; nbrow += M.nfl; nefc += M.nfl;
@@ -1002,6 +1024,44 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         }
       } else if (rtype == RT_FL) { t1 = dof_treeid[id]; J[SL*(id - tree_dofadr[t1])] = 1; }
       else if (rtype == RT_LIMIT) { const int d = jnt_dofadr[id]; t1 = dof_treeid[d]; J[SL*(d - tree_dofadr[t1])] = side ? -1.0f : 1.0f; }
+      else if (EXTRA && rtype == RT_WELD) {
+        // one row of a connect / weld equality (conventions: include/mjhip.h, oracle: orc_make_constraint): rows 0..2 = world
+        // components of p1 - p2 (point Jacobians), rows 3..5 = torquescale * vec(q1^-1 q2 relpose), whose rate is
+        // 1/2 torquescale vec(q1^-1 (w2 - w1) q2 relpose)
+        const int e = id & 0xffff, r = id >> 16;
+        const int b1 = eq_obj1id[e], b2 = eq_obj2id[e];
+        const bool weld = M.I[M.o_eq_type + e] == MJH_EQ_WELD;
+        const float* dat = eq_data + 11*e;
+        t1 = body_treeid[b1]; t2 = body_treeid[b2];
+        if (t1 < 0) { t1 = t2; t2 = -1; }
+        if (t2 == t1) t2 = -1;
+        float q1i[4] = {s_xquat[4*b1], -s_xquat[4*b1+1], -s_xquat[4*b1+2], -s_xquat[4*b1+3]}, q2r[4];
+        { const float rel[4] = {dat[6], dat[7], dat[8], dat[9]}; mulquat(q2r, s_xquat + 4*b2, rel); }
+        const float ts = dat[10];
+#pragma unroll
+        for (int sd = 0; sd < 2; sd++) {
+          const int bd = sd ? b2 : b1; const float ss = sd ? -1.0f : 1.0f;
+          int i = bd > 0 ? body_lastdof[bd] : -1;
+          if (i < 0 || t1 < 0) continue;
+          const float* an = weld ? (sd ? dat : dat + 3) : (sd ? dat + 3 : dat);      // the anchor in THIS body's frame
+          float pw[3]; rotvec(pw, s_xmat + 9*bd, an);
+          const float* com = s_com + 3*body_rootid[bd];
+          const float off[3] = {s_xpos[3*bd] + pw[0] - com[0], s_xpos[3*bd+1] + pw[1] - com[1], s_xpos[3*bd+2] + pw[2] - com[2]};
+          const int tr = dof_treeid[i];
+          const int o = (tr == t1) ? -tree_dofadr[t1] : tree_dofnum[t1] - tree_dofadr[t2];
+          for (; i >= 0; i = s_dofpar_i[i]) {
+            const float* cd = s_cdof + 6*i;
+            float v;
+            if (r < 3) { float cr[3]; cross3(cr, cd, off); v = ss * (cd[3 + r] + cr[r]); }
+            else {
+              const float w[4] = {0.0f, -ss * cd[0], -ss * cd[1], -ss * cd[2]};     // w2 - w1: body 2 enters with +, body 1 with -
+              float u[4], vv[4]; mulquat(u, q1i, w); mulquat(vv, u, q2r);
+              v = 0.5f * ts * vv[1 + (r - 3)];
+            }
+            J[SL*(o + i)] += v;
+          }
+        }
+      }
       else {
         const float* c = s_con + id * CON_STRIDE;
         const int g1 = CON_G1(c), g2 = CON_G2(c);
@@ -1030,7 +1090,10 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           }
         }
       }
-      if (jb == 0) { hd[2] = tree_dofadr[t1] | (tree_dofnum[t1] << 16); hd[3] = t2 >= 0 ? (tree_dofadr[t2] | (tree_dofnum[t2] << 16)) : 0xffff; }   // no second tree: n2 = 0, a2 matches no dof
+      if (jb == 0) {
+        if (EXTRA && t1 < 0) { hd[2] = 0xffff; hd[3] = 0xffff; }     // (an equality between two static bodies: no dofs, an inert row)
+        else { hd[2] = tree_dofadr[t1] | (tree_dofnum[t1] << 16); hd[3] = t2 >= 0 ? (tree_dofadr[t2] | (tree_dofnum[t2] << 16)) : 0xffff; }   // no second tree: n2 = 0, a2 matches no dof
+      }
     }
     // ---- block parameters: impedance, regulariser R, reference gains (lanes = blocks)
     auto p_dinv = [&](int d) __attribute__((always_inline)) { return S.p_dof_invweight0 ? S.p_dof_invweight0[(size_t)env * S.p_stride + d] : dof_invweight0[d]; };
@@ -1066,6 +1129,25 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         sr[0] = jnt_solref[2*id]; sr[1] = jnt_solref[2*id+1];
 #pragma unroll
         for (int q = 0; q < 5; q++) si[q] = jnt_solimp[5*id+q];
+      } else if (EXTRA && rtype == RT_WELD) {
+        const int e = id & 0xffff, r = id >> 16;
+        const int b1 = eq_obj1id[e], b2 = eq_obj2id[e];
+        const bool weld = M.I[M.o_eq_type + e] == MJH_EQ_WELD;
+        const float* dat = eq_data + 11*e;
+        if (r < 3) {
+          float p1[3], p2[3];
+          rotvec(p1, s_xmat + 9*b1, weld ? dat + 3 : dat); rotvec(p2, s_xmat + 9*b2, weld ? dat : dat + 3);
+          pos = (s_xpos[3*b1 + r] + p1[r]) - (s_xpos[3*b2 + r] + p2[r]);
+          diagA = p_binv(2*b1) + p_binv(2*b2);
+        } else {
+          const float q1i[4] = {s_xquat[4*b1], -s_xquat[4*b1+1], -s_xquat[4*b1+2], -s_xquat[4*b1+3]}, rel[4] = {dat[6], dat[7], dat[8], dat[9]};
+          float q2r[4], qe[4]; mulquat(q2r, s_xquat + 4*b2, rel); mulquat(qe, q1i, q2r);
+          pos = dat[10] * qe[1 + (r - 3)];
+          diagA = p_binv(2*b1+1) + p_binv(2*b2+1);
+        }
+        sr[0] = eq_solref[2*e]; sr[1] = eq_solref[2*e+1];
+#pragma unroll
+        for (int q = 0; q < 5; q++) si[q] = eq_solimp[5*e+q];
       } else {
         const float* c = s_con + id * CON_STRIDE;
         const int g1 = CON_G1(c), g2 = CON_G2(c), dim = CON_DIM(c);
@@ -1112,7 +1194,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         const float* J = s_J + BLK_JOFF(hd[0]) + jb; float* B = s_B + BLK_JOFF(hd[0]) + jb;
         if (jb >= ((hd[0] >> 8) & 15)) { for (int k = 0; k < rowW; k++) B[SL*k] = 0; continue; }
         ROW_TREES(hd[2], hd[3]);
-        float* x = s_xpos + lane * rowW;
+        float* x = lds + M.scratch_off + lane * rowW;
         for (int k = 0; k < rowW; k++) x[k] = J[SL*k];
         solve_tree(x - a1, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a1, n1, 1);
         if (n2 > 0) solve_tree(x + (n1 - a2), s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a2, n2, 1);
@@ -1146,7 +1228,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         // first, then first fit: a block plus up to three later unvisited blocks of the sequence that share no tree with any
         // block already in the group.  s_order_i[k] = k-th block, s_sched_i[g] = first k of group g (s_sched_i[ngrp] = nblk).
         // Scratch: one packed word per sequence position (block | tree1 | tree2+1 | used) in LDS that is dead here.
-        int* info = (int*)(NROW == 8 ? s_xpos : s_bv);
+        int* info = (int*)(NROW == 8 ? lds + M.scratch_off : s_bv);
         const bool fits = (NROW != 8 || nblk <= M.k1_floats) && nblk < 2048 && nv < 1023;
         if (!fits) {   // (cannot happen with the capacities the host accepts; keep a valid order)
           for (int i = lane; i < nblk; i += 64) { s_order_i[i] = i; s_sched_i[i] = i; }
@@ -1527,6 +1609,34 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       // ---- smooth acceleration (mj_fwdAcceleration)
       for (int d = lane; d < nv; d += 64) { float f = s_passive[d] - s_bias[d] + s_applied[d]; s_smooth[d] = f; s_asmooth[d] = f; }
       WSYNC();
+      if (EXTRA && S.xfrc_applied) {
+        // mj_xfrcAccumulate: d->xfrc_applied (force, torque at the body's centre of mass, world frame) as a spatial force about
+        // the tree root's COM, summed over each body's subtree and projected on the dofs.  Scratch: the velocity-stage
+        // spatial vectors (dead since qfrc_bias was formed).
+        const float* xf = S.xfrc_applied + (size_t)env * S.xfrc_stride;
+        for (int b = lane; b < nbody; b += 64) {
+          float F[6] = {0, 0, 0, 0, 0, 0};
+          if (b > 0) {
+            const float f[3] = {xf[6*b], xf[6*b+1], xf[6*b+2]};
+            const float* com = s_com + 3*body_rootid[b];
+            const float off[3] = {s_xipos[3*b] - com[0], s_xipos[3*b+1] - com[1], s_xipos[3*b+2] - com[2]};
+            float cr[3]; cross3(cr, off, f);
+            F[0] = xf[6*b+3] + cr[0]; F[1] = xf[6*b+4] + cr[1]; F[2] = xf[6*b+5] + cr[2]; F[3] = f[0]; F[4] = f[1]; F[5] = f[2];
+          }
+#pragma unroll
+          for (int q = 0; q < 6; q++) s_cfrc[6*b+q] = F[q];
+        }
+        WSYNC();
+        for (int d = lane; d < nv; d += 64) {
+          const int bd = dof_bodyid[d];
+          float acc = 0;
+          for (int c = bd; c < bd + body_subtreesize[bd]; c++)
+#pragma unroll
+            for (int q = 0; q < 6; q++) acc += s_cdof[6*d+q] * s_cfrc[6*c+q];
+          s_smooth[d] += acc; s_asmooth[d] += acc;
+        }
+        WSYNC();
+      }
       if (DIAGM) { for (int d = lane; d < nv; d += 64) s_asmooth[d] *= s_qLDinv[d]; }
       else {
         for (int t = 0; t < M.ntree; t++) if (tree_dofnum[t] >= MJH_WAVE_TREE_MIN) solve_tree_wave(s_asmooth, s_qLD, s_qLDinv, s_anc_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t], M.nM, nv, lane);
@@ -1687,7 +1797,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             // visiting order and group starts: LDS copies in the (dead) position-stage arrays when they fit
             mc.order = s_order_i; mc.gstart = s_sched_i; mc.ngrp = ngrp;
             if (nblk + ngrp + 2 <= M.k1_floats) {
-              int* ol = (int*)s_xpos; int* gl = ol + nblk;
+              int* ol = (int*)(lds + M.scratch_off); int* gl = ol + nblk;
               for (int i = lane; i < nblk; i += 64) ol[i] = s_order_i[i];
               if (nblk > 64) for (int i = lane; i <= ngrp; i += 64) gl[i] = s_sched_i[i];
               WSYNC();
@@ -1882,6 +1992,148 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       if (xflags & XF_FORCE) {
         const size_t e = (size_t)xrow * M.nvp;
         for (int d = lane; d < nv; d += 64) { if (S.x_smooth) S.x_smooth[e + d] = s_asmooth[d]; if (S.x_constraint) S.x_constraint[e + d] = s_tmpv2[d]; }
+      }
+      if (EXTRA && M.nsensor > 0 && S.sensordata && !post) {
+        // ---- mj_sensorAcc -> mj_rnePostConstraint (force / torque sensors; consumer: mj_ros.cpp:1933-1966).  External spatial
+        //      force per body about its tree root's COM (xfrc_applied, contact forces, connect / weld forces), then the RNE
+        //      forward pass with the SOLVED qacc, cfrc_int = cinert cacc + cvel x* (cinert cvel) - cfrc_ext summed over each
+        //      body's subtree, read at the site in the site frame.  Lanes = bodies gather their own forces (deterministic).
+        WSYNC();
+        const float* xf = S.xfrc_applied ? S.xfrc_applied + (size_t)env * S.xfrc_stride : nullptr;
+        for (int b = lane; b < nbody; b += 64) {
+          float F[6] = {0, 0, 0, 0, 0, 0};
+          if (b > 0) {
+            const float* com = s_com + 3*body_rootid[b];
+            auto add = [&](const float* point, const float* force, const float* torque, const float sg) __attribute__((always_inline)) {
+              const float off[3] = {point[0] - com[0], point[1] - com[1], point[2] - com[2]};
+              float cr[3]; cross3(cr, off, force);
+              F[0] += sg * (torque[0] + cr[0]); F[1] += sg * (torque[1] + cr[1]); F[2] += sg * (torque[2] + cr[2]);
+              F[3] += sg * force[0]; F[4] += sg * force[1]; F[5] += sg * force[2];
+            };
+            if (xf) { const float f[3] = {xf[6*b], xf[6*b+1], xf[6*b+2]}, t[3] = {xf[6*b+3], xf[6*b+4], xf[6*b+5]}; add(s_xipos + 3*b, f, t, 1.0f); }
+            for (int k = 0; k < nblk; k++) {
+              const int* hd = s_blki_i + k * BLKI_STRIDE;
+              const int id = hd[1] & 0xffffff, rtype = (hd[1] >> 24) & 15, kind = hd[0] & 15;
+              const float* bf = s_blkf + k * BLKF_STRIDE;
+              if (rtype == RT_CONTACT) {
+                const float* c = s_con + id * CON_STRIDE;
+                const int g1 = CON_G1(c), g2 = CON_G2(c);
+                const int b1 = geom_bodyid[g1], b2 = geom_bodyid[g2];
+                if (b1 != b && b2 != b) continue;
+                // contact-frame force on geom2's body: bases carry their friction coefficient, so the signed row sums of a
+                // base ARE its force component (phi_from_forces); torsional base 3 = torque about the normal
+                float ph[4] = {0, 0, 0, 0};
+                const int nr = (hd[0] >> 4) & 15;
+                for (int r = 0; r < nr; r++) {
+                  const float f = bf[BF_F + r];
+                  ph[0] += f;
+                  if (kind != BK_SINGLE) { const int kk = 1 + (r >> 1); ph[kk] += (r & 1) ? -f : f; }
+                }
+                const float mu1 = fmaxf(geom_friction[3*g1], geom_friction[3*g2]), mu3 = fmaxf(geom_friction[3*g1+1], geom_friction[3*g2+1]);
+                const float cf[3] = {ph[0], mu1 * ph[1], mu1 * ph[2]}, tors = mu3 * ph[3];
+                float Fw[3], Tw[3];
+#pragma unroll
+                for (int q = 0; q < 3; q++) { Fw[q] = c[4+q] * cf[0] + c[7+q] * cf[1] + c[10+q] * cf[2]; Tw[q] = c[4+q] * tors; }
+                if (b2 == b) add(c + 1, Fw, Tw, 1.0f);
+                if (b1 == b) add(c + 1, Fw, Tw, -1.0f);
+              } else if (rtype == RT_WELD) {
+                const int e = id & 0xffff, r = id >> 16;
+                const int b1 = eq_obj1id[e], b2 = eq_obj2id[e];
+                if (b1 != b && b2 != b) continue;
+                const bool weld = M.I[M.o_eq_type + e] == MJH_EQ_WELD;
+                const float* dat = eq_data + 11*e;
+                const float f = bf[BF_F];
+                const float z3[3] = {0, 0, 0};
+                const bool first = b1 == b;
+                float pw[3]; rotvec(pw, s_xmat + 9*b, weld ? (first ? dat + 3 : dat) : (first ? dat : dat + 3));
+                const float pt[3] = {s_xpos[3*b] + pw[0], s_xpos[3*b+1] + pw[1], s_xpos[3*b+2] + pw[2]};
+                if (r < 3) { float fv[3] = {0, 0, 0}; fv[r] = f; add(pt, fv, z3, first ? 1.0f : -1.0f); }
+                else {
+                  const float q1i[4] = {s_xquat[4*b1], -s_xquat[4*b1+1], -s_xquat[4*b1+2], -s_xquat[4*b1+3]}, rel[4] = {dat[6], dat[7], dat[8], dat[9]};
+                  float q2r[4]; mulquat(q2r, s_xquat + 4*b2, rel);
+                  float T[3];
+#pragma unroll
+                  for (int a = 0; a < 3; a++) {
+                    const float w[4] = {0.0f, a == 0 ? 1.0f : 0.0f, a == 1 ? 1.0f : 0.0f, a == 2 ? 1.0f : 0.0f};
+                    float u[4], vv[4]; mulquat(u, q1i, w); mulquat(vv, u, q2r);
+                    T[a] = 0.5f * dat[10] * vv[1 + (r - 3)] * f;
+                  }
+                  add(pt, z3, T, first ? -1.0f : 1.0f);
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 6; q++) s_fext[6*b+q] = F[q];
+        }
+        WSYNC();
+        // forward pass (as vel_levels with flg_acc), then cfrc_int and its subtree sums
+        if (lane == 0) { for (int k = 0; k < 6; k++) { s_cvel[k] = 0; s_cacc[k] = (k >= 3) ? -grav[k-3] : 0.0f; s_cfrc[k] = 0; } }
+        WSYNC();
+        for (int lev = 1; lev <= M.maxlevel; lev++) {
+          for (int b = lane; b < nbody; b += 64) {
+            if (body_level[b] != lev) continue;
+            const int p = body_parentid[b];
+            float cv[6], ca[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) { cv[q] = s_cvel[6*p+q]; ca[q] = s_cacc[6*p+q]; }
+            int bda = body_dofadr[b];
+            for (int j = 0; j < body_jntnum[b]; j++) {
+              const int jt = jnt_type[body_jntadr[b] + j];
+              if (jt == MJH_JNT_FREE) {
+                for (int k = 0; k < 3; k++)
+#pragma unroll
+                  for (int q = 0; q < 6; q++) { s_cdofdot[6*(bda+k)+q] = 0; cv[q] += s_cdof[6*(bda+k)+q] * s_qvel[bda+k]; }
+                bda += 3;
+              }
+              const int nd = (jt == MJH_JNT_FREE || jt == MJH_JNT_BALL) ? 3 : 1;
+              float cvn[6];
+#pragma unroll
+              for (int q = 0; q < 6; q++) cvn[q] = cv[q];
+              for (int k = 0; k < nd; k++) {
+                float cd[6], cdd[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) cd[q] = s_cdof[6*(bda+k)+q];
+                cross_motion(cdd, cv, cd);
+                const float v = s_qvel[bda+k];
+#pragma unroll
+                for (int q = 0; q < 6; q++) { s_cdofdot[6*(bda+k)+q] = cdd[q]; cvn[q] += cd[q] * v; }
+              }
+#pragma unroll
+              for (int q = 0; q < 6; q++) cv[q] = cvn[q];
+              bda += nd;
+            }
+            for (int d = body_dofadr[b]; d < body_dofadr[b] + body_dofnum[b]; d++) {
+              const float v = s_qvel[d], a = s_qacc[d];
+#pragma unroll
+              for (int q = 0; q < 6; q++) ca[q] += s_cdofdot[6*d+q] * v + s_cdof[6*d+q] * a;
+            }
+            float ci[10], f[6], t[6], t1[6];
+#pragma unroll
+            for (int k = 0; k < 10; k++) ci[k] = s_cinert[10*b+k];
+            mul_inert_vec(f, ci, ca); mul_inert_vec(t, ci, cv); cross_force(t1, cv, t);
+#pragma unroll
+            for (int q = 0; q < 6; q++) { s_cvel[6*b+q] = cv[q]; s_cacc[6*b+q] = ca[q]; s_cfrc[6*b+q] = f[q] + t1[q] - s_fext[6*b+q]; }
+          }
+          WSYNC();
+        }
+        for (int si = lane; si < M.nsensor; si += 64) {
+          const int site = M.I[M.o_sensor_objid + si], b = M.I[M.o_site_bodyid + site];
+          float F[6] = {0, 0, 0, 0, 0, 0};
+          for (int c = b; c < b + body_subtreesize[b]; c++)
+#pragma unroll
+            for (int q = 0; q < 6; q++) F[q] += s_cfrc[6*c+q];
+          const float* com = s_com + 3*body_rootid[b];
+          const float* sp = s_site + 12*site;
+          const float off[3] = {sp[0] - com[0], sp[1] - com[1], sp[2] - com[2]};
+          float cr[3]; cross3(cr, off, F + 3);
+          const float tq[3] = {F[0] - cr[0], F[1] - cr[1], F[2] - cr[2]};
+          const float* src = M.I[M.o_sensor_type + si] == MJH_SENS_FORCE ? F + 3 : tq;
+          float* out = S.sensordata + ((size_t)env * M.nsensor + si) * 3;
+#pragma unroll
+          for (int k = 0; k < 3; k++) out[k] = sp[3+k] * src[0] + sp[6+k] * src[1] + sp[9+k] * src[2];     // R_site^T v
+        }
+        WSYNC();
       }
       if (ph & PH_STEP2) {
         // ---- mj_checkAcc

@@ -31,7 +31,7 @@ class Model:
 
     def __getattr__(self, name):
         c = self.__dict__.get("c")
-        if c is not None and name in capi._INT_SIZES + ["meaninertia", "opt"]:
+        if c is not None and name in capi._INT_SIZES + capi._INT_SIZES2 + ["meaninertia", "opt"]:
             return getattr(c, name)
         raise AttributeError(name)
 
@@ -234,6 +234,29 @@ class Engine:
         v = np.ascontiguousarray(vec, dtype=np.float64).reshape(-1, self.nv); r = np.zeros_like(v)
         _chk(self.lib, self.lib.mjh_mulM(self.h, env0, v.shape[0], capi.dptr(v), capi.dptr(r)), "mjh_mulM")
         return r
+
+    def set_xfrc_applied(self, xfrc, env0=0):
+        """d->xfrc_applied: [n, nbody, 6] force + torque per body at its centre of mass, world frame"""
+        x = np.ascontiguousarray(xfrc, dtype=np.float64).reshape(-1, 6 * self.nbody)
+        _chk(self.lib, self.lib.mjh_set_xfrc_applied(self.h, env0, x.shape[0], capi.dptr(x)), "mjh_set_xfrc_applied")
+
+    def get_xfrc_applied(self, env0=0, n=None):
+        n = self.nenv - env0 if n is None else n
+        out = np.zeros((n, self.nbody, 6))
+        _chk(self.lib, self.lib.mjh_get_xfrc_applied(self.h, env0, n, capi.dptr(out)), "mjh_get_xfrc_applied")
+        return out
+
+    def get_sensordata(self, env0=0, n=None):
+        n = self.nenv - env0 if n is None else n
+        out = np.zeros((n, self.model.nsensordata))
+        _chk(self.lib, self.lib.mjh_get_sensordata(self.h, env0, n, capi.dptr(out)), "mjh_get_sensordata")
+        return out
+
+    def set_mocap_pose(self, mocapid, pos=None, quat=None, env0=0):
+        p = None if pos is None else np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+        q = None if quat is None else np.ascontiguousarray(quat, dtype=np.float64).reshape(-1, 4)
+        n = (p if p is not None else q).shape[0]
+        _chk(self.lib, self.lib.mjh_set_mocap_pose(self.h, env0, n, mocapid, capi.dptr(p), capi.dptr(q)), "mjh_set_mocap_pose")
 
     def set_env_param(self, name, values, env0=0):
         v = np.ascontiguousarray(values, dtype=np.float64)

@@ -12,14 +12,14 @@ _OPT_FIELDS = ["timestep", "iterations", "tolerance", "impratio", "noslip_iterat
 
 
 def save_model_tables(m, path, **extra):
-    d = {"int__" + k: np.int64(getattr(m.c, k)) for k in capi._INT_SIZES}
+    d = {"int__" + k: np.int64(getattr(m.c, k)) for k in capi._INT_SIZES + capi._INT_SIZES2}
     d["meaninertia"] = np.float64(m.c.meaninertia)
     for k in _OPT_FIELDS:
         d["opt__" + k] = np.float64(getattr(m.c.opt, k))
     d["opt__gravity"] = np.array(list(m.c.opt.gravity), dtype=np.float64)
-    for n, t, _ in capi._ARRAYS:
+    for n, t, _ in capi._ARRAYS + capi._ARRAYS2 + capi._ARRAYS3:
         d["arr__" + n] = m.array(n)
-    for kind, objtype, n in (("body", 0, m.c.nbody), ("jnt", 1, m.c.njnt), ("geom", 2, m.c.ngeom)):
+    for kind, objtype, n in (("body", 0, m.c.nbody), ("jnt", 1, m.c.njnt), ("geom", 2, m.c.ngeom), ("site", 3, m.c.nsite), ("sensor", 4, m.c.nsensor)):
         d["names__" + kind] = np.array([(m.lib.mjh_id2name(m.ptr, objtype, i) or b"").decode() for i in range(n)], dtype=str)
     d.update(extra)
     np.savez_compressed(path, **d)
@@ -31,6 +31,8 @@ def load_model_tables(path):
     st = capi.Model()
     for k in capi._INT_SIZES:
         setattr(st, k, int(z["int__" + k]))
+    for k in capi._INT_SIZES2:                      # fixtures written before sites / sensors / mocap bodies existed: none
+        setattr(st, k, int(z["int__" + k]) if "int__" + k in z else 0)
     st.meaninertia = float(z["meaninertia"])
     for k in _OPT_FIELDS:
         if "opt__" + k not in z:       # fixtures written before the field existed keep the struct's default
@@ -40,13 +42,19 @@ def load_model_tables(path):
     for i in range(3):
         st.opt.gravity[i] = float(z["opt__gravity"][i])
     keep = []
-    for n, t, _ in capi._ARRAYS:
-        a = np.ascontiguousarray(z["arr__" + n], dtype=np.int32 if t == "i" else np.float64)
+    for n, t, _ in capi._ARRAYS + capi._ARRAYS2 + capi._ARRAYS3:
+        if "arr__" + n not in z:
+            if n != "body_mocapid":
+                continue                             # (the struct's pointer stays NULL with a zero count)
+            src = -np.ones(st.nbody, dtype=np.int32)
+        else:
+            src = z["arr__" + n]
+        a = np.ascontiguousarray(src, dtype=np.int32 if t == "i" else np.float64)
         if a.size == 0:
             a = np.zeros(1, dtype=a.dtype)
         keep.append(a)
         setattr(st, n, a.ctypes.data_as(capi.c_int_p if t == "i" else capi.c_double_p))
-    for kind in ("body", "jnt", "geom"):          # name tables (mjh_name2id / mjh_id2name), if the file has them
+    for kind in ("body", "jnt", "geom", "site", "sensor"):          # name tables (mjh_name2id / mjh_id2name), if the file has them
         if "names__" + kind in z:
             bufs = [C.create_string_buffer(str(x).encode()) for x in z["names__" + kind]]
             arr = (C.c_char_p * max(1, len(bufs)))(*[C.cast(b, C.c_char_p) for b in bufs])

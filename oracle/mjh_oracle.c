@@ -143,6 +143,12 @@ orc_data* orc_make_data(const mjh_model* m) {
   d->scr_B = dalloc((size_t)(ne > 6 ? ne : 6)*nv);
   for (int i = 0; i < 3; i++) d->scr_body6[i] = dalloc(6*nb);
   for (int i = 0; i < 3; i++) { d->odom_lin[i] = -1; d->odom_ang[i] = -1; d->odom_angq[i] = -1; }
+  d->xfrc_applied = dalloc(6*nb); d->mocap_pos = dalloc(3*(size_t)m->nmocap); d->mocap_quat = dalloc(4*(size_t)m->nmocap);
+  d->sensordata = dalloc(m->nsensordata); d->site_xpos = dalloc(3*(size_t)m->nsite); d->site_xmat = dalloc(9*(size_t)m->nsite);
+  d->cacc = dalloc(6*nb); d->cfrc_int = dalloc(6*nb); d->cfrc_ext = dalloc(6*nb);
+  for (int b = 0; b < nb; b++) if (m->body_mocapid && m->body_mocapid[b] >= 0) {   /* mocap pose starts at the body's model pose */
+    copyv(d->mocap_pos + 3*m->body_mocapid[b], m->body_pos + 3*b, 3); copyv(d->mocap_quat + 4*m->body_mocapid[b], m->body_quat + 4*b, 4);
+  }
   copyv(d->initial_qpos, m->qpos0, nq);
   orc_reset(d);
   return d;
@@ -155,7 +161,8 @@ void orc_free_data(orc_data* d) {
     d->geom_xpos, d->geom_xmat, d->subtree_com, d->cinert, d->crb, d->cdof, d->cdof_dot, d->cvel, d->qM, d->qLD, d->qLDiagInv,
     d->efc_J, d->efc_pos, d->efc_margin, d->efc_frictionloss, d->efc_diagApprox, d->efc_R, d->efc_D, d->efc_KBIP, d->efc_vel,
     d->efc_aref, d->efc_b, d->efc_force, d->efc_AR, d->ddq, d->dq, d->tau, d->initial_qpos, d->scr_nM, d->scr_B,
-    d->geom_size, d->geom_rbound, d->body_mass, d->body_inertia, d->body_invweight0, d->dof_invweight0};
+    d->geom_size, d->geom_rbound, d->body_mass, d->body_inertia, d->body_invweight0, d->dof_invweight0,
+    d->xfrc_applied, d->mocap_pos, d->mocap_quat, d->sensordata, d->site_xpos, d->site_xmat, d->cacc, d->cfrc_int, d->cfrc_ext};
   for (size_t i = 0; i < sizeof(ps)/sizeof(ps[0]); i++) free(ps[i]);
   for (int i = 0; i < 6; i++) free(d->scr_nv[i]);
   for (int i = 0; i < 3; i++) { free(d->scr_efc[i]); free(d->scr_body6[i]); }
@@ -205,6 +212,9 @@ void orc_kinematics(orc_data* d) {
       copyv(xquat, d->qpos + qa + 3, 4);
       copyv(d->xanchor + 3*ja, xpos, 3);
       double ax[3] = {0, 0, 1}; copyv(d->xaxis + 3*ja, ax, 3);
+    } else if (m->body_mocapid && m->body_mocapid[i] >= 0) {   /* [UPSTREAM mj_kinematics]: mocap bodies take mocap_pos / mocap_quat */
+      copyv(xpos, d->mocap_pos + 3*m->body_mocapid[i], 3);
+      copyv(xquat, d->mocap_quat + 4*m->body_mocapid[i], 4);
     } else {
       int p = m->body_parentid[i];
       double t[3]; rotvec(t, d->xmat + 9*p, m->body_pos + 3*i);
@@ -250,6 +260,13 @@ void orc_kinematics(orc_data* d) {
     rotvec(t, d->xmat + 9*b, m->geom_pos + 3*g);
     for (int k = 0; k < 3; k++) d->geom_xpos[3*g+k] = d->xpos[3*b+k] + t[k];
     mulquat(q, d->xquat + 4*b, m->geom_quat + 4*g); quat2mat(d->geom_xmat + 9*g, q);
+  }
+  for (int s = 0; s < m->nsite; s++) {
+    int b = m->site_bodyid[s];
+    double t[3], q[4];
+    rotvec(t, d->xmat + 9*b, m->site_pos + 3*s);
+    for (int k = 0; k < 3; k++) d->site_xpos[3*s+k] = d->xpos[3*b+k] + t[k];
+    mulquat(q, d->xquat + 4*b, m->site_quat + 4*s); quat2mat(d->site_xmat + 9*s, q);
   }
 }
 
@@ -1021,7 +1038,49 @@ void orc_make_constraint(orc_data* d) {
   /* equality (joint coupling, as produced by mujoco_compile.cpp:235-242) */
   if (!(m->opt.disableflags & MJH_DSBL_EQUALITY))
     for (int e = 0; e < m->neq; e++) {
-      if (!m->eq_active[e] || m->eq_type[e] != MJH_EQ_JOINT) continue;
+      if (!m->eq_active[e]) continue;
+      if (m->eq_type[e] == MJH_EQ_CONNECT || m->eq_type[e] == MJH_EQ_WELD) {
+        /* [UPSTREAM mj_makeConstraint, mjEQ_CONNECT / mjEQ_WELD — restated, conventions in include/mjhip.h]: 3 rows
+         * p1 - p2 of the two anchors (world axes), weld: 3 more rows torquescale * vec(q1^-1 q2 relpose), whose time
+         * derivative is 1/2 torquescale vec(q1^-1 (w2 - w1) q2 relpose) */
+        const int weld = m->eq_type[e] == MJH_EQ_WELD, b1 = m->eq_obj1id[e], b2 = m->eq_obj2id[e];
+        const double* dat = m->eq_data + 11*e;
+        const double *a1 = weld ? dat + 3 : dat, *a2 = weld ? dat : dat + 3;
+        double p1[3], p2[3], t[3];
+        rotvec(t, d->xmat + 9*b1, a1); for (int k = 0; k < 3; k++) p1[k] = d->xpos[3*b1+k] + t[k];
+        rotvec(t, d->xmat + 9*b2, a2); for (int k = 0; k < 3; k++) p2[k] = d->xpos[3*b2+k] + t[k];
+        double* jb = (double*)malloc(sizeof(double) * 12 * (size_t)(nv ? nv : 1));
+        double *jp1 = jb, *jp2 = jb + 3*nv, *jr1 = jb + 6*nv, *jr2 = jb + 9*nv;
+        jac_point(d, jp1, jr1, p1, b1); jac_point(d, jp2, jr2, p2, b2);
+        const double tran = binv[2*b1] + binv[2*b2], rot = binv[2*b1+1] + binv[2*b2+1];
+        int fail = 0;
+        for (int k = 0; k < 3 && !fail; k++) {
+          int r = add_row(d, MJH_CNSTR_EQUALITY, e, p1[k] - p2[k], 0, 0);
+          if (r < 0) { fail = 1; break; }
+          for (int q = 0; q < nv; q++) d->efc_J[(size_t)r*nv + q] = jp1[k*nv+q] - jp2[k*nv+q];
+          d->efc_diagApprox[r] = tran;
+        }
+        if (weld && !fail) {
+          const double ts = dat[10];
+          double q1i[4] = {d->xquat[4*b1], -d->xquat[4*b1+1], -d->xquat[4*b1+2], -d->xquat[4*b1+3]}, q2r[4], qe[4];
+          mulquat(q2r, d->xquat + 4*b2, dat + 6); mulquat(qe, q1i, q2r);
+          for (int k = 0; k < 3 && !fail; k++) {
+            int r = add_row(d, MJH_CNSTR_EQUALITY, e, ts * qe[1+k], 0, 0);
+            if (r < 0) { fail = 1; break; }
+            for (int q = 0; q < nv; q++) {
+              double w[4] = {0, jr2[q] - jr1[q], jr2[nv+q] - jr1[nv+q], jr2[2*nv+q] - jr1[2*nv+q]}, u[4], v[4];
+              if (w[1] == 0 && w[2] == 0 && w[3] == 0) continue;
+              mulquat(u, q1i, w); mulquat(v, u, q2r);
+              d->efc_J[(size_t)r*nv + q] = 0.5 * ts * v[1+k];
+            }
+            d->efc_diagApprox[r] = rot;
+          }
+        }
+        free(jb);
+        if (fail) break;
+        continue;
+      }
+      if (m->eq_type[e] != MJH_EQ_JOINT) continue;
       int j1 = m->eq_obj1id[e], j2 = m->eq_obj2id[e];
       const double* dat = m->eq_data + 11*e;
       double pos1 = d->qpos[m->jnt_qposadr[j1]] - m->qpos0[m->jnt_qposadr[j1]], cpos, deriv = 0;
@@ -1262,6 +1321,18 @@ void orc_fwd_velocity(orc_data* d) { orc_com_vel(d); orc_passive(d); orc_referen
 void orc_fwd_acceleration(orc_data* d) {
   int nv = d->m->nv;
   for (int i = 0; i < nv; i++) d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_applied[i];
+  /* [UPSTREAM mj_xfrcAccumulate]: Cartesian force / torque on every body at its centre of mass, through the point Jacobian */
+  {
+    double* jb = NULL;
+    for (int b = 1; b < d->m->nbody; b++) {
+      const double* f = d->xfrc_applied + 6*b;
+      if (f[0] == 0 && f[1] == 0 && f[2] == 0 && f[3] == 0 && f[4] == 0 && f[5] == 0) continue;
+      if (!jb) jb = (double*)malloc(sizeof(double) * 6 * (size_t)(nv ? nv : 1));
+      jac_point(d, jb, jb + 3*nv, d->xipos + 3*b, b);
+      for (int i = 0; i < nv; i++) for (int k = 0; k < 3; k++) d->qfrc_smooth[i] += jb[k*nv+i] * f[k] + jb[(3+k)*nv+i] * f[3+k];
+    }
+    free(jb);
+  }
   copyv(d->qacc_smooth, d->qfrc_smooth, nv);
   orc_solve_m(d, d->qacc_smooth);
 }
@@ -1292,6 +1363,7 @@ static void block_trees(const orc_data* d, int row, int* t1, int* t2) {
   *t1 = *t2 = -1;
   switch (d->efc_type[row]) {
     case MJH_CNSTR_EQUALITY:
+      if (m->eq_type[id] != MJH_EQ_JOINT) { *t1 = m->body_treeid[m->eq_obj1id[id]]; *t2 = m->body_treeid[m->eq_obj2id[id]]; break; }
       *t1 = m->dof_treeid[m->jnt_dofadr[m->eq_obj1id[id]]];
       if (m->eq_obj2id[id] >= 0) *t2 = m->dof_treeid[m->jnt_dofadr[m->eq_obj2id[id]]];
       break;
@@ -1537,19 +1609,103 @@ void orc_set_odom_vels(orc_data* d) {
   for (int k = 0; k < 3; k++) if (d->odom_ang[k] >= 0) d->qvel[d->odom_ang[k]] = v[3+k];
 }
 
+/* [UPSTREAM mj_sensorAcc -> mj_rnePostConstraint, force / torque sensors]: cfrc_ext = external forces on every body
+ * (xfrc_applied, contact forces, connect / weld forces) as spatial forces about the subtree COM of the body's tree root;
+ * cacc with the solved qacc; cfrc_int = cinert cacc + cvel x* (cinert cvel) - cfrc_ext accumulated up the tree = the force the
+ * parent exerts on the body's subtree; a sensor reports it at its site, in the site frame */
+static void add_ext(orc_data* d, int b, const double* point, const double* force, const double* torque, double sign) {
+  if (b <= 0) return;
+  const double* com = d->subtree_com + 3*d->m->body_rootid[b];
+  double off[3] = {point[0] - com[0], point[1] - com[1], point[2] - com[2]}, t[3];
+  cross3(t, off, force);
+  for (int k = 0; k < 3; k++) { d->cfrc_ext[6*b+k] += sign * (torque[k] + t[k]); d->cfrc_ext[6*b+3+k] += sign * force[k]; }
+}
+void orc_sensor_acc(orc_data* d) {
+  const mjh_model* m = d->m; int nb = m->nbody, nv = m->nv;
+  if (m->nsensor == 0) return;
+  /* body velocities of the CURRENT qvel: the reference runs mj_inverse (-> mj_fwdVelocity) between step1 and step2 every step
+   * (mj_hw_interface.cpp:61), so d->cvel / cdof_dot always reflect the controller's velocity override when sensors are read */
+  orc_com_vel(d);
+  zero(d->cfrc_ext, 6*nb);
+  for (int b = 1; b < nb; b++) add_ext(d, b, d->xipos + 3*b, d->xfrc_applied + 6*b, d->xfrc_applied + 6*b + 3, 1.0);
+  for (int ic = 0; ic < d->ncon; ic++) {
+    const orc_contact* c = d->contact + ic;
+    if (c->exclude || c->efc_address < 0) continue;
+    const double* f = d->efc_force + c->efc_address;
+    double cf[3] = {0, 0, 0}, tors = 0;      /* contact-frame force on geom2's body (normal, tangent 1, tangent 2), torque about the normal */
+    if (c->dim == 1) cf[0] = f[0];
+    else for (int k = 1; k < c->dim; k++) {
+      const double mu = c->friction[k-1], fp = f[2*(k-1)], fm = f[2*(k-1)+1];
+      cf[0] += fp + fm;
+      if (k < 3) cf[k] += mu * (fp - fm); else tors += mu * (fp - fm);
+    }
+    double F[3], T[3];
+    for (int k = 0; k < 3; k++) { F[k] = c->frame[k]*cf[0] + c->frame[3+k]*cf[1] + c->frame[6+k]*cf[2]; T[k] = c->frame[k] * tors; }
+    add_ext(d, m->geom_bodyid[c->geom2], c->pos, F, T, 1.0);
+    add_ext(d, m->geom_bodyid[c->geom1], c->pos, F, T, -1.0);
+  }
+  for (int i = 0; i < d->nefc; i++) {          /* connect / weld: rows of one equality are consecutive */
+    if (d->efc_type[i] != MJH_CNSTR_EQUALITY || m->eq_type[d->efc_id[i]] == MJH_EQ_JOINT) continue;
+    const int e = d->efc_id[i], weld = m->eq_type[e] == MJH_EQ_WELD, b1 = m->eq_obj1id[e], b2 = m->eq_obj2id[e];
+    const double* dat = m->eq_data + 11*e;
+    const double *a1 = weld ? dat + 3 : dat, *a2 = weld ? dat : dat + 3, zero3[3] = {0, 0, 0};
+    double p1[3], p2[3], t[3];
+    rotvec(t, d->xmat + 9*b1, a1); for (int k = 0; k < 3; k++) p1[k] = d->xpos[3*b1+k] + t[k];
+    rotvec(t, d->xmat + 9*b2, a2); for (int k = 0; k < 3; k++) p2[k] = d->xpos[3*b2+k] + t[k];
+    add_ext(d, b1, p1, d->efc_force + i, zero3, 1.0);            /* rows p1 - p2: force +f on body1 at p1, -f on body2 at p2 */
+    add_ext(d, b2, p2, d->efc_force + i, zero3, -1.0);
+    if (weld) {                                                   /* rows 3..5: cpos' = A (w2 - w1): torque A^T f on body2, -A^T f on body1 */
+      const double ts = dat[10];
+      double q1i[4] = {d->xquat[4*b1], -d->xquat[4*b1+1], -d->xquat[4*b1+2], -d->xquat[4*b1+3]}, q2r[4], T[3] = {0, 0, 0};
+      mulquat(q2r, d->xquat + 4*b2, dat + 6);
+      for (int a = 0; a < 3; a++) {
+        double w[4] = {0, a == 0, a == 1, a == 2}, u[4], v[4];
+        mulquat(u, q1i, w); mulquat(v, u, q2r);
+        for (int k = 0; k < 3; k++) T[a] += 0.5 * ts * v[1+k] * d->efc_force[i + 3 + k];
+      }
+      add_ext(d, b2, p2, zero3, T, 1.0); add_ext(d, b1, p1, zero3, T, -1.0);
+    }
+    i += weld ? 5 : 2;
+  }
+  zero(d->cacc, 6); zero(d->cfrc_int, 6);
+  if (!(m->opt.disableflags & MJH_DSBL_GRAVITY)) for (int k = 0; k < 3; k++) d->cacc[3+k] = -m->opt.gravity[k];
+  for (int i = 1; i < nb; i++) {
+    int bda = m->body_dofadr[i], p = m->body_parentid[i];
+    double tmp[6], tmp1[6];
+    copyv(d->cacc + 6*i, d->cacc + 6*p, 6);
+    for (int k = 0; k < m->body_dofnum[i]; k++) for (int q = 0; q < 6; q++)
+      d->cacc[6*i+q] += d->cdof_dot[6*(bda+k)+q] * d->qvel[bda+k] + d->cdof[6*(bda+k)+q] * d->qacc[bda+k];
+    mul_inert_vec(d->cfrc_int + 6*i, d->cinert + 10*i, d->cacc + 6*i);
+    mul_inert_vec(tmp, d->cinert + 10*i, d->cvel + 6*i);
+    cross_force(tmp1, d->cvel + 6*i, tmp);
+    for (int q = 0; q < 6; q++) d->cfrc_int[6*i+q] += tmp1[q] - d->cfrc_ext[6*i+q];
+  }
+  for (int i = nb - 1; i > 0; i--) { int p = m->body_parentid[i]; if (p > 0) for (int q = 0; q < 6; q++) d->cfrc_int[6*p+q] += d->cfrc_int[6*i+q]; }
+  (void)nv;
+  for (int s = 0; s < m->nsensor; s++) {
+    const int site = m->sensor_objid[s], b = m->site_bodyid[site];
+    const double* com = d->subtree_com + 3*m->body_rootid[b];
+    const double* F = d->cfrc_int + 6*b;
+    double off[3] = {d->site_xpos[3*site] - com[0], d->site_xpos[3*site+1] - com[1], d->site_xpos[3*site+2] - com[2]}, t[3], tq[3];
+    cross3(t, off, F + 3);
+    for (int k = 0; k < 3; k++) tq[k] = F[k] - t[k];                      /* torque about the site */
+    rotvecT(d->sensordata + m->sensor_adr[s], d->site_xmat + 9*site, m->sensor_type[s] == MJH_SENS_FORCE ? F + 3 : tq);
+  }
+}
+
 void orc_step1(orc_data* d) {
   check_state(d);
   orc_fwd_position(d); orc_energy(d); orc_fwd_velocity(d);
   orc_controller(d);
 }
 void orc_step2(orc_data* d) {
-  orc_fwd_acceleration(d); orc_fwd_constraint(d); check_state(d); orc_euler(d);
+  orc_fwd_acceleration(d); orc_fwd_constraint(d); orc_sensor_acc(d); check_state(d); orc_euler(d);
   orc_set_odom_vels(d);
 }
 void orc_forward(orc_data* d) {
   check_state(d);
   orc_fwd_position(d); orc_energy(d); orc_fwd_velocity(d); orc_controller(d);
-  orc_fwd_acceleration(d); orc_fwd_constraint(d);
+  orc_fwd_acceleration(d); orc_fwd_constraint(d); orc_sensor_acc(d);
 }
 
 /* mj_inverse as called by MjHWInterface::read (mj_hw_interface.cpp:61) [UPSTREAM mj_inverse]:
@@ -1612,7 +1768,9 @@ double* orc_field(orc_data* d, const char* name, int* n) {
   F("efc_aref", d->efc_aref, ne) F("efc_b", d->efc_b, ne) F("efc_force", d->efc_force, ne) F("efc_AR", d->efc_AR, ne*ne)
   F("efc_vel", d->efc_vel, ne) F("efc_diagApprox", d->efc_diagApprox, ne) F("efc_KBIP", d->efc_KBIP, 4*ne)
   F("energy", d->energy, 2) F("time", &d->time, 1) F("ddq", d->ddq, nv) F("dq", d->dq, nv) F("odom_vel", d->odom_vel, 6)
-  F("initial_qpos", d->initial_qpos, m->nq)
+  F("initial_qpos", d->initial_qpos, m->nq) F("xfrc_applied", d->xfrc_applied, 6*nb) F("mocap_pos", d->mocap_pos, 3*m->nmocap)
+  F("mocap_quat", d->mocap_quat, 4*m->nmocap) F("sensordata", d->sensordata, m->nsensordata) F("site_xpos", d->site_xpos, 3*m->nsite)
+  F("site_xmat", d->site_xmat, 9*m->nsite) F("cfrc_int", d->cfrc_int, 6*nb) F("cfrc_ext", d->cfrc_ext, 6*nb) F("cacc", d->cacc, 6*nb)
 #undef F
   *n = 0; return NULL;
 }

@@ -55,6 +55,10 @@ typedef struct orc_data {
   int odom_lin[3], odom_ang[3], odom_angq[3]; double odom_vel[6];
   double* initial_qpos;
   unsigned slot_mask; /* bit b = body b is an inactive spawn/destroy slot */
+  /* d->xfrc_applied [6*nbody] (force, torque per body at its centre of mass, world frame; mj_sim.cpp:499), d->mocap_pos /
+   * mocap_quat [3 / 4 per mocap body] (mj_sim.cpp:903: the *_ref bodies), d->sensordata [nsensordata] (mj_ros.cpp:1933-1966),
+   * site frames, and the body accelerations / interaction forces of mj_rnePostConstraint that the sensors read */
+  double *xfrc_applied, *mocap_pos, *mocap_quat, *sensordata, *site_xpos, *site_xmat, *cacc, *cfrc_int, *cfrc_ext;
   /* joint-space PD effort controller evaluated in front of every step of orc_step (what ros_control's effort controllers do
    * between read() and write(), mj_main.cpp:86-106): ddq = kp (target - q) - kd qvel on hinge / slide dofs */
   double *pd_target, pd_kp, pd_kd;
@@ -82,6 +86,7 @@ void orc_passive(orc_data* d);
 void orc_reference_constraint(orc_data* d);
 void orc_rne(orc_data* d, int flg_acc, double* result);
 void orc_energy(orc_data* d);
+void orc_sensor_acc(orc_data* d);    /* mj_sensorAcc -> mj_rnePostConstraint: force / torque sensors (end of mj_step2's forward part) */
 
 void orc_fwd_position(orc_data* d);
 void orc_fwd_velocity(orc_data* d);

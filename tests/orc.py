@@ -24,7 +24,7 @@ def lib():
                   "orc_make_constraint", "orc_project_constraint", "orc_com_vel", "orc_passive",
                   "orc_reference_constraint", "orc_energy", "orc_fwd_position", "orc_fwd_velocity",
                   "orc_fwd_acceleration", "orc_fwd_constraint", "orc_euler", "orc_controller",
-                  "orc_set_odom_vels", "orc_step1", "orc_step2", "orc_forward", "orc_inverse"]:
+                  "orc_set_odom_vels", "orc_step1", "orc_step2", "orc_forward", "orc_inverse", "orc_sensor_acc"]:
             getattr(L, f).argtypes = [vp]; getattr(L, f).restype = None
         L.orc_step.argtypes = [vp, C.c_int, C.c_int]
         L.orc_rne.argtypes = [vp, C.c_int, dp]

@@ -425,3 +425,94 @@ def test_simulate_real_time_spin_and_adaptive_timestep(lib):
     assert sim_time / wall <= 1.0 + 1e-2
     assert abs(e.timestep - final_dt) < 1e-15
     e.close()
+
+
+# ------------------------------------------------------------------ xfrc_applied, sensors, mocap + weld / connect (B1, F4, F1)
+def _feature_scene(lib):
+    """floor + a free base box carrying an upper body on a limited slide joint (force + torque sensors at a rotated site on it) +
+    a free box welded (torquescale 0.9) to its mocap clone + a free box connected to the base: every new row type at once"""
+    from helpers import D, set_opt
+    b = lib.mjh_builder_create()
+    set_opt(lib, b, timestep=0.002)
+    lib.mjh_builder_add_geom(b, b"floor", 0, 0, D(0, 0, 0.05), None, None, None, -1, -1, -1, -1)
+    base = lib.mjh_builder_add_body(b, b"base", 0, D(0, 0, 0.0995), None, 0.0)
+    lib.mjh_builder_add_joint(b, b"base_free", base, 0, None, None, None, 0, 0, 0, 0, 0)
+    lib.mjh_builder_add_geom(b, b"bg", base, 6, D(0.2, 0.2, 0.1), None, None, None, -1, -1, -1, -1)
+    up = lib.mjh_builder_add_body(b, b"upper", base, D(0, 0, 0.3), None, 0.0)
+    lib.mjh_builder_add_joint(b, b"slide", up, 2, None, D(0, 0, 1), D(0.0, 0.5), 0, 0, 0, 0, 0)
+    lib.mjh_builder_set_inertial(b, up, 1.5, D(0.02, 0, 0.01), None, D(0.01, 0.02, 0.015))
+    s1 = lib.mjh_builder_add_site(b, b"s_up", up, D(0.01, 0.02, -0.03), D(0.9, 0.1, -0.3, 0.2))
+    s0 = lib.mjh_builder_add_site(b, b"s_base", base, D(0, 0, 0.05), None)
+    for k, (t, s) in enumerate(((4, s1), (5, s1), (4, s0), (5, s0))):
+        lib.mjh_builder_add_sensor(b, b"sens%d" % k, t, s)
+    cube = lib.mjh_builder_add_body(b, b"cube", 0, D(1.0, 0, 0.6), None, 0.0)
+    lib.mjh_builder_add_joint(b, b"cube_free", cube, 0, None, None, None, 0, 0, 0, 0, 0)
+    lib.mjh_builder_add_geom(b, b"cg", cube, 6, D(0.1, 0.1, 0.1), None, None, None, -1, -1, -1, -1)
+    ref = lib.mjh_builder_add_body(b, b"cube_ref", 0, D(1.0, 0, 0.6), None, 0.0)
+    lib.mjh_builder_add_geom(b, b"rg", ref, 6, D(0.1, 0.1, 0.1), None, None, None, -1, 0, 0, -1)
+    lib.mjh_builder_set_mocap(b, ref)
+    lib.mjh_builder_add_eq_weld(b, cube, ref, None, 0.9)
+    bob = lib.mjh_builder_add_body(b, b"bob", 0, D(0.0, 0.5, 0.5), None, 0.0)
+    lib.mjh_builder_add_joint(b, b"bob_free", bob, 0, None, None, None, 0, 0, 0, 0, 0)
+    lib.mjh_builder_add_geom(b, b"bb", bob, 2, D(0.08, 0, 0), None, None, None, -1, -1, -1, -1)
+    lib.mjh_builder_add_eq_connect(b, bob, base, D(0.0, -0.25, 0.0))
+    lib.mjh_builder_set_capacity(b, 24, 24 * 4 + 12)
+    m = ms.Model(lib.mjh_builder_compile(b), lib); lib.mjh_builder_destroy(b)
+    return m
+
+
+@pytest.mark.parametrize("layout", [1, 2], ids=["lds-resident", "global-pools"])
+def test_sensors_mocap_weld_connect_and_xfrc_match_the_oracle(layout, lib):
+    m = _feature_scene(lib)
+    assert (m.nsensor, m.nmocap, m.neq) == (4, 1, 2)
+    lib.mjh_set_layout_policy(layout)
+    try:
+        nenv = 6
+        e = ms.Engine(m, nenv)
+    finally:
+        lib.mjh_set_layout_policy(0)
+    ds = [orc.OrcData(m.ptr) for _ in range(nenv)]
+    rng = np.random.default_rng(3)
+    tp = np.array([1.0, 0, 0.6]) + rng.uniform(-0.3, 0.3, size=(nenv, 3))
+    tq = rng.normal(size=(nenv, 4)); tq[:, 0] += 3.0; tq /= np.linalg.norm(tq, axis=1, keepdims=True)
+    xf = np.zeros((nenv, m.nbody, 6))
+    up, bob = m.name2id(0, "upper"), m.name2id(0, "bob")
+    xf[:, up, 2] = rng.uniform(0, 6, nenv); xf[:, up, 3:] = rng.uniform(-0.2, 0.2, (nenv, 3)); xf[:, bob, :3] = rng.uniform(-1, 1, (nenv, 3))
+    e.reset(); e.set_mocap_pose(0, tp, tq); e.set_xfrc_applied(xf)
+    np.testing.assert_allclose(e.get_xfrc_applied(), xf, atol=1e-6)
+    for i, d in enumerate(ds):
+        d.call("reset"); d.f("mocap_pos")[:] = tp[i]; d.f("mocap_quat")[:] = tq[i]; d.f("xfrc_applied")[:] = xf[i].reshape(-1)
+    for seg in range(6):
+        e.step(50, True); [d.step(50, 1) for d in ds]
+        _, q, v, _ = e.get_state(); st = e.get_stats(); sd = e.get_sensordata()
+        oq = np.array([d.f("qpos") for d in ds]); ov = np.array([d.f("qvel") for d in ds]); osd = np.array([d.f("sensordata") for d in ds])
+        assert (st[:, 3] == 0).all() and all(d.i("warn") == 0 for d in ds)
+        assert (st[:, 1] == np.array([d.i("nefc") for d in ds])).all(), (seg, st[:, 1], [d.i("nefc") for d in ds])
+        np.testing.assert_allclose(q, oq, atol=2e-3, err_msg=f"segment {seg}")
+        np.testing.assert_allclose(v, ov, atol=2e-2, err_msg=f"segment {seg}")
+        scale = max(1.0, np.abs(osd).max())
+        np.testing.assert_allclose(sd, osd, atol=2e-2 * scale, err_msg=f"sensordata, segment {seg}")
+        e.set_state(qpos=oq, qvel=ov, warmstart=np.array([d.f("qacc_warmstart") for d in ds]))
+    # the welded cube arrived at ITS env's mocap pose, the upper body's force sensor sees weight minus the pull
+    cq = m.array("jnt_qposadr")[m.array("body_jntadr")[m.name2id(0, "cube")]]
+    np.testing.assert_allclose(oq[:, cq:cq + 3], tp + np.array([0, 0, 0.0]), atol=5e-3)
+    assert np.abs(osd).max() > 1.0
+    e.close()
+
+
+def test_xfrc_applied_survives_a_model_change_and_zero_xfrc_changes_nothing(lib):
+    """B1: add_old_state() copies xfrc_applied per body across a recompile (mj_sim.cpp:496-500); an all-zero xfrc array routes
+    the S24 kernel through the feature-carrying instance without changing the trajectory beyond fp32 rounding"""
+    m = ms.scene("s24")
+    a = ms.Engine(m, 8); a.load_s24(); b = ms.Engine(m, 8); b.load_s24()
+    b.set_xfrc_applied(np.zeros((8, m.nbody, 6)))
+    a.step(120); b.step(120)
+    np.testing.assert_allclose(a.get_state()[1], b.get_state()[1], atol=2e-3)
+    xf = np.zeros((8, m.nbody, 6)); xf[:, 2, 2] = 3.0; xf[:, 4, 3] = 0.1
+    b.set_xfrc_applied(xf)
+    c = ms.Engine(m, 8); c.load_s24()
+    assert c.transplant_state_from(b) == 4
+    np.testing.assert_allclose(c.get_xfrc_applied(), xf, atol=1e-7)
+    b.step(1); c.step(1)
+    assert np.array_equal(b.get_state()[1], c.get_state()[1])
+    a.close(); b.close(); c.close()
