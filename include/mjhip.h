@@ -170,7 +170,8 @@ int mjh_builder_add_body(mjh_builder*, const char* name, int parent, const doubl
                          const double quat[4], double gravcomp);
 int mjh_builder_set_inertial(mjh_builder*, int body, double mass, const double ipos[3],
                              const double iquat[4], const double diaginertia[3]);
-/* range==NULL -> unlimited */
+/* range==NULL -> unlimited.  Sentinels of add_geom / add_mesh_geom: friction NULL, condim / contype / conaffinity < 0 and
+ * density < 0 mean "MuJoCo's default" (1 0.005 0.0001, 3, 1, 1, 1000); an explicit density 0 is a massless geom */
 int mjh_builder_add_joint(mjh_builder*, const char* name, int body, int type, const double pos[3],
                           const double axis[3], const double range[2], double damping,
                           double stiffness, double armature, double frictionloss, double ref);

@@ -185,6 +185,8 @@ struct Loader {
       }
       if (gt == MJH_GEOM_CAPSULE || gt == MJH_GEOM_CYLINDER) size[1] = 0.5 * len; else { size[1] = size[1] > 0 ? size[1] : size[0]; size[2] = 0.5 * len; }
     }
+    for (const char* a : {"solref", "solimp", "margin", "gap", "solmix", "priority", "fluidshape"})
+      if (n.get(a)) note += std::string("ignored geom attribute ") + a + " (MuJoCo defaults used); ";
     std::memcpy(fr, def.geom_friction, sizeof fr);
     double t3[3]; int nf = nums(n.get("friction"), t3, 3); for (int i = 0; i < nf; i++) fr[i] = t3[i];
     double v; int condim = def.geom_condim, contype = def.geom_contype, conaff = def.geom_conaffinity; double density = def.geom_density;
@@ -215,7 +217,10 @@ struct Loader {
     bool limited = false;
     if (const char* l = n.get("limited")) { std::string s = l; limited = s == "true" || (s == "auto" && hasrange); }
     else limited = autolimits && hasrange;
-    if (limited && type == MJH_JNT_HINGE) { range[0] = ang(range[0]); range[1] = ang(range[1]); }
+    if (limited && (type == MJH_JNT_HINGE || type == MJH_JNT_BALL)) { range[0] = ang(range[0]); range[1] = ang(range[1]); }   // angles for both
+    if (limited && type == MJH_JNT_BALL) note += "ball joint range of " + std::string(n0.get("name") ? n0.get("name") : "?") + " read but not enforced (ball limits are not implemented); ";
+    for (const char* a : {"springref", "solreflimit", "solimplimit", "solreffriction", "solimpfriction", "margin", "springdamper"})
+      if (n.get(a)) note += std::string("ignored joint attribute ") + a + "; ";
     double damping = def.jnt_damping, stiffness = def.jnt_stiffness, armature = def.jnt_armature, floss = def.jnt_frictionloss, ref = 0;
     if (nums(n.get("damping"), &v, 1)) damping = v;
     if (nums(n.get("stiffness"), &v, 1)) stiffness = v;
@@ -301,6 +306,7 @@ struct Loader {
     robot_file = !first;      // files after the world file are robots (MjSim::init composition)
     degree = true; autolimits = false; def = Defaults(); basedir = dir; meshdir.clear(); mesh_id.clear(); classes.clear(); childclass.clear();
     mjh_option o; mjh_builder_get_option(b, &o);
+    bool solver_named = false;
     // first pass: compiler / option / default (they may appear after worldbody in a file)
     for (auto& c : root.kids) {
       if (c->tag == "compiler") {
@@ -320,7 +326,9 @@ struct Loader {
         if (nums(c->get("tolerance"), &v, 1)) o.tolerance = v;
         if (nums(c->get("noslip_iterations"), &v, 1)) o.noslip_iterations = (int)v;
         if (nums(c->get("noslip_tolerance"), &v, 1)) o.noslip_tolerance = v;
-        if (const char* s = c->get("solver")) if (std::string(s) != "PGS") note += std::string("solver=") + s + " -> PGS; ";
+        if (const char* s = c->get("solver")) { solver_named = true; if (std::string(s) != "PGS") note += std::string("solver=") + s + " -> PGS; "; }
+        if (const char* s = c->get("cone")) if (std::string(s) != "pyramidal") note += std::string("cone=") + s + " -> pyramidal; ";
+        if (const char* s = c->get("integrator")) if (std::string(s) != "Euler") note += std::string("integrator=") + s + " ignored: the step1 / step2 split of the reference loop always integrates with Euler (mj_main.cpp:83,108); ";
         for (auto& f : c->kids) if (f->tag == "flag") {
           if (const char* s = f->get("gravity")) if (std::string(s) == "disable") o.disableflags |= MJH_DSBL_GRAVITY;
           if (const char* s = f->get("contact")) if (std::string(s) == "disable") o.disableflags |= MJH_DSBL_CONTACT;
@@ -347,6 +355,8 @@ struct Loader {
       }
     }
     if (first) mjh_builder_set_option(b, &o);
+    // said ALWAYS (no reference model names a solver, so every one of them silently ran on a different solver otherwise)
+    if (first && !solver_named) note += "no <option solver>: MuJoCo's default is Newton, this engine solves the same dual problem with PGS (100 iterations, tolerance 1e-8); ";
     // <asset><mesh>: binary STL files next to the MJCF file (pr2.xml:4-23); a mesh that cannot be read is reported and
     // the geoms that use it are skipped
     for (auto& c : root.kids) if (c->tag == "asset") for (auto& a : c->kids) if (a->tag == "mesh") {

@@ -135,7 +135,7 @@ extern "C" int mjh_builder_add_geom(mjh_builder* b, const char* name, int body, 
   g.friction[0] = friction ? friction[0] : 1.0; g.friction[1] = friction ? friction[1] : 0.005;
   g.friction[2] = friction ? friction[2] : 0.0001;
   g.condim = condim > 0 ? condim : 3; g.contype = contype >= 0 ? contype : 1;
-  g.conaffinity = conaffinity >= 0 ? conaffinity : 1; g.density = density > 0 ? density : 1000.0;
+  g.conaffinity = conaffinity >= 0 ? conaffinity : 1; g.density = density >= 0 ? density : 1000.0;   // negative = unset (MuJoCo default 1000); an explicit 0 is a massless geom
   b->geoms.push_back(g);
   return (int)b->geoms.size() - 1;
 }
