@@ -38,6 +38,7 @@ struct DModel {
   double timestep_d;   // opt.timestep in fp64: per-env time advances by exactly this (time == n * dt after n steps)
   // sites, force / torque sensors, mocap bodies, connect / weld equalities (EXTRA kernel instances only)
   int nsite, nsensor, nmocap, has_weld;
+  int group_max;     // Gauss-Seidel groups of many-block models hold up to 4 or 16 mutually independent blocks (16: <= 64 trees of <= 8 dofs)
   int scratch_off;   // many-body layout: LDS scratch of k1_floats floats (the dead position-stage arrays; an own region when sensors keep them alive)
   int o_site_bodyid, o_site_pos, o_site_quat, o_sensor_type, o_sensor_objid, o_body_mocapid, o_eq_type;
 };

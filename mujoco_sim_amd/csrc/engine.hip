@@ -235,6 +235,10 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     M.o_body_mocapid = addI(mocapid.data(), nb);
   }
   M.nsite = m->nsite; M.nsensor = m->nsensor; M.nmocap = m->nmocap; M.has_weld = has_weld ? 1 : 0;
+  // groups of up to 16 mutually independent blocks (four waves x four 16-lane rows in mjh_solve_kernel) when a tree bitmask fits
+  // one 64-bit word and every block fits a 16-lane row; else 4 (same rule as the oracle's m_group_max)
+  M.group_max = m->ntree <= 64 ? 16 : 4;
+  for (int t = 0; t < m->ntree; t++) if (m->tree_dofnum[t] > 8) M.group_max = 4;
 #undef PI
 #undef PF
   M.nq = m->nq; M.nv = nv; M.nbody = nb; M.njnt = nj; M.ngeom = ng; M.neq = m->neq; M.npair = m->npair; M.nM = m->nM; M.ntree = m->ntree;
@@ -540,12 +544,18 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
         // sweeps, which are > 90 % of such a step) -> integrate
         rc = launch_on(e, st, g0, g1 - g0, 1, ph | PH_PRE, 0);
         if (!rc) {
-          const size_t lds = (2 * (size_t)(((e->M.nv + 3) / 4) * 4) + 2 * (size_t)std::max(e->M.maxblk, 1) + 4) * sizeof(float);   // 2 dof vectors + visiting order + group starts
+          const size_t lds = (2 * (size_t)(((e->M.nv + 3) / 4) * 4) + 2 * (size_t)std::max(e->M.maxblk, 1) + 4 + 8) * sizeof(float);   // 2 dof vectors + visiting order + group starts + per-wave partial sums
           const bool xs = e->M.noslip_iterations > 0;      // (the convex narrow phase is not part of the solve launch)
-          if (e->M.diagM) { if (xs) hipLaunchKernelGGL((mjh_solve_kernel<true, true>), dim3(g1 - g0), dim3(64), lds, st, e->dC, e->S, g0);
-                            else hipLaunchKernelGGL((mjh_solve_kernel<true, false>), dim3(g1 - g0), dim3(64), lds, st, e->dC, e->S, g0); }
-          else { if (xs) hipLaunchKernelGGL((mjh_solve_kernel<false, true>), dim3(g1 - g0), dim3(64), lds, st, e->dC, e->S, g0);
-                 else hipLaunchKernelGGL((mjh_solve_kernel<false, false>), dim3(g1 - g0), dim3(64), lds, st, e->dC, e->S, g0); }
+          // wide groups (up to 16 independent blocks) can be shared by several waves per environment (MJH_SOLVE_WAVES = 2, 4: chunk
+          // c4 of a group goes to wave c4 % n, a workgroup barrier ends the group).  Measured on C2 (4096 envs, 215 contacts per
+          // env): 288 k / 282 k / 259 k env-steps/s with 1 / 2 / 4 waves — the sweep streams 0.4 MB of block operands per env and
+          // sweep from L2 / HBM and is bound by that stream, not by the length of the dependent chain; so the default stays 1
+          static const int nwave_env = getenv("MJH_SOLVE_WAVES") ? std::max(1, std::min(4, atoi(getenv("MJH_SOLVE_WAVES")))) : 1;
+          const dim3 thr(e->M.group_max == 16 && e->M.rowW <= 16 ? 64 * nwave_env : 64);
+          if (e->M.diagM) { if (xs) hipLaunchKernelGGL((mjh_solve_kernel<true, true>), dim3(g1 - g0), thr, lds, st, e->dC, e->S, g0);
+                            else hipLaunchKernelGGL((mjh_solve_kernel<true, false>), dim3(g1 - g0), thr, lds, st, e->dC, e->S, g0); }
+          else { if (xs) hipLaunchKernelGGL((mjh_solve_kernel<false, true>), dim3(g1 - g0), thr, lds, st, e->dC, e->S, g0);
+                 else hipLaunchKernelGGL((mjh_solve_kernel<false, false>), dim3(g1 - g0), thr, lds, st, e->dC, e->S, g0); }
           HIPCHK(hipGetLastError());
           rc = launch_on(e, st, g0, g1 - g0, 1, PH_STEP2 | PH_POST, 0);
         }

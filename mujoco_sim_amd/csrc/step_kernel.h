@@ -314,17 +314,23 @@ struct ManyCtx {
   float* qacc; const float* qLDinv;
   int nblk, nfixblk, rowW, iterations; bool has_dim4; float scale, tolerance;
   int noslip_iterations; float noslip_tolerance;     // noslip post-pass (EXTRA instances only)
+  int nwave, wid; float* red;                        // mjh_solve_kernel with wide groups: waves per environment, this wave, LDS partial sums
 };
 template <bool DIAGM, bool EXTRA>
 DEV int pgs_many_body(const ManyCtx& c, const int lane) {
   int niter = 0, nmain = 0;
+  // a four-wave workgroup (mjh_solve_kernel with wide groups) on an environment whose sweep is sequential (few blocks): wave 0
+  // works alone and meets the others at the kernel's final barrier; no workgroup barrier may then be executed in here
+  const bool wide = c.nblk > 64 && c.rowW <= 16 && c.ngrp >= 2;
+  const bool solo = c.nwave > 1 && !wide;
+  if (solo && c.wid != 0) return 0;
   // sweep mode: the main PGS sweeps, then (EXTRA instances, option noslip_iterations) the noslip sweeps over the same
   // schedule with the friction-only row math
   bool ns = false;
   int itmax = c.iterations; float tol = c.tolerance;
   const int nmode = (EXTRA && c.noslip_iterations > 0) ? 2 : 1;
   for (int mode = 0; mode < nmode; mode++) {
-  if (mode == 1) { ns = true; nmain = niter; niter = 0; itmax = c.noslip_iterations; tol = c.noslip_tolerance; __syncthreads(); }
+  if (mode == 1) { ns = true; nmain = niter; niter = 0; itmax = c.noslip_iterations; tol = c.noslip_tolerance; if (!solo) __syncthreads(); }
   // operands of one block; every address follows from the block index alone (contact blocks are laid out
   // regularly behind the c.nfixblk non-contact ones), so all loads of block k+1 are in flight while block k is solved
   struct MOp { int4 hd; int b; float4 J, B, p0, r0, r1, r2, A0, A1, A2, A3, X0, X1, X2; };
@@ -373,17 +379,21 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
       *(float2*)(bf + 4) = make_float2(f[4], f[5]);
     }
   };
-  if (c.nblk > 64 && c.rowW <= 16 && c.ngrp >= 2) {
-    // ======== four blocks per step: the blocks of a group (mutually independent by construction of the order) sit on the
-    //          four 16-lane rows of the wave; lanes of a row = the compact dofs of its block.  Everything "uniform" of the
-    //          single-block step is uniform per row; a row-wide sum is a 4-step DPP butterfly inside the row.
+  if (wide) {
+    // ======== four blocks per wave-step: the blocks of a group (mutually independent by construction of the order) sit on the
+    //          four 16-lane rows of a wave; lanes of a row = the compact dofs of its block.  Everything "uniform" of the
+    //          single-block step is uniform per row; a row-wide sum is a 4-step DPP butterfly inside the row.  A group holds
+    //          up to 16 blocks: chunk c4 of group g = positions gstart[g] + 4 c4 ...; ONE wave walks the chunks of a group one
+    //          after the other (fused kernel); the c.nwave waves of mjh_solve_kernel share them (chunk c4 goes to wave c4 % nwave) and meet at a
+    //          workgroup barrier after every group.
     const int row = lane >> 4, l = lane & 15;
+    const bool multi = c.nwave > 1;     // (solo is false here)
     struct QOp { int4 hd; int b; float act; float4 J, B, p0, r0, r1, r2, A0, A1, A2, A3, X0, X1, X2; };
-    auto fetchQ = [&](int g) __attribute__((always_inline)) {
+    auto fetchQ = [&](int g, int c4) __attribute__((always_inline)) {
       QOp op;
-      const int st = c.gstart[g], sz = c.gstart[g + 1] - st;
+      const int st = c.gstart[g] + 4 * c4, sz = c.gstart[g + 1] - st;       // sz <= 0: this wave has no chunk in this group
       const bool act = row < sz;
-      const int b = c.order[st + (act ? row : 0)];
+      const int b = c.order[act ? st + row : c.gstart[g]];
       op.b = b; op.act = act ? 1.0f : 0.0f; op.hd = ((const int4*)c.blki)[b];
       const bool quad = b >= c.nfixblk;
       const int jo = (quad ? c.nfixblk + 4 * (b - c.nfixblk) : b) * c.rowW;
@@ -437,15 +447,34 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
         *(float2*)(bf + 4) = make_float2(f[4], f[5]);
       }
     };
-    // operands are requested two group-steps ahead (three register sets in rotation): the pools of a cohort exceed the L2
-    // and one group-step is shorter than a miss
-    int gf = 0, g = 0;
-    auto nextFetch = [&]() __attribute__((always_inline)) { QOp o = fetchQ(gf); gf = gf + 1 == c.ngrp ? 0 : gf + 1; return o; };
+    // operands are requested two steps ahead (three register sets in rotation): the pools of a cohort exceed the L2 and one
+    // step is shorter than a miss.  A wave's items of one sweep: for every group g its chunks c4 = wid, wid + nwave, ... (at
+    // least one, possibly idle, so that every wave meets the barrier that ends the group).  Two iterators over that cyclic
+    // sequence: gF / cF fetches, gP / cP processes.
+    const int nw = c.nwave;
+    int gF = 0, cF = c.wid, gP = 0, cP = c.wid;
+    auto nextFetch = [&]() __attribute__((always_inline)) {
+      QOp o = fetchQ(gF, cF);
+      cF += nw;
+      if (c.gstart[gF] + 4 * cF >= c.gstart[gF + 1]) { cF = c.wid; gF = gF + 1 == c.ngrp ? 0 : gF + 1; }
+      return o;
+    };
     float impl = 0; bool done = false;
-    auto stepDone = [&]() __attribute__((always_inline)) {          // end of a sweep: convergence test
-      if (++g < c.ngrp) return;
-      g = 0; niter++;
-      const float improvement = readlane_f(impl, 0) + readlane_f(impl, 16) + readlane_f(impl, 32) + readlane_f(impl, 48);
+    auto stepDone = [&]() __attribute__((always_inline)) {          // end of a step; at the end of a sweep: convergence test
+      cP += nw;
+      if (c.gstart[gP] + 4 * cP < c.gstart[gP + 1]) return;         // more chunks of this group for this wave
+      cP = c.wid;
+      if (multi) __syncthreads();                                     // the group's scatters are visible to every wave
+      if (++gP < c.ngrp) return;
+      gP = 0; niter++;
+      float improvement = readlane_f(impl, 0) + readlane_f(impl, 16) + readlane_f(impl, 32) + readlane_f(impl, 48);
+      if (multi) {
+        if (lane == 0) c.red[c.wid] = improvement;
+        __syncthreads();
+        improvement = 0;
+        for (int w = 0; w < nw; w++) improvement += c.red[w];
+        __syncthreads();
+      }
       impl = 0;
       done = improvement * c.scale < tol || niter >= itmax;
     };
@@ -468,7 +497,7 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
     // (the prefetch would read the forces of a block before its pending update is stored)
     for (int it = 0; it < itmax; it++) {
       float improvement = 0;
-      for (int k = 0; k < c.nblk; k++) { MOp op = fetch8(blockAt(k)); process8(op, improvement); __syncthreads(); }
+      for (int k = 0; k < c.nblk; k++) { MOp op = fetch8(blockAt(k)); process8(op, improvement); if (!solo) __syncthreads(); }
       niter = it + 1;
       if (improvement * c.scale < tol) break;
     }
@@ -1266,6 +1295,27 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             k++; cursor = p0 + 1;
             int cnt = 1, pos = p0 + 1;
             WSYNC();
+            if (M.group_max == 16) {
+              // wide groups: up to 16 blocks, the trees of the group as a bitmask (<= 64 trees by the host's rule)
+              auto tmask = [&](int w) __attribute__((always_inline)) {
+                const int ta = (w >> 11) & 1023, tb = ((w >> 21) & 1023) - 1;
+                return (1ull << dof_treeid[ta]) | (tb >= 0 ? (1ull << dof_treeid[tb]) : 0ull);
+              };
+              unsigned long long gmask = tmask(w0);
+              while (cnt < 16 && pos < nblk) {
+                const int p = pos + lane;
+                bool cand = false; int w = 0;
+                if (p < nblk) { w = info[p]; cand = w >= 0 && !(tmask(w) & gmask); }
+                const unsigned long long mk = __ballot(cand);
+                if (!mk) { pos += 64; continue; }
+                const int q = __ffsll((long long)mk) - 1;
+                const int wq = __builtin_amdgcn_readlane(w, q);
+                if (lane == 0) { info[pos + q] = wq | 0x80000000; s_order_i[k] = wq & 2047; }
+                gmask |= tmask(wq);
+                k++; cnt++; pos = pos + q + 1;
+                WSYNC();
+              }
+            } else
             while (cnt < 4 && pos < nblk) {
               const int p = pos + lane;
               bool cand = false; int w = 0;
@@ -1807,6 +1857,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             mc.nblk = nblk; mc.nfixblk = __builtin_amdgcn_readfirstlane(nfixblk); mc.rowW = rowW; mc.iterations = M.iterations;
             mc.has_dim4 = has_dim4; mc.scale = scale; mc.tolerance = M.tolerance;
             mc.noslip_iterations = M.noslip_iterations; mc.noslip_tolerance = M.noslip_tolerance;
+            mc.nwave = 1; mc.wid = 0; mc.red = nullptr;
             niter = pgs_many_body<DIAGM, EXTRA>(mc, lane);
           }
           WSYNC();
@@ -2250,11 +2301,12 @@ __global__ __launch_bounds__(1024) void mjh_order_kernel(const int* __restrict__
 // (pools + hand-over vectors), its LDS footprint is two dof vectors, so many environments are resident per CU while the
 // fused kernel holds ~70 KB per env for the stages around the sweeps.
 template <bool DIAGM, bool EXTRA>
-__global__ __launch_bounds__(64) void mjh_solve_kernel(const DConst* __restrict__ C, const DState S, int env0) {
+__global__ __launch_bounds__(256) void mjh_solve_kernel(const DConst* __restrict__ C, const DState S, int env0) {
   const DModel& M = C->M;
   const Lay& L = C->L;
   extern __shared__ float lds[];
-  const int lane = threadIdx.x, nv = M.nv;
+  // 64 threads (one wave per environment) or 64 x nwave (wide groups: the waves share the chunks of a group)
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, nv = M.nv;
   const int env = S.env_order ? S.env_order[env0 + blockIdx.x] : env0 + (int)blockIdx.x;
   float* const gs = S.gscratch + (size_t)env * (size_t)S.gstride;
   int* meta = (int*)(gs + L.g_meta);
@@ -2262,11 +2314,12 @@ __global__ __launch_bounds__(64) void mjh_solve_kernel(const DConst* __restrict_
   if (nblk == 0) return;                                  // unconstrained env: the assemble launch wrote qacc itself
   const int nv4 = ((nv + 3) / 4) * 4, ngrp = __builtin_amdgcn_readfirstlane(meta[6]);
   float* s_qacc = lds; float* s_minv = lds + nv4;
-  int* s_ord = (int*)(lds + 2 * nv4); int* s_gst = s_ord + nblk;          // visiting order, group starts (many-block models)
+  float* s_red = lds + 2 * nv4;                                               // per-wave partial sums (8 floats)
+  int* s_ord = (int*)(s_red + 8); int* s_gst = s_ord + nblk;                  // visiting order, group starts (many-block models)
   const int* g_ord = (const int*)(gs + (-1 - L.order)); const int* g_gst = (const int*)(gs + (-1 - L.sched));
-  for (int d = lane; d < nv; d += 64) { s_qacc[d] = gs[L.g_a0 + d]; s_minv[d] = gs[L.g_minv + d]; }
-  for (int i = lane; i < nblk; i += 64) s_ord[i] = g_ord[i];
-  if (nblk > 64) for (int i = lane; i <= ngrp; i += 64) s_gst[i] = g_gst[i];
+  for (int d = tid; d < nv; d += nthr) { s_qacc[d] = gs[L.g_a0 + d]; s_minv[d] = gs[L.g_minv + d]; }
+  for (int i = tid; i < nblk; i += nthr) s_ord[i] = g_ord[i];
+  if (nblk > 64) for (int i = tid; i <= ngrp; i += nthr) s_gst[i] = g_gst[i];
   __syncthreads();
   ManyCtx mc;
   mc.J = gs + (-1 - L.J); mc.B = gs + (-1 - L.B); mc.blkf = gs + (-1 - L.blkf); mc.blkq = gs + (-1 - L.blkq); mc.ext = gs + (-1 - L.ext);
@@ -2275,8 +2328,9 @@ __global__ __launch_bounds__(64) void mjh_solve_kernel(const DConst* __restrict_
   mc.nblk = nblk; mc.nfixblk = __builtin_amdgcn_readfirstlane(meta[1]); mc.rowW = M.rowW; mc.iterations = M.iterations;
   mc.has_dim4 = M.has_dim4 != 0; mc.scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1)); mc.tolerance = M.tolerance;
   mc.noslip_iterations = M.noslip_iterations; mc.noslip_tolerance = M.noslip_tolerance;
+  mc.nwave = nthr >> 6; mc.wid = tid >> 6; mc.red = s_red;
   const int niter = pgs_many_body<DIAGM, EXTRA>(mc, lane);
   __syncthreads();
-  for (int d = lane; d < nv; d += 64) gs[L.g_qacc + d] = s_qacc[d];
-  if (lane == 0) meta[5] = niter;
+  for (int d = tid; d < nv; d += nthr) gs[L.g_qacc + d] = s_qacc[d];
+  if (tid == 0) meta[5] = niter;
 }

@@ -1380,6 +1380,11 @@ static void block_trees(const orc_data* d, int row, int* t1, int* t2) {
  * 100 sweeps at tolerance 1e-8) the iterates differ, and tests/test_oracle_pinning.py measures by how much. */
 static int g_pgs_row_order = 0;
 void orc_set_pgs_row_order(int plain) { g_pgs_row_order = plain != 0; }
+static int m_group_max(const mjh_model* m) {
+  if (m->ntree > 64) return 4;
+  for (int t = 0; t < m->ntree; t++) if (m->tree_dofnum[t] > 8) return 4;
+  return 16;
+}
 static int pgs_order(const orc_data* d, int* order) {
   int nefc = d->nefc, nblk = 0;
   if (g_pgs_row_order) { for (int i = 0; i < nefc; i++) order[i] = i; return nefc; }
@@ -1394,9 +1399,11 @@ static int pgs_order(const orc_data* d, int* order) {
   }
   int k = 0;
   if (nblk > 64) {
-    /* many-block models (the device solves them four independent blocks at a time, one per 16-lane row of the wave):
-     * same two-tree-first sequence; a group = a block plus up to three later unvisited blocks of the sequence, each sharing
-     * no tree with any block already in the group (first fit) */
+    /* many-block models (the device solves them four independent blocks at a time, one per 16-lane row of a wave, on up to
+     * four waves): same two-tree-first sequence; a group = a block plus up to GMAX - 1 later unvisited blocks of the
+     * sequence, each sharing no tree with any block already in the group (first fit).  GMAX = 16 when the model has at most
+     * 64 kinematic trees of at most 8 dofs each (free-body piles: BASELINE config C2), else 4. */
+    int gmax = m_group_max(d->m);
     int* seq = (int*)malloc(sizeof(int) * (size_t)(nblk + 1));
     int ns = 0;
     for (int pass = 0; pass < 2; pass++)
@@ -1407,12 +1414,12 @@ static int pgs_order(const orc_data* d, int* order) {
     for (int ii = 0; ii < nblk; ii++) {
       int i = seq[ii];
       if (used[i]) continue;
-      int gt[8], ngt = 0, cnt = 1;
+      int gt[32], ngt = 0, cnt = 1;
       used[i] = 1;
       for (int r = 0; r < bnum[i]; r++) order[k++] = bstart[i] + r;
       if (bt1[i] >= 0) gt[ngt++] = bt1[i];
       if (bt2[i] >= 0) gt[ngt++] = bt2[i];
-      for (int jj = ii + 1; jj < nblk && cnt < 4; jj++) {
+      for (int jj = ii + 1; jj < nblk && cnt < gmax; jj++) {
         int j = seq[jj];
         if (used[j]) continue;
         int share = 0;
