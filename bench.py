@@ -54,12 +54,35 @@ class Workload:
     (mj_inverse every step, mj_hw_interface.cpp:61): the robot configs always pay it, as the reference does."""
     name = ""; label = ""; envs_per_gpu = 4096; settle_steps = 0; inverse = False; min_ncon = None
 
+    pack = 1          # environments per wavefront (mjh_model_replicate: sub-wave packing of small models); 1 = one wave per env
+
     def __init__(self, ms, args, rank, device, stream):
         self.ms = ms; self.args = args; self.rank = rank
-        self.nenv = args.envs_per_gpu or self.envs_per_gpu
+        self.nenv = args.envs_per_gpu or self.envs_per_gpu          # ENVIRONMENTS per GPU
+        if args.pack > 0:
+            self.pack = args.pack
+        if self.nenv % self.pack:
+            raise SystemExit(f"--envs-per-gpu {self.nenv} is not a multiple of the {self.pack} environments per wavefront")
+        self.rows = self.nenv // self.pack                          # engine rows = wavefronts
         self.env_offset = rank * self.nenv
         self.tab = None; self.step_count = 0
         self.build(device, stream)
+        if not hasattr(self, "base_model"):
+            self.base_model = self.model                            # the single-environment model (oracle, byte accounting)
+
+    def packed(self, base):
+        """the model the engine steps: `pack` independent instances of `base` per wavefront (row w = envs w*pack .. w*pack+pack-1)"""
+        self.base_model = base
+        return base.replicate(self.pack) if self.pack > 1 else base
+
+    def env_state(self, n):
+        """(qpos, qvel, warmstart, stats) of the first n ENVIRONMENTS"""
+        rows = -(-n // self.pack)
+        _, q, v, ws = self.eng.get_state(0, rows); st = self.eng.get_stats(0, rows)
+        bq, bv = self.base_model.nq, self.base_model.nv
+        st = np.repeat(st.astype(np.float64), self.pack, axis=0)[:n]
+        st[:, :2] /= self.pack                                       # (a wavefront's contact / row counts cover its `pack` environments)
+        return q.reshape(rows * self.pack, bq)[:n], v.reshape(rows * self.pack, bv)[:n], ws.reshape(rows * self.pack, bv)[:n], st
 
     # -- hooks
     def build(self, device, stream): raise NotImplementedError
@@ -114,24 +137,26 @@ class C2(S24):
 class C3(Workload):
     name = "c3"; envs_per_gpu = 8192; settle_steps = 200; inverse = True
     label = ("C3: 7-hinge Panda chain (limits of ridgeback_panda.xml:53-87), fixed base, gravcomp 1, computed-torque wrapper + mj_inverse, "
-             "PD ddq = 200 (q* - q) - 50 qd in the engine, targets U[limits] re-drawn every 200 steps")
+             "PD ddq = 200 (q* - q) - 50 qd in the engine, targets U[limits] re-drawn every 200 steps; four arms per wavefront (mjh_model_replicate)")
+
+    pack = 4          # four arms per wavefront (7 of 64 lanes busy otherwise): mjh_model_replicate, DESIGN.md §9
 
     def build(self, device, stream):
-        self.model = self.ms.scene("arm7", 1)
-        self.eng = self.ms.Engine(self.model, self.nenv, device=device, stream=stream)
+        self.model = self.packed(self.ms.scene("arm7", 1))
+        self.eng = self.ms.Engine(self.model, self.rows, device=device, stream=stream)
         self.eng.set_controlled_dofs(np.ones(self.model.nv, dtype=np.int32))
         self.rng = np.random.default_rng(0xC3 + self.rank)
-        self.lo, self.hi = self.model.array("jnt_range").reshape(-1, 2).T
+        self.lo, self.hi = self.base_model.array("jnt_range").reshape(-1, 2).T
         self.eng.set_pd_controller(200.0, 50.0)          # box.yaml:8 (integral term dropped, as SURVEY §8-d D3 states)
         self.target = None
 
     def before_step(self, k):
         if k % 200 == 0:
-            self.target = self.rng.uniform(self.lo, self.hi, size=(self.nenv, self.model.nv))
-            self.eng.set_pd_target(self.target)
+            self.target = self.rng.uniform(self.lo, self.hi, size=(self.nenv, self.base_model.nv))
+            self.eng.set_pd_target(self.target.reshape(self.rows, -1))
 
     def oracle_data(self, orc, i, state):
-        d = orc.OrcData(self.model.ptr)
+        d = orc.OrcData(self.base_model.ptr)
         d.ifield("controlled")[:] = 1
         d.set_pd(self.target[i], 200.0, 50.0)
         return d
@@ -142,13 +167,14 @@ class RobotFixture(Workload):
 
     def build(self, device, stream):
         from mujoco_sim_amd.tables import load_model_tables
-        self.model, self.z = load_model_tables(os.path.join(GOLD, f"robot_{self.fixture}.npz"))
-        self.eng = self.ms.Engine(self.model, self.nenv, device=device, stream=stream)
+        base, self.z = load_model_tables(os.path.join(GOLD, f"robot_{self.fixture}.npz"))
+        self.model = self.packed(base)
+        self.eng = self.ms.Engine(self.model, self.rows, device=device, stream=stream)
         self.controlled = self.z["controlled"].astype(np.int32)
-        self.eng.set_controlled_dofs(self.controlled)
+        self.eng.set_controlled_dofs(np.tile(self.controlled, self.pack))
 
     def oracle_data(self, orc, i, state):
-        d = orc.OrcData(self.model.ptr)
+        d = orc.OrcData(self.base_model.ptr)
         d.ifield("controlled")[:] = self.controlled
         return d
 
@@ -171,17 +197,20 @@ class C4(RobotFixture):
 
     def churn(self):
         """spawn_objects / destroy_objects (mj_ros.cpp:859-1507) as slot toggles + initial pose and twist (mj_ros.cpp:1406-1412)"""
-        e = self.eng
         t0 = time.perf_counter()
+        senv, sbody, spos, denv, dbody = [], [], [], [], []
         for i in self.rng.choice(self.nenv, max(1, self.nenv // 16), replace=False):
             off = np.nonzero(~self.active[i])[0]; on = np.nonzero(self.active[i])[0]
             if len(on) > 2:
-                k = int(self.rng.choice(on)); e.set_slot_active(self.slots[k], False, env0=int(i), n=1); self.active[i, k] = False
+                k = int(self.rng.choice(on)); denv.append(int(i)); dbody.append(self.slots[k]); self.active[i, k] = False
             if len(off):
                 k = int(self.rng.choice(off)); a = self.rng.uniform(-np.pi, np.pi); r = self.rng.uniform(0.8, 1.5)
-                e.set_slot_active(self.slots[k], True, env0=int(i), n=1)
-                e.set_body_pose(int(i), self.slots[k], [r * np.sin(a), r * np.cos(a), 2.0], [1, 0, 0, 0], [0, 0, 0, 0, 0, 0])
-                self.active[i, k] = True
+                senv.append(int(i)); sbody.append(self.slots[k]); spos.append([r * np.sin(a), r * np.cos(a), 2.0]); self.active[i, k] = True
+        # one service call each, as the reference's services take lists of objects (mj_ros.cpp:859-904,1430-1507)
+        if denv:
+            self.eng.destroy_objects(denv, dbody)
+        if senv:
+            self.eng.spawn_objects(senv, sbody, np.array(spos))
         self.service_s += time.perf_counter() - t0; self.service_calls += 1
 
     def before_step(self, k):
@@ -211,13 +240,16 @@ class C4(RobotFixture):
 class C5(RobotFixture):
     name = "c5"; envs_per_gpu = 4096; settle_steps = 100; fixture = "c5_pendulum_bowl_mesh"
     label = ("C5: multi_mujoco_sim.launch scene (pendulum.xml world + static bowl.xml, 37 mesh geoms), 32768 envs over 8 GPUs = 4096 per GPU, "
-             "mj_inverse every step, state all-gather at 60 Hz")
+             "mj_inverse every step, state all-gather at 60 Hz; two worlds per wavefront sharing the static bowl (mjh_model_replicate)")
+
+    pack = 2          # two pendulum worlds per wavefront, the static bowl shared (mjh_model_replicate)
 
     def build(self, device, stream):
         super().build(device, stream)
         rng = np.random.default_rng(0xC5 + self.rank)
         if "qvel0" in self.z and np.any(self.z["qvel0"]):      # per-env spin so that the envs differ
-            self.eng.set_state(qvel=self.z["qvel0"][None, :] * rng.uniform(0.5, 1.5, size=(self.nenv, 1)))
+            v = self.z["qvel0"][None, :] * rng.uniform(0.5, 1.5, size=(self.nenv, 1))
+            self.eng.set_state(qvel=v.reshape(self.rows, -1))
 
 
 WORKLOADS = {w.name: w for w in (S24, C2, C3, C4, C5)}
@@ -231,10 +263,8 @@ def cpu_baseline(w, sample_envs, budget_s, with_inverse):
     import orc
 
     L = orc.lib()
-    eng = w.eng
     sample_envs = min(sample_envs, w.nenv)
-    t, q, v, ws = eng.get_state(0, sample_envs)
-    st = eng.get_stats(0, sample_envs)
+    q, v, ws, st = w.env_state(sample_envs)
     ds = []
     for i in range(sample_envs):
         d = w.oracle_data(orc, i, None)
@@ -279,6 +309,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="0 = the config's size (S24/C2/C5 4096, C3 8192, C4 2048)")
     ap.add_argument("--with-inverse", type=int, default=-1, help="mj_inverse every step in the MAIN timed window (-1: the config's default; the other variant is timed in a second window)")
     ap.add_argument("--cohorts", type=int, default=-1, help="env cohorts stepped on separate HIP streams (-1: engine default)")
+    ap.add_argument("--pack", type=int, default=0, help="environments per wavefront for the small-model configs (0: the config's default — C3 4, C5 2, others 1)")
     ap.add_argument("--maxcon", type=int, default=0, help="override the scene's contact capacity per env; 0 = scene default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
@@ -315,8 +346,8 @@ def main():
         eng.set_cohorts(args.cohorts)
     main_inverse = w.inverse if args.with_inverse < 0 else bool(args.with_inverse)
     stride = eng.state_stride
-    pub = torch.empty(nenv * stride, dtype=torch.float32, device="cuda")
-    gathered = torch.empty(world * nenv * stride, dtype=torch.float32, device="cuda") if use_dist else None
+    pub = torch.empty(w.rows * stride, dtype=torch.float32, device="cuda")
+    gathered = torch.empty(world * w.rows * stride, dtype=torch.float32, device="cuda") if use_dist else None
     publish_every = max(1, int(round(1.0 / (60.0 * model.opt.timestep))))  # 60 Hz of simulated time
 
     def run(nsteps, inverse):
@@ -357,7 +388,7 @@ def main():
     total_envs = nenv * world
     value = total_envs * args.steps / elapsed
     cohorts = eng.cohorts
-    bytes_step = algorithmic_bytes_per_env_step(model.nq, model.nv)
+    bytes_step = algorithmic_bytes_per_env_step(w.base_model.nq, w.base_model.nv)
     envs_per_launch = nenv * args.steps / max(n_launches, 1)   # one launch = one step of one cohort
     achieved = bytes_step * envs_per_launch / (kernel_ms * 1e-3) / 1e9
 
@@ -381,7 +412,7 @@ def main():
                 traffic_src = f"profiles/{tj.get('tag', '?')} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this config, scaled to this run's envs per launch; not measured in this run)"
         except Exception:
             traffic = None
-    mean_ncon = float(st[:, 0].mean())
+    mean_ncon = float(st[:, 0].mean()) / w.pack
     unsettled = w.min_ncon is not None and mean_ncon < w.min_ncon
     key_inv, key_no = ("value", "value_without_inverse") if main_inverse else ("value_with_inverse", "value")
     out = {
@@ -391,8 +422,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": w.label, "name": w.name, "settle_steps": w.settle_steps, "envs_per_gpu": nenv, "envs_total": total_envs,
                    "steps_per_launch": 1, "cohorts": cohorts, "with_inverse": bool(main_inverse), "parallelism": f"env-sharded x{world}",
-                   "nq": int(model.nq), "nv": int(model.nv),
-                   "mean_ncon": mean_ncon, "max_ncon": int(st[:, 0].max()), "mean_nefc": float(st[:, 1].mean()),
+                   "envs_per_wavefront": w.pack, "nq": int(w.base_model.nq), "nv": int(w.base_model.nv),
+                   "mean_ncon": mean_ncon, "max_ncon": int(st[:, 0].max()), "mean_nefc": float(st[:, 1].mean()) / w.pack,
                    "max_nefc": int(st[:, 1].max()), "mean_solver_iter": float(st[:, 2].mean()),
                    "overflow_envs": int((st[:, 3] & 3 != 0).sum()), "reset_envs": int((st[:, 3] & 4 != 0).sum()),
                    "lds_bytes_per_env": eng.lds_bytes, "contact_capacity": int(model.maxcon), **w.extra_config()},

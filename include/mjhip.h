@@ -366,6 +366,11 @@ int mjh_reset(mjh_engine*, const int* env_ids, int n);
  * Toggleable are the last 32 bodies of the model (all of them, except the world, in a model of up to 32 bodies):
  * declare the object pool after the robot. */
 int mjh_set_slot_active(mjh_engine*, int env0, int n, int body, int active);
+/* the services take LISTS (mujoco_msgs SpawnObject.objects[] / DestroyObject.names[], mj_ros.cpp:859-904,1430-1507): one call,
+ * one upload and one small kernel for n (env, body) pairs — activate + pose (pos[n*3], quat[n*4] or NULL) + twist (vel[n*6] or
+ * NULL: linear world, angular body frame, as qvel of a free joint) / deactivate */
+int mjh_spawn_objects(mjh_engine*, int n, const int* env, const int* body, const double* pos, const double* quat, const double* vel);
+int mjh_destroy_objects(mjh_engine*, int n, const int* env, const int* body);
 /* initial pose / twist of a spawned free body (mj_ros.cpp:1406-1412) */
 int mjh_set_body_pose(mjh_engine*, int env, int body, const double pos[3], const double quat[4], const double vel[6]);
 

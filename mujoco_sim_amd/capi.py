@@ -181,6 +181,8 @@ SYMBOLS = [
     ("mjh_reset", C.c_int, [_vp, c_int_p, C.c_int]),
     ("mjh_set_slot_active", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     ("mjh_set_body_pose", C.c_int, [_vp, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p]),
+    ("mjh_spawn_objects", C.c_int, [_vp, C.c_int, c_int_p, c_int_p, c_double_p, c_double_p, c_double_p]),
+    ("mjh_destroy_objects", C.c_int, [_vp, C.c_int, c_int_p, c_int_p]),
     ("mjh_export_state_device", C.c_int, [_vp, _vp]),
     ("mjh_state_stride", C.c_int, [_vp]),
     ("mjh_mirror_create", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),

@@ -984,6 +984,62 @@ extern "C" int mjh_set_slot_active(mjh_engine* e, int env0, int n, int body, int
   HIPCHK(hipStreamSynchronize(e->stream));
   return MJH_OK;
 }
+// Batched spawn / destroy: the reference's services take a LIST of objects per call (spawn_objects / destroy_objects,
+// mj_ros.cpp:859-904,1430-1507); with many environments one call carries (env, body) pairs and the whole list goes to the device
+// in one upload + one small kernel instead of three copies and syncs per object.
+__global__ void mjh_slot_kernel(const DConst* __restrict__ C, const DState S, const int* __restrict__ env, const int* __restrict__ body,
+                                const float* __restrict__ pose /* [n][13] pos3 quat4 vel6, or null: destroy */, int n, int sbase,
+                                const int* __restrict__ qadr, const int* __restrict__ dadr) {
+  const DModel& M = C->M;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int e = env[i], b = body[i];
+  const unsigned bit = 1u << (b - sbase);
+  if (pose) {
+    atomicAnd(&S.slot_mask[e], ~bit);
+    const float* p = pose + 13 * (size_t)i;
+    float* q = S.qpos + (size_t)e * M.nqp + qadr[i]; float* v = S.qvel + (size_t)e * M.nvp + dadr[i];
+    for (int k = 0; k < 7; k++) q[k] = p[k];
+    for (int k = 0; k < 6; k++) v[k] = p[7 + k];
+  } else atomicOr(&S.slot_mask[e], bit);
+}
+static int slot_batch(mjh_engine* e, int n, const int* env, const int* body, const double* pos, const double* quat, const double* vel, bool spawn) {
+  if (n <= 0) return MJH_OK;
+  if (!env || !body || (spawn && !pos)) { mjh_set_error("mjh_spawn/destroy_objects: null argument"); return MJH_ERR_ARG; }
+  const mjh_model* m = e->model;
+  const int sbase = e->M.nbody > 32 ? e->M.nbody - 32 : 0;
+  std::vector<int> ib(4 * (size_t)n);     // env | body | qpos address | dof address
+  std::vector<float> fp(spawn ? 13 * (size_t)n : 0);
+  for (int i = 0; i < n; i++) {
+    const int b = body[i];
+    if (env[i] < 0 || env[i] >= e->nenv || b <= 0 || b >= m->nbody || b < sbase) { mjh_set_error("mjh_spawn/destroy_objects: env or body out of range (slots are the last 32 bodies)"); return MJH_ERR_ARG; }
+    ib[i] = env[i]; ib[n + i] = b;
+    if (spawn) {
+      if (m->body_jntnum[b] != 1 || m->jnt_type[m->body_jntadr[b]] != MJH_JNT_FREE) { mjh_set_error("mjh_spawn_objects: not a free body"); return MJH_ERR_ARG; }
+      ib[2 * (size_t)n + i] = m->jnt_qposadr[m->body_jntadr[b]]; ib[3 * (size_t)n + i] = m->body_dofadr[b];
+      float* p = &fp[13 * (size_t)i];
+      for (int k = 0; k < 3; k++) p[k] = (float)pos[3 * (size_t)i + k];
+      for (int k = 0; k < 4; k++) p[3 + k] = (float)(quat ? quat[4 * (size_t)i + k] : (k == 0));
+      for (int k = 0; k < 6; k++) p[7 + k] = (float)(vel ? vel[6 * (size_t)i + k] : 0.0);
+    }
+  }
+  if (!e->S.slot_mask) { int rc = dev_alloc(e, &e->S.slot_mask, (size_t)e->nenv); if (rc) return rc; }
+  DevBuf di, df;
+  HIPCHK(hipMalloc(&di.p, ib.size() * sizeof(int)));
+  HIPCHK(hipMemcpyAsync(di.p, ib.data(), ib.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  if (spawn) { HIPCHK(hipMalloc(&df.p, fp.size() * sizeof(float))); HIPCHK(hipMemcpyAsync(df.p, fp.data(), fp.size() * sizeof(float), hipMemcpyHostToDevice, e->stream)); }
+  const int* d = (const int*)di.p;
+  hipLaunchKernelGGL(mjh_slot_kernel, dim3((n + 127) / 128), dim3(128), 0, e->stream, e->dC, e->S, d, d + n, (const float*)df.p, n, sbase, d + 2 * (size_t)n, d + 3 * (size_t)n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(e->stream));      // (the temporaries are freed on return)
+  return MJH_OK;
+}
+extern "C" int mjh_spawn_objects(mjh_engine* e, int n, const int* env, const int* body, const double* pos, const double* quat, const double* vel) {
+  ENG(e); return slot_batch(e, n, env, body, pos, quat, vel, true);
+}
+extern "C" int mjh_destroy_objects(mjh_engine* e, int n, const int* env, const int* body) {
+  ENG(e); return slot_batch(e, n, env, body, nullptr, nullptr, nullptr, false);
+}
 // pose + twist of one free body of one env (initial state of a spawned object, mj_ros.cpp:1406-1412)
 extern "C" int mjh_set_body_pose(mjh_engine* e, int env, int body, const double pos[3], const double quat[4], const double vel[6]) {
   ENG(e); RANGE(e, env, 1);

@@ -282,6 +282,16 @@ class Engine:
         n = self.nenv - env0 if n is None else n
         _chk(self.lib, self.lib.mjh_set_slot_active(self.h, env0, n, body, int(active)), "mjh_set_slot_active")
 
+    def spawn_objects(self, envs, bodies, pos, quat=None, vel=None):
+        """batched spawn service: n (env, body) pairs, pose [n,3] / [n,4] and twist [n,6] in one call"""
+        ev = np.ascontiguousarray(envs, dtype=np.int32); bd = np.ascontiguousarray(bodies, dtype=np.int32)
+        a = [None if x is None else np.ascontiguousarray(x, dtype=np.float64) for x in (pos, quat, vel)]
+        _chk(self.lib, self.lib.mjh_spawn_objects(self.h, len(ev), capi.iptr(ev), capi.iptr(bd), *[capi.dptr(x) for x in a]), "mjh_spawn_objects")
+
+    def destroy_objects(self, envs, bodies):
+        ev = np.ascontiguousarray(envs, dtype=np.int32); bd = np.ascontiguousarray(bodies, dtype=np.int32)
+        _chk(self.lib, self.lib.mjh_destroy_objects(self.h, len(ev), capi.iptr(ev), capi.iptr(bd)), "mjh_destroy_objects")
+
     def set_body_pose(self, env, body, pos, quat=None, vel=None):
         a = [None if x is None else np.ascontiguousarray(x, dtype=np.float64) for x in (pos, quat, vel)]
         _chk(self.lib, self.lib.mjh_set_body_pose(self.h, env, body, *[capi.dptr(x) for x in a]), "mjh_set_body_pose")

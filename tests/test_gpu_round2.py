@@ -516,3 +516,27 @@ def test_xfrc_applied_survives_a_model_change_and_zero_xfrc_changes_nothing(lib)
     b.step(1); c.step(1)
     assert np.array_equal(b.get_state()[1], c.get_state()[1])
     a.close(); b.close(); c.close()
+
+
+def test_batched_spawn_destroy_equals_the_per_object_calls():
+    """mjh_spawn_objects / mjh_destroy_objects (one call per service request, lists of (env, body)) leave exactly the state the
+    per-object mjh_set_slot_active + mjh_set_body_pose calls do"""
+    m = ms.scene("s24")
+    a = ms.Engine(m, 32); a.load_s24(); b = ms.Engine(m, 32); b.load_s24()
+    rng = np.random.default_rng(9)
+    a.step(40); b.step(40)
+    envs = rng.choice(32, 12, replace=False); bodies = rng.integers(1, 5, 12)
+    a.destroy_objects(envs, bodies)
+    for e_, b_ in zip(envs, bodies):
+        b.set_slot_active(int(b_), False, env0=int(e_), n=1)
+    a.step(30); b.step(30)
+    pos = rng.uniform(-0.05, 0.05, (12, 3)) + np.array([0, 0, 1.2]); quat = rng.normal(size=(12, 4)); quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    vel = rng.normal(size=(12, 6)) * 0.3
+    a.spawn_objects(envs, bodies, pos, quat, vel)
+    for k, (e_, b_) in enumerate(zip(envs, bodies)):
+        b.set_slot_active(int(b_), True, env0=int(e_), n=1); b.set_body_pose(int(e_), int(b_), pos[k], quat[k], vel[k])
+    a.step(60); b.step(60)
+    for x, y in zip(a.get_state(), b.get_state()):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a.get_stats(), b.get_stats())
+    a.close(); b.close()
