@@ -89,6 +89,34 @@ def test_both_orders_converge_to_the_same_solution_when_allowed_to():
         L.orc_set_pgs_row_order(0)
 
 
+def test_pgs_at_the_default_cap_against_the_converged_dual_solution_is_measured():
+    """The reference's models name no solver, so MuJoCo runs Newton on them: to solver precision, the OPTIMUM of the convex problem
+    PGS iterates on.  This engine (and the oracle) solve it with PGS at MuJoCo's default cap of 100 sweeps / tolerance 1e-8, which
+    does not converge on settled S24 piles (250-870 sweeps are needed at tolerance 1e-13).  Measured over 10 envs from identical
+    settled states (tools: /tmp study recorded in DESIGN.md §6): 1-step |d qacc| up to 0.5 m/s^2, 150-step |d qpos| up to 1.2e-2,
+    median 1.9e-4.  Asserted on 3 envs with margins; part of the stated tolerance."""
+    m = ms.scene("s24")
+    N = 3
+    tab = m.s24_randomize(0, N)
+    it0, tol0 = m.c.opt.iterations, m.c.opt.tolerance
+    worst_acc = worst_pos = 0.0; sweeps = []
+    try:
+        for i in range(N):
+            s = oracle_s24(m, tab, i); s.step(400)
+            a, b = _clone(m, tab, i, s), _clone(m, tab, i, s)
+            for k in range(150):
+                m.c.opt.iterations, m.c.opt.tolerance = it0, tol0; a.step(1)
+                m.c.opt.iterations, m.c.opt.tolerance = 4000, 1e-13; b.step(1)
+                if k == 0:
+                    worst_acc = max(worst_acc, float(np.abs(a.f("qacc") - b.f("qacc")).max())); sweeps.append(b.i("solver_iter"))
+            worst_pos = max(worst_pos, float(np.abs(a.f("qpos") - b.f("qpos")).max()))
+    finally:
+        m.c.opt.iterations, m.c.opt.tolerance = it0, tol0
+    print(f"PGS at the cap vs converged: 1-step |d qacc| {worst_acc:.3e}, 150-step |d qpos| {worst_pos:.3e}, sweeps to converge {sweeps}")
+    assert max(sweeps) > 100                      # the premise: the default cap ends the iteration early
+    assert worst_acc < 2.0 and worst_pos < 5e-2
+
+
 # ----------------------------------------------------------------------------- 2. the model compiler, independently
 def _quat2mat(q):
     w, x, y, z = q
