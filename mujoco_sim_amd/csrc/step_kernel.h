@@ -315,7 +315,10 @@ struct ManyCtx {
   int nblk, nfixblk, rowW, iterations; bool has_dim4; float scale, tolerance;
   int noslip_iterations; float noslip_tolerance;     // noslip post-pass (EXTRA instances only)
   int nwave, wid; float* red;                        // mjh_solve_kernel with wide groups: waves per environment, this wave, LDS partial sums
+  bool order_packed;    // the LDS copy of the order carries block | kind << 16 | ndof << 20: the fetch skips what the block does not have
 };
+// LDS order word of block b with header hd (kind: BK_*, ndof: dofs of the one or two trees it touches)
+#define MJH_ORDER_WORD(b, hd) ((b) | (((hd).x & 15) << 16) | (((((unsigned)(hd).z) >> 16) + ((((unsigned)(hd).w) >> 16))) << 20))
 template <bool DIAGM, bool EXTRA>
 DEV int pgs_many_body(const ManyCtx& c, const int lane) {
   int niter = 0, nmain = 0;
@@ -334,7 +337,7 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
   // operands of one block; every address follows from the block index alone (contact blocks are laid out
   // regularly behind the c.nfixblk non-contact ones), so all loads of block k+1 are in flight while block k is solved
   struct MOp { int4 hd; int b; float4 J, B, p0, r0, r1, r2, A0, A1, A2, A3, X0, X1, X2; };
-  auto blockAt = [&](int k) __attribute__((always_inline)) { return c.order[k]; };   // visiting order (LDS copy)
+  auto blockAt = [&](int k) __attribute__((always_inline)) { return c.order_packed ? (c.order[k] & 0xffff) : c.order[k]; };   // visiting order (LDS copy)
   auto fetch8 = [&](int b) __attribute__((always_inline)) {
     MOp op; op.b = b; op.hd = ((const int4*)c.blki)[b];
     const bool quad = b >= c.nfixblk;
@@ -393,19 +396,23 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
       QOp op;
       const int st = c.gstart[g] + 4 * c4, sz = c.gstart[g + 1] - st;       // sz <= 0: this wave has no chunk in this group
       const bool act = row < sz;
-      const int b = c.order[act ? st + row : c.gstart[g]];
+      const int ow = c.order[act ? st + row : c.gstart[g]];
+      const int b = c.order_packed ? (ow & 0xffff) : ow;
+      // what the block has (packed order word) bounds what is fetched: the condim-4 extension for condim-4 blocks only, the
+      // Jacobian for the block's own dofs only (a box-floor contact touches 6 of the 12 row slots)
+      const int okind = c.order_packed ? ((ow >> 16) & 15) : BK_PYR4, ondof = c.order_packed ? (ow >> 20) : c.rowW;
       op.b = b; op.act = act ? 1.0f : 0.0f; op.hd = ((const int4*)c.blki)[b];
       const bool quad = b >= c.nfixblk;
       const int jo = (quad ? c.nfixblk + 4 * (b - c.nfixblk) : b) * c.rowW;
       op.J = make_float4(0, 0, 0, 0); op.B = op.J;
-      if (l < c.rowW) {
+      if (l < ondof && act) {
         if (quad) op.J = *(const float4*)(c.J + jo + 4*l); else op.J.x = c.J[jo + l];
         if (!DIAGM) { if (quad) op.B = *(const float4*)(c.B + jo + 4*l); else op.B.x = c.B[jo + l]; }
       }
       op.p0 = ((const float4*)c.blkf)[4*b]; op.r0 = ((const float4*)c.blkf)[4*b+1]; op.r1 = ((const float4*)c.blkf)[4*b+2]; op.r2 = ((const float4*)c.blkf)[4*b+3];
       op.A0 = ((const float4*)c.blkq)[4*b]; op.A1 = ((const float4*)c.blkq)[4*b+1]; op.A2 = ((const float4*)c.blkq)[4*b+2]; op.A3 = ((const float4*)c.blkq)[4*b+3];
       op.X0 = make_float4(0, 0, 0, 0); op.X1 = op.X0; op.X2 = op.X0;
-      if (c.has_dim4) { const float4* x4 = (const float4*)(c.ext + b * SOLX_N); op.X0 = x4[0]; op.X1 = x4[1]; op.X2 = x4[2]; }
+      if (c.has_dim4 && okind == BK_PYR4 && act) { const float4* x4 = (const float4*)(c.ext + b * SOLX_N); op.X0 = x4[0]; op.X1 = x4[1]; op.X2 = x4[2]; }
       return op;
     };
     auto processQ = [&](QOp& op, float& impl) __attribute__((always_inline)) {
@@ -1845,13 +1852,13 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             ManyCtx mc;
             mc.J = s_J; mc.B = s_B; mc.blkf = s_blkf; mc.blkq = s_blkq; mc.ext = s_ext; mc.blki = s_blki_i;
             // visiting order and group starts: LDS copies in the (dead) position-stage arrays when they fit
-            mc.order = s_order_i; mc.gstart = s_sched_i; mc.ngrp = ngrp;
+            mc.order = s_order_i; mc.gstart = s_sched_i; mc.ngrp = ngrp; mc.order_packed = false;
             if (nblk + ngrp + 2 <= M.k1_floats) {
               int* ol = (int*)(lds + M.scratch_off); int* gl = ol + nblk;
-              for (int i = lane; i < nblk; i += 64) ol[i] = s_order_i[i];
+              for (int i = lane; i < nblk; i += 64) { const int b = s_order_i[i]; const int4 hd = ((const int4*)s_blki_i)[b]; ol[i] = MJH_ORDER_WORD(b, hd); }
               if (nblk > 64) for (int i = lane; i <= ngrp; i += 64) gl[i] = s_sched_i[i];
               WSYNC();
-              mc.order = ol; mc.gstart = gl;
+              mc.order = ol; mc.gstart = gl; mc.order_packed = true;
             }
             mc.qacc = s_qacc; mc.qLDinv = s_qLDinv;
             mc.nblk = nblk; mc.nfixblk = __builtin_amdgcn_readfirstlane(nfixblk); mc.rowW = rowW; mc.iterations = M.iterations;
@@ -2318,12 +2325,15 @@ __global__ __launch_bounds__(256) void mjh_solve_kernel(const DConst* __restrict
   int* s_ord = (int*)(s_red + 8); int* s_gst = s_ord + nblk;                  // visiting order, group starts (many-block models)
   const int* g_ord = (const int*)(gs + (-1 - L.order)); const int* g_gst = (const int*)(gs + (-1 - L.sched));
   for (int d = tid; d < nv; d += nthr) { s_qacc[d] = gs[L.g_a0 + d]; s_minv[d] = gs[L.g_minv + d]; }
-  for (int i = tid; i < nblk; i += nthr) s_ord[i] = g_ord[i];
+  {
+    const int4* g_hd = (const int4*)(gs + (-1 - L.blki));
+    for (int i = tid; i < nblk; i += nthr) { const int b = g_ord[i]; const int4 hd = g_hd[b]; s_ord[i] = MJH_ORDER_WORD(b, hd); }
+  }
   if (nblk > 64) for (int i = tid; i <= ngrp; i += nthr) s_gst[i] = g_gst[i];
   __syncthreads();
   ManyCtx mc;
   mc.J = gs + (-1 - L.J); mc.B = gs + (-1 - L.B); mc.blkf = gs + (-1 - L.blkf); mc.blkq = gs + (-1 - L.blkq); mc.ext = gs + (-1 - L.ext);
-  mc.blki = (const int*)(gs + (-1 - L.blki)); mc.order = s_ord; mc.gstart = s_gst; mc.ngrp = ngrp;
+  mc.blki = (const int*)(gs + (-1 - L.blki)); mc.order = s_ord; mc.gstart = s_gst; mc.ngrp = ngrp; mc.order_packed = true;
   mc.qacc = s_qacc; mc.qLDinv = s_minv;
   mc.nblk = nblk; mc.nfixblk = __builtin_amdgcn_readfirstlane(meta[1]); mc.rowW = M.rowW; mc.iterations = M.iterations;
   mc.has_dim4 = M.has_dim4 != 0; mc.scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1)); mc.tolerance = M.tolerance;
