@@ -311,6 +311,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="0 = the config's size (S24/C2/C5 4096, C3 8192, C4 2048)")
     ap.add_argument("--with-inverse", type=int, default=-1, help="mj_inverse every step in the MAIN timed window (-1: the config's default; the other variant is timed in a second window)")
     ap.add_argument("--cohorts", type=int, default=-1, help="env cohorts stepped on separate HIP streams (-1: engine default)")
+    ap.add_argument("--timing-stride", type=int, default=5, help="bracket every N-th step launch with HIP events (roofline.kernel_ms is their mean)")
     ap.add_argument("--pack", type=int, default=0, help="environments per wavefront for the small-model configs (0: the config's default — C3 4, C5 2, others 1)")
     ap.add_argument("--maxcon", type=int, default=0, help="override the scene's contact capacity per env; 0 = scene default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -365,7 +366,9 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
-        eng.set_launch_timing(True)   # HIP events around every step launch on the stream it is launched on (cohort streams)
+        # HIP events around step launches on the stream they are launched on (cohort streams); a sample of one launch in
+        # `--timing-stride` so that the event pairs do not slow launch-bound configs down (C5: 34 M with every launch timed)
+        eng.set_launch_timing(max(1, args.timing_stride))
         t0 = time.perf_counter()
         run(nsteps, inverse)
         torch.cuda.synchronize()
@@ -377,9 +380,9 @@ def main():
             tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-        kernel_ms, n_launches = eng.get_launch_timing()
+        kernel_ms, n_timed = eng.get_launch_timing()
         eng.set_launch_timing(False)
-        return elapsed, kernel_ms, n_launches
+        return elapsed, kernel_ms, n_timed
 
     # 1. the config's fixed settle phase — NOT --warmup: whatever the driver passes, the timed window steps the settled scene
     run(w.settle_steps, main_inverse)
@@ -391,7 +394,9 @@ def main():
     value = total_envs * args.steps / elapsed
     cohorts = eng.cohorts
     bytes_step = algorithmic_bytes_per_env_step(w.base_model.nq, w.base_model.nv)
-    envs_per_launch = nenv * args.steps / max(n_launches, 1)   # one launch = one step of one cohort
+    G = cohorts if (cohorts > 1 and w.rows >= 64 * cohorts) else 1      # the engine's rule (engine.hip: mjh_step)
+    envs_per_launch = nenv / G                                          # one launch = one step of one cohort
+    n_timed, n_launches = n_launches, args.steps * G
     achieved = bytes_step * envs_per_launch / (kernel_ms * 1e-3) / 1e9
 
     # 4. the other mj_inverse variant, same K steps (the reference always pays mj_inverse,
@@ -432,7 +437,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "mjh_step_kernel" + (" (+ mjh_solve_kernel: three-launch step of the many-body layout)" if eng.lds_bytes > 24 * 1024 or model.nv > 64 else ""),
-                     "kernel_ms": kernel_ms, "launches": n_launches, "envs_per_launch": envs_per_launch, "concurrent_launches": cohorts,
+                     "kernel_ms": kernel_ms, "launches": n_launches, "launches_timed": n_timed, "envs_per_launch": envs_per_launch, "concurrent_launches": cohorts,
                      "algorithmic_bytes_per_env_step": bytes_step,
                      "valu_issue_busy": valu_busy, "valu_issue_busy_source": traffic_src,
                      "note": "fused per-env pipeline keeps intermediates in LDS: the path is issue/latency bound, far below the HBM roofline by design (DESIGN.md §4)"},

@@ -426,8 +426,9 @@ double mjh_get_timestep(const mjh_engine*);
 void mjh_set_layout_policy(int policy);
 int mjh_set_cohorts(mjh_engine*, int n);
 int mjh_get_cohorts(const mjh_engine*);
-/* HIP-event timing of every step-kernel launch on the stream it runs on: enable, step, then read the mean
- * duration [ms] and the number of launches since the last read (bench.py's roofline leg). */
+/* HIP-event timing of the step-kernel launches on the stream they run on: enable (on = 1: every launch, on = N > 1: every
+ * N-th launch — the event pairs cost stream time of their own, visible in launch-bound configs), step, then read the mean
+ * duration [ms] and the number of launches timed since the last read (bench.py's roofline leg). */
 int mjh_set_launch_timing(mjh_engine*, int on);
 int mjh_get_launch_timing(mjh_engine*, double* mean_ms, int* count);
 

@@ -67,7 +67,7 @@ struct mjh_engine {
   hipEvent_t ev_fork = nullptr, ev_join[MJH_MAX_COHORTS] = {nullptr};
   bool forked = false;
   // optional per-launch timing of the step kernels (mjh_set_launch_timing)
-  bool timing = false;
+  bool timing = false; int timing_stride = 1; long timing_count = 0;   // every timing_stride-th step launch is bracketed
   std::vector<std::pair<hipEvent_t, hipEvent_t>> tev; size_t tev_used = 0;
   bool step1_done = false;
   // in-engine joint-space PD effort controller (mjh_set_pd_controller): ddq written on the device in front of every step
@@ -534,7 +534,7 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
         hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, st, (const int*)e->S.stats, e->d_order, g0, g1 - g0);
       if (e->pd_on) { rc = launch_pd(e, st, g0, g1 - g0); if (rc) break; }
       hipEvent_t ta = nullptr, tb = nullptr;
-      if (e->timing) {
+      if (e->timing && (e->timing_count++ % e->timing_stride) == 0) {
         if (e->tev_used == e->tev.size()) { hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); e->tev.push_back({a, b}); }
         ta = e->tev[e->tev_used].first; tb = e->tev[e->tev_used].second; e->tev_used++;
         HIPCHK(hipEventRecord(ta, st));
@@ -567,7 +567,9 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
   return rc;
 }
 // Per-launch timing of the step kernels with HIP events on the streams they are launched on (bench.py's roofline leg).
-extern "C" int mjh_set_launch_timing(mjh_engine* e, int on) { ENG(e); e->timing = on != 0; e->tev_used = 0; return MJH_OK; }
+// on = 1: every step launch; on = N > 1: every N-th one (a sample: the event pairs themselves cost several microseconds of
+// stream time per launch, which shows in launch-bound configs)
+extern "C" int mjh_set_launch_timing(mjh_engine* e, int on) { ENG(e); e->timing = on != 0; e->timing_stride = on > 1 ? on : 1; e->timing_count = 0; e->tev_used = 0; return MJH_OK; }
 extern "C" int mjh_get_launch_timing(mjh_engine* e, double* mean_ms, int* count) {
   ENG(e);
   HIPCHK(hipStreamSynchronize(e->stream));

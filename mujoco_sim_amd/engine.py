@@ -142,7 +142,7 @@ class Engine:
     def set_cohorts(self, n): _chk(self.lib, self.lib.mjh_set_cohorts(self.h, int(n)), "mjh_set_cohorts")
     @property
     def cohorts(self): return self.lib.mjh_get_cohorts(self.h)
-    def set_launch_timing(self, on=True): _chk(self.lib, self.lib.mjh_set_launch_timing(self.h, int(on)), "mjh_set_launch_timing")
+    def set_launch_timing(self, on=True): _chk(self.lib, self.lib.mjh_set_launch_timing(self.h, int(on)), "mjh_set_launch_timing")   # N > 1: every N-th launch
     def get_launch_timing(self):
         """-> (mean step-kernel duration [ms], launches) since the last call"""
         ms_, cnt = C.c_double(0), C.c_int(0)
