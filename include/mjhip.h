@@ -222,6 +222,19 @@ mjh_model* mjh_load_mjcf_file(const char* path);
  * (MjSim::init, mj_sim.cpp:573-710).  <option> comes from the first file; names must be unique across files. */
 mjh_model* mjh_load_mjcf_files(const char* const* paths, int n);
 const char* mjh_load_note(void);
+/* The loader options of ONE call (what MjSim::init_tmp reads from rosparams and writes into the files before mj_loadXML): the
+ * mjh_load_set_* functions below keep per-THREAD settings for all later loads; this variant takes them as an argument and
+ * leaves the thread's settings untouched. */
+typedef struct mjh_load_options {
+  double boundmass, boundinertia;   /* floor for <compiler boundmass boundinertia>: the reference writes 1e-6 / 1e-6 (mj_sim.cpp:584-590) */
+  int robot_gravcomp;               /* ~disable_gravity: -1 keep the files' values, 0 / 1 written on every robot body (mj_sim.cpp:301-310) */
+  int load_meshes;                  /* 1: mesh assets are read and collide as hulls; 0: mesh geoms are dropped (and noted) */
+  unsigned odom_joints;             /* ~add_odom_joints mask: bits 0..5 = lin x y z, ang x y z (mj_sim.cpp:337-415) */
+  int nrobot_pose;                  /* ~pose_init entries (mj_sim.cpp:312-335): root body names and x y z roll pitch yaw each */
+  const char* const* robot_pose_body; const double* robot_pose;
+} mjh_load_options;
+void mjh_load_default_options(mjh_load_options*);
+mjh_model* mjh_load_mjcf_files_opt(const char* const* paths, int n, const mjh_load_options* options);
 /* 1 (default): <asset><mesh> files are read and mesh geoms collide as convex hulls; 0: mesh geoms are dropped (and
  * listed in mjh_load_note), which leaves the primitive collision geometry only */
 void mjh_load_set_mesh_mode(int mode);
@@ -237,7 +250,7 @@ void mjh_load_set_odom_joints(unsigned mask);
 /* rosparam ~pose_init (mj_sim.cpp:312-335): position and roll / pitch / yaw (radians, tf2 setRPY) written onto the root body
  * of a robot file, by body name; pose NULL removes the entry, root_body NULL removes all */
 void mjh_load_set_robot_pose(const char* root_body, const double pose[6]);
-/* process-wide floor for <compiler boundmass boundinertia> of every file loaded afterwards: the reference writes
+/* per-thread floor for <compiler boundmass boundinertia> of every file loaded afterwards: the reference writes
  * 1e-6 / 1e-6 into each file before mj_loadXML (mj_sim.cpp:584-590) */
 void mjh_load_set_bounds(double boundmass, double boundinertia);
 

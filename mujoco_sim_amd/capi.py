@@ -101,6 +101,11 @@ class Model(C.Structure):
 
 Model_p = C.POINTER(Model)
 
+class LoadOptions(C.Structure):
+    _fields_ = [("boundmass", C.c_double), ("boundinertia", C.c_double), ("robot_gravcomp", C.c_int), ("load_meshes", C.c_int),
+                ("odom_joints", C.c_uint), ("nrobot_pose", C.c_int), ("robot_pose_body", C.POINTER(C.c_char_p)), ("robot_pose", c_double_p)]
+
+
 # every symbol include/mjhip.h declares: (name, restype, argtypes)
 _vp = C.c_void_p
 SYMBOLS = [
@@ -137,6 +142,8 @@ SYMBOLS = [
     ("mjh_load_mjcf_file", Model_p, [C.c_char_p]),
     ("mjh_load_mjcf_files", Model_p, [C.POINTER(C.c_char_p), C.c_int]),
     ("mjh_load_note", C.c_char_p, []),
+    ("mjh_load_default_options", None, [C.POINTER(LoadOptions)]),
+    ("mjh_load_mjcf_files_opt", Model_p, [C.POINTER(C.c_char_p), C.c_int, C.POINTER(LoadOptions)]),
     ("mjh_load_set_bounds", None, [C.c_double, C.c_double]),
     ("mjh_load_set_mesh_mode", None, [C.c_int]),
     ("mjh_load_set_robot_gravcomp", None, [C.c_int]),

@@ -100,11 +100,13 @@ struct Defaults {
 
 // floor applied to every file loaded afterwards: MjSim::init() writes boundmass = boundinertia = 1e-6 into the <compiler>
 // element of whatever it loads (mj_sim.cpp:584-590)
-static double g_boundmass = 0, g_boundinertia = 0;
-static int g_robot_gravcomp = -1;   // mjh_load_set_robot_gravcomp: -1 keep the files' values, 0 / 1 force it on every robot body
-static std::map<std::string, std::array<double, 6>> g_robot_pose;   // mjh_load_set_robot_pose: root body name -> x y z roll pitch yaw
-static unsigned g_odom_mask = 0;      // mjh_load_set_odom_joints: bits 0..5 = lin x y z, ang x y z
-static int g_load_meshes = 1;   // mjh_load_set_mesh_mode: 0 = skip mesh assets (their geoms are reported and dropped)
+// (thread_local: the options of one thread's loads never leak into another thread's; mjh_load_mjcf_files_opt takes them per
+// call and leaves the thread's settings as it found them)
+static thread_local double g_boundmass = 0, g_boundinertia = 0;
+static thread_local int g_robot_gravcomp = -1;   // mjh_load_set_robot_gravcomp: -1 keep the files' values, 0 / 1 force it on every robot body
+static thread_local std::map<std::string, std::array<double, 6>> g_robot_pose;   // mjh_load_set_robot_pose: root body name -> x y z roll pitch yaw
+static thread_local unsigned g_odom_mask = 0;      // mjh_load_set_odom_joints: bits 0..5 = lin x y z, ang x y z
+static thread_local int g_load_meshes = 1;   // mjh_load_set_mesh_mode: 0 = skip mesh assets (their geoms are reported and dropped)
 
 struct Loader {
   mjh_builder* b = nullptr;
@@ -497,6 +499,26 @@ extern "C" mjh_model* mjh_load_mjcf_files(const char* const* paths, int n) {
   mjh_model* m = L.finish();
   g_note = L.note;
   return m;
+}
+// the same with the options of THIS call only (the rosparams MjSim::init_tmp reads: mj_sim.cpp:301-415,584-590)
+extern "C" mjh_model* mjh_load_mjcf_files_opt(const char* const* paths, int n, const mjh_load_options* o) {
+  if (!o) return mjh_load_mjcf_files(paths, n);
+  const double sb = g_boundmass, si = g_boundinertia; const int sg = g_robot_gravcomp, sm = g_load_meshes; const unsigned so = g_odom_mask;
+  const auto sp = g_robot_pose;
+  g_boundmass = o->boundmass; g_boundinertia = o->boundinertia; g_robot_gravcomp = o->robot_gravcomp < 0 ? -1 : (o->robot_gravcomp ? 1 : 0);
+  g_load_meshes = o->load_meshes != 0; g_odom_mask = o->odom_joints & 63u;
+  g_robot_pose.clear();
+  for (int k = 0; k < o->nrobot_pose; k++) if (o->robot_pose_body && o->robot_pose_body[k] && o->robot_pose) {
+    std::array<double, 6> a; for (int q = 0; q < 6; q++) a[q] = o->robot_pose[6 * k + q];
+    g_robot_pose[o->robot_pose_body[k]] = a;
+  }
+  mjh_model* m = mjh_load_mjcf_files(paths, n);
+  g_boundmass = sb; g_boundinertia = si; g_robot_gravcomp = sg; g_load_meshes = sm; g_odom_mask = so; g_robot_pose = sp;
+  return m;
+}
+extern "C" void mjh_load_default_options(mjh_load_options* o) {
+  if (!o) return;
+  o->boundmass = 0; o->boundinertia = 0; o->robot_gravcomp = -1; o->load_meshes = 1; o->odom_joints = 0; o->nrobot_pose = 0; o->robot_pose_body = nullptr; o->robot_pose = nullptr;
 }
 extern "C" const char* mjh_load_note(void) { return g_note.c_str(); }
 extern "C" void mjh_load_set_bounds(double boundmass, double boundinertia) { g_boundmass = boundmass; g_boundinertia = boundinertia; }

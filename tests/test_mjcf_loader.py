@@ -277,3 +277,24 @@ def test_robot_pose_init(tmp_path, lib):
         lib.mjh_load_set_robot_pose(None, None)
     np.testing.assert_allclose(Rotation.from_quat([x, y, z, w]).as_matrix(), Rotation.from_euler("xyz", rpy).as_matrix(), atol=1e-12)   # extrinsic xyz = fixed-axis RPY
     np.testing.assert_allclose(ms.load_mjcf(paths=paths).array("qpos0")[:3], [9, 9, 9])
+
+
+def test_per_call_load_options_do_not_leak_into_later_loads(tmp_path):
+    """mjh_load_mjcf_files_opt: the rosparams of MjSim::init_tmp as an argument of ONE load (boundmass / boundinertia, gravcomp on
+    robot bodies, odom joints): a plain load afterwards sees the defaults again"""
+    import ctypes as C
+    import mujoco_sim_amd as ms
+    from mujoco_sim_amd import capi
+    lib = capi.load()
+    world = tmp_path / "w.xml"; robot = tmp_path / "r.xml"
+    world.write_text('<mujoco><worldbody><geom type="plane" size="0 0 0.05"/></worldbody></mujoco>')
+    robot.write_text('<mujoco><worldbody><body name="base" pos="0 0 0.5"><joint name="j" type="hinge" axis="0 1 0"/>'
+                     '<inertial pos="0 0 0" mass="1e-3" diaginertia="1e-4 1e-4 1e-4"/></body></worldbody></mujoco>')
+    paths = (C.c_char_p * 2)(str(world).encode(), str(robot).encode())
+    o = capi.LoadOptions(); lib.mjh_load_default_options(C.byref(o))
+    o.boundmass = 1e-2; o.boundinertia = 1e-3; o.robot_gravcomp = 1; o.odom_joints = 0b100011          # lin x, lin y, yaw
+    m = ms.Model(lib.mjh_load_mjcf_files_opt(paths, 2, C.byref(o)), lib)
+    assert m.array("body_mass")[1] == 1e-2 and m.array("body_inertia")[3] == 1e-3 and m.array("body_gravcomp")[1] == 1 and m.njnt == 4
+    assert m.name2id(1, "base_ang_odom_z_joint") >= 0
+    m2 = ms.load_mjcf(paths=[str(world), str(robot)])                         # the thread's settings were left alone
+    assert m2.array("body_mass")[1] == 1e-3 and m2.array("body_gravcomp")[1] == 0 and m2.njnt == 1
