@@ -155,6 +155,6 @@ int main() {
   run_kind<K_PERMLANE16_SWAP>(dout, dticks, ncu); run_kind<K_PERMLANE32_SWAP>(dout, dticks, ncu);
   run_kind<K_CNDMASK>(dout, dticks, ncu); run_kind<K_MED3>(dout, dticks, ncu);
   run_kind<K_DS_READ_B128>(dout, dticks, ncu); run_kind<K_DS_READ_B32>(dout, dticks, ncu); run_kind<K_RCP>(dout, dticks, ncu); run_kind<K_MIX_SOLVER>(dout, dticks, ncu);
-  run_kind<K_READLANE>(dout, dticks, ncu);
+  // (the v_readlane + s_add variant does not terminate on this box and is left out)
   return 0;
 }
