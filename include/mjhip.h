@@ -496,6 +496,10 @@ int mjh_host_run_realtime(mjh_engine*, int env, const double* target, double kp,
 int mjh_nenv(const mjh_engine*);
 const mjh_model* mjh_engine_model(const mjh_engine*);
 int mjh_lds_bytes(const mjh_engine*);  /* dynamic LDS per env (= per workgroup) */
+/* Gauss-Seidel visiting order of the engine's solver sweeps (any order is a valid mj_solPGS iteration; they agree at
+ * convergence): 0 = independent pairs / groups of constraint blocks, 1 = contact patches (small free-body models: up to 16
+ * rows between the same two bodies are solved as one unit, mujoco_sim_amd/csrc/patch_pgs.h). */
+int mjh_solver_order(const mjh_engine*);
 int mjh_query_lds_bytes(const mjh_model*); /* same figure without a device: capacity planning (160 KiB per CU) */
 const char* mjh_last_error(void);
 const char* mjh_version(void);

@@ -41,6 +41,10 @@ struct DModel {
   int group_max;     // Gauss-Seidel groups of many-block models hold up to 4 or 16 mutually independent blocks (16: <= 64 trees of <= 8 dofs)
   int scratch_off;   // many-body layout: LDS scratch of k1_floats floats (the dead position-stage arrays; an own region when sensors keep them alive)
   int o_site_bodyid, o_site_pos, o_site_quat, o_sensor_type, o_sensor_objid, o_body_mocapid, o_eq_type;
+  // contact-patch sweep (patch_pgs.h; small free-body models): LDS float offsets of the patch pool (it reuses everything that
+  // is dead once the solver starts, from the position-stage arrays to the base-row storage), its size, and of the two live
+  // tables next to it: one descriptor per patch, one descriptor per (step, 16-lane row) of the sweep schedule
+  int patch, pool, pool_floats, pdesc, pslot;
 };
 
 // per-env state in HBM (fp32, env-major rows)

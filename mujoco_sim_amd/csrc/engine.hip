@@ -285,9 +285,19 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     long long jsz = std::max<long long>((long long)(M.maxblk - M.maxcon) * rowW + (long long)M.maxcon * rowW * 4, 4);
     const long long need = (long long)nstage * RAW_STRIDE;            // raw-contact staging aliases J (+B)
     if ((diagM ? 1 : 2) * jsz < need) jsz = diagM ? need : (need + 1) / 2;
+    // contact-patch sweep (patch_pgs.h): free bodies only, no noslip pass, pools in LDS, at most 64 contacts (the patch builder
+    // keeps one contact per lane).  Same rule as the oracle's patch order (oracle/mjh_oracle.c: m_patch_order).
+    const bool patch = diagM && !big && nv <= 32 && M.noslip_iterations == 0 && M.maxcon <= 64 && !keep;
+    M.patch = patch ? 1 : 0;
     L.qpos = put(m->nq);
     L.qvel = put(nv); L.qvref = put(nv); L.ws = put(nv); L.qacc = put(nv); L.smooth = put(nv); L.asmooth = put(nv); L.passive = put(nv);
     L.bias = put(nv); L.applied = put(nv); L.tmpv = put(nv); L.tmpv2 = put(nv);
+    if (patch) {   // what the sweep still needs sits in front of the span the patch pool takes over
+      L.qM = put(m->nM); L.qLD = L.qM; L.qLDinv = put(nv); L.dofpar = 0; L.dofMadr = 0; L.anc = 0;
+      L.p_gsize = put(3*ng); L.p_rbound = put(ng); L.p_mass = put(nb); L.p_inertia = put(3*nb);
+      L.zero = put(4);
+      M.pdesc = put(M.maxcon); M.pslot = put(4 * M.maxcon);
+    }
     // K1: frames, composite inertias, joint anchors/axes and geom poses are dead once the position stage, CRBA and the
     // collision stage are done; the solver's per-base scratch vectors (bv, phi: first used by the velocity stage) reuse them
     const int k1 = off;
@@ -298,10 +308,12 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     M.scratch_off = (big && keep) ? put(k1_size) : k1;
     L.xipos = put(3*nb); L.com = put(3*nb); L.cinert = put(10*nb); L.cdof = put(6*nv);
     const int k2_size = off - k1;   // ... and all of these are dead when the solver sweeps run: the X extension of condim-4 models
-    L.qM = put(m->nM); L.qLD = diagM ? L.qM : put(m->nM); L.qLDinv = put(nv);   // diagonal M: no factor storage
-    if (diagM) { L.dofpar = 0; L.dofMadr = 0; L.anc = 0; }   // free-body models read the shared chain-walk tables (step_kernel.h)
-    else { L.dofpar = put(nv); L.dofMadr = put(nv); L.anc = put(m->nM); }
-    L.p_gsize = put(3*ng); L.p_rbound = put(ng); L.p_mass = put(nb); L.p_inertia = put(3*nb);
+    if (!patch) {
+      L.qM = put(m->nM); L.qLD = diagM ? L.qM : put(m->nM); L.qLDinv = put(nv);   // diagonal M: no factor storage
+      if (diagM) { L.dofpar = 0; L.dofMadr = 0; L.anc = 0; }   // free-body models read the shared chain-walk tables (step_kernel.h)
+      else { L.dofpar = put(nv); L.dofMadr = put(nv); L.anc = put(m->nM); }
+      L.p_gsize = put(3*ng); L.p_rbound = put(ng); L.p_mass = put(nb); L.p_inertia = put(3*nb);
+    }
     {  // the contact records die once the blocks are built; the velocity-stage spatial vectors reuse their space
       const int a4 = [](int n) { return ((std::max(n, 1) + 3) / 4) * 4; }(6*nb);
       const int velsz = 4 * a4 + ((6*nv + 3) / 4) * 4;
@@ -330,7 +342,14 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       L.ext = (extsz <= k2_size && !keep) ? k1 : put(extsz);
       L.J = put((int)jsz); L.B = diagM ? L.J : put((int)jsz);
     }
-    L.zero = put(4);
+    if (patch) {
+      // the pool: per patch of nr4 rows (a multiple of 4, at most 16)  12 nr4 (rows of J) + 5 nr4 (f, aref, R, 1/AR_rr, AR_rr/2)
+      // + 16 floats per 4x4 tile of the lower triangle of AR: 21 .. 27 floats per row.  Sized for two thirds of the row
+      // capacity at 27 floats per row (S24: 4336 floats against a largest observed need of 2880); patches beyond it are
+      // dropped with the capacity flag, like contacts beyond maxcon
+      M.pool = k1; M.pool_floats = std::max(off - k1, 18 * M.maxefc + 16);
+      off = k1 + M.pool_floats;
+    } else L.zero = put(4);
     L.site = m->nsite > 0 ? put(12 * m->nsite) : 0;        // world frame of every site: pos(3) + rotation(9)
     L.fext = m->nsensor > 0 ? put(6 * nb) : 0;             // external spatial force per body (mj_rnePostConstraint)
     if (big) {   // hand-over vectors of the three-launch step (non-negative offsets into the scratch slice)
@@ -355,6 +374,9 @@ static void derive_fitting(const mjh_model* m, HostPack& hp) {
   int policy = g_layout_policy;
   if (const char* fb = getenv("MJH_FORCE_BIG")) policy = atoi(fb) ? 2 : 1;
   const int limit = policy == 1 ? 160 * 1024 : (policy == 2 ? 0 : MJH_LDS_RESIDENT_MAX);
+  // (models on the contact-patch sweep stay LDS-resident under the default policy: their visiting order is the patch order,
+  //  which the many-body layout does not have; mjh_solver_order() tells which one an engine runs)
+  if (hp.M.patch && policy == 0 && hp.lds_bytes <= 64 * 1024) return;
   if ((hp.lds_bytes > 160 * 1024 || hp.lds_bytes > limit) && !hp.M.big && hp.M.rowW <= 64) { HostPack big; derive_device_model(m, big, true); hp = big; }
 }
 
@@ -1212,4 +1234,5 @@ extern "C" int mjh_debug_stop_at(mjh_engine* e, int stage, int with_inverse) {
 extern "C" int mjh_nenv(const mjh_engine* e) { return e ? e->nenv : 0; }
 extern "C" const mjh_model* mjh_engine_model(const mjh_engine* e) { return e ? e->model : nullptr; }
 extern "C" int mjh_lds_bytes(const mjh_engine* e) { return e ? e->lds_bytes : 0; }
+extern "C" int mjh_solver_order(const mjh_engine* e) { return e && e->M.patch ? 1 : 0; }
 extern "C" const char* mjh_version(void) { return "mjhip 0.1 (gfx950)"; }

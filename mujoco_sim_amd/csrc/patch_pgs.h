@@ -1,0 +1,328 @@
+// patch_pgs.h — contact-patch Gauss-Seidel for small free-body models (mj_solPGS, reached from mj_step2,
+// /root/reference/src/mj_main.cpp:108).  Used by the LDS-resident kernels of models whose trees are all single free bodies
+// (DModel::patch; BASELINE's 24-DoF scene is one).
+//
+// A patch = up to 16 constraint rows (whole contacts) between the SAME one or two bodies.  Its rows sit one per lane on a
+// 16-lane row of the wavefront, so a wave updates up to four mutually independent patches per step.  The coupling of the
+// rows inside a patch is precomputed (AR = J M^-1 J^T + R, 16 x 16, strictly lower triangle): one Gauss-Seidel row update is
+// then three instructions for all lanes,
+//     delta_q = max(-res_q / AR_qq, -f_q)          res_q <- res_q + AR_qr * delta_r   (v_fmac_f32_dpp row_newbcast:r)
+// instead of a cross-lane reduction per contact: a lane's residual only ever receives the updates of EARLIER rows (the later
+// columns of its AR row are stored as zeros), so once row q has been visited lane q keeps recomputing the same delta_q and the
+// value left after the last row is the Gauss-Seidel update of every row.  The patches talk to each other through the running
+// acceleration only (matrix-free, as before): u = J a before the rows, a += M^-1 J^T delta after them.
+//
+// Everything is kept in the scaled coordinates  a^ = M^1/2 a,  J^ = J M^-1/2  (M is diagonal here), so that neither product
+// needs 1/M_dd:  u = J^ a^,  a^ += J^T delta.
+//
+// Visiting order (shared with the oracle, oracle/mjh_oracle.c: pgs_order): contacts sorted by (couples two bodies first, body
+// pair, constraint order); a patch = a maximal run of contacts of one body pair with at most 16 rows; a step = a patch plus up
+// to three later unvisited patches of the sequence that share no body with the step (first fit); rows in order inside a patch.
+#pragma once
+
+// descriptor of a patch: pool offset / 4 | (rows / 4) << 13 | first dof of body A << 16 | first dof of body B (63: none) << 21
+#define PD_OFF(d) (((d) & 0x1fff) << 2)
+#define PD_N4(d) (((d) >> 13) & 7)
+#define PD_DA(d) (((d) >> 16) & 31)
+#define PD_DB(d) (((d) >> 21) & 63)
+// layout of a patch of nr4 rows inside the pool (floats):  J^ [3][nr4][4] | (f, aref, R, 1/AR_qq) [nr4][4] | AR_qq / 2 [nr4] |
+// 4 x 4 tiles (i, c <= i) of the strictly lower triangle of AR, [tile][q & 3][4]
+#define PP_PAR(nr4) (12 * (nr4))
+#define PP_HALF(nr4) (16 * (nr4))
+#define PP_TILES(nr4) (17 * (nr4))
+#define PP_SIZE(n4) (68 * (n4) + 8 * (n4) * ((n4) + 1))
+
+// acc += y * (x of lane R of this lane's 16-lane row).  The _H form waits out the VALU-write -> DPP-read hazard of x.
+#define PP_FMAC_BC(acc, x, y, R) asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #R " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y))
+#define PP_FMAC_BC_H(acc, x, y, R) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:" #R " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y))
+#define PP_BC12(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
+#define PP_BC16(M) PP_BC12(M) M(12) M(13) M(14) M(15)
+
+struct PatchArgs {
+  float* lds;                    // dynamic LDS base
+  int pool, pool_floats, pdesc, pslot, zero, ahat;   // float offsets: pool, the two live tables, 4 zero floats, the acceleration [nv]
+  const int* blki; const float* blkf; const float* J; const float* qLDinv;   // block tables (inside the pool span: consumed first)
+  int nblk, nv, maxcon;
+};
+
+// Groups the contact blocks into patches, schedules the patches into steps, and converts the blocks' base rows / parameters /
+// forces into the pool (which overwrites them: everything is staged through registers first).  Returns the number of steps.
+DEV int patch_build(const PatchArgs& A, const int lane, int& flags) {
+  const int nblk = A.nblk, maxcon = A.maxcon;
+  int* s_word = (int*)(A.lds + A.pool);       // [maxcon] block words in patch order
+  int* s_pinfo = s_word + maxcon;             // [maxcon] per patch
+  int* s_rowmap = s_pinfo + maxcon;           // [min(256, 9 maxcon)] pool row -> block | row << 6 | patch << 10 | row in patch << 16 (bit 30: padding row)
+  int* s_pdesc = (int*)(A.lds + A.pdesc);
+  int* s_pslot = (int*)(A.lds + A.pslot);
+  const int4* blki4 = (const int4*)A.blki;
+  // ---- patch order: (single-body contacts last, body pair, constraint order)
+  int word = 0x7fffffff;
+  if (lane < nblk) {
+    const int4 hd = blki4[lane];
+    const int a1 = hd.z & 0xffff, a2 = hd.w & 0xffff; const bool two = (hd.w >> 16) != 0;
+    const int dA = two ? min(a1, a2) : a1, dB = two ? max(a1, a2) : 63;
+    word = ((((two ? 0 : 1) << 11) | (dA << 6) | dB) << 10) | (lane << 4) | ((hd.x >> 4) & 15);
+  }
+  int rank = 0;
+  for (int i = 0; i < nblk; i++) rank += __builtin_amdgcn_readlane(word, i) < word;
+  if (lane < nblk) s_word[rank] = word;
+  WSYNC();
+  const int w = lane < nblk ? s_word[lane] : 0;   // lanes = positions of the sequence from here on
+  int np = -1, rows = 0, ck = -1, mypatch = -1, myrow0 = 0;
+  for (int p = 0; p < nblk; p++) {
+    const int wp = __builtin_amdgcn_readlane(w, p), k = wp >> 10, n = wp & 15;
+    if (k != ck || rows + n > 16) { np++; rows = 0; ck = k; }
+    if (lane == p) { mypatch = np; myrow0 = rows; }
+    rows += n;
+  }
+  int npatch = np + 1;
+  const int myn = w & 15;
+  {
+    const int nxt = __shfl_down(mypatch, 1);
+    if (lane < nblk && (lane == nblk - 1 || nxt != mypatch)) s_pinfo[mypatch] = (myrow0 + myn) | ((w >> 10) << 8);
+  }
+  WSYNC();
+  // ---- lanes = patches: rows, pool offsets, descriptors
+  const int pinfo = lane < npatch ? s_pinfo[lane] : 0;
+  const int pnr = pinfo & 255, pn4 = (pnr + 3) >> 2, pkey = pinfo >> 8;
+  const int pdA = (pkey >> 6) & 31, pdB = pkey & 63;
+  const int psize = lane < npatch ? PP_SIZE(pn4) : 0;
+  const int pend = wave_incl_scan_i(psize, lane);
+  const int prowend = wave_incl_scan_i(lane < npatch ? 4 * pn4 : 0, lane);
+  {   // patches that do not fit the pool (or the 256 rows staged below) are dropped with their contacts: capacity flag
+    const unsigned long long ok = __ballot(lane < npatch && pend <= A.pool_floats && prowend <= 256);
+    const int nfit = __popcll(ok);
+    if (nfit < npatch) { flags |= 2; npatch = nfit; }
+  }
+  const int desc = lane < npatch ? (((pend - psize) >> 2) | (pn4 << 13) | (pdA << 16) | (pdB << 21)) : 0;
+  const int tmask = lane < npatch ? ((1 << (pdA / 6)) | (pdB != 63 ? (1 << (pdB / 6)) : 0)) : 0;
+  const int prow0 = prowend - 4 * pn4;
+  const int tot4 = min(__shfl(prowend, 63), 256);
+  for (int g = lane; g < tot4; g += 64) s_rowmap[g] = -1;     // (rows of dropped patches stay unmapped)
+  WSYNC();
+  if (lane < npatch) { s_pdesc[lane] = desc; s_pinfo[lane] = prow0; }
+  if (lane < npatch) for (int qq = pnr; qq < 4 * pn4; qq++) s_rowmap[prow0 + qq] = (1 << 30) | (lane << 10) | (qq << 16);   // (kept patches end within 256 rows)
+  WSYNC();
+  if (lane < nblk && mypatch < npatch) {
+    const int base = s_pinfo[mypatch] + myrow0, b = (w >> 4) & 63;
+    for (int r = 0; r < myn; r++) s_rowmap[base + r] = b | (r << 6) | (mypatch << 10) | ((myrow0 + r) << 16);
+  }
+  // ---- steps: a patch plus up to three later unvisited patches that share no body with the step
+  int nstep = 0;
+  {
+    unsigned long long used = 0;
+    for (int i = 0; i < npatch; i++) {
+      if ((used >> i) & 1ull) continue;
+      used |= 1ull << i;
+      int gmask = __builtin_amdgcn_readlane(tmask, i), cnt = 1;
+      const int di = __builtin_amdgcn_readlane(desc, i);
+      if (lane == 0) s_pslot[4 * nstep] = di;
+      while (cnt < 4) {
+        const bool cand = lane < npatch && lane > i && !((used >> lane) & 1ull) && !(tmask & gmask);
+        const unsigned long long bal = __ballot(cand);
+        if (!bal) break;
+        const int q = __ffsll((long long)bal) - 1;
+        used |= 1ull << q; gmask |= __builtin_amdgcn_readlane(tmask, q);
+        const int dq = __builtin_amdgcn_readlane(desc, q);
+        if (lane == 0) s_pslot[4 * nstep + cnt] = dq;
+        cnt++;
+      }
+      if (lane == 0) for (int c = cnt; c < 4; c++) s_pslot[4 * nstep + c] = 0;
+      nstep++;
+    }
+  }
+  WSYNC();
+  // ---- stage every pool row in registers: the pool overwrites the tables it is built from
+  float jr[4][12], pr[4][3]; int mm[4];
+#pragma unroll
+  for (int ps = 0; ps < 4; ps++) {
+    mm[ps] = -1;
+#pragma unroll
+    for (int k = 0; k < 12; k++) jr[ps][k] = 0;
+    pr[ps][0] = 0; pr[ps][1] = 0; pr[ps][2] = 0;
+    const int g = ps * 64 + lane;
+    if (ps * 64 < tot4 && g < tot4) {
+      const int m = s_rowmap[g];
+      mm[ps] = m;
+      if (!(m & (1 << 30)) && ((m >> 10) & 63) < npatch) {
+        const int b = m & 63, r = (m >> 6) & 15;
+        const int4 hd = blki4[b];
+        const int a1 = hd.z & 0xffff, a2 = hd.w & 0xffff; const bool two = (hd.w >> 16) != 0, sw = two && a1 > a2;
+        const bool single = ((hd.x >> 4) & 15) == 1;
+        const int kk = 1 + (r >> 1); const float c = (r & 1) ? -1.0f : 1.0f;
+        const float* Jb = A.J + BLK_JOFF(hd.x);
+        const int dA = sw ? a2 : a1, dB = sw ? a1 : a2;
+#pragma unroll
+        for (int kp = 0; kp < 12; kp++) {
+          if (kp >= 6 && !two) continue;
+          const int k = sw ? (kp < 6 ? kp + 6 : kp - 6) : kp;
+          const float4 jb = *(const float4*)(Jb + 4 * k);
+          const float v = single ? jb.x : jb.x + c * (kk == 1 ? jb.y : (kk == 2 ? jb.z : jb.w));
+          jr[ps][kp] = v * sqrtf(A.qLDinv[kp < 6 ? dA + kp : dB + kp - 6]);
+        }
+        const float* bf = A.blkf + b * BLKF_STRIDE;
+        pr[ps][0] = bf[BF_F + r]; pr[ps][1] = single ? bf[BF_AREF] : bf[BF_AREF] + c * bf[BF_AREF + kk]; pr[ps][2] = bf[0];
+      }
+    }
+  }
+  WSYNC();
+  float* const pool = A.lds + A.pool;
+#pragma unroll
+  for (int ps = 0; ps < 4; ps++) {
+    const int m = mm[ps];
+    if (m < 0 || ((m >> 10) & 63) >= npatch) continue;
+    const int d = s_pdesc[(m >> 10) & 63], q = (m >> 16) & 15, nr4 = PD_N4(d) << 2;
+    float* P = pool + PD_OFF(d);
+    *(float4*)(P + 4 * q) = make_float4(jr[ps][0], jr[ps][1], jr[ps][2], jr[ps][3]);
+    *(float4*)(P + 4 * (nr4 + q)) = make_float4(jr[ps][4], jr[ps][5], jr[ps][6], jr[ps][7]);
+    *(float4*)(P + 4 * (2 * nr4 + q)) = make_float4(jr[ps][8], jr[ps][9], jr[ps][10], jr[ps][11]);
+    *(float4*)(P + PP_PAR(nr4) + 4 * q) = make_float4(pr[ps][0], pr[ps][1], pr[ps][2], 0.0f);
+    P[PP_HALF(nr4) + q] = 0.0f;
+  }
+  WSYNC();
+  // ---- AR = J^ J^T + R of every patch, four patches at a time (lanes = rows): strictly lower triangle in 4 x 4 tiles
+  const int rho = lane >> 4, q = lane & 15, ti = q >> 2;
+  const float* zero = A.lds + A.zero;
+  for (int p0 = 0; p0 < npatch; p0 += 4) {
+    const int pt = p0 + rho;
+    const int d = pt < npatch ? s_pdesc[pt] : 0, nr4 = PD_N4(d) << 2;
+    const bool on = q < nr4;
+    float* P = pool + PD_OFF(d);
+    const float4 j0 = *(const float4*)(on ? P + 4 * q : zero), j1 = *(const float4*)(on ? P + 4 * (nr4 + q) : zero), j2 = *(const float4*)(on ? P + 4 * (2 * nr4 + q) : zero);
+    const float R = *(on ? P + PP_PAR(nr4) + 4 * q + 2 : zero);
+    float Jv[12] = {j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w, j2.x, j2.y, j2.z, j2.w};
+    asm volatile("" : "+v"(Jv[0]), "+v"(Jv[1]), "+v"(Jv[2]), "+v"(Jv[3]), "+v"(Jv[4]), "+v"(Jv[5]));
+    asm volatile("" : "+v"(Jv[6]), "+v"(Jv[7]), "+v"(Jv[8]), "+v"(Jv[9]), "+v"(Jv[10]), "+v"(Jv[11]));
+    int nmax = max(max(__builtin_amdgcn_readlane(nr4, 0), __builtin_amdgcn_readlane(nr4, 16)), max(__builtin_amdgcn_readlane(nr4, 32), __builtin_amdgcn_readlane(nr4, 48)));
+    float acc[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) acc[s] = 0;
+    asm volatile("s_nop 1");
+#define PP_ACC(s) if (s < nmax) { PP_FMAC_BC(acc[s], Jv[0], Jv[0], s); PP_FMAC_BC(acc[s], Jv[1], Jv[1], s); PP_FMAC_BC(acc[s], Jv[2], Jv[2], s); PP_FMAC_BC(acc[s], Jv[3], Jv[3], s); \
+                                PP_FMAC_BC(acc[s], Jv[4], Jv[4], s); PP_FMAC_BC(acc[s], Jv[5], Jv[5], s); PP_FMAC_BC(acc[s], Jv[6], Jv[6], s); PP_FMAC_BC(acc[s], Jv[7], Jv[7], s); \
+                                PP_FMAC_BC(acc[s], Jv[8], Jv[8], s); PP_FMAC_BC(acc[s], Jv[9], Jv[9], s); PP_FMAC_BC(acc[s], Jv[10], Jv[10], s); PP_FMAC_BC(acc[s], Jv[11], Jv[11], s); }
+    PP_BC16(PP_ACC)
+#undef PP_ACC
+    float diag = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) diag += Jv[k] * Jv[k];
+    const float ARqq = diag + R;
+    if (on) {
+      P[PP_PAR(nr4) + 4 * q + 3] = ARqq < MJ_MINVAL ? 0.0f : 1.0f / ARqq;
+      P[PP_HALF(nr4) + q] = 0.5f * ARqq;
+      float* T = P + PP_TILES(nr4) + ((ti * (ti + 1)) >> 1) * 16 + (q & 3) * 4;
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+        if (c <= ti) *(float4*)(T + 16 * c) = make_float4(4*c < q ? acc[4*c] : 0.0f, 4*c + 1 < q ? acc[4*c + 1] : 0.0f, 4*c + 2 < q ? acc[4*c + 2] : 0.0f, 4*c + 3 < q ? acc[4*c + 3] : 0.0f);
+    }
+  }
+  WSYNC();
+  return nstep;
+}
+
+// four rows r0 .. r0+3 of the sweep: delta = max(-res / AR_qq, -f), res += AR_q,r * delta_r
+#define PP_ROW(r, ar) "v_mul_f32 %[t], %[res], %[ninv]\n\tv_max_f32 %[d], %[t], %[nf]\n\ts_nop 1\n\tv_fmac_f32_dpp %[res], %[d], " ar " row_newbcast:" #r " row_mask:0xf bank_mask:0xf\n\t"
+#define PP_ROWS4(r0, r1, r2, r3, T) asm volatile(PP_ROW(r0, "%[a0]") PP_ROW(r1, "%[a1]") PP_ROW(r2, "%[a2]") PP_ROW(r3, "%[a3]") \
+    : [res] "+v"(res), [d] "=&v"(dl), [t] "=&v"(tt) : [ninv] "v"(ninv), [nf] "v"(nf), [a0] "v"(T.x), [a1] "v"(T.y), [a2] "v"(T.z), [a3] "v"(T.w))
+
+struct PatchOps { float4 J0, J1, J2, P, A0, A1, A2, A3; float half; float* pf; const float* pa; float* padd; int nr4; };
+
+// The sweeps.  A.ahat holds a^ = M^1/2 a on entry and on exit.  Returns the number of sweeps.
+DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const int itmax, const float tol, const float scale) {
+  const int rho = lane >> 4, q = lane & 15, ti = q >> 2;
+  const int* s_pslot = (const int*)(A.lds + A.pslot);
+  float* const pool = A.lds + A.pool;
+  float* const zero = A.lds + A.zero;
+  float* const ahat = A.lds + A.ahat;
+  auto load = [&](const int t) __attribute__((always_inline)) {
+    PatchOps o;
+    const int d = s_pslot[4 * t + rho];
+    const int nr4 = PD_N4(d) << 2, dA = PD_DA(d), dB = PD_DB(d);
+    const bool on = q < nr4;
+    float* P = pool + PD_OFF(d);
+    o.J0 = *(const float4*)(on ? P + 4 * q : zero);
+    o.J1 = *(const float4*)(on ? P + 4 * (nr4 + q) : zero);
+    o.J2 = *(const float4*)(on ? P + 4 * (2 * nr4 + q) : zero);
+    o.pf = on ? P + PP_PAR(nr4) + 4 * q : zero;
+    o.P = *(const float4*)o.pf;
+    o.half = *(on ? P + PP_HALF(nr4) + q : zero);
+    const float* T = P + PP_TILES(nr4) + ((ti * (ti + 1)) >> 1) * 16 + (q & 3) * 4;
+    o.A0 = *(const float4*)(on ? T : zero);
+    o.A1 = *(const float4*)((on && ti >= 1) ? T + 16 : zero);
+    o.A2 = *(const float4*)((on && ti >= 2) ? T + 32 : zero);
+    o.A3 = *(const float4*)((on && ti >= 3) ? T + 48 : zero);
+    // lanes 0..11 of the row carry the dofs of body A, then B, for u = J^ a^; lanes 0..3 add the four dof triples of a^ += J^T delta
+    o.pa = q < 6 ? ahat + dA + q : ((q < 12 && dB != 63) ? ahat + dB + q - 6 : zero);
+    o.padd = ahat + (((q & 1) && dB != 63) ? dB : dA) + ((q & 2) ? 3 : 0);
+    o.nr4 = nr4;
+    return o;
+  };
+  auto solve = [&](PatchOps& o, float& impl) __attribute__((always_inline)) {
+    const float Jv[12] = {o.J0.x, o.J0.y, o.J0.z, o.J0.w, o.J1.x, o.J1.y, o.J1.z, o.J1.w, o.J2.x, o.J2.y, o.J2.z, o.J2.w};
+    const int nmax = max(max(__builtin_amdgcn_readlane(o.nr4, 0), __builtin_amdgcn_readlane(o.nr4, 16)), max(__builtin_amdgcn_readlane(o.nr4, 32), __builtin_amdgcn_readlane(o.nr4, 48)));
+    float al = *o.pa;
+    float u = 0;
+    asm volatile("s_nop 1" :: "v"(al));
+#define PP_U(k) PP_FMAC_BC(u, al, Jv[k], k);
+    PP_BC12(PP_U)
+#undef PP_U
+    const float f = o.P.x, ninv = -o.P.w, nf = -f;
+    float res = (u - o.P.y) + o.P.z * f, dl, tt;
+    PP_ROWS4(0, 1, 2, 3, o.A0);
+    if (nmax > 4) {
+      PP_ROWS4(4, 5, 6, 7, o.A1);
+      if (nmax > 8) {
+        PP_ROWS4(8, 9, 10, 11, o.A2);
+        if (nmax > 12) PP_ROWS4(12, 13, 14, 15, o.A3);
+      }
+    }
+    dl = fmaxf(res * ninv, nf);          // every lane's own update (its residual is final: header comment)
+    *o.pf = f + dl;
+    impl -= dl * (res + o.half * dl);
+    // a^ += J^T delta: 12 sums over the 16 lanes of the row, folded while they are reduced (lane q & 3 ends up with three of them)
+    float p[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) p[k] = Jv[k] * dl;
+    float ra[6], rb[3];
+    const bool odd = q & 1, up = q & 2;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const float keep = odd ? p[k + 6] : p[k], send = odd ? p[k] : p[k + 6];
+      ra[k] = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float keep = up ? ra[k + 3] : ra[k], send = up ? ra[k] : ra[k + 3];
+      rb[k] = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { MJH_DPP_ADD(rb[k], 0x124, 0xf, true); }   // row_ror:4
+#pragma unroll
+    for (int k = 0; k < 3; k++) { MJH_DPP_ADD(rb[k], 0x128, 0xf, true); }   // row_ror:8
+    if (q < 4) { atomicAdd(o.padd, rb[0]); atomicAdd(o.padd + 1, rb[1]); atomicAdd(o.padd + 2, rb[2]); }
+  };
+  int niter = 0;
+  if (nstep == 1) {
+    for (int it = 0; it < itmax; it++) {
+      float impl = 0;
+      PatchOps o = load(0);
+      solve(o, impl);
+      niter = it + 1;
+      if (wave_sum<4>(impl) * scale < tol) break;
+    }
+    return niter;
+  }
+  // two or more steps: the operands of the next step are in flight while this one is solved (a patch is written only in its own step)
+  PatchOps nxt = load(0);
+  for (int it = 0; it < itmax; it++) {
+    float impl = 0;
+    for (int t = 0; t < nstep; t++) {
+      PatchOps cur = nxt;
+      nxt = load(t + 1 < nstep ? t + 1 : 0);
+      solve(cur, impl);
+    }
+    niter = it + 1;
+    if (wave_sum<4>(impl) * scale < tol) break;
+  }
+  return niter;
+}

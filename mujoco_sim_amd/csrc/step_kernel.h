@@ -531,6 +531,8 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
 // EXTRA: the model has a pair for the generic convex narrow phase (cylinder-x, capsule-box, ellipsoid-x, mesh geoms) or
 // asks for noslip sweeps; a separate instantiation so that models without either (S24, box piles, the robots'
 // primitive geometry) keep their code size and register allocation
+#include "patch_pgs.h"
+
 template <int NROW, bool DIAGM, bool EXTRA>
 __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restrict__ C, const DState S, int env0, int nsteps, int ph, int xflags) {
   // model descriptor + LDS layout live in device memory (uploaded once): uniform scalar loads on demand instead
@@ -1744,6 +1746,28 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           for (int d = lane; d < nv; d += 64) s_tmpv[d] = 0;
         }
         WSYNC();
+        bool patched = false;
+        if constexpr (DIAGM && NROW <= 2) {
+          if (M.patch) {
+            // ---- contact-patch sweep (patch_pgs.h): the blocks are regrouped into patches of up to 16 rows between the same
+            //      bodies; the running acceleration lives in LDS in the scaled coordinates a^ = M^1/2 a
+            patched = true;
+            PatchArgs pa;
+            pa.lds = lds; pa.pool = M.pool; pa.pool_floats = M.pool_floats; pa.pdesc = M.pdesc; pa.pslot = M.pslot; pa.zero = L.zero; pa.ahat = L.qacc;
+            pa.blki = s_blki_i; pa.blkf = s_blkf; pa.J = s_J; pa.qLDinv = s_qLDinv; pa.nblk = nblk; pa.nv = nv; pa.maxcon = M.maxcon;
+            for (int d = lane; d < nv; d += 64) s_qacc[d] = (s_asmooth[d] + s_tmpv[d]) / sqrtf(s_qLDinv[d]);
+            const int nstep = patch_build(pa, lane, flags);
+            PROF(12);
+            niter = patch_sweep(pa, lane, nstep, M.iterations, M.tolerance, 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1)));
+            WSYNC();
+            for (int d = lane; d < nv; d += 64) { const float qa = s_qacc[d] * sqrtf(s_qLDinv[d]); s_qacc[d] = qa; s_ws[d] = qa; }
+            PROF(13);
+            WSYNC();
+            // qfrc_constraint = M (qacc - qacc_smooth): the base rows are gone
+            if (M.has_damping || (xflags & XF_FORCE)) for (int d = lane; d < nv; d += 64) s_tmpv2[d] = (s_qacc[d] - s_asmooth[d]) * s_qM[dof_Madr[d]];
+          }
+        }
+        if (!patched) {
         // ---- A_c = J_base M^-1 J_base^T, upper triangle (lanes = (block, base jb): row jb).  Built here, after the last user
         //      of the contact records and the velocity-stage spatial vectors: s_blkq reuses their space.
         for (int t = lane; t < 4 * nblk; t += 64) {
@@ -2045,6 +2069,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         WSYNC();
         // qfrc_constraint = J^T f (only needed by the implicit-damping integrator and for export)
         if (M.has_damping || (xflags & XF_FORCE)) { phi_from_forces(); accum_T(false, s_phi, s_tmpv2); }
+        }   // !patched
       }
       }   // !post
       if (xflags & XF_FORCE) {

@@ -307,6 +307,10 @@ class Engine:
     def lds_bytes(self):
         return self.lib.mjh_lds_bytes(self.h)
 
+    def solver_order(self):
+        """0: independent pairs / groups of blocks, 1: contact patches (mjh_solver_order)"""
+        return self.lib.mjh_solver_order(self.h)
+
     def load_tables(self, t):
         """apply per-env parameter tables + initial poses (dict as returned by *_randomize) and reset"""
         for k in ["geom_size", "geom_rbound", "body_mass", "body_inertia", "body_invweight0", "dof_invweight0"]:

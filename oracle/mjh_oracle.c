@@ -1385,6 +1385,22 @@ static int m_group_max(const mjh_model* m) {
   for (int t = 0; t < m->ntree; t++) if (m->tree_dofnum[t] > 8) return 4;
   return 16;
 }
+/* Contact-patch order (the device's patch_pgs.h): models whose trees are all single free bodies about their own centre of mass
+ * with body-aligned principal axes (diagonal M), at most 32 dofs, no noslip pass, at most 64 contacts.  -1: by that rule (default); 0 / 1: forced off / on (an engine tells which order it runs: mjh_solver_order). */
+static int g_pgs_patch_order = -1;
+void orc_set_pgs_patch_order(int mode) { g_pgs_patch_order = mode < 0 ? -1 : (mode != 0); }
+static int m_patch_order(const mjh_model* m) {
+  if (g_pgs_patch_order >= 0) return g_pgs_patch_order;
+  if (m->ntree <= 0 || m->neq != 0 || m->nsensor != 0 || m->nmocap != 0 || m->nv > 32 || m->maxcon > 64 || m->opt.noslip_iterations != 0) return 0;
+  for (int t = 0; t < m->ntree; t++) {
+    int b = m->tree_bodyid[t];
+    if (m->tree_dofnum[t] != 6 || m->body_jntnum[b] != 1 || m->jnt_type[m->body_jntadr[b]] != MJH_JNT_FREE) return 0;
+    for (int c = 1; c < m->nbody; c++) if (c != b && m->body_treeid[c] == t) return 0;
+    if (m->body_ipos[3*b] != 0 || m->body_ipos[3*b+1] != 0 || m->body_ipos[3*b+2] != 0 || m->body_iquat[4*b] != 1) return 0;
+  }
+  for (int i = 0; i < m->nv; i++) if (m->dof_frictionloss[i] > 0) return 0;
+  return 1;
+}
 static int pgs_order(const orc_data* d, int* order) {
   int nefc = d->nefc, nblk = 0;
   if (g_pgs_row_order) { for (int i = 0; i < nefc; i++) order[i] = i; return nefc; }
@@ -1398,6 +1414,46 @@ static int pgs_order(const orc_data* d, int* order) {
     nblk++; i += n;
   }
   int k = 0;
+  if (m_patch_order(d->m)) {
+    /* contacts sorted by (couples two bodies first, body pair, constraint order); a patch = a maximal run of contacts of one
+     * body pair with at most 16 rows; a step = a patch plus up to three later unvisited patches of the sequence that share no
+     * body with the step (first fit); rows in order inside a patch */
+    int* seq = (int*)malloc(sizeof(int) * (size_t)(nblk + 1) * 6);
+    int *pfirst = seq + nblk + 1, *pcount = pfirst + nblk + 1, *pa = pcount + nblk + 1, *pb = pa + nblk + 1, *pused = pb + nblk + 1;
+    long long* key = (long long*)malloc(sizeof(long long) * (size_t)(nblk + 1));
+    for (int i = 0; i < nblk; i++) {
+      int t1 = bt1[i], t2 = bt2[i];
+      if (t1 < 0) { t1 = t2; t2 = -1; }
+      if (t2 == t1) t2 = -1;
+      int two = t2 >= 0, a = two ? (t1 < t2 ? t1 : t2) : t1, b = two ? (t1 < t2 ? t2 : t1) : 1000;
+      bt1[i] = a; bt2[i] = two ? b : -1;
+      key[i] = (((long long)(two ? 0 : 1) * 2048 + a) * 2048 + b) * 65536 + i;
+      seq[i] = i;
+    }
+    for (int i = 1; i < nblk; i++) { int v = seq[i], j = i - 1; while (j >= 0 && key[seq[j]] > key[v]) { seq[j+1] = seq[j]; j--; } seq[j+1] = v; }
+    int npatch = 0, rows = 0;
+    for (int ii = 0; ii < nblk; ii++) {
+      int i = seq[ii];
+      int same = ii > 0 && bt1[seq[ii-1]] == bt1[i] && bt2[seq[ii-1]] == bt2[i];
+      if (!same || rows + bnum[i] > 16) { pfirst[npatch] = ii; pcount[npatch] = 0; pa[npatch] = bt1[i]; pb[npatch] = bt2[i]; pused[npatch] = 0; npatch++; rows = 0; }
+      pcount[npatch-1]++; rows += bnum[i];
+    }
+    for (int p = 0; p < npatch; p++) {
+      if (pused[p]) continue;
+      int gt[8], ngt = 0, cnt = 0;
+      for (int c = p; c < npatch && cnt < 4; c++) {
+        if (pused[c]) continue;
+        int share = 0;
+        for (int q = 0; q < ngt; q++) if (gt[q] == pa[c] || gt[q] == pb[c]) share = 1;
+        if (share) continue;
+        pused[c] = 1; cnt++;
+        gt[ngt++] = pa[c]; if (pb[c] >= 0) gt[ngt++] = pb[c];
+        for (int ii = pfirst[c]; ii < pfirst[c] + pcount[c]; ii++) { int i = seq[ii]; for (int r = 0; r < bnum[i]; r++) order[k++] = bstart[i] + r; }
+      }
+    }
+    free(key); free(seq); free(bstart);
+    return k;
+  }
   if (nblk > 64) {
     /* many-block models (the device solves them four independent blocks at a time, one per 16-lane row of a wave, on up to
      * four waves): same two-tree-first sequence; a group = a block plus up to GMAX - 1 later unvisited blocks of the

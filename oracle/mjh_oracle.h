@@ -120,6 +120,7 @@ void orc_set_slot_mask(orc_data* d, unsigned mask);
 /* Gauss-Seidel visiting order of orc_fwd_constraint (process-wide): 0 = the device's independent-pair order (default),
  * 1 = plain constraint-row order as mj_solPGS [UPSTREAM] */
 void orc_set_pgs_row_order(int plain);
+void orc_set_pgs_patch_order(int mode);   /* -1: by the model rule (default), 0 / 1: independent-pair order / contact-patch order */
 void orc_set_pd(orc_data* d, const double* target /* [nv], may be NULL with kp = kd = 0 */, double kp, double kd);
 
 #ifdef __cplusplus

@@ -42,6 +42,7 @@ def lib():
         L.orc_set_slot_mask.argtypes = [vp, C.c_uint]
         L.orc_set_pd.argtypes = [vp, dp, C.c_double, C.c_double]
         L.orc_set_pgs_row_order.argtypes = [C.c_int]
+        L.orc_set_pgs_patch_order.argtypes = [C.c_int]
         _lib = L
     return _lib
 
