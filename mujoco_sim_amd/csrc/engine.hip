@@ -296,7 +296,6 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       L.qM = put(m->nM); L.qLD = L.qM; L.qLDinv = put(nv); L.dofpar = 0; L.dofMadr = 0; L.anc = 0;
       L.p_gsize = put(3*ng); L.p_rbound = put(ng); L.p_mass = put(nb); L.p_inertia = put(3*nb);
       L.zero = put(4);
-      M.pdesc = put(M.maxcon); M.pslot = put(4 * M.maxcon);
     }
     // K1: frames, composite inertias, joint anchors/axes and geom poses are dead once the position stage, CRBA and the
     // collision stage are done; the solver's per-base scratch vectors (bv, phi: first used by the velocity stage) reuse them
@@ -344,11 +343,14 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     }
     if (patch) {
       // the pool: per patch of nr4 rows (a multiple of 4, at most 16)  12 nr4 (rows of J) + 5 nr4 (f, aref, R, 1/AR_rr, AR_rr/2)
-      // + 16 floats per 4x4 tile of the lower triangle of AR: 21 .. 27 floats per row.  Sized for two thirds of the row
-      // capacity at 27 floats per row (S24: 4336 floats against a largest observed need of 2880); patches beyond it are
-      // dropped with the capacity flag, like contacts beyond maxcon
-      M.pool = k1; M.pool_floats = std::max(off - k1, 18 * M.maxefc + 16);
-      off = k1 + M.pool_floats;
+      // + 16 floats per 4x4 tile of the lower triangle of AR: 21 .. 27 floats per row.  It takes the span of everything that
+      // is dead by then and no more (S24: 3948 floats against a largest observed need of 2880; the row capacity at 27 floats
+      // per row would be 6480); patches beyond it are dropped with the capacity flag, like contacts beyond maxcon
+      // The two small tables the sweep reads next to the pool (one descriptor per patch, one per schedule slot) sit in front
+      // of it: that space (position-stage arrays, contact records) is dead when they are written, unlike the span's tail.
+      M.pdesc = k1; M.pslot = k1 + ((M.maxcon + 3) / 4) * 4; M.pool = M.pslot + 4 * M.maxcon;
+      M.pool_floats = std::max(off - M.pool, 12 * M.maxefc);
+      off = M.pool + M.pool_floats;
     } else L.zero = put(4);
     L.site = m->nsite > 0 ? put(12 * m->nsite) : 0;        // world frame of every site: pos(3) + rotation(9)
     L.fext = m->nsensor > 0 ? put(6 * nb) : 0;             // external spatial force per body (mj_rnePostConstraint)

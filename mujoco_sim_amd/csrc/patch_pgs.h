@@ -208,22 +208,28 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags) {
     for (int k = 0; k < 12; k++) diag += Jv[k] * Jv[k];
     const float ARqq = diag + R;
     if (on) {
-      P[PP_PAR(nr4) + 4 * q + 3] = ARqq < MJ_MINVAL ? 0.0f : 1.0f / ARqq;
+      const float inv = ARqq < MJ_MINVAL ? 0.0f : 1.0f / ARqq, ninv = -inv;
+      P[PP_PAR(nr4) + 4 * q + 3] = inv;
       P[PP_HALF(nr4) + q] = 0.5f * ARqq;
+      // the tiles hold -AR_qr / AR_qq: the sweep carries t_q = -res_q / AR_qq instead of the residual itself
       float* T = P + PP_TILES(nr4) + ((ti * (ti + 1)) >> 1) * 16 + (q & 3) * 4;
 #pragma unroll
       for (int c = 0; c < 4; c++)
-        if (c <= ti) *(float4*)(T + 16 * c) = make_float4(4*c < q ? acc[4*c] : 0.0f, 4*c + 1 < q ? acc[4*c + 1] : 0.0f, 4*c + 2 < q ? acc[4*c + 2] : 0.0f, 4*c + 3 < q ? acc[4*c + 3] : 0.0f);
+        if (c <= ti) *(float4*)(T + 16 * c) = make_float4(4*c < q ? ninv * acc[4*c] : 0.0f, 4*c + 1 < q ? ninv * acc[4*c + 1] : 0.0f,
+                                                          4*c + 2 < q ? ninv * acc[4*c + 2] : 0.0f, 4*c + 3 < q ? ninv * acc[4*c + 3] : 0.0f);
     }
   }
   WSYNC();
   return nstep;
 }
 
-// four rows r0 .. r0+3 of the sweep: delta = max(-res / AR_qq, -f), res += AR_q,r * delta_r
-#define PP_ROW(r, ar) "v_mul_f32 %[t], %[res], %[ninv]\n\tv_max_f32 %[d], %[t], %[nf]\n\ts_nop 1\n\tv_fmac_f32_dpp %[res], %[d], " ar " row_newbcast:" #r " row_mask:0xf bank_mask:0xf\n\t"
+// four rows r0 .. r0+3 of the sweep, on t_q = -res_q / AR_qq:  delta = max(t, -f),  t_q += (-AR_qr / AR_qq) delta_r
+#define PP_ROW(r, ar) "v_max_f32 %[d], %[t], %[nf]\n\ts_nop 1\n\tv_fmac_f32_dpp %[t], %[d], " ar " row_newbcast:" #r " row_mask:0xf bank_mask:0xf\n\t"
 #define PP_ROWS4(r0, r1, r2, r3, T) asm volatile(PP_ROW(r0, "%[a0]") PP_ROW(r1, "%[a1]") PP_ROW(r2, "%[a2]") PP_ROW(r3, "%[a3]") \
-    : [res] "+v"(res), [d] "=&v"(dl), [t] "=&v"(tt) : [ninv] "v"(ninv), [nf] "v"(nf), [a0] "v"(T.x), [a1] "v"(T.y), [a2] "v"(T.z), [a3] "v"(T.w))
+    : [t] "+v"(tt), [d] "=&v"(dl) : [nf] "v"(nf), [a0] "v"(T.x), [a1] "v"(T.y), [a2] "v"(T.z), [a3] "v"(T.w))
+// dst = src + (src of the lane `ror` places down the row), written in the quads of bank mask bm only
+#define PP_ADD_ROR(dst, src, ror, bm) "v_add_f32_dpp " dst ", " src ", " src " row_ror:" #ror " row_mask:0xf bank_mask:" #bm "\n\t"
+#define PP_ADD_QP(dst, a, b, c, d) "v_add_f32_dpp " dst ", " dst ", " dst " quad_perm:[" #a "," #b "," #c "," #d "] row_mask:0xf bank_mask:0xf\n\t"
 
 struct PatchOps { float4 J0, J1, J2, P, A0, A1, A2, A3; float half; float* pf; const float* pa; float* padd; int nr4; };
 
@@ -234,9 +240,8 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
   float* const pool = A.lds + A.pool;
   float* const zero = A.lds + A.zero;
   float* const ahat = A.lds + A.ahat;
-  auto load = [&](const int t) __attribute__((always_inline)) {
+  auto load = [&](const int d) __attribute__((always_inline)) {
     PatchOps o;
-    const int d = s_pslot[4 * t + rho];
     const int nr4 = PD_N4(d) << 2, dA = PD_DA(d), dB = PD_DB(d);
     const bool on = q < nr4;
     float* P = pool + PD_OFF(d);
@@ -251,9 +256,10 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
     o.A1 = *(const float4*)((on && ti >= 1) ? T + 16 : zero);
     o.A2 = *(const float4*)((on && ti >= 2) ? T + 32 : zero);
     o.A3 = *(const float4*)((on && ti >= 3) ? T + 48 : zero);
-    // lanes 0..11 of the row carry the dofs of body A, then B, for u = J^ a^; lanes 0..3 add the four dof triples of a^ += J^T delta
+    // lanes 0..11 of the row carry the dofs of body A, then B, for u = J^ a^; the first lane of quad j adds dofs 3j .. 3j+2 of
+    // a^ += J^T delta (a patch on one body has zeros there: they go to body A)
     o.pa = q < 6 ? ahat + dA + q : ((q < 12 && dB != 63) ? ahat + dB + q - 6 : zero);
-    o.padd = ahat + (((q & 1) && dB != 63) ? dB : dA) + ((q & 2) ? 3 : 0);
+    o.padd = ahat + ((q >= 8 && dB != 63) ? dB : dA) + ((q & 4) ? 3 : 0);
     o.nr4 = nr4;
     return o;
   };
@@ -266,8 +272,8 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
 #define PP_U(k) PP_FMAC_BC(u, al, Jv[k], k);
     PP_BC12(PP_U)
 #undef PP_U
-    const float f = o.P.x, ninv = -o.P.w, nf = -f;
-    float res = (u - o.P.y) + o.P.z * f, dl, tt;
+    const float f = o.P.x, nf = -f;
+    float tt = ((u - o.P.y) + o.P.z * f) * -o.P.w, dl;
     PP_ROWS4(0, 1, 2, 3, o.A0);
     if (nmax > 4) {
       PP_ROWS4(4, 5, 6, 7, o.A1);
@@ -276,49 +282,53 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
         if (nmax > 12) PP_ROWS4(12, 13, 14, 15, o.A3);
       }
     }
-    dl = fmaxf(res * ninv, nf);          // every lane's own update (its residual is final: header comment)
+    dl = fmaxf(tt, nf);                  // every lane's own update (its t is final: header comment)
     *o.pf = f + dl;
-    impl -= dl * (res + o.half * dl);
-    // a^ += J^T delta: 12 sums over the 16 lanes of the row, folded while they are reduced (lane q & 3 ends up with three of them)
-    float p[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) p[k] = Jv[k] * dl;
-    float ra[6], rb[3];
-    const bool odd = q & 1, up = q & 2;
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-      const float keep = odd ? p[k + 6] : p[k], send = odd ? p[k] : p[k + 6];
-      ra[k] = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const float keep = up ? ra[k + 3] : ra[k], send = up ? ra[k] : ra[k + 3];
-      rb[k] = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) { MJH_DPP_ADD(rb[k], 0x124, 0xf, true); }   // row_ror:4
-#pragma unroll
-    for (int k = 0; k < 3; k++) { MJH_DPP_ADD(rb[k], 0x128, 0xf, true); }   // row_ror:8
-    if (q < 4) { atomicAdd(o.padd, rb[0]); atomicAdd(o.padd + 1, rb[1]); atomicAdd(o.padd + 2, rb[2]); }
+    impl += (o.half * dl) * (2.0f * tt - dl);     // cost decrease  -(delta res + AR_qq delta^2 / 2),  res = -t AR_qq
+    // a^ += J^T delta: 12 sums over the 16 lanes of the row.  Folded while they are reduced: across the quads first (the DPP bank
+    // mask picks which quads keep which half), then inside the quads; quad j ends up with the sums of dofs 3j .. 3j+2.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f d2 = {dl, dl};
+    const v2f p01 = v2f{Jv[0], Jv[1]} * d2, p23 = v2f{Jv[2], Jv[3]} * d2, p45 = v2f{Jv[4], Jv[5]} * d2;
+    const v2f p67 = v2f{Jv[6], Jv[7]} * d2, p89 = v2f{Jv[8], Jv[9]} * d2, pab = v2f{Jv[10], Jv[11]} * d2;
+    float r0, r1, r2, r3, r4, r5, b0, b1, b2;
+    asm volatile("s_nop 1\n\t"
+                 PP_ADD_ROR("%0", "%6", 8, 0x3) PP_ADD_ROR("%1", "%7", 8, 0x3) PP_ADD_ROR("%2", "%8", 8, 0x3)
+                 PP_ADD_ROR("%3", "%9", 8, 0x3) PP_ADD_ROR("%4", "%10", 8, 0x3) PP_ADD_ROR("%5", "%11", 8, 0x3)
+                 PP_ADD_ROR("%0", "%12", 8, 0xc) PP_ADD_ROR("%1", "%13", 8, 0xc) PP_ADD_ROR("%2", "%14", 8, 0xc)
+                 PP_ADD_ROR("%3", "%15", 8, 0xc) PP_ADD_ROR("%4", "%16", 8, 0xc) PP_ADD_ROR("%5", "%17", 8, 0xc)
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5)
+                 : "v"(p01.x), "v"(p01.y), "v"(p23.x), "v"(p23.y), "v"(p45.x), "v"(p45.y), "v"(p67.x), "v"(p67.y), "v"(p89.x), "v"(p89.y), "v"(pab.x), "v"(pab.y));
+    asm volatile("s_nop 1\n\t"
+                 PP_ADD_ROR("%0", "%3", 12, 0x5) PP_ADD_ROR("%1", "%4", 12, 0x5) PP_ADD_ROR("%2", "%5", 12, 0x5)
+                 PP_ADD_ROR("%0", "%6", 4, 0xa) PP_ADD_ROR("%1", "%7", 4, 0xa) PP_ADD_ROR("%2", "%8", 4, 0xa)
+                 PP_ADD_QP("%0", 1, 0, 3, 2) PP_ADD_QP("%1", 1, 0, 3, 2) PP_ADD_QP("%2", 1, 0, 3, 2)
+                 PP_ADD_QP("%0", 2, 3, 0, 1) PP_ADD_QP("%1", 2, 3, 0, 1) PP_ADD_QP("%2", 2, 3, 0, 1)
+                 : "=&v"(b0), "=&v"(b1), "=&v"(b2) : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4), "v"(r5));
+    if ((q & 3) == 0) { atomicAdd(o.padd, b0); atomicAdd(o.padd + 1, b1); atomicAdd(o.padd + 2, b2); }
   };
   int niter = 0;
   if (nstep == 1) {
     for (int it = 0; it < itmax; it++) {
       float impl = 0;
-      PatchOps o = load(0);
+      PatchOps o = load(s_pslot[rho]);
       solve(o, impl);
       niter = it + 1;
       if (wave_sum<4>(impl) * scale < tol) break;
     }
     return niter;
   }
-  // two or more steps: the operands of the next step are in flight while this one is solved (a patch is written only in its own step)
-  PatchOps nxt = load(0);
+  // two or more steps: software pipeline over the cyclic schedule, descriptor of step t+2 -> operands of step t+1 -> solve
+  // step t (a patch is only written in its own step, so what is in flight is never stale)
+  PatchOps nxt = load(s_pslot[rho]);
+  int dn = s_pslot[4 + rho];
   for (int it = 0; it < itmax; it++) {
     float impl = 0;
     for (int t = 0; t < nstep; t++) {
       PatchOps cur = nxt;
-      nxt = load(t + 1 < nstep ? t + 1 : 0);
+      nxt = load(dn);
+      dn = s_pslot[4 * (t + 2 < nstep ? t + 2 : t + 2 - nstep) + rho];
+      asm volatile("" ::: "memory");     // the loads above stay above: they are consumed one step later
       solve(cur, impl);
     }
     niter = it + 1;

@@ -1259,7 +1259,9 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
     //      greedy: a block, and the first later unvisited block of the sequence that shares no tree with it.  Pairs
     //      (i, q) are independent and can be solved side by side.
     int ngrp = 0;
-    {
+    bool patch_order = false;    // contact-patch sweep (patch_pgs.h): it builds its own schedule
+    if constexpr (DIAGM && NROW <= 2) patch_order = M.patch != 0;
+    if (!patch_order) {
       if (nblk > 64) {
         // many-block models: groups of up to 4 mutually independent blocks (the many-body solver puts one block on each
         // 16-lane row of the wave; sequential sweeps just follow the order).  Same rule as the oracle: two-tree blocks
