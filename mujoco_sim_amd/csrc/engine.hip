@@ -295,7 +295,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     if (patch) {   // what the sweep still needs sits in front of the span the patch pool takes over
       L.qM = put(m->nM); L.qLD = L.qM; L.qLDinv = put(nv); L.dofpar = 0; L.dofMadr = 0; L.anc = 0;
       L.p_gsize = put(3*ng); L.p_rbound = put(ng); L.p_mass = put(nb); L.p_inertia = put(3*nb);
-      L.zero = put(4);
+      L.zero = put(20);     // (PP_ZERO: a lane outside a patch reads a whole row record of zeros)
     }
     // K1: frames, composite inertias, joint anchors/axes and geom poses are dead once the position stage, CRBA and the
     // collision stage are done; the solver's per-base scratch vectors (bv, phi: first used by the velocity stage) reuse them
@@ -342,10 +342,10 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       L.J = put((int)jsz); L.B = diagM ? L.J : put((int)jsz);
     }
     if (patch) {
-      // the pool: per patch of nr4 rows (a multiple of 4, at most 16)  12 nr4 (rows of J) + 5 nr4 (f, aref, R, 1/AR_rr, AR_rr/2)
-      // + 16 floats per 4x4 tile of the lower triangle of AR: 21 .. 27 floats per row.  It takes the span of everything that
-      // is dead by then and no more (S24: 3948 floats against a largest observed need of 2880; the row capacity at 27 floats
-      // per row would be 6480); patches beyond it are dropped with the capacity flag, like contacts beyond maxcon
+      // the pool: per patch of nr4 rows (a multiple of 4, at most 16) a 20-float record per row (J, f, aref, R, 1/AR_rr, AR_rr/2)
+      // + 16 floats per 4x4 tile of the lower triangle of AR: 24 .. 30 floats per row.  It takes the span of everything that
+      // is dead by then and no more (S24: 3948 floats against a largest observed need of about 3250; the row capacity at 30
+      // floats per row would be 7200); patches beyond it are dropped with the capacity flag, like contacts beyond maxcon
       // The two small tables the sweep reads next to the pool (one descriptor per patch, one per schedule slot) sit in front
       // of it: that space (position-stage arrays, contact records) is dead when they are written, unlike the span's tail.
       M.pdesc = k1; M.pslot = k1 + ((M.maxcon + 3) / 4) * 4; M.pool = M.pslot + 4 * M.maxcon;
@@ -855,6 +855,7 @@ extern "C" int mjh_get_stats(mjh_engine* e, int env0, int n, int* out) {
   ENG(e); RANGE(e, env0, n);
   HIPCHK(hipMemcpyAsync(out, e->S.stats + (size_t)env0 * 4, (size_t)n * 4 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  for (int i = 0; i < n; i++) out[4*i + 3] &= 0xff;   // (bits 8.. : the kernel's cost hint for the launch order, not a flag)
   return MJH_OK;
 }
 

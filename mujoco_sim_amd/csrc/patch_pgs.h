@@ -25,12 +25,15 @@
 #define PD_N4(d) (((d) >> 13) & 7)
 #define PD_DA(d) (((d) >> 16) & 31)
 #define PD_DB(d) (((d) >> 21) & 63)
-// layout of a patch of nr4 rows inside the pool (floats):  J^ [3][nr4][4] | (f, aref, R, 1/AR_qq) [nr4][4] | AR_qq / 2 [nr4] |
-// 4 x 4 tiles (i, c <= i) of the strictly lower triangle of AR, [tile][q & 3][4]
-#define PP_PAR(nr4) (12 * (nr4))
-#define PP_HALF(nr4) (16 * (nr4))
-#define PP_TILES(nr4) (17 * (nr4))
-#define PP_SIZE(n4) (68 * (n4) + 8 * (n4) * ((n4) + 1))
+// layout of a patch of nr4 rows inside the pool (floats): one record of 20 per row,  J^ [12] | f, aref, R, 1/AR_qq | AR_qq / 2, pad [3]
+// (a lane reads its whole record off one address; stride 20 keeps 16 lanes' ds_read_b128 on distinct banks), then the 4 x 4 tiles
+// (i, c <= i) of the strictly lower triangle of -AR_qr / AR_qq, [tile][q & 3][4]
+#define PP_REC 20
+#define PP_PAR 12
+#define PP_HALF 16
+#define PP_TILES(nr4) (PP_REC * (nr4))
+#define PP_SIZE(n4) (80 * (n4) + 8 * (n4) * ((n4) + 1))
+#define PP_ZERO 20     // floats of zeros a lane outside a patch reads instead of a record
 
 // acc += y * (x of lane R of this lane's 16-lane row).  The _H form waits out the VALU-write -> DPP-read hazard of x.
 #define PP_FMAC_BC(acc, x, y, R) asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #R " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y))
@@ -47,7 +50,8 @@ struct PatchArgs {
 
 // Groups the contact blocks into patches, schedules the patches into steps, and converts the blocks' base rows / parameters /
 // forces into the pool (which overwrites them: everything is staged through registers first).  Returns the number of steps.
-DEV int patch_build(const PatchArgs& A, const int lane, int& flags) {
+// swork: cost of one sweep in units of about four instructions (launch-order hint): 24 per step + 1 per row of its longest patch.
+DEV int patch_build(const PatchArgs& A, const int lane, int& flags, int& swork) {
   const int nblk = A.nblk, maxcon = A.maxcon;
   int* s_word = (int*)(A.lds + A.pool);       // [maxcon] block words in patch order
   int* s_pinfo = s_word + maxcon;             // [maxcon] per patch
@@ -116,6 +120,7 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags) {
       used |= 1ull << i;
       int gmask = __builtin_amdgcn_readlane(tmask, i), cnt = 1;
       const int di = __builtin_amdgcn_readlane(desc, i);
+      int n4max = PD_N4(di);
       if (lane == 0) s_pslot[4 * nstep] = di;
       while (cnt < 4) {
         const bool cand = lane < npatch && lane > i && !((used >> lane) & 1ull) && !(tmask & gmask);
@@ -125,8 +130,10 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags) {
         used |= 1ull << q; gmask |= __builtin_amdgcn_readlane(tmask, q);
         const int dq = __builtin_amdgcn_readlane(desc, q);
         if (lane == 0) s_pslot[4 * nstep + cnt] = dq;
+        n4max = max(n4max, PD_N4(dq));
         cnt++;
       }
+      swork += 24 + 4 * n4max;
       if (lane == 0) for (int c = cnt; c < 4; c++) s_pslot[4 * nstep + c] = 0;
       nstep++;
     }
@@ -171,13 +178,13 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags) {
   for (int ps = 0; ps < 4; ps++) {
     const int m = mm[ps];
     if (m < 0 || ((m >> 10) & 63) >= npatch) continue;
-    const int d = s_pdesc[(m >> 10) & 63], q = (m >> 16) & 15, nr4 = PD_N4(d) << 2;
-    float* P = pool + PD_OFF(d);
-    *(float4*)(P + 4 * q) = make_float4(jr[ps][0], jr[ps][1], jr[ps][2], jr[ps][3]);
-    *(float4*)(P + 4 * (nr4 + q)) = make_float4(jr[ps][4], jr[ps][5], jr[ps][6], jr[ps][7]);
-    *(float4*)(P + 4 * (2 * nr4 + q)) = make_float4(jr[ps][8], jr[ps][9], jr[ps][10], jr[ps][11]);
-    *(float4*)(P + PP_PAR(nr4) + 4 * q) = make_float4(pr[ps][0], pr[ps][1], pr[ps][2], 0.0f);
-    P[PP_HALF(nr4) + q] = 0.0f;
+    const int d = s_pdesc[(m >> 10) & 63], q = (m >> 16) & 15;
+    float* Rq = pool + PD_OFF(d) + PP_REC * q;
+    *(float4*)(Rq) = make_float4(jr[ps][0], jr[ps][1], jr[ps][2], jr[ps][3]);
+    *(float4*)(Rq + 4) = make_float4(jr[ps][4], jr[ps][5], jr[ps][6], jr[ps][7]);
+    *(float4*)(Rq + 8) = make_float4(jr[ps][8], jr[ps][9], jr[ps][10], jr[ps][11]);
+    *(float4*)(Rq + PP_PAR) = make_float4(pr[ps][0], pr[ps][1], pr[ps][2], 0.0f);
+    *(float4*)(Rq + PP_HALF) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
   WSYNC();
   // ---- AR = J^ J^T + R of every patch, four patches at a time (lanes = rows): strictly lower triangle in 4 x 4 tiles
@@ -188,8 +195,10 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags) {
     const int d = pt < npatch ? s_pdesc[pt] : 0, nr4 = PD_N4(d) << 2;
     const bool on = q < nr4;
     float* P = pool + PD_OFF(d);
-    const float4 j0 = *(const float4*)(on ? P + 4 * q : zero), j1 = *(const float4*)(on ? P + 4 * (nr4 + q) : zero), j2 = *(const float4*)(on ? P + 4 * (2 * nr4 + q) : zero);
-    const float R = *(on ? P + PP_PAR(nr4) + 4 * q + 2 : zero);
+    float* Rq = P + PP_REC * q;
+    const float* Rz = on ? Rq : zero;
+    const float4 j0 = *(const float4*)(Rz), j1 = *(const float4*)(Rz + 4), j2 = *(const float4*)(Rz + 8);
+    const float R = Rz[PP_PAR + 2];
     float Jv[12] = {j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w, j2.x, j2.y, j2.z, j2.w};
     asm volatile("" : "+v"(Jv[0]), "+v"(Jv[1]), "+v"(Jv[2]), "+v"(Jv[3]), "+v"(Jv[4]), "+v"(Jv[5]));
     asm volatile("" : "+v"(Jv[6]), "+v"(Jv[7]), "+v"(Jv[8]), "+v"(Jv[9]), "+v"(Jv[10]), "+v"(Jv[11]));
@@ -209,8 +218,8 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags) {
     const float ARqq = diag + R;
     if (on) {
       const float inv = ARqq < MJ_MINVAL ? 0.0f : 1.0f / ARqq, ninv = -inv;
-      P[PP_PAR(nr4) + 4 * q + 3] = inv;
-      P[PP_HALF(nr4) + q] = 0.5f * ARqq;
+      Rq[PP_PAR + 3] = inv;
+      Rq[PP_HALF] = 0.5f * ARqq;
       // the tiles hold -AR_qr / AR_qq: the sweep carries t_q = -res_q / AR_qq instead of the residual itself
       float* T = P + PP_TILES(nr4) + ((ti * (ti + 1)) >> 1) * 16 + (q & 3) * 4;
 #pragma unroll
@@ -231,47 +240,59 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags) {
 #define PP_ADD_ROR(dst, src, ror, bm) "v_add_f32_dpp " dst ", " src ", " src " row_ror:" #ror " row_mask:0xf bank_mask:" #bm "\n\t"
 #define PP_ADD_QP(dst, a, b, c, d) "v_add_f32_dpp " dst ", " dst ", " dst " quad_perm:[" #a "," #b "," #c "," #d "] row_mask:0xf bank_mask:0xf\n\t"
 
-struct PatchOps { float4 J0, J1, J2, P, A0, A1, A2, A3; float half; float* pf; const float* pa; float* padd; int nr4; };
+struct PatchOps { float4 J0, J1, J2, P, A0, A1, A2, A3; float half; float* rec; const float* pa; float* padd; int nr4; };
 
 // The sweeps.  A.ahat holds a^ = M^1/2 a on entry and on exit.  Returns the number of sweeps.
 DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const int itmax, const float tol, const float scale) {
   const int rho = lane >> 4, q = lane & 15, ti = q >> 2;
-  const int* s_pslot = (const int*)(A.lds + A.pslot);
+  const int* s_pslot = (const int*)(A.lds + A.pslot) + rho;
   float* const pool = A.lds + A.pool;
   float* const zero = A.lds + A.zero;
   float* const ahat = A.lds + A.ahat;
+  // per-lane constants of the operand addresses
+  const int recoff = PP_REC * q, tileoff = ((ti * (ti + 1)) >> 1) * 16 + (q & 3) * 4;
+  const int gq = q < 6 ? q : q - 6;                        // u = J^ a^: lanes 0..5 carry the dofs of body A, 6..11 those of body B
+  const bool gA = q < 6, gB = q >= 6 && q < 12;
+  const int addoff = (q & 4) ? 3 : 0;                      // a^ += J^T delta: the first lane of quad j adds dofs 3j .. 3j+2
+  const bool addB = q >= 8, adder = (q & 3) == 0;
   auto load = [&](const int d) __attribute__((always_inline)) {
     PatchOps o;
     const int nr4 = PD_N4(d) << 2, dA = PD_DA(d), dB = PD_DB(d);
-    const bool on = q < nr4;
+    const bool on = q < nr4, hasB = dB != 63;
     float* P = pool + PD_OFF(d);
-    o.J0 = *(const float4*)(on ? P + 4 * q : zero);
-    o.J1 = *(const float4*)(on ? P + 4 * (nr4 + q) : zero);
-    o.J2 = *(const float4*)(on ? P + 4 * (2 * nr4 + q) : zero);
-    o.pf = on ? P + PP_PAR(nr4) + 4 * q : zero;
-    o.P = *(const float4*)o.pf;
-    o.half = *(on ? P + PP_HALF(nr4) + q : zero);
-    const float* T = P + PP_TILES(nr4) + ((ti * (ti + 1)) >> 1) * 16 + (q & 3) * 4;
+    o.rec = on ? P + recoff : zero;
+    o.J0 = *(const float4*)(o.rec); o.J1 = *(const float4*)(o.rec + 4); o.J2 = *(const float4*)(o.rec + 8);
+    o.P = *(const float4*)(o.rec + PP_PAR);
+    o.half = o.rec[PP_HALF];
+    const float* T = P + PP_TILES(nr4) + tileoff;
     o.A0 = *(const float4*)(on ? T : zero);
     o.A1 = *(const float4*)((on && ti >= 1) ? T + 16 : zero);
     o.A2 = *(const float4*)((on && ti >= 2) ? T + 32 : zero);
     o.A3 = *(const float4*)((on && ti >= 3) ? T + 48 : zero);
-    // lanes 0..11 of the row carry the dofs of body A, then B, for u = J^ a^; the first lane of quad j adds dofs 3j .. 3j+2 of
-    // a^ += J^T delta (a patch on one body has zeros there: they go to body A)
-    o.pa = q < 6 ? ahat + dA + q : ((q < 12 && dB != 63) ? ahat + dB + q - 6 : zero);
-    o.padd = ahat + ((q >= 8 && dB != 63) ? dB : dA) + ((q & 4) ? 3 : 0);
+    o.pa = (gA || (gB && hasB)) ? ahat + (gA ? dA : dB) + gq : zero;
+    o.padd = ahat + ((addB && hasB) ? dB : dA) + addoff;     // (a patch on one body has zeros in the B half: they go to body A)
     o.nr4 = nr4;
     return o;
   };
-  auto solve = [&](PatchOps& o, float& impl) __attribute__((always_inline)) {
-    const float Jv[12] = {o.J0.x, o.J0.y, o.J0.z, o.J0.w, o.J1.x, o.J1.y, o.J1.z, o.J1.w, o.J2.x, o.J2.y, o.J2.z, o.J2.w};
+  // one step: the four patches of the wave's rows.  al = this lane's entry of a^ (read before the next step's operands were
+  // requested, so that waiting for it does not wait for them)
+  auto solve = [&](PatchOps& o, const float al, float& impl) __attribute__((always_inline)) {
     const int nmax = max(max(__builtin_amdgcn_readlane(o.nr4, 0), __builtin_amdgcn_readlane(o.nr4, 16)), max(__builtin_amdgcn_readlane(o.nr4, 32), __builtin_amdgcn_readlane(o.nr4, 48)));
-    float al = *o.pa;
-    float u = 0;
-    asm volatile("s_nop 1" :: "v"(al));
-#define PP_U(k) PP_FMAC_BC(u, al, Jv[k], k);
-    PP_BC12(PP_U)
-#undef PP_U
+    float u;
+    asm volatile("v_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %1, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %1, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %1, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %1, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %1, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %1, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf"
+                 : "=&v"(u) : "v"(al), "v"(o.J0.x), "v"(o.J0.y), "v"(o.J0.z), "v"(o.J0.w), "v"(o.J1.x), "v"(o.J1.y), "v"(o.J1.z), "v"(o.J1.w),
+                   "v"(o.J2.x), "v"(o.J2.y), "v"(o.J2.z), "v"(o.J2.w));
     const float f = o.P.x, nf = -f;
     float tt = ((u - o.P.y) + o.P.z * f) * -o.P.w, dl;
     PP_ROWS4(0, 1, 2, 3, o.A0);
@@ -282,15 +303,15 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
         if (nmax > 12) PP_ROWS4(12, 13, 14, 15, o.A3);
       }
     }
-    dl = fmaxf(tt, nf);                  // every lane's own update (its t is final: header comment)
-    *o.pf = f + dl;
+    asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));     // every lane's own update (its t is final: header comment)
+    o.rec[PP_PAR] = f + dl;
     impl += (o.half * dl) * (2.0f * tt - dl);     // cost decrease  -(delta res + AR_qq delta^2 / 2),  res = -t AR_qq
     // a^ += J^T delta: 12 sums over the 16 lanes of the row.  Folded while they are reduced: across the quads first (the DPP bank
     // mask picks which quads keep which half), then inside the quads; quad j ends up with the sums of dofs 3j .. 3j+2.
     typedef float v2f __attribute__((ext_vector_type(2)));
     const v2f d2 = {dl, dl};
-    const v2f p01 = v2f{Jv[0], Jv[1]} * d2, p23 = v2f{Jv[2], Jv[3]} * d2, p45 = v2f{Jv[4], Jv[5]} * d2;
-    const v2f p67 = v2f{Jv[6], Jv[7]} * d2, p89 = v2f{Jv[8], Jv[9]} * d2, pab = v2f{Jv[10], Jv[11]} * d2;
+    const v2f p01 = v2f{o.J0.x, o.J0.y} * d2, p23 = v2f{o.J0.z, o.J0.w} * d2, p45 = v2f{o.J1.x, o.J1.y} * d2;
+    const v2f p67 = v2f{o.J1.z, o.J1.w} * d2, p89 = v2f{o.J2.x, o.J2.y} * d2, pab = v2f{o.J2.z, o.J2.w} * d2;
     float r0, r1, r2, r3, r4, r5, b0, b1, b2;
     asm volatile("s_nop 1\n\t"
                  PP_ADD_ROR("%0", "%6", 8, 0x3) PP_ADD_ROR("%1", "%7", 8, 0x3) PP_ADD_ROR("%2", "%8", 8, 0x3)
@@ -305,31 +326,41 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
                  PP_ADD_QP("%0", 1, 0, 3, 2) PP_ADD_QP("%1", 1, 0, 3, 2) PP_ADD_QP("%2", 1, 0, 3, 2)
                  PP_ADD_QP("%0", 2, 3, 0, 1) PP_ADD_QP("%1", 2, 3, 0, 1) PP_ADD_QP("%2", 2, 3, 0, 1)
                  : "=&v"(b0), "=&v"(b1), "=&v"(b2) : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4), "v"(r5));
-    if ((q & 3) == 0) { atomicAdd(o.padd, b0); atomicAdd(o.padd + 1, b1); atomicAdd(o.padd + 2, b2); }
+    if (adder) { atomicAdd(o.padd, b0); atomicAdd(o.padd + 1, b1); atomicAdd(o.padd + 2, b2); }
   };
   int niter = 0;
   if (nstep == 1) {
     for (int it = 0; it < itmax; it++) {
       float impl = 0;
-      PatchOps o = load(s_pslot[rho]);
-      solve(o, impl);
+      PatchOps o = load(s_pslot[0]);
+      solve(o, *o.pa, impl);
       niter = it + 1;
       if (wave_sum<4>(impl) * scale < tol) break;
     }
     return niter;
   }
   // two or more steps: software pipeline over the cyclic schedule, descriptor of step t+2 -> operands of step t+1 -> solve
-  // step t (a patch is only written in its own step, so what is in flight is never stale)
-  PatchOps nxt = load(s_pslot[rho]);
-  int dn = s_pslot[4 + rho];
+  // step t (a patch is only written in its own step, so what is in flight is never stale); two operand sets in ping-pong
+  auto cyc = [&](const int x) __attribute__((always_inline)) { return x >= nstep ? x - nstep : x; };
+  PatchOps opA = load(s_pslot[0]), opB;
+  int dn = s_pslot[4];
   for (int it = 0; it < itmax; it++) {
     float impl = 0;
-    for (int t = 0; t < nstep; t++) {
-      PatchOps cur = nxt;
-      nxt = load(dn);
-      dn = s_pslot[4 * (t + 2 < nstep ? t + 2 : t + 2 - nstep) + rho];
-      asm volatile("" ::: "memory");     // the loads above stay above: they are consumed one step later
-      solve(cur, impl);
+    for (int t = 0; t < nstep; t += 2) {
+      {
+        const float al = *opA.pa;
+        opB = load(dn);
+        dn = s_pslot[4 * cyc(t + 2)];
+        asm volatile("" ::: "memory");     // the requests above stay above: they are consumed one step later
+        solve(opA, al, impl);
+      }
+      if (t + 1 < nstep) {
+        const float al = *opB.pa;
+        opA = load(dn);
+        dn = s_pslot[4 * cyc(t + 3)];
+        asm volatile("" ::: "memory");
+        solve(opB, al, impl);
+      } else opA = opB;                    // odd step count: step 0 of the next sweep was requested into B
     }
     niter = it + 1;
     if (wave_sum<4>(impl) * scale < tol) break;

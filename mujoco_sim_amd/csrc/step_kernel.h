@@ -591,7 +591,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
     // qvel_ref / qfrc_applied only cross launches in the split API (step1 | inverse | step2 as separate calls)
     if (!(ph & PH_STEP1)) { s_qvref[i] = S.qvel_ref[vrow + i]; s_applied[i] = S.qfrc_applied[vrow + i]; }
   }
-  if (lane < 4) s_zero[lane] = 0;   // what lanes outside a block read instead of its Jacobian
+  if (lane < (M.patch ? 20 : 4)) s_zero[lane] = 0;   // what lanes outside a block read instead of its Jacobian (patch sweep: instead of a row record)
   // hot chain-walk tables and the (possibly per-env) model parameters go to LDS once per launch
   for (int i = lane; i < nv; i += 64) {
     if (!DIAGM) {
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   // spawn/destroy as slot toggling: bit b set = body b is an INACTIVE slot in this env
   const unsigned slotmask = S.slot_mask ? (unsigned)__builtin_amdgcn_readfirstlane((int)S.slot_mask[env]) : 0u;
   const int sbase = nbody > 32 ? nbody - 32 : 0;   // mask bit i = body sbase + i: the LAST 32 bodies of a big model are the toggleable slots
-  int flags = 0, ncon = 0, nefc = 0, niter = 0;
+  int flags = 0, ncon = 0, nefc = 0, niter = 0, cost_hint = 0;
   PROF(0);
   if ((xflags & XF_PROF) && lane == 0) {   // 100 MHz wall clock (comparable across CUs) and where this env ran: HW_ID | XCC_ID << 32
     S.x_prof[(size_t)blockIdx.x * PROF_STRIDE + 16] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -1758,9 +1758,11 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             pa.lds = lds; pa.pool = M.pool; pa.pool_floats = M.pool_floats; pa.pdesc = M.pdesc; pa.pslot = M.pslot; pa.zero = L.zero; pa.ahat = L.qacc;
             pa.blki = s_blki_i; pa.blkf = s_blkf; pa.J = s_J; pa.qLDinv = s_qLDinv; pa.nblk = nblk; pa.nv = nv; pa.maxcon = M.maxcon;
             for (int d = lane; d < nv; d += 64) s_qacc[d] = (s_asmooth[d] + s_tmpv[d]) / sqrtf(s_qLDinv[d]);
-            const int nstep = patch_build(pa, lane, flags);
+            int swork = 0;
+            const int nstep = patch_build(pa, lane, flags, swork);
             PROF(12);
             niter = patch_sweep(pa, lane, nstep, M.iterations, M.tolerance, 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1)));
+            cost_hint = ((niter * swork) >> 1) + 1;   // (100 sweeps x 5 steps of 40 -> 10000 -> bucket 156 of the launch order's 256)
             WSYNC();
             for (int d = lane; d < nv; d += 64) { const float qa = s_qacc[d] * sqrtf(s_qLDinv[d]); s_qacc[d] = qa; s_ws[d] = qa; }
             PROF(13);
@@ -2299,7 +2301,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
   }
   if (lane == 0) {
     S.time[env] = time;
-    S.stats[4*env] = ncon; S.stats[4*env+1] = nefc; S.stats[4*env+2] = niter; S.stats[4*env+3] |= flags;
+    S.stats[4*env] = ncon; S.stats[4*env+1] = nefc; S.stats[4*env+2] = niter; S.stats[4*env+3] = ((S.stats[4*env+3] | flags) & 0xff) | (cost_hint << 8);
   }
   PROF(15);
   if ((xflags & XF_PROF) && lane == 0) S.x_prof[(size_t)blockIdx.x * PROF_STRIDE + 17] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -2323,7 +2325,8 @@ __global__ __launch_bounds__(1024) void mjh_order_kernel(const int* __restrict__
   const int t = threadIdx.x;
   if (t < 256) hist[t] = 0;
   __syncthreads();
-  auto bucket = [&](int e) { const int cost = stats[4*e + 2] * (stats[4*e + 1] + 24); int b = cost >> 6; return b > 255 ? 255 : b; };   // 100 it x 232 rows -> 362 -> clamp
+  // (kernels that know their solver work better leave a hint in bits 8.. of the flag word: the patch sweep's sweeps x step cost)
+  auto bucket = [&](int e) { const int hint = stats[4*e + 3] >> 8; const int cost = hint ? hint : stats[4*e + 2] * (stats[4*e + 1] + 24); int b = cost >> 6; return b > 255 ? 255 : b; };   // 100 it x 232 rows -> 362 -> clamp
   for (int e = t; e < nenv; e += 1024) atomicAdd(&hist[255 - bucket(e)], 1);
   __syncthreads();
   if (t == 0) { int acc = 0; for (int b = 0; b < 256; b++) { base[b] = acc; acc += hist[b]; } }
