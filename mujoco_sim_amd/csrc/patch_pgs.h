@@ -21,10 +21,12 @@
 #pragma once
 
 // descriptor of a patch: pool offset / 4 | (rows / 4) << 13 | first dof of body A << 16 | first dof of body B (63: none) << 21
+// (in the schedule table every slot of a step also carries the rows / 4 of the step's longest patch << 27)
 #define PD_OFF(d) (((d) & 0x1fff) << 2)
 #define PD_N4(d) (((d) >> 13) & 7)
 #define PD_DA(d) (((d) >> 16) & 31)
 #define PD_DB(d) (((d) >> 21) & 63)
+#define PD_STEPN4(d) (((d) >> 27) & 7)
 // layout of a patch of nr4 rows inside the pool (floats): one record of 20 per row,  J^ [12] | f, aref, R, 1/AR_qq | AR_qq / 2, pad [3]
 // (a lane reads its whole record off one address; stride 20 keeps 16 lanes' ds_read_b128 on distinct banks), then the 4 x 4 tiles
 // (i, c <= i) of the strictly lower triangle of -AR_qr / AR_qq, [tile][q & 3][4]
@@ -134,7 +136,10 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags, int& swork) 
         cnt++;
       }
       swork += 24 + 4 * n4max;
-      if (lane == 0) for (int c = cnt; c < 4; c++) s_pslot[4 * nstep + c] = 0;
+      if (lane == 0) {
+        for (int c = cnt; c < 4; c++) s_pslot[4 * nstep + c] = 0;
+        for (int c = 0; c < 4; c++) s_pslot[4 * nstep + c] |= n4max << 27;
+      }
       nstep++;
     }
   }
@@ -240,7 +245,7 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags, int& swork) 
 #define PP_ADD_ROR(dst, src, ror, bm) "v_add_f32_dpp " dst ", " src ", " src " row_ror:" #ror " row_mask:0xf bank_mask:" #bm "\n\t"
 #define PP_ADD_QP(dst, a, b, c, d) "v_add_f32_dpp " dst ", " dst ", " dst " quad_perm:[" #a "," #b "," #c "," #d "] row_mask:0xf bank_mask:0xf\n\t"
 
-struct PatchOps { float4 J0, J1, J2, P, A0, A1, A2, A3; float half; float* rec; const float* pa; float* padd; int nr4; };
+struct PatchOps { float4 J0, J1, J2, P, A0, A1, A2, A3; float half; float* rec; const float* pa; float* padd; int nr4; };   // nr4: rows of the STEP's longest patch
 
 // The sweeps.  A.ahat holds a^ = M^1/2 a on entry and on exit.  Returns the number of sweeps.
 DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const int itmax, const float tol, const float scale) {
@@ -266,18 +271,18 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
     o.half = o.rec[PP_HALF];
     const float* T = P + PP_TILES(nr4) + tileoff;
     o.A0 = *(const float4*)(on ? T : zero);
-    o.A1 = *(const float4*)((on && ti >= 1) ? T + 16 : zero);
-    o.A2 = *(const float4*)((on && ti >= 2) ? T + 32 : zero);
-    o.A3 = *(const float4*)((on && ti >= 3) ? T + 48 : zero);
-    o.pa = (gA || (gB && hasB)) ? ahat + (gA ? dA : dB) + gq : zero;
-    o.padd = ahat + ((addB && hasB) ? dB : dA) + addoff;     // (a patch on one body has zeros in the B half: they go to body A)
-    o.nr4 = nr4;
+    o.A1 = *(const float4*)((on & (ti >= 1)) ? T + 16 : zero);
+    o.A2 = *(const float4*)((on & (ti >= 2)) ? T + 32 : zero);
+    o.A3 = *(const float4*)((on & (ti >= 3)) ? T + 48 : zero);
+    o.pa = (gA | (gB & hasB)) ? ahat + (gA ? dA : dB) + gq : zero;
+    o.padd = ahat + ((addB & hasB) ? dB : dA) + addoff;      // (a patch on one body has zeros in the B half: they go to body A)
+    o.nr4 = PD_STEPN4(d) << 2;
     return o;
   };
   // one step: the four patches of the wave's rows.  al = this lane's entry of a^ (read before the next step's operands were
   // requested, so that waiting for it does not wait for them)
   auto solve = [&](PatchOps& o, const float al, float& impl) __attribute__((always_inline)) {
-    const int nmax = max(max(__builtin_amdgcn_readlane(o.nr4, 0), __builtin_amdgcn_readlane(o.nr4, 16)), max(__builtin_amdgcn_readlane(o.nr4, 32), __builtin_amdgcn_readlane(o.nr4, 48)));
+    const int nmax = __builtin_amdgcn_readfirstlane(o.nr4);      // rows of the step's longest patch
     float u;
     asm volatile("v_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
                  "v_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
