@@ -350,7 +350,8 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       // of it: that space (position-stage arrays, contact records) is dead when they are written, unlike the span's tail.
       M.pdesc = k1; M.pslot = k1 + ((M.maxcon + 3) / 4) * 4; M.pool = M.pslot + 4 * M.maxcon;
       M.pool_floats = std::max(off - M.pool, 12 * M.maxefc);
-      off = M.pool + M.pool_floats;
+      if (const char* cap = getenv("MJH_PATCH_POOL_FLOATS")) M.pool_floats = std::max(512, std::min(M.pool_floats, atoi(cap)));   // (tests: the drop rule)
+      off = std::max(off, M.pool + M.pool_floats);
     } else L.zero = put(4);
     L.site = m->nsite > 0 ? put(12 * m->nsite) : 0;        // world frame of every site: pos(3) + rotation(9)
     L.fext = m->nsensor > 0 ? put(6 * nb) : 0;             // external spatial force per body (mj_rnePostConstraint)

@@ -540,3 +540,67 @@ def test_batched_spawn_destroy_equals_the_per_object_calls():
         assert np.array_equal(x, y)
     assert np.array_equal(a.get_stats(), b.get_stats())
     a.close(); b.close()
+
+
+# ----------------------------------------------------------------------------- contact-patch sweep (csrc/patch_pgs.h)
+@pytest.mark.gpu
+def test_solver_order_query_matches_the_model_class():
+    """mjh_solver_order: 1 for small free-body models (S24, cube pools), 0 for articulated ones"""
+    e = ms.Engine(ms.scene("s24"), 4); assert e.solver_order() == 1; e.close()
+    e = ms.Engine(ms.scene("arm7", 1), 4); assert e.solver_order() == 0; e.close()
+    e = ms.Engine(ms.scene("pendulum"), 4); assert e.solver_order() == 0; e.close()
+
+
+@pytest.mark.gpu
+def test_patch_sweep_with_condim_1_3_4_contacts_matches_oracle(lib):
+    """five free bodies (nv = 30) with frictionless (condim 1), condim-3 and condim-4 geoms stacked in a corner: patches mix 1-, 4-
+    and 6-row contacts, one- and two-body patches, partially filled patches; device (patch sweep) vs oracle (patch order)"""
+    from test_gpu_parity import _compare_rollout
+    from helpers import D, set_opt
+    b = lib.mjh_builder_create()
+    set_opt(lib, b, timestep=0.004)
+    lib.mjh_builder_add_geom(b, b"floor", 0, 0, D(0, 0, 0.05), None, None, None, 4, -1, -1, -1)           # condim 4 like empty.xml's floor
+    lib.mjh_builder_add_geom(b, b"wall", 0, 6, D(0.02, 0.6, 0.3), D(-0.25, 0, 0.3), None, None, 3, -1, -1, -1)
+    specs = [(b"box_a", 6, (0.10, 0.10, 0.05), (0.0, 0.0, 0.06), 3), (b"box_b", 6, (0.08, 0.08, 0.05), (0.02, 0.01, 0.18), 4),
+             (b"ball", 2, (0.06, 0, 0), (0.03, -0.02, 0.31), 1), (b"caps", 3, (0.04, 0.10, 0), (-0.12, 0.0, 0.12), 3),
+             (b"box_c", 6, (0.05, 0.12, 0.04), (0.16, 0.02, 0.05), 1)]
+    for name, gt, size, pos, condim in specs:
+        bd = lib.mjh_builder_add_body(b, name, 0, D(*pos), None, 0.0)
+        lib.mjh_builder_add_joint(b, None, bd, 0, None, None, None, 0, 0, 0, 0, 0)
+        lib.mjh_builder_add_geom(b, None, bd, gt, D(*size), None, None, None, condim, -1, -1, -1)
+    m = ms.Model(lib.mjh_builder_compile(b), lib)
+    lib.mjh_builder_destroy(b)
+    assert m.nv == 30
+    m.c.maxcon = 48; m.c.maxefc = 48 * 6          # (the default capacity is every pair at full manifold: beyond the patch sweep's 64 contacts)
+    e = ms.Engine(m, 2); assert e.solver_order() == 1; e.close()
+    q0 = m.array("qpos0").copy()
+    q0[7*3+3:7*3+7] = [np.cos(0.6), 0, np.sin(0.6), 0]          # lean the capsule against the wall
+    v0 = np.zeros(m.nv); v0[0] = -0.3; v0[6 + 1] = 0.2
+    st, ncon, nefc = _compare_rollout(m, q0, [1, 50, 150], [1e-5, 1e-3, 3e-2], v0=v0)
+    assert ncon >= 8 and st[0] == ncon and st[1] == nefc and nefc > ncon     # rows: a mix of 1, 4 and 6 per contact
+
+
+@pytest.mark.gpu
+def test_patch_pool_overflow_drops_patches_and_raises_the_capacity_flag():
+    """the patch pool takes the LDS span that is dead when the sweeps start and no more: patches beyond it are dropped with the
+    capacity flag, like contacts beyond maxcon.  Forced here with a pool of 600 floats (MJH_PATCH_POOL_FLOATS): settled S24 piles
+    need 1500-3000."""
+    m = ms.scene("s24")
+    full = ms.Engine(m, 64); tab = full.load_s24(); full.step(300)
+    t, q, v, w = full.get_state(); assert (full.get_stats()[:, 3] & 2).sum() == 0
+    os.environ["MJH_PATCH_POOL_FLOATS"] = "600"
+    try:
+        e = ms.Engine(m, 64)
+    finally:
+        del os.environ["MJH_PATCH_POOL_FLOATS"]
+    for k in EP:
+        e.set_env_param(k, tab[k])
+    e.set_initial_qpos(tab["qpos"]); e.set_state(qpos=q, qvel=v, warmstart=w)
+    e.step(1)
+    st = e.get_stats()
+    assert (st[:, 3] & 2).sum() > 32, "most settled piles need more than 600 floats"
+    q1 = e.get_state()[1]
+    assert np.isfinite(q1).all()
+    e.step(100)                                    # boxes sink where their contacts were dropped, nothing worse
+    assert np.isfinite(e.get_state()[1]).all()
+    e.close(); full.close()
