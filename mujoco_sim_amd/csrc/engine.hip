@@ -342,10 +342,10 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       L.J = put((int)jsz); L.B = diagM ? L.J : put((int)jsz);
     }
     if (patch) {
-      // the pool: per patch of nr4 rows (a multiple of 4, at most 16) a 20-float record per row (J, f, aref, R, 1/AR_rr, AR_rr/2)
-      // + 16 floats per 4x4 tile of the lower triangle of AR: 24 .. 30 floats per row.  It takes the span of everything that
-      // is dead by then and no more (S24: 3948 floats against a largest observed need of about 3250; the row capacity at 30
-      // floats per row would be 7200); patches beyond it are dropped with the capacity flag, like contacts beyond maxcon
+      // the pool: per patch of nr4 rows (a multiple of 4, at most 16) a record per row (20 floats between two bodies, 12 on one
+      // body) + 16 floats per 4x4 tile of the lower triangle of AR: 16 .. 30 floats per row.  It takes the span of everything that
+      // is dead by then and no more (S24: 3948 floats; a 20 000-step soak of 4096 envs never fills it); patches beyond it are
+      // dropped with the capacity flag, like contacts beyond maxcon
       // The two small tables the sweep reads next to the pool (one descriptor per patch, one per schedule slot) sit in front
       // of it: that space (position-stage arrays, contact records) is dead when they are written, unlike the span's tail.
       M.pdesc = k1; M.pslot = k1 + ((M.maxcon + 3) / 4) * 4; M.pool = M.pslot + 4 * M.maxcon;

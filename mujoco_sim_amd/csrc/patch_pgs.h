@@ -27,14 +27,14 @@
 #define PD_DA(d) (((d) >> 16) & 31)
 #define PD_DB(d) (((d) >> 21) & 63)
 #define PD_STEPN4(d) (((d) >> 27) & 7)
-// layout of a patch of nr4 rows inside the pool (floats): one record of 20 per row,  J^ [12] | f, aref, R, 1/AR_qq | AR_qq / 2, pad [3]
-// (a lane reads its whole record off one address; stride 20 keeps 16 lanes' ds_read_b128 on distinct banks), then the 4 x 4 tiles
-// (i, c <= i) of the strictly lower triangle of -AR_qr / AR_qq, [tile][q & 3][4]
-#define PP_REC 20
-#define PP_PAR 12
-#define PP_HALF 16
-#define PP_TILES(nr4) (PP_REC * (nr4))
-#define PP_SIZE(n4) (80 * (n4) + 8 * (n4) * ((n4) + 1))
+// layout of a patch of nr4 rows inside the pool (floats): one record per row, then the 4 x 4 tiles (i, c <= i) of the strictly lower
+// triangle of -AR_qr / AR_qq, [tile][q & 3][4].  Record of a patch between two bodies, 20 floats:  f, aref, R, 1/AR_qq | J^ [12] |
+// AR_qq / 2, pad [3];  of a patch on one body (floor / wall contacts: most rows of a pile), 12 floats:  f, aref, R, 1/AR_qq | J^ [6] |
+// AR_qq / 2, pad.  A lane reads its record off one address; strides 20 and 12 keep 16 lanes' ds_read_b128 on distinct banks.
+#define PP_REC(two) ((two) ? 20 : 12)
+#define PP_HALF(two) ((two) ? 16 : 10)
+#define PP_TILES(two, nr4) (PP_REC(two) * (nr4))
+#define PP_SIZE(two, n4) (4 * PP_REC(two) * (n4) + 8 * (n4) * ((n4) + 1))
 #define PP_ZERO 20     // floats of zeros a lane outside a patch reads instead of a record
 
 // acc += y * (x of lane R of this lane's 16-lane row).  The _H form waits out the VALU-write -> DPP-read hazard of x.
@@ -92,7 +92,7 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags, int& swork) 
   const int pinfo = lane < npatch ? s_pinfo[lane] : 0;
   const int pnr = pinfo & 255, pn4 = (pnr + 3) >> 2, pkey = pinfo >> 8;
   const int pdA = (pkey >> 6) & 31, pdB = pkey & 63;
-  const int psize = lane < npatch ? PP_SIZE(pn4) : 0;
+  const int psize = lane < npatch ? PP_SIZE(pdB != 63, pn4) : 0;
   const int pend = wave_incl_scan_i(psize, lane);
   const int prowend = wave_incl_scan_i(lane < npatch ? 4 * pn4 : 0, lane);
   {   // patches that do not fit the pool (or the 256 rows staged below) are dropped with their contacts: capacity flag
@@ -184,12 +184,15 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags, int& swork) 
     const int m = mm[ps];
     if (m < 0 || ((m >> 10) & 63) >= npatch) continue;
     const int d = s_pdesc[(m >> 10) & 63], q = (m >> 16) & 15;
-    float* Rq = pool + PD_OFF(d) + PP_REC * q;
-    *(float4*)(Rq) = make_float4(jr[ps][0], jr[ps][1], jr[ps][2], jr[ps][3]);
-    *(float4*)(Rq + 4) = make_float4(jr[ps][4], jr[ps][5], jr[ps][6], jr[ps][7]);
-    *(float4*)(Rq + 8) = make_float4(jr[ps][8], jr[ps][9], jr[ps][10], jr[ps][11]);
-    *(float4*)(Rq + PP_PAR) = make_float4(pr[ps][0], pr[ps][1], pr[ps][2], 0.0f);
-    *(float4*)(Rq + PP_HALF) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const bool two = PD_DB(d) != 63;
+    float* Rq = pool + PD_OFF(d) + PP_REC(two) * q;
+    *(float4*)(Rq) = make_float4(pr[ps][0], pr[ps][1], pr[ps][2], 0.0f);
+    *(float4*)(Rq + 4) = make_float4(jr[ps][0], jr[ps][1], jr[ps][2], jr[ps][3]);
+    if (two) {
+      *(float4*)(Rq + 8) = make_float4(jr[ps][4], jr[ps][5], jr[ps][6], jr[ps][7]);
+      *(float4*)(Rq + 12) = make_float4(jr[ps][8], jr[ps][9], jr[ps][10], jr[ps][11]);
+      *(float4*)(Rq + 16) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    } else *(float4*)(Rq + 8) = make_float4(jr[ps][4], jr[ps][5], 0.0f, 0.0f);
   }
   WSYNC();
   // ---- AR = J^ J^T + R of every patch, four patches at a time (lanes = rows): strictly lower triangle in 4 x 4 tiles
@@ -199,11 +202,15 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags, int& swork) 
     const int pt = p0 + rho;
     const int d = pt < npatch ? s_pdesc[pt] : 0, nr4 = PD_N4(d) << 2;
     const bool on = q < nr4;
+    const bool two = PD_DB(d) != 63;
     float* P = pool + PD_OFF(d);
-    float* Rq = P + PP_REC * q;
+    float* Rq = P + PP_REC(two) * q;
     const float* Rz = on ? Rq : zero;
-    const float4 j0 = *(const float4*)(Rz), j1 = *(const float4*)(Rz + 4), j2 = *(const float4*)(Rz + 8);
-    const float R = Rz[PP_PAR + 2];
+    const float4 j0 = *(const float4*)(Rz + 4);
+    float4 j1 = *(const float4*)(Rz + 8);
+    const float4 j2 = *(const float4*)((on & two) ? Rq + 12 : zero);
+    if (!two) { j1.z = 0; j1.w = 0; }
+    const float R = Rz[2];
     float Jv[12] = {j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w, j2.x, j2.y, j2.z, j2.w};
     asm volatile("" : "+v"(Jv[0]), "+v"(Jv[1]), "+v"(Jv[2]), "+v"(Jv[3]), "+v"(Jv[4]), "+v"(Jv[5]));
     asm volatile("" : "+v"(Jv[6]), "+v"(Jv[7]), "+v"(Jv[8]), "+v"(Jv[9]), "+v"(Jv[10]), "+v"(Jv[11]));
@@ -223,10 +230,10 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags, int& swork) 
     const float ARqq = diag + R;
     if (on) {
       const float inv = ARqq < MJ_MINVAL ? 0.0f : 1.0f / ARqq, ninv = -inv;
-      Rq[PP_PAR + 3] = inv;
-      Rq[PP_HALF] = 0.5f * ARqq;
+      Rq[3] = inv;
+      Rq[PP_HALF(two)] = 0.5f * ARqq;
       // the tiles hold -AR_qr / AR_qq: the sweep carries t_q = -res_q / AR_qq instead of the residual itself
-      float* T = P + PP_TILES(nr4) + ((ti * (ti + 1)) >> 1) * 16 + (q & 3) * 4;
+      float* T = P + PP_TILES(two, nr4) + ((ti * (ti + 1)) >> 1) * 16 + (q & 3) * 4;
 #pragma unroll
       for (int c = 0; c < 4; c++)
         if (c <= ti) *(float4*)(T + 16 * c) = make_float4(4*c < q ? ninv * acc[4*c] : 0.0f, 4*c + 1 < q ? ninv * acc[4*c + 1] : 0.0f,
@@ -255,7 +262,7 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
   float* const zero = A.lds + A.zero;
   float* const ahat = A.lds + A.ahat;
   // per-lane constants of the operand addresses
-  const int recoff = PP_REC * q, tileoff = ((ti * (ti + 1)) >> 1) * 16 + (q & 3) * 4;
+  const int recoff2 = PP_REC(true) * q, recoff1 = PP_REC(false) * q, tileoff = ((ti * (ti + 1)) >> 1) * 16 + (q & 3) * 4;
   const int gq = q < 6 ? q : q - 6;                        // u = J^ a^: lanes 0..5 carry the dofs of body A, 6..11 those of body B
   const bool gA = q < 6, gB = q >= 6 && q < 12;
   const int addoff = (q & 4) ? 3 : 0;                      // a^ += J^T delta: the first lane of quad j adds dofs 3j .. 3j+2
@@ -265,11 +272,14 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
     const int nr4 = PD_N4(d) << 2, dA = PD_DA(d), dB = PD_DB(d);
     const bool on = q < nr4, hasB = dB != 63;
     float* P = pool + PD_OFF(d);
-    o.rec = on ? P + recoff : zero;
-    o.J0 = *(const float4*)(o.rec); o.J1 = *(const float4*)(o.rec + 4); o.J2 = *(const float4*)(o.rec + 8);
-    o.P = *(const float4*)(o.rec + PP_PAR);
-    o.half = o.rec[PP_HALF];
-    const float* T = P + PP_TILES(nr4) + tileoff;
+    o.rec = on ? P + (hasB ? recoff2 : recoff1) : zero;
+    const float* rec2 = (on & hasB) ? o.rec : zero;          // the second half of a two-body record
+    o.P = *(const float4*)(o.rec); o.J0 = *(const float4*)(o.rec + 4); o.J1 = *(const float4*)(o.rec + 8);
+    o.J2 = *(const float4*)(rec2 + 12);
+    const float h2 = rec2[16];
+    o.half = hasB ? h2 : o.J1.z;
+    if (!hasB) { o.J1.z = 0; o.J1.w = 0; }
+    const float* T = P + PP_TILES(hasB, nr4) + tileoff;
     o.A0 = *(const float4*)(on ? T : zero);
     o.A1 = *(const float4*)((on & (ti >= 1)) ? T + 16 : zero);
     o.A2 = *(const float4*)((on & (ti >= 2)) ? T + 32 : zero);
@@ -309,7 +319,7 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
       }
     }
     asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));     // every lane's own update (its t is final: header comment)
-    o.rec[PP_PAR] = f + dl;
+    o.rec[0] = f + dl;
     impl += (o.half * dl) * (2.0f * tt - dl);     // cost decrease  -(delta res + AR_qq delta^2 / 2),  res = -t AR_qq
     // a^ += J^T delta: 12 sums over the 16 lanes of the row.  Folded while they are reduced: across the quads first (the DPP bank
     // mask picks which quads keep which half), then inside the quads; quad j ends up with the sums of dofs 3j .. 3j+2.
