@@ -46,7 +46,7 @@
 struct PatchArgs {
   float* lds;                    // dynamic LDS base
   int pool, pool_floats, pdesc, pslot, zero, ahat;   // float offsets: pool, the two live tables, 4 zero floats, the acceleration [nv]
-  const int* blki; const float* blkf; const float* J; const float* qLDinv;   // block tables (inside the pool span: consumed first)
+  const int* blki; const float* blkf; const float* J; const float* qLDinv;   // block tables (inside the pool span: consumed first); qLDinv: M^-1/2 per dof
   int nblk, nv, maxcon;
 };
 
@@ -170,10 +170,10 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags, int& swork) 
           const int k = sw ? (kp < 6 ? kp + 6 : kp - 6) : kp;
           const float4 jb = *(const float4*)(Jb + 4 * k);
           const float v = single ? jb.x : jb.x + c * (kk == 1 ? jb.y : (kk == 2 ? jb.z : jb.w));
-          jr[ps][kp] = v * sqrtf(A.qLDinv[kp < 6 ? dA + kp : dB + kp - 6]);
+          jr[ps][kp] = v * A.qLDinv[kp < 6 ? dA + kp : dB + kp - 6];
         }
         const float* bf = A.blkf + b * BLKF_STRIDE;
-        pr[ps][0] = bf[BF_F + r]; pr[ps][1] = single ? bf[BF_AREF] : bf[BF_AREF] + c * bf[BF_AREF + kk]; pr[ps][2] = bf[0];
+        pr[ps][0] = 0.0f; pr[ps][1] = single ? bf[BF_AREF] : bf[BF_AREF] + c * bf[BF_AREF + kk]; pr[ps][2] = bf[0];   // (forces: patch_warmstart)
       }
     }
   }
@@ -248,9 +248,104 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags, int& swork) 
 #define PP_ROW(r, ar) "v_max_f32 %[d], %[t], %[nf]\n\ts_nop 1\n\tv_fmac_f32_dpp %[t], %[d], " ar " row_newbcast:" #r " row_mask:0xf bank_mask:0xf\n\t"
 #define PP_ROWS4(r0, r1, r2, r3, T) asm volatile(PP_ROW(r0, "%[a0]") PP_ROW(r1, "%[a1]") PP_ROW(r2, "%[a2]") PP_ROW(r3, "%[a3]") \
     : [t] "+v"(tt), [d] "=&v"(dl) : [nf] "v"(nf), [a0] "v"(T.x), [a1] "v"(T.y), [a2] "v"(T.z), [a3] "v"(T.w))
+
 // dst = src + (src of the lane `ror` places down the row), written in the quads of bank mask bm only
 #define PP_ADD_ROR(dst, src, ror, bm) "v_add_f32_dpp " dst ", " src ", " src " row_ror:" #ror " row_mask:0xf bank_mask:" #bm "\n\t"
 #define PP_ADD_QP(dst, a, b, c, d) "v_add_f32_dpp " dst ", " dst ", " dst " quad_perm:[" #a "," #b "," #c "," #d "] row_mask:0xf bank_mask:0xf\n\t"
+
+// sum_k J_k * (al of lane k of this lane's 16-lane row), k = 0..11: a row of J^ times the dof vector held by lanes 0..11
+DEV float pp_dot12(const float al, const float4& J0, const float4& J1, const float4& J2) {
+  float u;
+  asm volatile("v_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f32_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f32_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f32_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f32_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f32_dpp %0, %1, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f32_dpp %0, %1, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f32_dpp %0, %1, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f32_dpp %0, %1, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f32_dpp %0, %1, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f32_dpp %0, %1, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf"
+               : "=&v"(u) : "v"(al), "v"(J0.x), "v"(J0.y), "v"(J0.z), "v"(J0.w), "v"(J1.x), "v"(J1.y), "v"(J1.z), "v"(J1.w),
+                 "v"(J2.x), "v"(J2.y), "v"(J2.z), "v"(J2.w));
+  return u;
+}
+// J^T x over the 16 lanes of a row: 12 sums, folded while they are reduced — across the quads first (the DPP bank mask picks which
+// quads keep which half), then inside the quads; every lane of quad j ends up with the sums of dofs 3j .. 3j+2 in b[0..2].
+DEV void pp_jt(const float4& J0, const float4& J1, const float4& J2, const float x, float* b) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f d2 = {x, x};
+  const v2f p01 = v2f{J0.x, J0.y} * d2, p23 = v2f{J0.z, J0.w} * d2, p45 = v2f{J1.x, J1.y} * d2;
+  const v2f p67 = v2f{J1.z, J1.w} * d2, p89 = v2f{J2.x, J2.y} * d2, pab = v2f{J2.z, J2.w} * d2;
+  float r0, r1, r2, r3, r4, r5;
+  asm volatile("s_nop 1\n\t"
+               PP_ADD_ROR("%0", "%6", 8, 0x3) PP_ADD_ROR("%1", "%7", 8, 0x3) PP_ADD_ROR("%2", "%8", 8, 0x3)
+               PP_ADD_ROR("%3", "%9", 8, 0x3) PP_ADD_ROR("%4", "%10", 8, 0x3) PP_ADD_ROR("%5", "%11", 8, 0x3)
+               PP_ADD_ROR("%0", "%12", 8, 0xc) PP_ADD_ROR("%1", "%13", 8, 0xc) PP_ADD_ROR("%2", "%14", 8, 0xc)
+               PP_ADD_ROR("%3", "%15", 8, 0xc) PP_ADD_ROR("%4", "%16", 8, 0xc) PP_ADD_ROR("%5", "%17", 8, 0xc)
+               : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5)
+               : "v"(p01.x), "v"(p01.y), "v"(p23.x), "v"(p23.y), "v"(p45.x), "v"(p45.y), "v"(p67.x), "v"(p67.y), "v"(p89.x), "v"(p89.y), "v"(pab.x), "v"(pab.y));
+  asm volatile("s_nop 1\n\t"
+               PP_ADD_ROR("%0", "%3", 12, 0x5) PP_ADD_ROR("%1", "%4", 12, 0x5) PP_ADD_ROR("%2", "%5", 12, 0x5)
+               PP_ADD_ROR("%0", "%6", 4, 0xa) PP_ADD_ROR("%1", "%7", 4, 0xa) PP_ADD_ROR("%2", "%8", 4, 0xa)
+               PP_ADD_QP("%0", 1, 0, 3, 2) PP_ADD_QP("%1", 1, 0, 3, 2) PP_ADD_QP("%2", 1, 0, 3, 2)
+               PP_ADD_QP("%0", 2, 3, 0, 1) PP_ADD_QP("%1", 2, 3, 0, 1) PP_ADD_QP("%2", 2, 3, 0, 1)
+               : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]) : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4), "v"(r5));
+}
+
+// Warm start in patch form (mj_fwdConstraint): the forces implied by qacc_warmstart, f = max(0, -(J a_ws - aref) / R), kept if
+// their dual cost  sum f (1/2 (J da + R f) + J a_smooth - aref),  da = M^-1 J^T f,  is not positive.  what / ashat: M^1/2 qacc_warmstart
+// and M^1/2 qacc_smooth (LDS vectors, float offsets); dahat: zeroed on entry, M^1/2 da on exit (zero again if the forces were dropped).
+DEV void patch_warmstart(const PatchArgs& A, const int lane, const int nstep, const int what, const int ashat, const int dahat) {
+  const int rho = lane >> 4, q = lane & 15;
+  const int* s_pslot = (const int*)(A.lds + A.pslot) + rho;
+  float* const pool = A.lds + A.pool;
+  float* const zero = A.lds + A.zero;
+  const int recoff2 = PP_REC(true) * q, recoff1 = PP_REC(false) * q;
+  const int gq = q < 6 ? q : q - 6; const bool gA = q < 6, gB = q >= 6 && q < 12;
+  const int addoff = (q & 4) ? 3 : 0; const bool addB = q >= 8, adder = (q & 3) == 0;
+  struct Row { float4 P, J0, J1, J2; float* rec; int gidx, aidx; };     // gidx: dof this lane carries (-1: none), aidx: first dof it adds to
+  auto row = [&](const int t) __attribute__((always_inline)) {
+    Row o;
+    const int d = s_pslot[4 * t];
+    const int nr4 = PD_N4(d) << 2, dA = PD_DA(d), dB = PD_DB(d);
+    const bool on = q < nr4, hasB = dB != 63;
+    o.rec = on ? pool + PD_OFF(d) + (hasB ? recoff2 : recoff1) : zero;
+    const float* rec2 = (on & hasB) ? o.rec : zero;
+    o.P = *(const float4*)(o.rec); o.J0 = *(const float4*)(o.rec + 4); o.J1 = *(const float4*)(o.rec + 8); o.J2 = *(const float4*)(rec2 + 12);
+    if (!hasB) { o.J1.z = 0; o.J1.w = 0; }
+    o.gidx = (gA | (gB & hasB)) ? (gA ? dA : dB) + gq : -1;
+    o.aidx = ((addB & hasB) ? dB : dA) + addoff;
+    return o;
+  };
+  auto gather = [&](const int vec, const int gidx) __attribute__((always_inline)) { return *(gidx >= 0 ? A.lds + vec + gidx : zero); };
+  for (int t = 0; t < nstep; t++) {
+    Row o = row(t);
+    const float jar = pp_dot12(gather(what, o.gidx), o.J0, o.J1, o.J2) - o.P.y;
+    const float f = (jar < 0.0f && o.P.z > 0.0f) ? -jar / o.P.z : 0.0f;
+    o.rec[0] = f;
+    float b[3];
+    pp_jt(o.J0, o.J1, o.J2, f, b);
+    if (adder) { float* pd = A.lds + dahat + o.aidx; atomicAdd(pd, b[0]); atomicAdd(pd + 1, b[1]); atomicAdd(pd + 2, b[2]); }
+  }
+  WSYNC();
+  float cost = 0;
+  for (int t = 0; t < nstep; t++) {
+    Row o = row(t);
+    const float jda = pp_dot12(gather(dahat, o.gidx), o.J0, o.J1, o.J2);
+    const float bb = pp_dot12(gather(ashat, o.gidx), o.J0, o.J1, o.J2) - o.P.y;
+    const float f = o.P.x;
+    cost += f * (0.5f * (jda + o.P.z * f) + bb);
+  }
+  cost = wave_sum<4>(cost);
+  if (cost > 0.0f) {
+    for (int t = 0; t < nstep; t++) { Row o = row(t); o.rec[0] = 0.0f; }
+    for (int d = lane; d < A.nv; d += 64) A.lds[dahat + d] = 0.0f;
+  }
+  WSYNC();
+}
 
 struct PatchOps { float4 J0, J1, J2, P, A0, A1, A2, A3; float half; float* rec; const float* pa; float* padd; int nr4; };   // nr4: rows of the STEP's longest patch
 
@@ -293,21 +388,7 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
   // requested, so that waiting for it does not wait for them)
   auto solve = [&](PatchOps& o, const float al, float& impl) __attribute__((always_inline)) {
     const int nmax = __builtin_amdgcn_readfirstlane(o.nr4);      // rows of the step's longest patch
-    float u;
-    asm volatile("v_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %0, %1, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %0, %1, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %0, %1, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %0, %1, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %0, %1, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %0, %1, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf"
-                 : "=&v"(u) : "v"(al), "v"(o.J0.x), "v"(o.J0.y), "v"(o.J0.z), "v"(o.J0.w), "v"(o.J1.x), "v"(o.J1.y), "v"(o.J1.z), "v"(o.J1.w),
-                   "v"(o.J2.x), "v"(o.J2.y), "v"(o.J2.z), "v"(o.J2.w));
+    const float u = pp_dot12(al, o.J0, o.J1, o.J2);
     const float f = o.P.x, nf = -f;
     float tt = ((u - o.P.y) + o.P.z * f) * -o.P.w, dl;
     PP_ROWS4(0, 1, 2, 3, o.A0);
@@ -321,27 +402,10 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
     asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));     // every lane's own update (its t is final: header comment)
     o.rec[0] = f + dl;
     impl += (o.half * dl) * (2.0f * tt - dl);     // cost decrease  -(delta res + AR_qq delta^2 / 2),  res = -t AR_qq
-    // a^ += J^T delta: 12 sums over the 16 lanes of the row.  Folded while they are reduced: across the quads first (the DPP bank
-    // mask picks which quads keep which half), then inside the quads; quad j ends up with the sums of dofs 3j .. 3j+2.
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    const v2f d2 = {dl, dl};
-    const v2f p01 = v2f{o.J0.x, o.J0.y} * d2, p23 = v2f{o.J0.z, o.J0.w} * d2, p45 = v2f{o.J1.x, o.J1.y} * d2;
-    const v2f p67 = v2f{o.J1.z, o.J1.w} * d2, p89 = v2f{o.J2.x, o.J2.y} * d2, pab = v2f{o.J2.z, o.J2.w} * d2;
-    float r0, r1, r2, r3, r4, r5, b0, b1, b2;
-    asm volatile("s_nop 1\n\t"
-                 PP_ADD_ROR("%0", "%6", 8, 0x3) PP_ADD_ROR("%1", "%7", 8, 0x3) PP_ADD_ROR("%2", "%8", 8, 0x3)
-                 PP_ADD_ROR("%3", "%9", 8, 0x3) PP_ADD_ROR("%4", "%10", 8, 0x3) PP_ADD_ROR("%5", "%11", 8, 0x3)
-                 PP_ADD_ROR("%0", "%12", 8, 0xc) PP_ADD_ROR("%1", "%13", 8, 0xc) PP_ADD_ROR("%2", "%14", 8, 0xc)
-                 PP_ADD_ROR("%3", "%15", 8, 0xc) PP_ADD_ROR("%4", "%16", 8, 0xc) PP_ADD_ROR("%5", "%17", 8, 0xc)
-                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5)
-                 : "v"(p01.x), "v"(p01.y), "v"(p23.x), "v"(p23.y), "v"(p45.x), "v"(p45.y), "v"(p67.x), "v"(p67.y), "v"(p89.x), "v"(p89.y), "v"(pab.x), "v"(pab.y));
-    asm volatile("s_nop 1\n\t"
-                 PP_ADD_ROR("%0", "%3", 12, 0x5) PP_ADD_ROR("%1", "%4", 12, 0x5) PP_ADD_ROR("%2", "%5", 12, 0x5)
-                 PP_ADD_ROR("%0", "%6", 4, 0xa) PP_ADD_ROR("%1", "%7", 4, 0xa) PP_ADD_ROR("%2", "%8", 4, 0xa)
-                 PP_ADD_QP("%0", 1, 0, 3, 2) PP_ADD_QP("%1", 1, 0, 3, 2) PP_ADD_QP("%2", 1, 0, 3, 2)
-                 PP_ADD_QP("%0", 2, 3, 0, 1) PP_ADD_QP("%1", 2, 3, 0, 1) PP_ADD_QP("%2", 2, 3, 0, 1)
-                 : "=&v"(b0), "=&v"(b1), "=&v"(b2) : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4), "v"(r5));
-    if (adder) { atomicAdd(o.padd, b0); atomicAdd(o.padd + 1, b1); atomicAdd(o.padd + 2, b2); }
+    // a^ += J^T delta: the first lane of quad j adds dofs 3j .. 3j+2
+    float b[3];
+    pp_jt(o.J0, o.J1, o.J2, dl, b);
+    if (adder) { atomicAdd(o.padd, b[0]); atomicAdd(o.padd + 1, b[1]); atomicAdd(o.padd + 2, b[2]); }
   };
   int niter = 0;
   if (nstep == 1) {

@@ -1720,7 +1720,9 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         // ---- warm start (mj_fwdConstraint): forces implied by qacc_warmstart, kept if their dual cost < 0
         const bool warm = !(M.disableflags & MJH_DSBL_WARMSTART);
         bool zero_f = !warm;
-        if (warm) {
+        bool patch_ws = false;   // contact-patch sweep: the warm start runs in patch form, after the patches are built
+        if constexpr (DIAGM && NROW <= 2) patch_ws = M.patch != 0;
+        if (warm && !patch_ws) {
           base_dots(s_ws, s_bv);
           forces_from(s_bv, true);
           accum_T(true, s_phi, s_tmpv);               // da = M^-1 J^T f
@@ -1743,7 +1745,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           cost = wave_sum<4>(cost);
           zero_f = cost > 0;
         }
-        if (zero_f) {
+        if (zero_f && !patch_ws) {
           for (int b = lane; b < nblk; b += 64) { float* bf = s_blkf + b * BLKF_STRIDE; for (int r = 0; r < 6; r++) bf[BF_F + r] = 0; }
           for (int d = lane; d < nv; d += 64) s_tmpv[d] = 0;
         }
@@ -1756,15 +1758,23 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             patched = true;
             PatchArgs pa;
             pa.lds = lds; pa.pool = M.pool; pa.pool_floats = M.pool_floats; pa.pdesc = M.pdesc; pa.pslot = M.pslot; pa.zero = L.zero; pa.ahat = L.qacc;
-            pa.blki = s_blki_i; pa.blkf = s_blkf; pa.J = s_J; pa.qLDinv = s_qLDinv; pa.nblk = nblk; pa.nv = nv; pa.maxcon = M.maxcon;
-            for (int d = lane; d < nv; d += 64) s_qacc[d] = (s_asmooth[d] + s_tmpv[d]) / sqrtf(s_qLDinv[d]);
+            // M^-1/2 per dof (s_bias is dead since the smooth force was formed), M^1/2 qacc_smooth, M^1/2 qacc_warmstart, da = 0
+            for (int d = lane; d < nv; d += 64) {
+              const float sq = sqrtf(s_qLDinv[d]);
+              s_bias[d] = sq; s_qacc[d] = s_asmooth[d] / sq; s_tmpv2[d] = s_ws[d] / sq; s_tmpv[d] = 0;
+            }
+            WSYNC();
+            pa.blki = s_blki_i; pa.blkf = s_blkf; pa.J = s_J; pa.qLDinv = s_bias; pa.nblk = nblk; pa.nv = nv; pa.maxcon = M.maxcon;
             int swork = 0;
             const int nstep = patch_build(pa, lane, flags, swork);
+            if (warm) patch_warmstart(pa, lane, nstep, L.tmpv2, L.qacc, L.tmpv);
+            for (int d = lane; d < nv; d += 64) s_qacc[d] += s_tmpv[d];       // a^ = M^1/2 (qacc_smooth + M^-1 J^T f)
+            WSYNC();
             PROF(12);
             niter = patch_sweep(pa, lane, nstep, M.iterations, M.tolerance, 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1)));
             cost_hint = ((niter * swork) >> 1) + 1;   // (100 sweeps x 5 steps of 40 -> 10000 -> bucket 156 of the launch order's 256)
             WSYNC();
-            for (int d = lane; d < nv; d += 64) { const float qa = s_qacc[d] * sqrtf(s_qLDinv[d]); s_qacc[d] = qa; s_ws[d] = qa; }
+            for (int d = lane; d < nv; d += 64) { const float qa = s_qacc[d] * s_bias[d]; s_qacc[d] = qa; s_ws[d] = qa; }
             PROF(13);
             WSYNC();
             // qfrc_constraint = M (qacc - qacc_smooth): the base rows are gone
