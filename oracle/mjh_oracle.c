@@ -1374,7 +1374,7 @@ static void block_trees(const orc_data* d, int row, int* t1, int* t2) {
       *t2 = m->body_treeid[m->geom_bodyid[d->contact[id].geom2]];
   }
 }
-/* 0 (default): the independent-pair / independent-group order above, shared with the device;
+/* 0 (default): the device's order — contact patches (m_patch_order below) or the independent-pair / independent-group order above;
  * 1: plain constraint-row order, the order mj_solPGS visits the rows in [UPSTREAM].  Both are Gauss-Seidel on the same dual
  * problem: they agree at convergence; where the sweep cap ends the iteration first (settled S24 piles run into the default
  * 100 sweeps at tolerance 1e-8) the iterates differ, and tests/test_oracle_pinning.py measures by how much. */
