@@ -59,6 +59,7 @@ struct mjh_engine {
   bool lpt = true;
   bool split3 = true;         // many-body layout: three-launch step (MJH_SPLIT3=0: fused kernel)
   bool order_valid = false;   // d_order holds a full-range permutation (split API); mjh_step sorts per cohort
+  long order_age = 0; int order_G = 0;   // mjh_step renews its per-cohort sorts every MJH_ORDER_EVERY-th step; order_G: cohort count they were made for (-1: none)
   // Cohorts: mjh_step() splits the envs into ncohort contiguous groups, each stepped on its own stream, so that the
   // low-occupancy tail of one cohort's step kernel overlaps the next cohort's (or its own next step's) bulk.  The
   // caller's stream forks into the cohort streams at mjh_step and joins them again at the next other API call.
@@ -370,6 +371,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
 // few environments per CU (pr2 / tiago / hsrb4s / ridgeback_panda: 1.6x - 5x); a working set beyond one CU's LDS has no choice.
 //   policy 0 (default): many-body layout above MJH_LDS_RESIDENT_MAX bytes;  1: LDS-resident whenever it fits;  2: many-body whenever possible
 #define MJH_LDS_RESIDENT_MAX (24 * 1024)
+#define MJH_ORDER_EVERY 8
 static int g_layout_policy = 0;
 extern "C" void mjh_set_layout_policy(int policy) { g_layout_policy = policy < 0 || policy > 2 ? 0 : policy; }
 static void derive_fitting(const mjh_model* m, HostPack& hp) {
@@ -517,7 +519,7 @@ static int launch_lpt(mjh_engine* e, int ph, int xflags, bool resort) {
     if (!e->d_order) { int rc = dev_alloc(e, &e->d_order, (size_t)e->nenv); if (rc) return rc; e->order_valid = false; }
     if (resort || !e->order_valid) {
       hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, e->stream, (const int*)e->S.stats, e->d_order, 0, e->nenv);
-      e->order_valid = true;
+      e->order_valid = true; e->order_G = -1;   // (a full-range sort: mjh_step's cohorts must sort their own ranges again)
     }
   }
   StateGuard guard(&e->S);
@@ -551,11 +553,15 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
   const int ph = PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0);
   StateGuard guard(&e->S);
   if (e->lpt && e->d_order) e->S.env_order = e->d_order;
-  for (int s = 0; s < nsteps && !rc; s++) {   // one launch per step and cohort (commands are consumed by the first one)
+  for (int s = 0; s < nsteps && !rc; s++, e->order_age++, e->order_G = G) {   // one launch per step and cohort (commands are consumed by the first one)
     for (int g = 0; g < G && !rc; g++) {
       const int g0 = (int)((long long)e->nenv * g / G), g1 = (int)((long long)e->nenv * (g + 1) / G);
       hipStream_t st = G > 1 ? e->cstream[g] : e->stream;
-      if (e->S.env_order)   // dispatch the envs with the most solver work first (shorter kernel tail)
+      // dispatch the envs with the most solver work first (shorter kernel tail).  An env's cost drifts slowly, so the sort is
+      // renewed every MJH_ORDER_EVERY-th step only: its 10 us sit in front of every step launch of the cohort's stream, which
+      // is 9 % of a step of the small configs (C3, C5: 0.10 ms kernels)
+      static const int order_every = getenv("MJH_ORDER_EVERY") ? std::max(1, atoi(getenv("MJH_ORDER_EVERY"))) : MJH_ORDER_EVERY;
+      if (e->S.env_order && (e->order_G != G || e->order_age % order_every == 0))
         hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, st, (const int*)e->S.stats, e->d_order, g0, g1 - g0);
       if (e->pd_on) { rc = launch_pd(e, st, g0, g1 - g0); if (rc) break; }
       hipEvent_t ta = nullptr, tb = nullptr;
@@ -1220,7 +1226,7 @@ extern "C" int mjh_debug_stage_raw(mjh_engine* e, int with_inverse, long long* o
     e->S.x_prof = buf;
     if (e->lpt && e->d_order) {
       hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, e->stream, (const int*)e->S.stats, e->d_order, 0, e->nenv);
-      e->S.env_order = e->d_order; e->order_valid = true;
+      e->S.env_order = e->d_order; e->order_valid = true; e->order_G = -1;
     }
     rc = launch(e, 0, e->nenv, 1, PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0), XF_PROF);
   }
