@@ -69,6 +69,8 @@ struct DState {
   // optional per-env inputs / outputs of the EXTRA instances (null until used): Cartesian forces on bodies [nenv][xfrc_stride],
   // mocap poses [nenv][7*nmocap] (pos3 quat4), sensor outputs [nenv][3*nsensor]
   float *xfrc_applied, *mocap, *sensordata; int xfrc_stride;
+  // in-engine PD law (mjh_set_pd_controller) evaluated by the controller stage of a fused step: targets [nenv][nv] or null, gains
+  const float* pd_target; float pd_kp, pd_kd;
   // many-body models (nv > 64): per-env pools that do not fit LDS (contacts, blocks, Jacobians) live here; a negative
   // Lay offset -1-k addresses float k of the env's slice
   float* gscratch; long long gstride;

@@ -553,6 +553,7 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
   const int ph = PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0);
   StateGuard guard(&e->S);
   if (e->lpt && e->d_order) e->S.env_order = e->d_order;
+  if (e->pd_on && e->pd_target) { e->S.pd_target = e->pd_target; e->S.pd_kp = e->pd_kp; e->S.pd_kd = e->pd_kd; }   // the fused step evaluates the PD law itself
   for (int s = 0; s < nsteps && !rc; s++, e->order_age++, e->order_G = G) {   // one launch per step and cohort (commands are consumed by the first one)
     for (int g = 0; g < G && !rc; g++) {
       const int g0 = (int)((long long)e->nenv * g / G), g1 = (int)((long long)e->nenv * (g + 1) / G);
@@ -563,7 +564,6 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
       static const int order_every = getenv("MJH_ORDER_EVERY") ? std::max(1, atoi(getenv("MJH_ORDER_EVERY"))) : MJH_ORDER_EVERY;
       if (e->S.env_order && (e->order_G != G || e->order_age % order_every == 0))
         hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, st, (const int*)e->S.stats, e->d_order, g0, g1 - g0);
-      if (e->pd_on) { rc = launch_pd(e, st, g0, g1 - g0); if (rc) break; }
       hipEvent_t ta = nullptr, tb = nullptr;
       if (e->timing && (e->timing_count++ % e->timing_stride) == 0) {
         if (e->tev_used == e->tev.size()) { hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); e->tev.push_back({a, b}); }

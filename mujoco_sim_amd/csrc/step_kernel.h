@@ -1617,6 +1617,13 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       bool anydd = false, anydq = false;
       for (int d = lane; d < nv; d += 64) {
         float a = (step == 0) ? S.ddq[vrow + d] : 0.0f, v = (step == 0) ? S.dq[vrow + d] : 0.0f;
+        if (S.pd_target) {   // in-engine PD law (mjh_set_pd_controller): the command of this step, as mjh_pd_kernel would have written it
+          const int j = dof_jntid[d], jt = jnt_type[j];
+          if (jt == MJH_JNT_HINGE || jt == MJH_JNT_SLIDE) {
+            a = S.pd_kp * (S.pd_target[(size_t)env * nv + d] - s_qpos[jnt_qposadr[j]]) - S.pd_kd * s_qvel[d];
+            S.ddq[vrow + d] = a;
+          }
+        }
         s_tmpv[d] = a; s_tmpv2[d] = v; anydd |= a != 0; anydq |= fabsf(v) > MJ_MINVAL;
         s_applied[d] = 0; s_qvref[d] = s_qvel[d];
       }
