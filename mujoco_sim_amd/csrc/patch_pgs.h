@@ -27,6 +27,7 @@
 #define PD_DA(d) (((d) >> 16) & 31)
 #define PD_DB(d) (((d) >> 21) & 63)
 #define PD_STEPN4(d) (((d) >> 27) & 7)
+#define PD_STEPONE(d) (((d) >> 30) & 1)   // every patch of the step is on one body: 6 dofs instead of 12 in the two products
 // layout of a patch of nr4 rows inside the pool (floats): one record per row, then the 4 x 4 tiles (i, c <= i) of the strictly lower
 // triangle of -AR_qr / AR_qq, [tile][q & 3][4].  Record of a patch between two bodies, 20 floats:  f, aref, R, 1/AR_qq | J^ [12] |
 // AR_qq / 2, pad [3];  of a patch on one body (floor / wall contacts: most rows of a pile), 12 floats:  f, aref, R, 1/AR_qq | J^ [6] |
@@ -122,7 +123,7 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags, int& swork) 
       used |= 1ull << i;
       int gmask = __builtin_amdgcn_readlane(tmask, i), cnt = 1;
       const int di = __builtin_amdgcn_readlane(desc, i);
-      int n4max = PD_N4(di);
+      int n4max = PD_N4(di), allone = PD_DB(di) == 63;
       if (lane == 0) s_pslot[4 * nstep] = di;
       while (cnt < 4) {
         const bool cand = lane < npatch && lane > i && !((used >> lane) & 1ull) && !(tmask & gmask);
@@ -132,13 +133,13 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags, int& swork) 
         used |= 1ull << q; gmask |= __builtin_amdgcn_readlane(tmask, q);
         const int dq = __builtin_amdgcn_readlane(desc, q);
         if (lane == 0) s_pslot[4 * nstep + cnt] = dq;
-        n4max = max(n4max, PD_N4(dq));
+        n4max = max(n4max, PD_N4(dq)); allone &= PD_DB(dq) == 63;
         cnt++;
       }
       swork += 24 + 4 * n4max;
       if (lane == 0) {
         for (int c = cnt; c < 4; c++) s_pslot[4 * nstep + c] = 0;
-        for (int c = 0; c < 4; c++) s_pslot[4 * nstep + c] |= n4max << 27;
+        for (int c = 0; c < 4; c++) s_pslot[4 * nstep + c] |= (n4max << 27) | (allone << 30);
       }
       nstep++;
     }
@@ -295,6 +296,34 @@ DEV void pp_jt(const float4& J0, const float4& J1, const float4& J2, const float
                : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]) : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4), "v"(r5));
 }
 
+// the same two products for a step whose patches all sit on ONE body: 6 dofs
+DEV float pp_dot6(const float al, const float4& J0, const float4& J1) {
+  float u;
+  asm volatile("v_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f32_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f32_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f32_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f32_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf"
+               : "=&v"(u) : "v"(al), "v"(J0.x), "v"(J0.y), "v"(J0.z), "v"(J0.w), "v"(J1.x), "v"(J1.y));
+  return u;
+}
+// 6 sums over the 16 lanes: the even quads end up with dofs 0..2, the odd quads with dofs 3..5
+DEV void pp_jt6(const float4& J0, const float4& J1, const float x, float* b) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f d2 = {x, x};
+  const v2f p01 = v2f{J0.x, J0.y} * d2, p23 = v2f{J0.z, J0.w} * d2, p45 = v2f{J1.x, J1.y} * d2;
+  asm volatile("s_nop 1\n\t"
+               PP_ADD_ROR("%0", "%3", 12, 0x5) PP_ADD_ROR("%1", "%4", 12, 0x5) PP_ADD_ROR("%2", "%5", 12, 0x5)
+               PP_ADD_ROR("%0", "%6", 4, 0xa) PP_ADD_ROR("%1", "%7", 4, 0xa) PP_ADD_ROR("%2", "%8", 4, 0xa)
+               "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               PP_ADD_QP("%0", 1, 0, 3, 2) PP_ADD_QP("%1", 1, 0, 3, 2) PP_ADD_QP("%2", 1, 0, 3, 2)
+               PP_ADD_QP("%0", 2, 3, 0, 1) PP_ADD_QP("%1", 2, 3, 0, 1) PP_ADD_QP("%2", 2, 3, 0, 1)
+               : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]) : "v"(p01.x), "v"(p01.y), "v"(p23.x), "v"(p23.y), "v"(p45.x), "v"(p45.y));
+}
+
 // Warm start in patch form (mj_fwdConstraint): the forces implied by qacc_warmstart, f = max(0, -(J a_ws - aref) / R), kept if
 // their dual cost  sum f (1/2 (J da + R f) + J a_smooth - aref),  da = M^-1 J^T f,  is not positive.  what / ashat: M^1/2 qacc_warmstart
 // and M^1/2 qacc_smooth (LDS vectors, float offsets); dahat: zeroed on entry, M^1/2 da on exit (zero again if the forces were dropped).
@@ -347,7 +376,7 @@ DEV void patch_warmstart(const PatchArgs& A, const int lane, const int nstep, co
   WSYNC();
 }
 
-struct PatchOps { float4 J0, J1, J2, P, A0, A1, A2, A3; float half; float* rec; const float* pa; float* padd; int nr4; };   // nr4: rows of the STEP's longest patch
+struct PatchOps { float4 J0, J1, J2, P, A0, A1, A2, A3; float half; float* rec; const float* pa; float* padd; int nr4, stepone; };   // nr4: rows of the STEP's longest patch
 
 // The sweeps.  A.ahat holds a^ = M^1/2 a on entry and on exit.  Returns the number of sweeps.
 DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const int itmax, const float tol, const float scale) {
@@ -381,14 +410,15 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
     o.A3 = *(const float4*)((on & (ti >= 3)) ? T + 48 : zero);
     o.pa = (gA | (gB & hasB)) ? ahat + (gA ? dA : dB) + gq : zero;
     o.padd = ahat + ((addB & hasB) ? dB : dA) + addoff;      // (a patch on one body has zeros in the B half: they go to body A)
-    o.nr4 = PD_STEPN4(d) << 2;
+    o.nr4 = PD_STEPN4(d) << 2; o.stepone = PD_STEPONE(d);
     return o;
   };
   // one step: the four patches of the wave's rows.  al = this lane's entry of a^ (read before the next step's operands were
   // requested, so that waiting for it does not wait for them)
   auto solve = [&](PatchOps& o, const float al, float& impl) __attribute__((always_inline)) {
     const int nmax = __builtin_amdgcn_readfirstlane(o.nr4);      // rows of the step's longest patch
-    const float u = pp_dot12(al, o.J0, o.J1, o.J2);
+    const bool allone = __builtin_amdgcn_readfirstlane(o.stepone) != 0;   // every patch of the step on one body: 6 dofs in the two products
+    const float u = allone ? pp_dot6(al, o.J0, o.J1) : pp_dot12(al, o.J0, o.J1, o.J2);
     const float f = o.P.x, nf = -f;
     float tt = ((u - o.P.y) + o.P.z * f) * -o.P.w, dl;
     PP_ROWS4(0, 1, 2, 3, o.A0);
@@ -404,8 +434,8 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
     impl += (o.half * dl) * (2.0f * tt - dl);     // cost decrease  -(delta res + AR_qq delta^2 / 2),  res = -t AR_qq
     // a^ += J^T delta: the first lane of quad j adds dofs 3j .. 3j+2
     float b[3];
-    pp_jt(o.J0, o.J1, o.J2, dl, b);
-    if (adder) { atomicAdd(o.padd, b[0]); atomicAdd(o.padd + 1, b[1]); atomicAdd(o.padd + 2, b[2]); }
+    if (allone) pp_jt6(o.J0, o.J1, dl, b); else pp_jt(o.J0, o.J1, o.J2, dl, b);
+    if (adder && (!allone || q < 8)) { atomicAdd(o.padd, b[0]); atomicAdd(o.padd + 1, b[1]); atomicAdd(o.padd + 2, b[2]); }
   };
   int niter = 0;
   if (nstep == 1) {
