@@ -423,6 +423,8 @@ struct Loader {
     mjh_builder_set_balanceinertia(b, balance ? 1 : 0);
     mjh_model* m = mjh_builder_compile(b);
     mjh_builder_destroy(b); b = nullptr;
+    // a compile error after assets were skipped is usually their consequence (a body whose only geom is a missing mesh has no mass)
+    if (!m && note.find("not loaded") != std::string::npos) mjh_set_error(std::string(mjh_last_error()) + " [loader notes: " + note + "]");
     return m;
   }
   void abort() { if (b) mjh_builder_destroy(b); b = nullptr; }
