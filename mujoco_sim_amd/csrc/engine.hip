@@ -296,7 +296,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     if (patch) {   // what the sweep still needs sits in front of the span the patch pool takes over
       L.qM = put(m->nM); L.qLD = L.qM; L.qLDinv = put(nv); L.dofpar = 0; L.dofMadr = 0; L.anc = 0;
       L.p_gsize = put(3*ng); L.p_rbound = put(ng); L.p_mass = put(nb); L.p_inertia = put(3*nb);
-      L.zero = put(20);     // (PP_ZERO: a lane outside a patch reads a whole row record of zeros)
+      L.zero = put(PP_ZERO);     // (a lane outside a patch reads a whole row record of zeros)
     }
     // K1: frames, composite inertias, joint anchors/axes and geom poses are dead once the position stage, CRBA and the
     // collision stage are done; the solver's per-base scratch vectors (bv, phi: first used by the velocity stage) reuse them

@@ -1,15 +1,15 @@
-// patch_pgs.h — contact-patch Gauss-Seidel for small free-body models (mj_solPGS, reached from mj_step2,
-// /root/reference/src/mj_main.cpp:108).  Used by the LDS-resident kernels of models whose trees are all single free bodies
-// (DModel::patch; BASELINE's 24-DoF scene is one).
+// patch_pgs.h — contact-patch Gauss-Seidel for small free-body models (mj_solPGS and the warm start of mj_fwdConstraint, reached
+// from mj_step2, /root/reference/src/mj_main.cpp:108).  Used by the LDS-resident kernels of models whose trees are all single free
+// bodies (DModel::patch; BASELINE's 24-DoF scene is one).  DESIGN.md §4c.
 //
 // A patch = up to 16 constraint rows (whole contacts) between the SAME one or two bodies.  Its rows sit one per lane on a
 // 16-lane row of the wavefront, so a wave updates up to four mutually independent patches per step.  The coupling of the
-// rows inside a patch is precomputed (AR = J M^-1 J^T + R, 16 x 16, strictly lower triangle): one Gauss-Seidel row update is
-// then three instructions for all lanes,
-//     delta_q = max(-res_q / AR_qq, -f_q)          res_q <- res_q + AR_qr * delta_r   (v_fmac_f32_dpp row_newbcast:r)
-// instead of a cross-lane reduction per contact: a lane's residual only ever receives the updates of EARLIER rows (the later
-// columns of its AR row are stored as zeros), so once row q has been visited lane q keeps recomputing the same delta_q and the
-// value left after the last row is the Gauss-Seidel update of every row.  The patches talk to each other through the running
+// rows inside a patch is precomputed (AR = J M^-1 J^T + R, 16 x 16, strictly lower triangle).  Each lane carries
+// t_q = -res_q / AR_qq, and one Gauss-Seidel row update is two instructions for all lanes,
+//     delta = max(t, -f)            t_q <- t_q + (-AR_qr / AR_qq) delta_r        (v_fmac_f32_dpp row_newbcast:r)
+// instead of a cross-lane reduction per contact: a lane's t only ever receives the updates of EARLIER rows (the later columns
+// of its AR row are stored as zeros), so once row q has been visited lane q keeps recomputing the same delta_q and the value
+// left after the last row is the Gauss-Seidel update of every row.  The patches talk to each other through the running
 // acceleration only (matrix-free, as before): u = J a before the rows, a += M^-1 J^T delta after them.
 //
 // Everything is kept in the scaled coordinates  a^ = M^1/2 a,  J^ = J M^-1/2  (M is diagonal here), so that neither product
@@ -18,6 +18,8 @@
 // Visiting order (shared with the oracle, oracle/mjh_oracle.c: pgs_order): contacts sorted by (couples two bodies first, body
 // pair, constraint order); a patch = a maximal run of contacts of one body pair with at most 16 rows; a step = a patch plus up
 // to three later unvisited patches of the sequence that share no body with the step (first fit); rows in order inside a patch.
+//
+// patch_build (regroup the contact blocks, schedule, fill the pool) -> patch_warmstart -> patch_sweep.
 #pragma once
 
 // descriptor of a patch: pool offset / 4 | (rows / 4) << 13 | first dof of body A << 16 | first dof of body B (63: none) << 21
@@ -38,9 +40,8 @@
 #define PP_SIZE(two, n4) (4 * PP_REC(two) * (n4) + 8 * (n4) * ((n4) + 1))
 #define PP_ZERO 20     // floats of zeros a lane outside a patch reads instead of a record
 
-// acc += y * (x of lane R of this lane's 16-lane row).  The _H form waits out the VALU-write -> DPP-read hazard of x.
+// acc += y * (x of lane R of this lane's 16-lane row); x must not have been written by the VALU in the two instructions before
 #define PP_FMAC_BC(acc, x, y, R) asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #R " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y))
-#define PP_FMAC_BC_H(acc, x, y, R) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:" #R " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y))
 #define PP_BC12(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
 #define PP_BC16(M) PP_BC12(M) M(12) M(13) M(14) M(15)
 

@@ -591,7 +591,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
     // qvel_ref / qfrc_applied only cross launches in the split API (step1 | inverse | step2 as separate calls)
     if (!(ph & PH_STEP1)) { s_qvref[i] = S.qvel_ref[vrow + i]; s_applied[i] = S.qfrc_applied[vrow + i]; }
   }
-  if (lane < (M.patch ? 20 : 4)) s_zero[lane] = 0;   // what lanes outside a block read instead of its Jacobian (patch sweep: instead of a row record)
+  if (lane < (M.patch ? PP_ZERO : 4)) s_zero[lane] = 0;   // what lanes outside a block read instead of its Jacobian (patch sweep: instead of a row record)
   // hot chain-walk tables and the (possibly per-env) model parameters go to LDS once per launch
   for (int i = lane; i < nv; i += 64) {
     if (!DIAGM) {
