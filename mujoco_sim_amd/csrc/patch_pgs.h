@@ -458,9 +458,9 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
     typedef __attribute__((address_space(3))) float lds_float;
     auto laddr = [&](const float* pp) __attribute__((always_inline)) { return (unsigned)(unsigned long)(lds_float*)pp; };
     auto lptr = [&](const unsigned a) __attribute__((always_inline)) { return (float*)(lds_float*)(unsigned long)a; };
-    unsigned c0[PP_NSU], c1[PP_NSU], c2[PP_NSU], c3[PP_NSU];
+    unsigned c0[PP_NSU + 1], c1[PP_NSU + 1], c2[PP_NSU + 1], c3[PP_NSU + 1];   // entry nstep (and every later one) = step 0: the step after the sweep's last
 #pragma unroll
-    for (int t = 0; t < PP_NSU; t++) {
+    for (int t = 0; t <= PP_NSU; t++) {
       const int d = s_pslot[4 * (t < nstep ? t : 0)];
       const int nr4 = PD_N4(d) << 2, dA = PD_DA(d), dB = PD_DB(d);
       const bool on = q < nr4, hasB = dB != 63;
@@ -500,9 +500,7 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
       for (int t = 0; t < PP_NSU; t++) {
         if (t < nstep) {
           const float al = *op[t & 1].pa;
-          const bool wrap = t + 1 >= nstep;                 // the step after the sweep's last one is step 0
-          const int tn = t + 1 < PP_NSU ? t + 1 : 0;
-          op[(t + 1) & 1] = loadc(wrap ? c0[0] : c0[tn], wrap ? c1[0] : c1[tn], wrap ? c2[0] : c2[tn], wrap ? c3[0] : c3[tn]);
+          op[(t + 1) & 1] = loadc(c0[t + 1], c1[t + 1], c2[t + 1], c3[t + 1]);
           asm volatile("" ::: "memory");     // the requests above stay above: they are consumed one step later
           solve(op[t & 1], al, impl);
         }
