@@ -1105,6 +1105,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         const int g1 = CON_G1(c), g2 = CON_G2(c);
         const int b1 = geom_bodyid[g1], b2 = geom_bodyid[g2];
         t1 = body_treeid[b1]; t2 = body_treeid[b2];
+        const int t1raw = t1, t2raw = t2;                    // trees of geom1's / geom2's body (-1: static)
         if (t1 < 0) { t1 = t2; t2 = -1; }
         if (t2 == t1) t2 = -1;
         const float* dir = c + 4 + 3 * (jb < 3 ? jb : 0);   // base 0..2: translation along n,t1,t2 ; base 3: rotation about n
@@ -1113,6 +1114,22 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
 #pragma unroll
         for (int sd = 0; sd < 2; sd++) {
           const int bd = sd ? b2 : b1; const float ss = (sd ? 1.0f : -1.0f) * musc;
+          if constexpr (DIAGM) {
+            // every tree a free body about its own centre (cdof: translations along the world axes, rotations about the body
+            // axes through the centre): the point Jacobian in closed form, no walk over the dof chain
+            const int tr = sd ? t2raw : t1raw;
+            if (tr < 0) continue;
+            const int o = (tr == t1) ? 0 : 6;
+            const float* com = s_com + 3*bd;
+            const float off[3] = {c[1] - com[0], c[2] - com[1], c[3] - com[2]};
+            const float* xm = s_xmat + 9*bd;
+            float tq[3];
+            if (jb < 3) { cross3(tq, off, dir); J[SL*o] = ss * dir[0]; J[SL*(o+1)] = ss * dir[1]; J[SL*(o+2)] = ss * dir[2]; }
+            else { tq[0] = dir[0]; tq[1] = dir[1]; tq[2] = dir[2]; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) J[SL*(o+3+k)] = ss * (xm[k] * tq[0] + xm[3+k] * tq[1] + xm[6+k] * tq[2]);
+            continue;
+          }
           int i = body_lastdof[bd];
           if (i < 0) continue;
           const float* com = s_com + 3*body_rootid[bd];
