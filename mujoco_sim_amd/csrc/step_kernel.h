@@ -1327,6 +1327,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
               // wide groups: up to 16 blocks, the trees of the group as a bitmask (<= 64 trees by the host's rule)
               auto tmask = [&](int w) __attribute__((always_inline)) {
                 const int ta = (w >> 11) & 1023, tb = ((w >> 21) & 1023) - 1;
+                if constexpr (DIAGM) return (1ull << (ta / 6)) | (tb >= 0 ? (1ull << (tb / 6)) : 0ull);   // free bodies: tree t owns dofs 6t .. 6t+5 (no table look-up inside the loop)
                 return (1ull << dof_treeid[ta]) | (tb >= 0 ? (1ull << dof_treeid[tb]) : 0ull);
               };
               unsigned long long gmask = tmask(w0);
