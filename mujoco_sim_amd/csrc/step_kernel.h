@@ -1409,20 +1409,23 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       nefc = __builtin_amdgcn_readfirstlane(meta[2]); ncon = __builtin_amdgcn_readfirstlane(meta[3]); flags |= __builtin_amdgcn_readfirstlane(meta[4]);
     }
 
-    // dot products of every base row with a dof-space vector: out[4b+j] = J[b][.][j] . vec   (lanes = (block, base))
+    // dot products of every base row with a dof-space vector: out[4b+j] = J[b][.][j] . vec   (lanes = blocks: the four interleaved
+    // base entries of a dof are one 16-byte read)
     auto base_dots = [&](const float* vec, float* out) __attribute__((always_inline)) {
-      for (int t = lane; t < 4 * nblk; t += 64) {
-        const int b = t >> 2, jb = t & 3;
-        const int* hd = s_blki_i + b * BLKI_STRIDE;
-        ROW_TREES(hd[2], hd[3]);
-        const int SL = BLK_SLOTS(hd[1]);
-        float v = 0;
-        if (jb < SL) {
-          const float* J = s_J + BLK_JOFF(hd[0]) + jb;
-          for (int k = 0; k < n1; k++) v += J[SL*k] * vec[a1 + k];
-          for (int k = 0; k < n2; k++) v += J[SL*(n1 + k)] * vec[a2 + k];
+      for (int b = lane; b < nblk; b += 64) {
+        const int4 hd = *(const int4*)(s_blki_i + b * BLKI_STRIDE);
+        ROW_TREES(hd.z, hd.w);
+        float4 v = make_float4(0, 0, 0, 0);
+        if (BLK_SLOTS(hd.y) == 4) {
+          const float4* J4 = (const float4*)(s_J + BLK_JOFF(hd.x));
+          for (int k = 0; k < n1; k++) { const float4 j = J4[k]; const float x = vec[a1 + k]; v.x += j.x * x; v.y += j.y * x; v.z += j.z * x; v.w += j.w * x; }
+          for (int k = 0; k < n2; k++) { const float4 j = J4[n1 + k]; const float x = vec[a2 + k]; v.x += j.x * x; v.y += j.y * x; v.z += j.z * x; v.w += j.w * x; }
+        } else {
+          const float* J = s_J + BLK_JOFF(hd.x);
+          for (int k = 0; k < n1; k++) v.x += J[k] * vec[a1 + k];
+          for (int k = 0; k < n2; k++) v.x += J[n1 + k] * vec[a2 + k];
         }
-        out[t] = v;
+        *(float4*)(out + 4 * b) = v;
       }
       WSYNC();
     };
@@ -1809,27 +1812,27 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         if (!patched) {
         // ---- A_c = J_base M^-1 J_base^T, upper triangle (lanes = (block, base jb): row jb).  Built here, after the last user
         //      of the contact records and the velocity-stage spatial vectors: s_blkq reuses their space.
-        for (int t = lane; t < 4 * nblk; t += 64) {
-          const int b = t >> 2, jb = t & 3;
-          const int* hd = s_blki_i + b * BLKI_STRIDE;
-          const int nb = (hd[0] >> 8) & 15;
+        for (int b = lane; b < nblk; b += 64) {     // lanes = blocks: every dof's four base entries are one 16-byte read
+          const int4 hd = *(const int4*)(s_blki_i + b * BLKI_STRIDE);
+          const int nb = (hd.x >> 8) & 15;
           float* A = s_blkq + b * BLKQ_STRIDE;
-          A[4*jb] = 0; A[4*jb+1] = 0; A[4*jb+2] = 0; A[4*jb+3] = 0;   // unused rows / bases must be inert (dual-block solver)
-          if (jb >= nb) continue;
-          ROW_TREES(hd[2], hd[3]);
-          float acc[4] = {0, 0, 0, 0};
-          const int SL = BLK_SLOTS(hd[1]), jo = BLK_JOFF(hd[0]);
+          ROW_TREES(hd.z, hd.w);
+          const bool quad = BLK_SLOTS(hd.y) == 4; const int jo = BLK_JOFF(hd.x);
+          float a00 = 0, a01 = 0, a02 = 0, a03 = 0, a11 = 0, a12 = 0, a13 = 0, a22 = 0, a23 = 0, a33 = 0;
           for (int k = 0; k < n1 + n2; k++) {
-            float jv[4] = {0, 0, 0, 0};
-            if (SL == 4) { const float4 jk = *(const float4*)(s_J + jo + 4*k); jv[0] = jk.x; jv[1] = jk.y; jv[2] = jk.z; jv[3] = jk.w; }
-            else jv[0] = s_J[jo + k];
-            float bk;
-            if (DIAGM) bk = jv[jb] * s_qLDinv[k < n1 ? a1 + k : a2 + k - n1]; else bk = s_B[jo + SL*k + jb];
-    #pragma unroll
-            for (int i = 0; i < 4; i++) acc[i] += jv[i] * bk;
+            float4 jv = make_float4(0, 0, 0, 0), bv;
+            if (quad) jv = *(const float4*)(s_J + jo + 4*k); else jv.x = s_J[jo + k];
+            if (DIAGM) { const float mi = s_qLDinv[k < n1 ? a1 + k : a2 + k - n1]; bv = make_float4(jv.x * mi, jv.y * mi, jv.z * mi, jv.w * mi); }
+            else { bv = make_float4(0, 0, 0, 0); if (quad) bv = *(const float4*)(s_B + jo + 4*k); else bv.x = s_B[jo + k]; }
+            a00 += jv.x * bv.x; a01 += jv.y * bv.x; a02 += jv.z * bv.x; a03 += jv.w * bv.x;
+            a11 += jv.y * bv.y; a12 += jv.z * bv.y; a13 += jv.w * bv.y;
+            a22 += jv.z * bv.z; a23 += jv.w * bv.z; a33 += jv.w * bv.w;
           }
-    #pragma unroll
-          for (int i = 0; i < 4; i++) if (i >= jb && i < nb) A[4*jb + i] = acc[i];
+          // upper triangle over the block's nb bases; unused rows / bases must be inert (dual-block solver)
+          *(float4*)(A) = make_float4(nb > 0 ? a00 : 0.0f, nb > 1 ? a01 : 0.0f, nb > 2 ? a02 : 0.0f, nb > 3 ? a03 : 0.0f);
+          *(float4*)(A + 4) = make_float4(0.0f, nb > 1 ? a11 : 0.0f, nb > 2 ? a12 : 0.0f, nb > 3 ? a13 : 0.0f);
+          *(float4*)(A + 8) = make_float4(0.0f, 0.0f, nb > 2 ? a22 : 0.0f, nb > 3 ? a23 : 0.0f);
+          *(float4*)(A + 12) = make_float4(0.0f, 0.0f, 0.0f, nb > 3 ? a33 : 0.0f);
         }
         WSYNC();
         // ---- row-space matrix of every block: AR = E A_c E^T + R I (rows e_r = e_n +- e_k), laid out for pgs_rows().
