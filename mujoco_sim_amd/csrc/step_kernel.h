@@ -1515,6 +1515,24 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
     // ================================================================ velocity stage (lambdas: used by step1, inverse, step2-alone)
     auto vel_levels = [&](const float* qv, const float* qa, float* out) __attribute__((always_inline)) {
       // mj_comVel + mj_rne forward/backward; qa != null adds cdof*qacc (flg_acc)
+      if constexpr (DIAGM) {
+        // every tree a free body about its own centre with body-aligned principal axes: RNE in closed form.  Translations (world
+        // frame): m (a - g); rotations (body frame): I alpha + w x (I w).  (The spatial quantities cvel / cacc / cfrc are not
+        // formed: their only other reader for these models is the energy export, which has its own closed form.)
+        for (int d = lane; d < nv; d += 64) {
+          const int b = dof_bodyid[d], k = d - body_dofadr[b];
+          const float a = qa ? qa[d] : 0.0f;
+          if (k < 3) out[d] = s_p_mass[b] * (a - grav[k]);
+          else {
+            const float* w = qv + (d - k) + 3; const float* I = s_p_inertia + 3*b;
+            const float Iw[3] = {I[0] * w[0], I[1] * w[1], I[2] * w[2]};
+            float cr[3]; cross3(cr, w, Iw);
+            out[d] = I[k-3] * a + cr[k-3];
+          }
+        }
+        WSYNC();
+        return;
+      }
       if (lane == 0) { for (int k = 0; k < 6; k++) { s_cvel[k] = 0; s_cacc[k] = (k >= 3) ? -grav[k-3] : 0.0f; s_cfrc[k] = 0; } }
       WSYNC();
       for (int lev = 1; lev <= M.maxlevel; lev++) {
@@ -1628,8 +1646,15 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         float pe = 0, ke = 0;
         for (int b = lane; b < nbody; b += 64) if (b > 0) {
           pe -= s_p_mass[b] * (grav[0]*s_xipos[3*b] + grav[1]*s_xipos[3*b+1] + grav[2]*s_xipos[3*b+2]);
+          if constexpr (DIAGM) {   // free bodies: 1/2 m |v|^2 + 1/2 w . I w  (world-frame velocity, body-frame spin; see vel_levels)
+            if (body_dofnum[b] == 6) {
+              const float* v = s_qvel + body_dofadr[b]; const float* I = s_p_inertia + 3*b;
+              ke += 0.5f * (s_p_mass[b] * (v[0]*v[0] + v[1]*v[1] + v[2]*v[2]) + I[0]*v[3]*v[3] + I[1]*v[4]*v[4] + I[2]*v[5]*v[5]);
+            }
+          } else {
           float t[6]; mul_inert_vec(t, s_cinert + 10*b, s_cvel + 6*b);
           for (int q = 0; q < 6; q++) ke += 0.5f * t[q] * s_cvel[6*b+q];
+          }
         }
         pe = wave_sum<4>(pe); ke = wave_sum<4>(ke);
         if (lane == 0) { S.x_energy[2*xrow] = pe; S.x_energy[2*xrow+1] = ke; }
