@@ -301,12 +301,15 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     // K1: frames, composite inertias, joint anchors/axes and geom poses are dead once the position stage, CRBA and the
     // collision stage are done; the solver's per-base scratch vectors (bv, phi: first used by the velocity stage) reuse them
     const int k1 = off;
-    L.xpos = put(3*nb); L.xquat = put(4*nb); L.xmat = put(9*nb); L.ximat = put(9*nb); L.crb = put(10*nb);
+    // free-body models (diagM) form neither composite / spatial inertias nor motion axes nor the spatial velocity-stage vectors
+    // (closed forms in step_kernel.h): those arrays all alias one unused slot
+    const int unused = diagM ? put(4) : 0;
+    L.xpos = put(3*nb); L.xquat = put(4*nb); L.xmat = put(9*nb); L.ximat = put(9*nb); L.crb = diagM ? unused : put(10*nb);
     L.xanchor = put(3*nj); L.xaxis = put(3*nj); L.gpos = put(3*ng); L.gmat = put(9*ng);
     const int k1_size = off - k1;
     M.k1_floats = k1_size;
     M.scratch_off = (big && keep) ? put(k1_size) : k1;
-    L.xipos = put(3*nb); L.com = put(3*nb); L.cinert = put(10*nb); L.cdof = put(6*nv);
+    L.xipos = put(3*nb); L.com = put(3*nb); L.cinert = diagM ? unused : put(10*nb); L.cdof = diagM ? unused : put(6*nv);
     const int k2_size = off - k1;   // ... and all of these are dead when the solver sweeps run: the X extension of condim-4 models
     if (!patch) {
       L.qM = put(m->nM); L.qLD = diagM ? L.qM : put(m->nM); L.qLDinv = put(nv);   // diagonal M: no factor storage
@@ -316,7 +319,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     }
     {  // the contact records die once the blocks are built; the velocity-stage spatial vectors reuse their space
       const int a4 = [](int n) { return ((std::max(n, 1) + 3) / 4) * 4; }(6*nb);
-      const int velsz = 4 * a4 + ((6*nv + 3) / 4) * 4;
+      const int velsz = diagM ? 4 : 4 * a4 + ((6*nv + 3) / 4) * 4;
       int vel;
       if (big) { L.con = gput((long long)M.maxcon * CON_STRIDE); L.blkq = gput((long long)nblkcap * BLKQ_STRIDE); vel = put(velsz); }
       else if (keep) { L.con = put(M.maxcon * CON_STRIDE); L.blkq = put(nblkcap * BLKQ_STRIDE); vel = put(velsz); }
@@ -325,9 +328,10 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
         L.con = put(std::max(std::max(M.maxcon * CON_STRIDE, velsz), nblkcap * BLKQ_STRIDE));
         L.blkq = L.con; vel = L.con;
       }
-      L.cvel = vel; L.cacc = vel + a4; L.cfrc = vel + 2*a4; L.cfrcsub = vel + 3*a4; L.cdofdot = vel + 4*a4;
+      if (diagM) { L.cvel = unused; L.cacc = unused; L.cfrc = unused; L.cfrcsub = unused; L.cdofdot = unused; }
+      else { L.cvel = vel; L.cacc = vel + a4; L.cfrc = vel + 2*a4; L.cfrcsub = vel + 3*a4; L.cdofdot = vel + 4*a4; }
     }
-    const int extsz = M.has_dim4 ? nblkcap * SOLX_N : 0;
+    const int extsz = (M.has_dim4 && !patch) ? nblkcap * SOLX_N : 0;   // (the patch sweep does not use the condim-4 extension)
     if (big) {
       L.blki = gput((long long)nblkcap * BLKI_STRIDE); L.blkf = gput((long long)nblkcap * BLKF_STRIDE);
       L.bv = gput((long long)nblkcap * 4); L.phi = gput((long long)nblkcap * 4); L.sched = gput((long long)nblkcap * 2); L.order = gput(nblkcap);
@@ -350,7 +354,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       // The two small tables the sweep reads next to the pool (one descriptor per patch, one per schedule slot) sit in front
       // of it: that space (position-stage arrays, contact records) is dead when they are written, unlike the span's tail.
       M.pdesc = k1; M.pslot = k1 + ((M.maxcon + 3) / 4) * 4; M.pool = M.pslot + 4 * M.maxcon;
-      M.pool_floats = std::max(off - M.pool, 12 * M.maxefc);
+      M.pool_floats = std::max(off - M.pool, (33 * M.maxefc) / 2);   // (at least what the span was before free-body models dropped their spatial arrays: a 20 000-step soak never filled that)
       if (const char* cap = getenv("MJH_PATCH_POOL_FLOATS")) M.pool_floats = std::max(512, std::min(M.pool_floats, atoi(cap)));   // (tests: the drop rule)
       off = std::max(off, M.pool + M.pool_floats);
     } else L.zero = put(4);

@@ -769,6 +769,18 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       s_com[3*r] = c[0]; s_com[3*r+1] = c[1]; s_com[3*r+2] = c[2];
     }
     WSYNC();
+    if constexpr (DIAGM) {
+      // every tree a free body about its own centre with body-aligned principal axes: M = diag(m, m, m, Ix, Iy, Iz) per body, and
+      // nothing below needs the spatial inertias or motion axes (contact rows, bias forces, energy, gravity compensation and
+      // Cartesian forces have closed forms for these models): cinert / cdof / crb are neither formed nor allocated
+      for (int i = lane; i < M.nM; i += 64) { s_qM[i] = 0; }
+      WSYNC();
+      for (int d = lane; d < nv; d += 64) {
+        const int b = dof_bodyid[d], k = d - body_dofadr[b];
+        s_qM[s_dofMadr_i[d]] = (k < 3 ? s_p_mass[b] : s_p_inertia[3*b + k - 3]) + dof_armature[d];
+      }
+      WSYNC();
+    } else {
     for (int b = lane; b < nbody; b += 64) {
       float ci[10];
       if (b == 0) { for (int k = 0; k < 10; k++) ci[k] = 0; }
@@ -824,6 +836,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
       }
     }
     WSYNC();
+    }   // !DIAGM
     if (ph & PH_MULM) {  // mj_mulM (mj_sim.cpp:1057) for the host API
       for (int i = lane; i < nv; i += 64) { s_tmpv[i] = S.x_vec[(size_t)blockIdx.x * M.nvp + i]; s_tmpv2[i] = 0; }
       WSYNC();
@@ -1610,6 +1623,10 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           if ((jt == MJH_JNT_HINGE || jt == MJH_JNT_SLIDE) && jnt_stiffness[j] != 0) v -= jnt_stiffness[j] * (s_qpos[jnt_qposadr[j]] - qpos_spring[jnt_qposadr[j]]);
           v -= dof_damping[d] * qv[d];
           const int bd = dof_bodyid[d];
+          if constexpr (DIAGM) {   // free body: the compensating force -m gravcomp g acts at its centre: translational dofs only
+            const int k = d - body_dofadr[bd];
+            if (k < 3) for (int g = 0; g < M.ngc; g++) if (gc_body[g] == bd) v -= s_p_mass[bd] * body_gravcomp[bd] * grav[k];
+          } else
           for (int g = 0; g < M.ngc; g++) {
             const int b = gc_body[g];
             if (b < bd || b >= bd + body_subtreesize[bd]) continue;
@@ -1728,6 +1745,28 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         // the tree root's COM, summed over each body's subtree and projected on the dofs.  Scratch: the velocity-stage
         // spatial vectors (dead since qfrc_bias was formed).
         const float* xf = S.xfrc_applied + (size_t)env * S.xfrc_stride;
+        if constexpr (DIAGM) {
+          // free bodies: the force acts at the body's centre (translational dofs, world frame), the torque on the rotational dofs in
+          // the body frame (R^T tau, R from the body's quaternion: the frames of the position stage are gone by now)
+          for (int d = lane; d < nv; d += 64) {
+            const int b = dof_bodyid[d], k = d - body_dofadr[b];
+            float acc;
+            if (k < 3) acc = xf[6*b + k];
+            else {
+              const float* q7 = s_qpos + jnt_qposadr[dof_jntid[d]];
+              float qw = q7[3], qx = q7[4], qy = q7[5], qz = q7[6];
+              { const float inv = 1.0f / sqrtf(qw*qw + qx*qx + qy*qy + qz*qz); qw *= inv; qx *= inv; qy *= inv; qz *= inv; }
+              const float tx = xf[6*b+3], ty = xf[6*b+4], tz = xf[6*b+5];
+              const int c = k - 3;     // column c of R
+              const float r0 = c == 0 ? 1 - 2*(qy*qy + qz*qz) : (c == 1 ? 2*(qx*qy - qw*qz) : 2*(qx*qz + qw*qy));
+              const float r1 = c == 0 ? 2*(qx*qy + qw*qz) : (c == 1 ? 1 - 2*(qx*qx + qz*qz) : 2*(qy*qz - qw*qx));
+              const float r2 = c == 0 ? 2*(qx*qz - qw*qy) : (c == 1 ? 2*(qy*qz + qw*qx) : 1 - 2*(qx*qx + qy*qy));
+              acc = r0 * tx + r1 * ty + r2 * tz;
+            }
+            s_smooth[d] += acc; s_asmooth[d] += acc;
+          }
+          WSYNC();
+        } else {
         for (int b = lane; b < nbody; b += 64) {
           float F[6] = {0, 0, 0, 0, 0, 0};
           if (b > 0) {
@@ -1750,6 +1789,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           s_smooth[d] += acc; s_asmooth[d] += acc;
         }
         WSYNC();
+        }   // !DIAGM
       }
       if (DIAGM) { for (int d = lane; d < nv; d += 64) s_asmooth[d] *= s_qLDinv[d]; }
       else {
