@@ -604,3 +604,37 @@ def test_patch_pool_overflow_drops_patches_and_raises_the_capacity_flag():
     e.step(100)                                    # boxes sink where their contacts were dropped, nothing worse
     assert np.isfinite(e.get_state()[1]).all()
     e.close(); full.close()
+
+
+@pytest.mark.gpu
+def test_free_bodies_with_gravity_compensation_and_cartesian_forces_match_oracle(lib):
+    """free-body models form bias forces, gravity compensation (~disable_gravity: mj_sim.cpp:301-310) and xfrc_applied in closed form
+    (no spatial inertias / motion axes): a compensated box hovers, a half-compensated one falls slowly onto the floor, a third one is
+    pushed and twisted through xfrc_applied; device vs oracle"""
+    from helpers import D, set_opt
+    b = lib.mjh_builder_create()
+    set_opt(lib, b, timestep=0.004)
+    lib.mjh_builder_add_geom(b, b"floor", 0, 0, D(0, 0, 0.05), None, None, None, -1, -1, -1, -1)
+    for name, pos, gc in [(b"hover", (0.0, 0.0, 0.5), 1.0), (b"slow", (0.5, 0.0, 0.3), 0.5), (b"pushed", (-0.5, 0.0, 0.2), 0.0)]:
+        bd = lib.mjh_builder_add_body(b, name, 0, D(*pos), D(0.9, 0.1, 0.3, 0.2), gc)
+        lib.mjh_builder_add_joint(b, None, bd, 0, None, None, None, 0, 0, 0, 0, 0)
+        lib.mjh_builder_add_geom(b, None, bd, 6, D(0.08, 0.06, 0.05), None, None, None, -1, -1, -1, -1)
+    m = ms.Model(lib.mjh_builder_compile(b), lib)
+    lib.mjh_builder_destroy(b)
+    assert m.nv == 18
+    m.c.maxcon = 32; m.c.maxefc = 32 * 6
+    e = ms.Engine(m, 2); assert e.solver_order() == 1
+    d = orc.OrcData(m.ptr); d.call("reset")
+    v0 = np.zeros(m.nv); v0[3:6] = [0.5, -0.3, 0.2]; v0[6 + 3: 6 + 6] = [0.1, 0.4, -0.2]
+    e.set_state(qvel=np.tile(v0, (2, 1))); d.f("qvel")[:] = v0
+    xf = np.zeros((2, 6 * m.nbody)); xf[:, 6 * 3: 6 * 3 + 6] = [1.5, 0.0, 0.4, 0.02, -0.03, 0.05]      # force + torque on "pushed"
+    e.set_xfrc_applied(xf); d.f("xfrc_applied")[:] = xf[0]
+    done = 0
+    for n, tol in ((1, 1e-5), (50, 1e-3), (150, 2e-2)):
+        e.step(n - done); d.step(n - done); done = n
+        q = e.get_state()[1]
+        np.testing.assert_allclose(q[0], d.f("qpos"), atol=tol, err_msg=f"step {n}")
+        np.testing.assert_array_equal(q[0], q[1])
+    assert abs(d.f("qpos")[2] - 0.5) < 1e-6          # the compensated box has not moved vertically
+    assert d.i("ncon") >= 1
+    e.close()
