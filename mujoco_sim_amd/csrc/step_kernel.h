@@ -1344,19 +1344,30 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
                 return (1ull << dof_treeid[ta]) | (tb >= 0 ? (1ull << dof_treeid[tb]) : 0ull);
               };
               unsigned long long gmask = tmask(w0);
+              // first fit over the sequence, one 64-position window at a time: the window's unvisited blocks that do not touch the
+              // group yet are tried in order (a block accepted earlier in the window may rule a later one out); the visited
+              // marks go back to LDS once per window
               while (cnt < 16 && pos < nblk) {
                 const int p = pos + lane;
-                bool cand = false; int w = 0;
-                if (p < nblk) { w = info[p]; cand = w >= 0 && !(tmask(w) & gmask); }
-                const unsigned long long mk = __ballot(cand);
-                if (!mk) { pos += 64; continue; }
-                const int q = __ffsll((long long)mk) - 1;
-                const int wq = __builtin_amdgcn_readlane(w, q);
-                if (lane == 0) { info[pos + q] = wq | 0x80000000; s_order_i[k] = wq & 2047; }
-                gmask |= tmask(wq);
-                k++; cnt++; pos = pos + q + 1;
-                WSYNC();
+                int w = -1; unsigned long long tm = 0;
+                if (p < nblk) { w = info[p]; tm = tmask(w); }
+                unsigned long long mk = __ballot(w >= 0 && !(tm & gmask));
+                bool took = false;
+                while (mk && cnt < 16) {
+                  const int q = __ffsll((long long)mk) - 1;
+                  mk &= mk - 1ull;
+                  const unsigned long long tq = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(tm >> 32), q) << 32) | (unsigned)__builtin_amdgcn_readlane((int)tm, q);
+                  if (tq & gmask) continue;
+                  const int wq = __builtin_amdgcn_readlane(w, q);
+                  if (lane == 0) s_order_i[k] = wq & 2047;
+                  if (lane == q) { w |= 0x80000000; took = true; }
+                  gmask |= tq;
+                  k++; cnt++;
+                }
+                if (took) info[p] = w;
+                pos += 64;
               }
+              WSYNC();
             } else
             while (cnt < 4 && pos < nblk) {
               const int p = pos + lane;
