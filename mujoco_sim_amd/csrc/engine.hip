@@ -488,7 +488,9 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     HIPCHK(hipMemcpyAsync(S.initial_qpos, q0.data(), nq_all * sizeof(float), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
   }
-  { int nc = nenv >= 1024 ? 2 : 1;   // 2 cohorts recover ~95% of the slot-limited throughput; more need GPU_MAX_HW_QUEUES > 4
+  // 2 cohorts recover ~95% of the slot-limited throughput of the fused step; the many-body layout's step is three launches
+  // (assemble -> solve -> integrate) and three cohorts keep all three busy (C2 +4 %, C4 +11 %); more need GPU_MAX_HW_QUEUES > 4
+  { int nc = nenv >= 1024 ? (e->M.big && e->split3 ? 3 : 2) : 1;
     if (const char* v = getenv("MJH_COHORTS")) nc = atoi(v); if (set_cohorts(e, nc)) { mjh_destroy(e); return MJH_ERR_NO_DEVICE; } }
   *out = e;
   return MJH_OK;
