@@ -41,6 +41,10 @@ struct DevBuf {   // temporary device allocation freed on every path
 };
 
 #define MJH_MAX_COHORTS 8
+// HIP streams that share a hardware queue serialise; the engine uses up to five at once (three cohorts, the caller's stream, the
+// export stream) and RCCL adds its own.  The runtime reads GPU_MAX_HW_QUEUES (default 4) when it initialises, i.e. at the first
+// HIP call of the process: asked for here, when the library is loaded, unless the host has set it itself.
+__attribute__((constructor)) static void mjh_library_init() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 struct mjh_engine {
   const mjh_model* model = nullptr;
   int nenv = 0, device = 0;
@@ -488,9 +492,11 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     HIPCHK(hipMemcpyAsync(S.initial_qpos, q0.data(), nq_all * sizeof(float), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
   }
-  // 2 cohorts recover ~95% of the slot-limited throughput of the fused step; the many-body layout's step is three launches
-  // (assemble -> solve -> integrate) and three cohorts keep all three busy (C2 +4 %, C4 +11 %); more need GPU_MAX_HW_QUEUES > 4
-  { int nc = nenv >= 1024 ? (e->M.big && e->split3 ? 3 : 2) : 1;
+  // Cohorts: 2 recover ~95% of the slot-limited throughput of the fused step, a third one adds 0 - 9 % there (S24 +1 %, C3 +9 %);
+  // the many-body layout's step is three launches (assemble -> solve -> integrate) and three cohorts keep all three busy (C2 +4 %,
+  // C4 +11 %).  Four or more lose (C3 -30 %): streams start to share hardware queues.  Three cohort streams + the caller's stream +
+  // the export stream need more than the runtime's default of 4 hardware queues: see mjh_library_init below.
+  { int nc = nenv >= 1536 ? 3 : (nenv >= 1024 ? 2 : 1);
     if (const char* v = getenv("MJH_COHORTS")) nc = atoi(v); if (set_cohorts(e, nc)) { mjh_destroy(e); return MJH_ERR_NO_DEVICE; } }
   *out = e;
   return MJH_OK;
