@@ -24,7 +24,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# The engine steps two env cohorts on their own HIP streams; with RCCL's streams on top, more than the default 4
+# The engine steps two or three env cohorts on their own HIP streams; with RCCL's streams on top, more than the default 4
 # hardware queues are in use and streams that share a queue serialise (measured: 4.19 M vs 4.73 M env-steps/s on the
 # publish path).  Must be set before the HIP runtime initialises, i.e. before torch is imported.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
