@@ -492,11 +492,12 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     HIPCHK(hipMemcpyAsync(S.initial_qpos, q0.data(), nq_all * sizeof(float), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
   }
-  // Cohorts: 2 recover ~95% of the slot-limited throughput of the fused step, a third one adds 0 - 9 % there (S24 +1 %, C3 +9 %);
+  // Cohorts: 2 recover ~95% of the slot-limited throughput of the fused step, a third one adds 0 - 9 % there (S24 +1 %, C3 +9 %:
+  // not the default, a launch then covers a third of the envs for the same duration);
   // the many-body layout's step is three launches (assemble -> solve -> integrate) and three cohorts keep all three busy (C2 +4 %,
   // C4 +11 %).  Four or more lose (C3 -30 %): streams start to share hardware queues.  Three cohort streams + the caller's stream +
   // the export stream need more than the runtime's default of 4 hardware queues: see mjh_library_init below.
-  { int nc = nenv >= 1536 ? 3 : (nenv >= 1024 ? 2 : 1);
+  { int nc = nenv >= 1024 ? (e->M.big && e->split3 && nenv >= 1536 ? 3 : 2) : 1;   // (fused step: two by default, `mjh_set_cohorts(e, 3)` / MJH_COHORTS=3 for the last per cent)
     if (const char* v = getenv("MJH_COHORTS")) nc = atoi(v); if (set_cohorts(e, nc)) { mjh_destroy(e); return MJH_ERR_NO_DEVICE; } }
   *out = e;
   return MJH_OK;

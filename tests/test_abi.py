@@ -126,14 +126,15 @@ def test_engine_fails_loudly_without_gpu(lib):
         ms.Engine(m, 4)
 
 
-def test_s24_working_set_fits_nine_envs_per_cu(lib):
-    """The headline scene (40-contact capacity) must keep 9 environments resident per CU.  LDS is allocated in
-    1280-byte granules on gfx950 (measured: 15 328 B -> 10 per CU, 15 664 B -> 9), so the budget is 14 granules =
-    17 920 B per env; one granule more silently costs a ninth of the resident environments."""
+def test_s24_working_set_fits_eight_envs_per_cu(lib):
+    """The headline scene (40-contact capacity) must keep 8 environments resident per CU.  LDS is allocated in
+    1280-byte granules on gfx950 (measured: 15 328 B -> 10 per CU, 15 664 B -> 9), so the budget is 16 granules =
+    20 480 B per env.  (With the contact-patch sweep the step is bound by SIMD issue, not by residency: 8, 9 and 10 per CU
+    measured the same throughput, DESIGN.md section 4c, so the patch pool takes the room.)"""
     m = ms.scene("s24")
     assert m.maxcon == 40
     nbytes = lib.mjh_query_lds_bytes(m.ptr)
-    assert 0 < nbytes <= 14 * 1280, nbytes
+    assert 0 < nbytes <= 16 * 1280, nbytes
 
 
 def test_model_replicate_keeps_instances_apart(lib):
