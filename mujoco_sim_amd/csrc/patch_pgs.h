@@ -40,6 +40,7 @@
 #define PP_SIZE(two, n4) (4 * PP_REC(two) * (n4) + 8 * (n4) * ((n4) + 1))
 #define PP_ZERO 20     // floats of zeros a lane outside a patch reads instead of a record
 #define PP_NSU 6       // schedules of up to this many steps run with their per-lane addresses cached in registers
+#define PP_NRC 4       // ... and the row records (J^, f, row constants) of the first PP_NRC steps stay in registers over the sweeps
 
 // acc += y * (x of lane R of this lane's 16-lane row); x must not have been written by the VALU in the two instructions before
 #define PP_FMAC_BC(acc, x, y, R) asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #R " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y))
@@ -417,12 +418,12 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
   };
   // one step: the four patches of the wave's rows.  al = this lane's entry of a^ (read before the next step's operands were
   // requested, so that waiting for it does not wait for them)
-  auto solve = [&](PatchOps& o, const float al, float& impl) __attribute__((always_inline)) {
+  // the rows of a step once every lane has its t = -res / AR_qq (tt); returns the lane's force change
+  auto rows = [&](const PatchOps& o, const float4& J0, const float4& J1, const float4& J2, const float half, const bool allone,
+                  const float f, float tt, float& impl) __attribute__((always_inline)) {
     const int nmax = __builtin_amdgcn_readfirstlane(o.nr4);      // rows of the step's longest patch
-    const bool allone = __builtin_amdgcn_readfirstlane(o.stepone) != 0;   // every patch of the step on one body: 6 dofs in the two products
-    const float u = allone ? pp_dot6(al, o.J0, o.J1) : pp_dot12(al, o.J0, o.J1, o.J2);
-    const float f = o.P.x, nf = -f;
-    float tt = ((u - o.P.y) + o.P.z * f) * -o.P.w, dl;
+    const float nf = -f;
+    float dl;
     PP_ROWS4(0, 1, 2, 3, o.A0);
     if (nmax > 4) {
       PP_ROWS4(4, 5, 6, 7, o.A1);
@@ -432,12 +433,19 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
       }
     }
     asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));     // every lane's own update (its t is final: header comment)
-    o.rec[0] = f + dl;
-    impl += (o.half * dl) * (2.0f * tt - dl);     // cost decrease  -(delta res + AR_qq delta^2 / 2),  res = -t AR_qq
+    impl += (half * dl) * (2.0f * tt - dl);     // cost decrease  -(delta res + AR_qq delta^2 / 2),  res = -t AR_qq
     // a^ += J^T delta: the first lane of quad j adds dofs 3j .. 3j+2
     float b[3];
-    if (allone) pp_jt6(o.J0, o.J1, dl, b); else pp_jt(o.J0, o.J1, o.J2, dl, b);
+    if (allone) pp_jt6(J0, J1, dl, b); else pp_jt(J0, J1, J2, dl, b);
     if (adder && (!allone || q < 8)) { atomicAdd(o.padd, b[0]); atomicAdd(o.padd + 1, b[1]); atomicAdd(o.padd + 2, b[2]); }
+    return dl;
+  };
+  auto solve = [&](PatchOps& o, const float al, float& impl) __attribute__((always_inline)) {
+    const bool allone = __builtin_amdgcn_readfirstlane(o.stepone) != 0;   // every patch of the step on one body: 6 dofs in the two products
+    const float u = allone ? pp_dot6(al, o.J0, o.J1) : pp_dot12(al, o.J0, o.J1, o.J2);
+    const float f = o.P.x;
+    const float tt = ((u - o.P.y) + o.P.z * f) * -o.P.w;
+    o.rec[0] = f + rows(o, o.J0, o.J1, o.J2, o.half, allone, f, tt, impl);
   };
   int niter = 0;
   if (nstep == 1) {
@@ -492,23 +500,60 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
       o.nr4 = (int)((a1 & 3u) + 1u) << 2; o.stepone = (int)(a2 & 1u);
       return o;
     };
+    // The row records of the first PP_NRC steps do not change over the sweeps either (only the force does, and only its own lane
+    // reads it): they stay in registers, 17 per step; the forces go
+    // back to the records after the last sweep.  Per sweep such a step then fetches its tiles and its entry of a^ only.
+    struct RowC { float4 J0, J1, J2; float f, aref, R, nw, half; };
+    RowC rc[PP_NRC];
+#pragma unroll
+    for (int t = 0; t < PP_NRC; t++) {
+      if (t < nstep) {
+        const unsigned ra = c0[t] & 0xfff0u, rb = c0[t] >> 16; const bool hasB = (c0[t] & 1u) != 0;
+        const float4 P = ld4(ra);
+        rc[t].J0 = ld4(ra + 16); rc[t].J1 = ld4(ra + 32); rc[t].J2 = ld4(rb + 48);
+        const float h2 = *(const lds_float*)(unsigned long)(rb + 64);
+        rc[t].half = hasB ? h2 : rc[t].J1.z;
+        if (!hasB) { rc[t].J1.z = 0; rc[t].J1.w = 0; }
+        rc[t].f = P.x; rc[t].aref = P.y; rc[t].R = P.z; rc[t].nw = -P.w;
+      }
+    }
+    auto loadt = [&](const unsigned a0, const unsigned a1, const unsigned a2, const unsigned a3) __attribute__((always_inline)) {   // tiles + addresses only
+      PatchOps o;
+      o.rec = lptr(a0 & 0xfff0u);
+      o.A0 = ld4(a1 & 0xfff0u); o.A1 = ld4(a1 >> 16); o.A2 = ld4(a2 & 0xfff0u); o.A3 = ld4(a2 >> 16);
+      o.pa = lptr(a3 & 0xffffu); o.padd = lptr(a3 >> 16);
+      o.nr4 = (int)((a1 & 3u) + 1u) << 2; o.stepone = (int)(a2 & 1u);
+      return o;
+    };
+    // operands of step t (t = nstep: step 0 of the next sweep)
+#define PP_LOADSTEP(t) ((((t) < PP_NRC && (t) < nstep) || ((t) >= nstep)) ? loadt(c0[t], c1[t], c2[t], c3[t]) : loadc(c0[t], c1[t], c2[t], c3[t]))
     PatchOps op[2];
-    op[0] = loadc(c0[0], c1[0], c2[0], c3[0]);
+    op[0] = loadt(c0[0], c1[0], c2[0], c3[0]);
     for (int it = 0; it < itmax; it++) {
       float impl = 0;
 #pragma unroll
       for (int t = 0; t < PP_NSU; t++) {
         if (t < nstep) {
           const float al = *op[t & 1].pa;
-          op[(t + 1) & 1] = loadc(c0[t + 1], c1[t + 1], c2[t + 1], c3[t + 1]);
+          op[(t + 1) & 1] = PP_LOADSTEP(t + 1);
           asm volatile("" ::: "memory");     // the requests above stay above: they are consumed one step later
-          solve(op[t & 1], al, impl);
+          if (t < PP_NRC) {
+            PatchOps& o = op[t & 1];
+            const bool allone = __builtin_amdgcn_readfirstlane(o.stepone) != 0;
+            const float u = allone ? pp_dot6(al, rc[t].J0, rc[t].J1) : pp_dot12(al, rc[t].J0, rc[t].J1, rc[t].J2);
+            const float f = rc[t].f;
+            const float tt = ((u - rc[t].aref) + rc[t].R * f) * rc[t].nw;     // (same arithmetic as the uncached step)
+            rc[t].f = f + rows(o, rc[t].J0, rc[t].J1, rc[t].J2, rc[t].half, allone, f, tt, impl);
+          } else solve(op[t & 1], al, impl);
         }
       }
       if (nstep & 1) op[0] = op[1];          // odd step count: step 0 of the next sweep was requested into the other set
       niter = it + 1;
       if (wave_sum<4>(impl) * scale < tol) break;
     }
+#undef PP_LOADSTEP
+#pragma unroll
+    for (int t = 0; t < PP_NRC; t++) if (t < nstep) *lptr(c0[t] & 0xfff0u) = rc[t].f;
     return niter;
   }
   // more steps: software pipeline over the cyclic schedule, descriptor of step t+2 -> operands of step t+1 -> solve
