@@ -13,10 +13,11 @@
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 enum { K_FMA = 0, K_FMA_DEP, K_PKFMA, K_ADD_DPP_QUAD, K_ADD_DPP_ROWROR, K_ADD_DPP_ROWMIRROR, K_PERMLANE16_SWAP, K_PERMLANE32_SWAP, K_CNDMASK, K_MED3,
-       K_READLANE, K_DS_READ_B128, K_DS_READ_B32, K_RCP, K_MIX_SOLVER, K_COUNT };
+       K_READLANE, K_DS_READ_B128, K_DS_READ_B32, K_RCP, K_MIX_SOLVER, K_ROWCHAIN, K_ROWCHAIN_NONOP, K_SNOP, K_SALU, K_COUNT };
 static const char* kname[K_COUNT] = {"v_fma_f32 x8 independent", "v_fma_f32 dependent chain", "v_pk_fma_f32 x8 independent", "v_add_f32 dpp quad_perm x8", "v_add_f32 dpp row_ror:4 x8",
                                      "v_add_f32 dpp row_mirror x8", "v_permlane16_swap x4 pairs", "v_permlane32_swap x4 pairs", "v_cndmask_b32 x8", "v_med3_f32 x8",
-                                     "v_readlane_b32 + s_add x8", "ds_read_b128 x8 (broadcast addr)", "ds_read_b32 x8 (lane addr)", "v_rcp_f32 x8", "mix: 6 fma + 2 dpp add + 1 ds_read_b128"};
+                                     "v_readlane_b32 + s_add x8", "ds_read_b128 x8 (broadcast addr)", "ds_read_b32 x8 (lane addr)", "v_rcp_f32 x8", "mix: 6 fma + 2 dpp add + 1 ds_read_b128",
+                                     "row chain: (v_max, s_nop 1, v_fmac dpp) x4", "row chain without the s_nop x4", "s_nop 1 x8", "s_add_u32 x8"};
 
 template <int KIND>
 __global__ __launch_bounds__(64) void bench(float* out, long long* ticks, int reps) {
@@ -102,6 +103,24 @@ __global__ __launch_bounds__(64) void bench(float* out, long long* ticks, int re
                    "v_fma_f32 %4, %4, %10, %11\n\tv_fma_f32 %5, %5, %10, %11\n\tv_fma_f32 %6, %6, %10, %11\n\t"
                    "s_nop 1\n\tv_add_f32_dpp %7, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_waitcnt lgkmcnt(0)"
                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=v"(q0) : "v"(ba), "v"(b), "v"(c) : "memory");
+    if (KIND == K_ROWCHAIN)     // the Gauss-Seidel row of patch_pgs.h: per-rep 4 rows (the dependent chain t -> d -> t)
+      asm volatile("v_max_f32 %1, %0, %2\n\ts_nop 1\n\tv_fmac_f32_dpp %0, %1, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_max_f32 %1, %0, %2\n\ts_nop 1\n\tv_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_max_f32 %1, %0, %2\n\ts_nop 1\n\tv_fmac_f32_dpp %0, %1, %3 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_max_f32 %1, %0, %2\n\ts_nop 1\n\tv_fmac_f32_dpp %0, %1, %3 row_newbcast:3 row_mask:0xf bank_mask:0xf"
+                   : "+v"(a0), "+v"(a1) : "v"(b), "v"(c));
+    if (KIND == K_ROWCHAIN_NONOP)     // (timing only: without the wait states the DPP read is not guaranteed to see the v_max)
+      asm volatile("v_max_f32 %1, %0, %2\n\tv_fmac_f32_dpp %0, %1, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_max_f32 %1, %0, %2\n\tv_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_max_f32 %1, %0, %2\n\tv_fmac_f32_dpp %0, %1, %3 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_max_f32 %1, %0, %2\n\tv_fmac_f32_dpp %0, %1, %3 row_newbcast:3 row_mask:0xf bank_mask:0xf"
+                   : "+v"(a0), "+v"(a1) : "v"(b), "v"(c));
+    if (KIND == K_SNOP)
+      asm volatile("s_nop 1\n\ts_nop 1\n\ts_nop 1\n\ts_nop 1\n\ts_nop 1\n\ts_nop 1\n\ts_nop 1\n\ts_nop 1");
+    if (KIND == K_SALU)
+      asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %1, %1, 1\n\ts_add_u32 %2, %2, 1\n\ts_add_u32 %3, %3, 1\n\t"
+                   "s_add_u32 %0, %0, 1\n\ts_add_u32 %1, %1, 1\n\ts_add_u32 %2, %2, 1\n\ts_add_u32 %3, %3, 1"
+                   : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");
   }
   const long long t1 = (long long)__builtin_amdgcn_s_memtime();
   float acc = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y + q0.x + q1.y + q2.z + q3.w + q4.x + q5.y + q6.z + q7.w + (float)(s0 + s1 + s2 + s3);
@@ -125,7 +144,7 @@ template <int KIND> static void run_one(int W, float* dout, long long* dticks, i
   std::vector<long long> t(nblk);
   CHK(hipMemcpy(t.data(), dticks, nblk * sizeof(long long), hipMemcpyDeviceToHost));
   double mean = 0; for (auto v : t) mean += (double)v; mean /= nblk;
-  const int per_rep = (KIND == K_PERMLANE16_SWAP || KIND == K_PERMLANE32_SWAP) ? 4 : (KIND == K_READLANE ? 14 : (KIND == K_MIX_SOLVER ? 9 : 8));
+  const int per_rep = (KIND == K_PERMLANE16_SWAP || KIND == K_PERMLANE32_SWAP || KIND == K_ROWCHAIN || KIND == K_ROWCHAIN_NONOP) ? 4 : (KIND == K_READLANE ? 14 : (KIND == K_MIX_SOLVER ? 9 : 8));
   *cyc_per_instr_wave = mean / ((double)reps * per_rep);
   *ms_out = ms;
   CHK(hipEventDestroy(a)); CHK(hipEventDestroy(b));
@@ -155,6 +174,7 @@ int main() {
   run_kind<K_PERMLANE16_SWAP>(dout, dticks, ncu); run_kind<K_PERMLANE32_SWAP>(dout, dticks, ncu);
   run_kind<K_CNDMASK>(dout, dticks, ncu); run_kind<K_MED3>(dout, dticks, ncu);
   run_kind<K_DS_READ_B128>(dout, dticks, ncu); run_kind<K_DS_READ_B32>(dout, dticks, ncu); run_kind<K_RCP>(dout, dticks, ncu); run_kind<K_MIX_SOLVER>(dout, dticks, ncu);
+  run_kind<K_ROWCHAIN>(dout, dticks, ncu); run_kind<K_ROWCHAIN_NONOP>(dout, dticks, ncu); run_kind<K_SNOP>(dout, dticks, ncu); run_kind<K_SALU>(dout, dticks, ncu);   // (row chain: ticks per ROW)
   // (the v_readlane + s_add variant does not terminate on this box and is left out)
   return 0;
 }
