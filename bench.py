@@ -55,6 +55,7 @@ class Workload:
     name = ""; label = ""; envs_per_gpu = 4096; settle_steps = 0; inverse = False; min_ncon = None
 
     pack = 1          # environments per wavefront (mjh_model_replicate: sub-wave packing of small models); 1 = one wave per env
+    cohorts = 0       # env cohorts on separate HIP streams; 0 = the engine's default (two for a fused step, three for the many-body layout)
 
     def __init__(self, ms, args, rank, device, stream):
         self.ms = ms; self.args = args; self.rank = rank
@@ -140,6 +141,7 @@ class C3(Workload):
              "PD ddq = 200 (q* - q) - 50 qd in the engine, targets U[limits] re-drawn every 200 steps; four arms per wavefront (mjh_model_replicate)")
 
     pack = 4          # four arms per wavefront (7 of 64 lanes busy otherwise): mjh_model_replicate, DESIGN.md §9
+    cohorts = 3       # a 0.10 ms launch of 1024 wavefronts leaves the chip half empty: 74 / 79 M env-steps/s with 2 / 3 cohorts (four: 54 M, the per-step join for the publish copy costs more than the overlap gives; tools/c3_sweep.sh)
 
     def build(self, device, stream):
         self.model = self.packed(self.ms.scene("arm7", 1))
@@ -310,7 +312,7 @@ def main():
     ap.add_argument("--config", choices=sorted(WORKLOADS), default="s24", help="BASELINE.json config (default: the metric's scene, S24)")
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="0 = the config's size (S24/C2/C5 4096, C3 8192, C4 2048)")
     ap.add_argument("--with-inverse", type=int, default=-1, help="mj_inverse every step in the MAIN timed window (-1: the config's default; the other variant is timed in a second window)")
-    ap.add_argument("--cohorts", type=int, default=-1, help="env cohorts stepped on separate HIP streams (-1: engine default)")
+    ap.add_argument("--cohorts", type=int, default=-1, help="env cohorts stepped on separate HIP streams (-1: the config's default, else the engine's)")
     ap.add_argument("--timing-stride", type=int, default=5, help="bracket every N-th step launch with HIP events (roofline.kernel_ms is their mean)")
     ap.add_argument("--pack", type=int, default=0, help="environments per wavefront for the small-model configs (0: the config's default — C3 4, C5 2, others 1)")
     ap.add_argument("--maxcon", type=int, default=0, help="override the scene's contact capacity per env; 0 = scene default")
@@ -345,8 +347,8 @@ def main():
     stream = torch.cuda.current_stream()
     w = WORKLOADS[args.config](ms, args, rank, local_rank, stream.cuda_stream)
     eng, model, nenv = w.eng, w.model, w.nenv
-    if args.cohorts > 0:
-        eng.set_cohorts(args.cohorts)
+    if args.cohorts > 0 or w.cohorts > 0:
+        eng.set_cohorts(args.cohorts if args.cohorts > 0 else w.cohorts)
     main_inverse = w.inverse if args.with_inverse < 0 else bool(args.with_inverse)
     stride = eng.state_stride
     pub = torch.empty(w.rows * stride, dtype=torch.float32, device="cuda")
