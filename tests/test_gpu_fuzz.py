@@ -43,13 +43,16 @@ def test_random_free_body_scenes_match_the_oracle(lib, seed):
     v0[0::6] -= 0.3; v0[1::6] -= 0.3                              # push everything towards the corner
     e.set_state(qvel=np.tile(v0, (2, 1))); d.f("qvel")[:] = v0
     done = 0; seen = 0
-    for n, tol in ((1, 2e-5), (60, 2e-3), (140, 3e-2)):       # (later than that rolling bodies' orientations fork between fp32 and fp64)
+    pos = np.arange(m.nq).reshape(-1, 7)[:, :3].ravel()          # the translational coordinates of the free bodies
+    # (at the last mark positions only: a sphere's orientation, or a capsule's spin about its axis, feels no contact and integrates
+    #  rounding differences; later than that rolling bodies fork between fp32 and fp64 altogether)
+    for n, tol, sel in ((1, 2e-5, slice(None)), (60, 2e-3, slice(None)), (140, 3e-2, pos)):
         e.step(n - done); d.step(n - done); done = n
         st = e.get_stats(); q = e.get_state()[1]
         assert st[0, 3] == 0 and d.i("warn") == 0
         np.testing.assert_array_equal(q[0], q[1])
         if st[0, 0] == d.i("ncon") and st[0, 1] == d.i("nefc"):    # same contact set: positions must agree
-            np.testing.assert_allclose(q[0], d.f("qpos"), atol=tol, err_msg=f"seed {seed} step {n}")
+            np.testing.assert_allclose(q[0][sel], d.f("qpos")[sel], atol=tol, err_msg=f"seed {seed} step {n}")
             seen += 1
     assert seen >= 2, "the contact sets should agree at least up to step 60"
     assert np.isfinite(e.get_state()[1]).all()
