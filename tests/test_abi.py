@@ -129,8 +129,8 @@ def test_engine_fails_loudly_without_gpu(lib):
 def test_s24_working_set_fits_eight_envs_per_cu(lib):
     """The headline scene (40-contact capacity) must keep 8 environments resident per CU.  LDS is allocated in
     1280-byte granules on gfx950 (measured: 15 328 B -> 10 per CU, 15 664 B -> 9), so the budget is 16 granules =
-    20 480 B per env.  (With the contact-patch sweep the step is bound by SIMD issue, not by residency: 8, 9 and 10 per CU
-    measured the same throughput, DESIGN.md section 4c, so the patch pool takes the room.)"""
+    20 480 B per env.  (The unrolled patch sweep keeps its row records in registers, 235 VGPRs = two waves per SIMD = 8 per CU
+    whatever the LDS allows, DESIGN.md section 4c, so the patch pool takes the room.)"""
     m = ms.scene("s24")
     assert m.maxcon == 40
     nbytes = lib.mjh_query_lds_bytes(m.ptr)
