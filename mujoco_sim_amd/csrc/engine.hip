@@ -361,6 +361,12 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       M.pool_floats = std::max(off - M.pool, (33 * M.maxefc) / 2);   // (at least what the span was before free-body models dropped their spatial arrays: a 20 000-step soak never filled that)
       if (const char* cap = getenv("MJH_PATCH_POOL_FLOATS")) M.pool_floats = std::max(512, std::min(M.pool_floats, atoi(cap)));   // (tests: the drop rule)
       off = std::max(off, M.pool + M.pool_floats);
+      if (!getenv("MJH_PATCH_POOL_FLOATS")) {
+        // LDS is handed out in 1280-byte granules and a CU holds floor(128 / granules) workgroups: the pool takes what is left of
+        // the last granule that costs no workgroup (S24: 15 -> 16 granules at 8 per CU, +12 % pool)
+        const int gran = (off * 4 + 1279) / 1280, wg = 128 / std::max(gran, 1);
+        if (wg >= 1) { const int room = std::min((128 / wg) * 320, 16384); if (room > off) { M.pool_floats += room - off; off = room; } }
+      }
     } else L.zero = put(4);
     L.site = m->nsite > 0 ? put(12 * m->nsite) : 0;        // world frame of every site: pos(3) + rotation(9)
     L.fext = m->nsensor > 0 ? put(6 * nb) : 0;             // external spatial force per body (mj_rnePostConstraint)
