@@ -57,3 +57,41 @@ def test_random_free_body_scenes_match_the_oracle(lib, seed):
     assert seen >= 2, "the contact sets should agree at least up to step 60"
     assert np.isfinite(e.get_state()[1]).all()
     e.close()
+
+
+def _table_scene(lib, condim):
+    """A slab on the floor carrying four small boxes: the slab sits in 8 - 10 patches (two per small box with 6-row contacts, two
+    with the floor), so the sweep schedule has more steps than the unrolled loop of patch_pgs.h covers (PP_NSU = 6)."""
+    b = lib.mjh_builder_create()
+    set_opt(lib, b, timestep=0.004)
+    lib.mjh_builder_add_geom(b, b"floor", 0, 0, D(0, 0, 0.05), None, None, None, condim, -1, -1, -1)
+    slab = lib.mjh_builder_add_body(b, b"slab", 0, D(0, 0, 0.031), None, 0.0)
+    lib.mjh_builder_add_joint(b, None, slab, 0, None, None, None, 0, 0, 0, 0, 0)
+    lib.mjh_builder_add_geom(b, None, slab, 6, D(0.2, 0.2, 0.03), None, None, None, condim, -1, -1, -1)
+    for i, (x, y) in enumerate(((-0.1, -0.1), (0.1, -0.1), (-0.1, 0.1), (0.1, 0.1))):
+        bd = lib.mjh_builder_add_body(b, b"box%d" % i, 0, D(x, y, 0.062 + 0.03 + 0.002 * i), None, 0.0)
+        lib.mjh_builder_add_joint(b, None, bd, 0, None, None, None, 0, 0, 0, 0, 0)
+        lib.mjh_builder_add_geom(b, None, bd, 6, D(0.04 + 0.005 * i, 0.05, 0.03), None, None, None, condim, -1, -1, -1)
+    m = ms.Model(lib.mjh_builder_compile(b), lib)
+    lib.mjh_builder_destroy(b)
+    m.c.maxcon = 48; m.c.maxefc = 48 * 6
+    return m
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("condim", [3, 4])
+def test_slab_with_four_boxes_long_schedule(lib, condim):
+    m = _table_scene(lib, condim)
+    e = ms.Engine(m, 2)
+    assert e.solver_order() == 1
+    d = orc.OrcData(m.ptr); d.call("reset")
+    done = 0
+    for n, tol in ((1, 2e-5), (40, 1e-3), (120, 5e-3)):
+        e.step(n - done); d.step(n - done); done = n
+        st = e.get_stats(); q = e.get_state()[1]
+        assert st[0, 3] == 0 and d.i("warn") == 0
+        np.testing.assert_array_equal(q[0], q[1])
+        assert st[0, 0] == d.i("ncon") and st[0, 1] == d.i("nefc")
+        if n > 1: assert st[0, 0] >= 16                           # the four boxes and the slab rest on four corners each
+        np.testing.assert_allclose(q[0], d.f("qpos"), atol=tol, err_msg=f"condim {condim} step {n}")
+    e.close()
