@@ -316,10 +316,22 @@ struct ManyCtx {
   int noslip_iterations; float noslip_tolerance;     // noslip post-pass (EXTRA instances only)
   int nwave, wid; float* red;                        // mjh_solve_kernel with wide groups: waves per environment, this wave, LDS partial sums
   bool order_packed;    // the LDS copy of the order carries block | kind << 16 | ndof << 20: the fetch skips what the block does not have
+  // mjh_solve_kernel (BUF instances): every pool is inside the env's global slice, addressed through ONE buffer descriptor with the
+  // pool's byte offset as the scalar offset and a 32-bit per-lane offset - one shift per block instead of a 64-bit address per load,
+  // and a lane that has nothing to fetch / store points beyond the slice (reads 0, stores nothing) instead of being masked off
+  __amdgpu_buffer_rsrc_t rsrc; int oJ, oB, oblkf, oblkq, oext, oblki;
 };
+typedef unsigned mjh_v4u __attribute__((vector_size(16)));   // (the builtins' own vector types: an ext_vector_type of the same size converts by value, not by bits)
+typedef unsigned mjh_v2u __attribute__((vector_size(8)));
+#define MJH_BUF_OOB 0x7ffffff0u
+DEV float4 buf_load4(const __amdgpu_buffer_rsrc_t r, const unsigned voff, const int soff) {
+  const mjh_v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0);
+  float4 f; __builtin_memcpy(&f, &v, 16);
+  return f;
+}
 // LDS order word of block b with header hd (kind: BK_*, ndof: dofs of the one or two trees it touches)
 #define MJH_ORDER_WORD(b, hd) ((b) | (((hd).x & 15) << 16) | (((((unsigned)(hd).z) >> 16) + ((((unsigned)(hd).w) >> 16))) << 20))
-template <bool DIAGM, bool EXTRA>
+template <bool DIAGM, bool EXTRA, bool BUF = false>
 DEV int pgs_many_body(const ManyCtx& c, const int lane) {
   int niter = 0, nmain = 0;
   // a four-wave workgroup (mjh_solve_kernel with wide groups) on an environment whose sweep is sequential (few blocks): wave 0
@@ -339,9 +351,28 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
   struct MOp { int4 hd; int b; float4 J, B, p0, r0, r1, r2, A0, A1, A2, A3, X0, X1, X2; };
   auto blockAt = [&](int k) __attribute__((always_inline)) { return c.order_packed ? (c.order[k] & 0xffff) : c.order[k]; };   // visiting order (LDS copy)
   auto fetch8 = [&](int b) __attribute__((always_inline)) {
-    MOp op; op.b = b; op.hd = ((const int4*)c.blki)[b];
+    MOp op; op.b = b;
     const bool quad = b >= c.nfixblk;
     const int jo = (quad ? c.nfixblk + 4 * (b - c.nfixblk) : b) * c.rowW;      // = BLK_JOFF(hd.x), see put_block
+    if constexpr (BUF) {
+      const unsigned ob64 = (unsigned)b * 64u;
+      { const mjh_v4u h = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)((unsigned)b * 16u), c.oblki, 0); __builtin_memcpy(&op.hd, &h, 16); }
+      if (quad) {
+        const unsigned oj = lane < c.rowW ? (unsigned)(jo + 4 * lane) * 4u : MJH_BUF_OOB;
+        op.J = buf_load4(c.rsrc, oj, c.oJ);
+        op.B = DIAGM ? op.J : buf_load4(c.rsrc, oj, c.oB);
+      } else {
+        const unsigned oj = lane < c.rowW ? (unsigned)(jo + lane) * 4u : MJH_BUF_OOB;
+        op.J = make_float4(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rsrc, (int)oj, c.oJ, 0)), 0, 0, 0);
+        op.B = DIAGM ? op.J : make_float4(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rsrc, (int)oj, c.oB, 0)), 0, 0, 0);
+      }
+      op.p0 = buf_load4(c.rsrc, ob64, c.oblkf); op.r0 = buf_load4(c.rsrc, ob64 + 16u, c.oblkf); op.r1 = buf_load4(c.rsrc, ob64 + 32u, c.oblkf); op.r2 = buf_load4(c.rsrc, ob64 + 48u, c.oblkf);
+      op.A0 = buf_load4(c.rsrc, ob64, c.oblkq); op.A1 = buf_load4(c.rsrc, ob64 + 16u, c.oblkq); op.A2 = buf_load4(c.rsrc, ob64 + 32u, c.oblkq); op.A3 = buf_load4(c.rsrc, ob64 + 48u, c.oblkq);
+      op.X0 = make_float4(0, 0, 0, 0); op.X1 = op.X0; op.X2 = op.X0;
+      if (c.has_dim4) { const unsigned ox = (unsigned)b * (unsigned)(SOLX_N * 4); op.X0 = buf_load4(c.rsrc, ox, c.oext); op.X1 = buf_load4(c.rsrc, ox + 16u, c.oext); op.X2 = buf_load4(c.rsrc, ox + 32u, c.oext); }
+      return op;
+    }
+    op.hd = ((const int4*)c.blki)[b];
     op.J = make_float4(0, 0, 0, 0); op.B = op.J;
     if (lane < c.rowW) {                                                  // dofs beyond the block's trees hold zeros
       if (quad) op.J = *(const float4*)(c.J + jo + 4*lane); else op.J.x = c.J[jo + lane];
@@ -376,6 +407,13 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
     else if (kind == BK_PYR3) pgs_block<3, 4, 8, EXTRA>(ns, R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
     else pgs_block<1, 1, 8, EXTRA>(ns, R, lo, hi, aref, f, Q, X, Jd, Bp, bs, ak, improvement);
     if (on) c.qacc[d] = ak;                                              // scatter
+    if constexpr (BUF) {
+      const unsigned of = lane == 0 ? (unsigned)op.b * 64u + (unsigned)(BF_F * 4) : MJH_BUF_OOB;
+      mjh_v4u f4; mjh_v2u f2;
+      __builtin_memcpy(&f4, f, 16); __builtin_memcpy(&f2, f + 4, 8);
+      __builtin_amdgcn_raw_buffer_store_b128(f4, c.rsrc, (int)of, c.oblkf, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(f2, c.rsrc, (int)(of + 16u), c.oblkf, 0);
+    } else
     if (lane == 0) {
       float* bf = c.blkf + op.b * BLKF_STRIDE + BF_F;
       *(float4*)(bf) = make_float4(f[0], f[1], f[2], f[3]);
@@ -401,9 +439,32 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
       // what the block has (packed order word) bounds what is fetched: the condim-4 extension for condim-4 blocks only, the
       // Jacobian for the block's own dofs only (a box-floor contact touches 6 of the 12 row slots)
       const int okind = c.order_packed ? ((ow >> 16) & 15) : BK_PYR4, ondof = c.order_packed ? (ow >> 20) : c.rowW;
-      op.b = b; op.act = act ? 1.0f : 0.0f; op.hd = ((const int4*)c.blki)[b];
+      op.b = b; op.act = act ? 1.0f : 0.0f;
       const bool quad = b >= c.nfixblk;
       const int jo = (quad ? c.nfixblk + 4 * (b - c.nfixblk) : b) * c.rowW;
+      if constexpr (BUF) {
+        const unsigned ob64 = (unsigned)b * 64u;
+        { const mjh_v4u h = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)((unsigned)b * 16u), c.oblki, 0); __builtin_memcpy(&op.hd, &h, 16); }
+        const bool jon = l < ondof && act;
+        if (quad) {
+          const unsigned oj = jon ? (unsigned)(jo + 4 * l) * 4u : MJH_BUF_OOB;
+          op.J = buf_load4(c.rsrc, oj, c.oJ);
+          op.B = DIAGM ? op.J : buf_load4(c.rsrc, oj, c.oB);
+        } else {
+          const unsigned oj = jon ? (unsigned)(jo + l) * 4u : MJH_BUF_OOB;
+          op.J = make_float4(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rsrc, (int)oj, c.oJ, 0)), 0, 0, 0);
+          op.B = DIAGM ? op.J : make_float4(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rsrc, (int)oj, c.oB, 0)), 0, 0, 0);
+        }
+        op.p0 = buf_load4(c.rsrc, ob64, c.oblkf); op.r0 = buf_load4(c.rsrc, ob64 + 16u, c.oblkf); op.r1 = buf_load4(c.rsrc, ob64 + 32u, c.oblkf); op.r2 = buf_load4(c.rsrc, ob64 + 48u, c.oblkf);
+        op.A0 = buf_load4(c.rsrc, ob64, c.oblkq); op.A1 = buf_load4(c.rsrc, ob64 + 16u, c.oblkq); op.A2 = buf_load4(c.rsrc, ob64 + 32u, c.oblkq); op.A3 = buf_load4(c.rsrc, ob64 + 48u, c.oblkq);
+        op.X0 = make_float4(0, 0, 0, 0); op.X1 = op.X0; op.X2 = op.X0;
+        if (c.has_dim4) {
+          const unsigned ox = (okind == BK_PYR4 && act) ? (unsigned)b * (unsigned)(SOLX_N * 4) : MJH_BUF_OOB;
+          op.X0 = buf_load4(c.rsrc, ox, c.oext); op.X1 = buf_load4(c.rsrc, ox + 16u, c.oext); op.X2 = buf_load4(c.rsrc, ox + 32u, c.oext);
+        }
+        return op;
+      }
+      op.hd = ((const int4*)c.blki)[b];
       op.J = make_float4(0, 0, 0, 0); op.B = op.J;
       if (l < ondof && act) {
         if (quad) op.J = *(const float4*)(c.J + jo + 4*l); else op.J.x = c.J[jo + l];
@@ -448,6 +509,13 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
       ak += (Bp[0] * dphi[0] + Bp[1] * dphi[1] + Bp[2] * dphi[2] + Bp[3] * dphi[3]) * bs;
       if (on) c.qacc[d] = ak;                                                 // scatter (the group's blocks touch disjoint dofs)
       impl += op.act * imp;
+      if constexpr (BUF) {
+        const unsigned of = (l == 0 && op.act > 0.0f) ? (unsigned)op.b * 64u + (unsigned)(BF_F * 4) : MJH_BUF_OOB;
+        mjh_v4u f4; mjh_v2u f2;
+        __builtin_memcpy(&f4, f, 16); __builtin_memcpy(&f2, f + 4, 8);
+        __builtin_amdgcn_raw_buffer_store_b128(f4, c.rsrc, (int)of, c.oblkf, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(f2, c.rsrc, (int)(of + 16u), c.oblkf, 0);
+      } else
       if (l == 0 && op.act > 0.0f) {
         float* bf = c.blkf + op.b * BLKF_STRIDE + BF_F;
         *(float4*)(bf) = make_float4(f[0], f[1], f[2], f[3]);
@@ -2483,7 +2551,14 @@ __global__ __launch_bounds__(256) void mjh_solve_kernel(const DConst* __restrict
   mc.has_dim4 = M.has_dim4 != 0; mc.scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1)); mc.tolerance = M.tolerance;
   mc.noslip_iterations = M.noslip_iterations; mc.noslip_tolerance = M.noslip_tolerance;
   mc.nwave = nthr >> 6; mc.wid = tid >> 6; mc.red = s_red;
-  const int niter = pgs_many_body<DIAGM, EXTRA>(mc, lane);
+  {
+    const unsigned long long ga = (unsigned long long)gs;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ga), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ga >> 32));
+    const long long nb = S.gstride * 4;
+    mc.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)(nb > 0x7ffffff0ll ? 0x7ffffff0ll : nb), 0x00020000);
+    mc.oJ = 4 * (-1 - L.J); mc.oB = 4 * (-1 - L.B); mc.oblkf = 4 * (-1 - L.blkf); mc.oblkq = 4 * (-1 - L.blkq); mc.oext = 4 * (-1 - L.ext); mc.oblki = 4 * (-1 - L.blki);
+  }
+  const int niter = pgs_many_body<DIAGM, EXTRA, true>(mc, lane);
   __syncthreads();
   for (int d = tid; d < nv; d += nthr) gs[L.g_qacc + d] = s_qacc[d];
   if (tid == 0) meta[5] = niter;
