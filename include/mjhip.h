@@ -426,7 +426,9 @@ int mjh_debug_stop_at(mjh_engine*, int stage, int with_inverse);
  * step kernel then overlaps the bulk of another's, across consecutive mjh_step calls too.  The caller's
  * stream forks into the cohort streams inside mjh_step and is joined again by the next call of any other
  * entry point, so results and ordering seen through this API do not depend on `n`.  Within a launch the
- * envs are dispatched longest-solver-job first (order rebuilt on the device every step). */
+ * envs are dispatched longest-solver-job first (order rebuilt on the device every MJH_ORDER_EVERY-th step, default 8).
+ * Default n: 1 below 1024 envs, else 2 for the fused step and 3 (from 1536 envs) for the three-launch step of the many-body layout
+ * (MJH_COHORTS overrides it for engines created afterwards). */
 /* m->opt.timestep of a running engine: simulate() doubles it while the simulation lags the wall clock by > 1 ms (up to
  * max_time_step) and halves it back otherwise (mj_main.cpp:150-163) */
 int mjh_set_timestep(mjh_engine*, double dt);
