@@ -2075,7 +2075,14 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             mc.has_dim4 = has_dim4; mc.scale = scale; mc.tolerance = M.tolerance;
             mc.noslip_iterations = M.noslip_iterations; mc.noslip_tolerance = M.noslip_tolerance;
             mc.nwave = 1; mc.wid = 0; mc.red = nullptr;
-            niter = pgs_many_body<DIAGM, EXTRA>(mc, lane);
+            {   // the pools are in the env's global slice here too: same buffer-descriptor fetch as mjh_solve_kernel
+              const unsigned long long ga = (unsigned long long)gs;
+              const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ga), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ga >> 32));
+              const long long nb = S.gstride * 4;
+              mc.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)(nb > 0x7ffffff0ll ? 0x7ffffff0ll : nb), 0x00020000);
+              mc.oJ = 4 * (-1 - L.J); mc.oB = 4 * (-1 - L.B); mc.oblkf = 4 * (-1 - L.blkf); mc.oblkq = 4 * (-1 - L.blkq); mc.oext = 4 * (-1 - L.ext); mc.oblki = 4 * (-1 - L.blki);
+            }
+            niter = pgs_many_body<DIAGM, EXTRA, true>(mc, lane);
           }
           WSYNC();
           for (int d = lane; d < nv; d += 64) s_ws[d] = s_qacc[d];
