@@ -259,49 +259,259 @@ class C5(RobotFixture):
 WORKLOADS = {w.name: w for w in (S24, C2, C3, C4, C5)}
 
 
+def usable_cpus():
+    """CPUs this process may actually run on: the scheduler affinity mask, capped by the cgroup CPU quota (v2 cpu.max, v1
+    cfs_quota / cfs_period) — os.cpu_count() reports the machine, not the container."""
+    info = {"os_cpu_count": os.cpu_count() or 1}
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = info["os_cpu_count"]
+    info["sched_affinity"] = aff
+    quota = None
+    try:
+        t = open("/sys/fs/cgroup/cpu.max").read().split()
+        if t and t[0] != "max":
+            quota = float(t[0]) / float(t[1])
+        info["cgroup_cpu_max"] = " ".join(t)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+            info["cgroup_cfs_quota_over_period"] = q / p if q > 0 else "unlimited"
+        except Exception:
+            pass
+    n = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                info["cpu_model"] = line.split(":", 1)[1].strip(); break
+    except Exception:
+        pass
+    info["usable"] = n
+    return n, info
+
+
 def cpu_baseline(w, sample_envs, budget_s, with_inverse):
     """Oracle (fp64 C restatement, test infrastructure) timed on the host cores on a bounded sample of the SAME workload:
-    the first `sample_envs` envs, started from the state the GPU holds when the timed window ends."""
+    the first envs of the run, started from the state the GPU holds when the timed window ends.  Thread scaling 1 / 8 / 64 /
+    all usable cores, every point after a warm pass; `value` is the all-cores point, `cores` the threads it used."""
     import ctypes as C
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
 
     L = orc.lib()
+    ncores, cpuinfo = usable_cpus()
     sample_envs = min(sample_envs, w.nenv)
     q, v, ws, st = w.env_state(sample_envs)
     ds = []
-    for i in range(sample_envs):
-        d = w.oracle_data(orc, i, None)
-        d.set_qpos(q[i]); d.f("qvel")[:] = v[i]; d.f("qacc_warmstart")[:] = ws[i]; d.f("qacc")[:] = ws[i]
-        ds.append(d)
-    arr = (C.c_void_p * sample_envs)(*[d.d for d in ds])
-    ncores = os.cpu_count() or 1
-    # calibration pass (2 steps of up to one env per core), then a sample sized for the time budget
-    L.orc_set_threads(ncores)
-    ncal = min(sample_envs, ncores)
-    t0 = time.perf_counter(); L.orc_step_many(arr, ncal, 2, int(with_inverse)); cal = time.perf_counter() - t0
-    rate = 2 * ncal / max(cal, 1e-6)
-    steps = int(max(2, min(200, budget_s * rate / sample_envs)))
-    out = {}
-    for label, threads in (("mt", ncores), ("st", 1)):
-        n_envs = sample_envs if threads > 1 else max(1, min(sample_envs, 4))
-        n_steps = steps if threads > 1 else int(max(2, min(steps, budget_s * 0.25 * (rate / ncal) / n_envs)))
-        L.orc_set_threads(threads)
-        t0 = time.perf_counter()
-        L.orc_step_many(arr, n_envs, n_steps, int(with_inverse))
-        dt = time.perf_counter() - t0
-        out[label] = n_envs * n_steps / dt
-        out[label + "_steps"] = n_steps
+
+    def ensure(n):                                   # oracle data of the first n sample envs (created on demand: C2's are large)
+        for i in range(len(ds), n):
+            d = w.oracle_data(orc, i, None)
+            d.set_qpos(q[i]); d.f("qvel")[:] = v[i]; d.f("qacc_warmstart")[:] = ws[i]; d.f("qacc")[:] = ws[i]
+            ds.append(d)
+        return (C.c_void_p * n)(*[d.d for d in ds[:n]])
+
+    points = sorted({t for t in (1, 8, 64, ncores) if t <= ncores})
+    per_point = budget_s / len(points)
+    table = []
+    for T in points:
+        L.orc_set_threads(T)
+        ncal = min(sample_envs, T)
+        arr = ensure(ncal)
+        L.orc_step_many(arr, ncal, 1, int(with_inverse))                 # (creates the team's threads, faults the data in)
+        cal = max(L.orc_step_many_timed(arr, ncal, 1, 1, int(with_inverse)), 1e-6)   # one env-step per thread
+        afford = per_point * T / cal                  # env-steps this point can afford
+        n_envs = min(sample_envs, max(T, min(max(4 * T, 64), int(afford // 4))))
+        n_steps = max(1, min(200, int(afford // n_envs)))
+        arr = ensure(n_envs)
+        # warm step and timed steps inside ONE parallel region: the clock starts with every thread awake (orc_step_many_timed)
+        # (twice, the faster one counts: shared hosts are noisy — a run can lose half its threads to a neighbour)
+        n_steps = max(1, n_steps // 2)
+        runs = [L.orc_step_many_timed(arr, n_envs, 1, n_steps, int(with_inverse)) for _ in range(2)]
+        dt = min(runs)
+        table.append({"threads": T, "value": n_envs * n_steps / dt, "envs": n_envs, "steps": n_steps, "seconds": dt, "seconds_each_run": runs})
+    one, top = table[0], table[-1]
+    for r in table:
+        r["speedup_vs_1thread"] = r["value"] / one["value"]
     nefc = float(np.mean([d.i("nefc") for d in ds])); ncon = float(np.mean([d.i("ncon") for d in ds]))
+    n = len(ds)
     return {
-        "value": out["mt"], "unit": "env-steps/s", "cores": ncores, "kind": "port",
-        "value_1thread": out["st"], "mean_nefc": nefc, "mean_ncon": ncon,
-        "gpu_mean_nefc_same_envs": float(st[:, 1].mean()), "gpu_mean_ncon_same_envs": float(st[:, 0].mean()),
+        "value": top["value"], "unit": "env-steps/s", "cores": top["threads"], "kind": "port",
+        "value_1thread": one["value"], "env_steps_1thread": one["envs"] * one["steps"], "scaling": table, "host": cpuinfo,
+        "mean_nefc": nefc, "mean_ncon": ncon,
+        "gpu_mean_nefc_same_envs": float(st[:n, 1].mean()), "gpu_mean_ncon_same_envs": float(st[:n, 0].mean()),
         "with_inverse": bool(with_inverse),
-        "sample": f"oracle/ fp64 C restatement (PGS in MuJoCo's dense-AR form), first {sample_envs} {w.name} envs started from the GPU's state at the end "
-                  f"of the timed window, {out['mt_steps']} steps, OpenMP over envs ({ncores} threads; 1-thread figure: {out['st_steps']} steps of "
-                  f"{max(1, min(sample_envs, 4))} envs); reference library (libmujoco 2.3.7) absent from this image",
+        "sample": f"oracle/ fp64 C restatement (PGS in MuJoCo's dense-AR form; no allocation inside a step), the first {top['envs']} {w.name} envs started from the "
+                  f"GPU's state at the end of the timed window, {top['steps']} steps after a warm step (best of two runs), a team of {top['threads']} spinning threads drawing (env, 4-step) items = "
+                  f"the usable cores (affinity {cpuinfo['sched_affinity']}, os.cpu_count {cpuinfo['os_cpu_count']}, cgroup quota {cpuinfo.get('cgroup_cpu_max', cpuinfo.get('cgroup_cfs_quota_over_period', 'n/a'))}); "
+                  f"1-thread figure: {one['steps']} steps of {one['envs']} envs (the reference itself steps on one thread, mj_main.cpp:203); "
+                  f"reference library (libmujoco 2.3.7) absent from this image",
     }
+
+
+def launcher_command(argv, ngpus, port=None):
+    """argv of the one-rank-per-GPU launch of this script (what the driver runs for N > 1)"""
+    if port is None:
+        import socket
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` invoked plainly (no WORLD_SIZE): become the N-rank launch instead of refusing."""
+    cmd = launcher_command(sys.argv[1:], args.gpus)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+def run_group_host(args):
+    """--host group: ONE process drives every GPU through the C host API (mjh_group_*: one engine + stream per device, one
+    host thread, RCCL ncclAllGather of the published slice) — the shape of the reference's single node (mj_main.cpp:167-236,
+    one publisher set mj_ros.cpp:554-564; launch/multi_mujoco_sim.launch:9-34 for config C5).  Needs no launcher."""
+    import ctypes as C
+
+    import mujoco_sim_amd as ms
+
+    if args.config not in ("s24", "c5"):
+        raise SystemExit("--host group runs the configs whose environments need no per-step host work: s24, c5")
+    devices = [int(x) for x in args.group_devices.split(",")] if args.group_devices else list(range(args.gpus))
+    ndev = len(devices)
+    wcls = WORKLOADS[args.config]
+    per_gpu = args.envs_per_gpu or wcls.envs_per_gpu
+    total = per_gpu * ndev
+    if args.config == "s24":
+        model = ms.scene("s24"); z = None
+    else:
+        from mujoco_sim_amd.tables import load_model_tables
+        model, z = load_model_tables(os.path.join(GOLD, f"robot_{wcls.fixture}.npz"))
+    g = ms.Group(model, total, devices)
+    for k, (lo, n) in enumerate(g.ranges):
+        e = g.engines[k]
+        if args.cohorts > 0:
+            e.set_cohorts(args.cohorts)
+        if args.config == "s24":
+            e.load_s24(env_offset=lo)
+        else:
+            e.set_controlled_dofs(z["controlled"].astype(np.int32))
+            if "qvel0" in z and np.any(z["qvel0"]):
+                rng = np.random.default_rng(0xC5 + k)
+                e.set_state(qvel=z["qvel0"][None, :] * rng.uniform(0.5, 1.5, size=(n, 1)))
+    inverse = wcls.inverse if args.with_inverse < 0 else bool(args.with_inverse)
+    publish_every = max(1, int(round(1.0 / (60.0 * model.opt.timestep))))
+    count = [0]
+
+    def run(nsteps):
+        for _ in range(nsteps):
+            g.step(1, inverse); count[0] += 1
+            if not args.no_gather and count[0] % publish_every == 0:
+                g.publish_device()
+
+    run(wcls.settle_steps); run(args.warmup); g.synchronize()
+    g.engines[0].set_launch_timing(max(1, args.timing_stride)); g.set_publish_timing(True)
+    t0 = time.perf_counter(); run(args.steps); g.synchronize(); elapsed = time.perf_counter() - t0
+    kernel_ms, n_timed = g.engines[0].get_launch_timing(); g.engines[0].set_launch_timing(False)
+    ag_ms, ag_n = g.get_publish_timing(); g.set_publish_timing(False)
+    st = np.concatenate([e.get_stats() for e in g.engines])
+    cohorts = g.engines[0].cohorts
+    G = cohorts if (cohorts > 1 and g.ranges[0][1] >= 64 * cohorts) else 1
+    bytes_step = algorithmic_bytes_per_env_step(model.nq, model.nv)
+    envs_per_launch = g.ranges[0][1] / G
+    achieved = bytes_step * envs_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    out = {
+        "metric": METRIC if args.config == "s24" else f"env-steps/sec (whole node), BASELINE config {args.config.upper()}",
+        "value": total * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": ndev, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wcls.label, "name": args.config, "settle_steps": wcls.settle_steps, "envs_per_gpu": per_gpu, "envs_total": total,
+                   "cohorts": cohorts, "with_inverse": bool(inverse), "parallelism": f"env-sharded x{ndev}, one process (mjh_group)",
+                   "nq": int(model.nq), "nv": int(model.nv), "mean_ncon": float(st[:, 0].mean()), "mean_nefc": float(st[:, 1].mean()),
+                   "mean_solver_iter": float(st[:, 2].mean())},
+        "host": {"kind": "group", "api": "mjh_group_create / mjh_group_step / mjh_group_publish (csrc/group.hip)", "devices": devices,
+                 "ranks": [{"rank": k, "device": devices[k], "env0": lo, "nenv": n} for k, (lo, n) in enumerate(g.ranges)],
+                 "rccl": bool(g.uses_rccl), "rccl_ranks": ndev if g.uses_rccl else 0,
+                 "transport": "RCCL ncclAllGather (ncclCommInitAll, one group call)" if g.uses_rccl else "peer copies (hipMemcpyPeerAsync)",
+                 "all_gather": {"ms_mean": ag_ms, "count": ag_n, "bytes_per_rank": int(g.ranges[0][1] * g.stride * 4), "publish_every_steps": publish_every}},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "mjh_step_kernel", "kernel_ms": kernel_ms, "launches_timed": n_timed, "envs_per_launch": envs_per_launch,
+                     "algorithmic_bytes_per_env_step": bytes_step, "note": "device 0's launches; per-launch figure"},
+    }
+    g.close()
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
+
+
+def short_config_line(ms, args, name, device, stream):
+    """One of the other BASELINE configs under the driver's fixed command: the config's own settle phase + a short timed
+    window (its default mj_inverse variant), no CPU leg — a bounded run whose line rides in the S24 line's `configs`."""
+    import copy
+    a = copy.copy(args); a.envs_per_gpu = 0; a.pack = 0; a.maxcon = 0
+    w = WORKLOADS[name](ms, a, 0, device, stream)
+    eng = w.eng
+    try:
+        if w.cohorts > 0:
+            eng.set_cohorts(w.cohorts)
+        publish_every = max(1, int(round(1.0 / (60.0 * w.model.opt.timestep))))
+        import torch
+        pub = torch.empty(w.rows * eng.state_stride, dtype=torch.float32, device="cuda")
+
+        def run(n):
+            for _ in range(n):
+                w.step(1, w.inverse)
+                if w.step_count % publish_every == 0:
+                    eng.export_state_device(pub.data_ptr())
+
+        run(w.settle_steps); run(5); eng.synchronize()
+        steps = args.extra_steps
+        eng.set_launch_timing(1)
+        t0 = time.perf_counter(); run(steps); eng.synchronize(); el = time.perf_counter() - t0
+        kms, nt = eng.get_launch_timing(); eng.set_launch_timing(False)
+        st = eng.get_stats()
+        cohorts = eng.cohorts
+        G = cohorts if (cohorts > 1 and w.rows >= 64 * cohorts) else 1
+        b = algorithmic_bytes_per_env_step(w.base_model.nq, w.base_model.nv)
+        ach = b * (w.nenv / G) / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        return {"value": w.nenv * steps / el, "unit": "env-steps/s", "envs": w.nenv, "steps": steps, "settle_steps": w.settle_steps,
+                "ms_per_step": el / steps * 1e3, "with_inverse": bool(w.inverse), "cohorts": cohorts, "envs_per_wavefront": w.pack,
+                "kernel_ms": kms, "roofline_frac": ach / HBM_PEAK_GBS, "roofline_achieved_GBs": ach, "algorithmic_bytes_per_env_step": b,
+                "mean_ncon": float(st[:, 0].mean()) / w.pack, "mean_nefc": float(st[:, 1].mean()) / w.pack,
+                "mean_solver_iter": float(st[:, 2].mean()), "overflow_envs": int((st[:, 3] & 3 != 0).sum()), "workload": w.label}
+    finally:
+        eng.close()
+
+
+def literal_loop_line(w, steps):
+    """The LITERAL loop body of the reference (mj_main.cpp:82-112) on the main workload's engine: per step mjh_step1 ->
+    MjHWInterface::read of env 0 (mjh_inverse + joint state to the host: a host synchronisation) -> controller_manager ->
+    MjHWInterface::write of env 0 (command from the host) -> mjh_step2.  Three launches and two small transfers per step, no
+    cohort overlap: what a ROS node that keeps the per-step hand-off gets; the fused mjh_step is what `value` measures."""
+    e = w.eng
+    cmd = np.zeros((1, e.nv))
+    e.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        e.step1(); e.inverse()
+        e.get_joint_state(0, 1)
+        e.set_cmd(ddq=cmd, dq=None, env0=0)
+        e.step2()
+    e.synchronize()
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        e.step(1, True)
+        e.get_joint_state(0, 1)
+        e.set_cmd(ddq=cmd, dq=None, env0=0)
+    e.synchronize()
+    dt2 = time.perf_counter() - t0
+    return {"value": w.nenv * steps / dt, "unit": "env-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "envs": w.nenv,
+            "sequence": "mjh_step1 -> mjh_inverse + mjh_get_joint_state(env 0) -> mjh_set_cmd(env 0) -> mjh_step2 (3 launches, 2 host transfers per step)",
+            "fused_step_with_per_step_read_write": {"value": w.nenv * steps / dt2, "ms_per_step": dt2 / steps * 1e3}}
 
 
 def main():
@@ -320,18 +530,34 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-second-window", action="store_true", help="skip the second timed window (the other mj_inverse variant)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the publish all-gather even with one rank (self-test of the multi-GPU path)")
+    ap.add_argument("--host", choices=["ranks", "group"], default="ranks",
+                    help="N > 1: `ranks` = one process per GPU over torch.distributed (what the driver launches; a plain invocation re-executes itself "
+                         "under torch.distributed.run), `group` = ONE process driving every GPU through mjh_group_* (the C host API, RCCL all-gather)")
+    ap.add_argument("--group-devices", default="", help="--host group: comma-separated device list (default 0..N-1; the same device twice is a one-GPU self-test on peer copies)")
+    ap.add_argument("--no-extra-configs", action="store_true", help="S24 at N = 1 appends short lines of the other BASELINE configs (c2..c5) and the literal loop; skip them")
+    ap.add_argument("--extra-steps", type=int, default=20, help="timed steps of each appended config line")
+    ap.add_argument("--rank-probe", action="store_true", help=argparse.SUPPRESS)     # tests: every rank prints its rank / world size and exits
     ap.add_argument("--cpu-envs", type=int, default=1024)
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time budget of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="time budget of the CPU baseline sample")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.host == "group" and (args.gpus > 1 or args.group_devices):
+        if "WORLD_SIZE" in os.environ and world > 1:
+            raise SystemExit("--host group is ONE process for all GPUs: start it plainly, not under torch.distributed.run")
+        return run_group_host(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args)             # does not return
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} under a launcher with WORLD_SIZE={world}: start it with --nproc-per-node {args.gpus}, or plainly")
+    if args.rank_probe:
+        print(f"RANKPROBE {rank} {world} {local_rank}", flush=True)
+        return
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -355,13 +581,19 @@ def main():
     gathered = torch.empty(world * w.rows * stride, dtype=torch.float32, device="cuda") if use_dist else None
     publish_every = max(1, int(round(1.0 / (60.0 * model.opt.timestep))))  # 60 Hz of simulated time
 
-    def run(nsteps, inverse):
+    ag_events = []
+
+    def run(nsteps, inverse, time_gather=False):
         for _ in range(nsteps):
             w.step(1, inverse)
             if not args.no_gather and w.step_count % publish_every == 0:   # 60 Hz publish: packed state slice (+ RCCL all-gather)
                 eng.export_state_device(pub.data_ptr())
                 if use_dist:
-                    dist.all_gather_into_tensor(gathered, pub)
+                    if time_gather:
+                        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        a_.record(); dist.all_gather_into_tensor(gathered, pub); b_.record(); ag_events.append((a_, b_))
+                    else:
+                        dist.all_gather_into_tensor(gathered, pub)
 
     def timed(nsteps, inverse):
         torch.cuda.synchronize()
@@ -372,7 +604,7 @@ def main():
         # `--timing-stride` so that the event pairs do not slow launch-bound configs down (C5: 34 M with every launch timed)
         eng.set_launch_timing(max(1, args.timing_stride))
         t0 = time.perf_counter()
-        run(nsteps, inverse)
+        run(nsteps, inverse, time_gather=True)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -450,11 +682,31 @@ def main():
     if unsettled:
         out["unsettled"] = True; out["valid"] = False
         out["note"] = f"mean_ncon {mean_ncon:.1f} < {w.min_ncon}: the scene is not in the state the metric names — do not use `value`"
+    if use_dist:
+        from mujoco_sim_amd import shard
+        ag_ms = [a_.elapsed_time(b_) for a_, b_ in ag_events]
+        out["host"] = {"kind": "ranks", "api": "one process per GPU under torch.distributed.run; dist.all_gather_into_tensor over RCCL", "rccl_ranks": world,
+                       "ranks": [{"rank": r, "env0": shard.env_range(total_envs, world, r)[0], "nenv": shard.env_range(total_envs, world, r)[1] - shard.env_range(total_envs, world, r)[0]} for r in range(world)],
+                       "all_gather": {"ms_mean": float(np.mean(ag_ms)) if ag_ms else None, "count": len(ag_ms), "bytes_per_rank": int(w.rows * stride * 4),
+                                      "publish_every_steps": publish_every, "note": "stream time of the collective on rank 0 (includes waiting for the slowest rank's pack)"}}
+    if rank == 0 and world == 1 and w.name == "s24" and not args.no_extra_configs and not args.force_dist:
+        # the literal reference loop and the other four BASELINE configs, as short bounded runs, in the SAME line (extra keys)
+        try:
+            out["literal_loop"] = literal_loop_line(w, max(20, min(args.steps, 100)))
+        except Exception as ex:   # an extra must never cost the headline
+            out["literal_loop"] = {"error": repr(ex)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is timed at N = 1 only
         out["cpu_baseline"] = cpu_baseline(w, args.cpu_envs, args.cpu_seconds, main_inverse)
     if use_dist:
         dist.barrier()
     eng.close()
+    if rank == 0 and world == 1 and w.name == "s24" and not args.no_extra_configs and not args.force_dist:
+        out["configs"] = {}
+        for name in ("c2", "c3", "c4", "c5"):
+            try:
+                out["configs"][name] = short_config_line(ms, args, name, local_rank, stream.cuda_stream)
+            except Exception as ex:
+                out["configs"][name] = {"error": repr(ex)}
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

@@ -475,6 +475,10 @@ int mjh_group_publish(mjh_group*, float* host_out);
 const float* mjh_group_state_device(const mjh_group*, int rank);   /* the gathered state on device `rank` (valid after publish, in stream order) */
 int mjh_group_state_stride(const mjh_group*);
 int mjh_group_uses_rccl(const mjh_group*);
+/* HIP events on device 0's stream around the exchange of every publish (the all-gather, or the peer copies): mean duration in
+ * milliseconds and the number of publishes since the last call */
+int mjh_group_set_publish_timing(mjh_group*, int on);
+int mjh_group_get_publish_timing(mjh_group*, double* mean_ms, int* count);
 void mjh_group_set_transport(int mode);   /* groups created afterwards: 0 = RCCL when available (default), 1 = peer copies */
 
 /* ROS-free harness of the host loop (csrc/host_sim.cpp: simulate() + MjhHWInterface, mirrors of

@@ -161,7 +161,7 @@ static int pair_cap(int t1, int t2) {
 // Host-only derivation of the device model: packed tables, derived topology tables, capacities and the LDS
 // layout.  Needs no HIP device (mjh_query_lds_bytes uses it for capacity planning and in the CPU tests).
 struct HostPack { DModel M{}; Lay L{}; std::vector<int> I; std::vector<float> F; int o_controlled = 0, o_odom = 0, lds_bytes = 0; long long gstride = 0; };
-static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big = false) {
+static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big = false, bool allow_patch = true) {
   DModel& M = hp.M; std::vector<int>& I = hp.I; std::vector<float>& F = hp.F;
   // ---- derived integer tables
   const int nb = m->nbody, nv = m->nv, nj = m->njnt, ng = m->ngeom;
@@ -292,7 +292,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     if ((diagM ? 1 : 2) * jsz < need) jsz = diagM ? need : (need + 1) / 2;
     // contact-patch sweep (patch_pgs.h): free bodies only, no noslip pass, pools in LDS, at most 64 contacts (the patch builder
     // keeps one contact per lane).  Same rule as the oracle's patch order (oracle/mjh_oracle.c: m_patch_order).
-    const bool patch = diagM && !big && nv <= 32 && M.noslip_iterations == 0 && M.maxcon <= 64 && !keep;
+    const bool patch = allow_patch && diagM && !big && nv <= 32 && M.noslip_iterations == 0 && M.maxcon <= 64 && !keep;
     M.patch = patch ? 1 : 0;
     L.qpos = put(m->nq);
     L.qvel = put(nv); L.qvref = put(nv); L.ws = put(nv); L.qacc = put(nv); L.smooth = put(nv); L.asmooth = put(nv); L.passive = put(nv);
@@ -396,6 +396,10 @@ static void derive_fitting(const mjh_model* m, HostPack& hp) {
   // (models on the contact-patch sweep stay LDS-resident under the default policy: their visiting order is the patch order,
   //  which the many-body layout does not have; mjh_solver_order() tells which one an engine runs)
   if (hp.M.patch && policy == 0 && hp.lds_bytes <= 64 * 1024) return;
+  // The patch sweep packs two LDS byte addresses into one 32-bit word (patch_pgs.h: laddr(x) | laddr(y) << 16), which holds
+  // only while the workgroup's LDS stays within 64 KiB.  A patch model that would stay LDS-resident beyond that (policy 1 /
+  // MJH_FORCE_BIG=0 with a large user-set maxefc) is re-derived WITHOUT the patch sweep (pair order, mjh_solver_order() = 0).
+  if (hp.M.patch && hp.lds_bytes > 64 * 1024 && hp.lds_bytes <= limit) { HostPack np; derive_device_model(m, np, false, false); hp = np; }
   if ((hp.lds_bytes > 160 * 1024 || hp.lds_bytes > limit) && !hp.M.big && hp.M.rowW <= 64) { HostPack big; derive_device_model(m, big, true); hp = big; }
 }
 
@@ -558,7 +562,12 @@ extern "C" int mjh_step2(mjh_engine* e) {
   e->step1_done = false;
   return launch_lpt(e, PH_STEP2, XF_FORCE, false);
 }
-extern "C" int mjh_forward(mjh_engine* e) { ENG(e); return launch_lpt(e, PH_STEP1 | PH_NOINT, XF_FORCE, true); }
+extern "C" int mjh_forward(mjh_engine* e) {
+  ENG(e);
+  // mj_forward runs mjcb_control like mj_step1 does, so the in-engine PD law is evaluated in front of it as well
+  if (e->pd_on) { int rc = launch_pd(e, e->stream, 0, e->nenv); if (rc) return rc; }
+  return launch_lpt(e, PH_STEP1 | PH_NOINT, XF_FORCE, true);
+}
 extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
   ENG_NOJOIN(e);
   if (e->lpt && !e->d_order && e->nenv >= 1024) {

@@ -8,7 +8,6 @@
 // back to peer copies (hipMemcpyPeerAsync), which is also what a gather to ONE consumer would use.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cstring>
@@ -20,6 +19,15 @@
 void mjh_set_error(const std::string& s);  // model_builder.cpp
 
 #define GCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { mjh_set_error(std::string(#call) + ": " + hipGetErrorString(e_)); return MJH_ERR_NO_DEVICE; } } while (0)
+
+// The handful of RCCL declarations the all-gather needs, stated here instead of #include <rccl/rccl.h>: the library is a RUN-TIME
+// dependency only (dlopen below), so a ROCm install without the RCCL headers still builds libmjhip.so — single-GPU engine
+// and peer-copy group included.  Values are NCCL's public ABI (ncclSuccess = 0, ncclFloat32 = 7).
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+static const ncclResult_t ncclSuccess = 0;
+static const ncclDataType_t ncclFloat = 7;
 
 namespace {
 struct Rccl {
@@ -64,6 +72,10 @@ struct mjh_group {
   std::vector<mjh_engine*> eng;
   std::vector<hipStream_t> stream;
   std::vector<hipEvent_t> ready;                     // send buffer of device k packed (peer-copy transport)
+  std::vector<hipEvent_t> consumed;                  // stream k has finished reading every rank's send buffer (peer-copy transport)
+  bool published = false;                            // consumed[] have been recorded at least once
+  hipEvent_t t0 = nullptr, t1 = nullptr;             // device 0's stream around the exchange (mjh_group_publish_timing)
+  bool timing = false, t_pending = false; double t_sum_ms = 0; int t_count = 0;
   std::vector<float*> send, recv, packed;            // per device: own slice | every rank's slot | env-ordered, contiguous
   float* host = nullptr;                             // pinned staging of the gathered state (rank 0's copy)
   Rccl* rccl = nullptr; std::vector<ncclComm_t> comm;
@@ -82,8 +94,11 @@ extern "C" void mjh_group_destroy(mjh_group* g) {
     if (k < (int)g->recv.size() && g->recv[k]) (void)hipFree(g->recv[k]);
     if (g->padded && k < (int)g->packed.size() && g->packed[k]) (void)hipFree(g->packed[k]);
     if (k < (int)g->ready.size() && g->ready[k]) (void)hipEventDestroy(g->ready[k]);
+    if (k < (int)g->consumed.size() && g->consumed[k]) (void)hipEventDestroy(g->consumed[k]);
     if (k < (int)g->stream.size() && g->stream[k]) (void)hipStreamDestroy(g->stream[k]);
   }
+  if (g->t0) (void)hipEventDestroy(g->t0);
+  if (g->t1) (void)hipEventDestroy(g->t1);
   if (g->host) (void)hipHostFree(g->host);
   delete g;
 }
@@ -95,7 +110,7 @@ extern "C" int mjh_group_create(const mjh_model* model, int nenv_total, const in
   mjh_group* g = new mjh_group();
   g->model = model; g->nenv = nenv_total; g->ndev = ndev;
   g->dev.resize(ndev); g->env0.resize(ndev); g->n.resize(ndev);
-  g->eng.assign(ndev, nullptr); g->stream.assign(ndev, nullptr); g->ready.assign(ndev, nullptr);
+  g->eng.assign(ndev, nullptr); g->stream.assign(ndev, nullptr); g->ready.assign(ndev, nullptr); g->consumed.assign(ndev, nullptr);
   g->send.assign(ndev, nullptr); g->recv.assign(ndev, nullptr); g->packed.assign(ndev, nullptr);
   bool distinct = true;
   for (int k = 0; k < ndev; k++) {
@@ -112,6 +127,7 @@ extern "C" int mjh_group_create(const mjh_model* model, int nenv_total, const in
     GFAIL(hipSetDevice(g->dev[k]));
     GFAIL(hipStreamCreateWithFlags(&g->stream[k], hipStreamNonBlocking));
     GFAIL(hipEventCreateWithFlags(&g->ready[k], hipEventDisableTiming));
+    GFAIL(hipEventCreateWithFlags(&g->consumed[k], hipEventDisableTiming));
     const int rc = mjh_create(model, g->n[k], g->dev[k], g->stream[k], &g->eng[k]);
     if (rc) { mjh_group_destroy(g); return rc; }
   }
@@ -127,6 +143,8 @@ extern "C" int mjh_group_create(const mjh_model* model, int nenv_total, const in
     GFAIL(hipStreamSynchronize(g->stream[k]));
   }
   GFAIL(hipHostMalloc((void**)&g->host, (size_t)nenv_total * g->stride * sizeof(float), hipHostMallocDefault));
+  GFAIL(hipSetDevice(g->dev[0]));
+  GFAIL(hipEventCreate(&g->t0)); GFAIL(hipEventCreate(&g->t1));
 #undef GFAIL
   if (g_transport == 0 && distinct) {
     g->rccl = load_rccl();
@@ -171,23 +189,43 @@ extern "C" int mjh_group_synchronize(mjh_group* g) { if (!g) return MJH_ERR_ARG;
 
 // Publish: every device packs its slice (time | qpos | qvel per env) behind the steps queued so far, then ONE all-gather
 // leaves the full, env-ordered state on every device; host_out (optional, [nenv * stride] floats) receives device 0's copy.
+static void collect_timing(mjh_group* g) {
+  if (!g->t_pending) return;
+  float ms = 0;
+  if (hipEventSynchronize(g->t1) == hipSuccess && hipEventElapsedTime(&ms, g->t0, g->t1) == hipSuccess) { g->t_sum_ms += ms; g->t_count++; }
+  g->t_pending = false;
+}
 extern "C" int mjh_group_publish(mjh_group* g, float* host_out) {
   if (!g) { mjh_set_error("null group"); return MJH_ERR_ARG; }
   const size_t slot_bytes = g->slot * sizeof(float);
+  if (g->timing) collect_timing(g);
   for (int k = 0; k < g->ndev; k++) {
+    if (!g->rccl && g->published) {
+      // peer-copy transport: send[k] is about to be overwritten — every consumer stream must be done reading the previous
+      // publish's copy of it first (a lagging device would otherwise gather a torn slice, or one from a later step)
+      GCHK(hipSetDevice(g->dev[k]));
+      for (int r = 0; r < g->ndev; r++) if (r != k) GCHK(hipStreamWaitEvent(g->stream[k], g->consumed[r], 0));
+    }
     const int rc = mjh_export_state_device(g->eng[k], g->send[k]);      // (re-selects device k)
     if (rc) return rc;
     if (!g->rccl) GCHK(hipEventRecord(g->ready[k], g->stream[k]));
   }
+  if (g->timing) { GCHK(hipSetDevice(g->dev[0])); GCHK(hipEventRecord(g->t0, g->stream[0])); }
   if (g->rccl) {
+    // every exit path passes ncclGroupEnd: a failure inside the group is remembered, not returned from
     ncclResult_t r = g->rccl->GroupStart();
-    for (int k = 0; k < g->ndev && r == ncclSuccess; k++) {
-      GCHK(hipSetDevice(g->dev[k]));
-      r = g->rccl->AllGather(g->send[k], g->recv[k], g->slot, ncclFloat, g->comm[k], g->stream[k]);
+    hipError_t he = hipSuccess;
+    if (r == ncclSuccess) {
+      for (int k = 0; k < g->ndev && r == ncclSuccess && he == hipSuccess; k++) {
+        he = hipSetDevice(g->dev[k]);
+        if (he == hipSuccess) r = g->rccl->AllGather(g->send[k], g->recv[k], g->slot, ncclFloat, g->comm[k], g->stream[k]);
+      }
+      const ncclResult_t r2 = g->rccl->GroupEnd();
+      if (r == ncclSuccess) r = r2;
     }
-    const ncclResult_t r2 = g->rccl->GroupEnd();
-    if (r != ncclSuccess || r2 != ncclSuccess) {
-      mjh_set_error(std::string("ncclAllGather: ") + (g->rccl->GetErrorString ? g->rccl->GetErrorString(r != ncclSuccess ? r : r2) : "failed"));
+    if (he != hipSuccess) { mjh_set_error(std::string("hipSetDevice (all-gather): ") + hipGetErrorString(he)); return MJH_ERR_NO_DEVICE; }
+    if (r != ncclSuccess) {
+      mjh_set_error(std::string("ncclAllGather: ") + (g->rccl->GetErrorString ? g->rccl->GetErrorString(r) : "failed"));
       return MJH_ERR_NO_DEVICE;
     }
   } else {
@@ -197,8 +235,11 @@ extern "C" int mjh_group_publish(mjh_group* g, float* host_out) {
         GCHK(hipStreamWaitEvent(g->stream[k], g->ready[r], 0));
         GCHK(hipMemcpyPeerAsync(g->recv[k] + (size_t)r * g->slot, g->dev[k], g->send[r], g->dev[r], slot_bytes, g->stream[k]));
       }
+      GCHK(hipEventRecord(g->consumed[k], g->stream[k]));
     }
+    g->published = true;
   }
+  if (g->timing) { GCHK(hipSetDevice(g->dev[0])); GCHK(hipEventRecord(g->t1, g->stream[0])); g->t_pending = true; }
   if (g->padded)     // uneven shares: the ranks' slots carry padding behind the smaller shares; close the gaps
     for (int k = 0; k < g->ndev; k++) {
       GCHK(hipSetDevice(g->dev[k]));
@@ -213,6 +254,20 @@ extern "C" int mjh_group_publish(mjh_group* g, float* host_out) {
     GCHK(hipStreamSynchronize(g->stream[0]));
     std::memcpy(host_out, g->host, bytes);
   }
+  return MJH_OK;
+}
+// HIP events on device 0's stream around the exchange (all-gather or peer copies) of every publish: the collective's own time
+extern "C" int mjh_group_set_publish_timing(mjh_group* g, int on) {
+  if (!g) { mjh_set_error("null group"); return MJH_ERR_ARG; }
+  g->timing = on != 0; g->t_pending = false; g->t_sum_ms = 0; g->t_count = 0;
+  return MJH_OK;
+}
+extern "C" int mjh_group_get_publish_timing(mjh_group* g, double* mean_ms, int* count) {
+  if (!g) { mjh_set_error("null group"); return MJH_ERR_ARG; }
+  collect_timing(g);
+  if (mean_ms) *mean_ms = g->t_count ? g->t_sum_ms / g->t_count : 0.0;
+  if (count) *count = g->t_count;
+  g->t_sum_ms = 0; g->t_count = 0;
   return MJH_OK;
 }
 extern "C" const float* mjh_group_state_device(const mjh_group* g, int k) { return g && k >= 0 && k < g->ndev ? g->packed[k] : nullptr; }

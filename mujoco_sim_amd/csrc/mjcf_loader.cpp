@@ -2,10 +2,10 @@
 // (load_XML -> mj_loadXML, include/mujoco_sim/mj_util.h:185-193) for the element subset its models use on
 // the step path: <compiler angle autolimits>, <option timestep gravity impratio iterations tolerance>,
 // root <default> (<geom>, <joint>), <worldbody>/<body> trees with <inertial>, <joint> (free, ball, hinge, slide),
-// <freejoint>, <geom> (plane, sphere, capsule, cylinder, box; mesh geoms are skipped with a note), gravcomp,
+// <freejoint>, <geom> (plane, sphere, capsule, cylinder, box, ellipsoid, mesh: binary / ASCII STL and OBJ assets become convex hulls), gravcomp,
 // <contact><exclude>, <equality><joint polycoef> / <weld> / <connect>, <body mocap>, <site>, <sensor><force> / <torque>.  Everything is translated into mjh_builder_* calls; physics
 // defaults follow MuJoCo's documented defaults (angle = degree, hinge axis 0 0 1, geom type sphere, ...).
-// Not handled (reported in the returned note): tendons, actuators, sensors, <weld> / <connect> equalities.
+// Not handled (reported in the returned note, mjh_load_note): tendons, actuators, height fields, sensors other than force / torque.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

@@ -1944,7 +1944,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
             WSYNC();
             PROF(12);
             niter = patch_sweep(pa, lane, nstep, M.iterations, M.tolerance, 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1)));
-            cost_hint = ((niter * swork) >> 1) + 1;   // (100 sweeps x 5 steps of 40 -> 10000 -> bucket 156 of the launch order's 256)
+            cost_hint = min(((niter * swork) >> 1) + 1, 1 << 22);   // (100 sweeps x 5 steps of 40 -> 10000 -> bucket 156 of the launch order's 256)
             WSYNC();
             for (int d = lane; d < nv; d += 64) { const float qa = s_qacc[d] * s_bias[d]; s_qacc[d] = qa; s_ws[d] = qa; }
             PROF(13);
@@ -2515,7 +2515,7 @@ __global__ __launch_bounds__(1024) void mjh_order_kernel(const int* __restrict__
   if (t < 256) hist[t] = 0;
   __syncthreads();
   // (kernels that know their solver work better leave a hint in bits 8.. of the flag word: the patch sweep's sweeps x step cost)
-  auto bucket = [&](int e) { const int hint = stats[4*e + 3] >> 8; const int cost = hint ? hint : stats[4*e + 2] * (stats[4*e + 1] + 24); int b = cost >> 6; return b > 255 ? 255 : b; };   // 100 it x 232 rows -> 362 -> clamp
+  auto bucket = [&](int e) { const int hint = stats[4*e + 3] >> 8; const int cost = hint ? hint : stats[4*e + 2] * (stats[4*e + 1] + 24); int b = cost >> 6; return b > 255 ? 255 : (b < 0 ? 0 : b); };   // 100 it x 232 rows -> 362 -> clamp
   for (int e = t; e < nenv; e += 1024) atomicAdd(&hist[255 - bucket(e)], 1);
   __syncthreads();
   if (t == 0) { int acc = 0; for (int b = 0; b < 256; b++) { base[b] = acc; acc += hist[b]; } }

@@ -363,6 +363,17 @@ class Group:
         _chk(self.lib, self.lib.mjh_group_publish(self.h, out.ctypes.data_as(C.POINTER(C.c_float))), "mjh_group_publish")
         return out
 
+    def publish_device(self):
+        """pack + all-gather without the host copy (the gathered state stays on every device: mjh_group_state_device)"""
+        _chk(self.lib, self.lib.mjh_group_publish(self.h, None), "mjh_group_publish")
+
+    def set_publish_timing(self, on=True): _chk(self.lib, self.lib.mjh_group_set_publish_timing(self.h, int(on)), "mjh_group_set_publish_timing")
+    def get_publish_timing(self):
+        """-> (mean duration of the exchange [ms], publishes) since the last call"""
+        ms_, cnt = C.c_double(0), C.c_int(0)
+        _chk(self.lib, self.lib.mjh_group_get_publish_timing(self.h, C.byref(ms_), C.byref(cnt)), "mjh_group_get_publish_timing")
+        return ms_.value, cnt.value
+
     def locate(self, env):
         r, l = C.c_int(0), C.c_int(0)
         _chk(self.lib, self.lib.mjh_group_locate(self.h, env, C.byref(r), C.byref(l)), "mjh_group_locate")

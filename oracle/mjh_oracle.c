@@ -11,6 +11,7 @@
 #include "mjh_oracle.h"
 
 #include <math.h>
+#include <omp.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -139,6 +140,10 @@ orc_data* orc_make_data(const mjh_model* m) {
   d->initial_qpos = dalloc(nq);
   for (int i = 0; i < 6; i++) d->scr_nv[i] = dalloc(nv);
   d->scr_nM = dalloc(m->nM);
+  /* per-step scratch that used to be malloc'ed inside the step (Jacobian rows of one point; the Gauss-Seidel order builder) */
+  d->scr_jac = dalloc(12 * (size_t)(nv ? nv : 1));
+  d->scr_int = ialloc((size_t)(ne + 1) * 12);
+  d->scr_key = (long long*)calloc((size_t)ne + 1, sizeof(long long));
   for (int i = 0; i < 3; i++) d->scr_efc[i] = dalloc(ne);
   d->scr_B = dalloc((size_t)(ne > 6 ? ne : 6)*nv);
   for (int i = 0; i < 3; i++) d->scr_body6[i] = dalloc(6*nb);
@@ -166,6 +171,7 @@ void orc_free_data(orc_data* d) {
   for (size_t i = 0; i < sizeof(ps)/sizeof(ps[0]); i++) free(ps[i]);
   for (int i = 0; i < 6; i++) free(d->scr_nv[i]);
   for (int i = 0; i < 3; i++) { free(d->scr_efc[i]); free(d->scr_body6[i]); }
+  free(d->scr_jac); free(d->scr_int); free(d->scr_key);
   free(d->contact); free(d->efc_type); free(d->efc_id); free(d->controlled); free(d->pd_target);
   free(d);
 }
@@ -1049,7 +1055,7 @@ void orc_make_constraint(orc_data* d) {
         double p1[3], p2[3], t[3];
         rotvec(t, d->xmat + 9*b1, a1); for (int k = 0; k < 3; k++) p1[k] = d->xpos[3*b1+k] + t[k];
         rotvec(t, d->xmat + 9*b2, a2); for (int k = 0; k < 3; k++) p2[k] = d->xpos[3*b2+k] + t[k];
-        double* jb = (double*)malloc(sizeof(double) * 12 * (size_t)(nv ? nv : 1));
+        double* jb = d->scr_jac;
         double *jp1 = jb, *jp2 = jb + 3*nv, *jr1 = jb + 6*nv, *jr2 = jb + 9*nv;
         jac_point(d, jp1, jr1, p1, b1); jac_point(d, jp2, jr2, p2, b2);
         const double tran = binv[2*b1] + binv[2*b2], rot = binv[2*b1+1] + binv[2*b2+1];
@@ -1076,7 +1082,6 @@ void orc_make_constraint(orc_data* d) {
             d->efc_diagApprox[r] = rot;
           }
         }
-        free(jb);
         if (fail) break;
         continue;
       }
@@ -1119,7 +1124,7 @@ void orc_make_constraint(orc_data* d) {
       }
     }
   /* contacts: pyramidal friction cones */
-  double* jbuf = (double*)malloc(sizeof(double) * 12 * (size_t)(nv ? nv : 1));
+  double* jbuf = d->scr_jac;
   double *jp1 = jbuf, *jp2 = jbuf + 3*nv, *jr1 = jbuf + 6*nv, *jr2 = jbuf + 9*nv;
   for (int ic = 0; ic < d->ncon; ic++) {
     orc_contact* c = d->contact + ic;
@@ -1155,7 +1160,6 @@ void orc_make_constraint(orc_data* d) {
       }
     }
   }
-  free(jbuf);
   /* impedance, regulariser, reference parameters */
   int nefc = d->nefc;
   for (int i = 0; i < nefc; i++) {
@@ -1248,14 +1252,13 @@ void orc_passive(orc_data* d) {
   }
   for (int i = 0; i < nv; i++) d->qfrc_passive[i] -= m->dof_damping[i] * d->qvel[i];
   if (!(m->opt.disableflags & MJH_DSBL_GRAVITY)) {
-    double* jp = (double*)malloc(sizeof(double) * 3 * (size_t)(nv ? nv : 1));
+    double* jp = d->scr_jac;
     for (int i = 1; i < m->nbody; i++) {
       if (m->body_gravcomp[i] == 0) continue;
       double f[3]; for (int k = 0; k < 3; k++) f[k] = -m->opt.gravity[k] * mass[i] * m->body_gravcomp[i];
       jac_point(d, jp, NULL, d->xipos + 3*i, i);
       for (int q = 0; q < nv; q++) d->qfrc_passive[q] += jp[q]*f[0] + jp[nv+q]*f[1] + jp[2*nv+q]*f[2];
     }
-    free(jp);
   }
 }
 
@@ -1327,11 +1330,10 @@ void orc_fwd_acceleration(orc_data* d) {
     for (int b = 1; b < d->m->nbody; b++) {
       const double* f = d->xfrc_applied + 6*b;
       if (f[0] == 0 && f[1] == 0 && f[2] == 0 && f[3] == 0 && f[4] == 0 && f[5] == 0) continue;
-      if (!jb) jb = (double*)malloc(sizeof(double) * 6 * (size_t)(nv ? nv : 1));
+      jb = d->scr_jac;
       jac_point(d, jb, jb + 3*nv, d->xipos + 3*b, b);
       for (int i = 0; i < nv; i++) for (int k = 0; k < 3; k++) d->qfrc_smooth[i] += jb[k*nv+i] * f[k] + jb[(3+k)*nv+i] * f[3+k];
     }
-    free(jb);
   }
   copyv(d->qacc_smooth, d->qfrc_smooth, nv);
   orc_solve_m(d, d->qacc_smooth);
@@ -1404,7 +1406,7 @@ static int m_patch_order(const mjh_model* m) {
 static int pgs_order(const orc_data* d, int* order) {
   int nefc = d->nefc, nblk = 0;
   if (g_pgs_row_order) { for (int i = 0; i < nefc; i++) order[i] = i; return nefc; }
-  int* bstart = (int*)malloc(sizeof(int) * (size_t)(nefc + 1) * 5);
+  int* bstart = d->scr_int;                       /* (nefc + 1) * 5 ints; the sequences below take the next (nefc + 1) * 6 */
   int *bnum = bstart + nefc + 1, *bt1 = bnum + nefc + 1, *bt2 = bt1 + nefc + 1, *used = bt2 + nefc + 1;
   for (int i = 0; i < nefc;) {
     int n = 1;
@@ -1418,9 +1420,9 @@ static int pgs_order(const orc_data* d, int* order) {
     /* contacts sorted by (couples two bodies first, body pair, constraint order); a patch = a maximal run of contacts of one
      * body pair with at most 16 rows; a step = a patch plus up to three later unvisited patches of the sequence that share no
      * body with the step (first fit); rows in order inside a patch */
-    int* seq = (int*)malloc(sizeof(int) * (size_t)(nblk + 1) * 6);
+    int* seq = d->scr_int + (size_t)(nefc + 1) * 5;
     int *pfirst = seq + nblk + 1, *pcount = pfirst + nblk + 1, *pa = pcount + nblk + 1, *pb = pa + nblk + 1, *pused = pb + nblk + 1;
-    long long* key = (long long*)malloc(sizeof(long long) * (size_t)(nblk + 1));
+    long long* key = d->scr_key;
     for (int i = 0; i < nblk; i++) {
       int t1 = bt1[i], t2 = bt2[i];
       if (t1 < 0) { t1 = t2; t2 = -1; }
@@ -1451,7 +1453,6 @@ static int pgs_order(const orc_data* d, int* order) {
         for (int ii = pfirst[c]; ii < pfirst[c] + pcount[c]; ii++) { int i = seq[ii]; for (int r = 0; r < bnum[i]; r++) order[k++] = bstart[i] + r; }
       }
     }
-    free(key); free(seq); free(bstart);
     return k;
   }
   if (nblk > 64) {
@@ -1460,7 +1461,7 @@ static int pgs_order(const orc_data* d, int* order) {
      * sequence, each sharing no tree with any block already in the group (first fit).  GMAX = 16 when the model has at most
      * 64 kinematic trees of at most 8 dofs each (free-body piles: BASELINE config C2), else 4. */
     int gmax = m_group_max(d->m);
-    int* seq = (int*)malloc(sizeof(int) * (size_t)(nblk + 1));
+    int* seq = d->scr_int + (size_t)(nefc + 1) * 5;
     int ns = 0;
     for (int pass = 0; pass < 2; pass++)
       for (int i = 0; i < nblk; i++) {
@@ -1488,13 +1489,12 @@ static int pgs_order(const orc_data* d, int* order) {
         cnt++;
       }
     }
-    free(seq); free(bstart);
     return k;
   }
   /* visiting sequence: blocks that couple two kinematic trees first (they are the hard ones to pair), then the
    * single-tree blocks, each group in constraint order; then greedy: a block, and the first later unvisited block
    * of the sequence that shares no tree with it */
-  int* seq = (int*)malloc(sizeof(int) * (size_t)(nblk + 1));
+  int* seq = d->scr_int + (size_t)(nefc + 1) * 5;
   int ns = 0;
   for (int pass = 0; pass < 2; pass++)
     for (int i = 0; i < nblk; i++) {
@@ -1517,8 +1517,6 @@ static int pgs_order(const orc_data* d, int* order) {
       break;
     }
   }
-  free(seq);
-  free(bstart);
   return k;
 }
 
@@ -1546,7 +1544,7 @@ void orc_fwd_constraint(orc_data* d) {
   /* PGS sweeps */
   double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
   int iter = 0;
-  int* order = (int*)malloc(sizeof(int) * (size_t)nefc);
+  int* order = d->scr_int + (size_t)(m->maxefc + 1) * 11;   /* behind pgs_order's own scratch */
   pgs_order(d, order);
   while (iter < m->opt.iterations) {
     double improvement = 0;
@@ -1604,7 +1602,6 @@ void orc_fwd_constraint(orc_data* d) {
     }
     iter += nit;
   }
-  free(order);
   d->solver_iter = iter;
   /* qfrc_constraint = J^T f ; qacc = qacc_smooth + M^-1 qfrc_constraint */
   zero(d->qfrc_constraint, nv);
@@ -1812,8 +1809,66 @@ static int g_threads = 1;
 void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
 /* CPU baseline driver: envs split over OpenMP threads, private orc_data per env, shared read-only model */
 void orc_step_many(orc_data** ds, int nenv, int nsteps, int with_inverse) {
+  /* one env at a time to whichever thread is free (an env at the 100-sweep cap costs up to 50x a converged one: a static split
+   * leaves most threads idle behind the heaviest share — measured), no allocation inside a step */
 #pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
   for (int e = 0; e < nenv; e++) orc_step(ds[e], nsteps, with_inverse);
+}
+/* The timed variant bench.py's cpu_baseline uses: `warm_steps` untimed steps of every env, then `nsteps` timed ones, on a team of
+ * g_threads plain pthreads that NEVER sleep between the phases (spin barriers on C11 atomics), envs handed out one at a time from
+ * an atomic counter.  Why not the OpenMP loop above: measured in the VMs this runs in, a sleeping thread takes tens to hundreds
+ * of milliseconds to be woken (a halted vCPU has to be rescheduled by the host), so a region entered cold — or one whose
+ * threads dozed off at a barrier — shows no speed-up at all (2 threads 0.93x, 256 threads 1.04x) although the steps scale.
+ * Returns the seconds of the timed part, clocked from the moment every thread has passed the barrier behind the warm steps. */
+#include <pthread.h>
+#include <stdatomic.h>
+#include <time.h>
+typedef struct {
+  orc_data** ds; int nenv, warm_steps, nsteps, with_inverse, nthreads;
+  atomic_int next_warm, next_timed, arrived[3];
+  atomic_int* rounds_done;                               /* per env: timed chunks completed (keeps an env's chunks in order) */
+  int chunk;
+  double t0, t1;
+} orc_team;
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static void spin_barrier(orc_team* t, int k) {
+  atomic_fetch_add(&t->arrived[k], 1);
+  while (atomic_load(&t->arrived[k]) < t->nthreads) { /* busy wait: no futex, no halt */ }
+}
+static void* team_main(void* arg) {
+  orc_team* t = (orc_team*)arg;
+  spin_barrier(t, 0);                                    /* every thread exists and runs */
+  for (int e; (e = atomic_fetch_add(&t->next_warm, 1)) < t->nenv;) orc_step(t->ds[e], t->warm_steps, t->with_inverse);
+  if (atomic_fetch_add(&t->arrived[1], 1) == t->nthreads - 1) t->t0 = now_s();   /* the last one in starts the clock ... */
+  while (atomic_load(&t->arrived[1]) < t->nthreads) {}
+  /* timed work in items of (env, `chunk` steps), handed out round by round: an env at the 100-sweep cap costs many times a
+   * converged one, and whole-env items would leave the team waiting for whoever drew the heaviest envs */
+  const int nround = (t->nsteps + t->chunk - 1) / t->chunk;
+  for (int k; (k = atomic_fetch_add(&t->next_timed, 1)) < t->nenv * nround;) {
+    const int e = k % t->nenv, r = k / t->nenv;
+    while (atomic_load(&t->rounds_done[e]) < r) {}
+    const int n = (r + 1) * t->chunk <= t->nsteps ? t->chunk : t->nsteps - r * t->chunk;
+    orc_step(t->ds[e], n, t->with_inverse);
+    atomic_store(&t->rounds_done[e], r + 1);
+  }
+  if (atomic_fetch_add(&t->arrived[2], 1) == t->nthreads - 1) t->t1 = now_s();   /* ... and the last one out stops it */
+  return NULL;
+}
+double orc_step_many_timed(orc_data** ds, int nenv, int warm_steps, int nsteps, int with_inverse) {
+  orc_team t; memset(&t, 0, sizeof t);
+  t.ds = ds; t.nenv = nenv; t.warm_steps = warm_steps; t.nsteps = nsteps; t.with_inverse = with_inverse;
+  t.nthreads = g_threads < nenv ? g_threads : nenv;
+  if (t.nthreads < 1) t.nthreads = 1;
+  t.chunk = getenv("ORC_CHUNK") ? atoi(getenv("ORC_CHUNK")) : 4; if (t.chunk < 1) t.chunk = 1;
+  t.rounds_done = (atomic_int*)calloc((size_t)(nenv > 0 ? nenv : 1), sizeof(atomic_int));
+  pthread_t* th = (pthread_t*)calloc((size_t)t.nthreads, sizeof(pthread_t));
+  int made = 0;
+  for (int k = 1; k < t.nthreads; k++) { if (pthread_create(&th[k], NULL, team_main, &t)) break; made++; }
+  if (made != t.nthreads - 1) t.nthreads = made + 1;     /* (thread limit hit: the team is what could be created) */
+  team_main(&t);
+  for (int k = 1; k <= made; k++) pthread_join(th[k], NULL);
+  free(th); free(t.rounds_done);
+  return t.t1 - t.t0;
 }
 
 /* named-field access for the Python test harness */

@@ -64,6 +64,7 @@ typedef struct orc_data {
   double *pd_target, pd_kp, pd_kd;
   /* scratch */
   double *scr_nv[6], *scr_nM, *scr_efc[3], *scr_B, *scr_body6[3];
+  double* scr_jac; int* scr_int; long long* scr_key;   /* per-step scratch owned by the data (no malloc inside a step) */
 } orc_data;
 
 orc_data* orc_make_data(const mjh_model* m);
@@ -114,6 +115,7 @@ int* orc_int_field(orc_data* d, const char* name, int* n);
 int orc_get_contact(orc_data* d, int k, double* dist, double* pos, double* frame, int* geom, int* dim);
 
 /* multi-env convenience for the CPU baseline: steps `nenv` independent datas */
+double orc_step_many_timed(orc_data** ds, int nenv, int warm_steps, int nsteps, int with_inverse);
 void orc_step_many(orc_data** ds, int nenv, int nsteps, int with_inverse);
 void orc_set_threads(int n);
 void orc_set_slot_mask(orc_data* d, unsigned mask);

@@ -38,6 +38,7 @@ def lib():
         L.orc_convex_pair.restype = C.c_int
         L.orc_convex_pair.argtypes = [C.c_int, dp, dp, dp, dp, C.c_int, C.c_int, dp, dp, dp, dp, C.c_int, C.c_double, dp, dp, dp]
         L.orc_step_many.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int]
+        L.orc_step_many_timed.restype = C.c_double; L.orc_step_many_timed.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_set_threads.argtypes = [C.c_int]
         L.orc_set_slot_mask.argtypes = [vp, C.c_uint]
         L.orc_set_pd.argtypes = [vp, dp, C.c_double, C.c_double]

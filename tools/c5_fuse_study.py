@@ -1,5 +1,5 @@
 """Launch-bound configs: ms per step of the C5 scene (4096 envs) against steps per call, hardware-queue count, launch timing and
-the per-env initial spin — what the bench line's 0.11 ms per step is made of.   python tools/fuse_test.py"""
+the per-env initial spin — what the bench line's 0.11 ms per step is made of.   python tools/c5_fuse_study.py"""
 import sys, os, time
 if len(sys.argv) > 1 and sys.argv[1] == "q8":
     os.environ["GPU_MAX_HW_QUEUES"] = "8"
