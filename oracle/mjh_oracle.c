@@ -144,6 +144,7 @@ orc_data* orc_make_data(const mjh_model* m) {
   d->scr_jac = dalloc(12 * (size_t)(nv ? nv : 1));
   d->scr_int = ialloc((size_t)(ne + 1) * 12);
   d->scr_key = (long long*)calloc((size_t)ne + 1, sizeof(long long));
+  d->scr_nz = ialloc((size_t)ne * (nv ? nv : 1));
   for (int i = 0; i < 3; i++) d->scr_efc[i] = dalloc(ne);
   d->scr_B = dalloc((size_t)(ne > 6 ? ne : 6)*nv);
   for (int i = 0; i < 3; i++) d->scr_body6[i] = dalloc(6*nb);
@@ -171,7 +172,7 @@ void orc_free_data(orc_data* d) {
   for (size_t i = 0; i < sizeof(ps)/sizeof(ps[0]); i++) free(ps[i]);
   for (int i = 0; i < 6; i++) free(d->scr_nv[i]);
   for (int i = 0; i < 3; i++) { free(d->scr_efc[i]); free(d->scr_body6[i]); }
-  free(d->scr_jac); free(d->scr_int); free(d->scr_key);
+  free(d->scr_jac); free(d->scr_int); free(d->scr_key); free(d->scr_nz);
   free(d->contact); free(d->efc_type); free(d->efc_id); free(d->controlled); free(d->pd_target);
   free(d);
 }
@@ -1198,9 +1199,24 @@ void orc_project_constraint(orc_data* d) {
     copyv(B, d->efc_J + (size_t)i*nv, nv);
     orc_solve_m(d, B);
   }
-  for (int i = 0; i < nefc; i++) for (int j = 0; j <= i; j++) {
-    double v = dotn(d->efc_J + (size_t)i*nv, d->scr_B + (size_t)j*nv, nv);
-    d->efc_AR[(size_t)i*nefc + j] = v; d->efc_AR[(size_t)j*nefc + i] = v;
+  /* AR_ij = J_i . B_j over the NONZEROS of J_i only (a contact row of a 64-box pile has 12 of 384): the skipped terms are
+   * exact zeros, so every sum is the same sequence of additions — bit-identical to the dense dot, 30x fewer of them */
+  int* nz = d->scr_nz; int* nzadr = d->scr_int;        /* (scr_int is free here: the order builder runs in orc_fwd_constraint) */
+  int cnt = 0;
+  for (int i = 0; i < nefc; i++) {
+    nzadr[i] = cnt;
+    const double* Ji = d->efc_J + (size_t)i*nv;
+    for (int k = 0; k < nv; k++) if (Ji[k] != 0) nz[cnt++] = k;
+  }
+  nzadr[nefc] = cnt;
+  for (int i = 0; i < nefc; i++) {
+    const double* Ji = d->efc_J + (size_t)i*nv; const int* zi = nz + nzadr[i]; const int ni = nzadr[i+1] - nzadr[i];
+    for (int j = 0; j <= i; j++) {
+      const double* Bj = d->scr_B + (size_t)j*nv;
+      double v = 0;
+      for (int k = 0; k < ni; k++) v += Ji[zi[k]] * Bj[zi[k]];
+      d->efc_AR[(size_t)i*nefc + j] = v; d->efc_AR[(size_t)j*nefc + i] = v;
+    }
   }
   for (int i = 0; i < nefc; i++) d->efc_AR[(size_t)i*nefc + i] += d->efc_R[i];
 }

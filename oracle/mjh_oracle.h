@@ -64,7 +64,7 @@ typedef struct orc_data {
   double *pd_target, pd_kp, pd_kd;
   /* scratch */
   double *scr_nv[6], *scr_nM, *scr_efc[3], *scr_B, *scr_body6[3];
-  double* scr_jac; int* scr_int; long long* scr_key;   /* per-step scratch owned by the data (no malloc inside a step) */
+  double* scr_jac; int* scr_int; long long* scr_key; int* scr_nz;   /* per-step scratch owned by the data (no malloc inside a step) */
 } orc_data;
 
 orc_data* orc_make_data(const mjh_model* m);

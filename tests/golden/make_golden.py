@@ -32,14 +32,17 @@ def s24():
     marks = [1, 10, 60, 150]
     out = {f"tab_{k}": v for k, v in tab.items()}
     out["marks"] = np.array(marks)
+    hist_ncon = np.zeros((marks[-1], nenv), dtype=np.int32); hist_nefc = np.zeros((marks[-1], nenv), dtype=np.int32)
     for i in range(nenv):
         d = oracle_s24(m, tab, i)
-        done = 0
-        for mk in marks:
-            d.step(mk - done); done = mk
-            s = snap(d)
-            for k, v in s.items():
-                out[f"env{i}_step{mk}_{k}"] = np.asarray(v)
+        for step in range(1, marks[-1] + 1):
+            d.step(1)
+            hist_ncon[step - 1, i] = d.i("ncon"); hist_nefc[step - 1, i] = d.i("nefc")     # the contact-set history, step by step
+            if step in marks:
+                s = snap(d)
+                for k, v in s.items():
+                    out[f"env{i}_step{step}_{k}"] = np.asarray(v)
+    out["hist_ncon"] = hist_ncon; out["hist_nefc"] = hist_nefc
     np.savez_compressed(os.path.join(HERE, "s24_golden.npz"), **out)
 
 

@@ -9,7 +9,7 @@ to fp64 round-off; contact scenes are compared through what does not depend on t
 import numpy as np
 import pytest
 
-mujoco = pytest.importorskip("mujoco", reason="reference library (mujoco==2.3.7) not installed: parity stays unpinned")
+mujoco = pytest.importorskip("mujoco", reason="reference library (mujoco==2.3.7) not installed: parity stays UNPINNED (reported by tests/test_mjcf_emit_roundtrip.py::test_reference_library_presence_is_reported; the emitter half of this harness runs there)")
 
 import mujoco_sim_amd as ms  # noqa: E402
 import orc  # noqa: E402
