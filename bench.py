@@ -582,18 +582,25 @@ def main():
     publish_every = max(1, int(round(1.0 / (60.0 * model.opt.timestep))))  # 60 Hz of simulated time
 
     ag_events = []
+    comm_stream = torch.cuda.Stream() if use_dist else None
 
     def run(nsteps, inverse, time_gather=False):
         for _ in range(nsteps):
             w.step(1, inverse)
             if not args.no_gather and w.step_count % publish_every == 0:   # 60 Hz publish: packed state slice (+ RCCL all-gather)
+                if use_dist:
+                    stream.wait_stream(comm_stream)        # the previous gather has read `pub` (three steps ago: long done)
                 eng.export_state_device(pub.data_ptr())
                 if use_dist:
-                    if time_gather:
-                        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        a_.record(); dist.all_gather_into_tensor(gathered, pub); b_.record(); ag_events.append((a_, b_))
-                    else:
-                        dist.all_gather_into_tensor(gathered, pub)
+                    # the collective runs on a stream of its own, beside the steps: on the stepping stream it would sit between two
+                    # steps of every cohort (the next mjh_step forks from that stream) and drain the pipeline at every publish
+                    comm_stream.wait_stream(stream)
+                    with torch.cuda.stream(comm_stream):
+                        if time_gather:
+                            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            a_.record(); dist.all_gather_into_tensor(gathered, pub); b_.record(); ag_events.append((a_, b_))
+                        else:
+                            dist.all_gather_into_tensor(gathered, pub)
 
     def timed(nsteps, inverse):
         torch.cuda.synchronize()

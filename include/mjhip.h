@@ -472,7 +472,11 @@ int mjh_group_reset(mjh_group*);
 int mjh_group_synchronize(mjh_group*);
 /* pack + all-gather; host_out (may be NULL) receives device 0's copy: [nenv_total * mjh_group_state_stride()] floats, env order */
 int mjh_group_publish(mjh_group*, float* host_out);
-const float* mjh_group_state_device(const mjh_group*, int rank);   /* the gathered state on device `rank` (valid after publish, in stream order) */
+/* the gathered state on device `rank`: valid once the publish's exchange — which runs on a communication stream of its own,
+ * beside the steps — has finished: after mjh_group_wait_publish(rank, stream) in that stream's order, after
+ * mjh_group_synchronize(), or after a publish with host_out */
+const float* mjh_group_state_device(const mjh_group*, int rank);
+int mjh_group_wait_publish(mjh_group*, int rank, void* stream /* NULL: the device's engine stream */);
 int mjh_group_state_stride(const mjh_group*);
 int mjh_group_uses_rccl(const mjh_group*);
 /* HIP events on device 0's stream around the exchange of every publish (the all-gather, or the peer copies): mean duration in

@@ -226,6 +226,7 @@ SYMBOLS = [
     ("mjh_group_state_stride", C.c_int, [_vp]),
     ("mjh_group_uses_rccl", C.c_int, [_vp]),
     ("mjh_group_set_transport", None, [C.c_int]),
+    ("mjh_group_wait_publish", C.c_int, [_vp, C.c_int, _vp]),
     ("mjh_group_set_publish_timing", C.c_int, [_vp, C.c_int]),
     ("mjh_group_get_publish_timing", C.c_int, [_vp, c_double_p, C.POINTER(C.c_int)]),
     ("mjh_nenv", C.c_int, [_vp]),

@@ -90,9 +90,10 @@ def test_s24_trajectory_parity(s24):
     _, q, v, _ = e.get_state()
     print("S24 free run: agreeing envs after 1/60/150 steps", hist[0].sum(), hist[59].sum(), hist[149].sum(),
           "max err of agreeing envs", err[0][hist[0]].max(), err[59][hist[59]].max(), err[149][hist[149]].max() if hist[149].any() else None)
+    # measured (r03b): 16 / 16 / 14 of 16 envs keep the oracle's contact-set history over 1 / 60 / 150 steps; their errors 1.1e-7 / 4.3e-6 / 2.2e-5
     assert hist[0].all() and err[0].max() <= 1e-5
-    assert err[59][hist[59]].max() < 1e-3 and hist[59].sum() >= 12
-    assert hist[149].sum() >= 8 and err[149][hist[149]].max() < 1e-2
+    assert err[59][hist[59]].max() < 1e-4 and hist[59].sum() >= 14
+    assert hist[149].sum() >= 10 and err[149][hist[149]].max() < 5e-4
     st = e.get_stats()
     assert (st[:, 3] == 0).all() and all(d.i("warn") == 0 for d in ds)
 
@@ -108,7 +109,7 @@ def test_s24_against_golden_fixture():
     e.set_initial_qpos(g["tab_qpos"]); e.reset()
     hist_ncon, hist_nefc = g["hist_ncon"], g["hist_nefc"]            # [150, 6]
     same = np.ones(6, dtype=bool)
-    marks = {int(mk): tol for mk, tol in zip(g["marks"], (2e-6, 2e-5, 2e-3, 2e-2))}
+    marks = {int(mk): tol for mk, tol in zip(g["marks"], (2e-6, 2e-5, 2e-4, 2e-3))}
     for k in range(1, int(g["marks"][-1]) + 1):
         e.step(1)
         st = e.get_stats()
