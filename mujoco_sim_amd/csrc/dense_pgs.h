@@ -1,0 +1,291 @@
+// dense_pgs.h — the dense row-space solver of the many-body layout (articulated robots: BASELINE config C4, PR2 with its object
+// pool, nv 97, 100-170 constraint rows).  The projection stage mj_projectConstraint (reached through
+// mj_step1, /root/reference/src/mj_main.cpp:83) is the ONE dense contraction of the step:  AR = J M^-1 J^T + diag(R)  over the
+// pyramid rows of an environment.  The block solver (step_kernel.h: pgs_many_body) never forms it: it walks the blocks one at a
+// time on a whole wave — gather the block's dofs, a full-wave reduction per base row, uniform row math, scatter — ~600 clocks of
+// dependent latency per BLOCK, and the environment that sits at the 100-sweep cap sets the length of the launch (C4: 1.75 ms of a
+// 2.7 ms step, at 2.7 waves per CU).  Here the contraction is done once per step on the matrix cores and the sweeps become
+// column updates of a residual vector that lives in registers:
+//
+//   mjh_dense_build_kernel   one 256-thread workgroup per environment: expands the block rows (compact over <= 2 kinematic trees,
+//                            pyramid rows n +- k folded) into dense J [rows x nv] and B = J M^-1 [rows x nv], multiplies them
+//                            with v_mfma_f32_16x16x4_f32 (upper triangle of 16 x 16 tiles, fragments straight from L1 / L2; exact fp32), and writes
+//                            AR' = -AR_pq / AR_qq (column-scaled, diagonal -1) row by row in Gauss-Seidel VISITING order, plus the
+//                            per-row start values  t_q = -res_q / AR_qq,  f, lo, hi, AR_qq.
+//   mjh_dense_solve_kernel   one wave per environment, lane q owns rows q, q + 64, ...:   per visited row p
+//                               delta = med3(f_p + t_p, lo_p, hi_p) - f_p ;  f_p += delta ;  t_q += AR'_pq delta  for every q
+//                            = projected Gauss-Seidel on the dual exactly as mj_solPGS iterates it (same rows, same order as the
+//                            block solver and the oracle), ~12 instructions per ROW; then qacc = a0 + B^T (f - f0).
+//
+// Environments whose row count exceeds the dense capacity keep the block solver (meta[7] says which one ran).
+#pragma once
+#include "step_kernel.h"
+
+#define DN_CAP_MAX 256          // rows: four per lane
+#define DN_META_DENSE 7         // meta[7] = 1: this step of this env is solved by the dense kernels
+
+// float offsets of the dense region inside the env's scratch slice (L.g_dense .. ), CAP = M.dense_cap rows, NVS = M.dense_nvs
+struct DenseOff { int art, bd, jd, rf, rlo, rhi, rarr, rt, rmap; };
+DEV DenseOff dense_off(const DModel& M, const Lay& L) {
+  DenseOff o; const int cap = M.dense_cap, nvs = M.dense_nvs;
+  o.art = L.g_dense; o.bd = o.art + cap * cap; o.jd = o.bd + cap * nvs; o.rf = o.jd + cap * nvs;
+  o.rlo = o.rf + cap; o.rhi = o.rlo + cap; o.rarr = o.rhi + cap; o.rt = o.rarr + cap; o.rmap = o.rt + cap;
+  return o;
+}
+
+typedef float mjh_f4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------ build
+// LDS: s_a0[NVS] | s_inv[CAP] | s_row[CAP] int4 | s_start[maxblk + 1]  (a few KB: several workgroups per CU)
+__global__ __launch_bounds__(256) void mjh_dense_build_kernel(const DConst* __restrict__ C, const DState S, int env0) {
+  const DModel& M = C->M; const Lay& L = C->L;
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nv = M.nv;
+  const int env = S.env_order ? S.env_order[env0 + blockIdx.x] : env0 + (int)blockIdx.x;
+  float* const gs = S.gscratch + (size_t)env * (size_t)S.gstride;
+  int* meta = (int*)(gs + L.g_meta);
+  const int nblk = __builtin_amdgcn_readfirstlane(meta[0]), nefc = __builtin_amdgcn_readfirstlane(meta[2]);
+  const int cap = M.dense_cap, nvs = M.dense_nvs;
+  if (nblk == 0 || nefc > cap || nefc <= 0) return;                    // (meta[7] is 0: the block solver takes this env)
+  const int nr16 = (nefc + 15) & ~15, nr32 = (nefc + 31) & ~31, K = (nr32 + 63) >> 6, W = 64 * K;
+  const DenseOff o = dense_off(M, L);
+  float* s_a0 = lds; float* s_inv = s_a0 + nvs;
+  int4* s_row = (int4*)(s_inv + cap); int* s_start = (int*)(s_row + cap);
+  const int* g_ord = (const int*)(gs + (-1 - L.order)); const int4* g_hd = (const int4*)(gs + (-1 - L.blki));
+  const float* g_bf = gs + (-1 - L.blkf); const float* g_J = gs + (-1 - L.J); const float* g_B = gs + (-1 - L.B);
+  for (int d = tid; d < nvs; d += 256) s_a0[d] = d < nv ? gs[L.g_a0 + d] : 0.0f;
+  for (int q = tid; q < cap; q += 256) s_inv[q] = 0.0f;
+  // ---- rows in visiting order: position i of the order -> block, its rows start at the running sum of the row counts
+  if (wid == 0) {
+    int run = 0;
+    for (int base = 0; base < nblk; base += 64) {
+      const int i = base + lane;
+      const int nr = i < nblk ? (g_hd[g_ord[i]].x >> 4) & 15 : 0;
+      const int incl = wave_incl_scan_i(nr, lane);
+      if (i < nblk) s_start[i] = run + incl - nr;
+      run += __shfl(incl, 63);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < nblk; i += 256) {
+    const int b = g_ord[i]; const int4 hd = g_hd[b];
+    const int nr = (hd.x >> 4) & 15, p0 = s_start[i], sl4 = BLK_SLOTS(hd.y) == 4 ? 1 : 0;
+    for (int r = 0; r < nr; r++) s_row[p0 + r] = make_int4(hd.x, hd.z, hd.w, b | (r << 16) | (sl4 << 24));
+  }
+  __syncthreads();
+  // ---- dense rows, 16 lanes (one DPP row) per matrix row, 16 rows per pass: J_p and B_p = J_p M^-1 expanded to nv columns
+  //      (compact storage over <= 2 trees, pyramid rows n +- k folded), written to global for the fragments below; the same pass
+  //      forms  AR_pp = J_p . B_p + R  and  J_p . a0  (sums over the 16 lanes by DPP) and from them the row's start values, stored
+  //      in the lanes' layout [lane][K] of the sweep kernel
+  float* g_jd = gs + o.jd; float* g_bd = gs + o.bd;
+  const int sub = tid & 15;
+  for (int p = tid >> 4; p < W; p += 16) {
+    int4 ri = make_int4(0, 0, 0, 0);
+    if (p < nefc) ri = s_row[p];
+    ROW_TREES(ri.y, ri.z);
+    const int kind = ri.x & 15, jo = BLK_JOFF(ri.x), r = (ri.w >> 16) & 255, b = ri.w & 0xffff; const bool quad = (ri.w >> 24) & 1;
+    const int kk = 1 + (r >> 1); const float sg = (r & 1) ? -1.0f : 1.0f;
+    float jb = 0, ja = 0;
+    if (p < nr16)
+      for (int d = sub; d < nvs; d += 16) {
+        float jv = 0, bv = 0;
+        const int k = (p < nefc && d < nv) ? row_off(d, a1, n1, a2, n2) : -1;
+        if (k >= 0) {
+          if (quad) {
+            jv = g_J[jo + 4*k]; bv = g_B[jo + 4*k];
+            if (kind != BK_SINGLE) { jv += sg * g_J[jo + 4*k + kk]; bv += sg * g_B[jo + 4*k + kk]; }
+          } else { jv = g_J[jo + k]; bv = g_B[jo + k]; }
+        }
+        g_jd[p * nvs + d] = jv; g_bd[p * nvs + d] = bv;
+        jb += jv * bv; ja += jv * s_a0[d];
+      }
+    // sums over the 16 lanes of the DPP row: lane 15 of the row ends up with the totals
+    MJH_DPP_ADD(jb, 0x111, 0xf, true); MJH_DPP_ADD(ja, 0x111, 0xf, true);
+    MJH_DPP_ADD(jb, 0x112, 0xf, true); MJH_DPP_ADD(ja, 0x112, 0xf, true);
+    MJH_DPP_ADD(jb, 0x114, 0xf, true); MJH_DPP_ADD(ja, 0x114, 0xf, true);
+    MJH_DPP_ADD(jb, 0x118, 0xf, true); MJH_DPP_ADD(ja, 0x118, 0xf, true);
+    if (sub == 15) {
+      float f = 0, lo = 0, hi = 0, arr = 1.0f, t = 0; int map = -1;
+      if (p < nefc) {
+        const float* bf = g_bf + b * BLKF_STRIDE;
+        const float R = bf[0];
+        const float aref = bf[BF_AREF] + (kind != BK_SINGLE ? sg * bf[BF_AREF + kk] : 0.0f);
+        f = bf[BF_F + r]; lo = bf[BF_LO]; hi = bf[BF_LO + 1];
+        arr = jb + R;
+        const float inv = 1.0f / arr;
+        t = -(ja - aref + R * f) * inv;
+        map = b | (r << 16);
+        s_inv[p] = inv;
+      }
+      const int ix = (p & 63) * K + (p >> 6);
+      gs[o.rf + ix] = f; gs[o.rlo + ix] = lo; gs[o.rhi + ix] = hi; gs[o.rarr + ix] = arr; gs[o.rt + ix] = t;
+      ((int*)(gs + o.rmap))[ix] = map;
+    }
+  }
+  __syncthreads();
+  // ---- AR = J B^T on the matrix cores, upper triangle of 16 x 16 tiles (AR is symmetric: tile (Q, P) is the transpose of tile
+  //      (P, Q)), tiles dealt round-robin to the four waves.  Per 16-dof chunk a lane fetches 16 bytes of its A row (J) and of its
+  //      B row (J M^-1) — L1 / L2 hits, the rows were just written by this workgroup — and issues four v_mfma_f32_16x16x4_f32
+  //      (the k index inside a chunk is permuted identically on both sides: lane l carries k = 4 (l >> 4) + j, j = 0..3, so that a
+  //      lane's four values are contiguous).  D: col = l & 15, row = 4 (l >> 4) + v.  Stored column-scaled: AR'_pq = -AR_pq / AR_qq,
+  //      diagonal -1, at [p][lane = q & 63][k = q >> 6].
+  const int TD = nr16 >> 4, nch = nvs >> 4;
+  const int li = lane & 15, lk = lane >> 4;
+  float* g_art = gs + o.art;
+  int cnt = 0;
+  for (int P = 0; P < TD; P++)
+    for (int Q = P; Q < TD; Q++) {
+      if (((cnt++) & 3) != wid) continue;
+      mjh_f4 acc = (mjh_f4){0, 0, 0, 0};
+      const float* ap = g_jd + (16 * P + li) * nvs + 4 * lk; const float* bp = g_bd + (16 * Q + li) * nvs + 4 * lk;
+      for (int c = 0; c < nch; c++) {
+        const float4 a = *(const float4*)(ap + 16 * c), bq = *(const float4*)(bp + 16 * c);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc, 0, 0, 0);
+      }
+      const int q = 16 * Q + li; const float iq = s_inv[q];
+      const int ixq = (q & 63) * K + (q >> 6);
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int p = 16 * P + 4 * lk + v;
+        const float val = acc[v];
+        g_art[p * W + ixq] = (p == q && p < nefc) ? -1.0f : -val * iq;
+        if (P != Q) g_art[q * W + (p & 63) * K + (p >> 6)] = -val * s_inv[p];       // the mirrored element, scaled by ITS column
+      }
+    }
+  // ---- the inert border: rows nr16 .. nr32 and columns nr16 .. W of the visited rows
+  for (int idx = tid; idx < nr32 * W; idx += 256) {
+    const int p = idx / W, c = idx - p * W, q = (c % K) * 64 + c / K;
+    if (p >= nr16 || q >= nr16) g_art[idx] = 0.0f;
+  }
+  __syncthreads();
+  if (tid == 0) meta[DN_META_DENSE] = 1;
+}
+
+// ------------------------------------------------------------------------------------------------ sweeps
+template <int K> struct DnCol { float v[K]; };
+template <int K> DEV DnCol<K> dn_load(const __amdgpu_buffer_rsrc_t rs, const unsigned voff, const int soff) {
+  DnCol<K> c;
+  if constexpr (K == 1) { c.v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, soff, 0)); }
+  else if constexpr (K == 2) { const mjh_v2u u = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, soff, 0); __builtin_memcpy(c.v, &u, 8); }
+  else if constexpr (K == 3) { typedef unsigned v3u __attribute__((vector_size(12))); const v3u u = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)voff, soff, 0); __builtin_memcpy(c.v, &u, 12); }
+  else { const mjh_v4u u = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 0); __builtin_memcpy(c.v, &u, 16); }
+  return c;
+}
+
+// Gauss-Seidel sweeps over the rows p = 0 .. nr32 - 1 (visiting order; nr32 a multiple of 32, rows beyond nefc inert).  Lane q owns
+// rows 64 k + q.  The columns AR'_p. (64 K floats per row, a lane's K values contiguous) are fetched a 16-row group ahead into two
+// register buffers; the group count is even, so the buffer parity is static over the wrap of a sweep.  Returns the sweep count.
+template <int K>
+DEV int dn_sweeps(const __amdgpu_buffer_rsrc_t rs, const int art_bytes, const int nr32, const int itmax, const float tol, const float scale,
+                  float* f, float* t, const float* lo, const float* hi, const float* arr, const int lane) {
+  const int G = nr32 >> 4;
+  const unsigned voff = (unsigned)lane * (unsigned)(4 * K);
+  constexpr int ROWB = 64 * K * 4;                       // bytes per row of AR'
+  DnCol<K> buf[2][16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) buf[0][r] = dn_load<K>(rs, voff, art_bytes + r * ROWB);
+  int niter = 0;
+  for (;;) {
+    float imp = 0;
+    // (opaque per sweep: otherwise the 64 lane masks and the row offsets are hoisted out of the sweep loop as loop invariants and
+    //  spilled — v_writelane / v_readlane around every use)
+    unsigned long long m1 = 1ull; asm volatile("" : "+s"(m1));
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const float fprev = f[k]; float tc = 0;
+#pragma unroll
+      for (int gg = 0; gg < 4; gg++) {
+        const int g = 4 * k + gg;
+        if (g < G) {
+          const int gn = g + 1 < G ? g + 1 : 0;
+          int sb = art_bytes + gn * 16 * ROWB; asm volatile("" : "+s"(sb));
+#pragma unroll
+          for (int r = 0; r < 16; r++) buf[(gg + 1) & 1][r] = dn_load<K>(rs, voff, sb + r * ROWB);
+          unsigned long long mask = m1 << (16 * gg);
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int l = 16 * gg + r;
+            const float fn = __builtin_amdgcn_fmed3f(f[k] + t[k], lo[k], hi[k]);
+            const float d = fn - f[k];
+            const float sd = readlane_f(d, l);
+            const bool me = __builtin_amdgcn_inverse_ballot_w64(mask);     // lane l: v_cndmask on a scalar mask, no compare
+            mask <<= 1;
+            tc = me ? t[k] : tc;
+            f[k] = me ? fn : f[k];
+#pragma unroll
+            for (int j = 0; j < K; j++) t[j] = __builtin_fmaf(buf[gg & 1][r].v[j], sd, t[j]);
+          }
+        }
+      }
+      const float dc = f[k] - fprev;
+      imp += dc * arr[k] * (tc - 0.5f * dc);             // -delta (res + AR delta / 2) with res = -t AR at the row's visit
+    }
+    niter++;
+    const float improvement = wave_sum<4>(imp);
+    if (improvement * scale < tol || niter >= itmax) break;
+  }
+  return niter;
+}
+
+template <int K>
+DEV void dn_solve_env(const DModel& M, const Lay& L, float* gs, const __amdgpu_buffer_rsrc_t rs, const DenseOff& o, const int nefc, const int nr32,
+                      float* s_df, const int lane, int* meta) {
+  float f[K], f0[K], t[K], lo[K], hi[K], arr[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int ix = lane * K + k;
+    f[k] = gs[o.rf + ix]; f0[k] = f[k]; t[k] = gs[o.rt + ix]; lo[k] = gs[o.rlo + ix]; hi[k] = gs[o.rhi + ix]; arr[k] = gs[o.rarr + ix];
+  }
+  const float scale = 1.0f / (M.meaninertia * (float)(M.nv > 1 ? M.nv : 1));
+  const int niter = dn_sweeps<K>(rs, 4 * o.art, nr32, M.iterations, M.tolerance, scale, f, t, lo, hi, arr, lane);
+  // forces back into the block records (the integrate launch forms qfrc_constraint from them), force changes to LDS
+  const int* rmap = (const int*)(gs + o.rmap);
+  float* g_bf = gs + (-1 - L.blkf);
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int q = 64 * k + lane, map = rmap[lane * K + k];
+    s_df[q] = f[k] - f0[k];
+    if (map >= 0) g_bf[(map & 0xffff) * BLKF_STRIDE + BF_F + ((map >> 16) & 255)] = f[k];
+  }
+  __syncthreads();
+  // qacc = a0 + B^T (f - f0): lanes = dofs
+  const int nv = M.nv, nvs = M.dense_nvs;
+  const float* g_bd = gs + o.bd;
+  float q0 = lane < nv ? gs[L.g_a0 + lane] : 0.0f, q1 = lane + 64 < nv ? gs[L.g_a0 + lane + 64] : 0.0f;
+  for (int p = 0; p < nefc; p++) {
+    const float df = s_df[p];
+    if (df == 0.0f) continue;
+    if (lane < nvs) q0 += g_bd[p * nvs + lane] * df;
+    if (lane + 64 < nvs) q1 += g_bd[p * nvs + lane + 64] * df;
+  }
+  if (lane < nv) gs[L.g_qacc + lane] = q0;
+  if (lane + 64 < nv) gs[L.g_qacc + lane + 64] = q1;
+  if (lane == 0) meta[5] = niter;
+}
+
+__global__ __launch_bounds__(64) void mjh_dense_solve_kernel(const DConst* __restrict__ C, const DState S, int env0) {
+  const DModel& M = C->M; const Lay& L = C->L;
+  __shared__ float s_df[DN_CAP_MAX];
+  const int lane = threadIdx.x;
+  const int env = S.env_order ? S.env_order[env0 + blockIdx.x] : env0 + (int)blockIdx.x;
+  float* const gs = S.gscratch + (size_t)env * (size_t)S.gstride;
+  int* meta = (int*)(gs + L.g_meta);
+  if (__builtin_amdgcn_readfirstlane(meta[0]) == 0 || __builtin_amdgcn_readfirstlane(meta[DN_META_DENSE]) == 0) return;
+  const int nefc = __builtin_amdgcn_readfirstlane(meta[2]);
+  const int nr32 = (nefc + 31) & ~31, K = (nr32 + 63) >> 6;
+  const DenseOff o = dense_off(M, L);
+  __amdgpu_buffer_rsrc_t rs;
+  {
+    const unsigned long long ga = (unsigned long long)gs;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ga), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ga >> 32));
+    const long long nb = S.gstride * 4;
+    rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)(nb > 0x7ffffff0ll ? 0x7ffffff0ll : nb), 0x00020000);
+  }
+  if (K == 1) dn_solve_env<1>(M, L, gs, rs, o, nefc, nr32, s_df, lane, meta);
+  else if (K == 2) dn_solve_env<2>(M, L, gs, rs, o, nefc, nr32, s_df, lane, meta);
+  else if (K == 3) dn_solve_env<3>(M, L, gs, rs, o, nefc, nr32, s_df, lane, meta);
+  else dn_solve_env<4>(M, L, gs, rs, o, nefc, nr32, s_df, lane, meta);
+}

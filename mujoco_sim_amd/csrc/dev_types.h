@@ -45,6 +45,8 @@ struct DModel {
   // is dead once the solver starts, from the position-stage arrays to the base-row storage), its size, and of the two live
   // tables next to it: one descriptor per patch, one descriptor per (step, 16-lane row) of the sweep schedule
   int patch, pool, pool_floats, pdesc, pslot;
+  // dense row-space solver of the many-body layout (dense_pgs.h): on / off, row capacity (a multiple of 64, <= 256), nv padded to 16
+  int dense, dense_cap, dense_nvs;
 };
 
 // per-env state in HBM (fp32, env-major rows)
@@ -96,6 +98,7 @@ struct Lay {
   // (initial acceleration, 1/M_dd, velocity after the controller, smooth force, solved acceleration) and of 8 ints of
   // meta data (nblk, nfixblk, nefc, ncon, flags, solver iterations)
   int g_a0, g_minv, g_qvel, g_smooth, g_qacc, g_meta, g_qM;
+  int g_dense;   // dense solver: AR' [cap x cap] | B rows [cap x nvs] | J rows [cap x nvs] | f, lo, hi, AR_qq, t, row map [6 x cap]
 };
 
 struct DConst { DModel M; Lay L; };

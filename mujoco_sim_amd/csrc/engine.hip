@@ -15,6 +15,7 @@
 
 #include "../../include/mjhip.h"
 #include "step_kernel.h"
+#include "dense_pgs.h"
 
 void mjh_set_error(const std::string& s);  // model_builder.cpp
 
@@ -53,6 +54,7 @@ struct mjh_engine {
   DState S{};
   Lay L{};
   int lds_bytes = 0;
+  size_t dense_lds = 0;   // dynamic LDS of mjh_dense_build_kernel
   int* dI = nullptr; float* dF = nullptr; DConst* dC = nullptr;
   std::vector<int> hI;  // host copy of the int tables (controlled / odom are patched in place)
   int o_controlled = 0, o_odom = 0;
@@ -373,6 +375,13 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     if (big) {   // hand-over vectors of the three-launch step (non-negative offsets into the scratch slice)
       auto graw = [&](int n) { long long o = goff; goff += ((std::max(n, 1) + 3) / 4) * 4; return (int)o; };
       L.g_a0 = graw(nv); L.g_minv = graw(nv); L.g_qvel = graw(nv); L.g_smooth = graw(nv); L.g_qacc = graw(nv); L.g_meta = graw(8); L.g_qM = graw(m->nM);
+      // dense row-space solver (dense_pgs.h): articulated models (M not diagonal) without noslip sweeps, at most 128 dofs; an
+      // env takes it in the steps in which it has at most dense_cap rows.  MJH_DENSE=0 keeps the block solver everywhere.
+      static const bool dense_on = !(getenv("MJH_DENSE") && atoi(getenv("MJH_DENSE")) == 0);
+      M.dense = (dense_on && !diagM && M.noslip_iterations == 0 && nv <= 128 && nv >= 1) ? 1 : 0;
+      M.dense_cap = std::min(256, ((std::max(M.maxefc, 1) + 63) / 64) * 64); M.dense_nvs = ((nv + 15) / 16) * 16;
+      L.g_dense = 0;
+      if (M.dense) { long long o = goff; goff += (long long)M.dense_cap * M.dense_cap + 2LL * M.dense_cap * M.dense_nvs + 6LL * M.dense_cap; L.g_dense = (int)o; }
     }
     hp.gstride = goff;
     L.total = off;
@@ -460,6 +469,12 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   }
 #define MJH_ATTR(NR, DG) do { HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<NR, DG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes)); \
                               HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<NR, DG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes)); } while (0)
+  if (e->M.dense) {
+    // LDS of mjh_dense_build_kernel: a0 [nvs] | 1 / AR_qq [cap] | row table [cap] int4 | row starts [maxblk + 1]
+    e->dense_lds = ((size_t)e->M.dense_nvs + 5 * (size_t)e->M.dense_cap + (size_t)std::max(e->M.maxblk, 1) + 8) * sizeof(float);
+    if (e->dense_lds > 160 * 1024) { e->M.dense = 0; }
+    else HIPCHK(hipFuncSetAttribute((const void*)mjh_dense_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->dense_lds));
+  }
   MJH_ATTR(1, true); MJH_ATTR(2, true); MJH_ATTR(4, true); MJH_ATTR(8, true); MJH_ATTR(1, false); MJH_ATTR(2, false); MJH_ATTR(4, false); MJH_ATTR(8, false);
 #undef MJH_ATTR
 
@@ -602,6 +617,13 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
         // many-body layout: assemble -> solve (3 KB of LDS per env instead of ~70 KB: many more resident envs during the
         // sweeps, which are > 90 % of such a step) -> integrate
         rc = launch_on(e, st, g0, g1 - g0, 1, ph | PH_PRE, 0);
+        if (!rc && e->M.dense) {
+          // dense row-space solver (dense_pgs.h): AR = J M^-1 J^T on the matrix cores, then column sweeps, for every env of the
+          // launch whose row count fits; the block solver below skips those envs (meta[7])
+          hipLaunchKernelGGL(mjh_dense_build_kernel, dim3(g1 - g0), dim3(256), e->dense_lds, st, e->dC, e->S, g0);
+          hipLaunchKernelGGL(mjh_dense_solve_kernel, dim3(g1 - g0), dim3(64), 0, st, e->dC, e->S, g0);
+          HIPCHK(hipGetLastError());
+        }
         if (!rc) {
           const size_t lds = (2 * (size_t)(((e->M.nv + 3) / 4) * 4) + 2 * (size_t)std::max(e->M.maxblk, 1) + 4 + 8) * sizeof(float);   // 2 dof vectors + visiting order + group starts + per-wave partial sums
           const bool xs = e->M.noslip_iterations > 0;      // (the convex narrow phase is not part of the solve launch)

@@ -1882,7 +1882,7 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         int* meta = (int*)(gs + L.g_meta);
         for (int d = lane; d < nv; d += 64) { gs[L.g_qvel + d] = s_qvel[d]; gs[L.g_smooth + d] = s_smooth[d]; if (nefc == 0) gs[L.g_qacc + d] = s_asmooth[d]; }
         for (int i = lane; i < M.nM; i += 64) gs[L.g_qM + i] = s_qM[i];
-        if (lane == 0) { meta[0] = nefc == 0 ? 0 : nblk; meta[1] = nfixblk; meta[2] = nefc; meta[3] = ncon; meta[4] = flags; meta[5] = 0; meta[6] = ngrp; }
+        if (lane == 0) { meta[0] = nefc == 0 ? 0 : nblk; meta[1] = nfixblk; meta[2] = nefc; meta[3] = ncon; meta[4] = flags; meta[5] = 0; meta[6] = ngrp; meta[7] = 0; }   // meta[7]: set by mjh_dense_build_kernel when the dense solver takes this env
         if (nefc == 0) return;
       }
       if (nefc == 0) {
@@ -2538,6 +2538,7 @@ __global__ __launch_bounds__(256) void mjh_solve_kernel(const DConst* __restrict
   int* meta = (int*)(gs + L.g_meta);
   const int nblk = __builtin_amdgcn_readfirstlane(meta[0]);
   if (nblk == 0) return;                                  // unconstrained env: the assemble launch wrote qacc itself
+  if (__builtin_amdgcn_readfirstlane(meta[7]) != 0) return;   // solved by the dense kernels (dense_pgs.h)
   const int nv4 = ((nv + 3) / 4) * 4, ngrp = __builtin_amdgcn_readfirstlane(meta[6]);
   float* s_qacc = lds; float* s_minv = lds + nv4;
   float* s_red = lds + 2 * nv4;                                               // per-wave partial sums (8 floats)
