@@ -7,7 +7,7 @@
 // 2.7 ms step, at 2.7 waves per CU).  Here the contraction is done once per step on the matrix cores and the sweeps become
 // column updates of a residual vector that lives in registers:
 //
-//   mjh_dense_build_kernel   one 256-thread workgroup per environment: expands the block rows (compact over <= 2 kinematic trees,
+//   mjh_dense_build_kernel   one 512-thread workgroup per environment: expands the block rows (compact over <= 2 kinematic trees,
 //                            pyramid rows n +- k folded) into dense J [rows x nv] and B = J M^-1 [rows x nv], multiplies them
 //                            with v_mfma_f32_16x16x4_f32 (upper triangle of 16 x 16 tiles, fragments straight from L1 / L2; exact fp32), and writes
 //                            AR' = -AR_pq / AR_qq (column-scaled, diagonal -1) row by row in Gauss-Seidel VISITING order, plus the
@@ -37,7 +37,8 @@ typedef float mjh_f4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------ build
 // LDS: s_a0[NVS] | s_inv[CAP] | s_row[CAP] int4 | s_start[maxblk + 1]  (a few KB: several workgroups per CU)
-__global__ __launch_bounds__(256) void mjh_dense_build_kernel(const DConst* __restrict__ C, const DState S, int env0) {
+#define DN_BUILD_THREADS 512
+__global__ __launch_bounds__(DN_BUILD_THREADS) void mjh_dense_build_kernel(const DConst* __restrict__ C, const DState S, int env0) {
   const DModel& M = C->M; const Lay& L = C->L;
   extern __shared__ float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nv = M.nv;
@@ -53,8 +54,8 @@ __global__ __launch_bounds__(256) void mjh_dense_build_kernel(const DConst* __re
   int4* s_row = (int4*)(s_inv + cap); int* s_start = (int*)(s_row + cap);
   const int* g_ord = (const int*)(gs + (-1 - L.order)); const int4* g_hd = (const int4*)(gs + (-1 - L.blki));
   const float* g_bf = gs + (-1 - L.blkf); const float* g_J = gs + (-1 - L.J); const float* g_B = gs + (-1 - L.B);
-  for (int d = tid; d < nvs; d += 256) s_a0[d] = d < nv ? gs[L.g_a0 + d] : 0.0f;
-  for (int q = tid; q < cap; q += 256) s_inv[q] = 0.0f;
+  for (int d = tid; d < nvs; d += DN_BUILD_THREADS) s_a0[d] = d < nv ? gs[L.g_a0 + d] : 0.0f;
+  for (int q = tid; q < cap; q += DN_BUILD_THREADS) s_inv[q] = 0.0f;
   // ---- rows in visiting order: position i of the order -> block, its rows start at the running sum of the row counts
   if (wid == 0) {
     int run = 0;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void mjh_dense_build_kernel(const DConst* __re
     }
   }
   __syncthreads();
-  for (int i = tid; i < nblk; i += 256) {
+  for (int i = tid; i < nblk; i += DN_BUILD_THREADS) {
     const int b = g_ord[i]; const int4 hd = g_hd[b];
     const int nr = (hd.x >> 4) & 15, p0 = s_start[i], sl4 = BLK_SLOTS(hd.y) == 4 ? 1 : 0;
     for (int r = 0; r < nr; r++) s_row[p0 + r] = make_int4(hd.x, hd.z, hd.w, b | (r << 16) | (sl4 << 24));
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void mjh_dense_build_kernel(const DConst* __re
   //      in the lanes' layout [lane][K] of the sweep kernel
   float* g_jd = gs + o.jd; float* g_bd = gs + o.bd;
   const int sub = tid & 15;
-  for (int p = tid >> 4; p < W; p += 16) {
+  for (int p = tid >> 4; p < W; p += DN_BUILD_THREADS / 16) {
     int4 ri = make_int4(0, 0, 0, 0);
     if (p < nefc) ri = s_row[p];
     ROW_TREES(ri.y, ri.z);
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void mjh_dense_build_kernel(const DConst* __re
     const int kk = 1 + (r >> 1); const float sg = (r & 1) ? -1.0f : 1.0f;
     float jb = 0, ja = 0;
     if (p < nr16)
+#pragma unroll 8
       for (int d = sub; d < nvs; d += 16) {
         float jv = 0, bv = 0;
         const int k = (p < nefc && d < nv) ? row_off(d, a1, n1, a2, n2) : -1;
@@ -123,42 +125,68 @@ __global__ __launch_bounds__(256) void mjh_dense_build_kernel(const DConst* __re
     }
   }
   __syncthreads();
-  // ---- AR = J B^T on the matrix cores, upper triangle of 16 x 16 tiles (AR is symmetric: tile (Q, P) is the transpose of tile
-  //      (P, Q)), tiles dealt round-robin to the four waves.  Per 16-dof chunk a lane fetches 16 bytes of its A row (J) and of its
-  //      B row (J M^-1) — L1 / L2 hits, the rows were just written by this workgroup — and issues four v_mfma_f32_16x16x4_f32
-  //      (the k index inside a chunk is permuted identically on both sides: lane l carries k = 4 (l >> 4) + j, j = 0..3, so that a
-  //      lane's four values are contiguous).  D: col = l & 15, row = 4 (l >> 4) + v.  Stored column-scaled: AR'_pq = -AR_pq / AR_qq,
-  //      diagonal -1, at [p][lane = q & 63][k = q >> 6].
-  const int TD = nr16 >> 4, nch = nvs >> 4;
+  // ---- AR = J B^T on the matrix cores in 16 x 16 tiles.  A work item = a 16-row panel P and a column class Q0 = Q mod 4: its K
+  //      tiles Q0, Q0 + 4, ... hold, for one lane index, exactly the K row owners q, q + 64, ... whose values are adjacent in the
+  //      sweep kernel's layout [p][lane][K] — so a lane stores K adjacent floats and a 16-lane DPP row a contiguous run (the stores
+  //      are the traffic of this kernel: 4-byte scatters cost it 2x).  Items are dealt round-robin to the eight waves.  Per 16-dof
+  //      chunk a lane fetches 16 bytes of its A row (J) and of each B row (J M^-1) — L1 / L2 hits, the rows were just written by
+  //      this workgroup — and issues four v_mfma_f32_16x16x4_f32 per tile (the k index inside a chunk is permuted identically on
+  //      both sides: lane l carries k = 4 (l >> 4) + j, j = 0..3, so that a lane's four values are contiguous).
+  //      D: col = l & 15, row = 4 (l >> 4) + v.  Stored column-scaled: AR'_pq = -AR_pq / AR_qq, diagonal -1.  Panels and tiles
+  //      beyond the rows are zero without any arithmetic: the inert border of the sweep.
+  const int TD = nr16 >> 4, TP = nr32 >> 4, nch = nvs >> 4;
   const int li = lane & 15, lk = lane >> 4;
   float* g_art = gs + o.art;
-  int cnt = 0;
-  for (int P = 0; P < TD; P++)
-    for (int Q = P; Q < TD; Q++) {
-      if (((cnt++) & 3) != wid) continue;
-      mjh_f4 acc = (mjh_f4){0, 0, 0, 0};
-      const float* ap = g_jd + (16 * P + li) * nvs + 4 * lk; const float* bp = g_bd + (16 * Q + li) * nvs + 4 * lk;
-      for (int c = 0; c < nch; c++) {
-        const float4 a = *(const float4*)(ap + 16 * c), bq = *(const float4*)(bp + 16 * c);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc, 0, 0, 0);
-      }
-      const int q = 16 * Q + li; const float iq = s_inv[q];
-      const int ixq = (q & 63) * K + (q >> 6);
+  for (int item = wid; item < 4 * TP; item += DN_BUILD_THREADS / 64) {
+    const int P = item >> 2, Q0 = item & 3;
+    mjh_f4 acc[4];
 #pragma unroll
-      for (int v = 0; v < 4; v++) {
-        const int p = 16 * P + 4 * lk + v;
-        const float val = acc[v];
-        g_art[p * W + ixq] = (p == q && p < nefc) ? -1.0f : -val * iq;
-        if (P != Q) g_art[q * W + (p & 63) * K + (p >> 6)] = -val * s_inv[p];       // the mirrored element, scaled by ITS column
+    for (int j = 0; j < 4; j++) acc[j] = (mjh_f4){0, 0, 0, 0};
+    if (P < TD) {
+      const float* ap = g_jd + (16 * P + li) * nvs + 4 * lk;
+      // fragments of chunk c + 1 are requested before the matrix instructions of chunk c (a tile that does not exist reads row 0)
+      const float* bp[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) bp[j] = g_bd + (16 * (Q0 + 4 * j < TD ? Q0 + 4 * j : 0) + li) * nvs + 4 * lk;
+      float4 a = *(const float4*)ap, bq[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) bq[j] = *(const float4*)bp[j];
+      for (int c = 0; c < nch; c++) {
+        const int cn = c + 1 < nch ? c + 1 : c;
+        const float4 an = *(const float4*)(ap + 16 * cn);
+        float4 bn[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) bn[j] = *(const float4*)(bp[j] + 16 * cn);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (Q0 + 4 * j < TD) {
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq[j].x, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq[j].y, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[j].z, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq[j].w, acc[j], 0, 0, 0);
+          }
+        }
+        a = an;
+#pragma unroll
+        for (int j = 0; j < 4; j++) bq[j] = bn[j];
       }
     }
-  // ---- the inert border: rows nr16 .. nr32 and columns nr16 .. W of the visited rows
-  for (int idx = tid; idx < nr32 * W; idx += 256) {
-    const int p = idx / W, c = idx - p * W, q = (c % K) * 64 + c / K;
-    if (p >= nr16 || q >= nr16) g_art[idx] = 0.0f;
+    const int ql = 16 * Q0 + li;                          // lane index of the row owners q = ql + 64 j
+    float iq[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) iq[j] = (j < K && ql + 64 * j < cap) ? s_inv[ql + 64 * j] : 0.0f;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const int p = 16 * P + 4 * lk + v;
+      float out[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) out[j] = (p == ql + 64 * j && p < nefc) ? -1.0f : -acc[j][v] * iq[j];
+      float* dst = g_art + p * W + ql * K;
+      if (K == 1) dst[0] = out[0];
+      else if (K == 2) *(float2*)dst = make_float2(out[0], out[1]);
+      else if (K == 3) { dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2]; }
+      else *(float4*)dst = make_float4(out[0], out[1], out[2], out[3]);
+    }
   }
   __syncthreads();
   if (tid == 0) meta[DN_META_DENSE] = 1;

@@ -620,7 +620,7 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
         if (!rc && e->M.dense) {
           // dense row-space solver (dense_pgs.h): AR = J M^-1 J^T on the matrix cores, then column sweeps, for every env of the
           // launch whose row count fits; the block solver below skips those envs (meta[7])
-          hipLaunchKernelGGL(mjh_dense_build_kernel, dim3(g1 - g0), dim3(256), e->dense_lds, st, e->dC, e->S, g0);
+          hipLaunchKernelGGL(mjh_dense_build_kernel, dim3(g1 - g0), dim3(DN_BUILD_THREADS), e->dense_lds, st, e->dC, e->S, g0);
           hipLaunchKernelGGL(mjh_dense_solve_kernel, dim3(g1 - g0), dim3(64), 0, st, e->dC, e->S, g0);
           HIPCHK(hipGetLastError());
         }

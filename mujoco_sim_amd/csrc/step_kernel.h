@@ -1954,8 +1954,12 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
           }
         }
         if (!patched) {
+        // (an env that the dense solver takes — dense_pgs.h: it forms the full AR on the matrix cores — needs neither the blocks'
+        //  own A_c nor their row-space matrices, only the projection intervals)
+        const bool dense_env = pre && M.dense && nefc <= M.dense_cap;
         // ---- A_c = J_base M^-1 J_base^T, upper triangle (lanes = (block, base jb): row jb).  Built here, after the last user
         //      of the contact records and the velocity-stage spatial vectors: s_blkq reuses their space.
+        if (!dense_env)
         for (int b = lane; b < nblk; b += 64) {     // lanes = blocks: every dof's four base entries are one 16-byte read
           const int4 hd = *(const int4*)(s_blki_i + b * BLKI_STRIDE);
           const int nb = (hd.x >> 8) & 15;
@@ -1984,6 +1988,12 @@ __global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restric
         for (int b = lane; b < nblk; b += 64) {
           const int* hd = s_blki_i + b * BLKI_STRIDE;
           float* bf = s_blkf + b * BLKF_STRIDE;
+          if (dense_env) {
+            const int clamp = (hd[0] >> 12) & 3;
+            bf[BF_LO] = clamp == 0 ? -3.0e38f : (clamp == 2 ? -bf[1] : 0.0f);
+            bf[BF_LO + 1] = clamp == 2 ? bf[1] : 3.0e38f;
+            continue;
+          }
           float* Q = s_blkq + b * BLKQ_STRIDE;
           const int kind = hd[0] & 15, nr = (hd[0] >> 4) & 15;
           float Ac[4][4];
