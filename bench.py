@@ -117,6 +117,35 @@ class S24(Workload):
         return d
 
 
+class S24D(S24):
+    """the "30-contact" reading of the metric's name: S24's pen and S24's four boxes (same per-env sizes, masses, seeds), but released
+    flat and side by side (2 x 2, random yaw) instead of as a staggered column of random orientations: the boxes land on the floor
+    together (16 floor contacts of condim 4) and are wedged against each other and the walls — ~30 contacts, ~130 rows per env, what
+    SURVEY.md §8-d D2 expected of the scene.  Reported beside the D2-exact S24 line, never instead of it."""
+    name = "s24d"; settle_steps = 400; min_ncon = 20.0
+    pen_half = 0.175; capacity = 64
+    label = ("S24D: S24's pen and 4 free boxes (same sizes / seeds), released flat in a 2 x 2 layout with random yaw: ~30 contacts, ~130 rows per env, "
+             "PGS 100 it / tol 1e-8")
+
+    def build(self, device, stream):
+        mc = self.args.maxcon if self.args.maxcon > 0 else self.capacity
+        pen = float(self.args.pen_half or self.pen_half)
+        self.model = self.ms.scene("s24pen", pen, int(mc))
+        self.eng = self.ms.Engine(self.model, self.nenv, device=device, stream=stream)
+        self.tab = self.eng.load_s24(env_offset=self.env_offset)
+        q = self.tab["qpos"].reshape(self.nenv, 4, 7)
+        for i in range(self.nenv):
+            rng = np.random.default_rng(0x524D0000 + self.env_offset + i)
+            for k in range(4):
+                yaw = rng.uniform(-0.3, 0.3)
+                q[i, k] = [(-1 if k & 1 else 1) * pen / 2, (-1 if k & 2 else 1) * pen / 2, 0.16 + 0.02 * k, np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)]
+        self.eng.set_initial_qpos(self.tab["qpos"]); self.eng.reset()
+
+    def oracle_data(self, orc, i, state):
+        d = super().oracle_data(orc, i, state)
+        return d
+
+
 class C2(S24):
     name = "c2"; settle_steps = 200; min_ncon = None
     label = ("C2: 64 free boxes (nv 384), half-extents U[0.05,0.125]^3, 4x4x4 lattice (pitch 0.3 m, z0 0.5..1.4) with +-0.01 m jitter and "
@@ -256,7 +285,7 @@ class C5(RobotFixture):
             self.eng.set_state(qvel=v.reshape(self.rows, -1))
 
 
-WORKLOADS = {w.name: w for w in (S24, C2, C3, C4, C5)}
+WORKLOADS = {w.name: w for w in (S24, S24D, C2, C3, C4, C5)}
 
 
 def usable_cpus():
@@ -525,6 +554,7 @@ def main():
     ap.add_argument("--cohorts", type=int, default=-1, help="env cohorts stepped on separate HIP streams (-1: the config's default, else the engine's)")
     ap.add_argument("--timing-stride", type=int, default=5, help="bracket every N-th step launch with HIP events (roofline.kernel_ms is their mean)")
     ap.add_argument("--pack", type=int, default=0, help="environments per wavefront for the small-model configs (0: the config's default — C3 4, C5 2, others 1)")
+    ap.add_argument("--pen-half", type=float, default=0.0, help="s24d: half width of the pen in metres (default 0.14; S24 itself is 0.175)")
     ap.add_argument("--maxcon", type=int, default=0, help="override the scene's contact capacity per env; 0 = scene default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
@@ -709,7 +739,7 @@ def main():
     eng.close()
     if rank == 0 and world == 1 and w.name == "s24" and not args.no_extra_configs and not args.force_dist:
         out["configs"] = {}
-        for name in ("c2", "c3", "c4", "c5"):
+        for name in ("s24d", "c2", "c3", "c4", "c5"):
             try:
                 out["configs"][name] = short_config_line(ms, args, name, local_rank, stream.cuda_stream)
             except Exception as ex:

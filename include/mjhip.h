@@ -257,6 +257,7 @@ void mjh_load_set_bounds(double boundmass, double boundinertia);
 /* ------------------------------------------------------ scene builders */
 /* SURVEY.md §8-d configs, as programmatic models.  `seed_base+env` seeds PCG32. */
 mjh_model* mjh_scene_s24(void); /* 4 free boxes in a walled pen on the empty.xml floor  */
+mjh_model* mjh_scene_s24_pen(double pen_half, int maxcon); /* the same scene with another pen (S24 itself: 0.175, 40); bench.py `s24d`: a narrow pen, ~30 contacts */
 /* per-env S24 randomisation: fills qpos0[nenv*nq] and the per-env parameter tables
  * (each out pointer may be NULL).  Box half-extents U[0.05,0.125]^3.             */
 int mjh_scene_s24_randomize(const mjh_model*, int env0, int nenv, unsigned seed_base,

@@ -22,6 +22,9 @@ SOURCES = {
     "mjcf_loader.cpp": ["hmath.h", API],
 }
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-Wno-unused-result"]
+FLAGS += os.environ.get("MJH_EXTRA_FLAGS", "").split()      # A/B builds (e.g. -DPP_NRC=0 -DMJH_STEP_WAVES=3), together with MJH_BUILD_DIR / MJHIP_LIB
+if os.environ.get("MJH_BUILD_DIR"):
+    OBJ = os.environ["MJH_BUILD_DIR"]; LIB = os.path.join(OBJ, "libmjhip.so")
 
 
 def _digest(paths, extra=""):

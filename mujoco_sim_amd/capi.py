@@ -150,6 +150,7 @@ SYMBOLS = [
     ("mjh_load_set_odom_joints", None, [C.c_uint]),
     ("mjh_load_set_robot_pose", None, [C.c_char_p, c_double_p]),
     ("mjh_scene_s24", Model_p, []),
+    ("mjh_scene_s24_pen", Model_p, [C.c_double, C.c_int]),
     ("mjh_scene_s24_randomize", C.c_int, [Model_p, C.c_int, C.c_int, C.c_uint] + [c_double_p] * 7),
     ("mjh_scene_boxes_randomize", C.c_int, [Model_p, C.c_int, C.c_int, C.c_uint, C.c_double] + [c_double_p] * 7),
     ("mjh_scene_pendulum", Model_p, []),

@@ -39,8 +39,12 @@
 #define PP_TILES(two, nr4) (PP_REC(two) * (nr4))
 #define PP_SIZE(two, n4) (4 * PP_REC(two) * (n4) + 8 * (n4) * ((n4) + 1))
 #define PP_ZERO 20     // floats of zeros a lane outside a patch reads instead of a record
-#define PP_NSU 6       // schedules of up to this many steps run with their per-lane addresses cached in registers
-#define PP_NRC 6       // ... and the row records (J^, f, row constants) of the first PP_NRC steps stay in registers over the sweeps
+#ifndef PP_NSU
+#define PP_NSU 6
+#endif                 // schedules of up to this many steps run with their per-lane addresses cached in registers
+#ifndef PP_NRC
+#define PP_NRC 6
+#endif                 // ... and the row records (J^, f, row constants) of the first PP_NRC steps stay in registers over the sweeps
 
 // acc += y * (x of lane R of this lane's 16-lane row); x must not have been written by the VALU in the two instructions before
 #define PP_FMAC_BC(acc, x, y, R) asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #R " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y))

@@ -52,7 +52,12 @@ void add_floor(mjh_builder* b, bool empty_xml_params) {
 static const int S24_NBOX = 4;
 static const double S24_PEN_HALF = 0.175;  // 0.35 m square pen
 
-extern "C" mjh_model* mjh_scene_s24(void) {
+// S24 with another pen: the same four boxes (sizes, poses and seeds come from mjh_scene_s24_randomize) between walls pen_half
+// from the centre.  bench.py's `s24d` narrows the pen until the boxes have to stand on each other and lean on all four walls:
+// the ~30 contacts / >= 130 rows the metric's name speaks of (the D2-exact pen settles at ~17 contacts).
+extern "C" mjh_model* mjh_scene_s24_pen(double pen_half, int maxcon) {
+  if (!(pen_half > 0.05) || maxcon < 8) return nullptr;
+  const double S24_PEN_HALF = pen_half;
   mjh_builder* b = mjh_builder_create();
   empty_world_options(b, -9.81);
   add_floor(b, true);
@@ -77,11 +82,12 @@ extern "C" mjh_model* mjh_scene_s24(void) {
   // capacity: over 4096 envs the pile stays below 31 contacts in the benchmark window (1400 steps) and reaches 35 in a
   // 20 000-step soak (the piles keep compacting); 40 contacts x 6 rows leaves a margin (overflow is flagged, not silent)
   // (tools/ncon_hist.py); overflow drops the excess contacts and raises the per-env flag
-  mjh_builder_set_capacity(b, 40, 40 * 6);
+  mjh_builder_set_capacity(b, maxcon, maxcon * 6);
   mjh_model* m = mjh_builder_compile(b);
   mjh_builder_destroy(b);
   return m;
 }
+extern "C" mjh_model* mjh_scene_s24(void) { return mjh_scene_s24_pen(S24_PEN_HALF, 40); }
 
 extern "C" int mjh_scene_s24_randomize(const mjh_model* m, int env0, int nenv, unsigned seed_base,
                                        double* qpos, double* geom_size, double* geom_rbound,

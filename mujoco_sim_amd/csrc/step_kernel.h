@@ -602,7 +602,10 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
 #include "patch_pgs.h"
 
 template <int NROW, bool DIAGM, bool EXTRA>
-__global__ __launch_bounds__(64, 2) void mjh_step_kernel(const DConst* __restrict__ C, const DState S, int env0, int nsteps, int ph, int xflags) {
+#ifndef MJH_STEP_WAVES
+#define MJH_STEP_WAVES 2      // resident waves per SIMD the register allocation aims at (A/B builds: -DMJH_STEP_WAVES=3 with -DPP_NRC=0)
+#endif
+__global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DConst* __restrict__ C, const DState S, int env0, int nsteps, int ph, int xflags) {
   // model descriptor + LDS layout live in device memory (uploaded once): uniform scalar loads on demand instead
   // of a by-value kernarg struct that the lambdas below would force into a private (scratch) copy
   const DModel& M = C->M;

@@ -88,7 +88,7 @@ def load_mjcf(xml=None, path=None, paths=None):
 
 def scene(name, *args):
     lib = capi.load()
-    fn = {"s24": lib.mjh_scene_s24, "pendulum": lib.mjh_scene_pendulum, "arm7": lib.mjh_scene_arm7,
+    fn = {"s24": lib.mjh_scene_s24, "s24pen": lib.mjh_scene_s24_pen, "pendulum": lib.mjh_scene_pendulum, "arm7": lib.mjh_scene_arm7,
           "boxpile": lib.mjh_scene_boxpile}[name]
     return Model(fn(*args), lib)
 
