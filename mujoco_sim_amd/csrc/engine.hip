@@ -625,7 +625,7 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
           HIPCHK(hipGetLastError());
         }
         if (!rc) {
-          const size_t lds = (2 * (size_t)(((e->M.nv + 3) / 4) * 4) + 2 * (size_t)std::max(e->M.maxblk, 1) + 4 + 8) * sizeof(float);   // 2 dof vectors + visiting order + group starts + per-wave partial sums
+          const size_t lds = (2 * (size_t)(((e->M.nv + 3) / 4) * 4) + 2 * (size_t)std::max(e->M.maxblk, 1) + 4 + 8 + 8 + 8 * (size_t)((e->M.nv + 2) / 3)) * sizeof(float);   // ... + the quad sweep's padded copies (four floats per 3 dofs, twice)   // 2 dof vectors + visiting order + group starts + per-wave partial sums
           const bool xs = e->M.noslip_iterations > 0;      // (the convex narrow phase is not part of the solve launch)
           // wide groups (up to 16 independent blocks) can be shared by several waves per environment (MJH_SOLVE_WAVES = 2, 4: chunk
           // c4 of a group goes to wave c4 % n, a workgroup barrier ends the group).  Measured on C2 (4096 envs, 215 contacts per

@@ -320,6 +320,9 @@ struct ManyCtx {
   // pool's byte offset as the scalar offset and a 32-bit per-lane offset - one shift per block instead of a 64-bit address per load,
   // and a lane that has nothing to fetch / store points beyond the slice (reads 0, stores nothing) instead of being masked off
   __amdgpu_buffer_rsrc_t rsrc; int oJ, oB, oblkf, oblkq, oext, oblki;
+  // quad sweep (free-body piles, groups of up to 16 blocks): padded LDS copies of the running acceleration and of 1 / M_dd, four floats
+  // per 3 dofs (one ds_read_b128 per lane); null: not used
+  float* a4; const float* m4;
 };
 typedef unsigned mjh_v4u __attribute__((vector_size(16)));   // (the builtins' own vector types: an ext_vector_type of the same size converts by value, not by bits)
 typedef unsigned mjh_v2u __attribute__((vector_size(8)));
@@ -420,6 +423,115 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
       *(float2*)(bf + 4) = make_float2(f[4], f[5]);
     }
   };
+  if (BUF && DIAGM && wide && c.a4 != nullptr && c.nwave == 1) {
+    // ======== SIXTEEN blocks per wave-step (free-body piles: BASELINE config C2): a whole group of up to 16 mutually independent
+    //          blocks at once, four lanes per block — lane (s, h) of the wave owns dofs 3h .. 3h + 2 of the compact dofs of block
+    //          s of the group (h = 0, 1: body 1 translation / rotation; h = 2, 3: body 2).  The four-blocks-per-step form above
+    //          spends ~150 instructions per step doing the uniform row math redundantly on the 16 lanes of each block; here the
+    //          redundancy is 4 and a sweep over 200 blocks is ~14 steps instead of ~55.  Same groups, same order, same row math
+    //          (solve_rows) as the other forms and the oracle.  u_j = sum over the lane's 3 dofs, then two quad_perm adds.
+    const int s = lane >> 2, h = lane & 3;
+    struct SOp { int4 hd; int b; float act; float4 J0, J1, J2, p0, r0, r1, r2, A0, A1, A2, A3, X0, X1, X2; };
+    auto fetchS = [&](int g) __attribute__((always_inline)) {
+      SOp op;
+      const int st = c.gstart[g], sz = c.gstart[g + 1] - st;
+      const bool act = s < sz;
+      const int ow = c.order[act ? st + s : st];
+      const int b = ow & 0xffff, okind = (ow >> 16) & 15, ondof = ow >> 20;
+      op.b = b; op.act = act ? 1.0f : 0.0f;
+      const bool quad = b >= c.nfixblk;
+      const int jo = (quad ? c.nfixblk + 4 * (b - c.nfixblk) : b) * c.rowW;
+      const unsigned ob64 = (unsigned)b * 64u;
+      { const mjh_v4u hh = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)((unsigned)b * 16u), c.oblki, 0); __builtin_memcpy(&op.hd, &hh, 16); }
+      const bool jon = act && 3 * h < ondof;
+      if (quad) {
+        const unsigned oj = jon ? (unsigned)(jo + 12 * h) * 4u : MJH_BUF_OOB;
+        op.J0 = buf_load4(c.rsrc, oj, c.oJ); op.J1 = buf_load4(c.rsrc, oj + 16u, c.oJ); op.J2 = buf_load4(c.rsrc, oj + 32u, c.oJ);
+      } else {
+        const unsigned oj = jon ? (unsigned)(jo + 3 * h) * 4u : MJH_BUF_OOB;
+        op.J0 = make_float4(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rsrc, (int)oj, c.oJ, 0)), 0, 0, 0);
+        op.J1 = make_float4(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rsrc, (int)(oj + 4u), c.oJ, 0)), 0, 0, 0);
+        op.J2 = make_float4(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rsrc, (int)(oj + 8u), c.oJ, 0)), 0, 0, 0);
+      }
+      const unsigned ob = act ? ob64 : MJH_BUF_OOB;
+      op.p0 = buf_load4(c.rsrc, ob, c.oblkf); op.r0 = buf_load4(c.rsrc, ob + 16u, c.oblkf); op.r1 = buf_load4(c.rsrc, ob + 32u, c.oblkf); op.r2 = buf_load4(c.rsrc, ob + 48u, c.oblkf);
+      op.A0 = buf_load4(c.rsrc, ob, c.oblkq); op.A1 = buf_load4(c.rsrc, ob + 16u, c.oblkq); op.A2 = buf_load4(c.rsrc, ob + 32u, c.oblkq); op.A3 = buf_load4(c.rsrc, ob + 48u, c.oblkq);
+      op.X0 = make_float4(0, 0, 0, 0); op.X1 = op.X0; op.X2 = op.X0;
+      if (c.has_dim4) {
+        const unsigned ox = (okind == BK_PYR4 && act) ? (unsigned)b * (unsigned)(SOLX_N * 4) : MJH_BUF_OOB;
+        op.X0 = buf_load4(c.rsrc, ox, c.oext); op.X1 = buf_load4(c.rsrc, ox + 16u, c.oext); op.X2 = buf_load4(c.rsrc, ox + 32u, c.oext);
+      }
+      return op;
+    };
+    auto processS = [&](SOp& op, float& impl) __attribute__((always_inline)) {
+      KEEP4(op.hd); KEEP4(op.J0); KEEP4(op.J1); KEEP4(op.J2); KEEP4(op.p0); KEEP4(op.r0); KEEP4(op.r1); KEEP4(op.r2); KEEP4(op.A0); KEEP4(op.A1); KEEP4(op.A2); KEEP4(op.A3);
+      if (c.has_dim4) { KEEP4(op.X0); KEEP4(op.X1); KEEP4(op.X2); }
+      ROW_TREES(op.hd.z, op.hd.w);
+      const bool actb = op.act > 0.0f;
+      const bool on = actb && 3 * h < n1 + n2;
+      // triple index of the lane's dofs in the padded vectors: dofs a1 + 3h (h < n1 / 3) or a2 + 3h - n1  (x / 3 = x * 43691 >> 17)
+      const int d0 = 3 * h < n1 ? a1 + 3 * h : a2 + 3 * h - n1;
+      const int t4 = on ? (int)(((unsigned)d0 * 43691u) >> 17) << 2 : 0;
+      const float4 av = on ? *(const float4*)(c.a4 + t4) : make_float4(0, 0, 0, 0);
+      const float4 mv = on ? *(const float4*)(c.m4 + t4) : make_float4(0, 0, 0, 0);
+      const int kk = actb ? (op.hd.x & 15) : 0;
+      const int kind = __ballot(kk == BK_PYR4) ? BK_PYR4 : (__ballot(kk == BK_PYR3) ? BK_PYR3 : BK_SINGLE);    // rows of smaller blocks are inert
+      float f[6] = {op.r1.x, op.r1.y, op.r1.z, op.r1.w, op.r2.x, op.r2.y};
+      const float aref[4] = {op.r0.x, op.r0.y, op.r0.z, op.r0.w};
+      const float Q[16] = {op.A0.x, op.A0.y, op.A0.z, op.A0.w, op.A1.x, op.A1.y, op.A1.z, op.A1.w,
+                           op.A2.x, op.A2.y, op.A2.z, op.A2.w, op.A3.x, op.A3.y, op.A3.z, op.A3.w};
+      const float X[12] = {op.X0.x, op.X0.y, op.X0.z, op.X0.w, op.X1.x, op.X1.y, op.X1.z, op.X1.w, op.X2.x, op.X2.y, op.X2.z, op.X2.w};
+      const float R = op.p0.x, lo = op.r2.z, hi = op.r2.w;
+      float u[4] = {op.J0.x * av.x + op.J1.x * av.y + op.J2.x * av.z, op.J0.y * av.x + op.J1.y * av.y + op.J2.y * av.z,
+                    op.J0.z * av.x + op.J1.z * av.y + op.J2.z * av.z, op.J0.w * av.x + op.J1.w * av.y + op.J2.w * av.z}, dphi[4] = {0, 0, 0, 0};
+      asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]));
+      float imp;
+#define MJH_QUADSUM(N) do { MJH_DPP_BF4(u, N, 0xB1); MJH_DPP_BF4(u, N, 0x4E); } while (0)     // quad_perm [1,0,3,2], [2,3,0,1]: every lane of the quad holds the block's sum
+      if (kind == BK_PYR4) { MJH_QUADSUM(4); for (int j = 0; j < 4; j++) u[j] -= aref[j]; imp = solve_rows<4, 6, EXTRA>(ns, R, lo, hi, u, f, Q, X, dphi); }
+      else if (kind == BK_PYR3) { MJH_QUADSUM(3); for (int j = 0; j < 3; j++) u[j] -= aref[j]; imp = solve_rows<3, 4, EXTRA>(ns, R, lo, hi, u, f, Q, X, dphi); }
+      else { MJH_QUADSUM(1); u[0] -= aref[0]; imp = solve_rows<1, 1, EXTRA>(ns, R, lo, hi, u, f, Q, X, dphi); }
+#undef MJH_QUADSUM
+      if (on) {
+        float4 an = av;
+        an.x += (op.J0.x * dphi[0] + op.J0.y * dphi[1] + op.J0.z * dphi[2] + op.J0.w * dphi[3]) * mv.x;
+        an.y += (op.J1.x * dphi[0] + op.J1.y * dphi[1] + op.J1.z * dphi[2] + op.J1.w * dphi[3]) * mv.y;
+        an.z += (op.J2.x * dphi[0] + op.J2.y * dphi[1] + op.J2.z * dphi[2] + op.J2.w * dphi[3]) * mv.z;
+        *(float4*)(c.a4 + t4) = an;                                           // (the group's blocks touch disjoint bodies)
+      }
+      const bool head = actb && h == 0;
+      impl += head ? imp : 0.0f;
+      const unsigned of = head ? (unsigned)op.b * 64u + (unsigned)(BF_F * 4) : MJH_BUF_OOB;
+      mjh_v4u f4; mjh_v2u f2;
+      __builtin_memcpy(&f4, f, 16); __builtin_memcpy(&f2, f + 4, 8);
+      __builtin_amdgcn_raw_buffer_store_b128(f4, c.rsrc, (int)of, c.oblkf, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(f2, c.rsrc, (int)(of + 16u), c.oblkf, 0);
+    };
+    // operands two groups ahead (three register sets in rotation), as in the four-block form
+    int gF = 0, gP = 0;
+    auto nextFetch = [&]() __attribute__((always_inline)) { SOp o = fetchS(gF); gF = gF + 1 == c.ngrp ? 0 : gF + 1; return o; };
+    float impl = 0; bool done = false;
+    auto stepDone = [&]() __attribute__((always_inline)) {
+      if (++gP < c.ngrp) return;
+      gP = 0; niter++;
+      const float improvement = wave_sum<4>(impl);
+      impl = 0;
+      done = improvement * c.scale < tol || niter >= itmax;
+    };
+    if (c.ngrp >= 3) {
+      SOp o0 = nextFetch(), o1 = nextFetch(), o2;
+      while (true) {
+        o2 = nextFetch(); processS(o0, impl); stepDone(); if (done) break;
+        o0 = nextFetch(); processS(o1, impl); stepDone(); if (done) break;
+        o1 = nextFetch(); processS(o2, impl); stepDone(); if (done) break;
+      }
+    } else {
+      SOp o0 = nextFetch(), o1;
+      while (true) {
+        o1 = nextFetch(); processS(o0, impl); stepDone(); if (done) break;
+        o0 = nextFetch(); processS(o1, impl); stepDone(); if (done) break;
+      }
+    }
+  } else
   if (wide) {
     // ======== four blocks per wave-step: the blocks of a group (mutually independent by construction of the order) sit on the
     //          four 16-lane rows of a wave; lanes of a row = the compact dofs of its block.  Everything "uniform" of the
@@ -2087,7 +2199,7 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
             mc.nblk = nblk; mc.nfixblk = __builtin_amdgcn_readfirstlane(nfixblk); mc.rowW = rowW; mc.iterations = M.iterations;
             mc.has_dim4 = has_dim4; mc.scale = scale; mc.tolerance = M.tolerance;
             mc.noslip_iterations = M.noslip_iterations; mc.noslip_tolerance = M.noslip_tolerance;
-            mc.nwave = 1; mc.wid = 0; mc.red = nullptr;
+            mc.nwave = 1; mc.wid = 0; mc.red = nullptr; mc.a4 = nullptr; mc.m4 = nullptr;
             {   // the pools are in the env's global slice here too: same buffer-descriptor fetch as mjh_solve_kernel
               const unsigned long long ga = (unsigned long long)gs;
               const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ga), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ga >> 32));
@@ -2563,6 +2675,11 @@ __global__ __launch_bounds__(256) void mjh_solve_kernel(const DConst* __restrict
     for (int i = tid; i < nblk; i += nthr) { const int b = g_ord[i]; const int4 hd = g_hd[b]; s_ord[i] = MJH_ORDER_WORD(b, hd); }
   }
   if (nblk > 64) for (int i = tid; i <= ngrp; i += nthr) s_gst[i] = g_gst[i];
+  // quad sweep (free-body piles with groups of up to 16 blocks, one wave per env): padded copies, four floats per 3 dofs
+  const bool quad16 = DIAGM && M.group_max == 16 && M.rowW <= 12 && nthr == 64 && nblk > 64;
+  const int nt4 = 4 * ((nv + 2) / 3);
+  float* s_a4 = (float*)(((size_t)(s_gst + M.maxblk + 2) + 15) & ~(size_t)15); float* s_m4 = s_a4 + nt4;
+  if (quad16) for (int d = tid; d < nv; d += nthr) { const int t = d / 3, r = d - 3 * t; s_a4[4*t + r] = gs[L.g_a0 + d]; s_m4[4*t + r] = gs[L.g_minv + d]; }
   __syncthreads();
   ManyCtx mc;
   mc.J = gs + (-1 - L.J); mc.B = gs + (-1 - L.B); mc.blkf = gs + (-1 - L.blkf); mc.blkq = gs + (-1 - L.blkq); mc.ext = gs + (-1 - L.ext);
@@ -2572,6 +2689,7 @@ __global__ __launch_bounds__(256) void mjh_solve_kernel(const DConst* __restrict
   mc.has_dim4 = M.has_dim4 != 0; mc.scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1)); mc.tolerance = M.tolerance;
   mc.noslip_iterations = M.noslip_iterations; mc.noslip_tolerance = M.noslip_tolerance;
   mc.nwave = nthr >> 6; mc.wid = tid >> 6; mc.red = s_red;
+  mc.a4 = quad16 ? s_a4 : nullptr; mc.m4 = quad16 ? s_m4 : nullptr;
   {
     const unsigned long long ga = (unsigned long long)gs;
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ga), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ga >> 32));
@@ -2581,6 +2699,8 @@ __global__ __launch_bounds__(256) void mjh_solve_kernel(const DConst* __restrict
   }
   const int niter = pgs_many_body<DIAGM, EXTRA, true>(mc, lane);
   __syncthreads();
+  if (quad16 && nblk > 64 && M.rowW <= 16 && ngrp >= 2) { for (int d = tid; d < nv; d += nthr) { const int t = d / 3, r = d - 3 * t; gs[L.g_qacc + d] = s_a4[4*t + r]; } }
+  else
   for (int d = tid; d < nv; d += nthr) gs[L.g_qacc + d] = s_qacc[d];
   if (tid == 0) meta[5] = niter;
 }
