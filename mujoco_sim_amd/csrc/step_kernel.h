@@ -517,7 +517,10 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
       impl = 0;
       done = improvement * c.scale < tol || niter >= itmax;
     };
-    if (c.ngrp >= 3) {
+#ifndef MJH_QUAD_DEPTH
+#define MJH_QUAD_DEPTH 3      // operand sets in flight: 3 = two groups ahead (~210 VGPRs, two waves per SIMD): C2 0.658 M env-steps/s; 2 = one ahead (149 VGPRs, three waves per SIMD): 0.618 M — the fetch latency matters more than the third wave
+#endif
+    if (MJH_QUAD_DEPTH >= 3 && c.ngrp >= 3) {
       SOp o0 = nextFetch(), o1 = nextFetch(), o2;
       while (true) {
         o2 = nextFetch(); processS(o0, impl); stepDone(); if (done) break;
