@@ -169,7 +169,7 @@ class C3(Workload):
     label = ("C3: 7-hinge Panda chain (limits of ridgeback_panda.xml:53-87), fixed base, gravcomp 1, computed-torque wrapper + mj_inverse, "
              "PD ddq = 200 (q* - q) - 50 qd in the engine, targets U[limits] re-drawn every 200 steps; four arms per wavefront (mjh_model_replicate)")
 
-    pack = 4          # four arms per wavefront (7 of 64 lanes busy otherwise): mjh_model_replicate, DESIGN.md §9
+    pack = 4          # four arms per wavefront (7 of 64 lanes busy otherwise): mjh_model_replicate, HISTORY.md §9
     cohorts = 3       # a 0.10 ms launch of 1024 wavefronts leaves the chip half empty: 74 / 79 M env-steps/s with 2 / 3 cohorts (four: 54 M, the per-step join for the publish copy costs more than the overlap gives; tools/c3_sweep.sh)
 
     def build(self, device, stream):
@@ -711,7 +711,7 @@ def main():
                      "kernel_ms": kernel_ms, "launches": n_launches, "launches_timed": n_timed, "envs_per_launch": envs_per_launch, "concurrent_launches": cohorts,
                      "algorithmic_bytes_per_env_step": bytes_step,
                      "valu_issue_busy": valu_busy, "valu_issue_busy_source": traffic_src,
-                     "note": "fused per-env pipeline keeps intermediates in LDS: the path is issue/latency bound, far below the HBM roofline by design (DESIGN.md §4)"},
+                     "note": "fused per-env pipeline keeps intermediates in LDS: the path is issue/latency bound, far below the HBM roofline by design (DESIGN.md §4, §5)"},
     }
     if other is not None:
         out[key_inv if not main_inverse else key_no] = other["value"]

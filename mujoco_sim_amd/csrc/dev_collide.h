@@ -1,7 +1,7 @@
 // dev_collide.h — fp32 narrow-phase primitives, one candidate geom pair per lane.
 // Each routine writes up to its pair's capacity of raw contacts {dist, pos[3], normal[3]}
 // (normal from geom1 to geom2) into the lane's LDS staging slots and returns the count.
-// Definitions follow DESIGN.md §collision; plane-* / sphere-* / capsule-* follow MuJoCo's
+// Definitions follow DESIGN.md §2 (A6) / HISTORY.md §9; plane-* / sphere-* / capsule-* follow MuJoCo's
 // published primitives, box-box is this project's own SAT + face-manifold definition.
 #pragma once
 #include "dev_math.h"

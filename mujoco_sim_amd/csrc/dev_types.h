@@ -117,7 +117,7 @@ enum { XF_BODY = 1, XF_GEOM = 2, XF_CON = 4, XF_FORCE = 8, XF_PROF = 16,
 #define CON_G1(c) (__float_as_int((c)[CON_GEOMS]) & 0xfff)
 #define CON_G2(c) ((__float_as_int((c)[CON_GEOMS]) >> 12) & 0xfff)
 #define CON_DIM(c) (__float_as_int((c)[CON_GEOMS]) >> 24)
-// constraint blocks: header int4 + 16 parameter floats (s_blkf) + 16 solver-matrix floats (s_blkq) per block
+// constraint blocks (HISTORY.md §5): header int4 + 16 parameter floats (s_blkf) + 16 solver-matrix floats (s_blkq) per block
 //   hd.x = kind | nrows<<4 | nbase<<8 | clamp<<12 | jadr<<16 ; hd.y = id | rtype<<24 | side<<28 ; hd.z = a1 | n1<<16 ; hd.w = a2 | n2<<16
 //   floats: [0..3] R, frictionloss, KI, Bc ; [4..7] aref per BASE row (row r = n +- k has aref_n +- aref_k) ;
 //           [8..13] force per row ; [14..15] lo, hi ; s_blkq[0..15]: A_c = J_base M^-1 J_base^T (upper triangle), converted in

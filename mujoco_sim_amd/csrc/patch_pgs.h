@@ -1,6 +1,6 @@
 // patch_pgs.h — contact-patch Gauss-Seidel for small free-body models (mj_solPGS and the warm start of mj_fwdConstraint, reached
 // from mj_step2, /root/reference/src/mj_main.cpp:108).  Used by the LDS-resident kernels of models whose trees are all single free
-// bodies (DModel::patch; BASELINE's 24-DoF scene is one).  DESIGN.md §4c.
+// bodies (DModel::patch; BASELINE's 24-DoF scene is one).  HISTORY.md §4c.
 //
 // A patch = up to 16 constraint rows (whole contacts) between the SAME one or two bodies.  Its rows sit one per lane on a
 // 16-lane row of the wavefront, so a wave updates up to four mutually independent patches per step.  The coupling of the

@@ -2,7 +2,7 @@
 // the whole mj_step1 -> [mj_inverse] -> mj_step2 pipeline of the reference loop
 // (/root/reference/src/mj_main.cpp:82-112) fused in a single launch with every per-env
 // intermediate (body frames, spatial quantities, mass matrix, contacts, constraint rows) in LDS.
-// HBM traffic per env-step is the state row only (DESIGN.md §layout).
+// HBM traffic per env-step is the state row only (DESIGN.md §3).
 //
 // Stage map (reference call site -> block below):
 //   mj_step1 (mj_main.cpp:83)  FK, COM/cdof, CRBA, L'DL, collision, constraint rows, velocity stage
@@ -136,7 +136,7 @@ DEV int row_off(int d, int a1, int n1, int a2, int n2) {
 }
 
 
-// Row-space solver data of a block (written once per step by the "AR" pass):
+// Row-space solver data of a block (written once per step by the "AR" pass, HISTORY.md §5):
 //   Q[16] (block floats 16..31) and, for models with condim-4 contacts, X[12] (s_ext):
 //     1/AR_rr      : r < 4 -> Q[r]     ; r = 4,5 -> Q[14], Q[15]
 //     AR_rr / 2    : r < 4 -> Q[4 + r] ; r = 4,5 -> X[0], X[1]
@@ -166,7 +166,7 @@ DEV float pgs_rows(const float R, const float lo, const float hi, const float* u
   for (int r = 0; r < NR; r++) {
     const float fn = __builtin_amdgcn_fmed3f(f[r] - res[r] * AR_INV(Q, X, r), lo, hi);
     const float delta = fn - f[r];
-    // cost change delta*(res + delta*AR/2) <= 0 for every projected scalar update, so the
+    // cost change delta*(res + delta*AR/2) <= 0 for every projected scalar update (HISTORY.md §5), so the
     // reference's "revert if the cost went up" guard is dead code and is not evaluated here
     imp -= delta * (res[r] + AR_HALF(Q, X, r) * delta);
 #pragma unroll

@@ -1370,7 +1370,7 @@ static void constraint_update(orc_data* d, const double* jar, double* force) {
   }
 }
 
-/* Gauss-Seidel visiting order shared with the HIP path: rows are grouped into blocks
+/* Gauss-Seidel visiting order shared with the HIP path (HISTORY.md §5): rows are grouped into blocks
  * (one per equality / friction-loss / limit row, one per contact = its pyramid rows); blocks are visited in
  * the greedy "independent pair" order — block i, then the first later unvisited block that shares no
  * kinematic tree with it — so that the device can solve the two blocks of a pair side by side in the two

@@ -122,7 +122,7 @@ def test_pgs_at_the_default_cap_against_the_converged_dual_solution_is_measured(
     """The reference's models name no solver, so MuJoCo runs Newton on them: to solver precision, the OPTIMUM of the convex problem
     PGS iterates on.  This engine (and the oracle) solve it with PGS at MuJoCo's default cap of 100 sweeps / tolerance 1e-8, which
     does not converge on settled S24 piles (250-870 sweeps are needed at tolerance 1e-13).  Measured over 10 envs from identical
-    settled states (tools: /tmp study recorded in DESIGN.md §6): 1-step |d qacc| up to 0.5 m/s^2, 150-step |d qpos| up to 1.2e-2,
+    settled states (recorded in HISTORY.md §6): 1-step |d qacc| up to 0.5 m/s^2, 150-step |d qpos| up to 1.2e-2,
     median 1.9e-4.  Asserted on 3 envs with margins; part of the stated tolerance."""
     m = ms.scene("s24")
     N = 3

@@ -9,7 +9,7 @@ RAW=/tmp/prof_${TAG}_${CFG}
 OUT=$ROOT/gpurun_out/profiles
 rm -rf $RAW; mkdir -p $RAW $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --config $CFG --steps $STEPS --warmup 20 --no-cpu-baseline --no-second-window"
+BENCH="python $ROOT/bench.py --config $CFG --steps $STEPS --warmup 20 --no-cpu-baseline --no-second-window --no-extra-configs"
 rocprofv3 --kernel-trace --stats -d $RAW/trace -o trace -- $BENCH > $RAW/bench_trace.json 2> $RAW/trace.log
 rocprofv3 --pmc FETCH_SIZE -d $RAW/pmc_fetch -o fetch -- $BENCH > $RAW/bench_fetch.json 2> $RAW/fetch.log
 rocprofv3 --pmc WRITE_SIZE -d $RAW/pmc_write -o write -- $BENCH > $RAW/bench_write.json 2> $RAW/write.log

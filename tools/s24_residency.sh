@@ -1,5 +1,5 @@
 #!/bin/bash
-# S24 residency experiment: the default build (235 VGPRs: 2 waves / SIMD, records in registers) against the
+# S24 residency experiment (HISTORY.md Round 3): the default build (235 VGPRs: 2 waves / SIMD, records in registers) against the
 # A/B build -DPP_NRC=1 -DPP_NSU=4 -DMJH_STEP_WAVES=3 (168 VGPRs: 3 waves / SIMD), each at contact capacities 40 / 28 / 24 / 20
 # (LDS per env -> workgroups per CU).   usage: tools/s24_residency.sh <tag>
 set -u

@@ -7,7 +7,7 @@ RAW=/tmp/trace_${TAG}_${CFG}
 OUT=$ROOT/gpurun_out/profiles
 rm -rf $RAW; mkdir -p $RAW $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --config $CFG --steps 100 --warmup 20 --no-cpu-baseline --no-second-window $EXTRA"
+BENCH="python $ROOT/bench.py --config $CFG --steps 100 --warmup 20 --no-cpu-baseline --no-second-window --no-extra-configs $EXTRA"
 rocprofv3 --kernel-trace --stats -d $RAW/trace -o trace -- $BENCH > $RAW/bench_trace.json 2> $RAW/trace.log
 python $ROOT/tools/summarize_config.py $RAW $OUT $TAG $CFG | head -24
 rm -rf $RAW
