@@ -707,7 +707,8 @@ def main():
                    "lds_bytes_per_env": eng.lds_bytes, "contact_capacity": int(model.maxcon), **w.extra_config()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "mjh_step_kernel" + (" (+ mjh_solve_kernel: three-launch step of the many-body layout)" if eng.lds_bytes > 24 * 1024 or model.nv > 64 else ""),
+                     "kernel": "mjh_step_kernel" + ((" (+ mjh_dense_build_kernel [MFMA] + mjh_dense_solve_kernel: assemble -> build -> solve -> integrate chain of the many-body layout)" if eng.dense_solver() else
+                                                     " (+ mjh_solve_kernel: three-launch step of the many-body layout)") if eng.lds_bytes > 24 * 1024 or model.nv > 64 else ""),
                      "kernel_ms": kernel_ms, "launches": n_launches, "launches_timed": n_timed, "envs_per_launch": envs_per_launch, "concurrent_launches": cohorts,
                      "algorithmic_bytes_per_env_step": bytes_step,
                      "valu_issue_busy": valu_busy, "valu_issue_busy_source": traffic_src,

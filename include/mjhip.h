@@ -511,6 +511,10 @@ int mjh_lds_bytes(const mjh_engine*);  /* dynamic LDS per env (= per workgroup) 
  * convergence): 0 = independent pairs / groups of constraint blocks, 1 = contact patches (small free-body models: up to 16
  * rows between the same two bodies are solved as one unit, mujoco_sim_amd/csrc/patch_pgs.h). */
 int mjh_solver_order(const mjh_engine*);
+/* 1: mjh_step solves the environments of this engine whose rows fit with the dense row-space solver (AR = J M^-1 J^T on the matrix
+ * cores, column sweeps: csrc/dense_pgs.h) — articulated models in the many-body layout; same rows, same visiting order, same results up
+ * to fp32 rounding as the block solver (MJH_DENSE=0 turns it off) */
+int mjh_dense_solver(const mjh_engine*);
 int mjh_query_lds_bytes(const mjh_model*); /* same figure without a device: capacity planning (160 KiB per CU) */
 const char* mjh_last_error(void);
 const char* mjh_version(void);

@@ -1295,4 +1295,5 @@ extern "C" int mjh_nenv(const mjh_engine* e) { return e ? e->nenv : 0; }
 extern "C" const mjh_model* mjh_engine_model(const mjh_engine* e) { return e ? e->model : nullptr; }
 extern "C" int mjh_lds_bytes(const mjh_engine* e) { return e ? e->lds_bytes : 0; }
 extern "C" int mjh_solver_order(const mjh_engine* e) { return e && e->M.patch ? 1 : 0; }
+extern "C" int mjh_dense_solver(const mjh_engine* e) { return e && e->M.big && e->split3 && e->M.dense ? 1 : 0; }
 extern "C" const char* mjh_version(void) { return "mjhip 0.1 (gfx950)"; }

@@ -311,6 +311,10 @@ class Engine:
         """0: independent pairs / groups of blocks, 1: contact patches (mjh_solver_order)"""
         return self.lib.mjh_solver_order(self.h)
 
+    def dense_solver(self):
+        """1: articulated many-body model solved by the dense row-space solver (mjh_dense_solver)"""
+        return self.lib.mjh_dense_solver(self.h)
+
     def load_tables(self, t):
         """apply per-env parameter tables + initial poses (dict as returned by *_randomize) and reset"""
         for k in ["geom_size", "geom_rbound", "body_mass", "body_inertia", "body_invweight0", "dof_invweight0"]:

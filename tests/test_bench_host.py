@@ -19,8 +19,11 @@ def test_plain_multi_gpu_invocation_spawns_one_rank_per_gpu():
     """`python bench.py --gpus 2` with no launcher around it re-executes itself under torch.distributed.run (127.0.0.1
     rendezvous): both ranks come up with WORLD_SIZE 2.  --rank-probe makes every rank report and exit before it needs a GPU."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rank-probe"],
-                       env=env, capture_output=True, text=True, timeout=300)
+    for attempt in range(2):        # (the rendezvous port is picked free a moment before the launcher binds it: one retry)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rank-probe"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        if r.returncode == 0:
+            break
     assert r.returncode == 0, r.stderr[-2000:]
     probes = sorted(l.split()[1:] for l in r.stdout.splitlines() if l.startswith("RANKPROBE"))
     assert probes == [["0", "2", "0"], ["1", "2", "1"]], r.stdout
