@@ -377,9 +377,10 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       L.g_a0 = graw(nv); L.g_minv = graw(nv); L.g_qvel = graw(nv); L.g_smooth = graw(nv); L.g_qacc = graw(nv); L.g_meta = graw(8); L.g_qM = graw(m->nM);
       // dense row-space solver (dense_pgs.h): articulated models (M not diagonal) without noslip sweeps, at most 128 dofs; an
       // env takes it in the steps in which it has at most dense_cap rows.  MJH_DENSE=0 keeps the block solver everywhere.
-      static const bool dense_on = !(getenv("MJH_DENSE") && atoi(getenv("MJH_DENSE")) == 0);
+      const bool dense_on = !(getenv("MJH_DENSE") && atoi(getenv("MJH_DENSE")) == 0);
       M.dense = (dense_on && !diagM && M.noslip_iterations == 0 && nv <= 128 && nv >= 1) ? 1 : 0;
       M.dense_cap = std::min(256, ((std::max(M.maxefc, 1) + 63) / 64) * 64); M.dense_nvs = ((nv + 15) / 16) * 16;
+      if (const char* dc = getenv("MJH_DENSE_CAP")) M.dense_cap = std::max(64, std::min(M.dense_cap, (atoi(dc) / 64) * 64));   // (tests: envs beyond the capacity keep the block solver)
       L.g_dense = 0;
       if (M.dense) { long long o = goff; goff += (long long)M.dense_cap * M.dense_cap + 2LL * M.dense_cap * M.dense_nvs + 6LL * M.dense_cap; L.g_dense = (int)o; }
     }

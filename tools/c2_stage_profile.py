@@ -6,7 +6,9 @@ import mujoco_sim_amd as ms
 from mujoco_sim_amd import capi
 nenv = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 m = ms.scene("boxpile", 64); m.c.maxcon = 600; m.c.maxefc = 2400
-e = ms.Engine(m, nenv); e.reset(); e.step(200); e.synchronize()
+e = ms.Engine(m, nenv)
+e.load_tables(ms.boxes_randomize(m, 0, nenv, jitter=0.01))      # the D3-exact pile (random sizes / orientations), as bench.py --config c2
+e.step(200); e.synchronize()
 names = ["", "load state", "FK + geoms", "COM/cdof/CRBA", "factor", "collision", "row headers", "J rows + params", "B, schedule",
          "vel stage (RNE, aref)", "controller/inverse", "smooth acc", "warmstart + A_c + AR", "PGS sweeps", "checkAcc + integrate", "store"]
 out = np.zeros(16)
