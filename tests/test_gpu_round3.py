@@ -117,3 +117,107 @@ def test_quad_sweep_with_single_row_blocks_matches_the_oracle(lib):
             e.set_state(qpos=np.tile(d.f("qpos"), (nenv, 1)), qvel=np.tile(d.f("qvel"), (nenv, 1)), warmstart=np.tile(d.f("qacc_warmstart"), (nenv, 1)))
     assert saw_many, "the scene must reach the many-block regime"
     e.close()
+
+
+# ---------------------------------------------------------------- BASELINE size, compared with the oracle on sampled envs
+def _one_step_on_samples(e, make_oracle, sample, with_inverse=False):
+    """the engine holds its OWN settled state at full size; the sampled envs' state goes to the oracle, both step once, compare"""
+    _, q, v, w = e.get_state()
+    t = e.get_state()[0]
+    ds = []
+    for i in sample:
+        d = make_oracle(i)
+        d.f("qpos")[:] = q[i]; d.f("qvel")[:] = v[i]; d.f("qacc_warmstart")[:] = w[i]; d.f("qacc")[:] = w[i]; d.f("time")[0] = t[i]
+        ds.append(d)
+    e.step(1, with_inverse)
+    for d in ds:
+        d.step(1, int(with_inverse))
+    _, q1, v1, _ = e.get_state(); st = e.get_stats()
+    eq, ev, agree = [], [], []
+    for k, i in enumerate(sample):
+        d = ds[k]
+        agree.append(st[i, 0] == d.i("ncon") and st[i, 1] == d.i("nefc"))
+        eq.append(np.abs(q1[i] - d.f("qpos")).max() / max(1.0, np.abs(d.f("qpos")).max()))
+        ev.append(np.abs(v1[i] - d.f("qvel")).max() / max(1.0, np.abs(d.f("qvel")).max()))
+    return np.array(eq), np.array(ev), np.array(agree), ds
+
+
+def test_s24_at_4096_envs_one_step_parity_on_sampled_envs():
+    """BASELINE size: 4096 S24 envs settle 400 steps ON THE DEVICE (what bench.py times), then 64 envs spread over the batch are
+    handed to the oracle and both advance one step, five times over (state re-read from the device each time)"""
+    from helpers import oracle_s24
+    m = ms.scene("s24")
+    nenv = 4096
+    e = ms.Engine(m, nenv)
+    tab = e.load_s24()
+    e.step(400)
+    sample = list(range(0, nenv, 64))
+    worst_q = worst_v = 0.0; agreeing = total = 0
+    for rep in range(5):
+        eq, ev, ag, _ = _one_step_on_samples(e, lambda i: oracle_s24(m, tab, i), sample)
+        worst_q = max(worst_q, eq[ag].max()); worst_v = max(worst_v, ev[ag].max()); agreeing += int(ag.sum()); total += len(ag)
+        e.step(7)
+    print(f"S24 4096 envs, {total} sampled env-steps: contact sets agree {agreeing / total:.3f}, qpos {worst_q:.2e}, qvel {worst_v:.2e}")
+    assert agreeing / total >= 0.97 and worst_q <= 1e-6 and worst_v <= 2e-5
+    e.close()
+
+
+def test_c2_at_4096_envs_one_step_parity_on_sampled_envs():
+    from mujoco_sim_amd.engine import EP
+    m = ms.scene("boxpile", 64); m.c.maxcon = 600; m.c.maxefc = 2400
+    nenv = 4096
+    e = ms.Engine(m, nenv)
+    tab = e.load_tables(ms.boxes_randomize(m, 0, nenv, jitter=0.01))
+    e.step(200)
+
+    def make(i):
+        d = orc.OrcData(m.ptr)
+        for k, wh in EP.items():
+            d.set_env_param(wh, tab[k][i])
+        return d
+    sample = [5, 1300, 2700, 4090]
+    worst_q = worst_v = 0.0; agreeing = total = 0
+    for rep in range(3):
+        eq, ev, ag, ds = _one_step_on_samples(e, make, sample)
+        if ag.any():
+            worst_q = max(worst_q, eq[ag].max()); worst_v = max(worst_v, ev[ag].max())
+        agreeing += int(ag.sum()); total += len(ag)
+        e.step(5)
+    print(f"C2 4096 envs, {total} sampled env-steps at ~{ds[0].i('ncon')} contacts: contact sets agree {agreeing / total:.3f}, qpos {worst_q:.2e}, qvel {worst_v:.2e}")
+    assert agreeing >= total - 2 and worst_q <= 1e-6 and worst_v <= 1e-5
+    e.close()
+
+
+def test_c4_at_2048_envs_one_step_parity_on_sampled_envs():
+    """PR2 + world + (empty) object pool at BASELINE size, mj_inverse every step, commands as the fixtures use them: the dense
+    solver's path under the oracle at full size"""
+    from test_robot_fixtures import robot_command
+    m, z = _robot("c4_pr2_world_objects_mesh")
+    nenv = 2048
+    e = ms.Engine(m, nenv)
+    assert e.dense_solver() == 1
+    e.set_controlled_dofs(z["controlled"].astype(np.int32))
+    lib = m.lib
+    names = [lib.mjh_id2name(m.ptr, 0, b).decode() for b in range(m.c.nbody)]
+    slots = [b for b, n in enumerate(names) if n.startswith("object_")]
+    for b in slots:
+        e.set_slot_active(b, False)
+    sbase = m.c.nbody - 32 if m.c.nbody > 32 else 0
+    mask = 0
+    for b in slots:
+        mask |= 1 << (b - sbase)
+    rng = np.random.default_rng(4)
+    for k in range(1, 121):
+        if k % 10 == 1:
+            e.set_cmd(ddq=np.tile(robot_command(m, k), (nenv, 1)) * rng.uniform(0.5, 1.5, size=(nenv, 1)))
+        e.step(1, True)
+
+    def make(i):
+        d = orc.OrcData(m.ptr); d.ifield("controlled")[:] = z["controlled"]
+        orc.lib().orc_set_slot_mask(d.d, mask)
+        return d
+    sample = [0, 700, 1400, 2047]
+    eq, ev, ag, ds = _one_step_on_samples(e, make, sample, with_inverse=True)
+    print(f"C4 2048 envs, sampled: nefc {[d.i('nefc') for d in ds]}, contact sets agree {ag}, qpos {eq}, qvel {ev}")
+    assert ag.sum() >= 3 and eq[ag].max() <= 2e-6 and ev[ag].max() <= 1e-4
+    e.close()
