@@ -19,7 +19,12 @@ DEV float normalize3(float* a) {
   return n;
 }
 DEV void normalize4(float* q) {
-  float n = sqrtf(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
+  const float n2 = q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3];
+  // a quaternion within a few ulp of unit length is left alone (as mju_normalize4 leaves |n - 1| < mjMINVAL alone): re-scaling it
+  // flips it between two neighbouring representations, so that the state a launch stores would depend on HOW MANY launches have
+  // normalised it (split API: step1 | inverse | step2, each launch runs mj_kinematics) — with this the operation is idempotent
+  if (fabsf(n2 - 1.0f) <= 4.8e-7f) return;
+  const float n = sqrtf(n2);
   if (n < MJ_MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; } else { float s = 1.0f / n; q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s; }
 }
 DEV void mulquat(float* r, const float* a, const float* b) {

@@ -77,6 +77,7 @@ struct mjh_engine {
   bool timing = false; int timing_stride = 1; long timing_count = 0;   // every timing_stride-th step launch is bracketed
   std::vector<std::pair<hipEvent_t, hipEvent_t>> tev; size_t tev_used = 0;
   bool step1_done = false;
+  bool step1_pending = false;   // mjh_step1 has been called, its launch is deferred to the next entry point (fused with mjh_inverse if that is the one)
   // in-engine joint-space PD effort controller (mjh_set_pd_controller): ddq written on the device in front of every step
   float pd_kp = 0, pd_kd = 0; float* pd_target = nullptr; bool pd_on = false;
 };
@@ -545,8 +546,10 @@ extern "C" void mjh_destroy(mjh_engine* e) {
 
 // (every entry point re-selects the engine's device: one process may hold engines on several GPUs, and the caller's
 // current device is whatever its framework left it at)
+static int flush_step1(mjh_engine* e);
 #define ENG_NOJOIN(e) if (!(e)) { mjh_set_error("null engine"); return MJH_ERR_ARG; } \
-                      if (hipSetDevice((e)->device) != hipSuccess) { mjh_set_error("hipSetDevice failed"); return MJH_ERR_NO_DEVICE; }
+                      if (hipSetDevice((e)->device) != hipSuccess) { mjh_set_error("hipSetDevice failed"); return MJH_ERR_NO_DEVICE; } \
+                      if ((e)->step1_pending) { int rcf_ = flush_step1(e); if (rcf_) return rcf_; }
 // every entry point except mjh_step first joins the cohort streams back into the caller's stream
 #define ENG(e) ENG_NOJOIN(e) { int rcj_ = join_cohorts(e); if (rcj_) return rcj_; }
 #define RANGE(e, env0, n) if ((env0) < 0 || (n) < 0 || (env0) + (n) > (e)->nenv) { mjh_set_error("env range out of bounds"); return MJH_ERR_ARG; }
@@ -566,12 +569,32 @@ static int launch_lpt(mjh_engine* e, int ph, int xflags, bool resort) {
   return launch(e, 0, e->nenv, 1, ph, xflags);
 }
 static int launch_pd(mjh_engine* e, hipStream_t st, int env0, int n);
+// mjh_step1 defers its launch to the next entry point: the reference's loop calls MjHWInterface::read() = mj_inverse right behind
+// mj_step1 (mj_main.cpp:83-94), and step1 + inverse as ONE launch share the position and velocity stages (the literal loop's three
+// launches per step become two).  Any other entry point first issues the plain step1 launch (ENG / ENG_NOJOIN), so the order of
+// effects on the stream is the order of the calls.
+static int flush_step1(mjh_engine* e) {
+  e->step1_pending = false;
+  int rc = join_cohorts(e);
+  return rc ? rc : launch_lpt(e, PH_STEP1, XF_FORCE, true);
+}
 extern "C" int mjh_step1(mjh_engine* e) {
   ENG(e); e->step1_done = true;
   if (e->pd_on) { int rc = launch_pd(e, e->stream, 0, e->nenv); if (rc) return rc; }
-  return launch_lpt(e, PH_STEP1, XF_FORCE, true);
+  const bool lazy = !(getenv("MJH_LAZY_STEP1") && atoi(getenv("MJH_LAZY_STEP1")) == 0);
+  if (!lazy) return launch_lpt(e, PH_STEP1, XF_FORCE, true);
+  e->step1_pending = true;
+  return MJH_OK;
 }
-extern "C" int mjh_inverse(mjh_engine* e) { ENG(e); return launch_lpt(e, PH_INV, XF_FORCE, false); }
+extern "C" int mjh_inverse(mjh_engine* e) {
+  if (e && e->step1_pending) {      // step1 + inverse in one launch
+    if (hipSetDevice(e->device) != hipSuccess) { mjh_set_error("hipSetDevice failed"); return MJH_ERR_NO_DEVICE; }
+    e->step1_pending = false;
+    int rc = join_cohorts(e);
+    return rc ? rc : launch_lpt(e, PH_STEP1 | PH_INV, XF_FORCE, true);
+  }
+  ENG(e); return launch_lpt(e, PH_INV, XF_FORCE, false);
+}
 extern "C" int mjh_step2(mjh_engine* e) {
   ENG(e);
   if (!e->step1_done) { mjh_set_error("mjh_step2 called before mjh_step1"); return MJH_ERR_STATE; }
