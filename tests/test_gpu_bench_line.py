@@ -1,0 +1,59 @@
+"""The driver's contract, end to end on the GPU box: `python bench.py` prints ONE JSON line whose metric is BASELINE.json's, with the
+roofline and cpu_baseline objects, the literal loop and the other configs riding along; the one-process group host runs without a
+launcher.  (Short windows: this checks the shape and sanity of the line, not the numbers.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout"
+    assert r.stdout.strip().splitlines()[-1] == lines[0], "the JSON line is the LAST line of stdout"
+    return json.loads(lines[0])
+
+
+def test_driver_line_has_everything_the_contract_names():
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    r = _run(["--steps", "12", "--warmup", "3", "--cpu-seconds", "4", "--extra-steps", "6"])
+    assert r["metric"] == base["metric"] and r["unit"] == "env-steps/s" and r["n_gpus"] == 1 and r["steps"] == 12 and r["warmup"] == 3
+    assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "f32" and r["data"] == "synthetic"
+    assert r["value"] > 1e6 and abs(r["value"] - 4096 * 12 / (r["ms_per_step"] * 12e-3)) < 1e-3 * r["value"]
+    c = r["config"]
+    assert c["name"] == "s24" and c["envs_per_gpu"] == 4096 and c["settle_steps"] == 400 and 8 <= c["mean_ncon"] <= 48 and c["overflow_envs"] == 0
+    assert "unsettled" not in r
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and rf["algorithmic_bytes_per_env_step"] == 800
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["kernel_ms"] > 0 and rf["launches_timed"] > 0
+    assert abs(rf["achieved"] - 800 * rf["envs_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
+    assert rf["traffic"] is None or rf["traffic"] > 800 * rf["envs_per_launch"]
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == cb["scaling"][-1]["threads"] == cb["host"]["usable"] and cb["scaling"][0]["threads"] == 1
+    assert cb["env_steps_1thread"] >= 256 and cb["value"] > 0 and abs(cb["mean_ncon"] - cb["gpu_mean_ncon_same_envs"]) < 4
+    ll = r["literal_loop"]
+    assert ll["value"] > 1e5 and ll["fused_step_with_per_step_read_write"]["value"] >= ll["value"] * 0.8
+    assert set(r["configs"]) == {"s24d", "c2", "c3", "c4", "c5"}
+    for name, line in r["configs"].items():
+        assert "error" not in line, (name, line)
+        assert line["value"] > 0 and line["steps"] == 6 and line["roofline_frac"] > 0 and line["overflow_envs"] <= 0.02 * line["envs"], (name, line)
+    assert r["configs"]["s24d"]["mean_ncon"] >= 20 and r["configs"]["c2"]["mean_ncon"] >= 100 and r["configs"]["c4"]["mean_nefc"] >= 50
+
+
+def test_group_host_runs_in_one_process_without_a_launcher():
+    r = _run(["--gpus", "2", "--host", "group", "--group-devices", "0,0", "--envs-per-gpu", "1024", "--steps", "12", "--warmup", "3"])
+    h = r["host"]
+    assert r["n_gpus"] == 2 and h["kind"] == "group" and [x["nenv"] for x in h["ranks"]] == [1024, 1024] and h["ranks"][1]["env0"] == 1024
+    assert h["rccl"] is False and "peer copies" in h["transport"] and h["all_gather"]["count"] >= 3 and h["all_gather"]["ms_mean"] > 0
+    assert r["value"] > 1e6 and r["config"]["envs_total"] == 2048
+    r1 = _run(["--gpus", "1", "--host", "group", "--group-devices", "0", "--envs-per-gpu", "1024", "--steps", "12", "--warmup", "3"])
+    assert r1["host"]["rccl"] is True and r1["host"]["rccl_ranks"] == 1, "one device: the publish goes through ncclAllGather (the 8-GPU code path)"
