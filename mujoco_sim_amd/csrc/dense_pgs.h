@@ -13,9 +13,9 @@
 //                            AR' = -AR_pq / AR_qq (column-scaled, diagonal -1) row by row in Gauss-Seidel VISITING order, plus the
 //                            per-row start values  t_q = -res_q / AR_qq,  f, lo, hi, AR_qq.
 //   mjh_dense_solve_kernel   one wave per environment, lane q owns rows q, q + 64, ...:   per visited row p
-//                               delta = med3(f_p + t_p, lo_p, hi_p) - f_p ;  f_p += delta ;  t_q += AR'_pq delta  for every q
+//                               delta = med3(s_p, lo_p, hi_p) - f_p ;  f_p += delta ;  s_q += AR'_pq delta  for every q != p   (s = f + t)
 //                            = projected Gauss-Seidel on the dual exactly as mj_solPGS iterates it (same rows, same order as the
-//                            block solver and the oracle), ~12 instructions per ROW; then qacc = a0 + B^T (f - f0).
+//                            block solver and the oracle), ~9 instructions per ROW; then qacc = a0 + B^T (f - f0).
 //
 // Environments whose row count exceeds the dense capacity keep the block solver (meta[7] says which one ran).
 #pragma once
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(DN_BUILD_THREADS) void mjh_dense_build_kernel(const
       const int p = 16 * P + 4 * lk + v;
       float out[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) out[j] = (p == ql + 64 * j && p < nefc) ? -1.0f : -acc[j][v] * iq[j];
+      for (int j = 0; j < 4; j++) out[j] = (p == ql + 64 * j) ? 0.0f : -acc[j][v] * iq[j];     // (no self-coupling: the sweep carries s = f + t, which a row's own update leaves unchanged)
       float* dst = g_art + p * W + ql * K;
       if (K == 1) dst[0] = out[0];
       else if (K == 2) *(float2*)dst = make_float2(out[0], out[1]);
@@ -204,11 +204,18 @@ template <int K> DEV DnCol<K> dn_load(const __amdgpu_buffer_rsrc_t rs, const uns
 }
 
 // Gauss-Seidel sweeps over the rows p = 0 .. nr32 - 1 (visiting order; nr32 a multiple of 32, rows beyond nefc inert).  Lane q owns
-// rows 64 k + q.  The columns AR'_p. (64 K floats per row, a lane's K values contiguous) are fetched a 16-row group ahead into two
-// register buffers; the group count is even, so the buffer parity is static over the wrap of a sweep.  Returns the sweep count.
+// rows 64 k + q and carries  s_q = f_q + t_q  (t_q = -res_q / AR_qq):  the update of row p is  f_p <- med3(s_p, lo_p, hi_p)  and
+// s_q += AR'_pq delta for q != p — a row's own update leaves its s unchanged (its t moves by -delta, its f by +delta), so the stored
+// diagonal is 0 and the row costs: med3, sub, readlane, two selects, K multiply-adds (+ its share of the column fetch).  The second
+// select keeps s_p as it was at the row's visit: with it the decrease of the dual cost, -delta (res + AR_pp delta / 2), is summed per
+// row exactly as mj_solPGS (and the block solver, and the oracle) sum it, once per 64-row set.  (Evaluating the sweep's decrease from
+// its end points, 1/2 (f1 - f0) . (res1 + res0), saves that select but ends a sweep later on average — C4: 15.9 against 14.8
+// sweeps — because the rounding noise of t enters with either sign.)
+// The columns AR'_p. (64 K floats per row, a lane's K values contiguous) are fetched a 16-row group ahead into two register buffers;
+// the group count is even, so the buffer parity is static over the wrap of a sweep.  Returns the sweep count.
 template <int K>
 DEV int dn_sweeps(const __amdgpu_buffer_rsrc_t rs, const int art_bytes, const int nr32, const int itmax, const float tol, const float scale,
-                  float* f, float* t, const float* lo, const float* hi, const float* arr, const int lane) {
+                  float* f, float* s, const float* lo, const float* hi, const float* arr, const int lane) {
   const int G = nr32 >> 4;
   const unsigned voff = (unsigned)lane * (unsigned)(4 * K);
   constexpr int ROWB = 64 * K * 4;                       // bytes per row of AR'
@@ -217,13 +224,14 @@ DEV int dn_sweeps(const __amdgpu_buffer_rsrc_t rs, const int art_bytes, const in
   for (int r = 0; r < 16; r++) buf[0][r] = dn_load<K>(rs, voff, art_bytes + r * ROWB);
   int niter = 0;
   for (;;) {
-    float imp = 0;
+    float f0[K], sv[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { f0[k] = f[k]; sv[k] = s[k]; }      // sv: s of the lane's row at ITS visit (rows never visited: dc = 0)
     // (opaque per sweep: otherwise the 64 lane masks and the row offsets are hoisted out of the sweep loop as loop invariants and
     //  spilled — v_writelane / v_readlane around every use)
     unsigned long long m1 = 1ull; asm volatile("" : "+s"(m1));
 #pragma unroll
     for (int k = 0; k < K; k++) {
-      const float fprev = f[k]; float tc = 0;
 #pragma unroll
       for (int gg = 0; gg < 4; gg++) {
         const int g = 4 * k + gg;
@@ -236,22 +244,23 @@ DEV int dn_sweeps(const __amdgpu_buffer_rsrc_t rs, const int art_bytes, const in
 #pragma unroll
           for (int r = 0; r < 16; r++) {
             const int l = 16 * gg + r;
-            const float fn = __builtin_amdgcn_fmed3f(f[k] + t[k], lo[k], hi[k]);
+            const float fn = __builtin_amdgcn_fmed3f(s[k], lo[k], hi[k]);
             const float d = fn - f[k];
             const float sd = readlane_f(d, l);
             const bool me = __builtin_amdgcn_inverse_ballot_w64(mask);     // lane l: v_cndmask on a scalar mask, no compare
             mask <<= 1;
-            tc = me ? t[k] : tc;
             f[k] = me ? fn : f[k];
+            sv[k] = me ? s[k] : sv[k];
 #pragma unroll
-            for (int j = 0; j < K; j++) t[j] = __builtin_fmaf(buf[gg & 1][r].v[j], sd, t[j]);
+            for (int j = 0; j < K; j++) s[j] = __builtin_fmaf(buf[gg & 1][r].v[j], sd, s[j]);
           }
         }
       }
-      const float dc = f[k] - fprev;
-      imp += dc * arr[k] * (tc - 0.5f * dc);             // -delta (res + AR delta / 2) with res = -t AR at the row's visit
     }
     niter++;
+    float imp = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) { const float dc = f[k] - f0[k]; imp += dc * arr[k] * ((sv[k] - f0[k]) - 0.5f * dc); }   // -delta (res + AR delta / 2), res = -t AR, t = s - f at the row's visit
     const float improvement = wave_sum<4>(imp);
     if (improvement * scale < tol || niter >= itmax) break;
   }
@@ -268,6 +277,8 @@ DEV void dn_solve_env(const DModel& M, const Lay& L, float* gs, const __amdgpu_b
     f[k] = gs[o.rf + ix]; f0[k] = f[k]; t[k] = gs[o.rt + ix]; lo[k] = gs[o.rlo + ix]; hi[k] = gs[o.rhi + ix]; arr[k] = gs[o.rarr + ix];
   }
   const float scale = 1.0f / (M.meaninertia * (float)(M.nv > 1 ? M.nv : 1));
+#pragma unroll
+  for (int k = 0; k < K; k++) t[k] += f[k];                  // s = f + t
   const int niter = dn_sweeps<K>(rs, 4 * o.art, nr32, M.iterations, M.tolerance, scale, f, t, lo, hi, arr, lane);
   // forces back into the block records (the integrate launch forms qfrc_constraint from them), force changes to LDS
   const int* rmap = (const int*)(gs + o.rmap);
