@@ -500,9 +500,17 @@ def short_config_line(ms, args, name, device, stream):
 
         run(w.settle_steps); run(5); eng.synchronize()
         steps = args.extra_steps
-        eng.set_launch_timing(1)
-        t0 = time.perf_counter(); run(steps); eng.synchronize(); el = time.perf_counter() - t0
-        kms, nt = eng.get_launch_timing(); eng.set_launch_timing(False)
+
+        def window(n):
+            eng.set_launch_timing(1)
+            t0 = time.perf_counter(); run(n); eng.synchronize(); el_ = time.perf_counter() - t0
+            k_, n_ = eng.get_launch_timing(); eng.set_launch_timing(False)
+            return el_, k_, n_
+
+        el, kms, nt = window(steps)
+        if el < 0.03:      # a window of a few milliseconds (C3, C5: 0.1 ms per step) is at the mercy of one host hiccup: time >= 30 ms instead
+            steps = int(min(600, max(steps, steps * 0.04 / max(el, 1e-4))))
+            el, kms, nt = window(steps)
         st = eng.get_stats()
         cohorts = eng.cohorts
         G = cohorts if (cohorts > 1 and w.rows >= 64 * cohorts) else 1

@@ -17,7 +17,14 @@
 //                            = projected Gauss-Seidel on the dual exactly as mj_solPGS iterates it (same rows, same order as the
 //                            block solver and the oracle), ~9 instructions per ROW; then qacc = a0 + B^T (f - f0).
 //
-// Environments whose row count exceeds the dense capacity keep the block solver (meta[7] says which one ran).
+// Environments whose row count exceeds the dense capacity keep the block solver (meta[7] says which one ran).  The dense form pays
+// ~0.1 ms of build latency per env and wins ~3x per sweep, so it pays when some env of the launch sweeps long — such an env sets
+// the length of the solve launch (C4: 1.03 M env-steps/s against 0.75 M) — and loses on robots that converge in a dozen sweeps
+// (PR2 on the floor, all envs alike: 1.53 M with it, 1.87 M without).  The HOST therefore decides per cohort (engine.hip: mjh_step):
+// whenever mjh_order_kernel rebuilds a cohort's launch order it also leaves "an env of this cohort swept >= M.dense_min_iter (32)
+// times" in host-mapped memory; the host adopts the word of two rebuilds ago (after that kernel's event: no stall, and the choice
+// depends on the step count only, so runs stay reproducible), queues the build and dense-solve launches only then, and tells the
+// assemble launch (XF_DENSE).  Engines without a launch order (< 1024 envs) always take the dense form.
 #pragma once
 #include "step_kernel.h"
 

@@ -47,6 +47,7 @@ struct DModel {
   int patch, pool, pool_floats, pdesc, pslot;
   // dense row-space solver of the many-body layout (dense_pgs.h): on / off, row capacity (a multiple of 64, <= 256), nv padded to 16
   int dense, dense_cap, dense_nvs;
+  int dense_min_iter;   // a cohort takes the dense form while one of its envs swept at least this often in the step its launch order was built from (the host decides per launch)
 };
 
 // per-env state in HBM (fp32, env-major rows)
@@ -109,7 +110,8 @@ enum { PH_STEP1 = 1, PH_INV = 2, PH_STEP2 = 4, PH_NOINT = 8, PH_FKONLY = 16, PH_
        PH_PRE = 128, PH_POST = 256 };
 // export flags
 enum { XF_BODY = 1, XF_GEOM = 2, XF_CON = 4, XF_FORCE = 8, XF_PROF = 16,
-       XF_NOSTORE = 32 };   // read-only launch: nothing of the env's state, statistics or time is written back
+       XF_NOSTORE = 32,     // read-only launch: nothing of the env's state, statistics or time is written back
+       XF_DENSE = 64 };     // assemble launch of a cohort whose solve runs the dense row-space solver (dense_pgs.h): no per-block solver matrices
 
 #define CON_STRIDE 16  // dist, pos3, frame9, [13] geom1 | geom2 << 12 | dim << 24, [14] includemargin, [15] pad
 #define CON_GEOMS 13

@@ -55,6 +55,10 @@ struct mjh_engine {
   Lay L{};
   int lds_bytes = 0;
   size_t dense_lds = 0;   // dynamic LDS of mjh_dense_build_kernel
+  // dense solver on / off per cohort: mjh_order_kernel leaves "an env of the cohort swept long" in a host-mapped word (four slots per
+  // cohort, one per rebuild of the launch order); the host adopts the word of TWO rebuilds ago after waiting for that kernel's event
+  // (long finished: no stall, and the decision depends on the step count only, not on timing: runs stay reproducible)
+  int* h_dense = nullptr; int* d_dense = nullptr; hipEvent_t ev_dense[MJH_MAX_COHORTS][4] = {}; unsigned dense_epoch[MJH_MAX_COHORTS] = {}; bool dense_now[MJH_MAX_COHORTS];
   int* dI = nullptr; float* dF = nullptr; DConst* dC = nullptr;
   std::vector<int> hI;  // host copy of the int tables (controlled / odom are patched in place)
   int o_controlled = 0, o_odom = 0;
@@ -382,6 +386,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       M.dense = (dense_on && !diagM && M.noslip_iterations == 0 && nv <= 128 && nv >= 1) ? 1 : 0;
       M.dense_cap = std::min(256, ((std::max(M.maxefc, 1) + 63) / 64) * 64); M.dense_nvs = ((nv + 15) / 16) * 16;
       if (const char* dc = getenv("MJH_DENSE_CAP")) M.dense_cap = std::max(64, std::min(M.dense_cap, (atoi(dc) / 64) * 64));   // (tests: envs beyond the capacity keep the block solver)
+      M.dense_min_iter = getenv("MJH_DENSE_MIN_ITER") ? std::max(0, atoi(getenv("MJH_DENSE_MIN_ITER"))) : 32;
       L.g_dense = 0;
       if (M.dense) { long long o = goff; goff += (long long)M.dense_cap * M.dense_cap + 2LL * M.dense_cap * M.dense_nvs + 6LL * M.dense_cap; L.g_dense = (int)o; }
     }
@@ -494,6 +499,14 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   rc |= dev_alloc(e, &S.qfrc_inverse, nv_all);
   S.gscratch = nullptr; S.gstride = hp.gstride;
   if (M.big) rc |= dev_alloc(e, &S.gscratch, (size_t)nenv * (size_t)hp.gstride, false);   // many-body models: contact / block / Jacobian pools
+  if (M.big && M.dense && e->lpt && nenv >= 1024) {
+    // one word per cohort in host-mapped memory: "a env of the cohort swept long when its launch order was last rebuilt" (mjh_order_kernel)
+    HIPCHK(hipHostMalloc((void**)&e->h_dense, MJH_MAX_COHORTS * 4 * sizeof(int), hipHostMallocMapped));
+    for (int g = 0; g < MJH_MAX_COHORTS * 4; g++) e->h_dense[g] = 1;
+    for (int g = 0; g < MJH_MAX_COHORTS; g++) e->dense_now[g] = true;
+    HIPCHK(hipHostGetDevicePointer((void**)&e->d_dense, e->h_dense, 0));
+    for (int g = 0; g < MJH_MAX_COHORTS; g++) for (int k = 0; k < 4; k++) HIPCHK(hipEventCreateWithFlags(&e->ev_dense[g][k], hipEventDisableTiming));
+  }
   rc |= dev_alloc(e, &S.time, (size_t)nenv); rc |= dev_alloc(e, &S.odom_vel, (size_t)nenv * 6); rc |= dev_alloc(e, &S.stats, (size_t)nenv * 4);
   rc |= dev_alloc(e, &S.x_bias, nv_all); rc |= dev_alloc(e, &S.x_passive, nv_all); rc |= dev_alloc(e, &S.x_smooth, nv_all);
   rc |= dev_alloc(e, &S.x_constraint, nv_all); rc |= dev_alloc(e, &S.x_energy, (size_t)nenv * 2);
@@ -541,6 +554,8 @@ extern "C" void mjh_destroy(mjh_engine* e) {
   for (auto& p : e->tev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->scratch) (void)hipFree(e->scratch);
+  if (e->h_dense) (void)hipHostFree(e->h_dense);
+  for (int g = 0; g < MJH_MAX_COHORTS; g++) for (int k = 0; k < 4; k++) if (e->ev_dense[g][k]) (void)hipEventDestroy(e->ev_dense[g][k]);
   delete e;
 }
 
@@ -560,7 +575,7 @@ static int launch_lpt(mjh_engine* e, int ph, int xflags, bool resort) {
   if (e->lpt && e->nenv >= 1024) {
     if (!e->d_order) { int rc = dev_alloc(e, &e->d_order, (size_t)e->nenv); if (rc) return rc; e->order_valid = false; }
     if (resort || !e->order_valid) {
-      hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, e->stream, (const int*)e->S.stats, e->d_order, 0, e->nenv);
+      hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, e->stream, (const int*)e->S.stats, e->d_order, 0, e->nenv, (int*)nullptr, 0);
       e->order_valid = true; e->order_G = -1;   // (a full-range sort: mjh_step's cohorts must sort their own ranges again)
     }
   }
@@ -629,8 +644,16 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
       // renewed every MJH_ORDER_EVERY-th step only: its 10 us sit in front of every step launch of the cohort's stream, which
       // is 9 % of a step of the small configs (C3, C5: 0.10 ms kernels)
       static const int order_every = getenv("MJH_ORDER_EVERY") ? std::max(1, atoi(getenv("MJH_ORDER_EVERY"))) : MJH_ORDER_EVERY;
-      if (e->S.env_order && (e->order_G != G || e->order_age % order_every == 0))
-        hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, st, (const int*)e->S.stats, e->d_order, g0, g1 - g0);
+      if (e->S.env_order && (e->order_G != G || e->order_age % order_every == 0)) {
+        const bool dsel = e->M.big && e->split3 && e->M.dense && e->d_dense;
+        const unsigned ep = e->dense_epoch[g];
+        hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, st, (const int*)e->S.stats, e->d_order, g0, g1 - g0, dsel ? e->d_dense + 4 * g + (ep & 3) : (int*)nullptr, e->M.dense_min_iter);
+        if (dsel) {
+          HIPCHK(hipEventRecord(e->ev_dense[g][ep & 3], st));
+          if (ep >= 2) { HIPCHK(hipEventSynchronize(e->ev_dense[g][(ep - 2) & 3])); e->dense_now[g] = *(volatile int*)(e->h_dense + 4 * g + ((ep - 2) & 3)) != 0; }
+          e->dense_epoch[g] = ep + 1;
+        }
+      }
       hipEvent_t ta = nullptr, tb = nullptr;
       if (e->timing && (e->timing_count++ % e->timing_stride) == 0) {
         if (e->tev_used == e->tev.size()) { hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); e->tev.push_back({a, b}); }
@@ -640,8 +663,11 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
       if (e->M.big && e->split3) {
         // many-body layout: assemble -> solve (3 KB of LDS per env instead of ~70 KB: many more resident envs during the
         // sweeps, which are > 90 % of such a step) -> integrate
-        rc = launch_on(e, st, g0, g1 - g0, 1, ph | PH_PRE, 0);
-        if (!rc && e->M.dense) {
+        // dense row-space solver for this cohort's step?  (the word mjh_order_kernel left two rebuilds of the launch order ago; the
+        // assemble launch is TOLD the decision, nothing on the device reads the word)
+        const bool dn = e->M.dense && (!e->h_dense || e->dense_now[g]);
+        rc = launch_on(e, st, g0, g1 - g0, 1, ph | PH_PRE, dn ? XF_DENSE : 0);
+        if (!rc && dn) {
           // dense row-space solver (dense_pgs.h): AR = J M^-1 J^T on the matrix cores, then column sweeps, for every env of the
           // launch whose row count fits; the block solver below skips those envs (meta[7])
           hipLaunchKernelGGL(mjh_dense_build_kernel, dim3(g1 - g0), dim3(DN_BUILD_THREADS), e->dense_lds, st, e->dC, e->S, g0);
@@ -1299,7 +1325,7 @@ extern "C" int mjh_debug_stage_raw(mjh_engine* e, int with_inverse, long long* o
     StateGuard guard(&e->S);
     e->S.x_prof = buf;
     if (e->lpt && e->d_order) {
-      hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, e->stream, (const int*)e->S.stats, e->d_order, 0, e->nenv);
+      hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, e->stream, (const int*)e->S.stats, e->d_order, 0, e->nenv, (int*)nullptr, 0);
       e->S.env_order = e->d_order; e->order_valid = true; e->order_G = -1;
     }
     rc = launch(e, 0, e->nenv, 1, PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0), XF_PROF);

@@ -2074,7 +2074,7 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
         if (!patched) {
         // (an env that the dense solver takes — dense_pgs.h: it forms the full AR on the matrix cores — needs neither the blocks'
         //  own A_c nor their row-space matrices, only the projection intervals)
-        const bool dense_env = pre && M.dense && nefc <= M.dense_cap;
+        const bool dense_env = pre && (xflags & XF_DENSE) && nefc <= M.dense_cap;   // (the host launches mjh_dense_build_kernel behind this launch: same rule there)
         // ---- A_c = J_base M^-1 J_base^T, upper triangle (lanes = (block, base jb): row jb).  Built here, after the last user
         //      of the contact records and the velocity-stage spatial vectors: s_blkq reuses their space.
         if (!dense_env)
@@ -2636,8 +2636,18 @@ __global__ void mjh_export_kernel(const DState S, float* out, int env0, int nenv
 
 // Longest-processing-time-first order of the environments for the next launch: counting sort (descending) of the
 // previous step's cost estimate (solver sweeps x constraint rows) in one 1024-thread workgroup.
-__global__ __launch_bounds__(1024) void mjh_order_kernel(const int* __restrict__ stats, int* __restrict__ order, int env0, int nenv) {
+__global__ __launch_bounds__(1024) void mjh_order_kernel(const int* __restrict__ stats, int* __restrict__ order, int env0, int nenv, int* __restrict__ dense_sel, int dense_min_iter) {
   stats += 4 * (size_t)env0; order += env0;   // this cohort's slice; order[] holds absolute env ids
+  if (dense_sel) {   // dense row-space solver (dense_pgs.h) for this cohort's next steps iff one of its envs swept long in the last one:
+    __shared__ int mx;   // one word in host-mapped memory; the host reads it, unsynchronised, when it queues the cohort's next steps
+    if (threadIdx.x == 0) mx = 0;
+    __syncthreads();
+    int m = 0;
+    for (int e = threadIdx.x; e < nenv; e += 1024) m = max(m, stats[4*e + 2]);
+    atomicMax(&mx, m);
+    __syncthreads();
+    if (threadIdx.x == 0) *dense_sel = mx >= dense_min_iter ? 1 : 0;
+  }
   __shared__ int hist[256], base[256];
   const int t = threadIdx.x;
   if (t < 256) hist[t] = 0;
@@ -2655,7 +2665,7 @@ __global__ __launch_bounds__(1024) void mjh_order_kernel(const int* __restrict__
 // (pools + hand-over vectors), its LDS footprint is two dof vectors, so many environments are resident per CU while the
 // fused kernel holds ~70 KB per env for the stages around the sweeps.
 template <bool DIAGM, bool EXTRA>
-__global__ __launch_bounds__(256) void mjh_solve_kernel(const DConst* __restrict__ C, const DState S, int env0) {
+DEV void mjh_solve_body(const DConst* __restrict__ C, const DState& S, int env0) {
   const DModel& M = C->M;
   const Lay& L = C->L;
   extern __shared__ float lds[];
@@ -2707,3 +2717,5 @@ __global__ __launch_bounds__(256) void mjh_solve_kernel(const DConst* __restrict
   for (int d = tid; d < nv; d += nthr) gs[L.g_qacc + d] = s_qacc[d];
   if (tid == 0) meta[5] = niter;
 }
+template <bool DIAGM, bool EXTRA>
+__global__ __launch_bounds__(256) void mjh_solve_kernel(const DConst* __restrict__ C, const DState S, int env0) { mjh_solve_body<DIAGM, EXTRA>(C, S, env0); }

@@ -45,7 +45,7 @@ def test_driver_line_has_everything_the_contract_names():
     assert set(r["configs"]) == {"s24d", "c2", "c3", "c4", "c5"}
     for name, line in r["configs"].items():
         assert "error" not in line, (name, line)
-        assert line["value"] > 0 and line["steps"] == 6 and line["roofline_frac"] > 0 and line["overflow_envs"] <= 0.02 * line["envs"], (name, line)
+        assert line["value"] > 0 and line["steps"] >= 6 and line["roofline_frac"] > 0 and line["overflow_envs"] <= 0.02 * line["envs"], (name, line)
     assert r["configs"]["s24d"]["mean_ncon"] >= 20 and r["configs"]["c2"]["mean_ncon"] >= 100 and r["configs"]["c4"]["mean_nefc"] >= 50
 
 

@@ -37,11 +37,11 @@ if con:
         lines.append(f"| `{r[0][:110]}` | {r[1]} | {r[2]:.1f} | {r[3]:.2f} | {r[4]:.3f} |")
         csv.append(",".join(['"%s"' % r[0]] + [str(x) for x in r[1:]]))
     open(os.path.join(dst, f"{tag}_{cfg}_kernel_stats.csv"), "w").write("\n".join(csv) + "\n")
-    rows = con.execute("select k.name, k.start, k.end, k.vgpr_count, k.sgpr_count, k.lds_size, k.scratch_size from kernels k where k.name like '%mjh_step_kernel%' or k.name like '%mjh_solve_kernel%' or k.name like '%mjh_dense_%' order by k.start").fetchall()
+    rows = con.execute("select k.name, k.start, k.end, k.vgpr_count, k.sgpr_count, k.lds_size, k.scratch_size from kernels k where k.name like '%mjh_step_kernel%' or k.name like '%mjh_solve_kernel%' or k.name like '%mjh_dense_%' or k.name like '%mjh_solve_mixed%' order by k.start").fetchall()
     if rows:
         per = 3 if any("mjh_solve_kernel" in r[0] for r in rows) else 1
         if any("mjh_dense_" in r[0] for r in rows):
-            per = 5        # assemble -> dense build -> dense solve -> block solve (envs beyond the dense capacity) -> integrate
+            per = 5        # assemble -> dense build -> dense solve -> block solve (cohorts without a long-sweeping env, envs beyond the capacity) -> integrate
         last = rows[-timed * per:]
         tot = sum(e - s for _, s, e, *_ in last) / 1e3
         per_step_us = tot / max(timed, 1)
@@ -59,7 +59,7 @@ for sub, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     if not con:
         continue
     acc = 0.0; cnt = 0
-    rows = con.execute("select kernel_name, value from counters_collection where (kernel_name like '%mjh_step_kernel%' or kernel_name like '%mjh_solve_kernel%' or kernel_name like '%mjh_dense_%') and counter_name=? order by start", (name,)).fetchall()
+    rows = con.execute("select kernel_name, value from counters_collection where (kernel_name like '%mjh_step_kernel%' or kernel_name like '%mjh_solve_kernel%' or kernel_name like '%mjh_dense_%' or kernel_name like '%mjh_solve_mixed%') and counter_name=? order by start", (name,)).fetchall()
     per = 3 if any("mjh_solve_kernel" in r[0] for r in rows) else 1
     if any("mjh_dense_" in r[0] for r in rows):
         per = 5
