@@ -7,15 +7,20 @@
 // 2.7 ms step, at 2.7 waves per CU).  Here the contraction is done once per step on the matrix cores and the sweeps become
 // column updates of a residual vector that lives in registers:
 //
+//   (assemble launch)        with M = L^T D L (mj_factorM) the contraction is a SYRK:  J M^-1 J^T = Y D^-1 Y^T,  Y = J L^-1.  An env
+//                            that takes the dense solver therefore stores Y where the block solver wants B = J M^-1: the half
+//                            solve x <- L^-T x keeps a row's sparsity (only the ancestors of its dofs), ~7x fewer updates on PR2.
 //   mjh_dense_build_kernel   one 512-thread workgroup per environment: expands the block rows (compact over <= 2 kinematic trees,
-//                            pyramid rows n +- k folded) into dense J [rows x nv] and B = J M^-1 [rows x nv], multiplies them
-//                            with v_mfma_f32_16x16x4_f32 (upper triangle of 16 x 16 tiles, fragments straight from L1 / L2; exact fp32), and writes
-//                            AR' = -AR_pq / AR_qq (column-scaled, diagonal -1) row by row in Gauss-Seidel VISITING order, plus the
-//                            per-row start values  t_q = -res_q / AR_qq,  f, lo, hi, AR_qq.
+//                            pyramid rows n +- k folded) into the dense Y [rows x nv], multiplies  (Y D^-1) Y^T  with
+//                            v_mfma_f32_16x16x4_f32 (16 x 16 tiles, fragments straight from L1 / L2, the A side scaled by 1 / D
+//                            in registers; exact fp32), and writes AR' = -AR_pq / AR_qq (column-scaled, diagonal 0) row by row in
+//                            Gauss-Seidel VISITING order, plus the per-row start values  t_q = -res_q / AR_qq,  f, lo, hi, AR_qq
+//                            (res needs J a0: the base-row products of the assemble launch's warm start).
 //   mjh_dense_solve_kernel   one wave per environment, lane q owns rows q, q + 64, ...:   per visited row p
 //                               delta = med3(s_p, lo_p, hi_p) - f_p ;  f_p += delta ;  s_q += AR'_pq delta  for every q != p   (s = f + t)
 //                            = projected Gauss-Seidel on the dual exactly as mj_solPGS iterates it (same rows, same order as the
-//                            block solver and the oracle), ~9 instructions per ROW; then qacc = a0 + B^T (f - f0).
+//                            block solver and the oracle), ~9 instructions per ROW; then qacc = a0 + L^-1 D^-1 Y^T (f - f0)
+//                            (L^-1 level by level: every dof of one tree depth in parallel).
 //
 // Environments whose row count exceeds the dense capacity keep the block solver (meta[7] says which one ran).  The dense form pays
 // ~0.1 ms of build latency per env and wins ~3x per sweep, so it pays when some env of the launch sweeps long — such an env sets
@@ -32,10 +37,10 @@
 #define DN_META_DENSE 7         // meta[7] = 1: this step of this env is solved by the dense kernels
 
 // float offsets of the dense region inside the env's scratch slice (L.g_dense .. ), CAP = M.dense_cap rows, NVS = M.dense_nvs
-struct DenseOff { int art, bd, jd, rf, rlo, rhi, rarr, rt, rmap; };
+struct DenseOff { int art, yd, rf, rlo, rhi, rarr, rt, rmap; };
 DEV DenseOff dense_off(const DModel& M, const Lay& L) {
   DenseOff o; const int cap = M.dense_cap, nvs = M.dense_nvs;
-  o.art = L.g_dense; o.bd = o.art + cap * cap; o.jd = o.bd + cap * nvs; o.rf = o.jd + cap * nvs;
+  o.art = L.g_dense; o.yd = o.art + cap * cap; o.rf = o.yd + cap * nvs;
   o.rlo = o.rf + cap; o.rhi = o.rlo + cap; o.rarr = o.rhi + cap; o.rt = o.rarr + cap; o.rmap = o.rt + cap;
   return o;
 }
@@ -43,7 +48,7 @@ DEV DenseOff dense_off(const DModel& M, const Lay& L) {
 typedef float mjh_f4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------ build
-// LDS: s_a0[NVS] | s_inv[CAP] | s_row[CAP] int4 | s_start[maxblk + 1]  (a few KB: several workgroups per CU)
+// LDS: s_minv[NVS] | s_inv[CAP] | s_row[CAP] int4 | s_start[maxblk + 1]  (a few KB: several workgroups per CU)
 #define DN_BUILD_THREADS 512
 __global__ __launch_bounds__(DN_BUILD_THREADS) void mjh_dense_build_kernel(const DConst* __restrict__ C, const DState S, int env0) {
   const DModel& M = C->M; const Lay& L = C->L;
@@ -57,11 +62,13 @@ __global__ __launch_bounds__(DN_BUILD_THREADS) void mjh_dense_build_kernel(const
   if (nblk == 0 || nefc > cap || nefc <= 0) return;                    // (meta[7] is 0: the block solver takes this env)
   const int nr16 = (nefc + 15) & ~15, nr32 = (nefc + 31) & ~31, K = (nr32 + 63) >> 6, W = 64 * K;
   const DenseOff o = dense_off(M, L);
-  float* s_a0 = lds; float* s_inv = s_a0 + nvs;
+  float* s_minv = lds; float* s_inv = s_minv + nvs;
   int4* s_row = (int4*)(s_inv + cap); int* s_start = (int*)(s_row + cap);
   const int* g_ord = (const int*)(gs + (-1 - L.order)); const int4* g_hd = (const int4*)(gs + (-1 - L.blki));
-  const float* g_bf = gs + (-1 - L.blkf); const float* g_J = gs + (-1 - L.J); const float* g_B = gs + (-1 - L.B);
-  for (int d = tid; d < nvs; d += DN_BUILD_THREADS) s_a0[d] = d < nv ? gs[L.g_a0 + d] : 0.0f;
+  const float* g_bf = gs + (-1 - L.blkf); const float* g_Y = gs + (-1 - L.B);      // (this env's assemble stored Y = J L^-1 there)
+  // J a0 per base row: the assemble launch's warm start left J qacc_smooth and J da (da = M^-1 J^T f_warm, zero if rejected) in the pools
+  const float* g_ja = gs + (-1 - L.phi); const float* g_jda = gs + (-1 - L.bv);
+  for (int d = tid; d < nvs; d += DN_BUILD_THREADS) s_minv[d] = d < nv ? gs[L.g_minv + d] : 0.0f;
   for (int q = tid; q < cap; q += DN_BUILD_THREADS) s_inv[q] = 0.0f;
   // ---- rows in visiting order: position i of the order -> block, its rows start at the running sum of the row counts
   if (wid == 0) {
@@ -81,11 +88,11 @@ __global__ __launch_bounds__(DN_BUILD_THREADS) void mjh_dense_build_kernel(const
     for (int r = 0; r < nr; r++) s_row[p0 + r] = make_int4(hd.x, hd.z, hd.w, b | (r << 16) | (sl4 << 24));
   }
   __syncthreads();
-  // ---- dense rows, 16 lanes (one DPP row) per matrix row, 16 rows per pass: J_p and B_p = J_p M^-1 expanded to nv columns
-  //      (compact storage over <= 2 trees, pyramid rows n +- k folded), written to global for the fragments below; the same pass
-  //      forms  AR_pp = J_p . B_p + R  and  J_p . a0  (sums over the 16 lanes by DPP) and from them the row's start values, stored
-  //      in the lanes' layout [lane][K] of the sweep kernel
-  float* g_jd = gs + o.jd; float* g_bd = gs + o.bd;
+  // ---- dense rows, 16 lanes (one DPP row) per matrix row, 16 rows per pass: Y_p expanded to nv columns (compact storage over
+  //      <= 2 trees, pyramid rows n +- k folded), written to global for the fragments below; the same pass forms
+  //      AR_pp = Y_p D^-1 Y_p^T + R  (sum over the 16 lanes by DPP) and from it the row's start values, stored in the lanes' layout
+  //      [lane][K] of the sweep kernel
+  float* g_yd = gs + o.yd;
   const int sub = tid & 15;
   for (int p = tid >> 4; p < W; p += DN_BUILD_THREADS / 16) {
     int4 ri = make_int4(0, 0, 0, 0);
@@ -93,26 +100,23 @@ __global__ __launch_bounds__(DN_BUILD_THREADS) void mjh_dense_build_kernel(const
     ROW_TREES(ri.y, ri.z);
     const int kind = ri.x & 15, jo = BLK_JOFF(ri.x), r = (ri.w >> 16) & 255, b = ri.w & 0xffff; const bool quad = (ri.w >> 24) & 1;
     const int kk = 1 + (r >> 1); const float sg = (r & 1) ? -1.0f : 1.0f;
-    float jb = 0, ja = 0;
+    float jb = 0;
     if (p < nr16)
 #pragma unroll 8
       for (int d = sub; d < nvs; d += 16) {
-        float jv = 0, bv = 0;
+        float yv = 0;
         const int k = (p < nefc && d < nv) ? row_off(d, a1, n1, a2, n2) : -1;
         if (k >= 0) {
           if (quad) {
-            jv = g_J[jo + 4*k]; bv = g_B[jo + 4*k];
-            if (kind != BK_SINGLE) { jv += sg * g_J[jo + 4*k + kk]; bv += sg * g_B[jo + 4*k + kk]; }
-          } else { jv = g_J[jo + k]; bv = g_B[jo + k]; }
+            yv = g_Y[jo + 4*k];
+            if (kind != BK_SINGLE) yv += sg * g_Y[jo + 4*k + kk];
+          } else yv = g_Y[jo + k];
         }
-        g_jd[p * nvs + d] = jv; g_bd[p * nvs + d] = bv;
-        jb += jv * bv; ja += jv * s_a0[d];
+        g_yd[p * nvs + d] = yv;
+        jb += yv * yv * s_minv[d];
       }
     // sums over the 16 lanes of the DPP row: lane 15 of the row ends up with the totals
-    MJH_DPP_ADD(jb, 0x111, 0xf, true); MJH_DPP_ADD(ja, 0x111, 0xf, true);
-    MJH_DPP_ADD(jb, 0x112, 0xf, true); MJH_DPP_ADD(ja, 0x112, 0xf, true);
-    MJH_DPP_ADD(jb, 0x114, 0xf, true); MJH_DPP_ADD(ja, 0x114, 0xf, true);
-    MJH_DPP_ADD(jb, 0x118, 0xf, true); MJH_DPP_ADD(ja, 0x118, 0xf, true);
+    MJH_DPP_ADD(jb, 0x111, 0xf, true); MJH_DPP_ADD(jb, 0x112, 0xf, true); MJH_DPP_ADD(jb, 0x114, 0xf, true); MJH_DPP_ADD(jb, 0x118, 0xf, true);
     if (sub == 15) {
       float f = 0, lo = 0, hi = 0, arr = 1.0f, t = 0; int map = -1;
       if (p < nefc) {
@@ -120,6 +124,7 @@ __global__ __launch_bounds__(DN_BUILD_THREADS) void mjh_dense_build_kernel(const
         const float R = bf[0];
         const float aref = bf[BF_AREF] + (kind != BK_SINGLE ? sg * bf[BF_AREF + kk] : 0.0f);
         f = bf[BF_F + r]; lo = bf[BF_LO]; hi = bf[BF_LO + 1];
+        const float ja = (g_ja[4 * b] + g_jda[4 * b]) + (kind != BK_SINGLE ? sg * (g_ja[4 * b + kk] + g_jda[4 * b + kk]) : 0.0f);
         arr = jb + R;
         const float inv = 1.0f / arr;
         t = -(ja - aref + R * f) * inv;
@@ -132,11 +137,11 @@ __global__ __launch_bounds__(DN_BUILD_THREADS) void mjh_dense_build_kernel(const
     }
   }
   __syncthreads();
-  // ---- AR = J B^T on the matrix cores in 16 x 16 tiles.  A work item = a 16-row panel P and a column class Q0 = Q mod 4: its K
+  // ---- AR = (Y D^-1) Y^T on the matrix cores in 16 x 16 tiles.  A work item = a 16-row panel P and a column class Q0 = Q mod 4: its K
   //      tiles Q0, Q0 + 4, ... hold, for one lane index, exactly the K row owners q, q + 64, ... whose values are adjacent in the
   //      sweep kernel's layout [p][lane][K] — so a lane stores K adjacent floats and a 16-lane DPP row a contiguous run (the stores
   //      are the traffic of this kernel: 4-byte scatters cost it 2x).  Items are dealt round-robin to the eight waves.  Per 16-dof
-  //      chunk a lane fetches 16 bytes of its A row (J) and of each B row (J M^-1) — L1 / L2 hits, the rows were just written by
+  //      chunk a lane fetches 16 bytes of its A row and of each B row (both from Y; the A side times 1 / D) — L1 / L2 hits, the rows were just written by
   //      this workgroup — and issues four v_mfma_f32_16x16x4_f32 per tile (the k index inside a chunk is permuted identically on
   //      both sides: lane l carries k = 4 (l >> 4) + j, j = 0..3, so that a lane's four values are contiguous).
   //      D: col = l & 15, row = 4 (l >> 4) + v.  Stored column-scaled: AR'_pq = -AR_pq / AR_qq, diagonal -1.  Panels and tiles
@@ -150,17 +155,19 @@ __global__ __launch_bounds__(DN_BUILD_THREADS) void mjh_dense_build_kernel(const
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[j] = (mjh_f4){0, 0, 0, 0};
     if (P < TD) {
-      const float* ap = g_jd + (16 * P + li) * nvs + 4 * lk;
+      const float* ap = g_yd + (16 * P + li) * nvs + 4 * lk;
       // fragments of chunk c + 1 are requested before the matrix instructions of chunk c (a tile that does not exist reads row 0)
       const float* bp[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) bp[j] = g_bd + (16 * (Q0 + 4 * j < TD ? Q0 + 4 * j : 0) + li) * nvs + 4 * lk;
+      for (int j = 0; j < 4; j++) bp[j] = g_yd + (16 * (Q0 + 4 * j < TD ? Q0 + 4 * j : 0) + li) * nvs + 4 * lk;
       float4 a = *(const float4*)ap, bq[4];
+      { const float4 mv = *(const float4*)(s_minv + 4 * lk); a.x *= mv.x; a.y *= mv.y; a.z *= mv.z; a.w *= mv.w; }
 #pragma unroll
       for (int j = 0; j < 4; j++) bq[j] = *(const float4*)bp[j];
       for (int c = 0; c < nch; c++) {
         const int cn = c + 1 < nch ? c + 1 : c;
-        const float4 an = *(const float4*)(ap + 16 * cn);
+        float4 an = *(const float4*)(ap + 16 * cn);
+        { const float4 mv = *(const float4*)(s_minv + 16 * cn + 4 * lk); an.x *= mv.x; an.y *= mv.y; an.z *= mv.z; an.w *= mv.w; }
         float4 bn[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) bn[j] = *(const float4*)(bp[j] + 16 * cn);
@@ -276,7 +283,7 @@ DEV int dn_sweeps(const __amdgpu_buffer_rsrc_t rs, const int art_bytes, const in
 
 template <int K>
 DEV void dn_solve_env(const DModel& M, const Lay& L, float* gs, const __amdgpu_buffer_rsrc_t rs, const DenseOff& o, const int nefc, const int nr32,
-                      float* s_df, const int lane, int* meta) {
+                      float* s_df, float* s_x, const float* s_qld, const int* s_anc, const int lane, int* meta) {
   float f[K], f0[K], t[K], lo[K], hi[K], arr[K];
 #pragma unroll
   for (int k = 0; k < K; k++) {
@@ -297,24 +304,30 @@ DEV void dn_solve_env(const DModel& M, const Lay& L, float* gs, const __amdgpu_b
     if (map >= 0) g_bf[(map & 0xffff) * BLKF_STRIDE + BF_F + ((map >> 16) & 255)] = f[k];
   }
   __syncthreads();
-  // qacc = a0 + B^T (f - f0): lanes = dofs
+  // qacc = a0 + M^-1 J^T (f - f0) = a0 + L^-1 D^-1 Y^T (f - f0): lanes = dofs
   const int nv = M.nv, nvs = M.dense_nvs;
-  const float* g_bd = gs + o.bd;
-  float q0 = lane < nv ? gs[L.g_a0 + lane] : 0.0f, q1 = lane + 64 < nv ? gs[L.g_a0 + lane + 64] : 0.0f;
+  const float* g_yd = gs + o.yd;
+  float q0 = 0.0f, q1 = 0.0f;
   for (int p = 0; p < nefc; p++) {
     const float df = s_df[p];
     if (df == 0.0f) continue;
-    if (lane < nvs) q0 += g_bd[p * nvs + lane] * df;
-    if (lane + 64 < nvs) q1 += g_bd[p * nvs + lane + 64] * df;
+    if (lane < nvs) q0 += g_yd[p * nvs + lane] * df;
+    if (lane + 64 < nvs) q1 += g_yd[p * nvs + lane + 64] * df;
   }
-  if (lane < nv) gs[L.g_qacc + lane] = q0;
-  if (lane + 64 < nv) gs[L.g_qacc + lane + 64] = q1;
+  if (lane < nv) s_x[lane] = q0 * gs[L.g_minv + lane];
+  if (lane + 64 < nv) s_x[lane + 64] = q1 * gs[L.g_minv + lane + 64];
+  __syncthreads();
+  tree_l_levels(s_x, s_qld, s_anc, M.I + M.o_dof_Madr, nv, M.nM, lane);
+  if (lane < nv) gs[L.g_qacc + lane] = gs[L.g_a0 + lane] + s_x[lane];
+  if (lane + 64 < nv) gs[L.g_qacc + lane + 64] = gs[L.g_a0 + lane + 64] + s_x[lane + 64];
   if (lane == 0) meta[5] = niter;
 }
 
 __global__ __launch_bounds__(64) void mjh_dense_solve_kernel(const DConst* __restrict__ C, const DState S, int env0) {
   const DModel& M = C->M; const Lay& L = C->L;
-  __shared__ float s_df[DN_CAP_MAX];
+  // LDS: s_df[DN_CAP_MAX] | s_x[128] | factor L [nM] | ancestor lists [nM]
+  extern __shared__ float lds[];
+  float* s_df = lds; float* s_x = s_df + DN_CAP_MAX; float* s_qld = s_x + 128; int* s_anc = (int*)(s_qld + M.nM);
   const int lane = threadIdx.x;
   const int env = S.env_order ? S.env_order[env0 + blockIdx.x] : env0 + (int)blockIdx.x;
   float* const gs = S.gscratch + (size_t)env * (size_t)S.gstride;
@@ -323,6 +336,7 @@ __global__ __launch_bounds__(64) void mjh_dense_solve_kernel(const DConst* __res
   const int nefc = __builtin_amdgcn_readfirstlane(meta[2]);
   const int nr32 = (nefc + 31) & ~31, K = (nr32 + 63) >> 6;
   const DenseOff o = dense_off(M, L);
+  for (int i = lane; i < M.nM; i += 64) { s_qld[i] = gs[L.g_qLD + i]; s_anc[i] = ((const int*)(gs + L.g_anc))[i]; }   // (used after the sweeps)
   __amdgpu_buffer_rsrc_t rs;
   {
     const unsigned long long ga = (unsigned long long)gs;
@@ -330,8 +344,8 @@ __global__ __launch_bounds__(64) void mjh_dense_solve_kernel(const DConst* __res
     const long long nb = S.gstride * 4;
     rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)(nb > 0x7ffffff0ll ? 0x7ffffff0ll : nb), 0x00020000);
   }
-  if (K == 1) dn_solve_env<1>(M, L, gs, rs, o, nefc, nr32, s_df, lane, meta);
-  else if (K == 2) dn_solve_env<2>(M, L, gs, rs, o, nefc, nr32, s_df, lane, meta);
-  else if (K == 3) dn_solve_env<3>(M, L, gs, rs, o, nefc, nr32, s_df, lane, meta);
-  else dn_solve_env<4>(M, L, gs, rs, o, nefc, nr32, s_df, lane, meta);
+  if (K == 1) dn_solve_env<1>(M, L, gs, rs, o, nefc, nr32, s_df, s_x, s_qld, s_anc, lane, meta);
+  else if (K == 2) dn_solve_env<2>(M, L, gs, rs, o, nefc, nr32, s_df, s_x, s_qld, s_anc, lane, meta);
+  else if (K == 3) dn_solve_env<3>(M, L, gs, rs, o, nefc, nr32, s_df, s_x, s_qld, s_anc, lane, meta);
+  else dn_solve_env<4>(M, L, gs, rs, o, nefc, nr32, s_df, s_x, s_qld, s_anc, lane, meta);
 }

@@ -99,6 +99,7 @@ struct Lay {
   // (initial acceleration, 1/M_dd, velocity after the controller, smooth force, solved acceleration) and of 8 ints of
   // meta data (nblk, nfixblk, nefc, ncon, flags, solver iterations)
   int g_a0, g_minv, g_qvel, g_smooth, g_qacc, g_meta, g_qM;
+  int g_qLD, g_anc;   // dense solver: the factor L of M (nM floats) and the ancestor lists (nM ints), handed over by the assemble launch
   int g_dense;   // dense solver: AR' [cap x cap] | B rows [cap x nvs] | J rows [cap x nvs] | f, lo, hi, AR_qq, t, row map [6 x cap]
 };
 

@@ -387,8 +387,9 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       M.dense_cap = std::min(256, ((std::max(M.maxefc, 1) + 63) / 64) * 64); M.dense_nvs = ((nv + 15) / 16) * 16;
       if (const char* dc = getenv("MJH_DENSE_CAP")) M.dense_cap = std::max(64, std::min(M.dense_cap, (atoi(dc) / 64) * 64));   // (tests: envs beyond the capacity keep the block solver)
       M.dense_min_iter = getenv("MJH_DENSE_MIN_ITER") ? std::max(0, atoi(getenv("MJH_DENSE_MIN_ITER"))) : 32;
-      L.g_dense = 0;
-      if (M.dense) { long long o = goff; goff += (long long)M.dense_cap * M.dense_cap + 2LL * M.dense_cap * M.dense_nvs + 6LL * M.dense_cap; L.g_dense = (int)o; }
+      L.g_dense = 0; L.g_qLD = 0; L.g_anc = 0;
+      if (M.dense) { L.g_qLD = graw(m->nM); L.g_anc = graw(m->nM); }
+      if (M.dense) { long long o = goff; goff += (long long)M.dense_cap * M.dense_cap + (long long)M.dense_cap * M.dense_nvs + 6LL * M.dense_cap; L.g_dense = (int)o; }
     }
     hp.gstride = goff;
     L.total = off;
@@ -477,7 +478,7 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
 #define MJH_ATTR(NR, DG) do { HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<NR, DG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes)); \
                               HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<NR, DG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes)); } while (0)
   if (e->M.dense) {
-    // LDS of mjh_dense_build_kernel: a0 [nvs] | 1 / AR_qq [cap] | row table [cap] int4 | row starts [maxblk + 1]
+    // LDS of mjh_dense_build_kernel: 1 / D [nvs] | 1 / AR_qq [cap] | row table [cap] int4 | row starts [maxblk + 1]
     e->dense_lds = ((size_t)e->M.dense_nvs + 5 * (size_t)e->M.dense_cap + (size_t)std::max(e->M.maxblk, 1) + 8) * sizeof(float);
     if (e->dense_lds > 160 * 1024) { e->M.dense = 0; }
     else HIPCHK(hipFuncSetAttribute((const void*)mjh_dense_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->dense_lds));
@@ -671,7 +672,7 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
           // dense row-space solver (dense_pgs.h): AR = J M^-1 J^T on the matrix cores, then column sweeps, for every env of the
           // launch whose row count fits; the block solver below skips those envs (meta[7])
           hipLaunchKernelGGL(mjh_dense_build_kernel, dim3(g1 - g0), dim3(DN_BUILD_THREADS), e->dense_lds, st, e->dC, e->S, g0);
-          hipLaunchKernelGGL(mjh_dense_solve_kernel, dim3(g1 - g0), dim3(64), 0, st, e->dC, e->S, g0);
+          hipLaunchKernelGGL(mjh_dense_solve_kernel, dim3(g1 - g0), dim3(64), (DN_CAP_MAX + 128 + 2 * (size_t)e->M.nM) * sizeof(float), st, e->dC, e->S, g0);
           HIPCHK(hipGetLastError());
         }
         if (!rc) {

@@ -58,6 +58,17 @@ DEV void solve_tree(float* x, const float* qLD, const float* qLDinv, const int* 
     x[k * STRIDE] = xk;
   }
 }
+// The first half of solve_tree for the dense row-space solver (dense_pgs.h), which works with Y = J L^-1 instead of B = J M^-1
+// (M^-1 = L^-1 D^-1 L^-T, so J M^-1 J^T = Y D^-1 Y^T): x <- L^-T x keeps a row's sparsity — only the ancestors of its nonzero
+// dofs are touched, a contact row of a 49-dof robot costs ~170 updates instead of ~1200 — and tree_l_levels (x <- L^-1 x) finishes a solve.
+DEV void solve_tree_lt(float* x, const float* qLD, const int* dof_parentid, const int* dof_Madr, int adr, int num, const int STRIDE = 1) {
+  for (int k = adr + num - 1; k >= adr; k--) {
+    float xk = x[k * STRIDE];
+    if (xk == 0) continue;
+    int a = dof_Madr[k] + 1;
+    for (int i = dof_parentid[k]; i >= 0; i = dof_parentid[i]) x[i * STRIDE] -= qLD[a++] * xk;
+  }
+}
 DEV void factor_tree(float* qLD, float* qLDinv, const int* dof_parentid, const int* dof_Madr, int adr, int num) {
   for (int k = adr + num - 1; k >= adr; k--) {
     int Mkk_a = dof_Madr[k], Mki = Mkk_a + 1;
@@ -98,6 +109,29 @@ DEV void factor_tree_wave(float* qLD, float* qLDinv, const int* anc, const int* 
     __syncthreads();
     for (int p = 1 + lane; p <= d; p += 64) qLD[Mk + p] *= inv;
     if (lane == 0) qLDinv[k] = inv;
+    __syncthreads();
+  }
+}
+// x <- L^-1 x for a vector in LDS, lanes = dofs (nv <= 128: two per lane), level by level: a dof's value needs its ancestors'
+// final values, and a dof with d ancestors sits at depth d — all dofs of one depth go together.  qLD / anc: the factor and the
+// ancestor lists (anc[dof_Madr[k] + p] = p-th ancestor of dof k).  One wavefront.
+DEV void tree_l_levels(float* x, const float* qLD, const int* anc, const int* dof_Madr, const int nv, const int nM, const int lane) {
+  int Mk[2], dep[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int k = lane + 64 * h;
+    Mk[h] = k < nv ? dof_Madr[k] : 0;
+    dep[h] = k < nv ? (k + 1 < nv ? dof_Madr[k + 1] : nM) - Mk[h] - 1 : 0;
+  }
+  for (int lev = 1; __ballot(dep[0] >= lev || dep[1] >= lev) != 0; lev++) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      if (dep[h] == lev) {
+        const int k = lane + 64 * h; float xk = x[k];
+        for (int p = 1; p <= lev; p++) xk -= qLD[Mk[h] + p] * x[anc[Mk[h] + p]];
+        x[k] = xk;
+      }
+    }
     __syncthreads();
   }
 }
@@ -1229,6 +1263,9 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
       }
     }
     nefc = __builtin_amdgcn_readfirstlane(nefc); nblk = __builtin_amdgcn_readfirstlane(nblk); nbrow = __builtin_amdgcn_readfirstlane(nbrow);
+    // assemble launch of a cohort whose solve runs the dense row-space solver (the host queues mjh_dense_build_kernel behind this
+    // launch: same rule there).  Such an env stores Y = J L^-1 where the others store B = J M^-1, and needs no per-block matrices.
+    const bool dense_pre = NROW == 8 && !DIAGM && pre && (xflags & XF_DENSE) && nefc > 0 && nefc <= M.dense_cap;
     WSYNC();
     PROF(6);
     // ---- base Jacobian rows: lanes = (block, base) tasks.  Storage is interleaved per block, J[b][k][4]
@@ -1450,8 +1487,13 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
         ROW_TREES(hd[2], hd[3]);
         float* x = lds + M.scratch_off + lane * rowW;
         for (int k = 0; k < rowW; k++) x[k] = J[SL*k];
-        solve_tree(x - a1, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a1, n1, 1);
-        if (n2 > 0) solve_tree(x + (n1 - a2), s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a2, n2, 1);
+        if (dense_pre) {
+          solve_tree_lt(x - a1, s_qLD, s_dofpar_i, s_dofMadr_i, a1, n1, 1);
+          if (n2 > 0) solve_tree_lt(x + (n1 - a2), s_qLD, s_dofpar_i, s_dofMadr_i, a2, n2, 1);
+        } else {
+          solve_tree(x - a1, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a1, n1, 1);
+          if (n2 > 0) solve_tree(x + (n1 - a2), s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a2, n2, 1);
+        }
         for (int k = 0; k < rowW; k++) B[SL*k] = x[k];
       }
       WSYNC();
@@ -1465,6 +1507,11 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
         if (jb >= ((hd[0] >> 8) & 15)) { for (int k = 0; k < rowW; k++) B[SL*k] = 0; continue; }
         ROW_TREES(hd[2], hd[3]);
         for (int k = 0; k < rowW; k++) B[SL*k] = J[SL*k];
+        if (dense_pre) {
+          solve_tree_lt(B - SL*a1, s_qLD, s_dofpar_i, s_dofMadr_i, a1, n1, SL);
+          if (n2 > 0) solve_tree_lt(B + SL*(n1 - a2), s_qLD, s_dofpar_i, s_dofMadr_i, a2, n2, SL);
+          continue;
+        }
         solve_tree(B - SL*a1, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a1, n1, SL);
         if (n2 > 0) solve_tree(B + SL*(n1 - a2), s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a2, n2, SL);
       }
@@ -2016,6 +2063,12 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
           base_dots(s_ws, s_bv);
           forces_from(s_bv, true);
           accum_T(true, s_phi, s_tmpv);               // da = M^-1 J^T f
+          if (dense_pre) {                            // (the pool holds Y = J L^-1: what came out is Y^T f = L^-T J^T f; finish with D^-1 and L^-1)
+            for (int d = lane; d < nv; d += 64) s_tmpv[d] *= s_qLDinv[d];
+            WSYNC();
+            tree_l_levels(s_tmpv, s_qLD, s_anc_i, s_dofMadr_i, nv, M.nM, lane);
+            WSYNC();
+          }
           base_dots(s_tmpv, s_bv);                    // J da
           base_dots(s_asmooth, s_phi);                // J a_smooth  (phi is free again)
           float cost = 0;
@@ -2074,7 +2127,7 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
         if (!patched) {
         // (an env that the dense solver takes — dense_pgs.h: it forms the full AR on the matrix cores — needs neither the blocks'
         //  own A_c nor their row-space matrices, only the projection intervals)
-        const bool dense_env = pre && (xflags & XF_DENSE) && nefc <= M.dense_cap;   // (the host launches mjh_dense_build_kernel behind this launch: same rule there)
+        const bool dense_env = dense_pre;
         // ---- A_c = J_base M^-1 J_base^T, upper triangle (lanes = (block, base jb): row jb).  Built here, after the last user
         //      of the contact records and the velocity-stage spatial vectors: s_blkq reuses their space.
         if (!dense_env)
@@ -2161,6 +2214,12 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
         PROF(12);
         if (pre) {   // initial acceleration and 1/M_dd for the stand-alone solver; the blocks are in the pools already
           for (int d = lane; d < nv; d += 64) { gs[L.g_a0 + d] = s_asmooth[d] + s_tmpv[d]; gs[L.g_minv + d] = s_qLDinv[d]; }
+          if (dense_pre) {
+            for (int i = lane; i < M.nM; i += 64) { gs[L.g_qLD + i] = s_qLD[i]; ((int*)(gs + L.g_anc))[i] = s_anc_i[i]; }     // (the dense solve finishes qacc with L^-1)
+            // mjh_dense_build_kernel takes J a0 = J qacc_smooth + J da from the warm start's base-row products (pools phi, bv)
+            if (!warm) base_dots(s_asmooth, s_phi);
+            if (zero_f) for (int i = lane; i < 4 * nblk; i += 64) s_bv[i] = 0;
+          }
           return;
         }
         // ---- PGS (mj_solPGS), matrix-free, one block at a time.  lanes = dofs, running acceleration `a` in a
