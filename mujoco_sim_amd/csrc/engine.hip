@@ -323,7 +323,8 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     L.xipos = put(3*nb); L.com = put(3*nb); L.cinert = diagM ? unused : put(10*nb); L.cdof = diagM ? unused : put(6*nv);
     const int k2_size = off - k1;   // ... and all of these are dead when the solver sweeps run: the X extension of condim-4 models
     if (!patch) {
-      L.qM = put(m->nM); L.qLD = diagM ? L.qM : put(m->nM); L.qLDinv = put(nv);   // diagonal M: no factor storage
+      // diagonal M: no factor storage; many-body layout: the factor is built in M's place (M itself stays in the env's scratch slice)
+      L.qM = put(m->nM); L.qLD = (diagM || big) ? L.qM : put(m->nM); L.qLDinv = put(nv);
       if (diagM) { L.dofpar = 0; L.dofMadr = 0; L.anc = 0; }   // free-body models read the shared chain-walk tables (step_kernel.h)
       else { L.dofpar = put(nv); L.dofMadr = put(nv); L.anc = put(m->nM); }
       L.p_gsize = put(3*ng); L.p_rbound = put(ng); L.p_mass = put(nb); L.p_inertia = put(3*nb);
@@ -332,7 +333,8 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       const int a4 = [](int n) { return ((std::max(n, 1) + 3) / 4) * 4; }(6*nb);
       const int velsz = diagM ? 4 : 4 * a4 + ((6*nv + 3) / 4) * 4;
       int vel;
-      if (big) { L.con = gput((long long)M.maxcon * CON_STRIDE); L.blkq = gput((long long)nblkcap * BLKQ_STRIDE); vel = put(velsz); }
+      // (many-body layout: they reuse the position-stage arrays instead, which are dead when the velocity stage starts)
+      if (big) { L.con = gput((long long)M.maxcon * CON_STRIDE); L.blkq = gput((long long)nblkcap * BLKQ_STRIDE); vel = (!keep && !diagM && velsz <= k1_size) ? k1 : put(velsz); }
       else if (keep) { L.con = put(M.maxcon * CON_STRIDE); L.blkq = put(nblkcap * BLKQ_STRIDE); vel = put(velsz); }
       else {
         // (and, once those are dead too, the per-block solver matrices A_c / Q, built when the solver starts)
@@ -392,6 +394,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       if (M.dense) { long long o = goff; goff += (long long)M.dense_cap * M.dense_cap + (long long)M.dense_cap * M.dense_nvs + 6LL * M.dense_cap; L.g_dense = (int)o; }
     }
     hp.gstride = goff;
+    if (const char* pad = getenv("MJH_LDS_PAD")) off += std::max(0, atoi(pad));   // (occupancy experiments: floats of unused LDS per env)
     L.total = off;
     hp.lds_bytes = off * (int)sizeof(float);
   }
@@ -1303,7 +1306,24 @@ extern "C" int mjh_debug_stage_cycles(mjh_engine* e, int with_inverse, double* o
   {
     StateGuard guard(&e->S);
     e->S.x_prof = buf;
-    rc = launch(e, 0, e->nenv, 1, PH_STEP1 | PH_STEP2 | (with_inverse ? PH_INV : 0), XF_PROF);
+    const int ph = PH_STEP1 | PH_STEP2 | ((with_inverse & 1) ? PH_INV : 0);
+    if ((with_inverse & 6) && e->M.big && e->split3) {
+      // the launch chain of the many-body layout on all envs, stamps from its assemble (2) or integrate (4) launch
+      const bool dn = e->M.dense != 0;
+      rc = launch(e, 0, e->nenv, 1, ph | PH_PRE, (dn ? XF_DENSE : 0) | ((with_inverse & 2) ? XF_PROF : 0));
+      if (!rc && dn) {
+        hipLaunchKernelGGL(mjh_dense_build_kernel, dim3(e->nenv), dim3(DN_BUILD_THREADS), e->dense_lds, e->stream, e->dC, e->S, 0);
+        hipLaunchKernelGGL(mjh_dense_solve_kernel, dim3(e->nenv), dim3(64), (DN_CAP_MAX + 128 + 2 * (size_t)e->M.nM) * sizeof(float), e->stream, e->dC, e->S, 0);
+      }
+      if (!rc) {
+        const size_t lds = (2 * (size_t)(((e->M.nv + 3) / 4) * 4) + 2 * (size_t)std::max(e->M.maxblk, 1) + 4 + 8 + 8 + 8 * (size_t)((e->M.nv + 2) / 3)) * sizeof(float);
+        if (e->M.diagM) hipLaunchKernelGGL((mjh_solve_kernel<true, false>), dim3(e->nenv), dim3(64), lds, e->stream, e->dC, e->S, 0);
+        else hipLaunchKernelGGL((mjh_solve_kernel<false, false>), dim3(e->nenv), dim3(64), lds, e->stream, e->dC, e->S, 0);
+        HIPCHK(hipGetLastError());
+        rc = launch(e, 0, e->nenv, 1, PH_STEP2 | PH_POST, (with_inverse & 4) ? XF_PROF : 0);
+      }
+    } else
+    rc = launch(e, 0, e->nenv, 1, ph, XF_PROF);
   }
   std::vector<long long> h((size_t)e->nenv * PROF_STRIDE);
   if (!rc) { HIPCHK(hipMemcpyAsync(h.data(), buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }

@@ -89,58 +89,140 @@ DEV void factor_tree(float* qLD, float* qLDinv, const int* dof_parentid, const i
 // lane-per-tree routines above leave 63 lanes idle during O(n depth^2) work).  Sequential over the dofs k of the tree,
 // lanes = ancestors a_p of k (p = 1..depth); every update of one k touches a different row / entry per lane.
 #define MJH_WAVE_TREE_MIN 12
-// anc[dof_Madr[k] + p] = p-th ancestor of dof k (p = 0: k itself): same layout as the rows of qLD, built once per launch.
-// The depth of k is the length of its qLD row minus one.
-DEV void factor_tree_wave(float* qLD, float* qLDinv, const int* anc, const int* dof_Madr, int adr, int num, int nM, int nv, const int lane) {
-  for (int k = adr + num - 1; k >= adr; k--) {
-    const int Mk = dof_Madr[k], d = (k + 1 < nv ? dof_Madr[k + 1] : nM) - Mk - 1;
-    const float inv = 1.0f / qLD[Mk];
-    // lanes = (p, q) with 1 <= p <= q <= d: row a_p, column a_q  -=  (M_kp / M_kk) M_kq   (row k is only read)
-    for (int p0 = 1; p0 <= d; p0 += 4) {
-      const int pp = p0 + (lane >> 4);
-      for (int q0 = 1; q0 <= d; q0 += 16) {
-        const int q = q0 + (lane & 15);
-        if (pp <= d && q >= pp && q <= d) {
-          const int ai = dof_Madr[anc[Mk + pp]];
-          qLD[ai + (q - pp)] -= qLD[Mk + pp] * inv * qLD[Mk + q];
-        }
+// anc[dof_Madr[k] + p] = (p-th ancestor a of dof k) | dof_Madr[a] << 16  (p = 0: k itself): same layout as the rows of qLD, built
+// once per launch.  The depth of k is the length of its qLD row minus one.
+#define ANC_DOF(w) ((w) & 0xffff)
+#define ANC_MADR(w) ((int)((unsigned)(w) >> 16))
+// One dof k at a time, from the leaves up (mj_factorM's order, so the result is the sequential one bit for bit); lanes = the
+// pairs (p, q), 1 <= p <= q <= depth, of ancestors of k:  M[a_p][a_q] -= (M_kp / M_kk) M_kq.  Row k is only read, so everything a
+// lane needs from it is fetched in one go (row starts and depths come out of registers by v_readlane), then the targets, then the
+// stores: two LDS round trips per dof instead of one per dependent index (PR2: 110 k -> 25 k clocks for 49 dofs).
+// the pairs of one dof of depth d <= 4 NP, d <= 16 NQ:  p = 1 + 4 it + (lane >> 4), it < NP;  q = 1 + 16 c + (lane & 15), c < NQ.
+// Every load is unconditional (a lane without a pair reads an address that is valid anyway): a predicated load becomes a
+// branch with its own s_waitcnt, and the point is to have all of a round's loads in flight together.
+template <int NP, int NQ>
+DEV void factor_dof_pairs(float* qLD, float* qLDinv, const int* anc, const int Mk, const int d, const int k, const int lane) {
+  const int q = 1 + (lane & 15), pr = lane >> 4;
+  const float dk = qLD[Mk];
+  float aq[NQ], ap[NP], tg[NP][NQ]; int am[NP];
+#pragma unroll
+  for (int c = 0; c < NQ; c++) aq[c] = qLD[Mk + min(q + 16 * c, d)];
+#pragma unroll
+  for (int it = 0; it < NP; it++) { const int pp = min(1 + 4 * it + pr, d); ap[it] = qLD[Mk + pp]; am[it] = ANC_MADR(anc[Mk + pp]); }
+  const float inv = 1.0f / dk;
+#pragma unroll
+  for (int it = 0; it < NP; it++)
+#pragma unroll
+    for (int c = 0; c < NQ; c++) {
+      tg[it][c] = 0.0f;
+      if (16 * c + 16 > 4 * it) {      // (the chunk holds some q >= p)
+        const int pp = 1 + 4 * it + pr, qq = q + 16 * c; const bool v = pp <= d && qq >= pp && qq <= d;
+        tg[it][c] = qLD[v ? am[it] + (qq - pp) : Mk];
       }
     }
-    __syncthreads();
-    for (int p = 1 + lane; p <= d; p += 64) qLD[Mk + p] *= inv;
-    if (lane == 0) qLDinv[k] = inv;
+#pragma unroll
+  for (int it = 0; it < NP; it++)
+#pragma unroll
+    for (int c = 0; c < NQ; c++)
+      if (16 * c + 16 > 4 * it) {
+        const int pp = 1 + 4 * it + pr, qq = q + 16 * c; const bool v = pp <= d && qq >= pp && qq <= d;
+        if (v) qLD[am[it] + (qq - pp)] = tg[it][c] - ap[it] * inv * aq[c];
+      }
+#pragma unroll
+  for (int c = 0; c < NQ; c++) if (pr == 0 && q + 16 * c <= d) qLD[Mk + q + 16 * c] = aq[c] * inv;
+  if (lane == 0) qLDinv[k] = inv;
+}
+DEV void factor_tree_wave(float* qLD, float* qLDinv, const int* anc, const int* dof_Madr, int adr, int num, int nM, int nv, const int lane) {
+  int chunk = -1, MkL = 0, dL = 0;
+  for (int k = adr + num - 1; k >= adr; k--) {
+    const int ck = (k - adr) >> 6;
+    if (ck != chunk) {
+      chunk = ck;
+      const int kk = adr + 64 * ck + lane;
+      MkL = kk < adr + num ? dof_Madr[kk] : 0;
+      dL = kk < adr + num ? (kk + 1 < nv ? dof_Madr[kk + 1] : nM) - MkL - 1 : 0;
+    }
+    const int Mk = __builtin_amdgcn_readlane(MkL, (k - adr) & 63), d = __builtin_amdgcn_readlane(dL, (k - adr) & 63);
+    if (d <= 16) factor_dof_pairs<4, 1>(qLD, qLDinv, anc, Mk, d, k, lane);
+    else if (d <= 32) factor_dof_pairs<8, 2>(qLD, qLDinv, anc, Mk, d, k, lane);
+    else {
+      const int q = 1 + (lane & 15), pr = lane >> 4;
+      const float inv = 1.0f / qLD[Mk];
+      for (int p0 = 1; p0 <= d; p0 += 4) {
+        const int pp = p0 + pr;
+        for (int q0 = 0; q0 < d; q0 += 16) {
+          const int qq = q0 + q;
+          if (pp <= d && qq >= pp && qq <= d) {
+            const int ai = ANC_MADR(anc[Mk + pp]);
+            qLD[ai + (qq - pp)] -= qLD[Mk + pp] * inv * qLD[Mk + qq];
+          }
+        }
+      }
+      __syncthreads();
+      for (int p = 1 + lane; p <= d; p += 64) qLD[Mk + p] *= inv;
+      if (lane == 0) qLDinv[k] = inv;
+    }
     __syncthreads();
   }
 }
-// x <- L^-1 x for a vector in LDS, lanes = dofs (nv <= 128: two per lane), level by level: a dof's value needs its ancestors'
-// final values, and a dof with d ancestors sits at depth d — all dofs of one depth go together.  qLD / anc: the factor and the
-// ancestor lists (anc[dof_Madr[k] + p] = p-th ancestor of dof k).  One wavefront.
-DEV void tree_l_levels(float* x, const float* qLD, const int* anc, const int* dof_Madr, const int nv, const int nM, const int lane) {
-  int Mk[2], dep[2];
+// Solves with the factor, lanes = dofs (nv <= 128: two per lane), level by level instead of dof by dof: a dof with d ancestors
+// sits at depth d, and all dofs of one depth are independent of each other.  One wavefront.
+struct TreeLanes { int Mk[2], dep[2]; };
+DEV TreeLanes tree_lanes(const int* dof_Madr, const int nv, const int nM, const int lane) {
+  TreeLanes t;
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     const int k = lane + 64 * h;
-    Mk[h] = k < nv ? dof_Madr[k] : 0;
-    dep[h] = k < nv ? (k + 1 < nv ? dof_Madr[k + 1] : nM) - Mk[h] - 1 : 0;
+    t.Mk[h] = k < nv ? dof_Madr[k] : 0;
+    t.dep[h] = k < nv ? (k + 1 < nv ? dof_Madr[k + 1] : nM) - t.Mk[h] - 1 : 0;
   }
-  for (int lev = 1; __ballot(dep[0] >= lev || dep[1] >= lev) != 0; lev++) {
+  return t;
+}
+// x <- L^-1 x: a dof's value needs its ancestors' final values: levels from the roots down, every dof pulls
+DEV void tree_l_levels(float* x, const float* qLD, const int* anc, const int* dof_Madr, const int nv, const int nM, const int lane) {
+  const TreeLanes t = tree_lanes(dof_Madr, nv, nM, lane);
+  for (int lev = 1; __ballot(t.dep[0] >= lev || t.dep[1] >= lev) != 0; lev++) {
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      if (dep[h] == lev) {
+      if (t.dep[h] == lev) {
         const int k = lane + 64 * h; float xk = x[k];
-        for (int p = 1; p <= lev; p++) xk -= qLD[Mk[h] + p] * x[anc[Mk[h] + p]];
+        for (int p = 1; p <= lev; p++) xk -= qLD[t.Mk[h] + p] * x[ANC_DOF(anc[t.Mk[h] + p])];
         x[k] = xk;
       }
     }
     __syncthreads();
   }
 }
+// x <- L^-T x: a dof's final value goes to all its ancestors: levels from the leaves up, every dof pushes (LDS atomics: dofs
+// of one depth on different branches share ancestors; one wavefront issues them in a fixed order)
+DEV void tree_lt_levels(float* x, const float* qLD, const int* anc, const int* dof_Madr, const int nv, const int nM, const int lane) {
+  const TreeLanes t = tree_lanes(dof_Madr, nv, nM, lane);
+  int maxd = 0;
+  while (__ballot(t.dep[0] > maxd || t.dep[1] > maxd) != 0) maxd++;
+  for (int lev = maxd; lev >= 1; lev--) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      if (t.dep[h] == lev) {
+        const float xk = x[lane + 64 * h];
+        if (xk != 0.0f) for (int p = 1; p <= lev; p++) atomicAdd(&x[ANC_DOF(anc[t.Mk[h] + p])], -qLD[t.Mk[h] + p] * xk);
+      }
+    }
+    __syncthreads();
+  }
+}
+// x <- M^-1 x = L^-1 D^-1 L^-T x for every tree of the model at once
+DEV void solve_trees_levels(float* x, const float* qLD, const float* qLDinv, const int* anc, const int* dof_Madr, const int nv, const int nM, const int lane) {
+  tree_lt_levels(x, qLD, anc, dof_Madr, nv, nM, lane);
+  for (int k = lane; k < nv; k += 64) x[k] *= qLDinv[k];
+  __syncthreads();
+  tree_l_levels(x, qLD, anc, dof_Madr, nv, nM, lane);
+}
 DEV void solve_tree_wave(float* x, const float* qLD, const float* qLDinv, const int* anc, const int* dof_Madr, int adr, int num, int nM, int nv, const int lane) {
   for (int k = adr + num - 1; k >= adr; k--) {                                // x <- L^-T x
     const float xk = x[k];
     if (xk != 0) {
       const int Mk = dof_Madr[k], d = (k + 1 < nv ? dof_Madr[k + 1] : nM) - Mk - 1;
-      for (int p = 1 + lane; p <= d; p += 64) x[anc[Mk + p]] -= qLD[Mk + p] * xk;
+      for (int p = 1 + lane; p <= d; p += 64) x[ANC_DOF(anc[Mk + p])] -= qLD[Mk + p] * xk;
     }
     __syncthreads();
   }
@@ -149,7 +231,7 @@ DEV void solve_tree_wave(float* x, const float* qLD, const float* qLDinv, const 
   for (int k = adr; k < adr + num; k++) {                                     // x <- L^-1 x
     const int Mk = dof_Madr[k], d = (k + 1 < nv ? dof_Madr[k + 1] : nM) - Mk - 1;
     float part = 0;
-    for (int p = 1 + lane; p <= d; p += 64) part += qLD[Mk + p] * x[anc[Mk + p]];
+    for (int p = 1 + lane; p <= d; p += 64) part += qLD[Mk + p] * x[ANC_DOF(anc[Mk + p])];
     part = wave_sum<4>(part);
     if (lane == 0) x[k] -= part;
     __syncthreads();
@@ -788,6 +870,11 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
   // and read the shared tables instead (their LDS space is not allocated)
   const int* s_dofpar_i = DIAGM ? (dof_parentid + 0) : (const int*)s_dofpar; const int* s_dofMadr_i = DIAGM ? (dof_Madr + 0) : (const int*)s_dofMadr;
   int* s_anc_i = (int*)s_anc;
+  // solves with the factor level by level (all trees at once) for models with a long kinematic tree and at most 128 dofs
+  bool level_solves = false;
+  if (!DIAGM && nv <= 128) for (int t = 0; t < M.ntree; t++) level_solves |= tree_dofnum[t] >= MJH_WAVE_TREE_MIN;
+  // M after the factorisation: articulated models in the many-body layout keep only the factor in LDS (it is built in M's place)
+  const float* qM_ro = (NROW == 8 && !DIAGM) ? gs + L.g_qM : s_qM;
   float* s_stage = s_J;  // raw-contact staging aliases the (not yet built) base-row storage
   const int rowW = M.rowW;
 
@@ -813,11 +900,12 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
   }
   if (lane < (M.patch ? PP_ZERO : 4)) s_zero[lane] = 0;   // what lanes outside a block read instead of its Jacobian (patch sweep: instead of a row record)
   // hot chain-walk tables and the (possibly per-env) model parameters go to LDS once per launch
-  for (int i = lane; i < nv; i += 64) {
-    if (!DIAGM) {
-      ((int*)s_dofpar)[i] = dof_parentid[i]; ((int*)s_dofMadr)[i] = dof_Madr[i];
-      int a = dof_Madr[i]; s_anc_i[a] = i;                      // ancestor lists (wave-cooperative factor / solve)
-      for (int j = dof_parentid[i]; j >= 0; j = dof_parentid[j]) s_anc_i[++a] = j;
+  if (!DIAGM) {
+    for (int i = lane; i < nv; i += 64) { ((int*)s_dofpar)[i] = dof_parentid[i]; ((int*)s_dofMadr)[i] = dof_Madr[i]; }
+    WSYNC();
+    for (int i = lane; i < nv; i += 64) {       // ancestor lists (wave-cooperative factor / solve): chain walks on the LDS copies
+      int a = s_dofMadr_i[i]; s_anc_i[a] = i | (a << 16);
+      for (int j = s_dofpar_i[i]; j >= 0; j = s_dofpar_i[j]) s_anc_i[++a] = j | (s_dofMadr_i[j] << 16);
     }
   }
   for (int i = lane; i < 3 * ngeom; i += 64) s_p_gsize[i] = S.p_geom_size ? S.p_geom_size[(size_t)env * S.p_stride + i] : geom_size[i];
@@ -1052,7 +1140,9 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
 #pragma unroll
         for (int q = 0; q < 6; q++) v += s_cdof[6*j+q] * buf[q];
         if (j == i) v += dof_armature[i];
-        s_qM[adr] = v; s_qLD[adr] = v; adr++;
+        s_qM[adr] = v; s_qLD[adr] = v;
+        if (NROW == 8) gs[L.g_qM + adr] = v;      // many-body layout: the factor takes M's place in LDS (L.qLD == L.qM), M itself lives in the env's scratch slice
+        adr++;
       }
     }
     WSYNC();
@@ -1938,8 +2028,8 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
       WSYNC();
       if (anydd) {  // tau = M ddq (mj_mulM, :1057)
         for (int i = lane; i < nv; i += 64) {
-          int adr = s_dofMadr_i[i]; float vi = s_tmpv[i], acc = s_qM[adr] * vi; int k = 1;
-          for (int j = s_dofpar_i[i]; j >= 0; j = s_dofpar_i[j]) { float mij = s_qM[adr + k]; acc += mij * s_tmpv[j]; atomicAdd(&s_applied[j], mij * vi); k++; }
+          int adr = s_dofMadr_i[i]; float vi = s_tmpv[i], acc = qM_ro[adr] * vi; int k = 1;
+          for (int j = s_dofpar_i[i]; j >= 0; j = s_dofpar_i[j]) { float mij = qM_ro[adr + k]; acc += mij * s_tmpv[j]; atomicAdd(&s_applied[j], mij * vi); k++; }
           atomicAdd(&s_applied[i], acc);
         }
         WSYNC();
@@ -2037,8 +2127,11 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
       }
       if (DIAGM) { for (int d = lane; d < nv; d += 64) s_asmooth[d] *= s_qLDinv[d]; }
       else {
+        if (level_solves) solve_trees_levels(s_asmooth, s_qLD, s_qLDinv, s_anc_i, s_dofMadr_i, nv, M.nM, lane);
+        else {
         for (int t = 0; t < M.ntree; t++) if (tree_dofnum[t] >= MJH_WAVE_TREE_MIN) solve_tree_wave(s_asmooth, s_qLD, s_qLDinv, s_anc_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t], M.nM, nv, lane);
         for (int t = lane; t < M.ntree; t += 64) if (tree_dofnum[t] < MJH_WAVE_TREE_MIN) solve_tree(s_asmooth, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t]);
+        }
       }
       WSYNC();
       niter = 0;
@@ -2046,7 +2139,7 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
       if (pre) {   // hand-over to mjh_solve_kernel / the PH_POST launch
         int* meta = (int*)(gs + L.g_meta);
         for (int d = lane; d < nv; d += 64) { gs[L.g_qvel + d] = s_qvel[d]; gs[L.g_smooth + d] = s_smooth[d]; if (nefc == 0) gs[L.g_qacc + d] = s_asmooth[d]; }
-        for (int i = lane; i < M.nM; i += 64) gs[L.g_qM + i] = s_qM[i];
+        if (DIAGM) for (int i = lane; i < M.nM; i += 64) gs[L.g_qM + i] = s_qM[i];      // (articulated models: written by the CRBA)
         if (lane == 0) { meta[0] = nefc == 0 ? 0 : nblk; meta[1] = nfixblk; meta[2] = nefc; meta[3] = ncon; meta[4] = flags; meta[5] = 0; meta[6] = ngrp; meta[7] = 0; }   // meta[7]: set by mjh_dense_build_kernel when the dense solver takes this env
         if (nefc == 0) return;
       }
@@ -2611,20 +2704,21 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
         // ---- semi-implicit Euler with implicit joint damping (mj_Euler)
         float* qint = s_qacc;
         if (M.has_damping && !(M.disableflags & MJH_DSBL_EULERDAMP)) {
-          for (int i = lane; i < M.nM; i += 64) s_qLD[i] = s_qM[i];
+          for (int i = lane; i < M.nM; i += 64) s_qLD[i] = qM_ro[i];
           for (int d = lane; d < nv; d += 64) s_tmpv[d] = s_smooth[d] + s_tmpv2[d];
           WSYNC();
           for (int d = lane; d < nv; d += 64) s_qLD[s_dofMadr_i[d]] += h * dof_damping[d];
           WSYNC();
           for (int t = 0; t < M.ntree; t++) if (tree_dofnum[t] >= MJH_WAVE_TREE_MIN) {
             factor_tree_wave(s_qLD, s_qLDinv, s_anc_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t], M.nM, nv, lane);
-            solve_tree_wave(s_tmpv, s_qLD, s_qLDinv, s_anc_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t], M.nM, nv, lane);
+            if (!level_solves) solve_tree_wave(s_tmpv, s_qLD, s_qLDinv, s_anc_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t], M.nM, nv, lane);
           }
           for (int t = lane; t < M.ntree; t += 64) if (tree_dofnum[t] < MJH_WAVE_TREE_MIN) {
             factor_tree(s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t]);
-            solve_tree(s_tmpv, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t]);
+            if (!level_solves) solve_tree(s_tmpv, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t]);
           }
           WSYNC();
+          if (level_solves) solve_trees_levels(s_tmpv, s_qLD, s_qLDinv, s_anc_i, s_dofMadr_i, nv, M.nM, lane);
           qint = s_tmpv;
         }
         for (int d = lane; d < nv; d += 64) {

@@ -589,7 +589,7 @@ def test_reference_robot_models_match_oracle(name, layout, layout_policy):
             assert np.array_equal(q[0], q[-1]) and np.array_equal(v[0], v[-1])
             np.testing.assert_allclose(d.f("qpos"), z[f"qpos_{k}"], atol=1e-9)          # oracle == golden
             # friction loss and grazing contacts make these trajectories fork over long horizons, so the engine is
-            # re-synchronised with the oracle after every check: each segment (<= 100 steps) starts from identical states
+            # re-synchronised with the oracle after every check and every 50 steps: each segment (<= 50 steps) starts from identical states
             # (tiago / hsrb4s with meshes: hulls that overlap by centimetres for good — portal refinement is
             # ill-conditioned there, fp32 and fp64 pick contact points millimetres apart)
             tol = 5e-3 if name in ("tiago_mesh", "hsrb4s_mesh") else 4e-4
@@ -605,6 +605,9 @@ def test_reference_robot_models_match_oracle(name, layout, layout_policy):
             # only compared when every oracle contact is a real penetration
             if all(c["dist"] < -1e-6 for c in d.contacts()):
                 assert st[0, 1] == int(z[f"nefc_{k}"])
+        if k in KEEP or k % 50 == 0:
+            # (also between two checks that are 100 steps apart: tiago's segment 200 -> 300 amplifies a rounding-level change of
+            #  the tree solves a hundredfold — 3.8e-4 with dof-by-dof solves, 7.7e-4 level by level, 3e-6 at step 200 for both)
             e.set_state(qpos=np.tile(d.f("qpos"), (nenv, 1)), qvel=np.tile(d.f("qvel"), (nenv, 1)),
                         warmstart=np.tile(d.f("qacc_warmstart"), (nenv, 1)))
     e.close()

@@ -20,13 +20,19 @@ for k in range(1, 120):
     e.step(1, True)
 names = ["", "load state", "FK + geoms", "COM/cdof/CRBA", "factor", "collision", "row headers", "J rows + params", "B, schedule",
          "vel stage (RNE, aref)", "controller/inverse", "smooth acc", "warmstart + A_c + AR", "PGS sweeps", "checkAcc + integrate", "store"]
-out = np.zeros(16)
-for rep in range(2):
-    lib.mjh_debug_stage_cycles(e.h, 1, capi.dptr(out))
+def show(mode, title):
+    out = np.zeros(16)
+    for rep in range(2):
+        lib.mjh_debug_stage_cycles(e.h, mode, capi.dptr(out))
+    print(title)
+    prev = 0
+    for k in range(1, 16):
+        if out[k] == 0: continue
+        print(f"{k:2d} {names[k]:24s} +{out[k]-prev:10.0f} ticks   cum {out[k]:10.0f}")
+        prev = out[k]
+
 st = e.get_stats()
 print("nenv", nenv, "nv", m.nv, "lds", e.lds_bytes, "mean ncon %.1f nefc %.1f iter %.1f" % (st[:, 0].mean(), st[:, 1].mean(), st[:, 2].mean()))
-prev = 0
-for k in range(1, 16):
-    if out[k] == 0: continue
-    print(f"{k:2d} {names[k]:24s} +{out[k]-prev:10.0f} ticks   cum {out[k]:10.0f}")
-    prev = out[k]
+show(1, "fused kernel (one launch)")
+show(1 | 2, "launch chain: assemble launch (dense cohort)")
+show(1 | 4, "launch chain: integrate launch")
