@@ -101,29 +101,28 @@ DEV int c_plane_mesh(const float* pp, const float* pm, const float* c, const flo
   rotvecT(nl, mm, n);
   const float d0 = dot3(t, n);
   float best = 3.0e38f; int i1 = -1, i2 = -1, ipos = -1, ineg = -1;
-  for (int i = 0; i < nvert; i++) { const float di = d0 + vert[3*i]*nl[0] + vert[3*i+1]*nl[1] + vert[3*i+2]*nl[2]; if (di < best) { best = di; i1 = i; } }
+  mesh_scan(vert, nvert, [&](const int i, const float x, const float y, const float z) __attribute__((always_inline)) {
+    const float di = d0 + x*nl[0] + y*nl[1] + z*nl[2]; if (di < best) { best = di; i1 = i; } });
   if (i1 < 0 || best > margin) return 0;
   const float v1[3] = {vert[3*i1], vert[3*i1+1], vert[3*i1+2]};
   best = PLANE_MESH_EPS2;
-  for (int i = 0; i < nvert; i++) {
-    const float x = vert[3*i], y = vert[3*i+1], z = vert[3*i+2];
-    if (d0 + x*nl[0] + y*nl[1] + z*nl[2] > margin) continue;
+  mesh_scan(vert, nvert, [&](const int i, const float x, const float y, const float z) __attribute__((always_inline)) {
+    if (d0 + x*nl[0] + y*nl[1] + z*nl[2] > margin) return;
     const float e[3] = {x - v1[0], y - v1[1], z - v1[2]}, l2 = dot3(e, e);
     if (l2 > best) { best = l2; i2 = i; }
-  }
+  });
   bool posfirst = true;
   if (i2 >= 0) {
     const float e12[3] = {vert[3*i2] - v1[0], vert[3*i2+1] - v1[1], vert[3*i2+2] - v1[2]};
     float side[3];
     cross3(side, e12, nl);
     float bpos = sqrtf(PLANE_MESH_EPS2 * dot3(e12, e12)), bneg = bpos;
-    for (int i = 0; i < nvert; i++) {
-      const float x = vert[3*i], y = vert[3*i+1], z = vert[3*i+2];
-      if (d0 + x*nl[0] + y*nl[1] + z*nl[2] > margin) continue;
+    mesh_scan(vert, nvert, [&](const int i, const float x, const float y, const float z) __attribute__((always_inline)) {
+      if (d0 + x*nl[0] + y*nl[1] + z*nl[2] > margin) return;
       const float sd = (x - v1[0])*side[0] + (y - v1[1])*side[1] + (z - v1[2])*side[2];
       if (sd > bpos) { bpos = sd; ipos = i; }
       if (-sd > bneg) { bneg = -sd; ineg = i; }
-    }
+    });
     posfirst = bpos >= bneg;
   }
   const int third = (ipos >= 0 && ineg >= 0) ? (posfirst ? ipos : ineg) : (ipos >= 0 ? ipos : ineg);

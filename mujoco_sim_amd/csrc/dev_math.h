@@ -140,3 +140,30 @@ DEV int wave_sum_i(int v) {
   return v;
 }
 DEV bool wave_any(bool p) { return __ballot(p) != 0ull; }
+// maximum / minimum over the 64 lanes (uniform result).  A lane without a source in a DPP step keeps its own value.
+#define MJH_DPP_KEEP(v, ctrl, rm) __builtin_amdgcn_update_dpp(v, v, ctrl, rm, 0xf, false)
+DEV float wave_max_f(float v) {
+#define MJH_MAXSTEP(ctrl, rm) v = fmaxf(v, __builtin_bit_cast(float, MJH_DPP_KEEP(__builtin_bit_cast(int, v), ctrl, rm)))
+  MJH_MAXSTEP(0x111, 0xf); MJH_MAXSTEP(0x112, 0xf); MJH_MAXSTEP(0x114, 0xf); MJH_MAXSTEP(0x118, 0xf); MJH_MAXSTEP(0x142, 0xa); MJH_MAXSTEP(0x143, 0xc);
+#undef MJH_MAXSTEP
+  return readlane_f(v, 63);
+}
+DEV int wave_min_i(int v) {
+#define MJH_MINSTEP(ctrl, rm) v = min(v, MJH_DPP_KEEP(v, ctrl, rm))
+  MJH_MINSTEP(0x111, 0xf); MJH_MINSTEP(0x112, 0xf); MJH_MINSTEP(0x114, 0xf); MJH_MINSTEP(0x118, 0xf); MJH_MINSTEP(0x142, 0xa); MJH_MINSTEP(0x143, 0xc);
+#undef MJH_MINSTEP
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Visits the vertices of a convex hull in index order, eight at a time: the loads of a batch are issued together (a plain loop
+// waits out the full memory latency per vertex — the hulls are read from global memory, a different one per lane).
+template <class F>
+DEV void mesh_scan(const float* vert, const int nvert, F f) {
+  for (int i0 = 0; i0 < nvert; i0 += 8) {
+    float x[8], y[8], z[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int i = min(i0 + u, nvert - 1); x[u] = vert[3*i]; y[u] = vert[3*i+1]; z[u] = vert[3*i+2]; }
+#pragma unroll
+    for (int u = 0; u < 8; u++) if (i0 + u < nvert) f(i0 + u, x[u], y[u], z[u]);
+  }
+}

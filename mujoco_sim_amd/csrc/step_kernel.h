@@ -1178,6 +1178,10 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
       auto collide_round = [&](const int ip) __attribute__((always_inline)) {
         int n = 0, g1 = 0, g2 = 0; float margin = 0, gap = 0;
         float* st = s_stage;
+        CvxGeom G1, G2; bool cvx = false;
+        G1.type = G2.type = 0; G1.vert = G2.vert = nullptr; G1.nvert = G2.nvert = 0; G1.pad = G2.pad = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) { G1.mat[k] = G2.mat[k] = 0; if (k < 3) { G1.pos[k] = G2.pos[k] = 0; G1.size[k] = G2.size[k] = 0; } }
         if (ip >= 0) {
           g1 = pair_geom1[ip]; g2 = pair_geom2[ip];
           st = s_stage + pair_stageadr[ip] * RAW_STRIDE;
@@ -1214,7 +1218,7 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
             } else if (EXTRA && pair_is_convex(t1, t2)) {
               const Tab<int> geom_dataid{M.I, M.o_geom_dataid}, mesh_vertadr{M.I, M.o_mesh_vertadr}, mesh_vertnum{M.I, M.o_mesh_vertnum};
               const Tab<float> mesh_vert{M.F, M.o_mesh_vert};
-              CvxGeom G1, G2;
+              cvx = true;
               G1.type = t1; G2.type = t2; G1.vert = G2.vert = nullptr; G1.nvert = G2.nvert = 0;
               if (t1 == MJH_GEOM_MESH) { const int id = geom_dataid[g1]; G1.vert = mesh_vert + 3 * mesh_vertadr[id]; G1.nvert = mesh_vertnum[id]; }
               if (t2 == MJH_GEOM_MESH) { const int id = geom_dataid[g2]; G2.vert = mesh_vert + 3 * mesh_vertadr[id]; G2.nvert = mesh_vertnum[id]; }
@@ -1222,10 +1226,11 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
               for (int k = 0; k < 3; k++) { G1.pos[k] = p1[k]; G2.pos[k] = p2[k]; G1.size[k] = z1[k]; G2.size[k] = z2[k]; }
 #pragma unroll
               for (int k = 0; k < 9; k++) { G1.mat[k] = m1[k]; G2.mat[k] = m2[k]; }
-              n = c_convex(G1, G2, margin, st);
             }
           }
         }
+        // generic convex pairs (dev_convex.h): the lanes run the portal algorithm on their pairs, the wave serves their mesh scans
+        if constexpr (EXTRA) { if (wave_any(cvx)) { const int nc = c_convex_wave(G1, G2, margin, st, cvx, lane); if (cvx) n = nc; } }
         const int incl = wave_incl_scan_i(n, lane);
         const int total = __shfl(incl, 63);
         const int first = conbase + incl - n;
@@ -1244,33 +1249,43 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
         conbase += total;
       };
       // bounding-sphere / plane-distance cull of one pair (the narrow phase repeats it; it is cheap)
-      auto survives = [&](const int ip) __attribute__((always_inline)) {
+      auto survives = [&](const int ip) __attribute__((always_inline)) {     // (branch-free: four of them are evaluated side by side)
         const int g1 = pair_geom1[ip], g2 = pair_geom2[ip];
         const float margin = fmaxf(geom_margin[g1], geom_margin[g2]);
         const int sb1 = geom_bodyid[g1], sb2 = geom_bodyid[g2];
         const unsigned r1 = (unsigned)(sb1 - sbase), r2 = (unsigned)(sb2 - sbase);
-        if ((r1 < 32u && ((slotmask >> r1) & 1u)) || (r2 < 32u && ((slotmask >> r2) & 1u))) return false;
+        const bool parked = (r1 < 32u && ((slotmask >> (r1 & 31u)) & 1u)) | (r2 < 32u && ((slotmask >> (r2 & 31u)) & 1u));
         const float tt[3] = {s_gpos[3*g2] - s_gpos[3*g1], s_gpos[3*g2+1] - s_gpos[3*g1+1], s_gpos[3*g2+2] - s_gpos[3*g1+2]};
-        if (geom_type[g1] == MJH_GEOM_PLANE) { const float nn[3] = {s_gmat[9*g1+2], s_gmat[9*g1+5], s_gmat[9*g1+8]}; return !(dot3(tt, nn) > s_p_rbound[g2] + margin); }
-        const float bound = s_p_rbound[g1] + s_p_rbound[g2] + margin;
-        return !(dot3(tt, tt) > bound * bound);
+        const float nn[3] = {s_gmat[9*g1+2], s_gmat[9*g1+5], s_gmat[9*g1+8]};
+        const float rb2 = s_p_rbound[g2], bound = s_p_rbound[g1] + rb2 + margin;
+        const bool far_plane = dot3(tt, nn) > rb2 + margin, far_sphere = dot3(tt, tt) > bound * bound;
+        return !parked & !(geom_type[g1] == MJH_GEOM_PLANE ? far_plane : far_sphere);
       };
       // Many candidate pairs (64 free boxes: 2080): the divergent narrow phase would run once per 64 pairs whether or not
       // anything is close; first compact the pairs that pass the cull (pair order is preserved, so is the contact order),
       // then run the narrow phase on full rounds of survivors.  The list lives in dof vectors that are unused until the
       // velocity stage (smooth, asmooth, passive, bias: contiguous).
-      const int listcap = (4 * (((nv + 3) / 4) * 4)) & ~63;
+      // (many-body layout: in the per-block matrix pool of the env's scratch slice instead, dead until the solver starts — it
+      //  holds every pair, so the divergent narrow phase runs once over ALL survivors: PR2 + objects, 1760 pairs, 47 survivors
+      //  spread over five 384-pair chunks)
+      const int poolcap = NROW == 8 ? (max(M.maxblk, 1) * BLKQ_STRIDE) & ~63 : 0;
+      const bool pool_list = NROW == 8 && poolcap >= M.npair;
+      const int listcap = pool_list ? poolcap : (4 * (((nv + 3) / 4) * 4)) & ~63;
       if (M.npair > 64 && listcap >= 64) {
-        int* list = (int*)s_smooth;
+        int* list = pool_list ? (int*)s_blkq : (int*)s_smooth;
         for (int c0 = 0; c0 < M.npair; c0 += listcap) {
           const int c1 = min(c0 + listcap, M.npair);
           int cnt = 0;
-          for (int base = c0; base < c1; base += 64) {
-            const int ip = base + lane;
-            const bool sv = ip < c1 && survives(ip);
-            const unsigned long long mk = __ballot(sv);
-            if (sv) list[cnt + __popcll(mk & ((1ull << lane) - 1ull))] = ip;
-            cnt += __popcll(mk);
+          for (int base = c0; base < c1; base += 256) {       // four rounds of 64 pairs at a time: their table loads overlap
+            bool sv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int ip = base + 64 * u + lane; sv[u] = survives(min(ip, c1 - 1)) & (ip < c1); }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const unsigned long long mk = __ballot(sv[u]);
+              if (sv[u]) list[cnt + __popcll(mk & ((1ull << lane) - 1ull))] = base + 64 * u + lane;
+              cnt += __popcll(mk);
+            }
           }
           WSYNC();
           for (int b2 = 0; b2 < cnt; b2 += 64) collide_round(b2 + lane < cnt ? list[b2 + lane] : -1);

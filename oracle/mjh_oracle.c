@@ -765,7 +765,15 @@ static void cvx_support(const cvx_geom* g, const double* dir, double* out) {
   rotvec(out, g->mat, pl);
   for (int k = 0; k < 3; k++) out[k] += g->pos[k] + g->pad * dir[k];
 }
+/* test hook: support-mapping evaluations (what the narrow phase costs), total and the maximum over the pairs since the last reset */
+static long mpr_calls_total = 0, mpr_calls_pair = 0, mpr_calls_max = 0, mpr_pairs = 0;
+long orc_debug_mpr_calls(int what, int reset) {
+  long v = what == 0 ? mpr_calls_total : what == 1 ? mpr_calls_max : mpr_pairs;
+  if (reset) { mpr_calls_total = 0; mpr_calls_max = 0; mpr_pairs = 0; }
+  return v;
+}
 static void mpr_support(const cvx_geom* g1, const cvx_geom* g2, const double* dir, mpr_pt* p) {
+  mpr_calls_total++; mpr_calls_pair++;
   double nd[3] = {-dir[0], -dir[1], -dir[2]};
   cvx_support(g1, dir, p->a); cvx_support(g2, nd, p->b);
   for (int k = 0; k < 3; k++) p->v[k] = p->a[k] - p->b[k];
@@ -891,7 +899,10 @@ static int c_convex(const cvx_geom* g1, const cvx_geom* g2, double margin, rawco
   cvx_geom a = *g1, b = *g2;
   a.pad = b.pad = 0.5 * margin;
   double depth, dir[3], pos[3];
-  if (!mpr_penetration(&a, &b, &depth, dir, pos)) return 0;
+  mpr_calls_pair = 0; mpr_pairs++;
+  const int hit = mpr_penetration(&a, &b, &depth, dir, pos);
+  if (mpr_calls_pair > mpr_calls_max) mpr_calls_max = mpr_calls_pair;
+  if (!hit) return 0;
   out->dist = margin - depth; copyv(out->pos, pos, 3); copyv(out->n, dir, 3);
   return 1;
 }
