@@ -11,13 +11,19 @@ e.load_tables(ms.boxes_randomize(m, 0, nenv, jitter=0.01))      # the D3-exact p
 e.step(200); e.synchronize()
 names = ["", "load state", "FK + geoms", "COM/cdof/CRBA", "factor", "collision", "row headers", "J rows + params", "B, schedule",
          "vel stage (RNE, aref)", "controller/inverse", "smooth acc", "warmstart + A_c + AR", "PGS sweeps", "checkAcc + integrate", "store"]
-out = np.zeros(16)
-for rep in range(2):
-    capi.load().mjh_debug_stage_cycles(e.h, 0, capi.dptr(out))
+def show(mode, title):
+    out = np.zeros(16)
+    for rep in range(2):
+        capi.load().mjh_debug_stage_cycles(e.h, mode, capi.dptr(out))
+    print(title)
+    prev = 0
+    for k in range(1, 16):
+        if out[k] == 0: continue
+        print(f"{k:2d} {names[k]:24s} +{out[k]-prev:12.0f} ticks   cum {out[k]:12.0f}")
+        prev = out[k]
+
 st = e.get_stats()
 print("nenv", nenv, "mean ncon %.1f nefc %.1f iter %.1f" % (st[:,0].mean(), st[:,1].mean(), st[:,2].mean()))
-prev = 0
-for k in range(1, 16):
-    if out[k] == 0: continue
-    print(f"{k:2d} {names[k]:24s} +{out[k]-prev:12.0f} ticks   cum {out[k]:12.0f}")
-    prev = out[k]
+show(0, "fused kernel (one launch)")
+show(2, "launch chain: assemble launch")
+show(4, "launch chain: integrate launch")
