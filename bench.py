@@ -568,6 +568,7 @@ def main():
     ap.add_argument("--pack", type=int, default=0, help="environments per wavefront for the small-model configs (0: the config's default — C3 4, C5 2, others 1)")
     ap.add_argument("--pen-half", type=float, default=0.0, help="s24d: half width of the pen in metres (default 0.14; S24 itself is 0.175)")
     ap.add_argument("--maxcon", type=int, default=0, help="override the scene's contact capacity per env; 0 = scene default")
+    ap.add_argument("--pgs-row-order", action="store_true", help="Gauss-Seidel in mj_solPGS's own row order on the device (mjh_set_pgs_row_order): what exactness of the ORDER costs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-second-window", action="store_true", help="skip the second timed window (the other mj_inverse variant)")
@@ -613,6 +614,9 @@ def main():
     import mujoco_sim_amd as ms
 
     stream = torch.cuda.current_stream()
+    if args.pgs_row_order:
+        from mujoco_sim_amd import capi
+        capi.load().mjh_set_pgs_row_order(1)
     w = WORKLOADS[args.config](ms, args, rank, local_rank, stream.cuda_stream)
     eng, model, nenv = w.eng, w.model, w.nenv
     if args.cohorts > 0 or w.cohorts > 0:
@@ -716,7 +720,8 @@ def main():
                    "mean_ncon": mean_ncon, "max_ncon": int(st[:, 0].max()), "mean_nefc": float(st[:, 1].mean()) / w.pack,
                    "max_nefc": int(st[:, 1].max()), "mean_solver_iter": float(st[:, 2].mean()),
                    "overflow_envs": int((st[:, 3] & 3 != 0).sum()), "reset_envs": int((st[:, 3] & 4 != 0).sum()),
-                   "lds_bytes_per_env": eng.lds_bytes, "contact_capacity": int(model.maxcon), **w.extra_config()},
+                   "lds_bytes_per_env": eng.lds_bytes, "contact_capacity": int(model.maxcon),
+                   "pgs_order": ["independent pairs / groups of blocks", "contact patches", "mj_solPGS row order"][eng.solver_order()], **w.extra_config()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "mjh_step_kernel" + ((" (+ mjh_dense_build_kernel [MFMA] + mjh_dense_solve_kernel: assemble -> build -> solve -> integrate chain of the many-body layout)" if eng.dense_solver() else

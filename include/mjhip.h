@@ -515,8 +515,15 @@ const mjh_model* mjh_engine_model(const mjh_engine*);
 int mjh_lds_bytes(const mjh_engine*);  /* dynamic LDS per env (= per workgroup) */
 /* Gauss-Seidel visiting order of the engine's solver sweeps (any order is a valid mj_solPGS iteration; they agree at
  * convergence): 0 = independent pairs / groups of constraint blocks, 1 = contact patches (small free-body models: up to 16
- * rows between the same two bodies are solved as one unit, mujoco_sim_amd/csrc/patch_pgs.h). */
+ * rows between the same two bodies are solved as one unit, mujoco_sim_amd/csrc/patch_pgs.h), 2 = the constraint rows in their
+ * own order, one block after the other: the order mj_solPGS itself walks (mjh_set_pgs_row_order). */
 int mjh_solver_order(const mjh_engine*);
+/* Gauss-Seidel order of engines created afterwards (process-wide; no reference counterpart).  0 (default): the engine picks an
+ * order that exposes independent work (pairs / groups of blocks without a common kinematic tree, or contact patches).  1: the rows
+ * of efc_* in their own order, exactly as mj_solPGS (engine_solver.c, reached through mj_step2, mj_main.cpp:108) visits them — no
+ * blocks side by side, several times slower; for users who need the reference's iterates rather than its fixed point.  A PGS
+ * stopped at the iteration cap depends on the order: BASELINE.md section 3 has the size of that effect. */
+void mjh_set_pgs_row_order(int on);
 /* 1: mjh_step solves the environments of this engine whose rows fit with the dense row-space solver (AR = J M^-1 J^T on the matrix
  * cores, column sweeps: csrc/dense_pgs.h) — articulated models in the many-body layout; same rows, same visiting order, same results up
  * to fp32 rounding as the block solver (MJH_DENSE=0 turns it off) */

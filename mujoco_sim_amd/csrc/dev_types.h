@@ -45,6 +45,7 @@ struct DModel {
   // is dead once the solver starts, from the position-stage arrays to the base-row storage), its size, and of the two live
   // tables next to it: one descriptor per patch, one descriptor per (step, 16-lane row) of the sweep schedule
   int patch, pool, pool_floats, pdesc, pslot;
+  int pgs_row_order;   // 1: Gauss-Seidel visits the constraint rows in their own order, one block after the other (mj_solPGS's order; mjh_set_pgs_row_order)
   // dense row-space solver of the many-body layout (dense_pgs.h): on / off, row capacity (a multiple of 64, <= 256), nv padded to 16
   int dense, dense_cap, dense_nvs;
   int dense_min_iter;   // a cohort takes the dense form while one of its envs swept at least this often in the step its launch order was built from (the host decides per launch)

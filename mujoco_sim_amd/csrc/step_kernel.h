@@ -1629,7 +1629,15 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
     int ngrp = 0;
     bool patch_order = false;    // contact-patch sweep (patch_pgs.h): it builds its own schedule
     if constexpr (DIAGM && NROW <= 2) patch_order = M.patch != 0;
-    if (!patch_order) {
+    if (!patch_order && M.pgs_row_order) {
+      // mj_solPGS's own order (mjh_set_pgs_row_order): block after block as the rows were made, nothing side by side
+      for (int i = lane; i < nblk; i += 64) {
+        s_order_i[i] = i;
+        if (NROW <= 2) { s_sched_i[2*i] = i; s_sched_i[2*i+1] = -1; } else if (nblk > 64) s_sched_i[i] = i;
+      }
+      if (NROW > 2 && nblk > 64 && lane == 0) s_sched_i[nblk] = nblk;
+      ngrp = nblk;
+    } else if (!patch_order) {
       if (nblk > 64) {
         // many-block models: groups of up to 4 mutually independent blocks (the many-body solver puts one block on each
         // 16-lane row of the wave; sequential sweeps just follow the order).  Same rule as the oracle: two-tree blocks

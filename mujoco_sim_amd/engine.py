@@ -308,7 +308,7 @@ class Engine:
         return self.lib.mjh_lds_bytes(self.h)
 
     def solver_order(self):
-        """0: independent pairs / groups of blocks, 1: contact patches (mjh_solver_order)"""
+        """0: independent pairs / groups of blocks, 1: contact patches, 2: mj_solPGS's row order (mjh_solver_order)"""
         return self.lib.mjh_solver_order(self.h)
 
     def dense_solver(self):

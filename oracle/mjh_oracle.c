@@ -1430,9 +1430,17 @@ static int m_patch_order(const mjh_model* m) {
   for (int i = 0; i < m->nv; i++) if (m->dof_frictionloss[i] > 0) return 0;
   return 1;
 }
+/* Models whose sweeps are sequential on the device whatever the order (more than 32 dofs and a kinematic tree of more than 16:
+ * articulated robots — one block at a time on a whole wavefront, or the dense row-space solver) are solved in mj_solPGS's own row
+ * order by default: there it costs nothing.  Same rule as engine.hip (derive_device_model: M.pgs_row_order). */
+static int m_row_order(const mjh_model* m) {
+  if (m->nv <= 32) return 0;
+  for (int t = 0; t < m->ntree; t++) if (m->tree_dofnum[t] > 16) return 1;
+  return 0;
+}
 static int pgs_order(const orc_data* d, int* order) {
   int nefc = d->nefc, nblk = 0;
-  if (g_pgs_row_order) { for (int i = 0; i < nefc; i++) order[i] = i; return nefc; }
+  if (g_pgs_row_order || m_row_order(d->m)) { for (int i = 0; i < nefc; i++) order[i] = i; return nefc; }
   int* bstart = d->scr_int;                       /* (nefc + 1) * 5 ints; the sequences below take the next (nefc + 1) * 6 */
   int *bnum = bstart + nefc + 1, *bt1 = bnum + nefc + 1, *bt2 = bt1 + nefc + 1, *used = bt2 + nefc + 1;
   for (int i = 0; i < nefc;) {

@@ -272,7 +272,7 @@ def test_c4_pr2_spawn_destroy_schedule_matches_the_oracle(layout, lib):
         jq, bj, bd = m.array("jnt_qposadr"), m.array("body_jntadr"), m.array("body_dofadr")
         nrobot = int(min(bd[b] for b in slots))                        # dofs in front of the object pool
         order = [rng.permutation(len(slots)) for _ in range(nenv)]
-        worst = 0.0; step = 0
+        worst = 0.0; step = 0; forked = 0
         for rnd in range(7):
             for i, d in enumerate(ds):
                 if rnd < 5:                                           # spawn next to the robot, with a twist
@@ -288,21 +288,27 @@ def test_c4_pr2_spawn_destroy_schedule_matches_the_oracle(layout, lib):
                     b = slots[int(order[i][rnd - 5])]
                     e.set_slot_active(b, False, env0=i, n=1)
                     mask[i] |= 1 << (b - sbase); d.L.orc_set_slot_mask(d.d, mask[i])
+            same = np.ones(nenv, dtype=bool)          # the env's contact-set history equals the oracle's over this segment
             for k in range(25):
                 step += 1
                 cmd = robot_command(m, step)
                 e.set_cmd(ddq=np.tile(cmd, (nenv, 1))); e.step(1, True)
                 for d in ds:
                     d.f("ddq")[:] = cmd; d.step(1, 1)
+                sk = e.get_stats()
+                same &= (sk[:, 0] == np.array([d.i("ncon") for d in ds])) & (sk[:, 1] == np.array([d.i("nefc") for d in ds]))
             _, q, v, _ = e.get_state(); st = e.get_stats()
             assert (st[:, 3] == 0).all() and all(d.i("warn") == 0 for d in ds), (rnd, st[:, 3])
             oq = np.array([d.f("qpos") for d in ds]); ov = np.array([d.f("qvel") for d in ds])
             err = np.abs(q - oq).max(axis=1)
-            worst = max(worst, float(err.max()))
-            assert (err < 5e-3).sum() >= nenv - 1 and err.max() < 0.2, (rnd, err)
+            worst = max(worst, float(err[same].max())) if same.any() else worst
+            forked += int((~same).sum())
+            # an env is held to the tolerance as long as it sees the oracle's contacts; one whose contact history differs in the
+            # segment (a round object touching down a step earlier or later) is only required to stay in the neighbourhood
+            assert (err[same] < 5e-3).all() and err.max() < 0.5, (rnd, err, same)
             fi = e.get_field("qfrc_inverse")
             for i, d in enumerate(ds):
-                if err[i] < 5e-3:
+                if same[i]:
                     # what read() hands to ros_control: the ROBOT's joints (the pool objects' free dofs carry impact forces whose
                     # inverse is a difference of large numbers)
                     ref = d.f("qfrc_inverse")[:nrobot]
@@ -312,7 +318,8 @@ def test_c4_pr2_spawn_destroy_schedule_matches_the_oracle(layout, lib):
                         assert (v[i, bd[b]:bd[b] + 6] == 0).all() and (ov[i, bd[b]:bd[b] + 6] == 0).all()
             e.set_state(qpos=oq, qvel=ov, warmstart=np.array([d.f("qacc_warmstart") for d in ds]))
         assert max(d.i("ncon") for d in ds) >= 16
-        print(f"C4 spawn/destroy schedule vs oracle (layout {layout}): worst |dqpos| over 7 segments {worst:.2e}")
+        assert forked <= 3, forked                    # of 28 (env, segment) pairs
+        print(f"C4 spawn/destroy schedule vs oracle (layout {layout}): worst |dqpos| over 7 segments {worst:.2e}; {forked} of 28 (env, segment) pairs saw a different contact history")
         e.close()
     finally:
         lib.mjh_set_layout_policy(0)
