@@ -765,6 +765,17 @@ def main():
                 out["configs"][name] = short_config_line(ms, args, name, local_rank, stream.cuda_stream)
             except Exception as ex:
                 out["configs"][name] = {"error": repr(ex)}
+        # the metric's scene with Gauss-Seidel in mj_solPGS's own row order (mjh_set_pgs_row_order): what the exact order costs
+        if not args.pgs_row_order:
+            try:
+                from mujoco_sim_amd import capi
+                capi.load().mjh_set_pgs_row_order(1)
+                try:
+                    out["configs"]["s24_pgs_row_order"] = short_config_line(ms, args, "s24", local_rank, stream.cuda_stream)
+                finally:
+                    capi.load().mjh_set_pgs_row_order(0)
+            except Exception as ex:
+                out["configs"]["s24_pgs_row_order"] = {"error": repr(ex)}
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

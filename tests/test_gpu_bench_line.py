@@ -42,7 +42,7 @@ def test_driver_line_has_everything_the_contract_names():
     assert cb["env_steps_1thread"] >= 256 and cb["value"] > 0 and abs(cb["mean_ncon"] - cb["gpu_mean_ncon_same_envs"]) < 4
     ll = r["literal_loop"]
     assert ll["value"] > 1e5 and ll["fused_step_with_per_step_read_write"]["value"] >= ll["value"] * 0.8
-    assert set(r["configs"]) == {"s24d", "c2", "c3", "c4", "c5"}
+    assert set(r["configs"]) == {"s24d", "c2", "c3", "c4", "c5", "s24_pgs_row_order"}
     for name, line in r["configs"].items():
         assert "error" not in line, (name, line)
         assert line["value"] > 0 and line["steps"] >= 6 and line["roofline_frac"] > 0 and line["overflow_envs"] <= 0.02 * line["envs"], (name, line)
