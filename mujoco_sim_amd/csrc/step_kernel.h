@@ -165,6 +165,47 @@ DEV void factor_tree_wave(float* qLD, float* qLDinv, const int* anc, const int* 
     __syncthreads();
   }
 }
+// Short trees (fewer than MJH_WAVE_TREE_MIN dofs: the arms of C3, free bodies beside a robot), four at a time: tree t of a
+// group on the 16-lane row t & 3 of the wave, its dofs from the leaf up in lockstep with the other rows; lanes of a row = the
+// ancestors q of the current dof (depth <= 10), the pairs (p, q) for all p with their loads issued together.  Same arithmetic
+// per entry as factor_tree (bit-identical), a quarter of its dependent LDS round trips.
+template <int PMAX>      // deepest dof the step handles
+DEV void factor_short_step(float* qLD, float* qLDinv, const int* anc, const int* dof_Madr, const bool on, const int k, const int nM, const int nv, const int q) {
+  const int Mk = dof_Madr[k], d = on ? (k + 1 < nv ? dof_Madr[k + 1] : nM) - Mk - 1 : 0;
+  const float dk = qLD[Mk], aq = qLD[Mk + min(q, d)];
+  float ap[PMAX], tg[PMAX]; int am[PMAX];
+#pragma unroll
+  for (int p = 1; p <= PMAX; p++) { const int pp = min(p, d); ap[p-1] = qLD[Mk + pp]; am[p-1] = ANC_MADR(anc[Mk + pp]); }
+  const float inv = 1.0f / dk;
+#pragma unroll
+  for (int p = 1; p <= PMAX; p++) { const bool v = p <= d && q >= p && q <= d; tg[p-1] = qLD[v ? am[p-1] + (q - p) : Mk]; }
+#pragma unroll
+  for (int p = 1; p <= PMAX; p++) { const bool v = p <= d && q >= p && q <= d; if (v) qLD[am[p-1] + (q - p)] = tg[p-1] - ap[p-1] * inv * aq; }
+  if (on && q <= d) qLD[Mk + q] = aq * inv;
+  if (on && q == 1) qLDinv[k] = inv;
+}
+DEV void factor_trees_short(float* qLD, float* qLDinv, const int* anc, const int* dof_Madr, const Tab<int>& tree_dofadr, const Tab<int>& tree_dofnum,
+                            const int ntree, const int nM, const int nv, const int lane) {
+  const int q = 1 + (lane & 15), row = lane >> 4;
+  for (int t0 = 0; t0 < ntree; t0 += 4) {
+    const int t = t0 + row;
+    int adr = 0, num = 0;
+    if (t < ntree) { num = tree_dofnum[t]; adr = tree_dofadr[t]; if (num >= MJH_WAVE_TREE_MIN) num = 0; }
+    int steps = 0;
+    { const int n0 = __builtin_amdgcn_readlane(num, 0), n1 = __builtin_amdgcn_readlane(num, 16), n2 = __builtin_amdgcn_readlane(num, 32), n3 = __builtin_amdgcn_readlane(num, 48);
+      steps = max(max(n0, n1), max(n2, n3)); }
+    for (int st = 0; st < steps; st++) {
+      const bool on = st < num;
+      const int k = on ? adr + num - 1 - st : 0;
+      // (a dof of a short tree with `num` dofs has at most num - 1 ancestors: the later steps of a group are shallow)
+      const int deep = steps - 1 - st;
+      if (deep <= 3) factor_short_step<3>(qLD, qLDinv, anc, dof_Madr, on, k, nM, nv, q);
+      else if (deep <= 6) factor_short_step<6>(qLD, qLDinv, anc, dof_Madr, on, k, nM, nv, q);
+      else factor_short_step<MJH_WAVE_TREE_MIN - 2>(qLD, qLDinv, anc, dof_Madr, on, k, nM, nv, q);
+      __syncthreads();
+    }
+  }
+}
 // Solves with the factor, lanes = dofs (nv <= 128: two per lane), level by level instead of dof by dof: a dof with d ancestors
 // sits at depth d, and all dofs of one depth are independent of each other.  One wavefront.
 struct TreeLanes { int Mk[2], dep[2]; };
@@ -870,9 +911,10 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
   // and read the shared tables instead (their LDS space is not allocated)
   const int* s_dofpar_i = DIAGM ? (dof_parentid + 0) : (const int*)s_dofpar; const int* s_dofMadr_i = DIAGM ? (dof_Madr + 0) : (const int*)s_dofMadr;
   int* s_anc_i = (int*)s_anc;
-  // solves with the factor level by level (all trees at once) for models with a long kinematic tree and at most 128 dofs
-  bool level_solves = false;
-  if (!DIAGM && nv <= 128) for (int t = 0; t < M.ntree; t++) level_solves |= tree_dofnum[t] >= MJH_WAVE_TREE_MIN;
+  // articulated models with at most 128 dofs: solves with the factor level by level (all trees at once), short trees factored four at a time
+  const bool level_solves = !DIAGM && nv <= 128;
+  // ... up to four trees (one group of factor_trees_short: C3's four arms); more of them are better off one per lane
+  const bool short_rows = level_solves && M.ntree <= 4;
   // M after the factorisation: articulated models in the many-body layout keep only the factor in LDS (it is built in M's place)
   const float* qM_ro = (NROW == 8 && !DIAGM) ? gs + L.g_qM : s_qM;
   float* s_stage = s_J;  // raw-contact staging aliases the (not yet built) base-row storage
@@ -1164,7 +1206,8 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
     if (DIAGM) { for (int d = lane; d < nv; d += 64) s_qLDinv[d] = 1.0f / s_qM[s_dofMadr_i[d]]; }   // every tree: M is diagonal (single free body about its COM)
     else {
       for (int t = 0; t < M.ntree; t++) if (tree_dofnum[t] >= MJH_WAVE_TREE_MIN) factor_tree_wave(s_qLD, s_qLDinv, s_anc_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t], M.nM, nv, lane);
-      for (int t = lane; t < M.ntree; t += 64) if (tree_dofnum[t] < MJH_WAVE_TREE_MIN) factor_tree(s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t]);
+      if (short_rows) factor_trees_short(s_qLD, s_qLDinv, s_anc_i, s_dofMadr_i, tree_dofadr, tree_dofnum, M.ntree, M.nM, nv, lane);
+      else for (int t = lane; t < M.ntree; t += 64) if (tree_dofnum[t] < MJH_WAVE_TREE_MIN) factor_tree(s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t]);
     }
     WSYNC();
     }   // !post
@@ -1590,16 +1633,16 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
         const float* J = s_J + BLK_JOFF(hd[0]) + jb; float* B = s_B + BLK_JOFF(hd[0]) + jb;
         if (jb >= ((hd[0] >> 8) & 15)) { for (int k = 0; k < rowW; k++) B[SL*k] = 0; continue; }
         ROW_TREES(hd[2], hd[3]);
-        float* x = lds + M.scratch_off + lane * rowW;
-        for (int k = 0; k < rowW; k++) x[k] = J[SL*k];
+        float* x = lds + M.scratch_off + lane;          // entry k of the lane's vector at x[k P]: consecutive lanes on consecutive banks
+        for (int k = 0; k < rowW; k++) x[k * P] = J[SL*k];
         if (dense_pre) {
-          solve_tree_lt(x - a1, s_qLD, s_dofpar_i, s_dofMadr_i, a1, n1, 1);
-          if (n2 > 0) solve_tree_lt(x + (n1 - a2), s_qLD, s_dofpar_i, s_dofMadr_i, a2, n2, 1);
+          solve_tree_lt(x - a1 * P, s_qLD, s_dofpar_i, s_dofMadr_i, a1, n1, P);
+          if (n2 > 0) solve_tree_lt(x + (n1 - a2) * P, s_qLD, s_dofpar_i, s_dofMadr_i, a2, n2, P);
         } else {
-          solve_tree(x - a1, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a1, n1, 1);
-          if (n2 > 0) solve_tree(x + (n1 - a2), s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a2, n2, 1);
+          solve_tree(x - a1 * P, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a1, n1, P);
+          if (n2 > 0) solve_tree(x + (n1 - a2) * P, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, a2, n2, P);
         }
-        for (int k = 0; k < rowW; k++) B[SL*k] = x[k];
+        for (int k = 0; k < rowW; k++) B[SL*k] = x[k * P];
       }
       WSYNC();
     } else if (!DIAGM) {
@@ -2736,7 +2779,8 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
             factor_tree_wave(s_qLD, s_qLDinv, s_anc_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t], M.nM, nv, lane);
             if (!level_solves) solve_tree_wave(s_tmpv, s_qLD, s_qLDinv, s_anc_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t], M.nM, nv, lane);
           }
-          for (int t = lane; t < M.ntree; t += 64) if (tree_dofnum[t] < MJH_WAVE_TREE_MIN) {
+          if (short_rows) factor_trees_short(s_qLD, s_qLDinv, s_anc_i, s_dofMadr_i, tree_dofadr, tree_dofnum, M.ntree, M.nM, nv, lane);
+          else for (int t = lane; t < M.ntree; t += 64) if (tree_dofnum[t] < MJH_WAVE_TREE_MIN) {
             factor_tree(s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t]);
             if (!level_solves) solve_tree(s_tmpv, s_qLD, s_qLDinv, s_dofpar_i, s_dofMadr_i, tree_dofadr[t], tree_dofnum[t]);
           }
