@@ -528,8 +528,9 @@ def short_config_line(ms, args, name, device, stream):
 def literal_loop_line(w, steps):
     """The LITERAL loop body of the reference (mj_main.cpp:82-112) on the main workload's engine: per step mjh_step1 ->
     MjHWInterface::read of env 0 (mjh_inverse + joint state to the host: a host synchronisation) -> controller_manager ->
-    MjHWInterface::write of env 0 (command from the host) -> mjh_step2.  Three launches and two small transfers per step, no
-    cohort overlap: what a ROS node that keeps the per-step hand-off gets; the fused mjh_step is what `value` measures."""
+    MjHWInterface::write of env 0 (command from the host) -> mjh_step2.  Two launches per cohort and two small transfers per step;
+    only env 0's cohort waits for the host (include/mjhip.h, launch scheduling): what a ROS node that keeps the per-step hand-off
+    gets; the fused mjh_step is what `value` measures."""
     e = w.eng
     cmd = np.zeros((1, e.nv))
 

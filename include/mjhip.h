@@ -430,9 +430,13 @@ int mjh_debug_stop_at(mjh_engine*, int stage, int with_inverse);
 /* ---- launch scheduling (no reference counterpart: the reference steps one mjData on one CPU thread,
  * mj_main.cpp:82-112).  Environments are independent, so mjh_step() may split them into `n` cohorts
  * (contiguous env ranges, 1..8), each stepped on its own HIP stream: the low-occupancy tail of one cohort's
- * step kernel then overlaps the bulk of another's, across consecutive mjh_step calls too.  The caller's
- * stream forks into the cohort streams inside mjh_step and is joined again by the next call of any other
- * entry point, so results and ordering seen through this API do not depend on `n`.  Within a launch the
+ * step kernel then overlaps the bulk of another's, across consecutive mjh_step calls too.  The split entry
+ * points of the reference's loop (mjh_step1 / mjh_inverse / mjh_step2) are issued per cohort as well, and the
+ * two calls that loop makes for ONE robot in between — mjh_get_joint_state and mjh_set_cmd (MjHWInterface::read /
+ * write) — on an env range inside one cohort are ordered on that cohort's stream only: the host waits for that
+ * cohort, the others keep stepping.  The caller's stream forks into the cohort streams inside these calls and is
+ * joined again by the next call of any other entry point (and by a ranged call that spans cohorts), so results and
+ * ordering seen through this API do not depend on `n` (tests/test_gpu_round3.py: bitwise).  Within a launch the
  * envs are dispatched longest-solver-job first (order rebuilt on the device every MJH_ORDER_EVERY-th step, default 8).
  * Default n: 1 below 1024 envs, else 2 for the fused step and 3 (from 1536 envs) for the three-launch step of the many-body layout
  * (MJH_COHORTS overrides it for engines created afterwards). */

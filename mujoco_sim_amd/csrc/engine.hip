@@ -582,7 +582,35 @@ static int flush_step1(mjh_engine* e);
 
 // full-range launch on the caller's stream in longest-job-first order (split API: step1 | inverse | step2 | forward);
 // `resort` rebuilds the order from the previous step's solver statistics, otherwise the last order is reused
+// With cohorts (mjh_set_cohorts > 1) the range is issued cohort by cohort on the cohort streams, like mjh_step: the reference's loop
+// reads and commands ONE environment between the calls (MjHWInterface::read / write, mj_main.cpp:86-106), and only that environment's
+// cohort has to wait for the host (mjh_get_joint_state / mjh_set_cmd on a range inside one cohort touch that cohort's stream only).
 static int launch_lpt(mjh_engine* e, int ph, int xflags, bool resort) {
+  const int G = e->ncohort > 1 && e->nenv >= 64 * e->ncohort ? e->ncohort : 1;
+  static const bool split_cohorts = !(getenv("MJH_SPLIT_COHORTS") && atoi(getenv("MJH_SPLIT_COHORTS")) == 0);
+  if (G > 1 && split_cohorts) {
+    if (e->lpt && e->nenv >= 1024 && !e->d_order) { int rc = join_cohorts(e); if (!rc) rc = dev_alloc(e, &e->d_order, (size_t)e->nenv); if (rc) return rc; e->order_valid = false; e->order_G = -1; }
+    int rc = fork_cohorts(e);
+    if (rc) return rc;
+    StateGuard guard(&e->S);
+    const bool lpt = e->lpt && e->d_order && e->nenv >= 1024;
+    if (lpt) e->S.env_order = e->d_order;
+    static const int order_every = getenv("MJH_ORDER_EVERY") ? std::max(1, atoi(getenv("MJH_ORDER_EVERY"))) : MJH_ORDER_EVERY;
+    const bool sort = lpt && (e->order_G != G || !e->order_valid || (resort && e->order_age % order_every == 0));
+    // (the XF_FORCE exports are engine-sized arrays indexed by the row inside the launch's range: shifted to the cohort's first row)
+    float* const xb = e->S.x_bias; float* const xp = e->S.x_passive; float* const xs = e->S.x_smooth; float* const xc = e->S.x_constraint; float* const xe = e->S.x_energy;
+    for (int g = 0; g < G && !rc; g++) {
+      const int g0 = (int)((long long)e->nenv * g / G), g1 = (int)((long long)e->nenv * (g + 1) / G);
+      if (sort) hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, e->cstream[g], (const int*)e->S.stats, e->d_order, g0, g1 - g0, (int*)nullptr, 0);
+      const size_t o = (size_t)g0 * e->M.nvp;
+      e->S.x_bias = xb ? xb + o : nullptr; e->S.x_passive = xp ? xp + o : nullptr; e->S.x_smooth = xs ? xs + o : nullptr;
+      e->S.x_constraint = xc ? xc + o : nullptr; e->S.x_energy = xe ? xe + 2 * (size_t)g0 : nullptr;
+      rc = launch_on(e, e->cstream[g], g0, g1 - g0, 1, ph, xflags);
+    }
+    if (sort) { e->order_G = G; e->order_valid = true; }
+    return rc;
+  }
+  { int rc = join_cohorts(e); if (rc) return rc; }
   if (e->lpt && e->nenv >= 1024) {
     if (!e->d_order) { int rc = dev_alloc(e, &e->d_order, (size_t)e->nenv); if (rc) return rc; e->order_valid = false; }
     if (resort || !e->order_valid) {
@@ -601,12 +629,11 @@ static int launch_pd(mjh_engine* e, hipStream_t st, int env0, int n);
 // effects on the stream is the order of the calls.
 static int flush_step1(mjh_engine* e) {
   e->step1_pending = false;
-  int rc = join_cohorts(e);
-  return rc ? rc : launch_lpt(e, PH_STEP1, XF_FORCE, true);
+  return launch_lpt(e, PH_STEP1, XF_FORCE, true);
 }
 extern "C" int mjh_step1(mjh_engine* e) {
-  ENG(e); e->step1_done = true;
-  if (e->pd_on) { int rc = launch_pd(e, e->stream, 0, e->nenv); if (rc) return rc; }
+  ENG_NOJOIN(e); e->step1_done = true;
+  if (e->pd_on) { int rc = join_cohorts(e); if (!rc) rc = launch_pd(e, e->stream, 0, e->nenv); if (rc) return rc; }
   const bool lazy = !(getenv("MJH_LAZY_STEP1") && atoi(getenv("MJH_LAZY_STEP1")) == 0);
   if (!lazy) return launch_lpt(e, PH_STEP1, XF_FORCE, true);
   e->step1_pending = true;
@@ -616,15 +643,15 @@ extern "C" int mjh_inverse(mjh_engine* e) {
   if (e && e->step1_pending) {      // step1 + inverse in one launch
     if (hipSetDevice(e->device) != hipSuccess) { mjh_set_error("hipSetDevice failed"); return MJH_ERR_NO_DEVICE; }
     e->step1_pending = false;
-    int rc = join_cohorts(e);
-    return rc ? rc : launch_lpt(e, PH_STEP1 | PH_INV, XF_FORCE, true);
+    return launch_lpt(e, PH_STEP1 | PH_INV, XF_FORCE, true);
   }
-  ENG(e); return launch_lpt(e, PH_INV, XF_FORCE, false);
+  ENG_NOJOIN(e); return launch_lpt(e, PH_INV, XF_FORCE, false);
 }
 extern "C" int mjh_step2(mjh_engine* e) {
-  ENG(e);
+  ENG_NOJOIN(e);
   if (!e->step1_done) { mjh_set_error("mjh_step2 called before mjh_step1"); return MJH_ERR_STATE; }
   e->step1_done = false;
+  e->order_age++;
   return launch_lpt(e, PH_STEP2, XF_FORCE, false);
 }
 extern "C" int mjh_forward(mjh_engine* e) {
@@ -741,13 +768,27 @@ extern "C" int mjh_synchronize(mjh_engine* e) { ENG(e); HIPCHK(hipStreamSynchron
 // ---- host <-> device marshalling helpers (double on the host side, padded fp32 rows on the device)
 // rows of `width` floats at `stride` floats apart; only the `width` floats are touched (rows may be columns of a wider
 // per-env record, see the state layout in mjh_create)
-static int put_rows(mjh_engine* e, float* dst, int stride, int width, int env0, int n, const double* src) {
+// The stream a transfer of the envs [env0, env0 + n) has to be ordered on: while the cohorts run on their own streams, a range inside
+// ONE cohort uses that cohort's stream and leaves the others running; anything else joins them into the caller's stream first.
+static int range_stream(mjh_engine* e, int env0, int n, hipStream_t* st) {
+  *st = e->stream;
+  if (!e->forked) return MJH_OK;
+  const int G = e->ncohort;
+  if (n > 0 && G > 1 && e->nenv >= 64 * G)
+    for (int g = 0; g < G; g++) {
+      const int g0 = (int)((long long)e->nenv * g / G), g1 = (int)((long long)e->nenv * (g + 1) / G);
+      if (env0 >= g0 && env0 + n <= g1) { *st = e->cstream[g]; return MJH_OK; }
+    }
+  return join_cohorts(e);
+}
+static int put_rows(mjh_engine* e, float* dst, int stride, int width, int env0, int n, const double* src, hipStream_t st = nullptr) {
   if (!src || n == 0) return MJH_OK;
+  if (!st) st = e->stream;
   std::vector<float> tmp((size_t)n * width);
   for (size_t i = 0; i < tmp.size(); i++) tmp[i] = (float)src[i];
   HIPCHK(hipMemcpy2DAsync(dst + (size_t)env0 * stride, (size_t)stride * sizeof(float), tmp.data(), (size_t)width * sizeof(float),
-                          (size_t)width * sizeof(float), (size_t)n, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+                          (size_t)width * sizeof(float), (size_t)n, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
   return MJH_OK;
 }
 // a column block of wider rows: only `width` floats of every row are written (the rest belongs to other tables)
@@ -763,10 +804,13 @@ static int get_rows(mjh_engine* e, const float* src, int stride, int width, int 
 }
 
 extern "C" int mjh_set_cmd(mjh_engine* e, int env0, int n, const double* ddq, const double* dq) {
-  ENG(e); RANGE(e, env0, n);
-  int rc = put_rows(e, e->S.ddq, e->M.nvp, e->M.nv, env0, n, ddq);
+  ENG_NOJOIN(e); RANGE(e, env0, n);
+  hipStream_t st;
+  int rc = range_stream(e, env0, n, &st);
   if (rc) return rc;
-  return put_rows(e, e->S.dq, e->M.nvp, e->M.nv, env0, n, dq);
+  rc = put_rows(e, e->S.ddq, e->M.nvp, e->M.nv, env0, n, ddq, st);
+  if (rc) return rc;
+  return put_rows(e, e->S.dq, e->M.nvp, e->M.nv, env0, n, dq, st);
 }
 
 // ---- in-engine PD effort controller.  The reference runs ros_control effort controllers on the host between read() and
@@ -841,11 +885,24 @@ extern "C" int mjh_set_odom_vel(mjh_engine* e, int env0, int n, const double* tw
 }
 
 extern "C" int mjh_get_joint_state(mjh_engine* e, int env0, int n, double* qpos, double* qvel, double* qfrc_inverse) {
-  ENG(e); RANGE(e, env0, n);
-  int rc = get_rows(e, e->S.qpos, e->M.nqp, e->M.nq, env0, n, qpos);
-  if (!rc) rc = get_rows(e, e->S.qvel, e->M.nvp, e->M.nv, env0, n, qvel);
-  if (!rc) rc = get_rows(e, e->S.qfrc_inverse, e->M.nvp, e->M.nv, env0, n, qfrc_inverse);
-  return rc;
+  ENG_NOJOIN(e); RANGE(e, env0, n);
+  hipStream_t st;
+  int rc = range_stream(e, env0, n, &st);
+  if (rc || n == 0) return rc;
+  // three strided copies, ONE synchronisation (this is MjHWInterface::read: once per step of the reference's loop)
+  const float* src[3] = {e->S.qpos, e->S.qvel, e->S.qfrc_inverse};
+  const int stride[3] = {e->M.nqp, e->M.nvp, e->M.nvp}, width[3] = {e->M.nq, e->M.nv, e->M.nv};
+  double* dst[3] = {qpos, qvel, qfrc_inverse};
+  std::vector<float> tmp[3];
+  for (int k = 0; k < 3; k++) {
+    if (!dst[k]) continue;
+    tmp[k].resize((size_t)n * width[k]);
+    HIPCHK(hipMemcpy2DAsync(tmp[k].data(), (size_t)width[k] * sizeof(float), src[k] + (size_t)env0 * stride[k], (size_t)stride[k] * sizeof(float),
+                            (size_t)width[k] * sizeof(float), (size_t)n, hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  for (int k = 0; k < 3; k++) if (dst[k]) for (size_t i = 0; i < tmp[k].size(); i++) dst[k][i] = (double)tmp[k][i];
+  return MJH_OK;
 }
 
 // position-stage recompute for a range of envs with export pointers set

@@ -221,3 +221,40 @@ def test_c4_at_2048_envs_one_step_parity_on_sampled_envs():
     print(f"C4 2048 envs, sampled: nefc {[d.i('nefc') for d in ds]}, contact sets agree {ag}, qpos {eq}, qvel {ev}")
     assert ag.sum() >= 3 and eq[ag].max() <= 2e-6 and ev[ag].max() <= 1e-4
     e.close()
+
+
+def test_literal_loop_on_cohort_streams_equals_the_single_stream_loop():
+    """The reference's loop body (mj_main.cpp:82-112: mj_step1 -> read() -> update -> write() -> mj_step2) through the split entry
+    points.  With cohorts the launches go out per cohort stream and a read / write of ONE environment only waits for that
+    environment's cohort (engine.hip: launch_lpt, range_stream) — the other cohorts keep running.  Commands to envs of different
+    cohorts, a range that spans two cohorts (joins them) and full-range calls in between: bitwise the same trajectories as the
+    same calls on one stream."""
+    m = ms.scene("arm7", 1)
+    nenv = 1536                                   # 512 envs per cohort
+    rng = np.random.default_rng(5)
+    q0 = 0.3 * rng.normal(size=(nenv, m.nq))
+    out = []
+    for cohorts in (1, 3):
+        e = ms.Engine(m, nenv); e.set_cohorts(cohorts)
+        e.set_controlled_dofs(np.ones(m.nv, dtype=np.int32))
+        e.set_state(qpos=q0)
+        r2 = np.random.default_rng(6)
+        reads = []
+        for k in range(40):
+            e.step1(); e.inverse()
+            for env in (0, 700, 1535):                                    # one env of each cohort
+                q, v, f = e.get_joint_state(env, 1)
+                reads.append(np.concatenate([q.ravel(), v.ravel(), f.ravel()]))
+                e.set_cmd(ddq=(2.0 * r2.normal(size=(1, m.nv)) - 5.0 * v), dq=None, env0=env)
+            if k % 7 == 3:
+                e.set_cmd(ddq=r2.normal(size=(40, m.nv)), dq=None, env0=500)   # envs 500 .. 539: two cohorts
+            if k % 11 == 5:
+                reads.append(e.get_field("qfrc_inverse")[::97].ravel())      # a full-range getter in the middle of the loop
+            e.step2()
+            if k % 13 == 6:
+                e.step(2, True)                                               # the fused step mixed in
+        t, q, v, w = e.get_state()
+        out.append((q.copy(), v.copy(), np.concatenate(reads)))
+        e.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert np.abs(out[0][1]).max() > 1e-2
