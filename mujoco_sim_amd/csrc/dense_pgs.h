@@ -24,8 +24,8 @@
 //
 // Environments whose row count exceeds the dense capacity keep the block solver (meta[7] says which one ran).  The dense form pays
 // ~0.1 ms of build latency per env and wins ~3x per sweep, so it pays when some env of the launch sweeps long — such an env sets
-// the length of the solve launch (C4: 1.03 M env-steps/s against 0.75 M) — and loses on robots that converge in a dozen sweeps
-// (PR2 on the floor, all envs alike: 1.53 M with it, 1.87 M without).  The HOST therefore decides per cohort (engine.hip: mjh_step):
+// the length of the solve launch (C4: 1.28 M env-steps/s against 0.82 M) — and loses on robots that converge in a dozen sweeps
+// (PR2 on the floor, all envs alike: 1.95 M with it, 2.36 M without).  The HOST therefore decides per cohort (engine.hip: mjh_step):
 // whenever mjh_order_kernel rebuilds a cohort's launch order it also leaves "an env of this cohort swept >= M.dense_min_iter (32)
 // times" in host-mapped memory; the host adopts the word of two rebuilds ago (after that kernel's event: no stall, and the choice
 // depends on the step count only, so runs stay reproducible), queues the build and dense-solve launches only then, and tells the
@@ -220,8 +220,8 @@ template <int K> DEV DnCol<K> dn_load(const __amdgpu_buffer_rsrc_t rs, const uns
 // Gauss-Seidel sweeps over the rows p = 0 .. nr32 - 1 (visiting order; nr32 a multiple of 32, rows beyond nefc inert).  Lane q owns
 // rows 64 k + q and carries  s_q = f_q + t_q  (t_q = -res_q / AR_qq):  the update of row p is  f_p <- med3(s_p, lo_p, hi_p)  and
 // s_q += AR'_pq delta for q != p — a row's own update leaves its s unchanged (its t moves by -delta, its f by +delta), so the stored
-// diagonal is 0 and the row costs: med3, sub, readlane, two selects, K multiply-adds (+ its share of the column fetch).  The second
-// select keeps s_p as it was at the row's visit: with it the decrease of the dual cost, -delta (res + AR_pp delta / 2), is summed per
+// diagonal is 0 and the row costs: med3, sub, readlane, one select, K multiply-adds in pairs (v_pk_fma_f32) (+ its share of the column
+// fetch): 7 instructions at K = 3.  The select keeps s_p as it was at the row's visit (the row's new force is med3 of it, taken at the end of the sweep): with it the decrease of the dual cost, -delta (res + AR_pp delta / 2), is summed per
 // row exactly as mj_solPGS (and the block solver, and the oracle) sum it, once per 64-row set.  (Evaluating the sweep's decrease from
 // its end points, 1/2 (f1 - f0) . (res1 + res0), saves that select but ends a sweep later on average — C4: 15.9 against 14.8
 // sweeps — because the rounding noise of t enters with either sign.)
@@ -238,9 +238,9 @@ DEV int dn_sweeps(const __amdgpu_buffer_rsrc_t rs, const int art_bytes, const in
   for (int r = 0; r < 16; r++) buf[0][r] = dn_load<K>(rs, voff, art_bytes + r * ROWB);
   int niter = 0;
   for (;;) {
-    float f0[K], sv[K];
+    float sv[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) { f0[k] = f[k]; sv[k] = s[k]; }      // sv: s of the lane's row at ITS visit (rows never visited: dc = 0)
+    for (int k = 0; k < K; k++) sv[k] = s[k];      // sv: s of the lane's row at ITS visit (rows never visited are inert: lo = hi = f = 0)
     // (opaque per sweep: otherwise the 64 lane masks and the row offsets are hoisted out of the sweep loop as loop invariants and
     //  spilled — v_writelane / v_readlane around every use)
     unsigned long long m1 = 1ull; asm volatile("" : "+s"(m1));
@@ -263,10 +263,16 @@ DEV int dn_sweeps(const __amdgpu_buffer_rsrc_t rs, const int art_bytes, const in
             const float sd = readlane_f(d, l);
             const bool me = __builtin_amdgcn_inverse_ballot_w64(mask);     // lane l: v_cndmask on a scalar mask, no compare
             mask <<= 1;
-            f[k] = me ? fn : f[k];
-            sv[k] = me ? s[k] : sv[k];
+            sv[k] = me ? s[k] : sv[k];            // (f itself is not touched inside the sweep: a row is visited once, its new force is med3 of sv)
+            // (pairs of the lane's rows in one v_pk_fma_f32: 2 instead of 3 instructions at K = 3)
+            typedef float dn_f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int j = 0; j < K; j++) s[j] = __builtin_fmaf(buf[gg & 1][r].v[j], sd, s[j]);
+            for (int j = 0; j + 1 < K; j += 2) {
+              const dn_f2 c2 = {buf[gg & 1][r].v[j], buf[gg & 1][r].v[j + 1]}, d2 = {sd, sd}, s2 = {s[j], s[j + 1]};
+              const dn_f2 o2 = __builtin_elementwise_fma(c2, d2, s2);
+              s[j] = o2.x; s[j + 1] = o2.y;
+            }
+            if (K & 1) s[K - 1] = __builtin_fmaf(buf[gg & 1][r].v[K - 1], sd, s[K - 1]);
           }
         }
       }
@@ -274,7 +280,11 @@ DEV int dn_sweeps(const __amdgpu_buffer_rsrc_t rs, const int art_bytes, const in
     niter++;
     float imp = 0;
 #pragma unroll
-    for (int k = 0; k < K; k++) { const float dc = f[k] - f0[k]; imp += dc * arr[k] * ((sv[k] - f0[k]) - 0.5f * dc); }   // -delta (res + AR delta / 2), res = -t AR, t = s - f at the row's visit
+    for (int k = 0; k < K; k++) {      // -delta (res + AR delta / 2), res = -t AR, t = s - f at the row's visit
+      const float fn = __builtin_amdgcn_fmed3f(sv[k], lo[k], hi[k]), dc = fn - f[k];
+      imp += dc * arr[k] * ((sv[k] - f[k]) - 0.5f * dc);
+      f[k] = fn;
+    }
     const float improvement = wave_sum<4>(imp);
     if (improvement * scale < tol || niter >= itmax) break;
   }

@@ -3,7 +3,8 @@ sys.path.insert(0, "/root/repo")
 import torch
 torch.cuda.set_device(0)
 import mujoco_sim_amd as ms
-st = torch.cuda.current_stream().cuda_stream
+own = torch.cuda.Stream() if "own" in (sys.argv[1] if len(sys.argv) > 1 else "") else None
+st = own.cuda_stream if own is not None else torch.cuda.current_stream().cuda_stream
 print("torch stream handle", st)
 m = ms.scene("s24"); e = ms.Engine(m, 4096, device=0, stream=st); e.load_s24(); e.set_cohorts(3)
 pub = torch.empty(4096 * e.state_stride, dtype=torch.float32, device="cuda")
