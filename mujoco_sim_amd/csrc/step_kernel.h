@@ -2123,8 +2123,22 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
       base_dots(s_qacc, s_bv);
       forces_from(s_bv, false);
       accum_T(false, s_phi, s_tmpv2);
-      vel_levels(s_qvel, s_qacc, s_tmpv);  // RNE with acceleration
-      for (int d = lane; d < nv; d += 64) S.qfrc_inverse[vrow + d] = s_tmpv[d] + dof_armature[d] * s_qacc[d] - s_passive[d] - s_tmpv2[d];
+      if constexpr (DIAGM) {
+        vel_levels(s_qvel, s_qacc, s_tmpv);  // RNE with acceleration
+        for (int d = lane; d < nv; d += 64) S.qfrc_inverse[vrow + d] = s_tmpv[d] + dof_armature[d] * s_qacc[d] - s_passive[d] - s_tmpv2[d];
+      } else {
+        // RNE with acceleration = M qacc + qfrc_bias (M without armature); both terms are at hand — qfrc_bias from the velocity stage of
+        // this launch, M from the CRBA (armature included) — so the second pass over the tree levels is one mj_mulM instead
+        for (int d = lane; d < nv; d += 64) s_tmpv[d] = 0;
+        WSYNC();
+        for (int i = lane; i < nv; i += 64) {
+          int adr = s_dofMadr_i[i]; const float vi = s_qacc[i]; float acc = qM_ro[adr] * vi; int k = 1;
+          for (int j = s_dofpar_i[i]; j >= 0; j = s_dofpar_i[j]) { const float mij = qM_ro[adr + k]; acc += mij * s_qacc[j]; atomicAdd(&s_tmpv[j], mij * vi); k++; }
+          atomicAdd(&s_tmpv[i], acc);
+        }
+        WSYNC();
+        for (int d = lane; d < nv; d += 64) S.qfrc_inverse[vrow + d] = s_tmpv[d] + s_bias[d] - s_passive[d] - s_tmpv2[d];
+      }
     }
 
     PROF(10);
