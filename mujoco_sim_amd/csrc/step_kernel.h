@@ -2149,7 +2149,7 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
         niter = __builtin_amdgcn_readfirstlane(meta[5]);
         for (int d = lane; d < nv; d += 64) { const float qa = gs[L.g_qacc + d]; s_qacc[d] = qa; s_ws[d] = qa; s_smooth[d] = gs[L.g_smooth + d]; s_asmooth[d] = 0; s_tmpv2[d] = 0; }
         WSYNC();
-        if (nefc > 0 && (M.has_damping || (xflags & XF_FORCE))) { phi_from_forces(); accum_T(false, s_phi, s_tmpv2); }
+        if (nefc > 0 && (xflags & XF_FORCE)) { phi_from_forces(); accum_T(false, s_phi, s_tmpv2); }
       } else {
       // ---- smooth acceleration (mj_fwdAcceleration)
       for (int d = lane; d < nv; d += 64) { float f = s_passive[d] - s_bias[d] + s_applied[d]; s_smooth[d] = f; s_asmooth[d] = f; }
@@ -2294,7 +2294,7 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
             PROF(13);
             WSYNC();
             // qfrc_constraint = M (qacc - qacc_smooth): the base rows are gone
-            if (M.has_damping || (xflags & XF_FORCE)) for (int d = lane; d < nv; d += 64) s_tmpv2[d] = (s_qacc[d] - s_asmooth[d]) * s_qM[dof_Madr[d]];
+            if (xflags & XF_FORCE) for (int d = lane; d < nv; d += 64) s_tmpv2[d] = (s_qacc[d] - s_asmooth[d]) * s_qM[dof_Madr[d]];
           }
         }
         if (!patched) {
@@ -2620,8 +2620,8 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
         if (NROW != 8 && d0 < nv && lane < 64 / (NROW <= 2 ? 2 : 1)) { s_qacc[d0] = a; s_ws[d0] = a; }
         PROF(13);
         WSYNC();
-        // qfrc_constraint = J^T f (only needed by the implicit-damping integrator and for export)
-        if (M.has_damping || (xflags & XF_FORCE)) { phi_from_forces(); accum_T(false, s_phi, s_tmpv2); }
+        // qfrc_constraint = J^T f (only needed for export: the implicit-damping integrator works from qacc)
+        if (xflags & XF_FORCE) { phi_from_forces(); accum_T(false, s_phi, s_tmpv2); }
         }   // !patched
       }
       }   // !post
@@ -2784,8 +2784,10 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
         // ---- semi-implicit Euler with implicit joint damping (mj_Euler)
         float* qint = s_qacc;
         if (M.has_damping && !(M.disableflags & MJH_DSBL_EULERDAMP)) {
+          // (M + h D) qacc' = qfrc_smooth + qfrc_constraint = M qacc   <=>   qacc' = qacc - h (M + h D)^-1 D qacc: the same update
+          // without forming the constraint force (J^T f over all blocks), and the solve only carries the small correction
           for (int i = lane; i < M.nM; i += 64) s_qLD[i] = qM_ro[i];
-          for (int d = lane; d < nv; d += 64) s_tmpv[d] = s_smooth[d] + s_tmpv2[d];
+          for (int d = lane; d < nv; d += 64) s_tmpv[d] = dof_damping[d] * s_qacc[d];
           WSYNC();
           for (int d = lane; d < nv; d += 64) s_qLD[s_dofMadr_i[d]] += h * dof_damping[d];
           WSYNC();
@@ -2800,6 +2802,9 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
           }
           WSYNC();
           if (level_solves) solve_trees_levels(s_tmpv, s_qLD, s_qLDinv, s_anc_i, s_dofMadr_i, nv, M.nM, lane);
+          WSYNC();
+          for (int d = lane; d < nv; d += 64) s_tmpv[d] = s_qacc[d] - h * s_tmpv[d];
+          WSYNC();
           qint = s_tmpv;
         }
         for (int d = lane; d < nv; d += 64) {
