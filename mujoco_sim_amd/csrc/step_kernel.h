@@ -132,8 +132,28 @@ DEV void factor_dof_pairs(float* qLD, float* qLDinv, const int* anc, const int M
   for (int c = 0; c < NQ; c++) if (pr == 0 && q + 16 * c <= d) qLD[Mk + q + 16 * c] = aq[c] * inv;
   if (lane == 0) qLDinv[k] = inv;
 }
+// depth <= 15: the d (d + 1) / 2 <= 120 pairs enumerated along the triangle (q-major: pair t = q (q - 1) / 2 + p - 1, so the pairs of a
+// dof of depth d are exactly t < d (d + 1) / 2), two per lane (t = lane, lane + 64) — the 4 x 16 tiling above keeps a fifth of its lanes busy
+DEV void factor_dof_tri(float* qLD, float* qLDinv, const int* anc, const int Mk, const int d, const int k, const int lane,
+                        const int pA, const int qA, const int pB, const int qB) {
+  const int np = (d * (d + 1)) >> 1;
+  const bool vA = lane < np, vB = lane + 64 < np;
+  const float dk = qLD[Mk];
+  const float apA = qLD[Mk + min(pA, d)], aqA = qLD[Mk + min(qA, d)], apB = qLD[Mk + min(pB, d)], aqB = qLD[Mk + min(qB, d)];
+  const int amA = ANC_MADR(anc[Mk + min(pA, d)]), amB = ANC_MADR(anc[Mk + min(pB, d)]);
+  const float row = qLD[Mk + min(1 + lane, d)];                      // row k itself: scaled by 1 / M_kk at the end
+  const float inv = 1.0f / dk;
+  const float tgA = qLD[vA ? amA + (qA - pA) : Mk], tgB = qLD[vB ? amB + (qB - pB) : Mk];
+  if (vA) qLD[amA + (qA - pA)] = tgA - apA * inv * aqA;
+  if (vB) qLD[amB + (qB - pB)] = tgB - apB * inv * aqB;
+  if (lane < d) qLD[Mk + 1 + lane] = row * inv;
+  if (lane == 0) qLDinv[k] = inv;
+}
 DEV void factor_tree_wave(float* qLD, float* qLDinv, const int* anc, const int* dof_Madr, int adr, int num, int nM, int nv, const int lane) {
   int chunk = -1, MkL = 0, dL = 0;
+  int pA, qA, pB, qB;       // the lane's two pairs of the triangular enumeration
+  { int t = lane, q = 1; while (t >= q) { t -= q; q++; } pA = t + 1; qA = q;
+    t = lane + 64; q = 1; while (t >= q) { t -= q; q++; } pB = t + 1; qB = q; }
   for (int k = adr + num - 1; k >= adr; k--) {
     const int ck = (k - adr) >> 6;
     if (ck != chunk) {
@@ -143,7 +163,8 @@ DEV void factor_tree_wave(float* qLD, float* qLDinv, const int* anc, const int* 
       dL = kk < adr + num ? (kk + 1 < nv ? dof_Madr[kk + 1] : nM) - MkL - 1 : 0;
     }
     const int Mk = __builtin_amdgcn_readlane(MkL, (k - adr) & 63), d = __builtin_amdgcn_readlane(dL, (k - adr) & 63);
-    if (d <= 16) factor_dof_pairs<4, 1>(qLD, qLDinv, anc, Mk, d, k, lane);
+    if (d <= 15) factor_dof_tri(qLD, qLDinv, anc, Mk, d, k, lane, pA, qA, pB, qB);
+    else if (d <= 16) factor_dof_pairs<4, 1>(qLD, qLDinv, anc, Mk, d, k, lane);
     else if (d <= 32) factor_dof_pairs<8, 2>(qLD, qLDinv, anc, Mk, d, k, lane);
     else {
       const int q = 1 + (lane & 15), pr = lane >> 4;
