@@ -569,7 +569,9 @@ def main():
     ap.add_argument("--pack", type=int, default=0, help="environments per wavefront for the small-model configs (0: the config's default — C3 4, C5 2, others 1)")
     ap.add_argument("--pen-half", type=float, default=0.0, help="s24d: half width of the pen in metres (default 0.14; S24 itself is 0.175)")
     ap.add_argument("--maxcon", type=int, default=0, help="override the scene's contact capacity per env; 0 = scene default")
-    ap.add_argument("--pgs-row-order", action="store_true", help="Gauss-Seidel in mj_solPGS's own row order on the device (mjh_set_pgs_row_order): what exactness of the ORDER costs")
+    ap.add_argument("--pgs-schedule", type=int, default=1, choices=[0, 1, 2],
+                    help="mjh_set_pgs_row_order: 1 (default) mj_solPGS's own row order, independent blocks side by side under a precedence-preserving list "
+                         "schedule; 2 the same order strictly one block after the other (bit-identical results); 0 the legacy reordering schedules (patch / group first fit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-second-window", action="store_true", help="skip the second timed window (the other mj_inverse variant)")
@@ -615,9 +617,8 @@ def main():
     import mujoco_sim_amd as ms
 
     stream = torch.cuda.current_stream()
-    if args.pgs_row_order:
-        from mujoco_sim_amd import capi
-        capi.load().mjh_set_pgs_row_order(1)
+    from mujoco_sim_amd import capi
+    capi.load().mjh_set_pgs_row_order(args.pgs_schedule)
     w = WORKLOADS[args.config](ms, args, rank, local_rank, stream.cuda_stream)
     eng, model, nenv = w.eng, w.model, w.nenv
     if args.cohorts > 0 or w.cohorts > 0:
@@ -722,7 +723,10 @@ def main():
                    "max_nefc": int(st[:, 1].max()), "mean_solver_iter": float(st[:, 2].mean()),
                    "overflow_envs": int((st[:, 3] & 3 != 0).sum()), "reset_envs": int((st[:, 3] & 4 != 0).sum()),
                    "lds_bytes_per_env": eng.lds_bytes, "contact_capacity": int(model.maxcon),
-                   "pgs_order": ["independent pairs / groups of blocks", "contact patches", "mj_solPGS row order"][eng.solver_order()], **w.extra_config()},
+                   "pgs_order": ["legacy: independent pairs / groups of blocks (first fit)", "legacy: contact patches sorted by body pair (first fit)", "mj_solPGS row order"][eng.solver_order()],
+                   "pgs_schedule": ["legacy reordering schedule", "precedence-preserving list schedule (bit-identical to the sequential sweep)", "sequential, one block after the other"][eng.pgs_schedule()],
+                   "solver_form": "contact patches (<= 16 rows of one body pair, <= 4 side by side)" if eng.patch_sweep() else "constraint blocks",
+                   "timed_window_ms": elapsed * 1e3, **w.extra_config()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "mjh_step_kernel" + ((" (+ mjh_dense_build_kernel [MFMA] + mjh_dense_solve_kernel: assemble -> build -> solve -> integrate chain of the many-body layout)" if eng.dense_solver() else
@@ -766,17 +770,18 @@ def main():
                 out["configs"][name] = short_config_line(ms, args, name, local_rank, stream.cuda_stream)
             except Exception as ex:
                 out["configs"][name] = {"error": repr(ex)}
-        # the metric's scene with Gauss-Seidel in mj_solPGS's own row order (mjh_set_pgs_row_order): what the exact order costs
-        if not args.pgs_row_order:
-            try:
-                from mujoco_sim_amd import capi
-                capi.load().mjh_set_pgs_row_order(1)
+        # the metric's scene under the LEGACY patch order (mjh_set_pgs_row_order(0): contacts regrouped by body pair, first-fit steps — the
+        # round-3 default) and with the row order walked strictly sequentially (2): what the reference's order costs, and what the list schedule buys
+        if args.pgs_schedule == 1:
+            for key, mode in (("s24_legacy_patch_order", 0), ("s24_row_order_sequential", 2)):
                 try:
-                    out["configs"]["s24_pgs_row_order"] = short_config_line(ms, args, "s24", local_rank, stream.cuda_stream)
-                finally:
-                    capi.load().mjh_set_pgs_row_order(0)
-            except Exception as ex:
-                out["configs"]["s24_pgs_row_order"] = {"error": repr(ex)}
+                    capi.load().mjh_set_pgs_row_order(mode)
+                    try:
+                        out["configs"][key] = short_config_line(ms, args, "s24", local_rank, stream.cuda_stream)
+                    finally:
+                        capi.load().mjh_set_pgs_row_order(1)
+                except Exception as ex:
+                    out["configs"][key] = {"error": repr(ex)}
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

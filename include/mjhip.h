@@ -517,17 +517,27 @@ int mjh_host_run_realtime(mjh_engine*, int env, const double* target, double kp,
 int mjh_nenv(const mjh_engine*);
 const mjh_model* mjh_engine_model(const mjh_engine*);
 int mjh_lds_bytes(const mjh_engine*);  /* dynamic LDS per env (= per workgroup) */
-/* Gauss-Seidel visiting order of the engine's solver sweeps (any order is a valid mj_solPGS iteration; they agree at
- * convergence): 0 = independent pairs / groups of constraint blocks, 1 = contact patches (small free-body models: up to 16
- * rows between the same two bodies are solved as one unit, mujoco_sim_amd/csrc/patch_pgs.h), 2 = the constraint rows in their
- * own order, one block after the other: the order mj_solPGS itself walks (mjh_set_pgs_row_order). */
+/* Gauss-Seidel visiting order of the engine's solver sweeps: 2 = the constraint rows of efc_* in their own order, the order
+ * mj_solPGS (engine_solver.c, reached through mj_step2, mj_main.cpp:108) walks — the DEFAULT; 1 / 0 = the legacy orders that regroup
+ * the rows to expose more independent work (1: contact patches sorted by body pair, small free-body models; 0: independent pairs /
+ * groups of constraint blocks).  Any order is a valid PGS iteration and they agree at convergence; stopped at the iteration cap they do
+ * not (BASELINE.md section 3 has the size of that effect), which is why the reference's order is the default. */
 int mjh_solver_order(const mjh_engine*);
-/* Gauss-Seidel order of engines created afterwards (process-wide; no reference counterpart).  0 (default): the engine picks an
- * order that exposes independent work (pairs / groups of blocks without a common kinematic tree, or contact patches).  1: the rows
- * of efc_* in their own order, exactly as mj_solPGS (engine_solver.c, reached through mj_step2, mj_main.cpp:108) visits them — no
- * blocks side by side, several times slower; for users who need the reference's iterates rather than its fixed point.  A PGS
- * stopped at the iteration cap depends on the order: BASELINE.md section 3 has the size of that effect. */
-void mjh_set_pgs_row_order(int on);
+/* How the engine walks that order: 1 = row order with a precedence-preserving list schedule (default) — a constraint block (or contact
+ * patch) starts once every EARLIER block that shares a kinematic tree with it is done; blocks without a common tree touch disjoint
+ * dofs, their updates commute exactly, so up to 2 / 4 / 16 of them run side by side in one wavefront and the iterates (and the sweep
+ * count: the convergence test sums fixed-point integers) are bit-identical to the strictly sequential sweep; 2 = that sequential sweep
+ * itself, one block after the other (the reference the tests compare 1 against); 0 = a legacy reordering schedule (mjh_solver_order
+ * says which). */
+int mjh_pgs_schedule(const mjh_engine*);
+/* 1: the engine's sweeps take the contact-patch form (csrc/patch_pgs.h: small free-body models — up to 16 rows between the same two
+ * bodies are one unit, up to four units side by side), 0: a block form (one constraint block = one equality / limit / friction-loss
+ * row or the pyramid rows of one contact) */
+int mjh_patch_sweep(const mjh_engine*);
+/* Gauss-Seidel order / schedule of engines created afterwards (process-wide; no reference counterpart): 1 (default), 2 or 0 as
+ * mjh_pgs_schedule reports them.  Articulated models whose sweeps are sequential in any case (more than 32 dofs and a kinematic tree
+ * of more than 16) run row order under 0 as well. */
+void mjh_set_pgs_row_order(int mode);
 /* 1: mjh_step solves the environments of this engine whose rows fit with the dense row-space solver (AR = J M^-1 J^T on the matrix
  * cores, column sweeps: csrc/dense_pgs.h) — articulated models in the many-body layout; same rows, same visiting order, same results up
  * to fp32 rounding as the block solver (MJH_DENSE=0 turns it off) */

@@ -235,6 +235,8 @@ SYMBOLS = [
     ("mjh_engine_model", Model_p, [_vp]),
     ("mjh_lds_bytes", C.c_int, [_vp]),
     ("mjh_solver_order", C.c_int, [_vp]),
+    ("mjh_pgs_schedule", C.c_int, [_vp]),
+    ("mjh_patch_sweep", C.c_int, [_vp]),
     ("mjh_dense_solver", C.c_int, [_vp]),
     ("mjh_query_lds_bytes", C.c_int, [Model_p]),
     ("mjh_host_run_pd", C.c_int, [_vp, C.c_int, c_double_p, C.c_double, C.c_double, C.c_long, c_double_p, c_double_p, c_double_p]),

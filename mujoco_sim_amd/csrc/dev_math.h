@@ -139,6 +139,29 @@ DEV int wave_sum_i(int v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// integer sum over the 64 lanes through DPP (uniform result): order-independent, so a convergence test built on it does not depend
+// on which lane carried which term
+DEV int wave_sum_dpp_i(int v) {
+#define MJH_IADD(ctrl, rm, bc) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rm, 0xf, bc)
+  MJH_IADD(0x111, 0xf, true); MJH_IADD(0x112, 0xf, true); MJH_IADD(0x114, 0xf, true); MJH_IADD(0x118, 0xf, true);
+  MJH_IADD(0x142, 0xa, false); MJH_IADD(0x143, 0xc, false);
+#undef MJH_IADD
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// One term of a sweep's cost decrease as a fixed-point integer: x = decrease * (scale / tolerance) (the sweep has converged when the
+// terms sum to less than 1), clamped to +-2 (a single term of 2 decides the test) and counted in units of 2^-MJH_IMP_BITS.  Integer
+// addition is associative: the total does not depend on the order in which a schedule visits independent blocks, which float
+// addition would (a sequential sweep and a side-by-side schedule of the same Gauss-Seidel order must stop after the same sweep).
+#define MJH_IMP_BITS 18     // 2048 blocks x 2 x 2^18 < 2^31
+DEV int imp_fixed(const float decrease, const float qscale) {   // qscale = scale / tolerance * 2^MJH_IMP_BITS
+  return (int)__builtin_amdgcn_fmed3f(decrease * qscale, -(float)(2 << MJH_IMP_BITS), (float)(2 << MJH_IMP_BITS));
+}
+struct ImpQ { float qs; int thr; };     // thr: the sweep has converged when the fixed-point total is below it
+DEV ImpQ imp_quantum(const float scale, const float tol) {      // tolerance 0: never converged (the float test improvement * scale < 0 never holds either)
+  ImpQ q; const bool on = tol > 0.0f;
+  q.qs = on ? scale / tol * (float)(1 << MJH_IMP_BITS) : 0.0f; q.thr = on ? (1 << MJH_IMP_BITS) : (int)0x80000000;
+  return q;
+}
 DEV bool wave_any(bool p) { return __ballot(p) != 0ull; }
 // maximum / minimum over the 64 lanes (uniform result).  A lane without a source in a DPP step keeps its own value.
 #define MJH_DPP_KEEP(v, ctrl, rm) __builtin_amdgcn_update_dpp(v, v, ctrl, rm, 0xf, false)

@@ -169,8 +169,8 @@ static int pair_cap(int t1, int t2) {
 // layout.  Needs no HIP device (mjh_query_lds_bytes uses it for capacity planning and in the CPU tests).
 struct HostPack { DModel M{}; Lay L{}; std::vector<int> I; std::vector<float> F; int o_controlled = 0, o_odom = 0, lds_bytes = 0; long long gstride = 0; };
 // Gauss-Seidel order of engines created afterwards (mjhip.h): 1 = mj_solPGS's own row order
-static int g_pgs_row_order = 0;
-extern "C" void mjh_set_pgs_row_order(int on) { g_pgs_row_order = on ? 1 : 0; }
+static int g_pgs_row_order = 1;
+extern "C" void mjh_set_pgs_row_order(int mode) { g_pgs_row_order = mode < 0 || mode > 2 ? 1 : mode; }
 static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big = false, bool allow_patch = true) {
   DModel& M = hp.M; std::vector<int>& I = hp.I; std::vector<float>& F = hp.F;
   // ---- derived integer tables
@@ -302,11 +302,14 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     if ((diagM ? 1 : 2) * jsz < need) jsz = diagM ? need : (need + 1) / 2;
     // contact-patch sweep (patch_pgs.h): free bodies only, no noslip pass, pools in LDS, at most 64 contacts (the patch builder
     // keeps one contact per lane).  Same rule as the oracle's patch order (oracle/mjh_oracle.c: m_patch_order).
-    // mj_solPGS's own row order: on request (mjh_set_pgs_row_order), and by default for the models whose sweeps are sequential in
-    // either layout anyway (more than 32 dofs and a kinematic tree of more than 16: articulated robots) — same rule as the oracle's m_row_order
+    // Gauss-Seidel order (mjh_set_pgs_row_order).  1 (default): mj_solPGS's own constraint-row order, blocks without a common kinematic
+    // tree side by side under a precedence-preserving list schedule (bit-identical to the sequential sweep: 2).  0: the legacy orders
+    // that reorder conflicting blocks (patch / pair / group first fit) — except for the models whose sweeps are sequential in either
+    // layout anyway (more than 32 dofs and a kinematic tree of more than 16: articulated robots), which always run row order;
+    // same rules as the oracle's (oracle/mjh_oracle.c: m_row_order)
     M.pgs_row_order = g_pgs_row_order;
-    if (nv > 32) for (int t = 0; t < m->ntree; t++) if (m->tree_dofnum[t] > 16) M.pgs_row_order = 1;
-    const bool patch = allow_patch && !g_pgs_row_order && diagM && !big && nv <= 32 && M.noslip_iterations == 0 && M.maxcon <= 64 && !keep;
+    if (!M.pgs_row_order && nv > 32) for (int t = 0; t < m->ntree; t++) if (m->tree_dofnum[t] > 16) M.pgs_row_order = 1;
+    const bool patch = allow_patch && diagM && !big && nv <= 32 && M.noslip_iterations == 0 && M.maxcon <= 64 && !keep;
     M.patch = patch ? 1 : 0;
     L.qpos = put(m->nq);
     L.qvel = put(nv); L.qvref = put(nv); L.ws = put(nv); L.qacc = put(nv); L.smooth = put(nv); L.asmooth = put(nv); L.passive = put(nv);
@@ -1430,5 +1433,7 @@ extern "C" int mjh_nenv(const mjh_engine* e) { return e ? e->nenv : 0; }
 extern "C" const mjh_model* mjh_engine_model(const mjh_engine* e) { return e ? e->model : nullptr; }
 extern "C" int mjh_lds_bytes(const mjh_engine* e) { return e ? e->lds_bytes : 0; }
 extern "C" int mjh_solver_order(const mjh_engine* e) { return !e ? 0 : e->M.pgs_row_order ? 2 : e->M.patch ? 1 : 0; }
+extern "C" int mjh_pgs_schedule(const mjh_engine* e) { return !e ? 0 : e->M.pgs_row_order; }
+extern "C" int mjh_patch_sweep(const mjh_engine* e) { return !e ? 0 : e->M.patch; }
 extern "C" int mjh_dense_solver(const mjh_engine* e) { return e && e->M.big && e->split3 && e->M.dense ? 1 : 0; }
 extern "C" const char* mjh_version(void) { return "mjhip 0.1 (gfx950)"; }

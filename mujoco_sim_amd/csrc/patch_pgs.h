@@ -15,9 +15,15 @@
 // Everything is kept in the scaled coordinates  a^ = M^1/2 a,  J^ = J M^-1/2  (M is diagonal here), so that neither product
 // needs 1/M_dd:  u = J^ a^,  a^ += J^T delta.
 //
-// Visiting order (shared with the oracle, oracle/mjh_oracle.c: pgs_order): contacts sorted by (couples two bodies first, body
-// pair, constraint order); a patch = a maximal run of contacts of one body pair with at most 16 rows; a step = a patch plus up
-// to three later unvisited patches of the sequence that share no body with the step (first fit); rows in order inside a patch.
+// Visiting order.  DEFAULT (row_order 1): mj_solPGS's own constraint-row order.  A patch = a maximal run of CONSECUTIVE contacts (in
+// constraint order) of one body pair with at most 16 rows, rows in order inside it; the patches are list-scheduled in that order: a
+// patch goes to the first step (with a free 16-lane row) after every EARLIER patch that shares a body with it.  Two patches without
+// a common body touch disjoint entries of a^, so their updates commute exactly: every reordering that keeps the relative order of
+// conflicting patches produces the iterates of the sequential row-order sweep BIT FOR BIT (row_order 2 runs that sequential sweep —
+// one patch per step — for the test that asserts it; the convergence test sums fixed-point integers for the same reason).
+// LEGACY (row_order 0, mjh_set_pgs_row_order(0); oracle: orc_set_pgs_row_order(0)): contacts sorted by (couples two bodies first,
+// body pair, constraint order); a step = a patch plus up to three later unvisited patches of the sequence that share no body with
+// the step (first fit) — fewer steps per sweep (S24: 3.9 against 5.7), but not the reference's iteration.
 //
 // patch_build (regroup the contact blocks, schedule, fill the pool) -> patch_warmstart -> patch_sweep.
 #pragma once
@@ -56,12 +62,13 @@ struct PatchArgs {
   int pool, pool_floats, pdesc, pslot, zero, ahat;   // float offsets: pool, the two live tables, 4 zero floats, the acceleration [nv]
   const int* blki; const float* blkf; const float* J; const float* qLDinv;   // block tables (inside the pool span: consumed first); qLDinv: M^-1/2 per dof
   int nblk, nv, maxcon;
+  int row_order;                 // 0: legacy patch order (first fit), 1: constraint order, list-scheduled, 2: constraint order, one patch per step
 };
 
 // Groups the contact blocks into patches, schedules the patches into steps, and converts the blocks' base rows / parameters /
 // forces into the pool (which overwrites them: everything is staged through registers first).  Returns the number of steps.
 // swork: cost of one sweep in units of about four instructions (launch-order hint): 24 per step + 1 per row of its longest patch.
-DEV int patch_build(const PatchArgs& A, const int lane, int& flags, int& swork) {
+DEV int patch_build(const PatchArgs& A, const int lane, int& flags, int& swork, int& npatch_out) {
   const int nblk = A.nblk, maxcon = A.maxcon;
   int* s_word = (int*)(A.lds + A.pool);       // [maxcon] block words in patch order
   int* s_pinfo = s_word + maxcon;             // [maxcon] per patch
@@ -77,8 +84,8 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags, int& swork) 
     const int dA = two ? min(a1, a2) : a1, dB = two ? max(a1, a2) : 63;
     word = ((((two ? 0 : 1) << 11) | (dA << 6) | dB) << 10) | (lane << 4) | ((hd.x >> 4) & 15);
   }
-  int rank = 0;
-  for (int i = 0; i < nblk; i++) rank += __builtin_amdgcn_readlane(word, i) < word;
+  int rank = lane;               // constraint order: the blocks as they were made
+  if (!A.row_order) { rank = 0; for (int i = 0; i < nblk; i++) rank += __builtin_amdgcn_readlane(word, i) < word; }
   if (lane < nblk) s_word[rank] = word;
   WSYNC();
   const int w = lane < nblk ? s_word[lane] : 0;   // lanes = positions of the sequence from here on
@@ -121,8 +128,32 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags, int& swork) 
     const int base = s_pinfo[mypatch] + myrow0, b = (w >> 4) & 63;
     for (int r = 0; r < myn; r++) s_rowmap[base + r] = b | (r << 6) | (mypatch << 10) | ((myrow0 + r) << 16);
   }
-  // ---- steps: a patch plus up to three later unvisited patches that share no body with the step
   int nstep = 0;
+  if (A.row_order) {
+    // ---- list schedule of the constraint order: patch i goes to the first step >= (1 + the step of the last earlier patch on one of
+    //      its bodies) that still has a free 16-lane row.  lastv: lane b = first step body b is free again; cntv / n4v / onev: lane s =
+    //      patches, longest patch and "all on one body" of step s (at most 64 patches, so at most 64 steps).
+    const int cap = A.row_order == 2 ? 1 : 4;
+    int lastv = 0, cntv = 0, n4v = 0, onev = 1;
+    for (int i = 0; i < npatch; i++) {
+      const int di = __builtin_amdgcn_readlane(desc, i);
+      const int bA = PD_DA(di) / 6, bB = PD_DB(di) == 63 ? bA : PD_DB(di) / 6;
+      const int e = max(__builtin_amdgcn_readlane(lastv, bA), __builtin_amdgcn_readlane(lastv, bB));
+      const unsigned long long bal = __ballot(cntv < cap && lane >= e);
+      const int st = __ffsll((long long)bal) - 1;              // (steps <= patches <= 64: a free step always exists)
+      const int c = __builtin_amdgcn_readlane(cntv, st);
+      if (lane == 0) s_pslot[4 * st + c] = di;
+      if (lane == st) { cntv++; n4v = max(n4v, PD_N4(di)); onev &= PD_DB(di) == 63; }
+      if (lane == bA || lane == bB) lastv = st + 1;
+      nstep = max(nstep, st + 1);
+    }
+    WSYNC();
+    if (lane < nstep) {
+      for (int c = 0; c < 4; c++) { const int d = c < cntv ? s_pslot[4 * lane + c] : 0; s_pslot[4 * lane + c] = d | (n4v << 27) | (onev << 30); }
+    }
+    swork += wave_sum_dpp_i(lane < nstep ? 24 + 4 * n4v : 0);
+  } else
+  // ---- legacy steps: a patch plus up to three later unvisited patches that share no body with the step
   {
     unsigned long long used = 0;
     for (int i = 0; i < npatch; i++) {
@@ -249,6 +280,7 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags, int& swork) 
     }
   }
   WSYNC();
+  npatch_out = npatch;
   return nstep;
 }
 
@@ -334,18 +366,18 @@ DEV void pp_jt6(const float4& J0, const float4& J1, const float x, float* b) {
 // Warm start in patch form (mj_fwdConstraint): the forces implied by qacc_warmstart, f = max(0, -(J a_ws - aref) / R), kept if
 // their dual cost  sum f (1/2 (J da + R f) + J a_smooth - aref),  da = M^-1 J^T f,  is not positive.  what / ashat: M^1/2 qacc_warmstart
 // and M^1/2 qacc_smooth (LDS vectors, float offsets); dahat: zeroed on entry, M^1/2 da on exit (zero again if the forces were dropped).
-DEV void patch_warmstart(const PatchArgs& A, const int lane, const int nstep, const int what, const int ashat, const int dahat) {
+DEV void patch_warmstart(const PatchArgs& A, const int lane, const int nstep, const int npatch, const int what, const int ashat, const int dahat) {
   const int rho = lane >> 4, q = lane & 15;
   const int* s_pslot = (const int*)(A.lds + A.pslot) + rho;
+  const int* s_pdesc = (const int*)(A.lds + A.pdesc);
   float* const pool = A.lds + A.pool;
   float* const zero = A.lds + A.zero;
   const int recoff2 = PP_REC(true) * q, recoff1 = PP_REC(false) * q;
   const int gq = q < 6 ? q : q - 6; const bool gA = q < 6, gB = q >= 6 && q < 12;
   const int addoff = (q & 4) ? 3 : 0; const bool addB = q >= 8, adder = (q & 3) == 0;
   struct Row { float4 P, J0, J1, J2; float* rec; int gidx, aidx; };     // gidx: dof this lane carries (-1: none), aidx: first dof it adds to
-  auto row = [&](const int t) __attribute__((always_inline)) {
+  auto rowd = [&](const int d) __attribute__((always_inline)) {
     Row o;
-    const int d = s_pslot[4 * t];
     const int nr4 = PD_N4(d) << 2, dA = PD_DA(d), dB = PD_DB(d);
     const bool on = q < nr4, hasB = dB != 63;
     o.rec = on ? pool + PD_OFF(d) + (hasB ? recoff2 : recoff1) : zero;
@@ -356,6 +388,7 @@ DEV void patch_warmstart(const PatchArgs& A, const int lane, const int nstep, co
     o.aidx = ((addB & hasB) ? dB : dA) + addoff;
     return o;
   };
+  auto row = [&](const int t) __attribute__((always_inline)) { return rowd(s_pslot[4 * t]); };
   auto gather = [&](const int vec, const int gidx) __attribute__((always_inline)) { return *(gidx >= 0 ? A.lds + vec + gidx : zero); };
   for (int t = 0; t < nstep; t++) {
     Row o = row(t);
@@ -367,9 +400,11 @@ DEV void patch_warmstart(const PatchArgs& A, const int lane, const int nstep, co
     if (adder) { float* pd = A.lds + dahat + o.aidx; atomicAdd(pd, b[0]); atomicAdd(pd + 1, b[1]); atomicAdd(pd + 2, b[2]); }
   }
   WSYNC();
+  // the dual cost: summed over the patches in THEIR order, four at a time (not over the steps: the sum, and with it the decision,
+  // must not depend on the schedule)
   float cost = 0;
-  for (int t = 0; t < nstep; t++) {
-    Row o = row(t);
+  for (int p0 = 0; p0 < npatch; p0 += 4) {
+    Row o = rowd(p0 + rho < npatch ? s_pdesc[p0 + rho] : 0);
     const float jda = pp_dot12(gather(dahat, o.gidx), o.J0, o.J1, o.J2);
     const float bb = pp_dot12(gather(ashat, o.gidx), o.J0, o.J1, o.J2) - o.P.y;
     const float f = o.P.x;
@@ -423,8 +458,9 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
   // one step: the four patches of the wave's rows.  al = this lane's entry of a^ (read before the next step's operands were
   // requested, so that waiting for it does not wait for them)
   // the rows of a step once every lane has its t = -res / AR_qq (tt); returns the lane's force change
+  const ImpQ iq = imp_quantum(scale, tol);
   auto rows = [&](const PatchOps& o, const float4& J0, const float4& J1, const float4& J2, const float half, const bool allone,
-                  const float f, float tt, float& impl) __attribute__((always_inline)) {
+                  const float f, float tt, int& impl) __attribute__((always_inline)) {
     const int nmax = __builtin_amdgcn_readfirstlane(o.nr4);      // rows of the step's longest patch
     const float nf = -f;
     float dl;
@@ -437,14 +473,14 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
       }
     }
     asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));     // every lane's own update (its t is final: header comment)
-    impl += (half * dl) * (2.0f * tt - dl);     // cost decrease  -(delta res + AR_qq delta^2 / 2),  res = -t AR_qq
+    impl += imp_fixed((half * dl) * (2.0f * tt - dl), iq.qs);     // cost decrease  -(delta res + AR_qq delta^2 / 2),  res = -t AR_qq  (fixed point: dev_math.h)
     // a^ += J^T delta: the first lane of quad j adds dofs 3j .. 3j+2
     float b[3];
     if (allone) pp_jt6(J0, J1, dl, b); else pp_jt(J0, J1, J2, dl, b);
     if (adder && (!allone || q < 8)) { atomicAdd(o.padd, b[0]); atomicAdd(o.padd + 1, b[1]); atomicAdd(o.padd + 2, b[2]); }
     return dl;
   };
-  auto solve = [&](PatchOps& o, const float al, float& impl) __attribute__((always_inline)) {
+  auto solve = [&](PatchOps& o, const float al, int& impl) __attribute__((always_inline)) {
     const bool allone = __builtin_amdgcn_readfirstlane(o.stepone) != 0;   // every patch of the step on one body: 6 dofs in the two products
     const float u = allone ? pp_dot6(al, o.J0, o.J1) : pp_dot12(al, o.J0, o.J1, o.J2);
     const float f = o.P.x;
@@ -454,11 +490,11 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
   int niter = 0;
   if (nstep == 1) {
     for (int it = 0; it < itmax; it++) {
-      float impl = 0;
+      int impl = 0;
       PatchOps o = load(s_pslot[0]);
       solve(o, *o.pa, impl);
       niter = it + 1;
-      if (wave_sum<4>(impl) * scale < tol) break;
+      if (wave_sum_dpp_i(impl) < iq.thr) break;
     }
     return niter;
   }
@@ -534,7 +570,7 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
     PatchOps op[2];
     op[0] = loadt(c0[0], c1[0], c2[0], c3[0]);
     for (int it = 0; it < itmax; it++) {
-      float impl = 0;
+      int impl = 0;
 #pragma unroll
       for (int t = 0; t < PP_NSU; t++) {
         if (t < nstep) {
@@ -553,7 +589,7 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
       }
       if (nstep & 1) op[0] = op[1];          // odd step count: step 0 of the next sweep was requested into the other set
       niter = it + 1;
-      if (wave_sum<4>(impl) * scale < tol) break;
+      if (wave_sum_dpp_i(impl) < iq.thr) break;
     }
 #undef PP_LOADSTEP
 #pragma unroll
@@ -566,7 +602,7 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
   PatchOps opA = load(s_pslot[0]), opB;
   int dn = s_pslot[4];
   for (int it = 0; it < itmax; it++) {
-    float impl = 0;
+    int impl = 0;
     for (int t = 0; t < nstep; t += 2) {
       {
         const float al = *opA.pa;
@@ -584,7 +620,7 @@ DEV int patch_sweep(const PatchArgs& A, const int lane, const int nstep, const i
       } else opA = opB;                    // odd step count: step 0 of the next sweep was requested into B
     }
     niter = it + 1;
-    if (wave_sum<4>(impl) * scale < tol) break;
+    if (wave_sum_dpp_i(impl) < iq.thr) break;
   }
   return niter;
 }

@@ -527,6 +527,9 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
   const int nmode = (EXTRA && c.noslip_iterations > 0) ? 2 : 1;
   for (int mode = 0; mode < nmode; mode++) {
   if (mode == 1) { ns = true; nmain = niter; niter = 0; itmax = c.noslip_iterations; tol = c.noslip_tolerance; if (!solo) __syncthreads(); }
+  // (the side-by-side forms below sum a sweep's cost decrease as fixed-point integers: the total must not depend on which lane
+  //  carried which block — dev_math.h: imp_fixed)
+  const ImpQ iq = imp_quantum(c.scale, tol);
   // operands of one block; every address follows from the block index alone (contact blocks are laid out
   // regularly behind the c.nfixblk non-contact ones), so all loads of block k+1 are in flight while block k is solved
   struct MOp { int4 hd; int b; float4 J, B, p0, r0, r1, r2, A0, A1, A2, A3, X0, X1, X2; };
@@ -641,7 +644,7 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
       }
       return op;
     };
-    auto processS = [&](SOp& op, float& impl) __attribute__((always_inline)) {
+    auto processS = [&](SOp& op, int& impl) __attribute__((always_inline)) {
       KEEP4(op.hd); KEEP4(op.J0); KEEP4(op.J1); KEEP4(op.J2); KEEP4(op.p0); KEEP4(op.r0); KEEP4(op.r1); KEEP4(op.r2); KEEP4(op.A0); KEEP4(op.A1); KEEP4(op.A2); KEEP4(op.A3);
       if (c.has_dim4) { KEEP4(op.X0); KEEP4(op.X1); KEEP4(op.X2); }
       ROW_TREES(op.hd.z, op.hd.w);
@@ -677,7 +680,7 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
         *(float4*)(c.a4 + t4) = an;                                           // (the group's blocks touch disjoint bodies)
       }
       const bool head = actb && h == 0;
-      impl += head ? imp : 0.0f;
+      impl += imp_fixed(head ? imp : 0.0f, iq.qs);
       const unsigned of = head ? (unsigned)op.b * 64u + (unsigned)(BF_F * 4) : MJH_BUF_OOB;
       mjh_v4u f4; mjh_v2u f2;
       __builtin_memcpy(&f4, f, 16); __builtin_memcpy(&f2, f + 4, 8);
@@ -687,13 +690,13 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
     // operands two groups ahead (three register sets in rotation), as in the four-block form
     int gF = 0, gP = 0;
     auto nextFetch = [&]() __attribute__((always_inline)) { SOp o = fetchS(gF); gF = gF + 1 == c.ngrp ? 0 : gF + 1; return o; };
-    float impl = 0; bool done = false;
+    int impl = 0; bool done = false;
     auto stepDone = [&]() __attribute__((always_inline)) {
       if (++gP < c.ngrp) return;
       gP = 0; niter++;
-      const float improvement = wave_sum<4>(impl);
+      const int improvement = wave_sum_dpp_i(impl);
       impl = 0;
-      done = improvement * c.scale < tol || niter >= itmax;
+      done = improvement < iq.thr || niter >= itmax;
     };
 #ifndef MJH_QUAD_DEPTH
 #define MJH_QUAD_DEPTH 3      // operand sets in flight: 3 = two groups ahead (~210 VGPRs, two waves per SIMD): C2 0.658 M env-steps/s; 2 = one ahead (149 VGPRs, three waves per SIMD): 0.618 M — the fetch latency matters more than the third wave
@@ -769,7 +772,7 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
       if (c.has_dim4 && okind == BK_PYR4 && act) { const float4* x4 = (const float4*)(c.ext + b * SOLX_N); op.X0 = x4[0]; op.X1 = x4[1]; op.X2 = x4[2]; }
       return op;
     };
-    auto processQ = [&](QOp& op, float& impl) __attribute__((always_inline)) {
+    auto processQ = [&](QOp& op, int& impl) __attribute__((always_inline)) {
       KEEP4(op.hd); KEEP4(op.J); KEEP4(op.p0); KEEP4(op.r0); KEEP4(op.r1); KEEP4(op.r2); KEEP4(op.A0); KEEP4(op.A1); KEEP4(op.A2); KEEP4(op.A3);
       if (!DIAGM) KEEP4(op.B);
       if (c.has_dim4) { KEEP4(op.X0); KEEP4(op.X1); KEEP4(op.X2); }
@@ -801,7 +804,7 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
 #undef MJH_ROWSUM
       ak += (Bp[0] * dphi[0] + Bp[1] * dphi[1] + Bp[2] * dphi[2] + Bp[3] * dphi[3]) * bs;
       if (on) c.qacc[d] = ak;                                                 // scatter (the group's blocks touch disjoint dofs)
-      impl += op.act * imp;
+      impl += imp_fixed(op.act * imp, iq.qs);
       if constexpr (BUF) {
         const unsigned of = (l == 0 && op.act > 0.0f) ? (unsigned)op.b * 64u + (unsigned)(BF_F * 4) : MJH_BUF_OOB;
         mjh_v4u f4; mjh_v2u f2;
@@ -827,7 +830,7 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
       if (c.gstart[gF] + 4 * cF >= c.gstart[gF + 1]) { cF = c.wid; gF = gF + 1 == c.ngrp ? 0 : gF + 1; }
       return o;
     };
-    float impl = 0; bool done = false;
+    int impl = 0; bool done = false;
     auto stepDone = [&]() __attribute__((always_inline)) {          // end of a step; at the end of a sweep: convergence test
       cP += nw;
       if (c.gstart[gP] + 4 * cP < c.gstart[gP + 1]) return;         // more chunks of this group for this wave
@@ -835,16 +838,16 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
       if (multi) __syncthreads();                                     // the group's scatters are visible to every wave
       if (++gP < c.ngrp) return;
       gP = 0; niter++;
-      float improvement = readlane_f(impl, 0) + readlane_f(impl, 16) + readlane_f(impl, 32) + readlane_f(impl, 48);
+      int improvement = __builtin_amdgcn_readlane(impl, 0) + __builtin_amdgcn_readlane(impl, 16) + __builtin_amdgcn_readlane(impl, 32) + __builtin_amdgcn_readlane(impl, 48);
       if (multi) {
-        if (lane == 0) c.red[c.wid] = improvement;
+        if (lane == 0) ((int*)c.red)[c.wid] = improvement;
         __syncthreads();
         improvement = 0;
-        for (int w = 0; w < nw; w++) improvement += c.red[w];
+        for (int w = 0; w < nw; w++) improvement += ((const int*)c.red)[w];
         __syncthreads();
       }
       impl = 0;
-      done = improvement * c.scale < tol || niter >= itmax;
+      done = improvement < iq.thr || niter >= itmax;
     };
     if (c.ngrp >= 3) {
       QOp o0 = nextFetch(), o1 = nextFetch(), o2;
@@ -1694,13 +1697,98 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
     bool patch_order = false;    // contact-patch sweep (patch_pgs.h): it builds its own schedule
     if constexpr (DIAGM && NROW <= 2) patch_order = M.patch != 0;
     if (!patch_order && M.pgs_row_order) {
-      // mj_solPGS's own order (mjh_set_pgs_row_order): block after block as the rows were made, nothing side by side
-      for (int i = lane; i < nblk; i += 64) {
-        s_order_i[i] = i;
-        if (NROW <= 2) { s_sched_i[2*i] = i; s_sched_i[2*i+1] = -1; } else if (nblk > 64) s_sched_i[i] = i;
+      // mj_solPGS's own order: block after block as the rows were made.  Blocks without a common kinematic tree touch disjoint dofs, so
+      // their updates commute exactly; pgs_row_order 1 list-schedules the sequence — block i goes to the first group (with a free place)
+      // after every EARLIER block that shares a tree with it — and the sweeps that solve several blocks side by side (dual: 2, many-body:
+      // 4 or 16 per wave-step) produce the sequential sweep's iterates bit for bit.  pgs_row_order 2 (and the forms that are
+      // sequential anyway, and models with more than 64 trees): one block per group.
+      bool listed = false;
+      auto tree_of = [&](const int adr) __attribute__((always_inline)) { if constexpr (DIAGM) return adr / 6; else return (int)dof_treeid[adr]; };
+      if constexpr (NROW <= 2) {
+        if (M.pgs_row_order == 1 && nblk <= 64 && M.ntree <= 64) {
+          // dual-block sweep: lanes = blocks; lastv: lane t = first group tree t is free again; cntv: lane g = blocks of group g
+          listed = true;
+          int t1 = -1, t2 = -1;
+          if (lane < nblk) {
+            const int* hd = s_blki_i + lane * BLKI_STRIDE;
+            const int a = hd[2] & 0xffff;
+            if (a != 0xffff) t1 = tree_of(a);
+            if ((hd[3] >> 16) != 0) t2 = tree_of(hd[3] & 0xffff);
+          }
+          int lastv = 0, cntv = 0, mygrp = 0, myrank = 0;
+          for (int i = 0; i < nblk; i++) {
+            const int a = __builtin_amdgcn_readlane(t1, i), b = __builtin_amdgcn_readlane(t2, i);
+            const int ea = a >= 0 ? __builtin_amdgcn_readlane(lastv, a) : 0, eb = b >= 0 ? __builtin_amdgcn_readlane(lastv, b) : 0;
+            const int e = max(ea, eb);
+            const unsigned long long bal = __ballot(cntv < 2 && lane >= e);
+            const int g = __ffsll((long long)bal) - 1;
+            const int c = __builtin_amdgcn_readlane(cntv, g);
+            if (lane == i) { mygrp = g; myrank = c; }
+            if (lane == g) cntv++;
+            if (lane == a || lane == b) lastv = g + 1;
+            ngrp = max(ngrp, g + 1);
+          }
+          const int gend = wave_incl_scan_i(lane < ngrp ? cntv : 0, lane);
+          if (lane < ngrp && cntv < 2) s_sched_i[2*lane + 1] = -1;
+          if (lane < nblk) { s_sched_i[2*mygrp + myrank] = lane; s_order_i[__shfl(gend, mygrp) - __shfl(cntv, mygrp) + myrank] = lane; }
+        }
       }
-      if (NROW > 2 && nblk > 64 && lane == 0) s_sched_i[nblk] = nblk;
-      ngrp = nblk;
+      if constexpr (NROW == 8) {
+        int* info = (int*)(lds + M.scratch_off);        // [nblk] group | rank << 16 of every block, then [nblk] blocks per group
+        if (M.pgs_row_order == 1 && nblk > 64 && M.rowW <= 16 && M.ntree <= 64 && 2 * nblk <= M.k1_floats && nblk < 2048) {   // (rowW <= 16: the forms that solve blocks side by side)
+          listed = true;
+          int* gcnt = info + nblk;
+          const int cap = M.group_max;
+          for (int i = lane; i < nblk; i += 64) gcnt[i] = 0;
+          WSYNC();
+          int lastv = 0;
+          for (int base = 0; base < nblk; base += 64) {
+            int t1 = -1, t2 = -1;
+            if (base + lane < nblk) {
+              const int* hd = s_blki_i + (base + lane) * BLKI_STRIDE;
+              const int a = hd[2] & 0xffff;
+              if (a != 0xffff) t1 = tree_of(a);
+              if ((hd[3] >> 16) != 0) t2 = tree_of(hd[3] & 0xffff);
+            }
+            const int nb = min(64, nblk - base);
+            for (int i = 0; i < nb; i++) {
+              const int a = __builtin_amdgcn_readlane(t1, i), b = __builtin_amdgcn_readlane(t2, i);
+              const int ea = a >= 0 ? __builtin_amdgcn_readlane(lastv, a) : 0, eb = b >= 0 ? __builtin_amdgcn_readlane(lastv, b) : 0;
+              int e = max(ea, eb), g = -1, c = 0;
+              while (g < 0) {                           // first group >= e with a free place (group nblk - 1 at the latest)
+                const int gg = e + lane;
+                const int cc = gg < nblk ? gcnt[gg] : cap;
+                const unsigned long long bal = __ballot(cc < cap);
+                if (bal) { const int q = __ffsll((long long)bal) - 1; g = e + q; c = __builtin_amdgcn_readlane(cc, q); } else e += 64;
+              }
+              if (lane == 0) { gcnt[g] = c + 1; info[base + i] = g | (c << 16); }
+              if (lane == a || lane == b) lastv = g + 1;
+              ngrp = max(ngrp, g + 1);
+              WSYNC();
+            }
+          }
+          // group starts (exclusive prefix of the counts), then the blocks to their places
+          int carry = 0;
+          for (int base = 0; base < ngrp; base += 64) {
+            const int g = base + lane;
+            const int cnt = g < ngrp ? gcnt[g] : 0;
+            const int incl = wave_incl_scan_i(cnt, lane);
+            if (g < ngrp) s_sched_i[g] = carry + incl - cnt;
+            carry += __shfl(incl, 63);
+          }
+          if (lane == 0) s_sched_i[ngrp] = nblk;
+          WSYNC();
+          for (int i = lane; i < nblk; i += 64) { const int w = info[i]; s_order_i[s_sched_i[w & 0xffff] + (w >> 16)] = i; }
+        }
+      }
+      if (!listed) {
+        for (int i = lane; i < nblk; i += 64) {
+          s_order_i[i] = i;
+          if (NROW <= 2) { s_sched_i[2*i] = i; s_sched_i[2*i+1] = -1; } else if (nblk > 64) s_sched_i[i] = i;
+        }
+        if (NROW > 2 && nblk > 64 && lane == 0) s_sched_i[nblk] = nblk;
+        ngrp = nblk;
+      }
     } else if (!patch_order) {
       if (nblk > 64) {
         // many-block models: groups of up to 4 mutually independent blocks (the many-body solver puts one block on each
@@ -2302,9 +2390,10 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
             }
             WSYNC();
             pa.blki = s_blki_i; pa.blkf = s_blkf; pa.J = s_J; pa.qLDinv = s_bias; pa.nblk = nblk; pa.nv = nv; pa.maxcon = M.maxcon;
-            int swork = 0;
-            const int nstep = patch_build(pa, lane, flags, swork);
-            if (warm) patch_warmstart(pa, lane, nstep, L.tmpv2, L.qacc, L.tmpv);
+            pa.row_order = M.pgs_row_order;
+            int swork = 0, npatch = 0;
+            const int nstep = patch_build(pa, lane, flags, swork, npatch);
+            if (warm) patch_warmstart(pa, lane, nstep, npatch, L.tmpv2, L.qacc, L.tmpv);
             for (int d = lane; d < nv; d += 64) s_qacc[d] += s_tmpv[d];       // a^ = M^1/2 (qacc_smooth + M^-1 J^T f)
             WSYNC();
             PROF(12);
@@ -2512,7 +2601,8 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
             if (has_dim4 && op.kind == BK_PYR4) { const float4* x4 = (const float4*)(s_ext + b * SOLX_N); op.X0 = x4[0]; op.X1 = x4[1]; op.X2 = x4[2]; }
             return op;
           };
-          auto processD = [&](DOp& op, float& improvement) __attribute__((always_inline)) {
+          ImpQ iq = imp_quantum(scale, tol);     // (fixed-point cost decrease: the total must not depend on which half carried which block)
+          auto processD = [&](DOp& op, int& improvement) __attribute__((always_inline)) {
             const int kind = op.kind;
             KEEP4(op.J); KEEP4(op.r0); KEEP4(op.r1); KEEP4(op.r2); KEEP4(op.A0); KEEP4(op.A1); KEEP4(op.A2); KEEP4(op.A3);
             if (!DIAGM) KEEP4(op.B);
@@ -2530,7 +2620,7 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
             if (kind == BK_PYR4) imp = pgs_dual<4, 6, EXTRA>(ns, op.R, lo, hi, ab, f, Q, X, Jd, Bp, bs, lq, a);
             else if (kind == BK_PYR3) imp = pgs_dual<3, 4, EXTRA>(ns, op.R, lo, hi, ab, f, Q, X, Jd, Bp, bs, lq, a);
             else imp = pgs_dual<1, 1, EXTRA>(ns, op.R, lo, hi, ab, f, Q, X, Jd, Bp, bs, lq, a);
-            improvement += op.act * imp;
+            improvement += imp_fixed(op.act * imp, iq.qs);
             if (d0 == 0 && op.act > 0.0f) {
               float* bf = s_blkf + op.b * BLKF_STRIDE + BF_F;
               *(float4*)(bf) = make_float4(f[0], f[1], f[2], f[3]);
@@ -2538,16 +2628,15 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
             }
           };
           for (int mode = 0; mode < nmode; mode++) {   // main sweeps, then (EXTRA) the noslip sweeps over the same schedule
-          if (mode == 1) { ns = true; nmain = niter; niter = 0; itmax = M.noslip_iterations; tol = M.noslip_tolerance; gS = 0; WSYNC(); }
+          if (mode == 1) { ns = true; nmain = niter; niter = 0; itmax = M.noslip_iterations; tol = M.noslip_tolerance; gS = 0; iq = imp_quantum(scale, tol); WSYNC(); }
           if (ngrp == 1) {
             // a single group: its operands (the forces) change under the prefetch, so no pipeline
             for (int it = 0; it < itmax; it++) {
-              float impl = 0;
+              int impl = 0;
               DOp op = loadOp(hdrOf(*(const int2*)s_sched_i));
               processD(op, impl);
               niter = it + 1;
-              const float improvement = readlane_f(impl, 0) + readlane_f(impl, 32);
-              if (improvement * scale < tol) break;
+              if (__builtin_amdgcn_readlane(impl, 0) + __builtin_amdgcn_readlane(impl, 32) < iq.thr) break;
             }
           } else {
             int2 pqN = nextS();                      // pair of step 0
@@ -2555,7 +2644,7 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
             DOp opA = loadOp(hN), opB;               // operands of step 0
             hN = hdrOf(pqN); pqN = nextS();          // header of step 1, pair of step 2
             for (int it = 0; it < itmax; it++) {
-              float impl = 0;
+              int impl = 0;
               for (int g = 0; g < ngrp; g += 2) {
                 opB = loadOp(hN); hN = hdrOf(pqN); pqN = nextS();
                 processD(opA, impl);
@@ -2565,8 +2654,7 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
                 } else opA = opB;                    // odd group count: step 0 of the next sweep was loaded into B
               }
               niter = it + 1;
-              const float improvement = readlane_f(impl, 0) + readlane_f(impl, 32);
-              if (improvement * scale < tol) break;
+              if (__builtin_amdgcn_readlane(impl, 0) + __builtin_amdgcn_readlane(impl, 32) < iq.thr) break;
             }
           }
           }   // sweep mode

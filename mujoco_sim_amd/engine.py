@@ -308,8 +308,16 @@ class Engine:
         return self.lib.mjh_lds_bytes(self.h)
 
     def solver_order(self):
-        """0: independent pairs / groups of blocks, 1: contact patches, 2: mj_solPGS's row order (mjh_solver_order)"""
+        """2: mj_solPGS's row order (default); legacy: 1 contact patches, 0 independent pairs / groups of blocks (mjh_solver_order)"""
         return self.lib.mjh_solver_order(self.h)
+
+    def patch_sweep(self):
+        """1: contact-patch form of the sweeps (small free-body models), 0: a block form (mjh_patch_sweep)"""
+        return self.lib.mjh_patch_sweep(self.h)
+
+    def pgs_schedule(self):
+        """1: row order, list-scheduled (default), 2: row order, strictly sequential, 0: legacy reordering schedule (mjh_pgs_schedule)"""
+        return self.lib.mjh_pgs_schedule(self.h)
 
     def dense_solver(self):
         """1: articulated many-body model solved by the dense row-space solver (mjh_dense_solver)"""

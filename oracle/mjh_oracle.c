@@ -1381,12 +1381,11 @@ static void constraint_update(orc_data* d, const double* jar, double* force) {
   }
 }
 
-/* Gauss-Seidel visiting order shared with the HIP path (HISTORY.md §5): rows are grouped into blocks
- * (one per equality / friction-loss / limit row, one per contact = its pyramid rows); blocks are visited in
- * the greedy "independent pair" order — block i, then the first later unvisited block that shares no
- * kinematic tree with it — so that the device can solve the two blocks of a pair side by side in the two
- * halves of a wavefront.  Any permutation is a valid PGS order (MuJoCo uses plain row order); the converged
- * solution is the same. */
+/* Gauss-Seidel visiting order.  Default: plain constraint-row order (mj_solPGS).  The LEGACY orders of the HIP path (HISTORY.md §5;
+ * reachable with orc_set_pgs_row_order(0) / mjh_set_pgs_row_order(0)) group the rows into blocks (one per equality / friction-loss /
+ * limit row, one per contact = its pyramid rows) and visit them in the greedy "independent pair" order — block i, then the first
+ * later unvisited block that shares no kinematic tree with it.  Any permutation is a valid PGS order; the converged solution is the
+ * same, the iterates at the sweep cap are not. */
 static void block_trees(const orc_data* d, int row, int* t1, int* t2) {
   const mjh_model* m = d->m; int id = d->efc_id[row];
   *t1 = *t2 = -1;
@@ -1403,12 +1402,17 @@ static void block_trees(const orc_data* d, int row, int* t1, int* t2) {
       *t2 = m->body_treeid[m->geom_bodyid[d->contact[id].geom2]];
   }
 }
-/* 0 (default): the device's order — contact patches (m_patch_order below) or the independent-pair / independent-group order above;
- * 1: plain constraint-row order, the order mj_solPGS visits the rows in [UPSTREAM].  Both are Gauss-Seidel on the same dual
- * problem: they agree at convergence; where the sweep cap ends the iteration first (settled S24 piles run into the default
- * 100 sweeps at tolerance 1e-8) the iterates differ, and tests/test_oracle_pinning.py measures by how much. */
-static int g_pgs_row_order = 0;
-void orc_set_pgs_row_order(int plain) { g_pgs_row_order = plain != 0; }
+/* 1 (default): plain constraint-row order, the order mj_solPGS visits the rows in [UPSTREAM] — and the device's default: it runs this
+ * very sequence, blocks without a common kinematic tree side by side (they commute exactly: patch_pgs.h, step_kernel.h "list schedule").
+ * 0: the device's legacy orders (mjh_set_pgs_row_order(0)) — contact patches (m_patch_order below) or the independent-pair /
+ * independent-group order above.  Both are Gauss-Seidel on the same dual problem: they agree at convergence; where the sweep cap ends
+ * the iteration first (settled S24 piles run into the default 100 sweeps at tolerance 1e-8) the iterates differ, and
+ * tests/test_oracle_pinning.py measures by how much. */
+static int g_pgs_row_order = 1;
+/* 2: the constraint-row order as the DEVICE walks it by default — the same sequence, list-scheduled (pgs_order below): blocks that
+ * share no kinematic tree swap places, nothing else does.  Exists so that a test can show the claim the device relies on in fp64 too:
+ * the iterates of 2 equal those of 1 bit for bit (tests/test_oracle_pinning.py). */
+void orc_set_pgs_row_order(int mode) { g_pgs_row_order = mode < 0 || mode > 2 ? 1 : mode; }
 static int m_group_max(const mjh_model* m) {
   if (m->ntree > 64) return 4;
   for (int t = 0; t < m->ntree; t++) if (m->tree_dofnum[t] > 8) return 4;
@@ -1440,7 +1444,7 @@ static int m_row_order(const mjh_model* m) {
 }
 static int pgs_order(const orc_data* d, int* order) {
   int nefc = d->nefc, nblk = 0;
-  if (g_pgs_row_order || m_row_order(d->m)) { for (int i = 0; i < nefc; i++) order[i] = i; return nefc; }
+  if (g_pgs_row_order == 1 || (!g_pgs_row_order && m_row_order(d->m))) { for (int i = 0; i < nefc; i++) order[i] = i; return nefc; }
   int* bstart = d->scr_int;                       /* (nefc + 1) * 5 ints; the sequences below take the next (nefc + 1) * 6 */
   int *bnum = bstart + nefc + 1, *bt1 = bnum + nefc + 1, *bt2 = bt1 + nefc + 1, *used = bt2 + nefc + 1;
   for (int i = 0; i < nefc;) {
@@ -1451,6 +1455,44 @@ static int pgs_order(const orc_data* d, int* order) {
     nblk++; i += n;
   }
   int k = 0;
+  if (g_pgs_row_order == 2) {
+    /* the device's default walk of the constraint order (patch_pgs.h: patch_build; step_kernel.h: "list schedule"; the places per step
+     * differ by kernel form — every such schedule gives the same iterates): units = blocks, or
+     * (patch models) maximal runs of consecutive contacts of one body pair with at most 16 rows; unit i goes to the first step with
+     * a free place after every EARLIER unit that shares a tree with it; the steps are emitted one after the other.  Relative order
+     * of any two units with a common tree = constraint order. */
+    int* seq = d->scr_int + (size_t)(nefc + 1) * 5;
+    int *ufirst = seq, *ucount = ufirst + nefc + 1, *ustep = ucount + nefc + 1, *scount = ustep + nefc + 1, *tlast = scount + nefc + 1;
+    int patches = m_patch_order(d->m), cap = patches ? 4 : (nblk > 64 ? m_group_max(d->m) : 2), nu = 0, rows = 0, nstep = 0;
+    for (int i = 0; i < nblk; i++) {
+      int t1 = bt1[i], t2 = bt2[i];
+      if (t1 < 0) { t1 = t2; t2 = -1; }
+      if (t2 == t1) t2 = -1;
+      if (t2 >= 0 && t2 < t1) { int t = t1; t1 = t2; t2 = t; }
+      bt1[i] = t1; bt2[i] = t2;
+      int same = patches && i > 0 && bt1[i-1] == t1 && bt2[i-1] == t2;
+      if (!same || rows + bnum[i] > 16) { ufirst[nu] = i; ucount[nu] = 0; nu++; rows = 0; }
+      ucount[nu-1]++; rows += bnum[i];
+    }
+    for (int s = 0; s <= nu; s++) scount[s] = 0;
+    for (int t = 0; t < d->m->ntree && t <= nefc; t++) tlast[t] = 0;
+    if (d->m->ntree > nefc + 1) { for (int i = 0; i < nefc; i++) order[i] = i; return nefc; }   /* (scratch bound; never with the models at hand) */
+    for (int u = 0; u < nu; u++) {
+      int i = ufirst[u], e = 0;
+      if (bt1[i] >= 0 && tlast[bt1[i]] > e) e = tlast[bt1[i]];
+      if (bt2[i] >= 0 && tlast[bt2[i]] > e) e = tlast[bt2[i]];
+      while (scount[e] >= cap) e++;
+      scount[e]++; ustep[u] = e;
+      if (bt1[i] >= 0) tlast[bt1[i]] = e + 1;
+      if (bt2[i] >= 0) tlast[bt2[i]] = e + 1;
+      if (e + 1 > nstep) nstep = e + 1;
+    }
+    for (int st = 0; st < nstep; st++)
+      for (int u = 0; u < nu; u++)
+        if (ustep[u] == st)
+          for (int i = ufirst[u]; i < ufirst[u] + ucount[u]; i++) for (int r = 0; r < bnum[i]; r++) order[k++] = bstart[i] + r;
+    return k;
+  }
   if (m_patch_order(d->m)) {
     /* contacts sorted by (couples two bodies first, body pair, constraint order); a patch = a maximal run of contacts of one
      * body pair with at most 16 rows; a step = a patch plus up to three later unvisited patches of the sequence that share no

@@ -44,7 +44,7 @@ def test_driver_line_has_everything_the_contract_names():
     # (no ordering between the two is asserted: with the split entry points on cohort streams the literal loop is the faster one in a
     #  process that holds PyTorch's HIP runtime, the fused step in one that does not — HISTORY.md, Round 3)
     assert ll["value"] > 1e5 and ll["fused_step_with_per_step_read_write"]["value"] > 1e5
-    assert set(r["configs"]) == {"s24d", "c2", "c3", "c4", "c5", "s24_pgs_row_order"}
+    assert set(r["configs"]) == {"s24d", "c2", "c3", "c4", "c5", "s24_legacy_patch_order", "s24_row_order_sequential"}
     for name, line in r["configs"].items():
         assert "error" not in line, (name, line)
         assert line["value"] > 0 and line["steps"] >= 6 and line["roofline_frac"] > 0 and line["overflow_envs"] <= 0.02 * line["envs"], (name, line)

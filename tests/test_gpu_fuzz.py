@@ -37,7 +37,7 @@ def test_random_free_body_scenes_match_the_oracle(lib, seed):
     rng = np.random.default_rng(seed)
     m = _scene(lib, rng)
     e = ms.Engine(m, 2)
-    assert e.solver_order() == 1
+    assert e.solver_order() == 2 and e.patch_sweep() == 1
     d = orc.OrcData(m.ptr); d.call("reset")
     v0 = rng.normal(size=m.nv) * 0.3
     v0[0::6] -= 0.3; v0[1::6] -= 0.3                              # push everything towards the corner
@@ -83,7 +83,7 @@ def _table_scene(lib, condim):
 def test_slab_with_four_boxes_long_schedule(lib, condim):
     m = _table_scene(lib, condim)
     e = ms.Engine(m, 2)
-    assert e.solver_order() == 1
+    assert e.solver_order() == 2 and e.patch_sweep() == 1
     d = orc.OrcData(m.ptr); d.call("reset")
     done = 0
     for n, tol in ((1, 2e-5), (40, 1e-3), (120, 5e-3)):

@@ -552,10 +552,18 @@ def test_batched_spawn_destroy_equals_the_per_object_calls():
 # ----------------------------------------------------------------------------- contact-patch sweep (csrc/patch_pgs.h)
 @pytest.mark.gpu
 def test_solver_order_query_matches_the_model_class():
-    """mjh_solver_order: 1 for small free-body models (S24, cube pools), 0 for articulated ones"""
-    e = ms.Engine(ms.scene("s24"), 4); assert e.solver_order() == 1; e.close()
-    e = ms.Engine(ms.scene("arm7", 1), 4); assert e.solver_order() == 0; e.close()
-    e = ms.Engine(ms.scene("pendulum"), 4); assert e.solver_order() == 0; e.close()
+    """mjh_solver_order: 2 (mj_solPGS's row order) by default for every model; mjh_patch_sweep: 1 for small free-body models (S24,
+    cube pools), 0 for articulated ones; mjh_set_pgs_row_order(0) brings the legacy orders back (1: patches, 0: pairs / groups)"""
+    e = ms.Engine(ms.scene("s24"), 4); assert e.solver_order() == 2 and e.patch_sweep() == 1 and e.pgs_schedule() == 1; e.close()
+    e = ms.Engine(ms.scene("arm7", 1), 4); assert e.solver_order() == 2 and e.patch_sweep() == 0; e.close()
+    e = ms.Engine(ms.scene("pendulum"), 4); assert e.solver_order() == 2 and e.patch_sweep() == 0; e.close()
+    lib = ms.capi.load()
+    lib.mjh_set_pgs_row_order(0)
+    try:
+        e = ms.Engine(ms.scene("s24"), 4); assert e.solver_order() == 1 and e.pgs_schedule() == 0; e.close()
+        e = ms.Engine(ms.scene("arm7", 1), 4); assert e.solver_order() == 0; e.close()
+    finally:
+        lib.mjh_set_pgs_row_order(1)
 
 
 @pytest.mark.gpu
@@ -579,7 +587,7 @@ def test_patch_sweep_with_condim_1_3_4_contacts_matches_oracle(lib):
     lib.mjh_builder_destroy(b)
     assert m.nv == 30
     m.c.maxcon = 48; m.c.maxefc = 48 * 6          # (the default capacity is every pair at full manifold: beyond the patch sweep's 64 contacts)
-    e = ms.Engine(m, 2); assert e.solver_order() == 1; e.close()
+    e = ms.Engine(m, 2); assert e.solver_order() == 2 and e.patch_sweep() == 1; e.close()
     q0 = m.array("qpos0").copy()
     q0[7*3+3:7*3+7] = [np.cos(0.6), 0, np.sin(0.6), 0]          # lean the capsule against the wall
     v0 = np.zeros(m.nv); v0[0] = -0.3; v0[6 + 1] = 0.2
@@ -630,7 +638,7 @@ def test_free_bodies_with_gravity_compensation_and_cartesian_forces_match_oracle
     lib.mjh_builder_destroy(b)
     assert m.nv == 18
     m.c.maxcon = 32; m.c.maxefc = 32 * 6
-    e = ms.Engine(m, 2); assert e.solver_order() == 1
+    e = ms.Engine(m, 2); assert e.solver_order() == 2 and e.patch_sweep() == 1
     d = orc.OrcData(m.ptr); d.call("reset")
     v0 = np.zeros(m.nv); v0[3:6] = [0.5, -0.3, 0.2]; v0[6 + 3: 6 + 6] = [0.1, 0.4, -0.2]
     e.set_state(qvel=np.tile(v0, (2, 1))); d.f("qvel")[:] = v0

@@ -99,7 +99,7 @@ def test_quad_sweep_with_single_row_blocks_matches_the_oracle(lib):
     assert m.nv == 120 and m.neq == 4
     nenv = 3
     e = ms.Engine(m, nenv)
-    assert e.solver_order() == 0 and e.lds_bytes <= 160 * 1024
+    assert e.solver_order() == 2 and e.patch_sweep() == 0 and e.lds_bytes <= 160 * 1024
     d = orc.OrcData(m.ptr)
     rng = np.random.default_rng(5)
     v0 = rng.normal(size=m.nv) * 0.2

@@ -60,7 +60,7 @@ def test_pgs_row_order_deviation_at_the_sweep_cap_is_measured():
             worst_pos = max(worst_pos, float(np.abs(a.f("qpos") - b.f("qpos")).max()))
             assert a.i("ncon") > 8 and np.isfinite(a.f("qpos")).all() and np.isfinite(b.f("qpos")).all()
     finally:
-        L.orc_set_pgs_row_order(0)
+        L.orc_set_pgs_row_order(1)
     print(f"row-order deviation over {N} envs: 1-step |d qacc| {worst_acc:.3e}, 150-step |d qpos| {worst_pos:.3e}, envs at the cap {capped}")
     assert capped >= 2                       # the premise: the default cap, not convergence, ends most solves
     assert 0 < worst_acc < 2.0 and worst_pos < 5e-2
@@ -86,7 +86,37 @@ def test_both_orders_converge_to_the_same_solution_when_allowed_to():
             assert np.abs(a.f("qacc") - b.f("qacc")).max() < 2e-5 * scale, (i, a.i("solver_iter"), b.i("solver_iter"))
     finally:
         m.c.opt.iterations, m.c.opt.tolerance = it0, tol0
-        L.orc_set_pgs_row_order(0)
+        L.orc_set_pgs_row_order(1)
+
+
+def test_list_scheduled_row_order_gives_the_sequential_iterates_bit_for_bit():
+    """what the device's default relies on: blocks without a common kinematic tree commute EXACTLY under Gauss-Seidel, so a schedule
+    that only swaps such blocks (orc_set_pgs_row_order(2): the constraint order, list-scheduled as patch_pgs.h / step_kernel.h do)
+    reproduces the plain row-order sweep (1, mj_solPGS) bit for bit — in fp64 here, asserted on the device itself in
+    tests/test_gpu_teacher_forced.py.  S24 settled piles at the sweep cap (where any REAL reordering shows: test above) and a 12-box pile."""
+    L = orc.lib()
+    cases = []
+    m = ms.scene("s24"); tab = m.s24_randomize(0, 3)
+    for i in range(3):
+        cases.append((m, tab, i, 300, 40))
+    mp = ms.scene("boxpile", 12); tp = ms.boxes_randomize(mp, 0, 2, jitter=0.01)
+    for i in range(2):
+        cases.append((mp, tp, i, 150, 25))
+    try:
+        for (mm, tt, i, settle, n) in cases:
+            L.orc_set_pgs_row_order(1)
+            s = oracle_s24(mm, tt, i); s.step(settle)
+            a, b = _clone(mm, tt, i, s), _clone(mm, tt, i, s)
+            its = []
+            for k in range(n):
+                L.orc_set_pgs_row_order(1); a.step(1)
+                L.orc_set_pgs_row_order(2); b.step(1)
+                its.append(a.i("solver_iter"))
+                assert a.i("solver_iter") == b.i("solver_iter") and a.i("nefc") == b.i("nefc")
+                assert np.array_equal(a.f("qacc"), b.f("qacc")) and np.array_equal(a.f("qpos"), b.f("qpos")), (mm.nv, i, k)
+            assert a.i("ncon") >= 8 and max(its) > 5
+    finally:
+        L.orc_set_pgs_row_order(1)
 
 
 def test_patch_and_pair_orders_converge_to_the_same_solution_and_deviate_little_at_the_cap():
@@ -99,6 +129,7 @@ def test_patch_and_pair_orders_converge_to_the_same_solution_and_deviate_little_
     it0, tol0 = m.c.opt.iterations, m.c.opt.tolerance
     worst = 0.0
     try:
+        L.orc_set_pgs_row_order(0)             # the two LEGACY orders (mjh_set_pgs_row_order(0))
         for i in range(3):
             L.orc_set_pgs_patch_order(-1)
             s = oracle_s24(m, tab, i); s.step(300)
@@ -114,7 +145,7 @@ def test_patch_and_pair_orders_converge_to_the_same_solution_and_deviate_little_
             assert np.abs(a.f("qacc") - b.f("qacc")).max() < 2e-5 * scale, (i, a.i("solver_iter"), b.i("solver_iter"))
     finally:
         m.c.opt.iterations, m.c.opt.tolerance = it0, tol0
-        L.orc_set_pgs_patch_order(-1)
+        L.orc_set_pgs_patch_order(-1); L.orc_set_pgs_row_order(1)
     assert worst < 0.5, worst
 
 
