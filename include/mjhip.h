@@ -450,6 +450,13 @@ double mjh_get_timestep(const mjh_engine*);
  * memory with the step issued as three launches (assemble, solve, integrate); 1: LDS whenever the working set fits one
  * CU's 160 KiB; 2: global pools whenever possible.  Results do not depend on the layout beyond fp32 rounding. */
 void mjh_set_layout_policy(int policy);
+/* Engines created afterwards (process-wide; default 1, environment MJH_WINDOW): mjh_step of a small free-body model (the models that take
+ * the contact-patch sweep: every kinematic tree a single free body, nv <= 32) in the default row order runs as two launches — the step
+ * kernel up to the constraint rows, then mjh_window_kernel (csrc/window_pgs.h): projected Gauss-Seidel over windows of 16 consecutive
+ * rows, FOUR environments per wavefront with the rows in registers, followed by mj_Euler.  0: the one-launch fused step with the
+ * contact-patch sweep (same order, same iterates up to fp32 rounding).  mjh_window_solver() reports what an engine runs. */
+void mjh_set_window_solver(int on);
+int mjh_window_solver(const mjh_engine*);
 int mjh_set_cohorts(mjh_engine*, int n);
 int mjh_get_cohorts(const mjh_engine*);
 /* HIP-event timing of the step-kernel launches on the stream they run on: enable (on = 1: every launch, on = N > 1: every

@@ -205,6 +205,8 @@ SYMBOLS = [
     ("mjh_set_timestep", C.c_int, [_vp, C.c_double]),
     ("mjh_get_timestep", C.c_double, [_vp]),
     ("mjh_set_layout_policy", None, [C.c_int]),
+    ("mjh_set_window_solver", None, [C.c_int]),
+    ("mjh_window_solver", C.c_int, [_vp]),
     ("mjh_set_pgs_row_order", None, [C.c_int]),
     ("mjh_set_cohorts", C.c_int, [_vp, C.c_int]),
     ("mjh_get_cohorts", C.c_int, [_vp]),

@@ -45,6 +45,9 @@ struct DModel {
   // is dead once the solver starts, from the position-stage arrays to the base-row storage), its size, and of the two live
   // tables next to it: one descriptor per patch, one descriptor per (step, 16-lane row) of the sweep schedule
   int patch, pool, pool_floats, pdesc, pslot;
+  // window sweep (window_pgs.h): the fused step of a patch-eligible model in row order as two launches, assemble (PH_PRE) -> mjh_window_kernel
+  // (four envs per wavefront, rows in registers); win_nvt: dof slots of a row record (24 or 32)
+  int window, win_nvt;
   int pgs_row_order;   // 1: Gauss-Seidel visits the constraint rows in their own order, one block after the other (mj_solPGS's order; mjh_set_pgs_row_order)
   // dense row-space solver of the many-body layout (dense_pgs.h): on / off, row capacity (a multiple of 64, <= 256), nv padded to 16
   int dense, dense_cap, dense_nvs;
@@ -78,6 +81,8 @@ struct DState {
   // many-body models (nv > 64): per-env pools that do not fit LDS (contacts, blocks, Jacobians) live here; a negative
   // Lay offset -1-k addresses float k of the env's slice
   float* gscratch; long long gstride;
+  // window sweep (window_pgs.h): per-env hand-over slice (header, scaled dof vectors, state, window rows, tiles of streamed windows)
+  float* wbuf; long long wstride;
 };
 
 // LDS layout (float offsets into the dynamic shared array; negative: offset into the env's global scratch slice)

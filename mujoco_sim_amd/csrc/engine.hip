@@ -169,6 +169,8 @@ static int pair_cap(int t1, int t2) {
 // layout.  Needs no HIP device (mjh_query_lds_bytes uses it for capacity planning and in the CPU tests).
 struct HostPack { DModel M{}; Lay L{}; std::vector<int> I; std::vector<float> F; int o_controlled = 0, o_odom = 0, lds_bytes = 0; long long gstride = 0; };
 // Gauss-Seidel order of engines created afterwards (mjhip.h): 1 = mj_solPGS's own row order
+static int g_window_solver = getenv("MJH_WINDOW") ? (atoi(getenv("MJH_WINDOW")) != 0) : 1;
+extern "C" void mjh_set_window_solver(int on) { g_window_solver = on ? 1 : 0; }
 static int g_pgs_row_order = 1;
 extern "C" void mjh_set_pgs_row_order(int mode) { g_pgs_row_order = mode < 0 || mode > 2 ? 1 : mode; }
 static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big = false, bool allow_patch = true) {
@@ -311,6 +313,10 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     if (!M.pgs_row_order && nv > 32) for (int t = 0; t < m->ntree; t++) if (m->tree_dofnum[t] > 16) M.pgs_row_order = 1;
     const bool patch = allow_patch && diagM && !big && nv <= 32 && M.noslip_iterations == 0 && M.maxcon <= 64 && !keep;
     M.patch = patch ? 1 : 0;
+    // window sweep (window_pgs.h): mjh_step of a patch-eligible model in row order = assemble launch + mjh_window_kernel (MJH_WINDOW=0 /
+    // mjh_set_window_solver(0): the fused kernel's patch sweep instead — same order, same iterates up to fp32 rounding)
+    M.window = (patch && M.pgs_row_order != 0 && g_window_solver && nv <= 32 && m->njnt <= 16 && m->nq <= 40) ? 1 : 0;
+    M.win_nvt = nv <= 24 ? 24 : 32;
     L.qpos = put(m->nq);
     L.qvel = put(nv); L.qvref = put(nv); L.ws = put(nv); L.qacc = put(nv); L.smooth = put(nv); L.asmooth = put(nv); L.passive = put(nv);
     L.bias = put(nv); L.applied = put(nv); L.tmpv = put(nv); L.tmpv2 = put(nv);
@@ -513,6 +519,11 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   rc |= dev_alloc(e, &S.qfrc_inverse, nv_all);
   S.gscratch = nullptr; S.gstride = hp.gstride;
   if (M.big) rc |= dev_alloc(e, &S.gscratch, (size_t)nenv * (size_t)hp.gstride, false);   // many-body models: contact / block / Jacobian pools
+  S.wbuf = nullptr; S.wstride = 0;
+  if (M.window) {   // window sweep: header + vectors + WN_MAXW windows of rows + tiles of the streamed windows, per env
+    S.wstride = ((WN_ROWS + WN_MAXW * (M.win_nvt + 2) * 16 + WN_MAXW * WN_TILE * 16 + 63) / 64) * 64;
+    rc |= dev_alloc(e, &S.wbuf, (size_t)nenv * (size_t)S.wstride, true);
+  }
   if (M.big && M.dense && e->lpt && nenv >= 1024) {
     // one word per cohort in host-mapped memory: "a env of the cohort swept long when its launch order was last rebuilt" (mjh_order_kernel)
     HIPCHK(hipHostMalloc((void**)&e->h_dense, MJH_MAX_COHORTS * 4 * sizeof(int), hipHostMallocMapped));
@@ -730,6 +741,15 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
                  else hipLaunchKernelGGL((mjh_solve_kernel<false, false>), dim3(g1 - g0), thr, lds, st, e->dC, e->S, g0); }
           HIPCHK(hipGetLastError());
           rc = launch_on(e, st, g0, g1 - g0, 1, PH_STEP2 | PH_POST, 0);
+        }
+      } else if (e->M.window && e->S.wbuf) {
+        // window sweep (window_pgs.h): assemble launch, then four envs per wavefront through the sweeps and the integration
+        rc = launch_on(e, st, g0, g1 - g0, 1, ph | PH_PRE, 0);
+        if (!rc) {
+          const int n = g1 - g0;
+          if (e->M.win_nvt == 24) hipLaunchKernelGGL((mjh_window_kernel<24, WN_NW24>), dim3((n + 3) / 4), dim3(64), 0, st, e->dC, e->S, g0, n);
+          else hipLaunchKernelGGL((mjh_window_kernel<32, WN_NW32>), dim3((n + 3) / 4), dim3(64), 0, st, e->dC, e->S, g0, n);
+          HIPCHK(hipGetLastError());
         }
       } else rc = launch_on(e, st, g0, g1 - g0, 1, ph, 0);
       if (ta && !rc) HIPCHK(hipEventRecord(tb, st));
@@ -1435,5 +1455,6 @@ extern "C" int mjh_lds_bytes(const mjh_engine* e) { return e ? e->lds_bytes : 0;
 extern "C" int mjh_solver_order(const mjh_engine* e) { return !e ? 0 : e->M.pgs_row_order ? 2 : e->M.patch ? 1 : 0; }
 extern "C" int mjh_pgs_schedule(const mjh_engine* e) { return !e ? 0 : e->M.pgs_row_order; }
 extern "C" int mjh_patch_sweep(const mjh_engine* e) { return !e ? 0 : e->M.patch; }
+extern "C" int mjh_window_solver(const mjh_engine* e) { return !e ? 0 : (e->M.window && e->S.wbuf ? 1 : 0); }
 extern "C" int mjh_dense_solver(const mjh_engine* e) { return e && e->M.big && e->split3 && e->M.dense ? 1 : 0; }
 extern "C" const char* mjh_version(void) { return "mjhip 0.1 (gfx950)"; }

@@ -896,6 +896,7 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
 // asks for noslip sweeps; a separate instantiation so that models without either (S24, box piles, the robots'
 // primitive geometry) keep their code size and register allocation
 #include "patch_pgs.h"
+#include "window_pgs.h"
 
 template <int NROW, bool DIAGM, bool EXTRA>
 #ifndef MJH_STEP_WAVES
@@ -981,6 +982,11 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
   // many-body layout, three-launch step (engine.hip): PH_PRE stops in front of the solver sweeps and hands over through the
   // env's scratch slice; PH_POST skips everything between the factorisation and the end of the sweeps
   const bool pre = NROW == 8 && (ph & PH_PRE), post = NROW == 8 && (ph & PH_POST);
+  // window sweep (window_pgs.h): assemble launch of a patch-eligible free-body model; an env WITHOUT constraint rows (or with more than
+  // the window kernel takes) finishes the step in this launch and leaves 0 in its hand-over header
+  bool wpre = false;
+  if constexpr (DIAGM && NROW <= 2) wpre = M.window != 0 && M.patch != 0 && (ph & PH_PRE) && S.wbuf != nullptr;
+  if (wpre && lane == 0) ((int*)(S.wbuf + (size_t)env * (size_t)S.wstride))[0] = 0;
   if (post) for (int i = lane; i < nv; i += 64) s_qvel[i] = gs[L.g_qvel + i];     // (the controller may have overridden velocities)
   double time = S.time[env];
   // spawn/destroy as slot toggling: bit b set = body b is an INACTIVE slot in this env
@@ -2391,6 +2397,20 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
             WSYNC();
             pa.blki = s_blki_i; pa.blkf = s_blkf; pa.J = s_J; pa.qLDinv = s_bias; pa.nblk = nblk; pa.nv = nv; pa.maxcon = M.maxcon;
             pa.row_order = M.pgs_row_order;
+            if (wpre) {
+              // ---- window sweep (window_pgs.h): this launch ends here; mjh_window_kernel (four envs per wavefront) runs the warm start,
+              //      the sweeps in constraint-row order, mj_checkAcc and mj_Euler, and stores the state.  Handed over: the rows (J^ dense over
+              //      the dofs, aref, R), M^1/2 qacc_smooth, M^1/2 qacc_warmstart, M^-1/2, qvel after the controller, the normalised qpos.
+              float* wb = S.wbuf + (size_t)env * (size_t)S.wstride;
+              const int nrow = window_emit(wb, M.win_nvt, s_blki_i, s_blkf, s_J, s_bias, nblk, lane);
+              if (nrow > 0) {
+                for (int d = lane; d < nv; d += 64) { wb[WN_AS + d] = s_qacc[d]; wb[WN_AWS + d] = s_tmpv2[d]; wb[WN_SINV + d] = s_bias[d]; wb[WN_QVEL + d] = s_qvel[d]; }
+                for (int i = lane; i < nq; i += 64) wb[WN_QPOS + i] = s_qpos[i];
+                if (lane == 0) { int* wh = (int*)wb; wh[0] = nrow; wh[1] = ncon; wh[2] = nefc; wh[3] = flags; }
+                return;
+              }
+              // (more rows than the window kernel takes: this env finishes the step here, in patch form)
+            }
             int swork = 0, npatch = 0;
             const int nstep = patch_build(pa, lane, flags, swork, npatch);
             if (warm) patch_warmstart(pa, lane, nstep, npatch, L.tmpv2, L.qacc, L.tmpv);

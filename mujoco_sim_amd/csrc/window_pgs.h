@@ -1,0 +1,347 @@
+// window_pgs.h — projected Gauss-Seidel in mj_solPGS's own constraint-row order for small free-body models (every tree a single free
+// body, nv <= 32: BASELINE's 24-DoF scene), FOUR environments per wavefront, operands in registers.  Replaces the sweeps of the fused
+// step (mj_step2's mj_fwdConstraint -> mj_solPGS, /root/reference/src/mj_main.cpp:108) in mjh_step for these models:
+//
+//     mjh_step_kernel  (PH_PRE: one env per wave, everything up to the constraint rows; window_emit() below hands the rows over)
+//  -> mjh_window_kernel (this file: warm start, sweeps, mj_checkAcc, Euler, state / statistics written back)
+//
+// Why.  The fused kernel keeps one environment per wavefront because the stages around the solver need ~20 KB of LDS per env: 8 envs
+// per CU, 2 waves per SIMD, and the sweeps — a chain of dependent 16-lane operations that leaves three quarters of every wave-step idle
+// in the reference's order (the conflict DAG of a 4-box pile is 5.7 patches deep) — run at the latency of that chain.  The sweeps
+// themselves need no LDS at all: a WINDOW of 16 consecutive constraint rows is one row per lane of a 16-lane DPP row, so a wavefront
+// holds four environments, and with one such wave per SIMD and the row records in the wave's 512 registers all 4096 environments of
+// the metric are resident at once (16 per CU).  Gauss-Seidel inside a window is exact and sequential (the strictly lower triangle of
+// the window's AR = J^ J^T + R is precomputed: t_q += (-AR_qr / AR_qq) delta_r, two instructions per row for all four envs); between
+// windows the running acceleration a^ = M^1/2 a lives in two registers per env (lane q: dofs q and 16 + q) and is updated by a
+// transpose-reduce over the 16 lanes — no LDS, no atomics, no schedule: the order IS the constraint order, row by row.
+//
+//     u = J^ a^ (row_newbcast multiply-adds) -> t = -(u - aref + R f) / AR_qq -> 16 rows -> delta -> a^ += J^T delta
+//
+// Same scaled coordinates as patch_pgs.h (J^ = J M^-1/2: M is diagonal for these models).  Rows: contacts only (f >= 0).
+#pragma once
+
+// per-env slice of DState::wbuf (floats).  Header ints: [0] rows handed over (0: nothing to do for the window kernel — no rows, or the
+// env finished the step in the assemble launch), [1] ncon, [2] nefc, [3] flags
+#define WN_AS 16        // M^1/2 qacc_smooth  [32]
+#define WN_AWS 48       // M^1/2 qacc_warmstart [32]
+#define WN_SINV 80      // M^-1/2 per dof [32]
+#define WN_QVEL 112     // qvel after the controller [32]
+#define WN_QPOS 144     // qpos after mj_kinematics' quaternion normalisation [40]
+#define WN_ROWS 192     // window w at WN_ROWS + w * NK * 16: [k][16 rows], k < NK = NVT + 2: J^[NVT], aref, R
+#define WN_MAXW 16      // windows per env (256 rows: the capacity of the patch sweep as well)
+#define WN_TILE 19      // streamed windows (beyond the register-resident ones): per row 16 tile entries, -1 / AR_qq, AR_qq / 2, force
+
+// Assemble launch (mjh_step_kernel with PH_PRE, free-body instance): the constraint blocks of this env -> window rows in global memory.
+// blki / blkf / J: the block tables in LDS (step_kernel.h); sinv = M^-1/2 per dof.  Returns the number of rows (0: too many, not written).
+DEV int window_emit(float* __restrict__ wb, const int nvt, const int* blki, const float* blkf, const float* J, const float* sinv, const int nblk, const int lane) {
+  const int4* blki4 = (const int4*)blki;
+  const int nk = nvt + 2;
+  int4 hd = make_int4(0, 0, 0, 0);
+  if (lane < nblk) hd = blki4[lane];
+  const int myn = lane < nblk ? (hd.x >> 4) & 15 : 0;
+  const int incl = wave_incl_scan_i(myn, lane);
+  const int nrow = __shfl(incl, 63);
+  if (nrow > 16 * WN_MAXW) return 0;
+  const int nwin = (nrow + 15) >> 4;
+  // padding rows of the last window: zeros (inert: AR_qq = 0 -> -1 / AR_qq stored as 0)
+  for (int t = lane; t < (16 * nwin - nrow) * nk; t += 64) {
+    const int r = nrow + t / nk, k = t - (t / nk) * nk;
+    wb[WN_ROWS + ((r >> 4) * nk + k) * 16 + (r & 15)] = 0.0f;
+  }
+  if (lane < nblk) {
+    const int a1 = hd.z & 0xffff, a2 = hd.w & 0xffff; const bool two = (hd.w >> 16) != 0, single = myn == 1;
+    const float* Jb = J + BLK_JOFF(hd.x);
+    float4 jb[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) jb[k] = (k < 6 || two) ? *(const float4*)(Jb + 4 * k) : make_float4(0, 0, 0, 0);
+    float sc[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) sc[k] = (k < 6 || two) ? sinv[k < 6 ? a1 + k : a2 + k - 6] : 0.0f;
+    const float* bf = blkf + lane * BLKF_STRIDE;
+    const int row0 = incl - myn;
+    for (int r = 0; r < myn; r++) {
+      const int g = row0 + r;
+      float* o = wb + WN_ROWS + (g >> 4) * nk * 16 + (g & 15);
+      const int kk = 1 + (r >> 1); const float c = (r & 1) ? -1.0f : 1.0f;
+      for (int k = 0; k < nvt; k++) o[16 * k] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 12; k++) {
+        if (k >= 6 && !two) continue;
+        const float v = single ? jb[k].x : jb[k].x + c * (kk == 1 ? jb[k].y : (kk == 2 ? jb[k].z : jb[k].w));
+        o[16 * (k < 6 ? a1 + k : a2 + k - 6)] = v * sc[k];
+      }
+      o[16 * nvt] = single ? bf[BF_AREF] : bf[BF_AREF] + c * bf[BF_AREF + kk];
+      o[16 * (nvt + 1)] = bf[0];
+    }
+  }
+  return nrow;
+}
+
+// ---- the sweep kernel ----
+#ifndef WN_NW24
+#define WN_NW24 8       // register-resident windows of the 24-dof instance (128 rows; S24 has 72 on average), the rest is streamed
+#endif
+#ifndef WN_NW32
+#define WN_NW32 6
+#endif
+#define WN_BC8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+template <int NV> struct WnWin { float J[NV]; float4 A0, A1, A2, A3; float aref, R, nw, half; };   // one window row: J^, tile row (-AR_qr / AR_qq, r < q), constants
+
+// transpose-reduce: x[k](lane q) -> lane q of the 16-lane row receives sum over the row's lanes of x[q]   (16 values, 33 instructions)
+#define WN_ROR2(d, s0, s1, r0, m0, r1, m1) "v_add_f32_dpp " d ", " s0 ", " s0 " row_ror:" #r0 " row_mask:0xf bank_mask:" #m0 "\n\tv_add_f32_dpp " d ", " s1 ", " s1 " row_ror:" #r1 " row_mask:0xf bank_mask:" #m1 "\n\t"
+DEV float wn_fold_tail(const float* z) {     // four values over the quads (lane bit 1 and bit 0 pick the value)
+  const int q = threadIdx.x & 15;
+  const bool b1 = (q & 2) != 0, b0 = (q & 1) != 0;
+  float w[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const float s = b1 ? z[k + 2] : z[k], o = b1 ? z[k] : z[k + 2];
+    w[k] = s + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, o), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  }
+  const float s = b0 ? w[1] : w[0], o = b0 ? w[0] : w[1];
+  return s + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, o), 0xB1, 0xf, 0xf, true));       // quad_perm [1,0,3,2]
+}
+DEV void wn_fold_8to4(const float* y, float* z) {   // lanes with bit 2 clear keep values 0..3, the others 4..7 (partner: 4 lanes away, same half of the row)
+  asm volatile(WN_ROR2("%0", "%4", "%8", 12, 0x5, 4, 0xa) WN_ROR2("%1", "%5", "%9", 12, 0x5, 4, 0xa) WN_ROR2("%2", "%6", "%10", 12, 0x5, 4, 0xa) WN_ROR2("%3", "%7", "%11", 12, 0x5, 4, 0xa)
+               : "=&v"(z[0]), "=&v"(z[1]), "=&v"(z[2]), "=&v"(z[3]) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]));
+}
+DEV float wn_fold16(const float* x) {
+  float y[8], z[4];
+  // lanes 0..7 keep values 0..7, lanes 8..15 values 8..15 (partner: 8 lanes away)
+  asm volatile("s_nop 1\n\t"
+               WN_ROR2("%0", "%8", "%16", 8, 0x3, 8, 0xc) WN_ROR2("%1", "%9", "%17", 8, 0x3, 8, 0xc) WN_ROR2("%2", "%10", "%18", 8, 0x3, 8, 0xc) WN_ROR2("%3", "%11", "%19", 8, 0x3, 8, 0xc)
+               WN_ROR2("%4", "%12", "%20", 8, 0x3, 8, 0xc) WN_ROR2("%5", "%13", "%21", 8, 0x3, 8, 0xc) WN_ROR2("%6", "%14", "%22", 8, 0x3, 8, 0xc) WN_ROR2("%7", "%15", "%23", 8, 0x3, 8, 0xc)
+               : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]), "=&v"(y[4]), "=&v"(y[5]), "=&v"(y[6]), "=&v"(y[7])
+               : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]),
+                 "v"(x[8]), "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]), "v"(x[13]), "v"(x[14]), "v"(x[15]));
+  wn_fold_8to4(y, z);
+  return wn_fold_tail(z);
+}
+// 8 values: lanes q and q + 8 both receive the sum of x[q & 7]   (25 instructions)
+DEV float wn_fold8(const float* x) {
+  float y[8], z[4];
+#define WN_R8(d, s) "v_add_f32_dpp " d ", " s ", " s " row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+  asm volatile("s_nop 1\n\t" WN_R8("%0", "%8") WN_R8("%1", "%9") WN_R8("%2", "%10") WN_R8("%3", "%11") WN_R8("%4", "%12") WN_R8("%5", "%13") WN_R8("%6", "%14") WN_R8("%7", "%15")
+               : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]), "=&v"(y[4]), "=&v"(y[5]), "=&v"(y[6]), "=&v"(y[7])
+               : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+#undef WN_R8
+  wn_fold_8to4(y, z);
+  return wn_fold_tail(z);
+}
+// sum over the 16 lanes of a row, result in every lane of the row (integers: order-independent)
+DEV int wn_rowsum_i(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true); v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  return __builtin_amdgcn_update_dpp(0, v, 0x15F, 0xf, 0xf, false);     // row_newbcast:15
+}
+DEV float wn_rowsum_f(float v) {
+  MJH_DPP_ADD(v, 0x111, 0xf, true); MJH_DPP_ADD(v, 0x112, 0xf, true); MJH_DPP_ADD(v, 0x114, 0xf, true); MJH_DPP_ADD(v, 0x118, 0xf, true);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x15F, 0xf, 0xf, false));
+}
+
+// u = J^ . a^ : a_lo / a_hi hold the dof vector (lane q of the row: dofs q and 16 + q); two independent chains
+#define WN_FM(acc, x, y, R) "v_fmac_f32_dpp " acc ", " x ", " y " row_newbcast:" #R " row_mask:0xf bank_mask:0xf\n\t"
+template <int NV> DEV float wn_dot(const float* J, const float a_lo, const float a_hi) {
+  static_assert(NV == 24 || NV == 32, "window kernel instances: 24 or 32 dof slots");
+  float u0, u1;
+  asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+               WN_FM("%0", "%1", "%3", 1) WN_FM("%0", "%1", "%4", 2) WN_FM("%0", "%1", "%5", 3) WN_FM("%0", "%1", "%6", 4) WN_FM("%0", "%1", "%7", 5)
+               WN_FM("%0", "%1", "%8", 6) WN_FM("%0", "%1", "%9", 7) WN_FM("%0", "%1", "%10", 8) WN_FM("%0", "%1", "%11", 9) WN_FM("%0", "%1", "%12", 10)
+               WN_FM("%0", "%1", "%13", 11) WN_FM("%0", "%1", "%14", 12) WN_FM("%0", "%1", "%15", 13) WN_FM("%0", "%1", "%16", 14) WN_FM("%0", "%1", "%17", 15)
+               : "=&v"(u0) : "v"(a_lo), "v"(J[0]), "v"(J[1]), "v"(J[2]), "v"(J[3]), "v"(J[4]), "v"(J[5]), "v"(J[6]), "v"(J[7]),
+                 "v"(J[8]), "v"(J[9]), "v"(J[10]), "v"(J[11]), "v"(J[12]), "v"(J[13]), "v"(J[14]), "v"(J[15]));
+  asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+               WN_FM("%0", "%1", "%3", 1) WN_FM("%0", "%1", "%4", 2) WN_FM("%0", "%1", "%5", 3) WN_FM("%0", "%1", "%6", 4) WN_FM("%0", "%1", "%7", 5)
+               WN_FM("%0", "%1", "%8", 6) WN_FM("%0", "%1", "%9", 7)
+               : "=&v"(u1) : "v"(a_hi), "v"(J[16]), "v"(J[17]), "v"(J[18]), "v"(J[19]), "v"(J[20]), "v"(J[21]), "v"(J[22]), "v"(J[23]));
+  if constexpr (NV == 32)
+    asm volatile("s_nop 1\n\t" WN_FM("%0", "%1", "%2", 8) WN_FM("%0", "%1", "%3", 9) WN_FM("%0", "%1", "%4", 10) WN_FM("%0", "%1", "%5", 11)
+                 WN_FM("%0", "%1", "%6", 12) WN_FM("%0", "%1", "%7", 13) WN_FM("%0", "%1", "%8", 14) WN_FM("%0", "%1", "%9", 15)
+                 : "+v"(u1) : "v"(a_hi), "v"(J[NV == 32 ? 24 : 0]), "v"(J[NV == 32 ? 25 : 0]), "v"(J[NV == 32 ? 26 : 0]), "v"(J[NV == 32 ? 27 : 0]),
+                   "v"(J[NV == 32 ? 28 : 0]), "v"(J[NV == 32 ? 29 : 0]), "v"(J[NV == 32 ? 30 : 0]), "v"(J[NV == 32 ? 31 : 0]));
+  return u0 + u1;
+}
+// a^ += J^T x over the row's 16 lanes
+template <int NV> DEV void wn_jt(const float* J, const float x, float& a_lo, float& a_hi) {
+  float p[NV];
+#pragma unroll
+  for (int k = 0; k < NV; k++) p[k] = J[k] * x;
+  a_lo += wn_fold16(p);
+  if constexpr (NV == 32) a_hi += wn_fold16(p + 16); else a_hi += wn_fold8(p + 16);
+}
+
+template <int NV, int NW>
+__global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restrict__ C, const DState S, const int env0, const int nenv) {
+  const DModel& M = C->M;
+  const int lane = threadIdx.x, rho = lane >> 4, q = lane & 15;
+  const int slot = (int)blockIdx.x * 4 + rho;
+  const bool have = slot < nenv;
+  const int env = have ? (S.env_order ? S.env_order[env0 + slot] : env0 + slot) : 0;
+  float* const wb = S.wbuf + (size_t)env * (size_t)S.wstride;
+  const int* const wh = (const int*)wb;
+  const int nrow = have ? wh[0] : 0;
+  if (__ballot(nrow > 0) == 0ull) return;
+  const int nwin = (nrow + 15) >> 4;
+  const int nwmax = max(max(__builtin_amdgcn_readlane(nwin, 0), __builtin_amdgcn_readlane(nwin, 16)), max(__builtin_amdgcn_readlane(nwin, 32), __builtin_amdgcn_readlane(nwin, 48)));
+  const int nv = M.nv;
+  constexpr int NK = NV + 2;
+  const bool lo_on = q < nv, hi_on = 16 + q < nv;
+  // dof vectors: lane q of the row carries dofs q and 16 + q
+  const float as_lo = lo_on ? wb[WN_AS + q] : 0.0f, as_hi = hi_on ? wb[WN_AS + 16 + q] : 0.0f;
+  const float ws_lo = lo_on ? wb[WN_AWS + q] : 0.0f, ws_hi = hi_on ? wb[WN_AWS + 16 + q] : 0.0f;
+
+  WnWin<NV> win[NW];
+  float f[NW];                                                 // forces of the register-resident windows (streamed ones: tile slot WN_TILE - 1)
+  const float* rows = wb + WN_ROWS + q;
+  float* tiles = wb + WN_ROWS + WN_MAXW * NK * 16 + q;       // streamed windows: [w][WN_TILE][16]
+  auto load_rows = [&](WnWin<NV>& W, const int w) __attribute__((always_inline)) {
+    const bool ok = w < nwin;
+    const float* p = rows + w * NK * 16;
+#pragma unroll
+    for (int k = 0; k < NV; k++) W.J[k] = ok ? p[16 * k] : 0.0f;
+    W.aref = ok ? p[16 * NV] : 0.0f; W.R = ok ? p[16 * (NV + 1)] : 0.0f;
+  };
+  // tile row of a window: acc_r = J^_q . J^_r for the 16 rows r of the window (every lane of the row at once), then -AR_qr / AR_qq, r < q
+  auto make_tile = [&](WnWin<NV>& W) __attribute__((always_inline)) {
+    float acc[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) acc[s] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) asm volatile("" : "+v"(W.J[k]));     // (materialised before the DPP reads below: no VALU write within two instructions of them)
+    asm volatile("s_nop 1");
+#define WN_ACC(s) _Pragma("unroll") for (int k = 0; k < NV; k++) PP_FMAC_BC(acc[s], W.J[k], W.J[k], s);
+    PP_BC16(WN_ACC)
+#undef WN_ACC
+    float diag = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) diag += W.J[k] * W.J[k];
+    const float ARqq = diag + W.R;
+    const float inv = ARqq < MJ_MINVAL ? 0.0f : 1.0f / ARqq, ninv = -inv;
+    W.nw = ninv; W.half = 0.5f * ARqq;
+    W.A0 = make_float4(0 < q ? ninv * acc[0] : 0.0f, 1 < q ? ninv * acc[1] : 0.0f, 2 < q ? ninv * acc[2] : 0.0f, 3 < q ? ninv * acc[3] : 0.0f);
+    W.A1 = make_float4(4 < q ? ninv * acc[4] : 0.0f, 5 < q ? ninv * acc[5] : 0.0f, 6 < q ? ninv * acc[6] : 0.0f, 7 < q ? ninv * acc[7] : 0.0f);
+    W.A2 = make_float4(8 < q ? ninv * acc[8] : 0.0f, 9 < q ? ninv * acc[9] : 0.0f, 10 < q ? ninv * acc[10] : 0.0f, 11 < q ? ninv * acc[11] : 0.0f);
+    W.A3 = make_float4(12 < q ? ninv * acc[12] : 0.0f, 13 < q ? ninv * acc[13] : 0.0f, 14 < q ? ninv * acc[14] : 0.0f, 0.0f);
+  };
+  auto store_tile = [&](const WnWin<NV>& W, const int w) __attribute__((always_inline)) {
+    float* t = tiles + w * WN_TILE * 16;
+    t[0] = W.A0.x; t[16] = W.A0.y; t[32] = W.A0.z; t[48] = W.A0.w; t[64] = W.A1.x; t[80] = W.A1.y; t[96] = W.A1.z; t[112] = W.A1.w;
+    t[128] = W.A2.x; t[144] = W.A2.y; t[160] = W.A2.z; t[176] = W.A2.w; t[192] = W.A3.x; t[208] = W.A3.y; t[224] = W.A3.z; t[240] = W.A3.w;
+    t[256] = W.nw; t[272] = W.half;
+  };
+  auto load_tile = [&](WnWin<NV>& W, const int w) __attribute__((always_inline)) {
+    const float* t = tiles + w * WN_TILE * 16;
+    W.A0 = make_float4(t[0], t[16], t[32], t[48]); W.A1 = make_float4(t[64], t[80], t[96], t[112]);
+    W.A2 = make_float4(t[128], t[144], t[160], t[176]); W.A3 = make_float4(t[192], t[208], t[224], t[240]);
+    W.nw = t[256]; W.half = t[272];
+  };
+#pragma unroll
+  for (int w = 0; w < NW; w++) if (w < nwmax) { load_rows(win[w], w); make_tile(win[w]); }
+  for (int w = NW; w < nwmax; w++) { WnWin<NV> W; load_rows(W, w); make_tile(W); store_tile(W, w); }
+  // every window of the wave, register-resident ones first; the body sees the window W and its force fw
+#define WN_FOR_WINDOWS(...) do { \
+    _Pragma("unroll") for (int w = 0; w < NW; w++) if (w < nwmax) { WnWin<NV>& W = win[w]; float& fw = f[w]; __VA_ARGS__ } \
+    for (int w = NW; w < nwmax; w++) { WnWin<NV> W; load_rows(W, w); load_tile(W, w); float* fp = tiles + (w * WN_TILE + 18) * 16; float fw = *fp; __VA_ARGS__ *fp = fw; } } while (0)
+
+  // ---- warm start (mj_fwdConstraint): f = max(0, -(J a_ws - aref) / R), kept if the dual cost is not positive
+  float a_lo = as_lo, a_hi = as_hi;
+#pragma unroll
+  for (int w = 0; w < NW; w++) f[w] = 0.0f;
+  for (int w = NW; w < nwmax; w++) tiles[(w * WN_TILE + 18) * 16] = 0.0f;
+  if (!(M.disableflags & MJH_DSBL_WARMSTART)) {
+    float da_lo = 0.0f, da_hi = 0.0f;
+    WN_FOR_WINDOWS({
+      const float jar = wn_dot<NV>(W.J, ws_lo, ws_hi) - W.aref;
+      fw = (jar < 0.0f && W.R > 0.0f) ? -jar / W.R : 0.0f;
+      wn_jt<NV>(W.J, fw, da_lo, da_hi);
+    });
+    float cost = 0.0f;
+    WN_FOR_WINDOWS({
+      const float jda = wn_dot<NV>(W.J, da_lo, da_hi), bb = wn_dot<NV>(W.J, as_lo, as_hi) - W.aref;
+      cost += fw * (0.5f * (jda + W.R * fw) + bb);
+    });
+    cost = wn_rowsum_f(cost);
+    if (cost > 0.0f) {
+#pragma unroll
+      for (int w = 0; w < NW; w++) f[w] = 0.0f;
+      for (int w = NW; w < nwmax; w++) tiles[(w * WN_TILE + 18) * 16] = 0.0f;
+    } else { a_lo += da_lo; a_hi += da_hi; }
+  }
+  // ---- sweeps: every env (16-lane row) until ITS improvement falls below the tolerance
+  const ImpQ iq = imp_quantum(1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1)), M.tolerance);
+  const int itmax = M.iterations;
+  int niter = 0;
+  bool act = nrow > 0;
+  while (__ballot(act) != 0ull) {
+    if (act) {
+      int impl = 0;
+      WN_FOR_WINDOWS({
+        const float u = wn_dot<NV>(W.J, a_lo, a_hi);
+        const float fo = fw;
+        float tt = ((u - W.aref) + W.R * fo) * W.nw;
+        const float nf = -fo;
+        float dl;
+        PP_ROWS4(0, 1, 2, 3, W.A0); PP_ROWS4(4, 5, 6, 7, W.A1); PP_ROWS4(8, 9, 10, 11, W.A2); PP_ROWS4(12, 13, 14, 15, W.A3);
+        asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));
+        impl += imp_fixed((W.half * dl) * (2.0f * tt - dl), iq.qs);
+        fw = fo + dl;
+        wn_jt<NV>(W.J, dl, a_lo, a_hi);
+      });
+      niter++;
+      if (wn_rowsum_i(impl) < iq.thr || niter >= itmax) act = false;
+    }
+  }
+  const bool mine = nrow > 0;        // (else: a row without an environment, or one that finished in the assemble launch)
+  // ---- qacc, mj_checkAcc, semi-implicit Euler (mj_Euler; free joints only), state and statistics
+  const float sv_lo = (mine && lo_on) ? wb[WN_SINV + q] : 0.0f, sv_hi = (mine && hi_on) ? wb[WN_SINV + 16 + q] : 0.0f;
+  float qa_lo = a_lo * sv_lo, qa_hi = a_hi * sv_hi;
+  float qv_lo = (mine && lo_on) ? wb[WN_QVEL + q] : 0.0f, qv_hi = (mine && hi_on) ? wb[WN_QVEL + 16 + q] : 0.0f;
+  int flags = mine ? wh[3] : 0;
+  const bool badl = !(qa_lo == qa_lo) || fabsf(qa_lo) > MJ_MAXVAL || !(qa_hi == qa_hi) || fabsf(qa_hi) > MJ_MAXVAL;
+  const bool bad = ((__ballot(badl) >> (16 * rho)) & 0xffffull) != 0ull;
+  const size_t qrow = (size_t)env * M.nqp, vrow = (size_t)env * M.nvp;
+  if (bad) { qa_lo = qa_hi = 0.0f; qv_lo = qv_hi = 0.0f; flags |= 4; }
+  const float h = M.timestep;
+  const Tab<int> dof_bodyid{M.I, M.o_dof_bodyid}, jnt_qposadr{M.I, M.o_jnt_qposadr}, jnt_dofadr{M.I, M.o_jnt_dofadr};
+  const Tab<float> dof_damping{M.F, M.o_dof_damping};
+  const unsigned slotmask = S.slot_mask ? S.slot_mask[env] : 0u;
+  const int sbase = M.nbody > 32 ? M.nbody - 32 : 0;
+  __shared__ float s_v[4][32];
+  auto advance = [&](const int d, float& qa, float& qv) __attribute__((always_inline)) {
+    float qint = qa;
+    if (M.has_damping && !(M.disableflags & MJH_DSBL_EULERDAMP)) {
+      // (M + h D) qacc' = M qacc, M diagonal: qacc' = qacc - h D qacc / (M_dd + h D)
+      const float sv = wb[WN_SINV + d], Mdd = 1.0f / (sv * sv), D = dof_damping[d];
+      qint = qa - h * (D * qa) / (Mdd + h * D);
+    }
+    const unsigned rb = (unsigned)(dof_bodyid[d] - sbase);
+    const bool parked = rb < 32u && ((slotmask >> rb) & 1u);
+    qv = parked ? 0.0f : qv + h * qint;
+    if (parked) qa = 0.0f;
+    S.qvel[vrow + d] = qv; S.qacc_ws[vrow + d] = qa;
+    s_v[rho][d] = qv;
+  };
+  if (mine && lo_on) advance(q, qa_lo, qv_lo);
+  if (mine && hi_on) advance(16 + q, qa_hi, qv_hi);
+  __syncthreads();
+  if (mine && q < M.njnt) {
+    const int qadr = jnt_qposadr[q], da = jnt_dofadr[q];
+    float p[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) p[k] = bad ? S.initial_qpos[qrow + qadr + k] : wb[WN_QPOS + qadr + k];
+    const float* v = s_v[rho] + da;
+    p[0] += h * v[0]; p[1] += h * v[1]; p[2] += h * v[2];
+    float w3[3] = {v[3], v[4], v[5]};
+    quat_integrate(p + 3, w3, h);
+#pragma unroll
+    for (int k = 0; k < 7; k++) S.qpos[qrow + qadr + k] = p[k];
+  }
+  if (mine && q == 0) {
+    S.time[env] += M.timestep_d;
+    // launch-order hint: sweeps x windows in units of the fused kernel's hint (patch_pgs.h: about four instructions)
+    const int cost_hint = min(niter * nwin * 20 + 1, 1 << 22);
+    S.stats[4 * env] = wh[1]; S.stats[4 * env + 1] = wh[2]; S.stats[4 * env + 2] = niter;
+    S.stats[4 * env + 3] = ((S.stats[4 * env + 3] | flags) & 0xff) | (cost_hint << 8);
+  }
+#undef WN_FOR_WINDOWS
+}

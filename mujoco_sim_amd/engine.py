@@ -315,6 +315,10 @@ class Engine:
         """1: contact-patch form of the sweeps (small free-body models), 0: a block form (mjh_patch_sweep)"""
         return self.lib.mjh_patch_sweep(self.h)
 
+    def window_solver(self):
+        """1: mjh_step = assemble launch + mjh_window_kernel (four envs per wavefront, rows in registers), 0: one fused launch"""
+        return self.lib.mjh_window_solver(self.h)
+
     def pgs_schedule(self):
         """1: row order, list-scheduled (default), 2: row order, strictly sequential, 0: legacy reordering schedule (mjh_pgs_schedule)"""
         return self.lib.mjh_pgs_schedule(self.h)
