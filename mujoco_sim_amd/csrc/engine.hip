@@ -111,6 +111,10 @@ static bool extra_instance(const DModel& M) { return M.has_convex || M.noslip_it
 
 static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps, int ph, int xflags) {
   if (n <= 0) return MJH_OK;
+  // window sweep (window_pgs.h): every launch that runs mj_step2 to the end (the fused step and the split API's step2) of a small
+  // free-body model = assemble launch (PH_PRE), then four envs per wavefront through the sweeps and the integration
+  const bool window = e->M.window && e->S.wbuf && (ph & PH_STEP2) && !(ph & (PH_NOINT | PH_PRE | PH_POST)) && !(xflags & ~XF_FORCE);
+  if (window) ph |= PH_PRE;
 #define MJH_LAUNCH2(NR, DG, CX) hipLaunchKernelGGL((mjh_step_kernel<NR, DG, CX>), dim3(n), dim3(64), (size_t)e->lds_bytes, st, e->dC, e->S, env0, nsteps, ph, xflags)
 #define MJH_LAUNCH(NR, DG) do { if (extra_instance(e->M) || e->S.xfrc_applied) MJH_LAUNCH2(NR, DG, true); else MJH_LAUNCH2(NR, DG, false); } while (0)
   const int nr = e->M.big ? 8 : (e->M.nv <= 16 ? 1 : (e->M.nv <= 32 ? 2 : 4));   // 8: many-body layout, running acceleration in LDS
@@ -119,6 +123,14 @@ static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps,
 #undef MJH_LAUNCH2
 #undef MJH_LAUNCH
   HIPCHK(hipGetLastError());
+  if (window) {
+    // LDS tier: windows beyond the register-resident ones, as many as leave four waves per CU (40 KB per wave)
+    const int nl = std::min(WN_MAXW, (int)((40 * 1024 - 1024) / (4 * WN_XREC(e->M.win_nvt) * 16 * sizeof(float))));
+    const size_t lds = (size_t)4 * nl * WN_XREC(e->M.win_nvt) * 16 * sizeof(float);
+    if (e->M.win_nvt == 24) hipLaunchKernelGGL((mjh_window_kernel<24, WN_NW24>), dim3((n + 3) / 4), dim3(64), lds, st, e->dC, e->S, env0, n, nl, xflags);
+    else hipLaunchKernelGGL((mjh_window_kernel<32, WN_NW32>), dim3((n + 3) / 4), dim3(64), lds, st, e->dC, e->S, env0, n, nl, xflags);
+    HIPCHK(hipGetLastError());
+  }
   return MJH_OK;
 }
 
@@ -521,7 +533,7 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   if (M.big) rc |= dev_alloc(e, &S.gscratch, (size_t)nenv * (size_t)hp.gstride, false);   // many-body models: contact / block / Jacobian pools
   S.wbuf = nullptr; S.wstride = 0;
   if (M.window) {   // window sweep: header + vectors + WN_MAXW windows of rows + tiles of the streamed windows, per env
-    S.wstride = ((WN_ROWS + WN_MAXW * (M.win_nvt + 2) * 16 + WN_MAXW * WN_TILE * 16 + 63) / 64) * 64;
+    S.wstride = ((WN_ROWS + WN_MAXW * (M.win_nvt + 2) * 16 + WN_MAXW * WN_XREC(M.win_nvt) * 16 + 63) / 64) * 64;
     rc |= dev_alloc(e, &S.wbuf, (size_t)nenv * (size_t)S.wstride, true);
   }
   if (M.big && M.dense && e->lpt && nenv >= 1024) {
@@ -741,15 +753,6 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
                  else hipLaunchKernelGGL((mjh_solve_kernel<false, false>), dim3(g1 - g0), thr, lds, st, e->dC, e->S, g0); }
           HIPCHK(hipGetLastError());
           rc = launch_on(e, st, g0, g1 - g0, 1, PH_STEP2 | PH_POST, 0);
-        }
-      } else if (e->M.window && e->S.wbuf) {
-        // window sweep (window_pgs.h): assemble launch, then four envs per wavefront through the sweeps and the integration
-        rc = launch_on(e, st, g0, g1 - g0, 1, ph | PH_PRE, 0);
-        if (!rc) {
-          const int n = g1 - g0;
-          if (e->M.win_nvt == 24) hipLaunchKernelGGL((mjh_window_kernel<24, WN_NW24>), dim3((n + 3) / 4), dim3(64), 0, st, e->dC, e->S, g0, n);
-          else hipLaunchKernelGGL((mjh_window_kernel<32, WN_NW32>), dim3((n + 3) / 4), dim3(64), 0, st, e->dC, e->S, g0, n);
-          HIPCHK(hipGetLastError());
         }
       } else rc = launch_on(e, st, g0, g1 - g0, 1, ph, 0);
       if (ta && !rc) HIPCHK(hipEventRecord(tb, st));

@@ -29,7 +29,7 @@
 #define WN_QPOS 144     // qpos after mj_kinematics' quaternion normalisation [40]
 #define WN_ROWS 192     // window w at WN_ROWS + w * NK * 16: [k][16 rows], k < NK = NVT + 2: J^[NVT], aref, R
 #define WN_MAXW 16      // windows per env (256 rows: the capacity of the patch sweep as well)
-#define WN_TILE 19      // streamed windows (beyond the register-resident ones): per row 16 tile entries, -1 / AR_qq, AR_qq / 2, force
+#define WN_XREC(nvt) ((nvt) + 21)   // record of a window beyond the register-resident ones, per row: J^[nvt], aref, R, 16 tile entries, -1 / AR_qq, AR_qq / 2, force
 
 // Assemble launch (mjh_step_kernel with PH_PRE, free-body instance): the constraint blocks of this env -> window rows in global memory.
 // blki / blkf / J: the block tables in LDS (step_kernel.h); sinv = M^-1/2 per dof.  Returns the number of rows (0: too many, not written).
@@ -117,16 +117,18 @@ DEV float wn_fold16(const float* x) {
   wn_fold_8to4(y, z);
   return wn_fold_tail(z);
 }
-// 8 values: lanes q and q + 8 both receive the sum of x[q & 7]   (25 instructions)
+// 8 values: lanes 2j and 2j + 1 both receive the sum of x[j]   (16 instructions: every stage halves the values a lane keeps)
 DEV float wn_fold8(const float* x) {
-  float y[8], z[4];
-#define WN_R8(d, s) "v_add_f32_dpp " d ", " s ", " s " row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-  asm volatile("s_nop 1\n\t" WN_R8("%0", "%8") WN_R8("%1", "%9") WN_R8("%2", "%10") WN_R8("%3", "%11") WN_R8("%4", "%12") WN_R8("%5", "%13") WN_R8("%6", "%14") WN_R8("%7", "%15")
-               : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]), "=&v"(y[4]), "=&v"(y[5]), "=&v"(y[6]), "=&v"(y[7])
-               : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
-#undef WN_R8
-  wn_fold_8to4(y, z);
-  return wn_fold_tail(z);
+  float y[4], z[2];
+  asm volatile("s_nop 1\n\t" WN_ROR2("%0", "%4", "%8", 8, 0x3, 8, 0xc) WN_ROR2("%1", "%5", "%9", 8, 0x3, 8, 0xc) WN_ROR2("%2", "%6", "%10", 8, 0x3, 8, 0xc) WN_ROR2("%3", "%7", "%11", 8, 0x3, 8, 0xc)
+               : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));   // lanes 0..7: values 0..3, lanes 8..15: values 4..7
+  asm volatile(WN_ROR2("%0", "%2", "%4", 12, 0x5, 4, 0xa) WN_ROR2("%1", "%3", "%5", 12, 0x5, 4, 0xa)
+               : "=&v"(z[0]), "=&v"(z[1]) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]));                                  // lane bit 2 clear: values 0, 1 of the half; set: 2, 3
+  const bool b1 = (threadIdx.x & 2) != 0;
+  const float s = b1 ? z[1] : z[0], o = b1 ? z[0] : z[1];
+  float r = s + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, o), 0x4E, 0xf, 0xf, true));   // value index = 4 bit3 + 2 bit2 + bit1 of the lane = lane >> 1
+  MJH_DPP_ADD(r, 0xB1, 0xf, true);                                                                                             // + the neighbour lane (bit 0): both keep the value
+  return r;
 }
 // sum over the 16 lanes of a row, result in every lane of the row (integers: order-independent)
 DEV int wn_rowsum_i(int v) {
@@ -150,10 +152,16 @@ template <int NV> DEV float wn_dot(const float* J, const float a_lo, const float
                WN_FM("%0", "%1", "%13", 11) WN_FM("%0", "%1", "%14", 12) WN_FM("%0", "%1", "%15", 13) WN_FM("%0", "%1", "%16", 14) WN_FM("%0", "%1", "%17", 15)
                : "=&v"(u0) : "v"(a_lo), "v"(J[0]), "v"(J[1]), "v"(J[2]), "v"(J[3]), "v"(J[4]), "v"(J[5]), "v"(J[6]), "v"(J[7]),
                  "v"(J[8]), "v"(J[9]), "v"(J[10]), "v"(J[11]), "v"(J[12]), "v"(J[13]), "v"(J[14]), "v"(J[15]));
-  asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-               WN_FM("%0", "%1", "%3", 1) WN_FM("%0", "%1", "%4", 2) WN_FM("%0", "%1", "%5", 3) WN_FM("%0", "%1", "%6", 4) WN_FM("%0", "%1", "%7", 5)
-               WN_FM("%0", "%1", "%8", 6) WN_FM("%0", "%1", "%9", 7)
-               : "=&v"(u1) : "v"(a_hi), "v"(J[16]), "v"(J[17]), "v"(J[18]), "v"(J[19]), "v"(J[20]), "v"(J[21]), "v"(J[22]), "v"(J[23]));
+  if constexpr (NV == 24)      // (a_hi: lane 2j carries dof 16 + j — wn_fold8)
+    asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 WN_FM("%0", "%1", "%3", 2) WN_FM("%0", "%1", "%4", 4) WN_FM("%0", "%1", "%5", 6) WN_FM("%0", "%1", "%6", 8) WN_FM("%0", "%1", "%7", 10)
+                 WN_FM("%0", "%1", "%8", 12) WN_FM("%0", "%1", "%9", 14)
+                 : "=&v"(u1) : "v"(a_hi), "v"(J[16]), "v"(J[17]), "v"(J[18]), "v"(J[19]), "v"(J[20]), "v"(J[21]), "v"(J[22]), "v"(J[23]));
+  else
+    asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 WN_FM("%0", "%1", "%3", 1) WN_FM("%0", "%1", "%4", 2) WN_FM("%0", "%1", "%5", 3) WN_FM("%0", "%1", "%6", 4) WN_FM("%0", "%1", "%7", 5)
+                 WN_FM("%0", "%1", "%8", 6) WN_FM("%0", "%1", "%9", 7)
+                 : "=&v"(u1) : "v"(a_hi), "v"(J[16]), "v"(J[17]), "v"(J[18]), "v"(J[19]), "v"(J[20]), "v"(J[21]), "v"(J[22]), "v"(J[23]));
   if constexpr (NV == 32)
     asm volatile("s_nop 1\n\t" WN_FM("%0", "%1", "%2", 8) WN_FM("%0", "%1", "%3", 9) WN_FM("%0", "%1", "%4", 10) WN_FM("%0", "%1", "%5", 11)
                  WN_FM("%0", "%1", "%6", 12) WN_FM("%0", "%1", "%7", 13) WN_FM("%0", "%1", "%8", 14) WN_FM("%0", "%1", "%9", 15)
@@ -163,15 +171,17 @@ template <int NV> DEV float wn_dot(const float* J, const float a_lo, const float
 }
 // a^ += J^T x over the row's 16 lanes
 template <int NV> DEV void wn_jt(const float* J, const float x, float& a_lo, float& a_hi) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f x2 = {x, x};
   float p[NV];
 #pragma unroll
-  for (int k = 0; k < NV; k++) p[k] = J[k] * x;
+  for (int k = 0; k < NV; k += 2) { const v2f pr = v2f{J[k], J[k + 1]} * x2; p[k] = pr.x; p[k + 1] = pr.y; }     // v_pk_mul_f32
   a_lo += wn_fold16(p);
   if constexpr (NV == 32) a_hi += wn_fold16(p + 16); else a_hi += wn_fold8(p + 16);
 }
 
 template <int NV, int NW>
-__global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restrict__ C, const DState S, const int env0, const int nenv) {
+__global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restrict__ C, const DState S, const int env0, const int nenv, const int nl, const int xflags) {
   const DModel& M = C->M;
   const int lane = threadIdx.x, rho = lane >> 4, q = lane & 15;
   const int slot = (int)blockIdx.x * 4 + rho;
@@ -181,19 +191,20 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
   const int* const wh = (const int*)wb;
   const int nrow = have ? wh[0] : 0;
   if (__ballot(nrow > 0) == 0ull) return;
+  const bool mine = nrow > 0;        // (else: a row without an environment, or one that finished in the assemble launch — it must not write anything)
   const int nwin = (nrow + 15) >> 4;
   const int nwmax = max(max(__builtin_amdgcn_readlane(nwin, 0), __builtin_amdgcn_readlane(nwin, 16)), max(__builtin_amdgcn_readlane(nwin, 32), __builtin_amdgcn_readlane(nwin, 48)));
   const int nv = M.nv;
   constexpr int NK = NV + 2;
-  const bool lo_on = q < nv, hi_on = 16 + q < nv;
-  // dof vectors: lane q of the row carries dofs q and 16 + q
-  const float as_lo = lo_on ? wb[WN_AS + q] : 0.0f, as_hi = hi_on ? wb[WN_AS + 16 + q] : 0.0f;
-  const float ws_lo = lo_on ? wb[WN_AWS + q] : 0.0f, ws_hi = hi_on ? wb[WN_AWS + 16 + q] : 0.0f;
+  // dof vectors: lane q of the row carries dof q (lo) and dof 16 + q (hi; the 24-slot instance: dof 16 + (q >> 1), wn_fold8)
+  const int dhi = NV == 24 ? 16 + (q >> 1) : 16 + q;
+  const bool lo_on = q < nv, hi_on = dhi < nv;
+  const float as_lo = lo_on ? wb[WN_AS + q] : 0.0f, as_hi = hi_on ? wb[WN_AS + dhi] : 0.0f;
+  const float ws_lo = lo_on ? wb[WN_AWS + q] : 0.0f, ws_hi = hi_on ? wb[WN_AWS + dhi] : 0.0f;
 
   WnWin<NV> win[NW];
-  float f[NW];                                                 // forces of the register-resident windows (streamed ones: tile slot WN_TILE - 1)
+  float f[NW];                                                 // forces of the register-resident windows
   const float* rows = wb + WN_ROWS + q;
-  float* tiles = wb + WN_ROWS + WN_MAXW * NK * 16 + q;       // streamed windows: [w][WN_TILE][16]
   auto load_rows = [&](WnWin<NV>& W, const int w) __attribute__((always_inline)) {
     const bool ok = w < nwin;
     const float* p = rows + w * NK * 16;
@@ -223,31 +234,49 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
     W.A2 = make_float4(8 < q ? ninv * acc[8] : 0.0f, 9 < q ? ninv * acc[9] : 0.0f, 10 < q ? ninv * acc[10] : 0.0f, 11 < q ? ninv * acc[11] : 0.0f);
     W.A3 = make_float4(12 < q ? ninv * acc[12] : 0.0f, 13 < q ? ninv * acc[13] : 0.0f, 14 < q ? ninv * acc[14] : 0.0f, 0.0f);
   };
-  auto store_tile = [&](const WnWin<NV>& W, const int w) __attribute__((always_inline)) {
-    float* t = tiles + w * WN_TILE * 16;
-    t[0] = W.A0.x; t[16] = W.A0.y; t[32] = W.A0.z; t[48] = W.A0.w; t[64] = W.A1.x; t[80] = W.A1.y; t[96] = W.A1.z; t[112] = W.A1.w;
-    t[128] = W.A2.x; t[144] = W.A2.y; t[160] = W.A2.z; t[176] = W.A2.w; t[192] = W.A3.x; t[208] = W.A3.y; t[224] = W.A3.z; t[240] = W.A3.w;
-    t[256] = W.nw; t[272] = W.half;
+  // windows beyond the register-resident ones: the whole record (J^, aref, R, tile row, -1 / AR_qq, AR_qq / 2, force) [NX][16] — the
+  // next NL windows of every env in LDS (the kernel has no other use for it: 40 KB per wave at four waves per CU), the rest in the env's
+  // slice of global memory (read every sweep: slow, and rare — S24D's 140-row piles reach the LDS tier only)
+  constexpr int NX = NV + 21;
+  extern __shared__ float wn_lds[];
+  auto store_ext = [&](float* t, const WnWin<NV>& W, const float fw) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) t[16 * k] = W.J[k];
+    t[16 * NV] = W.aref; t[16 * (NV + 1)] = W.R;
+    float* u = t + 16 * (NV + 2);
+    u[0] = W.A0.x; u[16] = W.A0.y; u[32] = W.A0.z; u[48] = W.A0.w; u[64] = W.A1.x; u[80] = W.A1.y; u[96] = W.A1.z; u[112] = W.A1.w;
+    u[128] = W.A2.x; u[144] = W.A2.y; u[160] = W.A2.z; u[176] = W.A2.w; u[192] = W.A3.x; u[208] = W.A3.y; u[224] = W.A3.z; u[240] = W.A3.w;
+    u[256] = W.nw; u[272] = W.half; u[288] = fw;
   };
-  auto load_tile = [&](WnWin<NV>& W, const int w) __attribute__((always_inline)) {
-    const float* t = tiles + w * WN_TILE * 16;
-    W.A0 = make_float4(t[0], t[16], t[32], t[48]); W.A1 = make_float4(t[64], t[80], t[96], t[112]);
-    W.A2 = make_float4(t[128], t[144], t[160], t[176]); W.A3 = make_float4(t[192], t[208], t[224], t[240]);
-    W.nw = t[256]; W.half = t[272];
+  auto load_ext = [&](const float* t, WnWin<NV>& W) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) W.J[k] = t[16 * k];
+    W.aref = t[16 * NV]; W.R = t[16 * (NV + 1)];
+    const float* u = t + 16 * (NV + 2);
+    W.A0 = make_float4(u[0], u[16], u[32], u[48]); W.A1 = make_float4(u[64], u[80], u[96], u[112]);
+    W.A2 = make_float4(u[128], u[144], u[160], u[176]); W.A3 = make_float4(u[192], u[208], u[224], u[240]);
+    W.nw = u[256]; W.half = u[272];
   };
+  float* const xl = wn_lds + (rho * nl * NX) * 16 + q;                               // LDS tier: window NW + j at xl + j * NX * 16
+  float* const xg = wb + WN_ROWS + WN_MAXW * NK * 16 + q;                            // global tier: window w at xg + w * NX * 16
+  const int nwl = min(nwmax, NW + nl);
 #pragma unroll
   for (int w = 0; w < NW; w++) if (w < nwmax) { load_rows(win[w], w); make_tile(win[w]); }
-  for (int w = NW; w < nwmax; w++) { WnWin<NV> W; load_rows(W, w); make_tile(W); store_tile(W, w); }
+  for (int w = NW; w < nwl; w++) { WnWin<NV> W; load_rows(W, w); make_tile(W); store_ext(xl + (w - NW) * NX * 16, W, 0.0f); }
+  for (int w = nwl; w < nwmax; w++) { WnWin<NV> W; load_rows(W, w); make_tile(W); if (mine) store_ext(xg + w * NX * 16, W, 0.0f); }
   // every window of the wave, register-resident ones first; the body sees the window W and its force fw
 #define WN_FOR_WINDOWS(...) do { \
     _Pragma("unroll") for (int w = 0; w < NW; w++) if (w < nwmax) { WnWin<NV>& W = win[w]; float& fw = f[w]; __VA_ARGS__ } \
-    for (int w = NW; w < nwmax; w++) { WnWin<NV> W; load_rows(W, w); load_tile(W, w); float* fp = tiles + (w * WN_TILE + 18) * 16; float fw = *fp; __VA_ARGS__ *fp = fw; } } while (0)
+    for (int w = NW; w < nwl; w++) { WnWin<NV> W; float* t = xl + (w - NW) * NX * 16; load_ext(t, W); float fw = t[16 * (NV + 20)]; __VA_ARGS__ t[16 * (NV + 20)] = fw; } \
+    for (int w = nwl; w < nwmax; w++) { WnWin<NV> W; float* t = xg + w * NX * 16; float fw = 0.0f; if (mine) { load_ext(t, W); fw = t[16 * (NV + 20)]; } else { load_rows(W, WN_MAXW); W.A0 = W.A1 = W.A2 = W.A3 = make_float4(0, 0, 0, 0); W.nw = 0; W.half = 0; } \
+                                          __VA_ARGS__ if (mine) t[16 * (NV + 20)] = fw; } } while (0)
+#define WN_ZERO_EXT_FORCES() do { for (int w = NW; w < nwl; w++) xl[(w - NW) * NX * 16 + 16 * (NV + 20)] = 0.0f; \
+                                  if (mine) for (int w = nwl; w < nwmax; w++) xg[w * NX * 16 + 16 * (NV + 20)] = 0.0f; } while (0)
 
   // ---- warm start (mj_fwdConstraint): f = max(0, -(J a_ws - aref) / R), kept if the dual cost is not positive
   float a_lo = as_lo, a_hi = as_hi;
 #pragma unroll
   for (int w = 0; w < NW; w++) f[w] = 0.0f;
-  for (int w = NW; w < nwmax; w++) tiles[(w * WN_TILE + 18) * 16] = 0.0f;
   if (!(M.disableflags & MJH_DSBL_WARMSTART)) {
     float da_lo = 0.0f, da_hi = 0.0f;
     WN_FOR_WINDOWS({
@@ -264,7 +293,7 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
     if (cost > 0.0f) {
 #pragma unroll
       for (int w = 0; w < NW; w++) f[w] = 0.0f;
-      for (int w = NW; w < nwmax; w++) tiles[(w * WN_TILE + 18) * 16] = 0.0f;
+      WN_ZERO_EXT_FORCES();
     } else { a_lo += da_lo; a_hi += da_hi; }
   }
   // ---- sweeps: every env (16-lane row) until ITS improvement falls below the tolerance
@@ -291,12 +320,16 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
       if (wn_rowsum_i(impl) < iq.thr || niter >= itmax) act = false;
     }
   }
-  const bool mine = nrow > 0;        // (else: a row without an environment, or one that finished in the assemble launch)
   // ---- qacc, mj_checkAcc, semi-implicit Euler (mj_Euler; free joints only), state and statistics
-  const float sv_lo = (mine && lo_on) ? wb[WN_SINV + q] : 0.0f, sv_hi = (mine && hi_on) ? wb[WN_SINV + 16 + q] : 0.0f;
+  const float sv_lo = (mine && lo_on) ? wb[WN_SINV + q] : 0.0f, sv_hi = (mine && hi_on) ? wb[WN_SINV + dhi] : 0.0f;
   float qa_lo = a_lo * sv_lo, qa_hi = a_hi * sv_hi;
-  float qv_lo = (mine && lo_on) ? wb[WN_QVEL + q] : 0.0f, qv_hi = (mine && hi_on) ? wb[WN_QVEL + 16 + q] : 0.0f;
+  float qv_lo = (mine && lo_on) ? wb[WN_QVEL + q] : 0.0f, qv_hi = (mine && hi_on) ? wb[WN_QVEL + dhi] : 0.0f;
   int flags = mine ? wh[3] : 0;
+  if (mine && (xflags & XF_FORCE)) {   // the split API's exports (mjh_step2): qacc_smooth and qfrc_constraint = M (qacc - qacc_smooth), indexed by the row inside the launch's range
+    const size_t xe = (size_t)(env - env0) * M.nvp;
+    if (lo_on) { if (S.x_smooth) S.x_smooth[xe + q] = as_lo * sv_lo; if (S.x_constraint) S.x_constraint[xe + q] = (a_lo - as_lo) / sv_lo; }
+    if (hi_on && (NV != 24 || !(q & 1))) { if (S.x_smooth) S.x_smooth[xe + dhi] = as_hi * sv_hi; if (S.x_constraint) S.x_constraint[xe + dhi] = (a_hi - as_hi) / sv_hi; }
+  }
   const bool badl = !(qa_lo == qa_lo) || fabsf(qa_lo) > MJ_MAXVAL || !(qa_hi == qa_hi) || fabsf(qa_hi) > MJ_MAXVAL;
   const bool bad = ((__ballot(badl) >> (16 * rho)) & 0xffffull) != 0ull;
   const size_t qrow = (size_t)env * M.nqp, vrow = (size_t)env * M.nvp;
@@ -322,7 +355,7 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
     s_v[rho][d] = qv;
   };
   if (mine && lo_on) advance(q, qa_lo, qv_lo);
-  if (mine && hi_on) advance(16 + q, qa_hi, qv_hi);
+  if (mine && hi_on && (NV != 24 || !(q & 1))) advance(dhi, qa_hi, qv_hi);
   __syncthreads();
   if (mine && q < M.njnt) {
     const int qadr = jnt_qposadr[q], da = jnt_dofadr[q];
@@ -344,4 +377,5 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
     S.stats[4 * env + 3] = ((S.stats[4 * env + 3] | flags) & 0xff) | (cost_hint << 8);
   }
 #undef WN_FOR_WINDOWS
+#undef WN_ZERO_EXT_FORCES
 }

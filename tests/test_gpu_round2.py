@@ -599,15 +599,18 @@ def test_patch_sweep_with_condim_1_3_4_contacts_matches_oracle(lib):
 def test_patch_pool_overflow_drops_patches_and_raises_the_capacity_flag():
     """the patch pool takes the LDS span that is dead when the sweeps start and no more: patches beyond it are dropped with the
     capacity flag, like contacts beyond maxcon.  Forced here with a pool of 600 floats (MJH_PATCH_POOL_FLOATS): settled S24 piles
-    need 1500-3000."""
+    need 1500-3000.  (The fused kernel's patch sweep: mjh_set_window_solver(0) — the window sweep of mjh_step has no pool.)"""
     m = ms.scene("s24")
     full = ms.Engine(m, 64); tab = full.load_s24(); full.step(300)
     t, q, v, w = full.get_state(); assert (full.get_stats()[:, 3] & 2).sum() == 0
     os.environ["MJH_PATCH_POOL_FLOATS"] = "600"
+    ms.capi.load().mjh_set_window_solver(0)
     try:
         e = ms.Engine(m, 64)
     finally:
         del os.environ["MJH_PATCH_POOL_FLOATS"]
+        ms.capi.load().mjh_set_window_solver(1)
+    assert e.window_solver() == 0
     for k in EP:
         e.set_env_param(k, tab[k])
     e.set_initial_qpos(tab["qpos"]); e.set_state(qpos=q, qvel=v, warmstart=w)

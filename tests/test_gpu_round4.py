@@ -1,0 +1,128 @@
+"""Round 4 GPU tests: the window sweep (csrc/window_pgs.h — mjh_step of small free-body models as assemble launch + mjh_window_kernel,
+projected Gauss-Seidel in mj_solPGS's row order over windows of 16 consecutive rows, four envs per wavefront) against the fused
+kernel's contact-patch sweep and against the oracle; S24D (the "30-contact" reading of the metric: 140 rows per env, windows streamed
+beyond the register-resident ones) teacher-forced like S24; the independent check of the project's own box-box manifold."""
+import numpy as np
+import pytest
+
+import mujoco_sim_amd as ms
+import orc
+from helpers import oracle_s24
+from test_gpu_teacher_forced import teacher_forced, summarize, S24_TOL_Q, S24_TOL_V
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(m, nenv, window, load=None):
+    lib = ms.capi.load()
+    lib.mjh_set_window_solver(1 if window else 0)
+    try:
+        e = ms.Engine(m, nenv)
+    finally:
+        lib.mjh_set_window_solver(1)
+    assert e.window_solver() == (1 if window else 0) and e.solver_order() == 2 and e.patch_sweep() == 1
+    tab = load(e) if load else e.load_s24()
+    return e, tab
+
+
+def test_window_sweep_equals_the_fused_patch_sweep_up_to_rounding():
+    """same constraint order, same clamps, same stopping rule, different grouping of the arithmetic (windows of 16 consecutive rows with
+    a dense J over the 24 dofs, against patches of one body pair): one step from identical states agrees to fp32 rounding — qpos 1e-6,
+    qvel 2e-5 relative, as each does against the oracle — with identical contact / row counts and (nearly always) identical sweep
+    counts; 200 free-running steps from reset stay together until a contact set forks"""
+    m = ms.scene("s24")
+    nenv = 64
+    a, tab = _engine(m, nenv, True)
+    b, _ = _engine(m, nenv, False)
+    a.step(150); b.step(150)                    # fall and settle, each on its own
+    worst_q = worst_v = 0.0; same_sweeps = []; n = 0
+    for k in range(80):
+        t, q, v, w = a.get_state()
+        b.set_state(qpos=q, qvel=v, time=t, warmstart=w)
+        a.step(1); b.step(1)
+        _, qa, va, wa = a.get_state(); _, qb, vb, wb = b.get_state()
+        sa, sb = a.get_stats(), b.get_stats()
+        assert np.array_equal(sa[:, :2], sb[:, :2]) and np.array_equal(sa[:, 3] & 7, sb[:, 3] & 7), "same contacts, rows and flags from the same state"
+        rq = np.abs(qa - qb).max(axis=1) / np.maximum(1, np.abs(qb).max(axis=1)); rv = np.abs(va - vb).max(axis=1) / np.maximum(1, np.abs(vb).max(axis=1))
+        worst_q = max(worst_q, rq.max()); worst_v = max(worst_v, rv.max())
+        same_sweeps.append(sa[:, 2] == sb[:, 2]); n += nenv
+    same = float(np.mean(same_sweeps))
+    print(f"WINDOW-vs-PATCH {n} env-steps: qpos rel max {worst_q:.2e}, qvel rel max {worst_v:.2e}, same sweep count {same:.4f}")
+    assert worst_q <= S24_TOL_Q and worst_v <= S24_TOL_V and same >= 0.98
+    st = a.get_stats()
+    assert st[:, 0].mean() >= 12 and (st[:, 3] & 7 == 0).all()
+    a.close(); b.close()
+
+
+def test_window_sweep_results_do_not_depend_on_which_envs_share_a_wavefront():
+    """four envs per wavefront, grouped by the launch order (longest job first, renewed every few steps) and by the cohort split:
+    every env's arithmetic stays inside its 16-lane row, so 1 cohort / 3 cohorts / another batch size give the same bits"""
+    m = ms.scene("s24")
+    outs = []
+    for nenv, nc in ((1280, 1), (1280, 3), (1283, 2)):
+        e, _ = _engine(m, nenv, True)
+        e.set_cohorts(nc)
+        e.step(70)
+        t, q, v, w = e.get_state(); st = e.get_stats()
+        outs.append((q[:1280], v[:1280], w[:1280], st[:1280, :3]))
+        e.close()
+    for k in (1, 2):
+        for x, y in zip(outs[0], outs[k]):
+            assert np.array_equal(x, y)
+
+
+def _s24d(nenv):
+    pen = 0.175
+    m = ms.scene("s24pen", pen, 64)
+    e, tab = _engine(m, nenv, True)
+    q = tab["qpos"].reshape(nenv, 4, 7)
+    for i in range(nenv):
+        rng = np.random.default_rng(0x524D0000 + i)
+        for k in range(4):
+            yaw = rng.uniform(-0.3, 0.3)
+            q[i, k] = [(-1 if k & 1 else 1) * pen / 2, (-1 if k & 2 else 1) * pen / 2, 0.16 + 0.02 * k, np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)]
+    e.set_initial_qpos(tab["qpos"]); e.reset()
+    return m, e, tab
+
+
+def test_s24d_teacher_forced_with_streamed_windows():
+    """S24D = bench.py's `s24d`: the four boxes released flat, ~33 contacts / ~140 rows per env — nine windows, the ninth and later ones
+    streamed from memory every sweep.  Oracle settles 400 steps; 100 teacher-forced steps at S24's tolerances, no capacity flag."""
+    nenv = 12
+    m, e, tab = _s24d(nenv)
+    ds = [oracle_s24(m, tab, i) for i in range(nenv)]
+    for d in ds:
+        d.step(400)
+    r = teacher_forced(e, ds, 100)
+    s = summarize("s24d/default=mj_solPGS-row-order(window sweep)", r)
+    a = r["agree"].astype(bool)
+    assert r["ncon"].mean() >= 24 and r["nefc"].max() > 128, "the scene must exercise the streamed windows (more than 8 x 16 rows)"
+    assert s["agree_fraction"] >= 0.95, s
+    assert r["eq"][a].max() <= S24_TOL_Q and r["ev"][a].max() <= S24_TOL_V, s
+    st = e.get_stats()
+    assert (st[:, 3] & 3 == 0).all()
+    e.close()
+
+
+def test_window_sweep_handles_empty_sparse_and_reset_environments():
+    """envs without any contact (in free fall) finish in the assemble launch; a NaN state is reset by the window kernel's mj_checkAcc
+    path or the assemble launch's mj_checkPos; time advances by dt for every env either way"""
+    m = ms.scene("s24")
+    nenv = 8
+    e, tab = _engine(m, nenv, True)
+    q0 = tab["qpos"].copy()
+    q0[0].reshape(4, 7)[:, 2] += 50.0                  # env 0: far above the floor, no contacts for a long time
+    e.set_initial_qpos(q0); e.reset()
+    d0 = oracle_s24(m, {k: (q0 if k == "qpos" else v) for k, v in tab.items()}, 0)
+    e.step(30); d0.step(30)
+    t, q, v, w = e.get_state(); st = e.get_stats()
+    np.testing.assert_allclose(t, 30 * m.opt.timestep, rtol=1e-12)
+    assert st[0, 0] == 0 and st[0, 2] == 0
+    np.testing.assert_allclose(q[0], d0.f("qpos"), atol=2e-5); np.testing.assert_allclose(v[0], d0.f("qvel"), atol=2e-5)
+    v[3, :] = np.nan
+    e.set_state(qvel=v)
+    e.step(2)
+    t2, q2, v2, _ = e.get_state(); st2 = e.get_stats()
+    assert np.isfinite(q2).all() and np.isfinite(v2).all() and (st2[3, 3] & 4) and not (st2[[0, 1, 2, 4, 5, 6, 7], 3] & 4).any()
+    np.testing.assert_allclose(t2, 32 * m.opt.timestep, rtol=1e-12)
+    e.close()
