@@ -125,7 +125,8 @@ static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps,
   HIPCHK(hipGetLastError());
   if (window) {
     // LDS tier: windows beyond the register-resident ones, as many as leave four waves per CU (40 KB per wave)
-    const int nl = std::min(WN_MAXW, (int)((40 * 1024 - 1024) / (4 * WN_XREC(e->M.win_nvt) * 16 * sizeof(float))));
+    static const int nl_env = getenv("MJH_WN_NL") ? atoi(getenv("MJH_WN_NL")) : -1;      // (experiments: force the number of LDS-tier windows)
+    const int nl = nl_env >= 0 ? nl_env : std::min(WN_MAXW, (int)((40 * 1024 - 1024) / (4 * WN_XREC(e->M.win_nvt) * 16 * sizeof(float))));
     const size_t lds = (size_t)4 * nl * WN_XREC(e->M.win_nvt) * 16 * sizeof(float);
     if (e->M.win_nvt == 24) hipLaunchKernelGGL((mjh_window_kernel<24, WN_NW24>), dim3((n + 3) / 4), dim3(64), lds, st, e->dC, e->S, env0, n, nl, xflags);
     else hipLaunchKernelGGL((mjh_window_kernel<32, WN_NW32>), dim3((n + 3) / 4), dim3(64), lds, st, e->dC, e->S, env0, n, nl, xflags);

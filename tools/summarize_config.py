@@ -37,9 +37,11 @@ if con:
         lines.append(f"| `{r[0][:110]}` | {r[1]} | {r[2]:.1f} | {r[3]:.2f} | {r[4]:.3f} |")
         csv.append(",".join(['"%s"' % r[0]] + [str(x) for x in r[1:]]))
     open(os.path.join(dst, f"{tag}_{cfg}_kernel_stats.csv"), "w").write("\n".join(csv) + "\n")
-    rows = con.execute("select k.name, k.start, k.end, k.vgpr_count, k.sgpr_count, k.lds_size, k.scratch_size from kernels k where k.name like '%mjh_step_kernel%' or k.name like '%mjh_solve_kernel%' or k.name like '%mjh_dense_%' or k.name like '%mjh_solve_mixed%' order by k.start").fetchall()
+    cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
+    acc = "k.accum_vgpr_count" if "accum_vgpr_count" in cols else "0"
+    rows = con.execute(f"select k.name, k.start, k.end, k.vgpr_count, k.sgpr_count, k.lds_size, k.scratch_size, {acc} from kernels k where k.name like '%mjh_step_kernel%' or k.name like '%mjh_solve_kernel%' or k.name like '%mjh_dense_%' or k.name like '%mjh_solve_mixed%' or k.name like '%mjh_window_kernel%' order by k.start").fetchall()
     if rows:
-        per = 3 if any("mjh_solve_kernel" in r[0] for r in rows) else 1
+        per = 3 if any("mjh_solve_kernel" in r[0] for r in rows) else (2 if any("mjh_window_kernel" in r[0] for r in rows) else 1)
         if any("mjh_dense_" in r[0] for r in rows):
             per = 5        # assemble -> dense build -> dense solve -> block solve (cohorts without a long-sweeping env, envs beyond the capacity) -> integrate
         last = rows[-timed * per:]
@@ -47,11 +49,13 @@ if con:
         per_step_us = tot / max(timed, 1)
         lines += ["", f"Step kernels per launch: {per}.  Summed kernel time per step launch over the LAST {timed} launches (the timed region): **{per_step_us:.1f} us**"]
         seen = {}
-        for n, s, e, vg, sg, lds, scr in last:
+        for n, s, e, vg, sg, lds, scr, av in last:
             k = n.split("(")[0]
-            a = seen.setdefault(k, [0, 0.0, vg, sg, lds, scr]); a[0] += 1; a[1] += (e - s) / 1e3
+            a = seen.setdefault(k, [0, 0.0, vg, sg, lds, scr, av]); a[0] += 1; a[1] += (e - s) / 1e3
         for k, a in seen.items():
-            lines.append(f"- `{k}`: {a[0]} launches, mean {a[1] / a[0]:.1f} us; VGPR {a[2]}, SGPR {a[3]}, LDS {a[4]} B/workgroup, scratch {a[5]} B/lane")
+            # (rocprofv3's vgpr_count is the ARCHITECTED half of gfx950's unified file; the allocation that sets the occupancy is
+            # arch + accum, what the code object's .vgpr_count note and tools/kernel_resources.sh report)
+            lines.append(f"- `{k}`: {a[0]} launches, mean {a[1] / a[0]:.1f} us; registers {a[2]} arch VGPR + {a[6]} AGPR = {a[2] + a[6]} unified, SGPR {a[3]}, LDS {a[4]} B/workgroup, scratch {a[5]} B/lane")
         lines.append("")
 tot = {}
 for sub, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
@@ -59,8 +63,8 @@ for sub, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     if not con:
         continue
     acc = 0.0; cnt = 0
-    rows = con.execute("select kernel_name, value from counters_collection where (kernel_name like '%mjh_step_kernel%' or kernel_name like '%mjh_solve_kernel%' or kernel_name like '%mjh_dense_%' or kernel_name like '%mjh_solve_mixed%') and counter_name=? order by start", (name,)).fetchall()
-    per = 3 if any("mjh_solve_kernel" in r[0] for r in rows) else 1
+    rows = con.execute("select kernel_name, value from counters_collection where (kernel_name like '%mjh_step_kernel%' or kernel_name like '%mjh_solve_kernel%' or kernel_name like '%mjh_dense_%' or kernel_name like '%mjh_solve_mixed%' or kernel_name like '%mjh_window_kernel%') and counter_name=? order by start", (name,)).fetchall()
+    per = 3 if any("mjh_solve_kernel" in r[0] for r in rows) else (2 if any("mjh_window_kernel" in r[0] for r in rows) else 1)
     if any("mjh_dense_" in r[0] for r in rows):
         per = 5
     last = rows[-timed * per:]
@@ -87,17 +91,35 @@ if "FETCH_SIZE" in tot or "WRITE_SIZE" in tot:
                "kernel_us_per_step_launch": per_step_us,
                "note": "rocprofv3 PMC, separate passes; raw FETCH_SIZE + WRITE_SIZE of the step kernels per step launch"},
               open(os.path.join(dst, f"{tag}_{cfg}_traffic.json"), "w"), indent=1)
-con = db("pmc_sq")
-if con:
-    lines += [f"## SQ counters of `mjh_step_kernel` (per launch, averages over the last {timed} launches)", "", "| counter | value | per env |", "|---|---|---|"]
-    names = [r[0] for r in con.execute("select distinct counter_name from counters_collection")]
-    for n in sorted(names):
-        rows = con.execute("select value from counters_collection where kernel_name like '%mjh_step_kernel%' and counter_name=? order by start", (n,)).fetchall()
-        last = [r[0] for r in rows[-timed:]]
-        if last:
-            v = sum(last) / len(last)
-            lines.append(f"| {n} | {v:.4g} | {v / envs_per_launch:.4g} |")
-    lines.append("")
+sq = {}
+for sub in ("pmc_sq", "pmc_sq2"):
+    con = db(sub)
+    if not con:
+        continue
+    for kn, cn, v in con.execute("select kernel_name, counter_name, value from counters_collection where kernel_name like '%mjh_%' and kernel_name not like '%order_kernel%' and kernel_name not like '%export%' order by start"):
+        sq.setdefault(kn.split("(")[0], {}).setdefault(cn, []).append(v)
+sqsum = {}
+if sq:
+    lines += [f"## SQ counters per kernel (`--pmc`, own passes; averages over each kernel's last {timed} launches; one launch = {envs_per_launch:.0f} envs)", ""]
+    for kn, cs in sq.items():
+        m = {c: sum(v[-timed:]) / len(v[-timed:]) for c, v in cs.items()}
+        sqsum[kn] = m
+        lines += [f"`{kn}`", "", "| counter | per launch | per env |", "|---|---|---|"]
+        for c in sorted(m):
+            lines.append(f"| {c} | {m[c]:.4g} | {m[c] / envs_per_launch:.4g} |")
+        d = []
+        if m.get("SQ_INSTS_VALU") and m.get("SQ_THREAD_CYCLES_VALU") and m.get("SQ_ACTIVE_INST_VALU"):
+            # SQ_ACTIVE_INST_VALU: cycles (x4 quad-cycles) the VALU is busy with wave instructions; SQ_THREAD_CYCLES_VALU: the same per
+            # active lane — their ratio / 64 is the fraction of lanes live in the average VALU instruction
+            d.append(f"active lanes per VALU instruction = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64 = **{m['SQ_THREAD_CYCLES_VALU'] / m['SQ_ACTIVE_INST_VALU'] / 64:.3f}**")
+        if m.get("SQ_BUSY_CYCLES") and m.get("SQ_ACTIVE_INST_VALU"):
+            d.append(f"SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES = {m['SQ_ACTIVE_INST_VALU'] / m['SQ_BUSY_CYCLES']:.3f}")
+        if m.get("SQ_WAVE_CYCLES") and m.get("SQ_WAVES"):
+            d.append(f"wave cycles per wave = {m['SQ_WAVE_CYCLES'] / m['SQ_WAVES']:.4g}")
+        if d:
+            lines += ["", "; ".join(d)]
+        lines.append("")
+    json.dump(sqsum, open(os.path.join(dst, f"{tag}_{cfg}_sq.json"), "w"), indent=1)
 if bench:
     json.dump(bench, open(os.path.join(dst, f"{tag}_{cfg}_bench.json"), "w"))
     lines += ["## bench.py line of the traced run", "", "```", json.dumps(bench), "```", ""]
