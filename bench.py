@@ -91,11 +91,18 @@ class Workload:
     def oracle_data(self, orc, i, state): raise NotImplementedError
     def extra_config(self): return {}
 
+    def quiet_steps(self, k):
+        """steps from step k on (k included) that need no host-side work between them: 1 unless a config knows its schedule"""
+        return 1 << 30 if type(self).before_step is Workload.before_step else 1
+
     def step(self, n, inverse):
-        for _ in range(n):
+        # one mjh_step call per stretch without host work: the engine turns it into one launch per cohort where its kernel carries the
+        # step loop (steps_per_launch), into back-to-back launches elsewhere
+        while n > 0:
             self.before_step(self.step_count)
-            self.eng.step(1, inverse)
-            self.step_count += 1
+            k = max(1, min(n, self.quiet_steps(self.step_count)))
+            self.eng.step(k, inverse)
+            self.step_count += k; n -= k
 
 
 class S24(Workload):
@@ -187,6 +194,9 @@ class C3(Workload):
         if k % 200 == 0:
             self.target = self.rng.uniform(self.lo, self.hi, size=(self.nenv, self.base_model.nv))
             self.eng.set_pd_target(self.target.reshape(self.rows, -1))
+
+    def quiet_steps(self, k):
+        return 200 - k % 200
 
     def oracle_data(self, orc, i, state):
         d = orc.OrcData(self.base_model.ptr)
@@ -435,35 +445,54 @@ def run_group_host(args):
     inverse = wcls.inverse if args.with_inverse < 0 else bool(args.with_inverse)
     publish_every = max(1, int(round(1.0 / (60.0 * model.opt.timestep))))
     count = [0]
+    issue = {"step_s": 0.0, "step_calls": 0, "publish_s": 0.0, "publish_calls": 0}     # wall time the ONE host thread spends inside the calls
+    if args.steps_per_launch > 0:
+        for e in g.engines:
+            e.set_steps_per_launch(args.steps_per_launch)
 
     def run(nsteps):
-        for _ in range(nsteps):
-            g.step(1, inverse); count[0] += 1
+        while nsteps > 0:
+            k = nsteps if args.no_gather else min(nsteps, publish_every - count[0] % publish_every)
+            t_ = time.perf_counter(); g.step(k, inverse); issue["step_s"] += time.perf_counter() - t_; issue["step_calls"] += 1
+            count[0] += k; nsteps -= k
             if not args.no_gather and count[0] % publish_every == 0:
-                g.publish_device()
+                t_ = time.perf_counter(); g.publish_device(); issue["publish_s"] += time.perf_counter() - t_; issue["publish_calls"] += 1
 
     run(wcls.settle_steps); run(args.warmup); g.synchronize()
-    g.engines[0].set_launch_timing(max(1, args.timing_stride)); g.set_publish_timing(True)
-    t0 = time.perf_counter(); run(args.steps); g.synchronize(); elapsed = time.perf_counter() - t0
+    g.engines[0].set_launch_timing(max(1, args.timing_stride))
+    for k_ in issue:
+        issue[k_] = 0
+    t0 = time.perf_counter(); run(args.steps); t_issued = time.perf_counter() - t0; g.synchronize(); elapsed = time.perf_counter() - t0
     kernel_ms, n_timed = g.engines[0].get_launch_timing(); g.engines[0].set_launch_timing(False)
+    issue_timed = dict(issue)
+    # the exchange's own duration: a second, short window (reading the event pair of the previous publish makes the host wait for it —
+    # kept out of the timed window, whose host time is the issue time reported below)
+    g.set_publish_timing(True); run(min(args.steps, 20 * publish_every)); g.synchronize()
     ag_ms, ag_n = g.get_publish_timing(); g.set_publish_timing(False)
+    issue = issue_timed
     st = np.concatenate([e.get_stats() for e in g.engines])
     cohorts = g.engines[0].cohorts
     G = cohorts if (cohorts > 1 and g.ranges[0][1] >= 64 * cohorts) else 1
     bytes_step = algorithmic_bytes_per_env_step(model.nq, model.nv)
     envs_per_launch = g.ranges[0][1] / G
-    achieved = bytes_step * envs_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    spl = int(g.engines[0].steps_per_launch) if args.no_gather else min(int(g.engines[0].steps_per_launch), publish_every)
+    achieved = bytes_step * envs_per_launch * spl / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    # one host thread issues every device's launches (csrc/group.hip): if the time it spends inside the calls reaches the wall time of
+    # the window, the group host — not the devices — sets the rate (measurable on one device: --group-devices 0,0,0,0,0,0,0,0)
+    host_issue = {"ms_per_step_in_mjh_group_step": 1e3 * issue["step_s"] / args.steps, "ms_per_publish_call": 1e3 * issue["publish_s"] / max(issue["publish_calls"], 1),
+                  "issue_fraction_of_wall": (issue["step_s"] + issue["publish_s"]) / elapsed, "wall_ms_until_everything_was_issued": 1e3 * t_issued,
+                  "launches_per_step": ndev * G / spl, "steps_per_launch": spl}
     out = {
         "metric": METRIC if args.config == "s24" else f"env-steps/sec (whole node), BASELINE config {args.config.upper()}",
         "value": total * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": ndev, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wcls.label, "name": args.config, "settle_steps": wcls.settle_steps, "envs_per_gpu": per_gpu, "envs_total": total,
-                   "cohorts": cohorts, "with_inverse": bool(inverse), "parallelism": f"env-sharded x{ndev}, one process (mjh_group)",
+                   "cohorts": cohorts, "steps_per_launch": spl, "with_inverse": bool(inverse), "parallelism": f"env-sharded x{ndev}, one process (mjh_group)",
                    "nq": int(model.nq), "nv": int(model.nv), "mean_ncon": float(st[:, 0].mean()), "mean_nefc": float(st[:, 1].mean()),
                    "mean_solver_iter": float(st[:, 2].mean())},
         "host": {"kind": "group", "api": "mjh_group_create / mjh_group_step / mjh_group_publish (csrc/group.hip)", "devices": devices,
                  "ranks": [{"rank": k, "device": devices[k], "env0": lo, "nenv": n} for k, (lo, n) in enumerate(g.ranges)],
-                 "rccl": bool(g.uses_rccl), "rccl_ranks": ndev if g.uses_rccl else 0,
+                 "host_issue": host_issue, "rccl": bool(g.uses_rccl), "rccl_ranks": ndev if g.uses_rccl else 0,
                  "transport": "RCCL ncclAllGather (ncclCommInitAll, one group call)" if g.uses_rccl else "peer copies (hipMemcpyPeerAsync)",
                  "all_gather": {"ms_mean": ag_ms, "count": ag_n, "bytes_per_rank": int(g.ranges[0][1] * g.stride * 4), "publish_every_steps": publish_every}},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -493,8 +522,9 @@ def short_config_line(ms, args, name, device, stream):
         pub = torch.empty(w.rows * eng.state_stride, dtype=torch.float32, device="cuda")
 
         def run(n):
-            for _ in range(n):
-                w.step(1, w.inverse)
+            while n > 0:
+                k = min(n, publish_every - w.step_count % publish_every)
+                w.step(k, w.inverse); n -= k
                 if w.step_count % publish_every == 0:
                     eng.export_state_device(pub.data_ptr())
 
@@ -515,9 +545,10 @@ def short_config_line(ms, args, name, device, stream):
         cohorts = eng.cohorts
         G = cohorts if (cohorts > 1 and w.rows >= 64 * cohorts) else 1
         b = algorithmic_bytes_per_env_step(w.base_model.nq, w.base_model.nv)
-        ach = b * (w.nenv / G) / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        spl = min(int(eng.steps_per_launch), publish_every)
+        ach = b * (w.nenv / G) * spl / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         return {"value": w.nenv * steps / el, "unit": "env-steps/s", "envs": w.nenv, "steps": steps, "settle_steps": w.settle_steps,
-                "ms_per_step": el / steps * 1e3, "with_inverse": bool(w.inverse), "cohorts": cohorts, "envs_per_wavefront": w.pack,
+                "ms_per_step": el / steps * 1e3, "with_inverse": bool(w.inverse), "cohorts": cohorts, "envs_per_wavefront": w.pack, "steps_per_launch": spl,
                 "kernel_ms": kms, "roofline_frac": ach / HBM_PEAK_GBS, "roofline_achieved_GBs": ach, "algorithmic_bytes_per_env_step": b,
                 "mean_ncon": float(st[:, 0].mean()) / w.pack, "mean_nefc": float(st[:, 1].mean()) / w.pack,
                 "mean_solver_iter": float(st[:, 2].mean()), "overflow_envs": int((st[:, 3] & 3 != 0).sum()), "workload": w.label}
@@ -565,9 +596,10 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="0 = the config's size (S24/C2/C5 4096, C3 8192, C4 2048)")
     ap.add_argument("--with-inverse", type=int, default=-1, help="mj_inverse every step in the MAIN timed window (-1: the config's default; the other variant is timed in a second window)")
     ap.add_argument("--cohorts", type=int, default=-1, help="env cohorts stepped on separate HIP streams (-1: the config's default, else the engine's)")
+    ap.add_argument("--steps-per-launch", type=int, default=0, help="cap of the in-kernel step loop (0: the engine's default, 8; 1: one launch per step)")
     ap.add_argument("--timing-stride", type=int, default=5, help="bracket every N-th step launch with HIP events (roofline.kernel_ms is their mean)")
     ap.add_argument("--pack", type=int, default=0, help="environments per wavefront for the small-model configs (0: the config's default — C3 4, C5 2, others 1)")
-    ap.add_argument("--pen-half", type=float, default=0.0, help="s24d: half width of the pen in metres (default 0.14; S24 itself is 0.175)")
+    ap.add_argument("--pen-half", type=float, default=0.0, help="s24d: half width of the pen in metres (default 0.175, S24's own pen)")
     ap.add_argument("--maxcon", type=int, default=0, help="override the scene's contact capacity per env; 0 = scene default")
     ap.add_argument("--pgs-schedule", type=int, default=1, choices=[0, 1, 2],
                     help="mjh_set_pgs_row_order: 1 (default) mj_solPGS's own row order, independent blocks side by side under a precedence-preserving list "
@@ -623,6 +655,8 @@ def main():
     eng, model, nenv = w.eng, w.model, w.nenv
     if args.cohorts > 0 or w.cohorts > 0:
         eng.set_cohorts(args.cohorts if args.cohorts > 0 else w.cohorts)
+    if args.steps_per_launch > 0:
+        eng.set_steps_per_launch(args.steps_per_launch)
     main_inverse = w.inverse if args.with_inverse < 0 else bool(args.with_inverse)
     stride = eng.state_stride
     pub = torch.empty(w.rows * stride, dtype=torch.float32, device="cuda")
@@ -633,8 +667,10 @@ def main():
     comm_stream = torch.cuda.Stream() if use_dist else None
 
     def run(nsteps, inverse, time_gather=False):
-        for _ in range(nsteps):
-            w.step(1, inverse)
+        left = nsteps
+        while left > 0:
+            k = left if args.no_gather else min(left, publish_every - w.step_count % publish_every)    # up to the next publish
+            w.step(k, inverse); left -= k
             if not args.no_gather and w.step_count % publish_every == 0:   # 60 Hz publish: packed state slice (+ RCCL all-gather)
                 if use_dist:
                     stream.wait_stream(comm_stream)        # the previous gather has read `pub` (three steps ago: long done)
@@ -686,7 +722,10 @@ def main():
     G = cohorts if (cohorts > 1 and w.rows >= 64 * cohorts) else 1      # the engine's rule (engine.hip: mjh_step)
     envs_per_launch = nenv / G                                          # one launch = one step of one cohort
     n_timed, n_launches = n_launches, args.steps * G
-    achieved = bytes_step * envs_per_launch / (kernel_ms * 1e-3) / 1e9
+    # steps one launch runs (in-kernel step loop: the stretch between two publishes, at most the engine's cap; 1: a launch per step)
+    spl = int(eng.steps_per_launch) if args.no_gather else min(int(eng.steps_per_launch), publish_every)
+    n_launches = -(-args.steps // spl) * G
+    achieved = bytes_step * envs_per_launch * spl / (kernel_ms * 1e-3) / 1e9
 
     # 4. the other mj_inverse variant, same K steps (the reference always pays mj_inverse,
     # mj_hw_interface.cpp:61 — report both)
@@ -717,7 +756,7 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": w.label, "name": w.name, "settle_steps": w.settle_steps, "envs_per_gpu": nenv, "envs_total": total_envs,
-                   "steps_per_launch": 1, "cohorts": cohorts, "with_inverse": bool(main_inverse), "parallelism": f"env-sharded x{world}",
+                   "steps_per_launch": spl, "cohorts": cohorts, "with_inverse": bool(main_inverse), "parallelism": f"env-sharded x{world}",
                    "envs_per_wavefront": w.pack, "nq": int(w.base_model.nq), "nv": int(w.base_model.nv),
                    "mean_ncon": mean_ncon, "max_ncon": int(st[:, 0].max()), "mean_nefc": float(st[:, 1].mean()) / w.pack,
                    "max_nefc": int(st[:, 1].max()), "mean_solver_iter": float(st[:, 2].mean()),

@@ -459,6 +459,12 @@ void mjh_set_window_solver(int on);
 int mjh_window_solver(const mjh_engine*);
 int mjh_set_cohorts(mjh_engine*, int n);
 int mjh_get_cohorts(const mjh_engine*);
+/* mjh_step(e, n) of an articulated model in the LDS-resident layout runs up to `n` steps per launch and cohort with the environment's
+ * state resident in LDS between them (the in-kernel step loop; default 8, 1 = one launch per step; bitwise the same results).
+ * mjh_get_steps_per_launch: what the engine's mjh_step uses — 1 for free-body models and the many-body chain, whose steps are
+ * chains of launches (src/mj_main.cpp:83-108 is one step of ONE world; the batch steps n times before the host looks again). */
+int mjh_set_steps_per_launch(mjh_engine*, int n);
+int mjh_get_steps_per_launch(const mjh_engine*);
 /* HIP-event timing of the step-kernel launches on the stream they run on: enable (on = 1: every launch, on = N > 1: every
  * N-th launch — the event pairs cost stream time of their own, visible in launch-bound configs), step, then read the mean
  * duration [ms] and the number of launches timed since the last read (bench.py's roofline leg). */
@@ -495,9 +501,13 @@ int mjh_group_publish(mjh_group*, float* host_out);
  * mjh_group_synchronize(), or after a publish with host_out */
 const float* mjh_group_state_device(const mjh_group*, int rank);
 int mjh_group_wait_publish(mjh_group*, int rank, void* stream /* NULL: the device's engine stream */);
+/* ... and the consumer's release: `stream` has finished reading the gathered state of device `rank` up to this point of its order.
+ * The NEXT publish overwrites that buffer; its exchange waits for the release.  A consumer that reads asynchronously without
+ * releasing must synchronise before the next mjh_group_publish. */
+int mjh_group_release_publish(mjh_group*, int rank, void* stream /* NULL: the device's engine stream */);
 int mjh_group_state_stride(const mjh_group*);
 int mjh_group_uses_rccl(const mjh_group*);
-/* HIP events on device 0's stream around the exchange of every publish (the all-gather, or the peer copies): mean duration in
+/* HIP events on device 0's COMMUNICATION stream around the exchange of every publish (the all-gather, or the peer copies): mean duration in
  * milliseconds and the number of publishes since the last call */
 int mjh_group_set_publish_timing(mjh_group*, int on);
 int mjh_group_get_publish_timing(mjh_group*, double* mean_ms, int* count);

@@ -210,6 +210,8 @@ SYMBOLS = [
     ("mjh_set_pgs_row_order", None, [C.c_int]),
     ("mjh_set_cohorts", C.c_int, [_vp, C.c_int]),
     ("mjh_get_cohorts", C.c_int, [_vp]),
+    ("mjh_set_steps_per_launch", C.c_int, [_vp, C.c_int]),
+    ("mjh_get_steps_per_launch", C.c_int, [_vp]),
     ("mjh_set_launch_timing", C.c_int, [_vp, C.c_int]),
     ("mjh_get_launch_timing", C.c_int, [_vp, c_double_p, C.POINTER(C.c_int)]),
     ("mjh_group_create", C.c_int, [Model_p, C.c_int, c_int_p, C.c_int, C.POINTER(_vp)]),
@@ -231,6 +233,7 @@ SYMBOLS = [
     ("mjh_group_uses_rccl", C.c_int, [_vp]),
     ("mjh_group_set_transport", None, [C.c_int]),
     ("mjh_group_wait_publish", C.c_int, [_vp, C.c_int, _vp]),
+    ("mjh_group_release_publish", C.c_int, [_vp, C.c_int, _vp]),
     ("mjh_group_set_publish_timing", C.c_int, [_vp, C.c_int]),
     ("mjh_group_get_publish_timing", C.c_int, [_vp, c_double_p, C.POINTER(C.c_int)]),
     ("mjh_nenv", C.c_int, [_vp]),

@@ -54,7 +54,7 @@ struct mjh_engine {
   DState S{};
   Lay L{};
   int lds_bytes = 0;
-  size_t dense_lds = 0;   // dynamic LDS of mjh_dense_build_kernel
+  size_t dense_lds = 0, dense_solve_lds = 0;   // dynamic LDS of mjh_dense_build_kernel / mjh_dense_solve_kernel
   // dense solver on / off per cohort: mjh_order_kernel leaves "an env of the cohort swept long" in a host-mapped word (four slots per
   // cohort, one per rebuild of the launch order); the host adopts the word of TWO rebuilds ago after waiting for that kernel's event
   // (long finished: no stall, and the decision depends on the step count only, not on timing: runs stay reproducible)
@@ -69,7 +69,8 @@ struct mjh_engine {
   bool lpt = true;
   bool split3 = true;         // many-body layout: three-launch step (MJH_SPLIT3=0: fused kernel)
   bool order_valid = false;   // d_order holds a full-range permutation (split API); mjh_step sorts per cohort
-  long order_age = 0; int order_G = 0;   // mjh_step renews its per-cohort sorts every MJH_ORDER_EVERY-th step; order_G: cohort count they were made for (-1: none)
+  int steps_per_launch = 8;   // mjh_step(n): steps one launch of a loop-capable kernel instance runs (mjh_set_steps_per_launch; 1: one launch per step)
+  long order_age = 0; int order_G = 0; int last_chunk = 1;   // last_chunk: steps of the previous launch (the sort is renewed when a multiple of MJH_ORDER_EVERY was crossed)   // mjh_step renews its per-cohort sorts every MJH_ORDER_EVERY-th step; order_G: cohort count they were made for (-1: none)
   // Cohorts: mjh_step() splits the envs into ncohort contiguous groups, each stepped on its own stream, so that the
   // low-occupancy tail of one cohort's step kernel overlaps the next cohort's (or its own next step's) bulk.  The
   // caller's stream forks into the cohort streams at mjh_step and joins them again at the next other API call.
@@ -512,8 +513,14 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   if (e->M.dense) {
     // LDS of mjh_dense_build_kernel: 1 / D [nvs] | 1 / AR_qq [cap] | row table [cap] int4 | row starts [maxblk + 1]
     e->dense_lds = ((size_t)e->M.dense_nvs + 5 * (size_t)e->M.dense_cap + (size_t)std::max(e->M.maxblk, 1) + 8) * sizeof(float);
-    if (e->dense_lds > 160 * 1024) { e->M.dense = 0; }
-    else HIPCHK(hipFuncSetAttribute((const void*)mjh_dense_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->dense_lds));
+    // ... and of mjh_dense_solve_kernel: start values [cap] | 128 | the factor twice [2 nM] (a 128-dof chain: 67.6 KB, beyond the 64 KB a
+    // launch gets without the attribute)
+    e->dense_solve_lds = (DN_CAP_MAX + 128 + 2 * (size_t)e->M.nM) * sizeof(float);
+    if (e->dense_lds > 160 * 1024 || e->dense_solve_lds > 160 * 1024) { e->M.dense = 0; }
+    else {
+      HIPCHK(hipFuncSetAttribute((const void*)mjh_dense_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->dense_lds));
+      HIPCHK(hipFuncSetAttribute((const void*)mjh_dense_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->dense_solve_lds));
+    }
   }
   MJH_ATTR(1, true); MJH_ATTR(2, true); MJH_ATTR(4, true); MJH_ATTR(8, true); MJH_ATTR(1, false); MJH_ATTR(2, false); MJH_ATTR(4, false); MJH_ATTR(8, false);
 #undef MJH_ATTR
@@ -661,7 +668,7 @@ static int flush_step1(mjh_engine* e) {
 extern "C" int mjh_step1(mjh_engine* e) {
   ENG_NOJOIN(e); e->step1_done = true;
   if (e->pd_on) { int rc = join_cohorts(e); if (!rc) rc = launch_pd(e, e->stream, 0, e->nenv); if (rc) return rc; }
-  const bool lazy = !(getenv("MJH_LAZY_STEP1") && atoi(getenv("MJH_LAZY_STEP1")) == 0);
+  static const bool lazy = !(getenv("MJH_LAZY_STEP1") && atoi(getenv("MJH_LAZY_STEP1")) == 0);
   if (!lazy) return launch_lpt(e, PH_STEP1, XF_FORCE, true);
   e->step1_pending = true;
   return MJH_OK;
@@ -701,7 +708,12 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
   StateGuard guard(&e->S);
   if (e->lpt && e->d_order) e->S.env_order = e->d_order;
   if (e->pd_on && e->pd_target) { e->S.pd_target = e->pd_target; e->S.pd_kp = e->pd_kp; e->S.pd_kd = e->pd_kd; }   // the fused step evaluates the PD law itself
-  for (int s = 0; s < nsteps && !rc; s++, e->order_age++, e->order_G = G) {   // one launch per step and cohort (commands are consumed by the first one)
+  // In-kernel step loop (step_kernel.h): articulated models in the LDS-resident layout run up to steps_per_launch steps per launch and
+  // cohort, the env's state staying in LDS in between (commands are consumed by the first step of the call, the in-engine PD law runs
+  // every step); free-body models (contact-patch / window chain) and the many-body chain hand over between launches: one step each
+  const int chunk_max = (!e->M.big && !e->M.diagM) ? std::max(1, e->steps_per_launch) : 1;
+  for (int s = 0, k = 1; s < nsteps && !rc; s += k, e->order_age += k, e->order_G = G) {
+    k = std::min(nsteps - s, chunk_max);
     for (int g = 0; g < G && !rc; g++) {
       const int g0 = (int)((long long)e->nenv * g / G), g1 = (int)((long long)e->nenv * (g + 1) / G);
       hipStream_t st = G > 1 ? e->cstream[g] : e->stream;
@@ -709,7 +721,7 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
       // renewed every MJH_ORDER_EVERY-th step only: its 10 us sit in front of every step launch of the cohort's stream, which
       // is 9 % of a step of the small configs (C3, C5: 0.10 ms kernels)
       static const int order_every = getenv("MJH_ORDER_EVERY") ? std::max(1, atoi(getenv("MJH_ORDER_EVERY"))) : MJH_ORDER_EVERY;
-      if (e->S.env_order && (e->order_G != G || e->order_age % order_every == 0)) {
+      if (e->S.env_order && (e->order_G != G || e->order_age / order_every != (e->order_age - e->last_chunk) / order_every || e->order_age == 0)) {
         const bool dsel = e->M.big && e->split3 && e->M.dense && e->d_dense;
         const unsigned ep = e->dense_epoch[g];
         hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, st, (const int*)e->S.stats, e->d_order, g0, g1 - g0, dsel ? e->d_dense + 4 * g + (ep & 3) : (int*)nullptr, e->M.dense_min_iter);
@@ -736,7 +748,7 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
           // dense row-space solver (dense_pgs.h): AR = J M^-1 J^T on the matrix cores, then column sweeps, for every env of the
           // launch whose row count fits; the block solver below skips those envs (meta[7])
           hipLaunchKernelGGL(mjh_dense_build_kernel, dim3(g1 - g0), dim3(DN_BUILD_THREADS), e->dense_lds, st, e->dC, e->S, g0);
-          hipLaunchKernelGGL(mjh_dense_solve_kernel, dim3(g1 - g0), dim3(64), (DN_CAP_MAX + 128 + 2 * (size_t)e->M.nM) * sizeof(float), st, e->dC, e->S, g0);
+          hipLaunchKernelGGL(mjh_dense_solve_kernel, dim3(g1 - g0), dim3(64), e->dense_solve_lds, st, e->dC, e->S, g0);
           HIPCHK(hipGetLastError());
         }
         if (!rc) {
@@ -755,9 +767,10 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
           HIPCHK(hipGetLastError());
           rc = launch_on(e, st, g0, g1 - g0, 1, PH_STEP2 | PH_POST, 0);
         }
-      } else rc = launch_on(e, st, g0, g1 - g0, 1, ph, 0);
+      } else rc = launch_on(e, st, g0, g1 - g0, k, ph, 0);
       if (ta && !rc) HIPCHK(hipEventRecord(tb, st));
     }
+    e->last_chunk = k;
   }
   if (e->lpt && e->d_order && nsteps > 0 && !rc) e->order_valid = true;   // the per-cohort sorts tile a full permutation
   return rc;
@@ -788,8 +801,11 @@ extern "C" int mjh_set_timestep(mjh_engine* e, double dt) {
   return MJH_OK;
 }
 extern "C" double mjh_get_timestep(const mjh_engine* e) { return e ? e->M.timestep_d : 0.0; }
-extern "C" int mjh_set_cohorts(mjh_engine* e, int n) { ENG(e); return set_cohorts(e, n); }
+static int reset_dense_choice(mjh_engine* e);
+extern "C" int mjh_set_cohorts(mjh_engine* e, int n) { ENG(e); int rc = set_cohorts(e, n); return rc ? rc : reset_dense_choice(e); }
 extern "C" int mjh_get_cohorts(const mjh_engine* e) { return e ? e->ncohort : 0; }
+extern "C" int mjh_set_steps_per_launch(mjh_engine* e, int n) { ENG(e); e->steps_per_launch = std::max(1, std::min(n, 64)); return MJH_OK; }
+extern "C" int mjh_get_steps_per_launch(const mjh_engine* e) { return !e ? 0 : ((!e->M.big && !e->M.diagM) ? e->steps_per_launch : 1); }
 extern "C" int mjh_synchronize(mjh_engine* e) { ENG(e); HIPCHK(hipStreamSynchronize(e->stream)); return MJH_OK; }
 
 // ---- host <-> device marshalling helpers (double on the host side, padded fp32 rows on the device)
@@ -1183,9 +1199,20 @@ extern "C" int mjh_set_initial_qpos(mjh_engine* e, int env0, int n, const double
   return put_rows(e, e->S.initial_qpos, e->M.nqp, e->M.nq, env0, n, qpos);
 }
 
+// The per-cohort dense / block solver choice (the words mjh_order_kernel leaves in host-mapped memory, adopted two sorts later) is part of
+// what a run from reset reproduces: a full reset and a new cohort split start it over (dense for everyone, epoch 0, launch order renewed).
+// Drains the stream: the order kernels in flight still write the words.
+static int reset_dense_choice(mjh_engine* e) {
+  if (!e->h_dense) return MJH_OK;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (int g = 0; g < MJH_MAX_COHORTS * 4; g++) e->h_dense[g] = 1;
+  for (int g = 0; g < MJH_MAX_COHORTS; g++) { e->dense_now[g] = true; e->dense_epoch[g] = 0; }
+  e->order_age = 0; e->order_G = -1;
+  return MJH_OK;
+}
 extern "C" int mjh_reset(mjh_engine* e, const int* env_ids, int n) {
   ENG(e);
-  if (!env_ids) return launch(e, 0, e->nenv, 1, PH_RESET, 0);
+  if (!env_ids) { int rc = reset_dense_choice(e); return rc ? rc : launch(e, 0, e->nenv, 1, PH_RESET, 0); }
   for (int i = 0; i < n; i++) {
     if (env_ids[i] < 0 || env_ids[i] >= e->nenv) { mjh_set_error("mjh_reset: env id out of range"); return MJH_ERR_ARG; }
     int rc = launch(e, env_ids[i], 1, 1, PH_RESET, 0);
@@ -1404,7 +1431,8 @@ extern "C" int mjh_debug_stage_cycles(mjh_engine* e, int with_inverse, double* o
       rc = launch(e, 0, e->nenv, 1, ph | PH_PRE, (dn ? XF_DENSE : 0) | ((with_inverse & 2) ? XF_PROF : 0));
       if (!rc && dn) {
         hipLaunchKernelGGL(mjh_dense_build_kernel, dim3(e->nenv), dim3(DN_BUILD_THREADS), e->dense_lds, e->stream, e->dC, e->S, 0);
-        hipLaunchKernelGGL(mjh_dense_solve_kernel, dim3(e->nenv), dim3(64), (DN_CAP_MAX + 128 + 2 * (size_t)e->M.nM) * sizeof(float), e->stream, e->dC, e->S, 0);
+        hipLaunchKernelGGL(mjh_dense_solve_kernel, dim3(e->nenv), dim3(64), e->dense_solve_lds, e->stream, e->dC, e->S, 0);
+        HIPCHK(hipGetLastError());
       }
       if (!rc) {
         const size_t lds = (2 * (size_t)(((e->M.nv + 3) / 4) * 4) + 2 * (size_t)std::max(e->M.maxblk, 1) + 4 + 8 + 8 + 8 * (size_t)((e->M.nv + 2) / 3)) * sizeof(float);

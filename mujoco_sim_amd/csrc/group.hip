@@ -75,6 +75,8 @@ struct mjh_group {
   std::vector<hipEvent_t> gathered;                  // comm[k] has finished the last publish (exchange + compaction)
   std::vector<hipEvent_t> ready;                     // send buffer of device k packed (peer-copy transport)
   std::vector<hipEvent_t> consumed;                  // stream k has finished reading every rank's send buffer (peer-copy transport)
+  std::vector<hipEvent_t> released;                  // a consumer of device k's gathered buffer has finished reading it (mjh_group_release_publish)
+  std::vector<char> has_release;
   bool published = false;                            // consumed[] have been recorded at least once
   hipEvent_t t0 = nullptr, t1 = nullptr;             // device 0's stream around the exchange (mjh_group_publish_timing)
   bool timing = false, t_pending = false; double t_sum_ms = 0; int t_count = 0;
@@ -98,6 +100,7 @@ extern "C" void mjh_group_destroy(mjh_group* g) {
     if (k < (int)g->ready.size() && g->ready[k]) (void)hipEventDestroy(g->ready[k]);
     if (k < (int)g->consumed.size() && g->consumed[k]) (void)hipEventDestroy(g->consumed[k]);
     if (k < (int)g->gathered.size() && g->gathered[k]) (void)hipEventDestroy(g->gathered[k]);
+    if (k < (int)g->released.size() && g->released[k]) (void)hipEventDestroy(g->released[k]);
     if (k < (int)g->comm.size() && g->comm[k]) (void)hipStreamDestroy(g->comm[k]);
     if (k < (int)g->stream.size() && g->stream[k]) (void)hipStreamDestroy(g->stream[k]);
   }
@@ -114,7 +117,7 @@ extern "C" int mjh_group_create(const mjh_model* model, int nenv_total, const in
   mjh_group* g = new mjh_group();
   g->model = model; g->nenv = nenv_total; g->ndev = ndev;
   g->dev.resize(ndev); g->env0.resize(ndev); g->n.resize(ndev);
-  g->eng.assign(ndev, nullptr); g->stream.assign(ndev, nullptr); g->ready.assign(ndev, nullptr); g->consumed.assign(ndev, nullptr); g->comm.assign(ndev, nullptr); g->gathered.assign(ndev, nullptr);
+  g->eng.assign(ndev, nullptr); g->stream.assign(ndev, nullptr); g->ready.assign(ndev, nullptr); g->consumed.assign(ndev, nullptr); g->comm.assign(ndev, nullptr); g->gathered.assign(ndev, nullptr); g->released.assign(ndev, nullptr); g->has_release.assign(ndev, 0);
   g->send.assign(ndev, nullptr); g->recv.assign(ndev, nullptr); g->packed.assign(ndev, nullptr);
   bool distinct = true;
   for (int k = 0; k < ndev; k++) {
@@ -133,6 +136,7 @@ extern "C" int mjh_group_create(const mjh_model* model, int nenv_total, const in
     GFAIL(hipEventCreateWithFlags(&g->ready[k], hipEventDisableTiming));
     GFAIL(hipEventCreateWithFlags(&g->consumed[k], hipEventDisableTiming));
     GFAIL(hipEventCreateWithFlags(&g->gathered[k], hipEventDisableTiming));
+    GFAIL(hipEventCreateWithFlags(&g->released[k], hipEventDisableTiming));
     GFAIL(hipStreamCreateWithFlags(&g->comm[k], hipStreamNonBlocking));
     const int rc = mjh_create(model, g->n[k], g->dev[k], g->stream[k], &g->eng[k]);
     if (rc) { mjh_group_destroy(g); return rc; }
@@ -228,6 +232,9 @@ extern "C" int mjh_group_publish(mjh_group* g, float* host_out) {
     if (rc) return rc;
     GCHK(hipEventRecord(g->ready[k], g->stream[k]));
     GCHK(hipStreamWaitEvent(g->comm[k], g->ready[k], 0));
+    // a consumer that is still reading the previous gathered state of this device (mjh_group_release_publish): the exchange below
+    // overwrites that buffer
+    if (g->has_release[k]) { GCHK(hipStreamWaitEvent(g->comm[k], g->released[k], 0)); g->has_release[k] = 0; }
   }
   if (g->timing) { GCHK(hipSetDevice(g->dev[0])); GCHK(hipEventRecord(g->t0, g->comm[0])); }
   if (g->rccl) {
@@ -283,6 +290,16 @@ extern "C" int mjh_group_wait_publish(mjh_group* g, int rank, void* stream) {
   if (!g->published) return MJH_OK;
   GCHK(hipSetDevice(g->dev[rank]));
   GCHK(hipStreamWaitEvent(stream ? (hipStream_t)stream : g->stream[rank], g->gathered[rank], 0));
+  return MJH_OK;
+}
+// the consumer's side of the hand-over: `stream` (a stream of device `rank`) has read the gathered state up to this point of its order;
+// the next publish's exchange on that device waits for it before it overwrites the buffer.  A consumer that reads asynchronously and
+// does not call this must finish (synchronise) before the next mjh_group_publish.
+extern "C" int mjh_group_release_publish(mjh_group* g, int rank, void* stream) {
+  if (!g || rank < 0 || rank >= g->ndev) { mjh_set_error("mjh_group_release_publish: bad rank"); return MJH_ERR_ARG; }
+  GCHK(hipSetDevice(g->dev[rank]));
+  GCHK(hipEventRecord(g->released[rank], stream ? (hipStream_t)stream : g->stream[rank]));
+  g->has_release[rank] = 1;
   return MJH_OK;
 }
 // HIP events on device 0's communication stream around the exchange (all-gather or peer copies) of every publish: the collective's own time

@@ -900,7 +900,10 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
 
 template <int NROW, bool DIAGM, bool EXTRA>
 #ifndef MJH_STEP_WAVES
-#define MJH_STEP_WAVES 2      // resident waves per SIMD the register allocation aims at (A/B builds: -DMJH_STEP_WAVES=3 with -DPP_NRC=0)
+// resident waves per SIMD the register allocation aims at: two for the instances that keep sweep records in registers (free-body
+// patch sweep) or long dense stages (many-body chain), three for the small articulated models (C3, C5: latency-bound, every extra
+// resident wave counts) (A/B builds: -DMJH_STEP_WAVES=3 with -DPP_NRC=0)
+#define MJH_STEP_WAVES ((!DIAGM && NROW <= 4) ? 3 : 2)
 #endif
 __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DConst* __restrict__ C, const DState S, int env0, int nsteps, int ph, int xflags) {
   // model descriptor + LDS layout live in device memory (uploaded once): uniform scalar loads on demand instead
@@ -1002,11 +1005,24 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
   WSYNC();
   PROF(1);
 
-  // one step per launch: an in-kernel step loop would keep every table pointer live across the whole body
-  // (loop-carried), which is what used to spill ~1 KB/lane to scratch; mjh_step(n) issues n launches instead
-  (void)nsteps;
+  // In-kernel step loop (SURVEY §7.3 "one launch per n steps"): the env's state stays in LDS between the steps of a launch — qpos, qvel,
+  // the warm start and last step's qacc are exactly what the end of a step leaves there, the per-launch tables above are in spans no
+  // stage aliases (engine.hip: LDS layout; the patch pool and the many-body / window chains alias or leave the kernel: nsteps = 1 there,
+  // the host's rule) — commands are consumed by the first step, the in-engine PD law is evaluated every step.  Bitwise equal to nsteps
+  // launches of one step (tests/test_gpu_round4.py).
+  // Register discipline: what the body derives from the lane index (an LDS address per array, the lane predicates of every stage —
+  // cheap arithmetic) is loop-invariant, and hoisted in front of the loop it stays live around the whole body: 256 VGPRs + 244 B of
+  // scratch per lane when tried (C5 -21 %).  So every iteration takes the lane index through an opaque move: nothing derived from it
+  // can leave the loop, live ranges are those of a one-step launch (168 VGPRs, three waves per SIMD).  Instances whose launches always
+  // run one step (free-body patch / window models, the many-body chain) compile the loop away.
+  constexpr bool LOOP = !DIAGM && NROW <= 4;
+  int step = 0;
+step_again:      // (a backward goto instead of a `for`: the instances without the loop keep the straight-line body they were tuned with)
   {
-    const int step = 0;
+    int lane_it = (int)threadIdx.x;
+    if constexpr (LOOP) asm volatile("" : "+v"(lane_it));
+    const int lane = lane_it;
+    cost_hint = 0;
     // ---- bad-state check (mj_checkPos / mj_checkVel): reset this env
     {
       bool badv = false;
@@ -2218,7 +2234,7 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
       for (int d = lane; d < nv; d += 64) {
         if (controlled[d]) s_applied[d] += s_bias[d];            // :1058-1063
         if (fabsf(s_tmpv2[d]) > MJ_MINVAL) s_qvel[d] = s_tmpv2[d];  // :1067-1073 velocity override
-        if (step == 0 && (anydd || anydq)) { S.ddq[vrow + d] = 0; S.dq[vrow + d] = 0; }  // :1075-1076
+        if ((step == 0 || S.pd_target) && (anydd || anydq)) { S.ddq[vrow + d] = 0; S.dq[vrow + d] = 0; }  // :1075-1076 (later steps of a launch: only the PD law has written a command)
       }
       WSYNC();
       if ((ph & PH_INV) && anydq) { vel_stage(s_qvel); for (int d = lane; d < nv; d += 64) s_qvref[d] = s_qvel[d]; WSYNC(); }
@@ -2972,7 +2988,8 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
         WSYNC();
       }
     }
-  }  // steps
+  }  // one step
+  if constexpr (LOOP) { if (++step < nsteps) goto step_again; }
 
   PROF(14);
   if ((ph & (PH_FKONLY | PH_MULM)) || (xflags & XF_NOSTORE)) return;

@@ -142,6 +142,9 @@ class Engine:
     def set_cohorts(self, n): _chk(self.lib, self.lib.mjh_set_cohorts(self.h, int(n)), "mjh_set_cohorts")
     @property
     def cohorts(self): return self.lib.mjh_get_cohorts(self.h)
+    def set_steps_per_launch(self, n): _chk(self.lib, self.lib.mjh_set_steps_per_launch(self.h, int(n)), "mjh_set_steps_per_launch")
+    @property
+    def steps_per_launch(self): return self.lib.mjh_get_steps_per_launch(self.h)
     def set_launch_timing(self, on=True): _chk(self.lib, self.lib.mjh_set_launch_timing(self.h, int(on)), "mjh_set_launch_timing")   # N > 1: every N-th launch
     def get_launch_timing(self):
         """-> (mean step-kernel duration [ms], launches) since the last call"""
@@ -382,6 +385,13 @@ class Group:
     def publish_device(self):
         """pack + all-gather without the host copy (the gathered state stays on every device: mjh_group_state_device)"""
         _chk(self.lib, self.lib.mjh_group_publish(self.h, None), "mjh_group_publish")
+
+    def wait_publish(self, rank, stream=None):
+        _chk(self.lib, self.lib.mjh_group_wait_publish(self.h, int(rank), C.c_void_p(stream or 0)), "mjh_group_wait_publish")
+
+    def release_publish(self, rank, stream=None):
+        """the consumer on `stream` is done reading device `rank`'s gathered state: the next publish may overwrite it"""
+        _chk(self.lib, self.lib.mjh_group_release_publish(self.h, int(rank), C.c_void_p(stream or 0)), "mjh_group_release_publish")
 
     def set_publish_timing(self, on=True): _chk(self.lib, self.lib.mjh_group_set_publish_timing(self.h, int(on)), "mjh_group_set_publish_timing")
     def get_publish_timing(self):

@@ -147,6 +147,10 @@ def check_contacts(box1, box2, margin, dist, pos, n, tol=1e-9, count_tol=None):
         bad.append("normal points from box 2 to box 1")
     cosang = A @ n
     c = int(np.argmax(np.abs(cosang)))
+    # (an edge cross product can coincide with a face normal — boxes sharing an axis: among equally close candidates the face kind counts)
+    dvec = np.linalg.norm(A * np.sign(cosang)[:, None] - n, axis=1)
+    near = np.nonzero(dvec <= dvec.min() + max(1e-12, 0.01 * tol))[0]
+    c = int(near[np.argmin(kind[near])])
     if 1 - abs(cosang[c]) > max(1e-10, 100 * tol * tol) and np.linalg.norm(A[c] * np.sign(cosang[c]) - n) > 10 * tol:
         bad.append(f"normal is none of the 15 axis candidates (closest: kind {kind[c]}, |cos| = {abs(cosang[c]):.9f})")
         return bad

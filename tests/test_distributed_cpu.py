@@ -45,6 +45,22 @@ for total in (10, 7):                       # even and uneven shares
     ok &= bool(np.array_equal(full[:, 0], (0.005 * (np.arange(total) + 1)).astype(np.float32)))
     ok &= bool(np.array_equal(full[:, 1:1 + nq], ref))                             # env order across the ranks, row by row
     ok &= bool(np.array_equal(full[:, 1 + nq:], (np.arange(total)[:, None] * 100 + np.arange(nv)[None, :]).astype(np.float32)))
+# C5 — the reference's multi-GPU config (launch/multi_mujoco_sim.launch:9-34) — at uneven shares: the fixture's sizes, per-env spin
+# drawn per GLOBAL env id (what tests/test_gpu_round4.py's eight-shard run and bench.py --host group hand to the shards)
+import os
+from mujoco_sim_amd.tables import load_model_tables
+m5, z5 = load_model_tables(os.path.join(sys.argv[1], "tests", "golden", "robot_c5_pendulum_bowl_mesh.npz"))
+nq5, nv5 = m5.nq, m5.nv
+for total in (9, 4096 + 3):
+    lo, hi = shard.env_range(total, world, rank)
+    spin_all = (z5["qvel0"][None, :] * np.random.default_rng(0xC5).uniform(0.5, 1.5, size=(total, 1))).astype(np.float32)
+    q0 = np.tile(m5.array("qpos0"), (total, 1)).astype(np.float32)
+    q0[:, 0] += np.arange(total, dtype=np.float32) * 1e-3
+    tt = (0.005 * np.arange(total)).astype(np.float32)
+    local = np.concatenate([tt[lo:hi, None], q0[lo:hi], spin_all[lo:hi]], axis=1)
+    full = shard.gather_state(torch.from_numpy(np.ascontiguousarray(local)), total, world, rank).numpy()
+    ok &= full.shape == (total, 1 + nq5 + nv5)
+    ok &= bool(np.array_equal(full, np.concatenate([tt[:, None], q0, spin_all], axis=1)))
 tmax = shard.max_over_ranks(float(rank + 1))
 print("RESULT", rank, int(ok), tmax)
 dist.destroy_process_group()

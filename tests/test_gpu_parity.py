@@ -66,6 +66,13 @@ def test_s24_stage_parity_after_forward(s24):
             assert [tuple(g) for g in c["geom"]] == [x["geom"] for x in oc]
 
 
+# floors of the free-running tests = what the MI355X measures (r04: printed by the tests below), so that a regression that forks one more
+# environment fails (the budgets used to be 10 of 16 and 3 of 6)
+# measured r04c (row order, window sweep): 16 / 16 / 16 of 16 envs keep the oracle's contact-set history over 1 / 60 / 150 steps (errors 8.5e-8 /
+# 7.2e-6 / 9.3e-6), the golden fixture's 6 of 6 at every mark; one env of slack
+FORK_FLOOR_60, FORK_FLOOR_150, FORK_FLOOR_GOLDEN = 15, 15, 5
+
+
 def _free_run(e, ds, nsteps):
     """free-running device and oracle, one step at a time -> per step: qpos error per env, and whether the env's contact-set
     HISTORY still agrees (same ncon and nefc in every step so far).  A contact that appears one step earlier or later in fp32
@@ -90,10 +97,16 @@ def test_s24_trajectory_parity(s24):
     _, q, v, _ = e.get_state()
     print("S24 free run: agreeing envs after 1/60/150 steps", hist[0].sum(), hist[59].sum(), hist[149].sum(),
           "max err of agreeing envs", err[0][hist[0]].max(), err[59][hist[59]].max(), err[149][hist[149]].max() if hist[149].any() else None)
-    # measured (r03b): 16 / 16 / 14 of 16 envs keep the oracle's contact-set history over 1 / 60 / 150 steps; their errors 1.1e-7 / 4.3e-6 / 2.2e-5
     assert hist[0].all() and err[0].max() <= 1e-5
-    assert err[59][hist[59]].max() < 1e-4 and hist[59].sum() >= 14
-    assert hist[149].sum() >= 10 and err[149][hist[149]].max() < 5e-4
+    assert err[59][hist[59]].max() < 1e-4 and hist[59].sum() >= FORK_FLOOR_60
+    assert hist[149].sum() >= FORK_FLOOR_150 and err[149][hist[149]].max() < 5e-4
+    # the envs that forked are not let go: they stay inside the pen and finite (a fork moves a box by centimetres, a defect by metres) ...
+    assert np.isfinite(err).all() and err.max() < 0.5, err.max(axis=0)
+    # ... and a fork starts as ONE manifold changing by a point or two (a contact crossing its margin a step early, a clipped vertex
+    # appearing), not as a different contact set
+    for i in np.nonzero(~hist[149])[0]:
+        k = int(np.argmin(hist[:, i]))
+        assert err[max(k - 1, 0), i] < 5e-4, (i, k, err[max(k - 1, 0), i])
     st = e.get_stats()
     assert (st[:, 3] == 0).all() and all(d.i("warn") == 0 for d in ds)
 
@@ -118,8 +131,10 @@ def test_s24_against_golden_fixture():
             t, q, v, _ = e.get_state()
             ref = np.array([g[f"env{i}_step{k}_qpos"] for i in range(6)])
             err = np.abs(q - ref).max(axis=1)
-            assert same.sum() >= (6 if k <= 10 else 3), (k, same)
+            print("S24 golden: mark", k, "agreeing envs", int(same.sum()), "max err of agreeing", err[same].max() if same.any() else None, "max err of all", err.max())
+            assert same.sum() >= (6 if k <= 10 else FORK_FLOOR_GOLDEN), (k, same)
             assert (err[same] < marks[k]).all(), (k, err, same)
+            assert np.isfinite(err).all() and err.max() < 0.5, (k, err)          # (forked envs: still a pile in the pen)
             np.testing.assert_allclose(t, k * 0.005, rtol=1e-5)
     e.close()
 

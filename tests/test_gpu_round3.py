@@ -175,16 +175,16 @@ def test_c2_at_4096_envs_one_step_parity_on_sampled_envs():
         for k, wh in EP.items():
             d.set_env_param(wh, tab[k][i])
         return d
-    sample = [5, 1300, 2700, 4090]
+    sample = [5 + 273 * k for k in range(15)] + [4090]        # 16 envs spread over the batch (VERDICT r03 #6b: was 4)
     worst_q = worst_v = 0.0; agreeing = total = 0
-    for rep in range(3):
+    for rep in range(2):
         eq, ev, ag, ds = _one_step_on_samples(e, make, sample)
         if ag.any():
             worst_q = max(worst_q, eq[ag].max()); worst_v = max(worst_v, ev[ag].max())
         agreeing += int(ag.sum()); total += len(ag)
         e.step(5)
     print(f"C2 4096 envs, {total} sampled env-steps at ~{ds[0].i('ncon')} contacts: contact sets agree {agreeing / total:.3f}, qpos {worst_q:.2e}, qvel {worst_v:.2e}")
-    assert agreeing >= total - 2 and worst_q <= 1e-6 and worst_v <= 1e-5
+    assert agreeing / total >= 0.9 and worst_q <= 1e-6 and worst_v <= 1e-5
     e.close()
 
 
@@ -216,10 +216,12 @@ def test_c4_at_2048_envs_one_step_parity_on_sampled_envs():
         d = orc.OrcData(m.ptr); d.ifield("controlled")[:] = z["controlled"]
         orc.lib().orc_set_slot_mask(d.d, mask)
         return d
-    sample = [0, 700, 1400, 2047]
+    sample = [66 * k for k in range(31)] + [2047]            # 32 envs spread over the batch (VERDICT r03 #6b: was 4, three of which had to agree)
     eq, ev, ag, ds = _one_step_on_samples(e, make, sample, with_inverse=True)
-    print(f"C4 2048 envs, sampled: nefc {[d.i('nefc') for d in ds]}, contact sets agree {ag}, qpos {eq}, qvel {ev}")
-    assert ag.sum() >= 3 and eq[ag].max() <= 2e-6 and ev[ag].max() <= 1e-4
+    print(f"C4 2048 envs, {len(sample)} sampled: nefc {min(d.i('nefc') for d in ds)}..{max(d.i('nefc') for d in ds)}, contact sets agree {ag.mean():.3f}, qpos {eq[ag].max():.2e}, qvel {ev[ag].max():.2e}; "
+          f"not agreeing: qpos {eq[~ag].max() if (~ag).any() else 0:.2e}")
+    assert ag.mean() >= 0.9 and eq[ag].max() <= 2e-6 and ev[ag].max() <= 1e-4
+    assert eq.max() < 1e-3                                     # (an env whose contact set differs by a point is still the same robot pose)
     e.close()
 
 
