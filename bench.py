@@ -735,7 +735,7 @@ def main():
         other = {"value": total_envs * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3, "kernel_ms": k2}
 
     # committed rocprofv3 PMC measurement of this config (profiles/), per launch: provenance stated, never re-measured here
-    traffic = traffic_src = valu_busy = None
+    traffic = traffic_src = valu_busy = valu_frac = valu_lanes = valu_instr = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
@@ -744,6 +744,9 @@ def main():
             if tj and tj.get("bytes_per_launch") and tj.get("envs_per_launch"):
                 traffic = tj["bytes_per_launch"] * envs_per_launch / tj["envs_per_launch"]
                 valu_busy = tj.get("valu_issue_busy")
+                valu_instr = tj.get("valu_instr_per_env_step"); valu_lanes = tj.get("valu_lane_util")
+                if valu_instr:      # wave-instructions per second at THIS run's rate, of the chip's 1024 SIMDs x one VALU instruction per 4 clocks at 2.4 GHz
+                    valu_frac = valu_instr * (value / world) / (1024 * 2.4e9 / 4)
                 traffic_src = f"profiles/{tj.get('tag', '?')} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this config, scaled to this run's envs per launch; not measured in this run)"
         except Exception:
             traffic = None
@@ -768,15 +771,20 @@ def main():
                    "timed_window_ms": elapsed * 1e3, **w.extra_config()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "mjh_step_kernel" + ((" (+ mjh_dense_build_kernel [MFMA] + mjh_dense_solve_kernel: assemble -> build -> solve -> integrate chain of the many-body layout)" if eng.dense_solver() else
+                     "kernel": ("mjh_step_kernel (assemble: position / velocity stages, collision, constraint rows) + mjh_window_kernel (PGS sweeps in mj_solPGS row order, four "
+                                "envs per wavefront, rows in registers; mj_Euler): the two-launch chain of one cohort's step, timed as one" if eng.window_solver() else "mjh_step_kernel") + ((" (+ mjh_dense_build_kernel [MFMA] + mjh_dense_solve_kernel: assemble -> build -> solve -> integrate chain of the many-body layout)" if eng.dense_solver() else
                                                      " (+ mjh_solve_kernel: three-launch step of the many-body layout)") if eng.lds_bytes > 24 * 1024 or model.nv > 64 else ""),
                      "kernel_ms": kernel_ms, "launches": n_launches, "launches_timed": n_timed, "envs_per_launch": envs_per_launch, "concurrent_launches": cohorts,
                      # `achieved` / `frac` are per launch (one cohort's step), as the contract defines them; the cohorts' launches overlap, so the
                      # chip as a whole moves the algorithmic bytes of ALL envs per step period:
                      "achieved_whole_chip": bytes_step * nenv / (elapsed / args.steps) / 1e9, "frac_whole_chip": bytes_step * nenv / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_env_step": bytes_step,
-                     "valu_issue_busy": valu_busy, "valu_issue_busy_source": traffic_src,
-                     "note": "fused per-env pipeline keeps intermediates in LDS: the path is issue/latency bound, far below the HBM roofline by design (DESIGN.md §4, §5)"},
+                     # the second fraction (say which binds): VALU issue — committed SQ-counter passes of this config x this run's rate
+                     "valu_issue_frac": valu_frac, "valu_lane_util": valu_lanes, "valu_instr_per_env_step": valu_instr,
+                     "valu_source": traffic_src.replace("FETCH_SIZE / WRITE_SIZE", "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_THREAD_CYCLES_VALU") if (traffic_src and valu_instr) else None,
+                     "binds": "VALU issue of the resident waves (valu_issue_frac), not HBM (frac)" if valu_frac else None,
+                     "timed_window_note": f"{args.steps} steps = {elapsed * 1e3:.1f} ms; kernel_ms is the mean of {n_timed} event-timed launches in it",
+                     "note": "fused per-env pipeline keeps intermediates in LDS / registers: the path is issue/latency bound, far below the HBM roofline by design (DESIGN.md §4, §5)"},
     }
     if other is not None:
         out[key_inv if not main_inverse else key_no] = other["value"]

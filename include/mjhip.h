@@ -423,6 +423,10 @@ int mjh_debug_stage_cycles(mjh_engine*, int with_inverse, double* out16);
 /* debug: raw stamps of one step launch, out[nenv*20] indexed by launch position: [0..15] shader-clock stage stamps,
  * [16],[17] 100 MHz wall clock at start/end, [18] HW_ID | XCC_ID<<32, [19] env id (tools/timeline.py) */
 int mjh_debug_stage_raw(mjh_engine*, int with_inverse, long long* out);
+/* debug: the solve launch of a free-body model's many-body chain (C2) timed on the pools of the last step — out_ms[0] as it is,
+ * out_ms[1] with every wave reading the block operands of one of `slices` environments (an L2-resident working set): what the
+ * operand stream from MALL / HBM costs the sweeps.  out_iter[2]: mean sweeps of the two runs. */
+int mjh_debug_solve_probe(mjh_engine*, int slices, int reps, double* out_ms, double* out_iter);
 /* debug: one step launch that returns at stage boundary `stage` (1..14) and stores nothing (tools/stage_valu.sh:
  * per-stage hardware-counter differences) */
 int mjh_debug_stop_at(mjh_engine*, int stage, int with_inverse);

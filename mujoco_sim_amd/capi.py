@@ -201,6 +201,7 @@ SYMBOLS = [
     ("mjh_mirror_time", c_double_p, [_vp]),
     ("mjh_debug_stage_cycles", C.c_int, [_vp, C.c_int, c_double_p]),
     ("mjh_debug_stage_raw", C.c_int, [_vp, C.c_int, _vp]),
+    ("mjh_debug_solve_probe", C.c_int, [_vp, C.c_int, C.c_int, c_double_p, c_double_p]),
     ("mjh_debug_stop_at", C.c_int, [_vp, C.c_int, C.c_int]),
     ("mjh_set_timestep", C.c_int, [_vp, C.c_double]),
     ("mjh_get_timestep", C.c_double, [_vp]),

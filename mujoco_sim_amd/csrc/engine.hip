@@ -1453,6 +1453,34 @@ extern "C" int mjh_debug_stage_cycles(mjh_engine* e, int with_inverse, double* o
   return MJH_OK;
 }
 
+// Debug: the solve launch of the many-body chain (free-body models: C2) on the pools the last step left, timed with HIP events —
+// once as it is, once with every wave reading the block operands of one of `slices` environments (a working set that stays in L2):
+// the difference is what the operand stream from MALL / HBM costs.  out_ms[2], out_iter[2] (mean sweeps).  The probe's results are
+// garbage: the next step rebuilds the pools; state, clock and warm start are not touched (the launches write qacc only into the
+// chain's hand-over slice).
+extern "C" int mjh_debug_solve_probe(mjh_engine* e, int slices, int reps, double* out_ms, double* out_iter) {
+  ENG(e);
+  if (!(e->M.big && e->split3 && e->M.diagM)) { mjh_set_error("mjh_debug_solve_probe: free-body model in the many-body layout only"); return MJH_ERR_ARG; }
+  hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+  const size_t lds = (2 * (size_t)(((e->M.nv + 3) / 4) * 4) + 2 * (size_t)std::max(e->M.maxblk, 1) + 4 + 8 + 8 + 8 * (size_t)((e->M.nv + 2) / 3)) * sizeof(float);
+  std::vector<float> meta((size_t)e->nenv);
+  for (int mode = 0; mode < 2; mode++) {
+    StateGuard guard(&e->S);
+    e->S.probe_slices = mode ? std::max(1, slices) : 0; e->S.env_order = nullptr;
+    HIPCHK(hipEventRecord(a, e->stream));
+    for (int r = 0; r < std::max(1, reps); r++) hipLaunchKernelGGL((mjh_solve_kernel<true, false>), dim3(e->nenv), dim3(64), lds, e->stream, e->dC, e->S, 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(b, e->stream)); HIPCHK(hipEventSynchronize(b));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b)); out_ms[mode] = ms / std::max(1, reps);
+    double it = 0;
+    HIPCHK(hipMemcpy2D(meta.data(), sizeof(float), e->S.gscratch + e->L.g_meta + 5, (size_t)e->S.gstride * sizeof(float), sizeof(float), (size_t)e->nenv, hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->nenv; i++) { int v; std::memcpy(&v, &meta[i], 4); it += v; }
+    out_iter[mode] = it / e->nenv;
+  }
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  return MJH_OK;
+}
+
 // raw per-env stamps of one LPT-ordered step launch (debug timeline tool): out[nenv*PROF_STRIDE]
 extern "C" int mjh_debug_stage_raw(mjh_engine* e, int with_inverse, long long* out) {
   ENG(e);

@@ -3089,7 +3089,9 @@ DEV void mjh_solve_body(const DConst* __restrict__ C, const DState& S, int env0)
   mc.nwave = nthr >> 6; mc.wid = tid >> 6; mc.red = s_red;
   mc.a4 = quad16 ? s_a4 : nullptr; mc.m4 = quad16 ? s_m4 : nullptr;
   {
-    const unsigned long long ga = (unsigned long long)gs;
+    // (debug probe: the operand stream of a few envs' slices — resident in L2 — instead of every env's own: what the sweeps cost without the
+    //  stream from MALL / HBM; the results are garbage and only timed)
+    const unsigned long long ga = (unsigned long long)(S.probe_slices > 0 ? S.gscratch + (size_t)(env0 + (int)(blockIdx.x % (unsigned)S.probe_slices)) * (size_t)S.gstride : gs);
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ga), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ga >> 32));
     const long long nb = S.gstride * 4;
     mc.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)(nb > 0x7ffffff0ll ? 0x7ffffff0ll : nb), 0x00020000);

@@ -120,6 +120,19 @@ if sq:
             lines += ["", "; ".join(d)]
         lines.append("")
     json.dump(sqsum, open(os.path.join(dst, f"{tag}_{cfg}_sq.json"), "w"), indent=1)
+    # whole step launch: VALU wave-instructions per env-step and the fraction of lanes live in them, into the traffic record (bench.py
+    # turns the first into an issue fraction with the rate IT measures: x env-steps/s / (1024 SIMDs x 2.4 GHz / 4 clocks))
+    vi = sum(m.get("SQ_INSTS_VALU", 0.0) for m in sqsum.values()); va = sum(m.get("SQ_ACTIVE_INST_VALU", 0.0) for m in sqsum.values())
+    vt = sum(m.get("SQ_THREAD_CYCLES_VALU", 0.0) for m in sqsum.values())
+    tp = os.path.join(dst, f"{tag}_{cfg}_traffic.json")
+    if vi > 0 and os.path.exists(tp):
+        tj = json.load(open(tp))
+        steps_per_launch = (bench or {}).get("config", {}).get("steps_per_launch", 1) or 1
+        tj["valu_instr_per_env_step"] = vi / envs_per_launch / steps_per_launch
+        tj["valu_lane_util"] = (vt / va / 64.0) if va > 0 and vt > 0 else None
+        tj["valu_note"] = "rocprofv3 --pmc SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_THREAD_CYCLES_VALU, own passes, summed over the kernels of one step launch"
+        json.dump(tj, open(tp, "w"), indent=1)
+        lines += [f"Whole step launch: **{tj['valu_instr_per_env_step']:.0f} VALU wave-instructions per env-step**, active lanes per VALU instruction **{(tj['valu_lane_util'] or 0):.3f}**", ""]
 if bench:
     json.dump(bench, open(os.path.join(dst, f"{tag}_{cfg}_bench.json"), "w"))
     lines += ["## bench.py line of the traced run", "", "```", json.dumps(bench), "```", ""]
