@@ -126,7 +126,7 @@ class S24(Workload):
 
 
 class S24D(S24):
-    cohorts = 0
+    cohorts = 3       # 4.20 / 4.37 M env-steps/s on 2 / 3 cohorts (tools/r04_final_s24.sh)
     """the "30-contact" reading of the metric's name: S24's pen and S24's four boxes (same per-env sizes, masses, seeds), but released
     flat and side by side (2 x 2, random yaw) instead of as a staggered column of random orientations: the boxes land on the floor
     together (16 floor contacts of condim 4) and are wedged against each other and the walls — ~30 contacts, ~130 rows per env, what
@@ -532,7 +532,7 @@ def short_config_line(ms, args, name, device, stream):
         steps = args.extra_steps
 
         def window(n):
-            eng.set_launch_timing(1)
+            eng.set_launch_timing(max(1, args.timing_stride))      # (a sample: an event pair on every launch slows launch-bound configs down)
             t0 = time.perf_counter(); run(n); eng.synchronize(); el_ = time.perf_counter() - t0
             k_, n_ = eng.get_launch_timing(); eng.set_launch_timing(False)
             return el_, k_, n_

@@ -58,6 +58,7 @@ struct mjh_engine {
   // dense solver on / off per cohort: mjh_order_kernel leaves "an env of the cohort swept long" in a host-mapped word (four slots per
   // cohort, one per rebuild of the launch order); the host adopts the word of TWO rebuilds ago after waiting for that kernel's event
   // (long finished: no stall, and the decision depends on the step count only, not on timing: runs stay reproducible)
+  int* h_wn = nullptr; int* d_wn = nullptr; int cur_cohort = -1;   // window models: largest row count per cohort (host-mapped, written by mjh_order_kernel); cohort of the launch being issued
   int* h_dense = nullptr; int* d_dense = nullptr; hipEvent_t ev_dense[MJH_MAX_COHORTS][4] = {}; unsigned dense_epoch[MJH_MAX_COHORTS] = {}; bool dense_now[MJH_MAX_COHORTS];
   int* dI = nullptr; float* dF = nullptr; DConst* dC = nullptr;
   std::vector<int> hI;  // host copy of the int tables (controlled / odom are patched in place)
@@ -119,6 +120,15 @@ static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps,
 #define MJH_LAUNCH2(NR, DG, CX) hipLaunchKernelGGL((mjh_step_kernel<NR, DG, CX>), dim3(n), dim3(64), (size_t)e->lds_bytes, st, e->dC, e->S, env0, nsteps, ph, xflags)
 #define MJH_LAUNCH(NR, DG) do { if (extra_instance(e->M) || e->S.xfrc_applied) MJH_LAUNCH2(NR, DG, true); else MJH_LAUNCH2(NR, DG, false); } while (0)
   const int nr = e->M.big ? 8 : (e->M.nv <= 16 ? 1 : (e->M.nv <= 32 ? 2 : 4));   // 8: many-body layout, running acceleration in LDS
+  static const bool slim = !(getenv("MJH_WINDOW_SLIM") && atoi(getenv("MJH_WINDOW_SLIM")) == 0);
+  if (window && slim) {
+    // the assemble-only instance (WPRE): the step kernel without any sweep of its own — 128 VGPRs instead of 236, so that its waves
+    // fit beside the window kernel's on a SIMD
+    const bool cx = extra_instance(e->M) || e->S.xfrc_applied;
+#define MJH_LAUNCHW(NR, CX) hipLaunchKernelGGL((mjh_step_kernel<NR, true, CX, true>), dim3(n), dim3(64), (size_t)e->lds_bytes, st, e->dC, e->S, env0, nsteps, ph, xflags)
+    if (nr == 1) { if (cx) MJH_LAUNCHW(1, true); else MJH_LAUNCHW(1, false); } else { if (cx) MJH_LAUNCHW(2, true); else MJH_LAUNCHW(2, false); }
+#undef MJH_LAUNCHW
+  } else
   if (e->M.diagM) { if (nr == 1) MJH_LAUNCH(1, true); else if (nr == 2) MJH_LAUNCH(2, true); else if (nr == 4) MJH_LAUNCH(4, true); else MJH_LAUNCH(8, true); }
   else { if (nr == 1) MJH_LAUNCH(1, false); else if (nr == 2) MJH_LAUNCH(2, false); else if (nr == 4) MJH_LAUNCH(4, false); else MJH_LAUNCH(8, false); }
 #undef MJH_LAUNCH2
@@ -127,7 +137,13 @@ static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps,
   if (window) {
     // LDS tier: windows beyond the register-resident ones, as many as leave four waves per CU (40 KB per wave)
     static const int nl_env = getenv("MJH_WN_NL") ? atoi(getenv("MJH_WN_NL")) : -1;      // (experiments: force the number of LDS-tier windows)
-    const int nl = nl_env >= 0 ? nl_env : std::min(WN_MAXW, (int)((40 * 1024 - 1024) / (4 * WN_XREC(e->M.win_nvt) * 16 * sizeof(float))));
+    // ... and none at all while no env of the cohort comes near the register-resident windows' rows: mjh_order_kernel leaves the cohort's
+    // largest row count in a host-mapped word whenever it renews the launch order; read unsynchronised — the tiers hold the same values,
+    // the choice changes where a window waits, not what is computed (S24: 9.13 -> 9.35 M env-steps/s; S24D needs the tier)
+    const int nwreg = e->M.win_nvt == 24 ? WN_NW24 : WN_NW32;
+    const int seen = (e->h_wn && e->cur_cohort >= 0) ? *(volatile int*)(e->h_wn + e->cur_cohort) : (1 << 20);
+    const int nl_full = std::min(WN_MAXW, (int)((40 * 1024 - 1024) / (4 * WN_XREC(e->M.win_nvt) * 16 * sizeof(float))));
+    const int nl = nl_env >= 0 ? nl_env : (seen + 16 <= 16 * nwreg ? 0 : nl_full);
     const size_t lds = (size_t)4 * nl * WN_XREC(e->M.win_nvt) * 16 * sizeof(float);
     if (e->M.win_nvt == 24) hipLaunchKernelGGL((mjh_window_kernel<24, WN_NW24>), dim3((n + 3) / 4), dim3(64), lds, st, e->dC, e->S, env0, n, nl, xflags);
     else hipLaunchKernelGGL((mjh_window_kernel<32, WN_NW32>), dim3((n + 3) / 4), dim3(64), lds, st, e->dC, e->S, env0, n, nl, xflags);
@@ -524,6 +540,12 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   }
   MJH_ATTR(1, true); MJH_ATTR(2, true); MJH_ATTR(4, true); MJH_ATTR(8, true); MJH_ATTR(1, false); MJH_ATTR(2, false); MJH_ATTR(4, false); MJH_ATTR(8, false);
 #undef MJH_ATTR
+  if (e->M.window) {
+    HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<1, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+    HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<1, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+    HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<2, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+    HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<2, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+  }
 
   // ---- per-env state
   DState& S = e->S;
@@ -543,6 +565,11 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   if (M.window) {   // window sweep: header + vectors + WN_MAXW windows of rows + tiles of the streamed windows, per env
     S.wstride = ((WN_ROWS + WN_MAXW * (M.win_nvt + 2) * 16 + WN_MAXW * WN_XREC(M.win_nvt) * 16 + 63) / 64) * 64;
     rc |= dev_alloc(e, &S.wbuf, (size_t)nenv * (size_t)S.wstride, true);
+  }
+  if (M.window && e->lpt && nenv >= 1024) {
+    HIPCHK(hipHostMalloc((void**)&e->h_wn, MJH_MAX_COHORTS * sizeof(int), hipHostMallocMapped));
+    for (int g = 0; g < MJH_MAX_COHORTS; g++) e->h_wn[g] = 1 << 20;        // (nothing seen yet: keep the LDS tier)
+    HIPCHK(hipHostGetDevicePointer((void**)&e->d_wn, e->h_wn, 0));
   }
   if (M.big && M.dense && e->lpt && nenv >= 1024) {
     // one word per cohort in host-mapped memory: "a env of the cohort swept long when its launch order was last rebuilt" (mjh_order_kernel)
@@ -600,6 +627,7 @@ extern "C" void mjh_destroy(mjh_engine* e) {
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->scratch) (void)hipFree(e->scratch);
   if (e->h_dense) (void)hipHostFree(e->h_dense);
+  if (e->h_wn) (void)hipHostFree(e->h_wn);
   for (int g = 0; g < MJH_MAX_COHORTS; g++) for (int k = 0; k < 4; k++) if (e->ev_dense[g][k]) (void)hipEventDestroy(e->ev_dense[g][k]);
   delete e;
 }
@@ -724,7 +752,7 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
       if (e->S.env_order && (e->order_G != G || e->order_age / order_every != (e->order_age - e->last_chunk) / order_every || e->order_age == 0)) {
         const bool dsel = e->M.big && e->split3 && e->M.dense && e->d_dense;
         const unsigned ep = e->dense_epoch[g];
-        hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, st, (const int*)e->S.stats, e->d_order, g0, g1 - g0, dsel ? e->d_dense + 4 * g + (ep & 3) : (int*)nullptr, e->M.dense_min_iter);
+        hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, st, (const int*)e->S.stats, e->d_order, g0, g1 - g0, dsel ? e->d_dense + 4 * g + (ep & 3) : (e->d_wn ? e->d_wn + g : (int*)nullptr), e->d_wn && !dsel ? -1 : e->M.dense_min_iter);
         if (dsel) {
           HIPCHK(hipEventRecord(e->ev_dense[g][ep & 3], st));
           if (ep >= 2) { HIPCHK(hipEventSynchronize(e->ev_dense[g][(ep - 2) & 3])); e->dense_now[g] = *(volatile int*)(e->h_dense + 4 * g + ((ep - 2) & 3)) != 0; }
@@ -767,7 +795,7 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
           HIPCHK(hipGetLastError());
           rc = launch_on(e, st, g0, g1 - g0, 1, PH_STEP2 | PH_POST, 0);
         }
-      } else rc = launch_on(e, st, g0, g1 - g0, k, ph, 0);
+      } else { e->cur_cohort = g; rc = launch_on(e, st, g0, g1 - g0, k, ph, 0); e->cur_cohort = -1; }
       if (ta && !rc) HIPCHK(hipEventRecord(tb, st));
     }
     e->last_chunk = k;
@@ -1212,7 +1240,10 @@ static int reset_dense_choice(mjh_engine* e) {
 }
 extern "C" int mjh_reset(mjh_engine* e, const int* env_ids, int n) {
   ENG(e);
-  if (!env_ids) { int rc = reset_dense_choice(e); return rc ? rc : launch(e, 0, e->nenv, 1, PH_RESET, 0); }
+  if (!env_ids) {
+    if (e->h_wn) for (int g = 0; g < MJH_MAX_COHORTS; g++) e->h_wn[g] = 1 << 20;     // (row counts of the old state: keep the window kernel's LDS tier until the next look)
+    int rc = reset_dense_choice(e); return rc ? rc : launch(e, 0, e->nenv, 1, PH_RESET, 0);
+  }
   for (int i = 0; i < n; i++) {
     if (env_ids[i] < 0 || env_ids[i] >= e->nenv) { mjh_set_error("mjh_reset: env id out of range"); return MJH_ERR_ARG; }
     int rc = launch(e, env_ids[i], 1, 1, PH_RESET, 0);

@@ -898,7 +898,7 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
 #include "patch_pgs.h"
 #include "window_pgs.h"
 
-template <int NROW, bool DIAGM, bool EXTRA>
+template <int NROW, bool DIAGM, bool EXTRA, bool WPRE = false>
 #ifndef MJH_STEP_WAVES
 // resident waves per SIMD the register allocation aims at: two for the instances that keep sweep records in registers (free-body
 // patch sweep) or long dense stages (many-body chain), three for the small articulated models (C3, C5: latency-bound, every extra
@@ -2418,7 +2418,8 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
               //      the sweeps in constraint-row order, mj_checkAcc and mj_Euler, and stores the state.  Handed over: the rows (J^ dense over
               //      the dofs, aref, R), M^1/2 qacc_smooth, M^1/2 qacc_warmstart, M^-1/2, qvel after the controller, the normalised qpos.
               float* wb = S.wbuf + (size_t)env * (size_t)S.wstride;
-              const int nrow = window_emit(wb, M.win_nvt, s_blki_i, s_blkf, s_J, s_bias, nblk, lane);
+              const int nrow = window_emit(wb, M.win_nvt, s_blki_i, s_blkf, s_J, s_bias, nblk, lane, WPRE);
+              if (WPRE && nefc > nrow) flags |= 2;          // (rows beyond the window kernel's capacity were dropped)
               if (nrow > 0) {
                 for (int d = lane; d < nv; d += 64) { wb[WN_AS + d] = s_qacc[d]; wb[WN_AWS + d] = s_tmpv2[d]; wb[WN_SINV + d] = s_bias[d]; wb[WN_QVEL + d] = s_qvel[d]; }
                 for (int i = lane; i < nq; i += 64) wb[WN_QPOS + i] = s_qpos[i];
@@ -2427,6 +2428,7 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
               }
               // (more rows than the window kernel takes: this env finishes the step here, in patch form)
             }
+            if constexpr (!WPRE) {
             int swork = 0, npatch = 0;
             const int nstep = patch_build(pa, lane, flags, swork, npatch);
             if (warm) patch_warmstart(pa, lane, nstep, npatch, L.tmpv2, L.qacc, L.tmpv);
@@ -2441,8 +2443,10 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
             WSYNC();
             // qfrc_constraint = M (qacc - qacc_smooth): the base rows are gone
             if (xflags & XF_FORCE) for (int d = lane; d < nv; d += 64) s_tmpv2[d] = (s_qacc[d] - s_asmooth[d]) * s_qM[dof_Madr[d]];
+            }   // !WPRE
           }
         }
+        if constexpr (!WPRE)
         if (!patched) {
         // (an env that the dense solver takes — dense_pgs.h: it forms the full AR on the matrix cores — needs neither the blocks'
         //  own A_c nor their row-space matrices, only the projection intervals)
@@ -3028,10 +3032,11 @@ __global__ __launch_bounds__(1024) void mjh_order_kernel(const int* __restrict__
     if (threadIdx.x == 0) mx = 0;
     __syncthreads();
     int m = 0;
-    for (int e = threadIdx.x; e < nenv; e += 1024) m = max(m, stats[4*e + 2]);
+    // (dense_min_iter < 0 — window models: the word receives the cohort's largest constraint-row count instead; engine.hip: LDS tier)
+    for (int e = threadIdx.x; e < nenv; e += 1024) m = max(m, stats[4*e + (dense_min_iter < 0 ? 1 : 2)]);
     atomicMax(&mx, m);
     __syncthreads();
-    if (threadIdx.x == 0) *dense_sel = mx >= dense_min_iter ? 1 : 0;
+    if (threadIdx.x == 0) *dense_sel = dense_min_iter < 0 ? mx : (mx >= dense_min_iter ? 1 : 0);
   }
   __shared__ int hist[256], base[256];
   const int t = threadIdx.x;

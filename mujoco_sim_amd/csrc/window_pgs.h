@@ -33,15 +33,17 @@
 
 // Assemble launch (mjh_step_kernel with PH_PRE, free-body instance): the constraint blocks of this env -> window rows in global memory.
 // blki / blkf / J: the block tables in LDS (step_kernel.h); sinv = M^-1/2 per dof.  Returns the number of rows (0: too many, not written).
-DEV int window_emit(float* __restrict__ wb, const int nvt, const int* blki, const float* blkf, const float* J, const float* sinv, const int nblk, const int lane) {
+// `clamp` (the assemble-only kernel instance, which has no sweep of its own to fall back to): rows beyond the window kernel's 256 are dropped,
+// like contacts beyond maxcon (the caller raises the capacity flag), instead of handing nothing over.
+DEV int window_emit(float* __restrict__ wb, const int nvt, const int* blki, const float* blkf, const float* J, const float* sinv, const int nblk, const int lane, const bool clamp = false) {
   const int4* blki4 = (const int4*)blki;
   const int nk = nvt + 2;
   int4 hd = make_int4(0, 0, 0, 0);
   if (lane < nblk) hd = blki4[lane];
   const int myn = lane < nblk ? (hd.x >> 4) & 15 : 0;
   const int incl = wave_incl_scan_i(myn, lane);
-  const int nrow = __shfl(incl, 63);
-  if (nrow > 16 * WN_MAXW) return 0;
+  int nrow = __shfl(incl, 63);
+  if (nrow > 16 * WN_MAXW) { if (!clamp) return 0; nrow = 16 * WN_MAXW; }
   const int nwin = (nrow + 15) >> 4;
   // padding rows of the last window: zeros (inert: AR_qq = 0 -> -1 / AR_qq stored as 0)
   for (int t = lane; t < (16 * nwin - nrow) * nk; t += 64) {
@@ -61,6 +63,7 @@ DEV int window_emit(float* __restrict__ wb, const int nvt, const int* blki, cons
     const int row0 = incl - myn;
     for (int r = 0; r < myn; r++) {
       const int g = row0 + r;
+      if (g >= nrow) break;
       float* o = wb + WN_ROWS + (g >> 4) * nk * 16 + (g & 15);
       const int kk = 1 + (r >> 1); const float c = (r & 1) ? -1.0f : 1.0f;
       for (int k = 0; k < nvt; k++) o[16 * k] = 0.0f;

@@ -17,4 +17,10 @@
 #ifndef ONE_EXTRA
 #define ONE_EXTRA false
 #endif
-template __global__ void mjh_step_kernel<ONE_NROW, ONE_DIAGM, ONE_EXTRA>(const DConst*, const DState, int, int, int, int);
+#ifndef ONE_WPRE
+#define ONE_WPRE false
+#endif
+template __global__ void mjh_step_kernel<ONE_NROW, ONE_DIAGM, ONE_EXTRA, ONE_WPRE>(const DConst*, const DState, int, int, int, int);
+#ifdef ONE_NW
+template __global__ void mjh_window_kernel<24, ONE_NW>(const DConst*, const DState, int, int, int, int);
+#endif
