@@ -285,7 +285,12 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags, int& swork, 
 }
 
 // four rows r0 .. r0+3 of the sweep, on t_q = -res_q / AR_qq:  delta = max(t, -f),  t_q += (-AR_qr / AR_qq) delta_r
-#define PP_ROW(r, ar) "v_max_f32 %[d], %[t], %[nf]\n\ts_nop 1\n\tv_fmac_f32_dpp %[t], %[d], " ar " row_newbcast:" #r " row_mask:0xf bank_mask:0xf\n\t"
+#ifdef MJH_NO_ROW_NOP      // (experiment: the row chain without the two wait states of the DPP read — tools/r04_nop.sh)
+#define PP_ROW_NOP ""
+#else
+#define PP_ROW_NOP "s_nop 1\n\t"
+#endif
+#define PP_ROW(r, ar) "v_max_f32 %[d], %[t], %[nf]\n\t" PP_ROW_NOP "v_fmac_f32_dpp %[t], %[d], " ar " row_newbcast:" #r " row_mask:0xf bank_mask:0xf\n\t"
 #define PP_ROWS4(r0, r1, r2, r3, T) asm volatile(PP_ROW(r0, "%[a0]") PP_ROW(r1, "%[a1]") PP_ROW(r2, "%[a2]") PP_ROW(r3, "%[a3]") \
     : [t] "+v"(tt), [d] "=&v"(dl) : [nf] "v"(nf), [a0] "v"(T.x), [a1] "v"(T.y), [a2] "v"(T.z), [a3] "v"(T.w))
 
