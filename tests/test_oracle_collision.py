@@ -417,3 +417,51 @@ def test_ascii_stl_and_obj_meshes(tmp_path, lib):
         assert m.c.nmesh == 1 and m.c.nmeshvert == 8, (fn, lib.mjh_load_note())
         np.testing.assert_allclose(m.array("body_mass")[1], 1000 * 0.2 * 0.1 * 0.1, rtol=1e-9)
         np.testing.assert_allclose(sorted(np.abs(m.array("mesh_vert").reshape(-1, 3)).max(axis=0)), [0.05, 0.05, 0.1], rtol=1e-9)
+
+
+def test_portal_refinement_against_the_exact_minkowski_difference():
+    """An independent look at the restated portal refinement (`orc_convex_pair`; MuJoCo sends such pairs through libccd's MPR, which is
+    not in this image): for POLYTOPE pairs (boxes, convex meshes) the Minkowski difference B - A is a convex hull scipy can build
+    exactly.  Asserted on ~230 overlapping of 6000 random pairs: a contact is reported iff the hull contains the origin; the depth is
+    never below the true minimal translation distance (min over facets of the origin's distance); and it IS exact portal refinement:
+    the depth equals the plane distance of the facet through which the ray from the interior point (centre difference) through the
+    origin leaves the hull — the property that defines the algorithm — in at least 90 % of the pairs (the rest: the ray leaves
+    through an edge or a vertex), with the normal that facet's; the median pair gets the minimal depth itself."""
+    from scipy.spatial import ConvexHull
+    MESH = 7
+    rng = np.random.default_rng(3)
+    signs = np.array([[a, b, c] for a in (-1, 1) for b in (-1, 1) for c in (-1, 1)], dtype=float)
+
+    def shape(kind):
+        if kind == BOX:
+            s = rng.uniform(0.05, 0.3, 3); return kind, s, signs * s, None
+        pts = rng.normal(size=(rng.integers(6, 24), 3)) * rng.uniform(0.05, 0.3, 3)
+        v = pts[ConvexHull(pts).vertices]; v = v - v.mean(0)
+        return kind, np.ones(3), v, v
+    overlapping = exact = 0; ratios = []
+    for _ in range(8000):
+        k1, s1, loc1, v1 = shape([BOX, MESH][rng.integers(2)]); k2, s2, loc2, v2 = shape([BOX, MESH][rng.integers(2)])
+        if k1 == BOX and k2 == BOX:
+            continue
+        R1 = rot(rng.normal(size=3), rng.uniform(0, 3)); R2 = rot(rng.normal(size=3), rng.uniform(0, 3))
+        p1 = rng.uniform(-1, 1, 3); d = rng.normal(size=3); d /= np.linalg.norm(d)
+        A = p1 + loc1 @ R1.T
+        p2 = p1 + d * (np.abs(loc1 @ R1.T @ d).max() + np.abs(loc2 @ R2.T @ d).max()) * rng.uniform(0.9, 1.02)
+        B = p2 + loc2 @ R2.T
+        k, dist, pos, n = convex_pair(k1, p1, R1, s1, k2, p2, R2, s2, v1=v1, v2=v2)
+        H = ConvexHull((B[:, None, :] - A[None, :, :]).reshape(-1, 3))
+        inside = bool((H.equations[:, 3] <= 0).all())
+        assert bool(k) == inside or abs(H.equations[:, 3].max()) < 1e-7, (k, H.equations[:, 3].max())
+        if not k:
+            continue
+        overlapping += 1
+        true_depth = (-H.equations[:, 3]).min()
+        assert -dist >= true_depth - 1e-9 and abs(np.linalg.norm(n) - 1) < 1e-9
+        v0 = p2 - p1
+        num = -(H.equations[:, :3] @ v0 + H.equations[:, 3]); den = H.equations[:, :3] @ (-v0)
+        f = int(np.argmin(np.where(den > 1e-14, num / np.where(den > 1e-14, den, 1), np.inf)))
+        if abs(-dist + H.equations[f, 3]) < 1e-6 and np.abs(n + H.equations[f, :3]).max() < 1e-5:      # (normal: from geom 1 into geom 2 = minus B - A's outward facet normal)
+            exact += 1
+        ratios.append(-dist / max(true_depth, 1e-12))
+    assert overlapping >= 150 and exact >= 0.9 * overlapping, (overlapping, exact)
+    assert np.median(ratios) < 1 + 1e-6 and np.quantile(ratios, 0.9) < 1.2, (np.median(ratios), np.quantile(ratios, 0.9))
