@@ -81,6 +81,7 @@ struct DState {
   // many-body models (nv > 64): per-env pools that do not fit LDS (contacts, blocks, Jacobians) live here; a negative
   // Lay offset -1-k addresses float k of the env's slice
   float* gscratch; long long gstride;
+  int win32;             // window kernel: envs with more than this many rows (default WN32_MIN_ROWS) are swept in 32-row windows, two per wavefront (0: every env in the 16-row form)
   int probe_slices;      // debug (mjh_debug_solve_probe): mjh_solve_kernel reads the block operands of env0 + blockIdx % probe_slices instead of its own (0: off)
   // window sweep (window_pgs.h): per-env hand-over slice (header, scaled dof vectors, state, window rows, tiles of streamed windows)
   float* wbuf; long long wstride;

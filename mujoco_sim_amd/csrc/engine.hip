@@ -145,8 +145,11 @@ static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps,
     const int nl_full = std::min(WN_MAXW, (int)((40 * 1024 - 1024) / (4 * WN_XREC(e->M.win_nvt) * 16 * sizeof(float))));
     const int nl = nl_env >= 0 ? nl_env : (seen + 16 <= 16 * nwreg ? 0 : nl_full);
     const size_t lds = (size_t)4 * nl * WN_XREC(e->M.win_nvt) * 16 * sizeof(float);
-    if (e->M.win_nvt == 24) hipLaunchKernelGGL((mjh_window_kernel<24, WN_NW24>), dim3((n + 3) / 4), dim3(64), lds, st, e->dC, e->S, env0, n, nl, xflags);
-    else hipLaunchKernelGGL((mjh_window_kernel<32, WN_NW32>), dim3((n + 3) / 4), dim3(64), lds, st, e->dC, e->S, env0, n, nl, xflags);
+    // 24-dof models: a first section of wavefronts sweeps the envs with many rows in 32-row windows, two per wavefront (they scan the
+    // same launch order and take the envs the assemble launch marked; almost all of them exit at once)
+    const int n32 = (e->S.win32 && e->M.win_nvt == 24) ? (n + 1) / 2 : 0;
+    if (e->M.win_nvt == 24) hipLaunchKernelGGL((mjh_window_kernel<24, WN_NW24>), dim3(n32 + (n + 3) / 4), dim3(64), lds, st, e->dC, e->S, env0, n, nl, xflags, n32);
+    else hipLaunchKernelGGL((mjh_window_kernel<32, WN_NW32>), dim3((n + 3) / 4), dim3(64), lds, st, e->dC, e->S, env0, n, nl, xflags, 0);
     HIPCHK(hipGetLastError());
   }
   return MJH_OK;
@@ -562,6 +565,7 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   S.gscratch = nullptr; S.gstride = hp.gstride;
   if (M.big) rc |= dev_alloc(e, &S.gscratch, (size_t)nenv * (size_t)hp.gstride, false);   // many-body models: contact / block / Jacobian pools
   S.wbuf = nullptr; S.wstride = 0;
+  S.win32 = getenv("MJH_WINDOW32") ? std::max(0, atoi(getenv("MJH_WINDOW32"))) : WN32_MIN_ROWS;     // (0: off; experiments: another row threshold)
   if (M.window) {   // window sweep: header + vectors + WN_MAXW windows of rows + tiles of the streamed windows, per env
     S.wstride = ((WN_ROWS + WN_MAXW * (M.win_nvt + 2) * 16 + WN_MAXW * WN_XREC(M.win_nvt) * 16 + 63) / 64) * 64;
     rc |= dev_alloc(e, &S.wbuf, (size_t)nenv * (size_t)S.wstride, true);

@@ -2423,7 +2423,8 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
               if (nrow > 0) {
                 for (int d = lane; d < nv; d += 64) { wb[WN_AS + d] = s_qacc[d]; wb[WN_AWS + d] = s_tmpv2[d]; wb[WN_SINV + d] = s_bias[d]; wb[WN_QVEL + d] = s_qvel[d]; }
                 for (int i = lane; i < nq; i += 64) wb[WN_QPOS + i] = s_qpos[i];
-                if (lane == 0) { int* wh = (int*)wb; wh[0] = nrow; wh[1] = ncon; wh[2] = nefc; wh[3] = flags; }
+                // [4]: the form the window kernel sweeps this env in — 32-row windows for many rows (window_pgs.h: wn_run32), a function of the env's own row count
+                if (lane == 0) { int* wh = (int*)wb; wh[0] = nrow; wh[1] = ncon; wh[2] = nefc; wh[3] = flags; wh[4] = (S.win32 > 0 && M.win_nvt == 24 && nrow > S.win32 && nrow <= 32 * WN32_NW) ? 1 : 0; }
                 return;
               }
               // (more rows than the window kernel takes: this env finishes the step here, in patch form)

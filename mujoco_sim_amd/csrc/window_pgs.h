@@ -28,6 +28,7 @@
 #define WN_QVEL 112     // qvel after the controller [32]
 #define WN_QPOS 144     // qpos after mj_kinematics' quaternion normalisation [40]
 #define WN_ROWS 192     // window w at WN_ROWS + w * NK * 16: [k][16 rows], k < NK = NVT + 2: J^[NVT], aref, R
+#define WN32_MIN_ROWS 96   // rows above which an env is swept in 32-row windows (3.5 % of S24's envs: the ones a cohort's step waits for)
 #define WN_MAXW 16      // windows per env (256 rows: the capacity of the patch sweep as well)
 #define WN_XREC(nvt) ((nvt) + 21)   // record of a window beyond the register-resident ones, per row: J^[nvt], aref, R, 16 tile entries, -1 / AR_qq, AR_qq / 2, force
 
@@ -183,16 +184,225 @@ template <int NV> DEV void wn_jt(const float* J, const float x, float& a_lo, flo
   if constexpr (NV == 32) a_hi += wn_fold16(p + 16); else a_hi += wn_fold8(p + 16);
 }
 
-template <int NV, int NW>
-__global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restrict__ C, const DState S, const int env0, const int nenv, const int nl, const int xflags) {
+
+// ---- 32-row windows: TWO environments per wavefront (a 32-lane half each), for the environments with many rows.  A cohort's step waits
+// for its slowest wavefront, and that one carries an env at the sweep cap with 7 or 8 windows of 16 (S24: 3.5 % of the envs have more
+// than 96 rows — tools/s24_critical_path.py, tools/s24_hybrid_model.py).  Per 32 rows one dot and one transpose-reduce instead of two:
+// ~186 instead of 260 instructions on that env's chain.  Lanes: env slot es = lane >> 5, half hq = (lane >> 4) & 1 (rows 0..15 / 16..31
+// of the window), q = lane & 15.  Gauss-Seidel stays row by row: the lower half's 16 rows (DPP row mask 0x5), then the upper half
+// receives the lower deltas through the cross tile (C: -AR_{16+q, r} / AR_qq, r < 16 — the lower deltas come over by ds_swizzle),
+// then its own 16 rows (row mask 0xa).  Both halves carry the same a^ (dof q / 16 + q / 2), their partial J^T sums are exchanged by
+// ds_swizzle.  The MODE of an env is a function of its own row count alone (96 < rows <= 128, set by the assemble launch): results do
+// not depend on which envs share a wavefront.  Same row math, same order, same stopping rule as the 16-row form; the grouping of
+// the arithmetic differs (fp32 rounding).
+#define WN_SWZ16(x) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, (x)), 0x401F))   // lane ^ 16 within 32 lanes
+#define WN_ROWM(r, ar, m) "v_max_f32 %[d], %[t], %[nf]\n\ts_nop 1\n\tv_fmac_f32_dpp %[t], %[d], " ar " row_newbcast:" #r " row_mask:" #m " bank_mask:0xf\n\t"
+#define WN_ROWS4M(r0, r1, r2, r3, T, m) asm volatile(WN_ROWM(r0, "%[a0]", m) WN_ROWM(r1, "%[a1]", m) WN_ROWM(r2, "%[a2]", m) WN_ROWM(r3, "%[a3]", m) \
+    : [t] "+v"(tt), [d] "=&v"(dl) : [nf] "v"(nf), [a0] "v"(T.x), [a1] "v"(T.y), [a2] "v"(T.z), [a3] "v"(T.w))
+#define WN_XFM(r, ar) "v_fmac_f32_dpp %[t], %[x], " ar " row_newbcast:" #r " row_mask:0xa bank_mask:0xf\n\t"
+#define WN_CROSS4(r0, r1, r2, r3, T) asm volatile(WN_XFM(r0, "%[a0]") WN_XFM(r1, "%[a1]") WN_XFM(r2, "%[a2]") WN_XFM(r3, "%[a3]") \
+    : [t] "+v"(tt) : [x] "v"(dx), [a0] "v"(T.x), [a1] "v"(T.y), [a2] "v"(T.z), [a3] "v"(T.w))
+#define WN32_NW 4       // 32-row windows of an env (128 rows), all register-resident
+struct WnWin32 { float J[24]; float4 A0, A1, A2, A3, C0, C1, C2, C3; float aref, R, nw, half; };
+
+DEV void wn_jt32(const float* J, const float x, float& a_lo, float& a_hi) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f x2 = {x, x};
+  float p[24];
+#pragma unroll
+  for (int k = 0; k < 24; k += 2) { const v2f pr = v2f{J[k], J[k + 1]} * x2; p[k] = pr.x; p[k + 1] = pr.y; }
+  float s_lo = wn_fold16(p), s_hi = wn_fold8(p + 16);
+  // + the other half's 16 rows: v_permlane16_swap exchanges the odd 16-lane rows of the first register with the even rows of the second,
+  // so (x, y) = (lower half's sum, upper half's sum) in EVERY lane afterwards: the same sum, in the same order, in both halves
+  // (a VALU instruction: the LDS crossbar's round trip — ds_swizzle — sat three times in every window-sweep's chain)
+  float y_lo = s_lo, y_hi = s_hi;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1" : "+v"(s_lo), "+v"(s_hi), "+v"(y_lo), "+v"(y_hi));
+  a_lo += s_lo + y_lo; a_hi += s_hi + y_hi;
+}
+
+DEV void wn_run32(const DConst* __restrict__ C, const DState& S, const int env0, const int nenv, const int xflags, const int blk) {
   const DModel& M = C->M;
-  const int lane = threadIdx.x, rho = lane >> 4, q = lane & 15;
-  const int slot = (int)blockIdx.x * 4 + rho;
+  constexpr int NV = 24, NK = NV + 2;
+  const int lane = threadIdx.x, es = lane >> 5, hq = (lane >> 4) & 1, q = lane & 15;
+  const int slot = blk * 2 + es;
   const bool have = slot < nenv;
   const int env = have ? (S.env_order ? S.env_order[env0 + slot] : env0 + slot) : 0;
   float* const wb = S.wbuf + (size_t)env * (size_t)S.wstride;
   const int* const wh = (const int*)wb;
-  const int nrow = have ? wh[0] : 0;
+  const int nrow = (have && wh[4] == 1) ? wh[0] : 0;          // (envs of the 16-row form are not this section's)
+  if (__ballot(nrow > 0) == 0ull) return;
+  const bool mine = nrow > 0;
+  const int nwin16 = (nrow + 15) >> 4, nwin = (nrow + 31) >> 5;
+  const int nwmax = max(__builtin_amdgcn_readlane(nwin, 0), __builtin_amdgcn_readlane(nwin, 32));
+  const int nv = M.nv;
+  const int dhi = 16 + (q >> 1);
+  const bool lo_on = q < nv, hi_on = dhi < nv;
+  const float as_lo = lo_on ? wb[WN_AS + q] : 0.0f, as_hi = hi_on ? wb[WN_AS + dhi] : 0.0f;
+  const float ws_lo = lo_on ? wb[WN_AWS + q] : 0.0f, ws_hi = hi_on ? wb[WN_AWS + dhi] : 0.0f;
+  WnWin32 win[WN32_NW];
+  float f[WN32_NW];
+  const float* rows = wb + WN_ROWS + q;
+#pragma unroll
+  for (int w = 0; w < WN32_NW; w++) if (w < nwmax) {
+    WnWin32& W = win[w];
+    const bool ok = (2 * w + hq) < nwin16;                  // (the assemble launch pads the last 16-row block with zero rows; a missing upper block is all zeros)
+    const float* p = rows + (2 * w + hq) * NK * 16;
+#pragma unroll
+    for (int k = 0; k < NV; k++) W.J[k] = ok ? p[16 * k] : 0.0f;
+    W.aref = ok ? p[16 * NV] : 0.0f; W.R = ok ? p[16 * (NV + 1)] : 0.0f;
+    float acc[16], acx[16], Jx[NV];
+#pragma unroll
+    for (int sidx = 0; sidx < 16; sidx++) { acc[sidx] = 0.0f; acx[sidx] = 0.0f; }
+#pragma unroll
+    for (int k = 0; k < NV; k++) Jx[k] = WN_SWZ16(W.J[k]);   // the other half's row q: upper lanes see the lower rows
+#pragma unroll
+    for (int k = 0; k < NV; k++) asm volatile("" : "+v"(W.J[k]), "+v"(Jx[k]));
+    asm volatile("s_nop 1");
+#define WN_ACC(sidx) _Pragma("unroll") for (int k = 0; k < NV; k++) { PP_FMAC_BC(acc[sidx], W.J[k], W.J[k], sidx); PP_FMAC_BC(acx[sidx], Jx[k], W.J[k], sidx); }
+    PP_BC16(WN_ACC)
+#undef WN_ACC
+    float diag = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) diag += W.J[k] * W.J[k];
+    const float ARqq = diag + W.R;
+    const float inv = ARqq < MJ_MINVAL ? 0.0f : 1.0f / ARqq, ninv = -inv, cinv = hq ? ninv : 0.0f;
+    W.nw = ninv; W.half = 0.5f * ARqq;
+    W.A0 = make_float4(0 < q ? ninv * acc[0] : 0.0f, 1 < q ? ninv * acc[1] : 0.0f, 2 < q ? ninv * acc[2] : 0.0f, 3 < q ? ninv * acc[3] : 0.0f);
+    W.A1 = make_float4(4 < q ? ninv * acc[4] : 0.0f, 5 < q ? ninv * acc[5] : 0.0f, 6 < q ? ninv * acc[6] : 0.0f, 7 < q ? ninv * acc[7] : 0.0f);
+    W.A2 = make_float4(8 < q ? ninv * acc[8] : 0.0f, 9 < q ? ninv * acc[9] : 0.0f, 10 < q ? ninv * acc[10] : 0.0f, 11 < q ? ninv * acc[11] : 0.0f);
+    W.A3 = make_float4(12 < q ? ninv * acc[12] : 0.0f, 13 < q ? ninv * acc[13] : 0.0f, 14 < q ? ninv * acc[14] : 0.0f, 0.0f);
+    W.C0 = make_float4(cinv * acx[0], cinv * acx[1], cinv * acx[2], cinv * acx[3]);
+    W.C1 = make_float4(cinv * acx[4], cinv * acx[5], cinv * acx[6], cinv * acx[7]);
+    W.C2 = make_float4(cinv * acx[8], cinv * acx[9], cinv * acx[10], cinv * acx[11]);
+    W.C3 = make_float4(cinv * acx[12], cinv * acx[13], cinv * acx[14], cinv * acx[15]);
+  }
+  auto rowsum_i32 = [&](int v) __attribute__((always_inline)) { v = wn_rowsum_i(v); return v + __builtin_amdgcn_ds_swizzle(v, 0x401F); };
+  auto rowsum_f32 = [&](float v) __attribute__((always_inline)) { v = wn_rowsum_f(v); return v + WN_SWZ16(v); };
+#define WN32_FOR_WINDOWS(...) do { _Pragma("unroll") for (int w = 0; w < WN32_NW; w++) if (w < nwmax) { WnWin32& W = win[w]; float& fw = f[w]; __VA_ARGS__ } } while (0)
+  // ---- warm start
+  float a_lo = as_lo, a_hi = as_hi;
+#pragma unroll
+  for (int w = 0; w < WN32_NW; w++) f[w] = 0.0f;
+  if (!(M.disableflags & MJH_DSBL_WARMSTART)) {
+    float da_lo = 0.0f, da_hi = 0.0f;
+    WN32_FOR_WINDOWS({
+      const float jar = wn_dot<NV>(W.J, ws_lo, ws_hi) - W.aref;
+      fw = (jar < 0.0f && W.R > 0.0f) ? -jar / W.R : 0.0f;
+      wn_jt32(W.J, fw, da_lo, da_hi);
+    });
+    float cost = 0.0f;
+    WN32_FOR_WINDOWS({
+      const float jda = wn_dot<NV>(W.J, da_lo, da_hi), bb = wn_dot<NV>(W.J, as_lo, as_hi) - W.aref;
+      cost += fw * (0.5f * (jda + W.R * fw) + bb);
+    });
+    cost = rowsum_f32(cost);
+    if (cost > 0.0f) {
+#pragma unroll
+      for (int w = 0; w < WN32_NW; w++) f[w] = 0.0f;
+    } else { a_lo += da_lo; a_hi += da_hi; }
+  }
+  // ---- sweeps
+  const ImpQ iq = imp_quantum(1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1)), M.tolerance);
+  const int itmax = M.iterations;
+  int niter = 0;
+  bool act = nrow > 0;
+  while (__ballot(act) != 0ull) {
+    if (act) {
+      int impl = 0;
+      WN32_FOR_WINDOWS({
+        const float u = wn_dot<NV>(W.J, a_lo, a_hi);
+        const float fo = fw;
+        float tt = ((u - W.aref) + W.R * fo) * W.nw;
+        const float nf = -fo;
+        float dl;
+        // rows 0..15 (lower half) ...
+        WN_ROWS4M(0, 1, 2, 3, W.A0, 0x5); WN_ROWS4M(4, 5, 6, 7, W.A1, 0x5); WN_ROWS4M(8, 9, 10, 11, W.A2, 0x5); WN_ROWS4M(12, 13, 14, 15, W.A3, 0x5);
+        asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));
+        // ... their deltas reach the upper half through the cross tile ...
+        float dx = dl, dy = dl;                                         // (dx: the lower half's deltas in the upper half's lanes)
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(dx), "+v"(dy));
+        WN_CROSS4(0, 1, 2, 3, W.C0); WN_CROSS4(4, 5, 6, 7, W.C1); WN_CROSS4(8, 9, 10, 11, W.C2); WN_CROSS4(12, 13, 14, 15, W.C3);
+        // ... rows 16..31 (upper half)
+        WN_ROWS4M(0, 1, 2, 3, W.A0, 0xa); WN_ROWS4M(4, 5, 6, 7, W.A1, 0xa); WN_ROWS4M(8, 9, 10, 11, W.A2, 0xa); WN_ROWS4M(12, 13, 14, 15, W.A3, 0xa);
+        asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));
+        impl += imp_fixed((W.half * dl) * (2.0f * tt - dl), iq.qs);
+        fw = fo + dl;
+        wn_jt32(W.J, dl, a_lo, a_hi);
+      });
+      niter++;
+      if (rowsum_i32(impl) < iq.thr || niter >= itmax) act = false;
+    }
+  }
+  // ---- qacc, mj_checkAcc, semi-implicit Euler, state and statistics (the lower half's lanes carry the dofs)
+  const bool dl_lane = mine && hq == 0;
+  const float sv_lo = (dl_lane && lo_on) ? wb[WN_SINV + q] : 0.0f, sv_hi = (dl_lane && hi_on) ? wb[WN_SINV + dhi] : 0.0f;
+  float qa_lo = a_lo * sv_lo, qa_hi = a_hi * sv_hi;
+  float qv_lo = (dl_lane && lo_on) ? wb[WN_QVEL + q] : 0.0f, qv_hi = (dl_lane && hi_on) ? wb[WN_QVEL + dhi] : 0.0f;
+  int flags = mine ? wh[3] : 0;
+  if (dl_lane && (xflags & XF_FORCE)) {
+    const size_t xe = (size_t)(env - env0) * M.nvp;
+    if (lo_on) { if (S.x_smooth) S.x_smooth[xe + q] = as_lo * sv_lo; if (S.x_constraint) S.x_constraint[xe + q] = (a_lo - as_lo) / sv_lo; }
+    if (hi_on && !(q & 1)) { if (S.x_smooth) S.x_smooth[xe + dhi] = as_hi * sv_hi; if (S.x_constraint) S.x_constraint[xe + dhi] = (a_hi - as_hi) / sv_hi; }
+  }
+  const bool badl = !(qa_lo == qa_lo) || fabsf(qa_lo) > MJ_MAXVAL || !(qa_hi == qa_hi) || fabsf(qa_hi) > MJ_MAXVAL;
+  const bool bad = ((__ballot(badl) >> (32 * es)) & 0xffffffffull) != 0ull;
+  const size_t qrow = (size_t)env * M.nqp, vrow = (size_t)env * M.nvp;
+  if (bad) { qa_lo = qa_hi = 0.0f; qv_lo = qv_hi = 0.0f; flags |= 4; }
+  const float h = M.timestep;
+  const Tab<int> dof_bodyid{M.I, M.o_dof_bodyid}, jnt_qposadr{M.I, M.o_jnt_qposadr}, jnt_dofadr{M.I, M.o_jnt_dofadr};
+  const Tab<float> dof_damping{M.F, M.o_dof_damping};
+  const unsigned slotmask = S.slot_mask ? S.slot_mask[env] : 0u;
+  const int sbase = M.nbody > 32 ? M.nbody - 32 : 0;
+  __shared__ float s_v32[2][32];
+  auto advance = [&](const int d, float& qa, float& qv) __attribute__((always_inline)) {
+    float qint = qa;
+    if (M.has_damping && !(M.disableflags & MJH_DSBL_EULERDAMP)) {
+      const float sv = wb[WN_SINV + d], Mdd = 1.0f / (sv * sv), D = dof_damping[d];
+      qint = qa - h * (D * qa) / (Mdd + h * D);
+    }
+    const unsigned rb = (unsigned)(dof_bodyid[d] - sbase);
+    const bool parked = rb < 32u && ((slotmask >> rb) & 1u);
+    qv = parked ? 0.0f : qv + h * qint;
+    if (parked) qa = 0.0f;
+    S.qvel[vrow + d] = qv; S.qacc_ws[vrow + d] = qa;
+    s_v32[es][d] = qv;
+  };
+  if (dl_lane && lo_on) advance(q, qa_lo, qv_lo);
+  if (dl_lane && hi_on && !(q & 1)) advance(dhi, qa_hi, qv_hi);
+  __syncthreads();
+  if (dl_lane && q < M.njnt) {
+    const int qadr = jnt_qposadr[q], da = jnt_dofadr[q];
+    float p[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) p[k] = bad ? S.initial_qpos[qrow + qadr + k] : wb[WN_QPOS + qadr + k];
+    const float* v = s_v32[es] + da;
+    p[0] += h * v[0]; p[1] += h * v[1]; p[2] += h * v[2];
+    float w3[3] = {v[3], v[4], v[5]};
+    quat_integrate(p + 3, w3, h);
+#pragma unroll
+    for (int k = 0; k < 7; k++) S.qpos[qrow + qadr + k] = p[k];
+  }
+  if (dl_lane && q == 0) {
+    S.time[env] += M.timestep_d;
+    const int cost_hint = min(niter * nwin16 * 20 + 1, 1 << 22);
+    S.stats[4 * env] = wh[1]; S.stats[4 * env + 1] = wh[2]; S.stats[4 * env + 2] = niter;
+    S.stats[4 * env + 3] = ((S.stats[4 * env + 3] | flags) & 0xff) | (cost_hint << 8);
+  }
+#undef WN32_FOR_WINDOWS
+}
+
+template <int NV, int NW>
+__global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restrict__ C, const DState S, const int env0, const int nenv, const int nl, const int xflags, const int n32waves) {
+  // the first n32waves wavefronts: the section of the envs with many rows (two per wavefront, 32-row windows); dispatched first
+  if constexpr (NV == 24) { if ((int)blockIdx.x < n32waves) { wn_run32(C, S, env0, nenv, xflags, (int)blockIdx.x); return; } }
+  const DModel& M = C->M;
+  const int lane = threadIdx.x, rho = lane >> 4, q = lane & 15;
+  const int slot = ((int)blockIdx.x - n32waves) * 4 + rho;
+  const bool have = slot < nenv;
+  const int env = have ? (S.env_order ? S.env_order[env0 + slot] : env0 + slot) : 0;
+  float* const wb = S.wbuf + (size_t)env * (size_t)S.wstride;
+  const int* const wh = (const int*)wb;
+  const int nrow = (have && !(n32waves > 0 && wh[4] == 1)) ? wh[0] : 0;
   if (__ballot(nrow > 0) == 0ull) return;
   const bool mine = nrow > 0;        // (else: a row without an environment, or one that finished in the assemble launch — it must not write anything)
   const int nwin = (nrow + 15) >> 4;

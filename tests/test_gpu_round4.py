@@ -288,3 +288,51 @@ def test_c5_as_eight_shards_on_one_device_equals_the_plain_engine():
     assert np.array_equal(pub, ref), np.abs(pub - ref).max()
     assert np.abs(v).max() > 0.1 and len(np.unique(np.round(v, 5), axis=0)) > nenv // 2      # the envs do differ
     g.close(); single.close()
+
+
+def test_32_row_windows_for_the_envs_with_many_rows_equal_the_16_row_form_up_to_rounding():
+    """window_pgs.h wn_run32: envs with more than 96 constraint rows (the ones a cohort's step waits for) are swept in 32-row windows, two
+    per wavefront — same rows, same order, same stopping rule, one dot and one transpose-reduce per 32 rows.  Against the same engine
+    with the section switched off (MJH_WINDOW32=0): envs with at most 96 rows are bitwise equal (their form did not change), the others
+    agree to fp32 rounding with identical sweep counts almost everywhere; and the 32-row envs against the oracle like every other env"""
+    import os
+    m = ms.scene("s24")
+    nenv = 2048
+    a = ms.Engine(m, nenv); tab = a.load_s24()
+    os.environ["MJH_WINDOW32"] = "0"
+    try:
+        b = ms.Engine(m, nenv); b.load_s24()
+    finally:
+        del os.environ["MJH_WINDOW32"]
+    a.step(300); a.synchronize()
+    heavy_seen = 0; worst_q = worst_v = 0.0; same_it = []
+    for k in range(40):
+        t, q, v, w = a.get_state()
+        b.set_state(qpos=q, qvel=v, time=t, warmstart=w)
+        a.step(1); b.step(1)
+        _, qa, va, _ = a.get_state(); _, qb, vb, _ = b.get_state()
+        sa, sb = a.get_stats(), b.get_stats()
+        assert np.array_equal(sa[:, :2], sb[:, :2])                       # same contacts, same rows
+        heavy = (sa[:, 1] > 96) & (sa[:, 1] <= 128)
+        assert np.array_equal(qa[~heavy], qb[~heavy]) and np.array_equal(va[~heavy], vb[~heavy]) and np.array_equal(sa[~heavy, 2], sb[~heavy, 2])
+        if heavy.any():
+            heavy_seen += int(heavy.sum())
+            worst_q = max(worst_q, float((np.abs(qa[heavy] - qb[heavy]).max(1) / np.maximum(1, np.abs(qb[heavy]).max(1))).max()))
+            worst_v = max(worst_v, float((np.abs(va[heavy] - vb[heavy]).max(1) / np.maximum(1, np.abs(vb[heavy]).max(1))).max()))
+            same_it.append(float((sa[heavy, 2] == sb[heavy, 2]).mean()))
+    print(f"WINDOW32: {heavy_seen} env-steps in 32-row windows of {40 * nenv}: qpos {worst_q:.2e} qvel {worst_v:.2e} against the 16-row form, same sweep count {np.mean(same_it):.3f}")
+    assert heavy_seen >= 400 and worst_q <= S24_TOL_Q and worst_v <= S24_TOL_V and np.mean(same_it) >= 0.9
+    # against the oracle: one step from the device's state, the envs in 32-row windows
+    t, q, v, w = a.get_state(); st0 = a.get_stats()
+    a.step(1); _, q1, v1, _ = a.get_state(); st = a.get_stats()
+    heavy = np.nonzero((st[:, 1] > 96) & (st[:, 1] <= 128))[0][:24]
+    assert len(heavy) >= 8
+    for i in heavy:
+        d = oracle_s24(m, tab, int(i))
+        d.f("qpos")[:] = q[i]; d.f("qvel")[:] = v[i]; d.f("qacc_warmstart")[:] = w[i]; d.f("qacc")[:] = w[i]; d.f("time")[0] = t[i]
+        d.step(1)
+        if d.i("ncon") != st[i, 0] or d.i("nefc") != st[i, 1]:
+            continue
+        assert np.abs(q1[i] - d.f("qpos")).max() / max(1.0, np.abs(d.f("qpos")).max()) <= S24_TOL_Q
+        assert np.abs(v1[i] - d.f("qvel")).max() / max(1.0, np.abs(d.f("qvel")).max()) <= S24_TOL_V
+    a.close(); b.close()

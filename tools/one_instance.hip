@@ -22,5 +22,5 @@
 #endif
 template __global__ void mjh_step_kernel<ONE_NROW, ONE_DIAGM, ONE_EXTRA, ONE_WPRE>(const DConst*, const DState, int, int, int, int);
 #ifdef ONE_NW
-template __global__ void mjh_window_kernel<24, ONE_NW>(const DConst*, const DState, int, int, int, int);
+template __global__ void mjh_window_kernel<24, ONE_NW>(const DConst*, const DState, int, int, int, int, int);
 #endif

@@ -22,6 +22,50 @@ lines = [f"# rocprofv3 summary `{tag}` / config `{cfg}` — `python bench.py --c
          f"{nenv} envs, {cohorts} cohorts on separate HIP streams; one step launch covers {envs_per_launch:.0f} envs; the timed region holds {timed} step launches.", ""]
 
 
+def mangled_key(name):
+    """'void mjh_step_kernel<2, true, false, true>' -> 'mjh_step_kernelILi2ELb1ELb0ELb1EE' (the piece of the mangled name that identifies the instance)"""
+    import re
+    m = re.search(r"(mjh_\w+)(?:<([^>]*)>)?", name)
+    if not m:
+        return name
+    base, args = m.group(1), m.group(2)
+    if not args:
+        return base
+    enc = "".join(("Lb1E" if a.strip() == "true" else "Lb0E" if a.strip() == "false" else f"Li{a.strip()}E") for a in args.split(","))
+    return f"{base}I{enc}E"
+
+
+def code_object_vgprs():
+    """{instance key: .vgpr_count} from the gfx950 code object embedded in libmjhip.so (llvm-readelf --notes)"""
+    import re, subprocess, tempfile
+    out = {}
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mujoco_sim_amd", "libmjhip.so")
+    try:
+        data = open(lib, "rb").read()
+        idx = 0
+        while True:
+            i = data.find(b"\x7fELF", idx)
+            if i < 0:
+                break
+            if data[i + 18:i + 20] == (224).to_bytes(2, "little"):
+                shoff = int.from_bytes(data[i + 40:i + 48], "little"); shentsize = int.from_bytes(data[i + 58:i + 60], "little"); shnum = int.from_bytes(data[i + 60:i + 62], "little")
+                with tempfile.NamedTemporaryFile(suffix=".elf") as f:
+                    f.write(data[i:i + shoff + shentsize * shnum]); f.flush()
+                    txt = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f.name], capture_output=True, text=True).stdout
+                for b in re.split(r"\n\s+- \.agpr_count:", "\n" + txt)[1:]:
+                    nm = re.search(r"\.name:\s+(\S+)", b); vg = re.search(r"\.vgpr_count:\s+(\d+)", b)
+                    if nm and vg:
+                        km = re.match(r"_Z(\d+)", nm.group(1))
+                        if km:
+                            st = len(km.group(0)); base = nm.group(1)[st:st + int(km.group(1))]
+                            tm = re.match(r"I(?:L[ib]\d+E)+E", nm.group(1)[st + int(km.group(1)):])
+                            out[base + (tm.group(0) if tm else "")] = int(vg.group(1))
+            idx = i + 4
+    except Exception:
+        pass
+    return out
+
+
 def db(sub):
     f = glob.glob(os.path.join(raw, sub, "**", "*.db"), recursive=True)
     return sqlite3.connect(f[0]) if f else None
@@ -52,10 +96,13 @@ if con:
         for n, s, e, vg, sg, lds, scr, av in last:
             k = n.split("(")[0]
             a = seen.setdefault(k, [0, 0.0, vg, sg, lds, scr, av]); a[0] += 1; a[1] += (e - s) / 1e3
+        notes = code_object_vgprs()
         for k, a in seen.items():
-            # (rocprofv3's vgpr_count is the ARCHITECTED half of gfx950's unified file; the allocation that sets the occupancy is
-            # arch + accum, what the code object's .vgpr_count note and tools/kernel_resources.sh report)
-            lines.append(f"- `{k}`: {a[0]} launches, mean {a[1] / a[0]:.1f} us; registers {a[2]} arch VGPR + {a[6]} AGPR = {a[2] + a[6]} unified, SGPR {a[3]}, LDS {a[4]} B/workgroup, scratch {a[5]} B/lane")
+            # (rocprofv3's vgpr_count column is not the allocation that sets the occupancy on gfx950's unified register file — it reads
+            #  about half of it; the code object's .vgpr_count note, what tools/kernel_resources.sh prints, is)
+            co = notes.get(mangled_key(k))
+            reg = f"{co} unified registers (code object .vgpr_count; rocprofv3's column: {a[2]})" if co else f"rocprofv3 vgpr_count {a[2]} (+ {a[6]} accum)"
+            lines.append(f"- `{k}`: {a[0]} launches, mean {a[1] / a[0]:.1f} us; {reg}, SGPR {a[3]}, LDS {a[4]} B/workgroup, scratch {a[5]} B/lane")
         lines.append("")
 tot = {}
 for sub, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
