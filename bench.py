@@ -772,7 +772,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": ("mjh_step_kernel (assemble: position / velocity stages, collision, constraint rows) + mjh_window_kernel (PGS sweeps in mj_solPGS row order, four "
-                                "envs per wavefront, rows in registers; mj_Euler): the two-launch chain of one cohort's step, timed as one" if eng.window_solver() else "mjh_step_kernel") + ((" (+ mjh_dense_build_kernel [MFMA] + mjh_dense_solve_kernel: assemble -> build -> solve -> integrate chain of the many-body layout)" if eng.dense_solver() else
+                                "envs per wavefront in 16-row windows — two in 32-row windows above 96 rows —, rows in registers; mj_Euler): the two-launch chain of one cohort's step, timed as one" if eng.window_solver() else "mjh_step_kernel") + ((" (+ mjh_dense_build_kernel [MFMA] + mjh_dense_solve_kernel: assemble -> build -> solve -> integrate chain of the many-body layout)" if eng.dense_solver() else
                                                      " (+ mjh_solve_kernel: three-launch step of the many-body layout)") if eng.lds_bytes > 24 * 1024 or model.nv > 64 else ""),
                      "kernel_ms": kernel_ms, "launches": n_launches, "launches_timed": n_timed, "envs_per_launch": envs_per_launch, "concurrent_launches": cohorts,
                      # `achieved` / `frac` are per launch (one cohort's step), as the contract defines them; the cohorts' launches overlap, so the
