@@ -53,7 +53,7 @@ struct mjh_engine {
   DModel M{};
   DState S{};
   Lay L{};
-  int lds_bytes = 0;
+  int lds_bytes = 0, lds_bytes_pre = 0;   // dynamic LDS per env of the step kernel; ... of its assemble-only instance (no patch pool: more envs per CU)
   size_t dense_lds = 0, dense_solve_lds = 0;   // dynamic LDS of mjh_dense_build_kernel / mjh_dense_solve_kernel
   // dense solver on / off per cohort: mjh_order_kernel leaves "an env of the cohort swept long" in a host-mapped word (four slots per
   // cohort, one per rebuild of the launch order); the host adopts the word of TWO rebuilds ago after waiting for that kernel's event
@@ -125,7 +125,9 @@ static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps,
     // the assemble-only instance (WPRE): the step kernel without any sweep of its own — 128 VGPRs instead of 236, so that its waves
     // fit beside the window kernel's on a SIMD
     const bool cx = extra_instance(e->M) || e->S.xfrc_applied;
-#define MJH_LAUNCHW(NR, CX) hipLaunchKernelGGL((mjh_step_kernel<NR, true, CX, true>), dim3(n), dim3(64), (size_t)e->lds_bytes, st, e->dC, e->S, env0, nsteps, ph, xflags)
+    static const bool slim_lds = !(getenv("MJH_WINDOW_SLIM_LDS") && atoi(getenv("MJH_WINDOW_SLIM_LDS")) == 0);
+    const size_t wlds = (size_t)((slim_lds && e->lds_bytes_pre > 0) ? e->lds_bytes_pre : e->lds_bytes);
+#define MJH_LAUNCHW(NR, CX) hipLaunchKernelGGL((mjh_step_kernel<NR, true, CX, true>), dim3(n), dim3(64), wlds, st, e->dC, e->S, env0, nsteps, ph, xflags)
     if (nr == 1) { if (cx) MJH_LAUNCHW(1, true); else MJH_LAUNCHW(1, false); } else { if (cx) MJH_LAUNCHW(2, true); else MJH_LAUNCHW(2, false); }
 #undef MJH_LAUNCHW
   } else
@@ -143,7 +145,10 @@ static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps,
     const int nwreg = e->M.win_nvt == 24 ? WN_NW24 : WN_NW32;
     const int seen = (e->h_wn && e->cur_cohort >= 0) ? *(volatile int*)(e->h_wn + e->cur_cohort) : (1 << 20);
     const int nl_full = std::min(WN_MAXW, (int)((40 * 1024 - 1024) / (4 * WN_XREC(e->M.win_nvt) * 16 * sizeof(float))));
-    const int nl = nl_env >= 0 ? nl_env : (seen + 16 <= 16 * nwreg ? 0 : nl_full);
+    // (with the 32-row section on, the 16-row form only meets envs of at most WN32_MIN_ROWS rows — or more than 128, the tier's clients)
+    const bool sec32 = e->S.win32 > 0 && e->M.win_nvt == 24 && e->S.win32 <= 16 * nwreg;
+    const bool tier = sec32 ? seen > 32 * WN32_NW : seen + 16 > 16 * nwreg;
+    const int nl = nl_env >= 0 ? nl_env : (tier ? nl_full : 0);
     const size_t lds = (size_t)4 * nl * WN_XREC(e->M.win_nvt) * 16 * sizeof(float);
     // 24-dof models: a first section of wavefronts sweeps the envs with many rows in 32-row windows, two per wavefront (they scan the
     // same launch order and take the envs the assemble launch marked; almost all of them exit at once)
@@ -200,7 +205,7 @@ static int pair_cap(int t1, int t2) {
 
 // Host-only derivation of the device model: packed tables, derived topology tables, capacities and the LDS
 // layout.  Needs no HIP device (mjh_query_lds_bytes uses it for capacity planning and in the CPU tests).
-struct HostPack { DModel M{}; Lay L{}; std::vector<int> I; std::vector<float> F; int o_controlled = 0, o_odom = 0, lds_bytes = 0; long long gstride = 0; };
+struct HostPack { DModel M{}; Lay L{}; std::vector<int> I; std::vector<float> F; int o_controlled = 0, o_odom = 0, lds_bytes = 0, lds_bytes_pre = 0; long long gstride = 0; };
 // Gauss-Seidel order of engines created afterwards (mjhip.h): 1 = mj_solPGS's own row order
 static int g_window_solver = getenv("MJH_WINDOW") ? (atoi(getenv("MJH_WINDOW")) != 0) : 1;
 extern "C" void mjh_set_window_solver(int on) { g_window_solver = on ? 1 : 0; }
@@ -408,6 +413,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       L.ext = (extsz <= k2_size && !keep) ? k1 : put(extsz);
       L.J = put((int)jsz); L.B = diagM ? L.J : put((int)jsz);
     }
+    hp.lds_bytes_pre = off * (int)sizeof(float);    // everything but the patch pool's own tail: what an assemble-only launch (window chain) touches
     if (patch) {
       // the pool: per patch of nr4 rows (a multiple of 4, at most 16) a record per row (20 floats between two bodies, 12 on one
       // body) + 16 floats per 4x4 tile of the lower triangle of AR: 16 .. 30 floats per row.  It takes the span of everything that
@@ -477,6 +483,11 @@ extern "C" int mjh_query_lds_bytes(const mjh_model* m) {
   HostPack hp; derive_fitting(m, hp);
   return hp.lds_bytes;
 }
+extern "C" int mjh_query_lds_bytes_assemble(const mjh_model* m) {   // ... of the assemble-only instance of the window chain (0: the model does not take it)
+  if (!m) return MJH_ERR_ARG;
+  HostPack hp; derive_fitting(m, hp);
+  return hp.M.window ? hp.lds_bytes_pre : 0;
+}
 
 extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream, mjh_engine** out) {
   if (!m || nenv <= 0 || !out) { mjh_set_error("mjh_create: bad argument"); return MJH_ERR_ARG; }
@@ -500,7 +511,7 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   e->model = m; e->nenv = nenv; e->device = device; e->stream = (hipStream_t)stream;
 
   HostPack hp; derive_fitting(m, hp);
-  e->M = hp.M; e->L = hp.L; e->lds_bytes = hp.lds_bytes; e->o_controlled = hp.o_controlled; e->o_odom = hp.o_odom;
+  e->M = hp.M; e->L = hp.L; e->lds_bytes = hp.lds_bytes; e->lds_bytes_pre = hp.lds_bytes_pre; e->o_controlled = hp.o_controlled; e->o_odom = hp.o_odom;
   DModel& M = e->M; std::vector<int>& I = hp.I; std::vector<float>& F = hp.F;
   e->hI = I;
   if (dev_alloc(e, &e->dI, I.size(), false) || dev_alloc(e, &e->dF, F.size(), false)) { mjh_destroy(e); return MJH_ERR_NO_DEVICE; }
