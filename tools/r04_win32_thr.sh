@@ -5,8 +5,8 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
-for thr in 0 104 96 88 80 64; do
- for c in 2 3; do
+for thr in 104 96 92 88 80; do
+ for c in 3; do
   MJH_WINDOW32=$thr timeout 300 python bench.py --config s24 --cohorts $c --no-extra-configs --no-cpu-baseline --no-second-window --steps 100 > $OUT/b_${thr}_${c}.json 2> $OUT/b_${thr}_${c}.err
   python - <<PY
 import json
