@@ -770,6 +770,8 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
         hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, st, (const int*)e->S.stats, e->d_order, g0, g1 - g0, dsel ? e->d_dense + 4 * g + (ep & 3) : (e->d_wn ? e->d_wn + g : (int*)nullptr), e->d_wn && !dsel ? -1 : e->M.dense_min_iter);
         if (dsel) {
           HIPCHK(hipEventRecord(e->ev_dense[g][ep & 3], st));
+          // (this wait bounds how far the host runs ahead of the device for such models: at most two rebuilds of the launch order,
+          //  2 x MJH_ORDER_EVERY steps per cohort — INTEGRATION.md §7a)
           if (ep >= 2) { HIPCHK(hipEventSynchronize(e->ev_dense[g][(ep - 2) & 3])); e->dense_now[g] = *(volatile int*)(e->h_dense + 4 * g + ((ep - 2) & 3)) != 0; }
           e->dense_epoch[g] = ep + 1;
         }
