@@ -3111,4 +3111,7 @@ DEV void mjh_solve_body(const DConst* __restrict__ C, const DState& S, int env0)
   if (tid == 0) meta[5] = niter;
 }
 template <bool DIAGM, bool EXTRA>
-__global__ __launch_bounds__(256) void mjh_solve_kernel(const DConst* __restrict__ C, const DState S, int env0) { mjh_solve_body<DIAGM, EXTRA>(C, S, env0); }
+#ifndef MJH_SOLVE_EU_WAVES
+#define MJH_SOLVE_EU_WAVES 1
+#endif
+__global__ __launch_bounds__(256, MJH_SOLVE_EU_WAVES) void mjh_solve_kernel(const DConst* __restrict__ C, const DState S, int env0) { mjh_solve_body<DIAGM, EXTRA>(C, S, env0); }

@@ -24,3 +24,7 @@ template __global__ void mjh_step_kernel<ONE_NROW, ONE_DIAGM, ONE_EXTRA, ONE_WPR
 #ifdef ONE_NW
 template __global__ void mjh_window_kernel<24, ONE_NW>(const DConst*, const DState, int, int, int, int, int);
 #endif
+#ifdef ONE_SOLVE
+template __global__ void mjh_solve_kernel<true, false>(const DConst*, const DState, int);
+template __global__ void mjh_solve_kernel<false, false>(const DConst*, const DState, int);
+#endif
