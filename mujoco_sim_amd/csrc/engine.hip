@@ -83,6 +83,7 @@ struct mjh_engine {
   bool timing = false; int timing_stride = 1; long timing_count = 0;   // every timing_stride-th step launch is bracketed
   std::vector<std::pair<hipEvent_t, hipEvent_t>> tev; size_t tev_used = 0;
   bool step1_done = false;
+  bool handover = false;        // window chain: the last step1 [+ inverse] launch left the hand-over mjh_step2 sweeps (dropped by any call that may change what it was built from)
   bool step1_pending = false;   // mjh_step1 has been called, its launch is deferred to the next entry point (fused with mjh_inverse if that is the one)
   // in-engine joint-space PD effort controller (mjh_set_pd_controller): ddq written on the device in front of every step
   float pd_kp = 0, pd_kd = 0; float* pd_target = nullptr; bool pd_on = false;
@@ -111,12 +112,17 @@ static int ensure_scratch(mjh_engine* e, size_t floats) {
 // ... or sites / sensors / mocap bodies / connect-weld equalities; and (engine state) Cartesian forces on bodies in use
 static bool extra_instance(const DModel& M) { return M.has_convex || M.noslip_iterations > 0 || M.nsensor > 0 || M.nmocap > 0 || M.has_weld; }
 
-static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps, int ph, int xflags) {
+// wmode (window chain of small free-body models): 0 the whole step; 1 the assemble launch only, every env handed over — the split API's
+// mjh_step1 [+ mjh_inverse] doing the work mjh_step2 would otherwise repeat (the rows only exist in LDS); 2 the window kernel only
+static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps, int ph, int xflags, int wmode = 0) {
   if (n <= 0) return MJH_OK;
   // window sweep (window_pgs.h): every launch that runs mj_step2 to the end (the fused step and the split API's step2) of a small
   // free-body model = assemble launch (PH_PRE), then four envs per wavefront through the sweeps and the integration
-  const bool window = e->M.window && e->S.wbuf && (ph & PH_STEP2) && !(ph & (PH_NOINT | PH_PRE | PH_POST)) && !(xflags & ~XF_FORCE);
+  const bool window = e->M.window && e->S.wbuf && (ph & PH_STEP2) && !(ph & (PH_NOINT | PH_PRE | PH_POST)) && !(xflags & ~(XF_FORCE | XF_DEFER));
   if (window) ph |= PH_PRE;
+  if (wmode && !window) { mjh_set_error("internal: window-chain launch mode on a launch that is not one"); return MJH_ERR_STATE; }
+  if (wmode == 1) xflags |= XF_DEFER;
+  if (wmode != 2) {
 #define MJH_LAUNCH2(NR, DG, CX) hipLaunchKernelGGL((mjh_step_kernel<NR, DG, CX>), dim3(n), dim3(64), (size_t)e->lds_bytes, st, e->dC, e->S, env0, nsteps, ph, xflags)
 #define MJH_LAUNCH(NR, DG) do { if (extra_instance(e->M) || e->S.xfrc_applied) MJH_LAUNCH2(NR, DG, true); else MJH_LAUNCH2(NR, DG, false); } while (0)
   const int nr = e->M.big ? 8 : (e->M.nv <= 16 ? 1 : (e->M.nv <= 32 ? 2 : 4));   // 8: many-body layout, running acceleration in LDS
@@ -136,7 +142,8 @@ static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps,
 #undef MJH_LAUNCH2
 #undef MJH_LAUNCH
   HIPCHK(hipGetLastError());
-  if (window) {
+  }
+  if (window && wmode != 1) {
     // LDS tier: windows beyond the register-resident ones, as many as leave four waves per CU (40 KB per wave)
     static const int nl_env = getenv("MJH_WN_NL") ? atoi(getenv("MJH_WN_NL")) : -1;      // (experiments: force the number of LDS-tier windows)
     // ... and none at all while no env of the cohort comes near the register-resident windows' rows: mjh_order_kernel leaves the cohort's
@@ -153,14 +160,15 @@ static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps,
     // 24-dof models: a first section of wavefronts sweeps the envs with many rows in 32-row windows, two per wavefront (they scan the
     // same launch order and take the envs the assemble launch marked; almost all of them exit at once)
     const int n32 = (e->S.win32 && e->M.win_nvt == 24) ? (n + 1) / 2 : 0;
-    if (e->M.win_nvt == 24) hipLaunchKernelGGL((mjh_window_kernel<24, WN_NW24>), dim3(n32 + (n + 3) / 4), dim3(64), lds, st, e->dC, e->S, env0, n, nl, xflags, n32);
-    else hipLaunchKernelGGL((mjh_window_kernel<32, WN_NW32>), dim3((n + 3) / 4), dim3(64), lds, st, e->dC, e->S, env0, n, nl, xflags, 0);
+    const int wxf = xflags & ~XF_DEFER;
+    if (e->M.win_nvt == 24) hipLaunchKernelGGL((mjh_window_kernel<24, WN_NW24>), dim3(n32 + (n + 3) / 4), dim3(64), lds, st, e->dC, e->S, env0, n, nl, wxf, n32);
+    else hipLaunchKernelGGL((mjh_window_kernel<32, WN_NW32>), dim3((n + 3) / 4), dim3(64), lds, st, e->dC, e->S, env0, n, nl, wxf, 0);
     HIPCHK(hipGetLastError());
   }
   return MJH_OK;
 }
 
-static int launch(mjh_engine* e, int env0, int n, int nsteps, int ph, int xflags) { return launch_on(e, e->stream, env0, n, nsteps, ph, xflags); }
+static int launch(mjh_engine* e, int env0, int n, int nsteps, int ph, int xflags, int wmode = 0) { return launch_on(e, e->stream, env0, n, nsteps, ph, xflags, wmode); }
 
 static int fork_cohorts(mjh_engine* e) {
   if (e->forked || e->ncohort <= 1) return MJH_OK;
@@ -652,7 +660,10 @@ extern "C" void mjh_destroy(mjh_engine* e) {
 static int flush_step1(mjh_engine* e);
 #define ENG_NOJOIN(e) if (!(e)) { mjh_set_error("null engine"); return MJH_ERR_ARG; } \
                       if (hipSetDevice((e)->device) != hipSuccess) { mjh_set_error("hipSetDevice failed"); return MJH_ERR_NO_DEVICE; } \
-                      if ((e)->step1_pending) { int rcf_ = flush_step1(e); if (rcf_) return rcf_; }
+                      if ((e)->step1_pending) { int rcf_ = flush_step1(e); if (rcf_) return rcf_; } \
+                      const bool mjh_ho_ = (e)->handover; (e)->handover = false; (void)mjh_ho_;
+// (entry points that cannot change what a pending window hand-over was built from — getters, mjh_set_cmd — put it back)
+#define KEEP_HANDOVER(e) (e)->handover = mjh_ho_;
 // every entry point except mjh_step first joins the cohort streams back into the caller's stream
 #define ENG(e) ENG_NOJOIN(e) { int rcj_ = join_cohorts(e); if (rcj_) return rcj_; }
 #define RANGE(e, env0, n) if ((env0) < 0 || (n) < 0 || (env0) + (n) > (e)->nenv) { mjh_set_error("env range out of bounds"); return MJH_ERR_ARG; }
@@ -662,7 +673,7 @@ static int flush_step1(mjh_engine* e);
 // With cohorts (mjh_set_cohorts > 1) the range is issued cohort by cohort on the cohort streams, like mjh_step: the reference's loop
 // reads and commands ONE environment between the calls (MjHWInterface::read / write, mj_main.cpp:86-106), and only that environment's
 // cohort has to wait for the host (mjh_get_joint_state / mjh_set_cmd on a range inside one cohort touch that cohort's stream only).
-static int launch_lpt(mjh_engine* e, int ph, int xflags, bool resort) {
+static int launch_lpt(mjh_engine* e, int ph, int xflags, bool resort, int wmode = 0) {
   const int G = e->ncohort > 1 && e->nenv >= 64 * e->ncohort ? e->ncohort : 1;
   static const bool split_cohorts = !(getenv("MJH_SPLIT_COHORTS") && atoi(getenv("MJH_SPLIT_COHORTS")) == 0);
   if (G > 1 && split_cohorts) {
@@ -682,7 +693,7 @@ static int launch_lpt(mjh_engine* e, int ph, int xflags, bool resort) {
       const size_t o = (size_t)g0 * e->M.nvp;
       e->S.x_bias = xb ? xb + o : nullptr; e->S.x_passive = xp ? xp + o : nullptr; e->S.x_smooth = xs ? xs + o : nullptr;
       e->S.x_constraint = xc ? xc + o : nullptr; e->S.x_energy = xe ? xe + 2 * (size_t)g0 : nullptr;
-      rc = launch_on(e, e->cstream[g], g0, g1 - g0, 1, ph, xflags);
+      e->cur_cohort = g; rc = launch_on(e, e->cstream[g], g0, g1 - g0, 1, ph, xflags, wmode); e->cur_cohort = -1;
     }
     if (sort) { e->order_G = G; e->order_valid = true; }
     return rc;
@@ -697,15 +708,26 @@ static int launch_lpt(mjh_engine* e, int ph, int xflags, bool resort) {
   }
   StateGuard guard(&e->S);
   if (e->lpt && e->d_order && e->order_valid) e->S.env_order = e->d_order;
-  return launch(e, 0, e->nenv, 1, ph, xflags);
+  return launch(e, 0, e->nenv, 1, ph, xflags, wmode);
 }
 static int launch_pd(mjh_engine* e, hipStream_t st, int env0, int n);
 // mjh_step1 defers its launch to the next entry point: the reference's loop calls MjHWInterface::read() = mj_inverse right behind
 // mj_step1 (mj_main.cpp:83-94), and step1 + inverse as ONE launch share the position and velocity stages (the literal loop's three
 // launches per step become two).  Any other entry point first issues the plain step1 launch (ENG / ENG_NOJOIN), so the order of
 // effects on the stream is the order of the calls.
+// Window chain (small free-body models): the split API's step1 [+ inverse] launch is the chain's ASSEMBLE launch — position and velocity
+// stages, controller, [mj_inverse,] and mj_step2's acceleration + constraint rows, handed over in the env's slice; qpos (normalised) and
+// qvel (after the controller's velocity override) are stored as mj_step1 leaves them, nothing is integrated — and mjh_step2 is the
+// window kernel alone, instead of a second pass over everything the rows need (they only ever exist in LDS).  What the reference's
+// loop does between the two (MjHWInterface::read: getters; write: mjh_set_cmd, consumed by the NEXT mj_step1) keeps the hand-over; any
+// other call that touches the engine in between drops it, and mjh_step2 runs the whole chain from the state it finds.
+static bool split_handover(const mjh_engine* e) {
+  static const bool on = !(getenv("MJH_SPLIT_HANDOVER") && atoi(getenv("MJH_SPLIT_HANDOVER")) == 0);
+  return on && e->M.window && e->S.wbuf != nullptr;
+}
 static int flush_step1(mjh_engine* e) {
   e->step1_pending = false;
+  if (split_handover(e)) { const int rc = launch_lpt(e, PH_STEP1 | PH_STEP2, XF_FORCE, true, 1); e->handover = rc == MJH_OK; return rc; }
   return launch_lpt(e, PH_STEP1, XF_FORCE, true);
 }
 extern "C" int mjh_step1(mjh_engine* e) {
@@ -720,6 +742,7 @@ extern "C" int mjh_inverse(mjh_engine* e) {
   if (e && e->step1_pending) {      // step1 + inverse in one launch
     if (hipSetDevice(e->device) != hipSuccess) { mjh_set_error("hipSetDevice failed"); return MJH_ERR_NO_DEVICE; }
     e->step1_pending = false;
+    if (split_handover(e)) { const int rc = launch_lpt(e, PH_STEP1 | PH_INV | PH_STEP2, XF_FORCE, true, 1); e->handover = rc == MJH_OK; return rc; }
     return launch_lpt(e, PH_STEP1 | PH_INV, XF_FORCE, true);
   }
   ENG_NOJOIN(e); return launch_lpt(e, PH_INV, XF_FORCE, false);
@@ -729,6 +752,7 @@ extern "C" int mjh_step2(mjh_engine* e) {
   if (!e->step1_done) { mjh_set_error("mjh_step2 called before mjh_step1"); return MJH_ERR_STATE; }
   e->step1_done = false;
   e->order_age++;
+  if (mjh_ho_) return launch_lpt(e, PH_STEP2, XF_FORCE, false, 2);
   return launch_lpt(e, PH_STEP2, XF_FORCE, false);
 }
 extern "C" int mjh_forward(mjh_engine* e) {
@@ -851,7 +875,7 @@ extern "C" int mjh_set_cohorts(mjh_engine* e, int n) { ENG(e); int rc = set_coho
 extern "C" int mjh_get_cohorts(const mjh_engine* e) { return e ? e->ncohort : 0; }
 extern "C" int mjh_set_steps_per_launch(mjh_engine* e, int n) { ENG(e); e->steps_per_launch = std::max(1, std::min(n, 64)); return MJH_OK; }
 extern "C" int mjh_get_steps_per_launch(const mjh_engine* e) { return !e ? 0 : ((!e->M.big && !e->M.diagM) ? e->steps_per_launch : 1); }
-extern "C" int mjh_synchronize(mjh_engine* e) { ENG(e); HIPCHK(hipStreamSynchronize(e->stream)); return MJH_OK; }
+extern "C" int mjh_synchronize(mjh_engine* e) { ENG(e); KEEP_HANDOVER(e); HIPCHK(hipStreamSynchronize(e->stream)); return MJH_OK; }
 
 // ---- host <-> device marshalling helpers (double on the host side, padded fp32 rows on the device)
 // rows of `width` floats at `stride` floats apart; only the `width` floats are touched (rows may be columns of a wider
@@ -892,7 +916,7 @@ static int get_rows(mjh_engine* e, const float* src, int stride, int width, int 
 }
 
 extern "C" int mjh_set_cmd(mjh_engine* e, int env0, int n, const double* ddq, const double* dq) {
-  ENG_NOJOIN(e); RANGE(e, env0, n);
+  ENG_NOJOIN(e); KEEP_HANDOVER(e); RANGE(e, env0, n);
   hipStream_t st;
   int rc = range_stream(e, env0, n, &st);
   if (rc) return rc;
@@ -973,7 +997,7 @@ extern "C" int mjh_set_odom_vel(mjh_engine* e, int env0, int n, const double* tw
 }
 
 extern "C" int mjh_get_joint_state(mjh_engine* e, int env0, int n, double* qpos, double* qvel, double* qfrc_inverse) {
-  ENG_NOJOIN(e); RANGE(e, env0, n);
+  ENG_NOJOIN(e); KEEP_HANDOVER(e); RANGE(e, env0, n);
   hipStream_t st;
   int rc = range_stream(e, env0, n, &st);
   if (rc || n == 0) return rc;
@@ -1018,7 +1042,7 @@ extern "C" int mjh_get_geom_state(mjh_engine* e, int env0, int n, double* gpos, 
 }
 
 extern "C" int mjh_get_state(mjh_engine* e, int env0, int n, double* time, double* qpos, double* qvel, double* ws) {
-  ENG(e); RANGE(e, env0, n);
+  ENG(e); KEEP_HANDOVER(e); RANGE(e, env0, n);
   int rc = MJH_OK;
   if (time && n) { HIPCHK(hipMemcpyAsync(time, e->S.time + env0, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }
   if (!rc) rc = get_rows(e, e->S.qpos, e->M.nqp, e->M.nq, env0, n, qpos);
@@ -1097,7 +1121,7 @@ extern "C" int mjh_transplant_state(mjh_engine* from, mjh_engine* to, int qpos_m
 }
 
 extern "C" int mjh_get_field(mjh_engine* e, const char* name, int env0, int n, double* out) {
-  ENG(e); RANGE(e, env0, n);
+  ENG(e); KEEP_HANDOVER(e); RANGE(e, env0, n);
   if (!name) return MJH_ERR_ARG;
   const std::string s(name);
   const int nvp = e->M.nvp, nv = e->M.nv;
@@ -1115,7 +1139,7 @@ extern "C" int mjh_get_field(mjh_engine* e, const char* name, int env0, int n, d
 }
 
 extern "C" int mjh_get_stats(mjh_engine* e, int env0, int n, int* out) {
-  ENG(e); RANGE(e, env0, n);
+  ENG(e); KEEP_HANDOVER(e); RANGE(e, env0, n);
   HIPCHK(hipMemcpyAsync(out, e->S.stats + (size_t)env0 * 4, (size_t)n * 4 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   for (int i = 0; i < n; i++) out[4*i + 3] &= 0xff;   // (bits 8.. : the kernel's cost hint for the launch order, not a flag)

@@ -989,7 +989,7 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
   // the window kernel takes) finishes the step in this launch and leaves 0 in its hand-over header
   bool wpre = false;
   if constexpr (DIAGM && NROW <= 2) wpre = M.window != 0 && M.patch != 0 && (ph & PH_PRE) && S.wbuf != nullptr;
-  if (wpre && lane == 0) ((int*)(S.wbuf + (size_t)env * (size_t)S.wstride))[0] = 0;
+  if (wpre && lane == 0) { int* wh0 = (int*)(S.wbuf + (size_t)env * (size_t)S.wstride); wh0[0] = 0; wh0[4] = 0; wh0[5] = 0; }
   if (post) for (int i = lane; i < nv; i += 64) s_qvel[i] = gs[L.g_qvel + i];     // (the controller may have overridden velocities)
   double time = S.time[env];
   // spawn/destroy as slot toggling: bit b set = body b is an INACTIVE slot in this env
@@ -2354,7 +2354,8 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
         if (lane == 0) { meta[0] = nefc == 0 ? 0 : nblk; meta[1] = nfixblk; meta[2] = nefc; meta[3] = ncon; meta[4] = flags; meta[5] = 0; meta[6] = ngrp; meta[7] = 0; }   // meta[7]: set by mjh_dense_build_kernel when the dense solver takes this env
         if (nefc == 0) return;
       }
-      if (nefc == 0) {
+      const bool wdefer = wpre && (xflags & XF_DEFER);       // (split API through the window chain: unconstrained envs are handed over as well)
+      if (nefc == 0 && !wdefer) {
         for (int d = lane; d < nv; d += 64) { s_qacc[d] = s_asmooth[d]; s_ws[d] = s_asmooth[d]; s_tmpv2[d] = 0; }
         WSYNC();
       } else {
@@ -2420,11 +2421,15 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
               float* wb = S.wbuf + (size_t)env * (size_t)S.wstride;
               const int nrow = window_emit(wb, M.win_nvt, s_blki_i, s_blkf, s_J, s_bias, nblk, lane, WPRE);
               if (WPRE && nefc > nrow) flags |= 2;          // (rows beyond the window kernel's capacity were dropped)
-              if (nrow > 0) {
+              if (nrow > 0 || wdefer) {
                 for (int d = lane; d < nv; d += 64) { wb[WN_AS + d] = s_qacc[d]; wb[WN_AWS + d] = s_tmpv2[d]; wb[WN_SINV + d] = s_bias[d]; wb[WN_QVEL + d] = s_qvel[d]; }
                 for (int i = lane; i < nq; i += 64) wb[WN_QPOS + i] = s_qpos[i];
+                if (wdefer) {     // what mj_step1 leaves in mjData for the calls between the two halves of the step (and for a later full mjh_step2)
+                  for (int i = lane; i < nq; i += 64) S.qpos[qrow + i] = s_qpos[i];
+                  for (int d = lane; d < nv; d += 64) { S.qvel[vrow + d] = s_qvel[d]; S.qvel_ref[vrow + d] = s_qvref[d]; S.qfrc_applied[vrow + d] = s_applied[d]; }
+                }
                 // [4]: the form the window kernel sweeps this env in — 32-row windows for many rows (window_pgs.h: wn_run32), a function of the env's own row count
-                if (lane == 0) { int* wh = (int*)wb; wh[0] = nrow; wh[1] = ncon; wh[2] = nefc; wh[3] = flags; wh[4] = (S.win32 > 0 && M.win_nvt == 24 && nrow > S.win32 && nrow <= 32 * WN32_NW) ? 1 : 0; }
+                if (lane == 0) { int* wh = (int*)wb; wh[0] = nrow; wh[1] = ncon; wh[2] = nefc; wh[3] = flags; wh[4] = (S.win32 > 0 && M.win_nvt == 24 && nrow > S.win32 && nrow <= 32 * WN32_NW) ? 1 : 0; wh[5] = (wdefer && nrow == 0) ? 1 : 0; }   // [5]: an env without rows that the window kernel integrates (split API)
                 return;
               }
               // (more rows than the window kernel takes: this env finishes the step here, in patch form)

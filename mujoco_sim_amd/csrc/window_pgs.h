@@ -403,8 +403,8 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
   float* const wb = S.wbuf + (size_t)env * (size_t)S.wstride;
   const int* const wh = (const int*)wb;
   const int nrow = (have && !(n32waves > 0 && wh[4] == 1)) ? wh[0] : 0;
-  if (__ballot(nrow > 0) == 0ull) return;
-  const bool mine = nrow > 0;        // (else: a row without an environment, or one that finished in the assemble launch — it must not write anything)
+  const bool mine = nrow > 0 || (have && wh[5] == 1);      // (else: a row without an environment, or one that finished in the assemble launch — it must not write anything; [5]: an env without rows handed over by the split API: integrated here)
+  if (__ballot(mine) == 0ull) return;
   const int nwin = (nrow + 15) >> 4;
   const int nwmax = max(max(__builtin_amdgcn_readlane(nwin, 0), __builtin_amdgcn_readlane(nwin, 16)), max(__builtin_amdgcn_readlane(nwin, 32), __builtin_amdgcn_readlane(nwin, 48)));
   const int nv = M.nv;

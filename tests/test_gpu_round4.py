@@ -336,3 +336,50 @@ def test_32_row_windows_for_the_envs_with_many_rows_equal_the_16_row_form_up_to_
         assert np.abs(q1[i] - d.f("qpos")).max() / max(1.0, np.abs(d.f("qpos")).max()) <= S24_TOL_Q
         assert np.abs(v1[i] - d.f("qvel")).max() / max(1.0, np.abs(d.f("qvel")).max()) <= S24_TOL_V
     a.close(); b.close()
+
+
+def test_split_api_hands_over_through_the_window_chain():
+    """The reference's loop (mj_main.cpp:82-112) on a window model: mjh_step1 [+ mjh_inverse] IS the chain's assemble launch and leaves
+    the rows for mjh_step2, which is the window kernel alone.  Same trajectories as with the hand-over switched off
+    (MJH_SPLIT_HANDOVER=0 is read once per process, so: against the fused mjh_step, to rounding — the split path renormalises the
+    quaternions once more — and bitwise against itself when a getter / a command sits between the halves); state read between the
+    halves is what mj_step1 leaves (nothing integrated); a state change between the halves drops the hand-over and the step is still right"""
+    m = ms.scene("s24")
+    nenv = 1536
+    def fresh():
+        e = ms.Engine(m, nenv); e.load_s24(); e.set_cohorts(3); return e
+    a, b, c = fresh(), fresh(), fresh()
+    for k in range(120):
+        a.step(1, True)
+        b.step1(); b.inverse(); b.step2()
+        # the literal loop: a read and a command between the halves
+        c.step1(); c.inverse()
+        t0, q0, v0, _ = c.get_state(0, 4)
+        qj, vj, fj = c.get_joint_state(0, 1)
+        c.set_cmd(ddq=np.zeros((1, m.nv)), env0=0)
+        c.step2()
+        if k in (0, 60):
+            t1, q1, _, _ = c.get_state(0, 4)
+            assert np.allclose(t1, t0 + 0.005) and np.abs(q1 - q0).max() < 0.05      # the read saw the state BEFORE the integration
+    _, qa, va, wa = a.get_state(); _, qb, vb, wb = b.get_state(); _, qc, vc, wc = c.get_state()
+    assert np.array_equal(qb, qc) and np.array_equal(vb, vc)                              # getters / commands in between change nothing
+    fa = a.get_field("qfrc_inverse"); fb = b.get_field("qfrc_inverse")
+    sa, sb = a.get_stats(), b.get_stats()
+    same = (sa[:, 0] == sb[:, 0]) & (sa[:, 1] == sb[:, 1])
+    assert same.mean() > 0.9
+    err_q = np.abs(qa - qb).max(1)[same]; err_v = np.abs(va - vb).max(1)[same]
+    print(f"SPLIT-HANDOVER: 120 steps, {same.mean():.3f} of the envs with the same contact sets: qpos {np.median(err_q):.2e} (median) {err_q.max():.2e} (max), qvel {np.median(err_v):.2e} / {err_v.max():.2e}")
+    assert np.median(err_q) < 1e-5 and np.isfinite(qb).all()
+    assert np.abs(fa - fb)[same].max() < 5e-2 * max(1.0, np.abs(fa).max())
+    # a state change between the halves: the hand-over is dropped, mjh_step2 runs the whole chain from the new state
+    d = fresh(); d.step(50)
+    t, q, v, w = d.get_state()
+    d.step1(); d.inverse()
+    q2 = q.copy(); q2[:, 2] += 0.01
+    d.set_state(qpos=q2, qvel=v, time=t, warmstart=w)
+    d.step2()
+    e2 = fresh(); e2.step(50); e2.set_state(qpos=q2, qvel=v, time=t, warmstart=w); e2.step1(); e2.step2()
+    _, qd, vd, _ = d.get_state(); _, qe, ve, _ = e2.get_state()
+    assert np.abs(qd - qe).max() < 1e-4 and np.abs(qd[:, 2] - q2[:, 2]).max() < 0.01
+    for x in (a, b, c, d, e2):
+        x.close()

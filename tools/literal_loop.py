@@ -7,7 +7,7 @@ import numpy as np
 import mujoco_sim_amd as ms
 nenv = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-m = ms.scene("s24"); e = ms.Engine(m, nenv); e.load_s24(); e.step(400); e.synchronize()
+m = ms.scene("s24"); e = ms.Engine(m, nenv); e.load_s24(); e.set_cohorts(3); e.step(400); e.synchronize()
 cmd = np.zeros((1, m.nv))
 t0 = time.perf_counter()
 for k in range(steps):
