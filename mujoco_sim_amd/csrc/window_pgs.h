@@ -83,7 +83,7 @@ DEV int window_emit(float* __restrict__ wb, const int nvt, const int* blki, cons
 
 // ---- the sweep kernel ----
 #ifndef WN_NW24
-#define WN_NW24 8       // register-resident windows of the 24-dof instance (128 rows; S24 has 72 on average), the rest is streamed
+#define WN_NW24 6       // register-resident windows of the 24-dof instance (96 rows: what the 16-row form meets with the 32-row section on; S24 has 72 on average), the rest is streamed
 #endif
 #ifndef WN_NW32
 #define WN_NW32 6
@@ -391,6 +391,23 @@ DEV void wn_run32(const DConst* __restrict__ C, const DState& S, const int env0,
 #undef WN32_FOR_WINDOWS
 }
 
+// a^ += J_a^T x_a + J_b^T x_b : two windows of the same 16 lanes, one transpose-reduce
+template <int NV> DEV void wn_jt2(const float* JA, const float xa, const float* JB, const float xb, float& a_lo, float& a_hi) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f xa2 = {xa, xa}, xb2 = {xb, xb};
+  float p[NV];
+#pragma unroll
+  for (int k = 0; k < NV; k += 2) {
+    const v2f pr = __builtin_elementwise_fma(v2f{JB[k], JB[k + 1]}, xb2, v2f{JA[k], JA[k + 1]} * xa2);     // v_pk_mul_f32, v_pk_fma_f32
+    p[k] = pr.x; p[k + 1] = pr.y;
+  }
+  a_lo += wn_fold16(p);
+  if constexpr (NV == 32) a_hi += wn_fold16(p + 16); else a_hi += wn_fold8(p + 16);
+}
+#define WN_XFMA(r, ar) "v_fmac_f32_dpp %[t], %[x], " ar " row_newbcast:" #r " row_mask:0xf bank_mask:0xf\n\t"
+#define WN_CROSS4A(r0, r1, r2, r3, T) asm volatile(WN_XFMA(r0, "%[a0]") WN_XFMA(r1, "%[a1]") WN_XFMA(r2, "%[a2]") WN_XFMA(r3, "%[a3]") \
+    : [t] "+v"(tt) : [x] "v"(dx), [a0] "v"(T.x), [a1] "v"(T.y), [a2] "v"(T.z), [a3] "v"(T.w))
+
 template <int NV, int NW>
 __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restrict__ C, const DState S, const int env0, const int nenv, const int nl, const int xflags, const int n32waves) {
   // the first n32waves wavefronts: the section of the envs with many rows (two per wavefront, 32-row windows); dispatched first
@@ -475,6 +492,29 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
   const int nwl = min(nwmax, NW + nl);
 #pragma unroll
   for (int w = 0; w < NW; w++) if (w < nwmax) { load_rows(win[w], w); make_tile(win[w]); }
+  // The register-resident windows are swept two at a time: window 2j + 1 takes its residual from the acceleration BEFORE window 2j's
+  // deltas plus the cross tile X_j[r] = (-1 / AR_qq) J^_{2j+1,q} . J^_{2j,r} times those deltas (16 broadcast multiply-adds), so that both
+  // windows' J^T delta go through ONE transpose-reduce: ~255 instead of 300 issue slots per 32 rows on every env's chain.  Same rows, same
+  // order, same row math; the grouping of the arithmetic differs (fp32 rounding).
+  static_assert(NW % 2 == 0, "register-resident windows are swept in pairs");
+  float4 X[NW / 2][4];
+#pragma unroll
+  for (int j = 0; j < NW / 2; j++) if (2 * j + 1 < nwmax) {
+    WnWin<NV>& A = win[2 * j]; WnWin<NV>& B = win[2 * j + 1];
+    float acx[16];
+#pragma unroll
+    for (int sidx = 0; sidx < 16; sidx++) acx[sidx] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) asm volatile("" : "+v"(A.J[k]), "+v"(B.J[k]));
+    asm volatile("s_nop 1");
+#define WN_ACX(sidx) _Pragma("unroll") for (int k = 0; k < NV; k++) PP_FMAC_BC(acx[sidx], A.J[k], B.J[k], sidx);
+    PP_BC16(WN_ACX)
+#undef WN_ACX
+    X[j][0] = make_float4(B.nw * acx[0], B.nw * acx[1], B.nw * acx[2], B.nw * acx[3]);
+    X[j][1] = make_float4(B.nw * acx[4], B.nw * acx[5], B.nw * acx[6], B.nw * acx[7]);
+    X[j][2] = make_float4(B.nw * acx[8], B.nw * acx[9], B.nw * acx[10], B.nw * acx[11]);
+    X[j][3] = make_float4(B.nw * acx[12], B.nw * acx[13], B.nw * acx[14], B.nw * acx[15]);
+  }
   for (int w = NW; w < nwl; w++) { WnWin<NV> W; load_rows(W, w); make_tile(W); store_ext(xl + (w - NW) * NX * 16, W, 0.0f); }
   for (int w = nwl; w < nwmax; w++) { WnWin<NV> W; load_rows(W, w); make_tile(W); if (mine) store_ext(xg + w * NX * 16, W, 0.0f); }
   // every window of the wave, register-resident ones first; the body sees the window W and its force fw
@@ -517,18 +557,59 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
   while (__ballot(act) != 0ull) {
     if (act) {
       int impl = 0;
-      WN_FOR_WINDOWS({
-        const float u = wn_dot<NV>(W.J, a_lo, a_hi);
-        const float fo = fw;
-        float tt = ((u - W.aref) + W.R * fo) * W.nw;
-        const float nf = -fo;
-        float dl;
-        PP_ROWS4(0, 1, 2, 3, W.A0); PP_ROWS4(4, 5, 6, 7, W.A1); PP_ROWS4(8, 9, 10, 11, W.A2); PP_ROWS4(12, 13, 14, 15, W.A3);
-        asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));
-        impl += imp_fixed((W.half * dl) * (2.0f * tt - dl), iq.qs);
-        fw = fo + dl;
-        wn_jt<NV>(W.J, dl, a_lo, a_hi);
-      });
+#define WN_SWEEP_ONE(W, fw) do { \
+        const float u = wn_dot<NV>(W.J, a_lo, a_hi); \
+        const float fo = fw; \
+        float tt = ((u - W.aref) + W.R * fo) * W.nw; \
+        const float nf = -fo; \
+        float dl; \
+        PP_ROWS4(0, 1, 2, 3, W.A0); PP_ROWS4(4, 5, 6, 7, W.A1); PP_ROWS4(8, 9, 10, 11, W.A2); PP_ROWS4(12, 13, 14, 15, W.A3); \
+        asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf)); \
+        impl += imp_fixed((W.half * dl) * (2.0f * tt - dl), iq.qs); \
+        fw = fo + dl; \
+        wn_jt<NV>(W.J, dl, a_lo, a_hi); } while (0)
+      // register-resident windows: pairs (see the cross tiles above), a last odd one alone
+#pragma unroll
+      for (int j = 0; j < NW / 2; j++) if (2 * j < nwmax) {
+        if (2 * j + 1 < nwmax) {
+          WnWin<NV>& A = win[2 * j]; WnWin<NV>& B = win[2 * j + 1];
+          const float ua = wn_dot<NV>(A.J, a_lo, a_hi), ub = wn_dot<NV>(B.J, a_lo, a_hi);
+          float dla, dlb;
+          {
+            const float fo = f[2 * j];
+            float tt = ((ua - A.aref) + A.R * fo) * A.nw;
+            const float nf = -fo;
+            float dl;
+            PP_ROWS4(0, 1, 2, 3, A.A0); PP_ROWS4(4, 5, 6, 7, A.A1); PP_ROWS4(8, 9, 10, 11, A.A2); PP_ROWS4(12, 13, 14, 15, A.A3);
+            asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));
+            impl += imp_fixed((A.half * dl) * (2.0f * tt - dl), iq.qs);
+            f[2 * j] = fo + dl; dla = dl;
+          }
+          {
+            const float fo = f[2 * j + 1];
+            float tt = ((ub - B.aref) + B.R * fo) * B.nw;
+            float dx = dla;
+            asm volatile("s_nop 1" : "+v"(dx));
+            WN_CROSS4A(0, 1, 2, 3, X[j][0]); WN_CROSS4A(4, 5, 6, 7, X[j][1]); WN_CROSS4A(8, 9, 10, 11, X[j][2]); WN_CROSS4A(12, 13, 14, 15, X[j][3]);
+            const float nf = -fo;
+            float dl;
+            PP_ROWS4(0, 1, 2, 3, B.A0); PP_ROWS4(4, 5, 6, 7, B.A1); PP_ROWS4(8, 9, 10, 11, B.A2); PP_ROWS4(12, 13, 14, 15, B.A3);
+            asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));
+            impl += imp_fixed((B.half * dl) * (2.0f * tt - dl), iq.qs);
+            f[2 * j + 1] = fo + dl; dlb = dl;
+          }
+          wn_jt2<NV>(A.J, dla, B.J, dlb, a_lo, a_hi);
+        } else { WnWin<NV>& W = win[2 * j]; WN_SWEEP_ONE(W, f[2 * j]); }
+      }
+      // the tiers beyond them: one window at a time
+      for (int w = NW; w < nwl; w++) { WnWin<NV> W; float* t = xl + (w - NW) * NX * 16; load_ext(t, W); float fw = t[16 * (NV + 20)]; WN_SWEEP_ONE(W, fw); t[16 * (NV + 20)] = fw; }
+      for (int w = nwl; w < nwmax; w++) {
+        WnWin<NV> W; float* t = xg + w * NX * 16; float fw = 0.0f;
+        if (mine) { load_ext(t, W); fw = t[16 * (NV + 20)]; } else { load_rows(W, WN_MAXW); W.A0 = W.A1 = W.A2 = W.A3 = make_float4(0, 0, 0, 0); W.nw = 0; W.half = 0; }
+        WN_SWEEP_ONE(W, fw);
+        if (mine) t[16 * (NV + 20)] = fw;
+      }
+#undef WN_SWEEP_ONE
       niter++;
       if (wn_rowsum_i(impl) < iq.thr || niter >= itmax) act = false;
     }
