@@ -59,3 +59,26 @@ def test_group_host_runs_in_one_process_without_a_launcher():
     assert r["value"] > 1e6 and r["config"]["envs_total"] == 2048
     r1 = _run(["--gpus", "1", "--host", "group", "--group-devices", "0", "--envs-per-gpu", "1024", "--steps", "12", "--warmup", "3"])
     assert r1["host"]["rccl"] is True and r1["host"]["rccl_ranks"] == 1, "one device: the publish goes through ncclAllGather (the 8-GPU code path)"
+
+
+def test_the_drivers_multi_gpu_invocation_runs_the_rccl_publish_path():
+    """The driver launches N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N ...`, one rank per GPU.  With the one GPU there is, the same launcher form with N = 1 (process group of one rank
+    over RCCL: init, barriers, the max-over-ranks reduction) and `--force-dist` (the 60 Hz publish as an all-gather on the
+    communication stream beside the steps): the line carries the ranks host record and the collective's timing."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "30", "--warmup", "6", "--force-dist", "--no-cpu-baseline", "--no-extra-configs", "--no-second-window"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["steps"] == 30 and j["value"] > 1e6 and j["scaling"] == "weak"
+    h = j["host"]
+    assert h["kind"] == "ranks" and h["rccl_ranks"] == 1 and h["ranks"] == [{"rank": 0, "env0": 0, "nenv": 4096}]
+    ag = h["all_gather"]
+    assert ag["count"] == 10 and ag["publish_every_steps"] == 3 and ag["bytes_per_rank"] == 4096 * (1 + 28 + 24) * 4 and 0 < ag["ms_mean"] < 50
