@@ -468,7 +468,10 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
 // few environments per CU (pr2 / tiago / hsrb4s / ridgeback_panda: 1.6x - 5x); a working set beyond one CU's LDS has no choice.
 //   policy 0 (default): many-body layout above MJH_LDS_RESIDENT_MAX bytes;  1: LDS-resident whenever it fits;  2: many-body whenever possible
 #define MJH_LDS_RESIDENT_MAX (24 * 1024)
-#define MJH_ORDER_EVERY 8
+// steps between renewals of a cohort's launch order.  The sort is one workgroup on the cohort's stream in front of a step: 6 us on an idle
+// chip, 74 us (S24) to 200 us (C2) beside the other cohorts' resident waves; an env's cost drifts slowly.  8 / 16 / 32 / 64 steps: S24
+// 11.29 / 11.46 / 11.52 / 11.40 M, C4 1.41 / 1.43 / 1.45 / 1.39 M, C2 0.541 / 0.545 / 0.546 / 0.544 M env-steps/s (tools/r04_order_every.sh)
+#define MJH_ORDER_EVERY 32
 static int g_layout_policy = 0;
 extern "C" void mjh_set_layout_policy(int policy) { g_layout_policy = policy < 0 || policy > 2 ? 0 : policy; }
 static void derive_fitting(const mjh_model* m, HostPack& hp) {
