@@ -578,10 +578,19 @@ def literal_loop_line(w, steps):
             e.get_joint_state(0, 1)
             e.set_cmd(ddq=cmd, dq=None, env0=0)
 
+    # This loop waits for the device once per step, so a pause of the HOST lands in the result whole: with torch imported a full
+    # pass of CPython's cycle collector takes 35-60 ms — as long as the timed window itself — and fell into the window of about
+    # every second run (tools/literal_bench_probe.py: median wait 0.36 ms, one wait of 36-59 ms).  The collector is run before and
+    # held off during the two windows, as around any latency measurement; a C++ host (the reference's loop) has none.
+    import gc
     literal(5); e.synchronize()                  # (first use of the split entry points: launch-order buffer, full-range sort)
-    t0 = time.perf_counter(); literal(steps); e.synchronize(); dt = time.perf_counter() - t0
-    fused(5); e.synchronize()
-    t0 = time.perf_counter(); fused(steps); e.synchronize(); dt2 = time.perf_counter() - t0
+    gc.collect(); gc_was = gc.isenabled(); gc.disable()
+    try:
+        t0 = time.perf_counter(); literal(steps); e.synchronize(); dt = time.perf_counter() - t0
+        fused(5); e.synchronize()
+        t0 = time.perf_counter(); fused(steps); e.synchronize(); dt2 = time.perf_counter() - t0
+    finally:
+        if gc_was: gc.enable()
     return {"value": w.nenv * steps / dt, "unit": "env-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "envs": w.nenv,
             "sequence": "mjh_step1 -> mjh_inverse + mjh_get_joint_state(env 0) -> mjh_set_cmd(env 0) -> mjh_step2 (2 launches — step1 + inverse fused —, 2 host transfers per step)",
             "fused_step_with_per_step_read_write": {"value": w.nenv * steps / dt2, "ms_per_step": dt2 / steps * 1e3}}
