@@ -692,7 +692,9 @@ static int launch_lpt(mjh_engine* e, int ph, int xflags, bool resort, int wmode 
     float* const xb = e->S.x_bias; float* const xp = e->S.x_passive; float* const xs = e->S.x_smooth; float* const xc = e->S.x_constraint; float* const xe = e->S.x_energy;
     for (int g = 0; g < G && !rc; g++) {
       const int g0 = (int)((long long)e->nenv * g / G), g1 = (int)((long long)e->nenv * (g + 1) / G);
-      if (sort) hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, e->cstream[g], (const int*)e->S.stats, e->d_order, g0, g1 - g0, (int*)nullptr, 0);
+      // (window models: the sort also leaves the cohort's largest row count for the window kernel's LDS-tier choice, as in mjh_step —
+      //  a host that only ever uses the split API would keep the tier of an engine that has seen nothing yet)
+      if (sort) hipLaunchKernelGGL(mjh_order_kernel, dim3(1), dim3(1024), 0, e->cstream[g], (const int*)e->S.stats, e->d_order, g0, g1 - g0, e->d_wn ? e->d_wn + g : (int*)nullptr, e->d_wn ? -1 : 0);
       const size_t o = (size_t)g0 * e->M.nvp;
       e->S.x_bias = xb ? xb + o : nullptr; e->S.x_passive = xp ? xp + o : nullptr; e->S.x_smooth = xs ? xs + o : nullptr;
       e->S.x_constraint = xc ? xc + o : nullptr; e->S.x_energy = xe ? xe + 2 * (size_t)g0 : nullptr;
