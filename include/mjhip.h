@@ -310,7 +310,10 @@ int mjh_synchronize(mjh_engine*);
 
 /* MjHWInterface::write (mj_hw_interface.cpp:73-91): ddq = effort command
  * (interpreted as desired acceleration), dq = velocity command; [n*nv] each,
- * either may be NULL.  Consumed (and zeroed, mj_sim.cpp:1075-1076) by the next step1. */
+ * either may be NULL.  Consumed (and zeroed, mj_sim.cpp:1075-1076) by the next step1.
+ * The buffers are read before the call returns; a call of at most 4096 values goes through a
+ * host-mapped staging ring and does not wait for the device (stream-ordered in front of the
+ * range's next step launch), larger ones copy and wait. */
 int mjh_set_cmd(mjh_engine*, int env0, int n, const double* ddq, const double* dq);
 /* In-engine joint-space PD effort controller for ALL environments.  The reference closes this loop on the host for its one
  * environment: read() -> controller_manager->update() -> write() (mj_main.cpp:86-106) with ros_control effort controllers
@@ -329,7 +332,9 @@ int mjh_set_odom_dofs(mjh_engine*, const int lin_dof[3], const int ang_dof[3],
                       const int ang_qpos[3]);
 int mjh_set_odom_vel(mjh_engine*, int env0, int n, const double* twist);
 
-/* MjHWInterface::read (mj_hw_interface.cpp:62-70) */
+/* MjHWInterface::read (mj_hw_interface.cpp:62-70): waits for the steps queued on the range's
+ * stream (one cohort's, if the range lies inside a cohort); up to 16384 values are packed by one
+ * small kernel into host-mapped memory (one synchronisation), larger ranges take strided copies */
 int mjh_get_joint_state(mjh_engine*, int env0, int n, double* qpos, double* qvel,
                         double* qfrc_inverse);
 /* d->xpos / d->xquat readers (mj_ros.cpp:2100-2147) */

@@ -2,6 +2,8 @@
 projected Gauss-Seidel in mj_solPGS's row order over windows of 16 consecutive rows, four envs per wavefront) against the fused
 kernel's contact-patch sweep and against the oracle; S24D (the "30-contact" reading of the metric: 140 rows per env, windows streamed
 beyond the register-resident ones) teacher-forced like S24; the independent check of the project's own box-box manifold."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,6 +13,7 @@ from helpers import oracle_s24
 from test_gpu_teacher_forced import teacher_forced, summarize, S24_TOL_Q, S24_TOL_V
 
 pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _engine(m, nenv, window, load=None):
@@ -383,3 +386,49 @@ def test_split_api_hands_over_through_the_window_chain():
     assert np.abs(qd - qe).max() < 1e-4 and np.abs(qd[:, 2] - q2[:, 2]).max() < 0.01
     for x in (a, b, c, d, e2):
         x.close()
+
+
+def test_per_step_read_write_through_host_mapped_staging_equals_the_copy_path():
+    """MjHWInterface::read / write of a few envs per step (mj_hw_interface.cpp:59-91) go through host-mapped staging — one small kernel
+    per call, mjh_set_cmd without waiting for the device, a ring of 8 slots — and whole-batch calls through strided copies: same
+    values on the device and back.  Arm7 (C3's model) with a PD effort command per env: engine A is commanded env by env (40 calls per
+    step: the ring wraps five times without a synchronisation in between) with both ddq and dq of some envs, engine B with two
+    whole-batch calls; read back in small ranges and as a whole."""
+    g = np.load(os.path.join(G, "arm7_golden.npz"))
+    m = ms.scene("arm7", 1)
+    nenv = 2048                                        # 2048 x 7 values: beyond the staging slot, the copy path
+    rng = np.random.default_rng(4)
+    q0 = np.tile(g["q0"], (nenv, 1)) + rng.uniform(-0.05, 0.05, size=(nenv, m.nq))
+    def fresh():
+        e = ms.Engine(m, nenv); e.set_initial_qpos(q0); e.reset(); e.set_controlled_dofs(np.ones(7, dtype=np.int32)); e.set_cohorts(3); return e
+    a, b = fresh(), fresh()
+    envs = np.sort(rng.choice(nenv, 40, replace=False))
+    for s in range(30):
+        qa, va, _ = a.get_joint_state(); qb, vb, _ = b.get_joint_state()
+        assert np.array_equal(qa, qb) and np.array_equal(va, vb)
+        ddq = np.zeros((nenv, 7)); dq = np.zeros((nenv, 7))
+        ddq[envs] = 200.0 * (g["target"] - qa[envs]) - 50.0 * va[envs]
+        dq[envs[::4], 6] = 0.3                         # a velocity command on the last joint of every fourth of them
+        for i in envs:
+            if i in envs[::4]: a.set_cmd(ddq=ddq[i:i+1], dq=dq[i:i+1], env0=int(i))
+            else: a.set_cmd(ddq=ddq[i:i+1], env0=int(i))
+        b.set_cmd(ddq=ddq, dq=dq)
+        if s % 2: a.step(1, True); b.step(1, True)
+        else:
+            for x in (a, b): x.step1(); x.inverse()
+            if s == 0:      # between the halves: the velocity command has overridden qvel of the controlled dof (mj_sim.cpp:1066-1070)
+                for i in envs[::4]:
+                    assert a.get_joint_state(int(i), 1)[1][0, 6] == np.float32(0.3) == b.get_joint_state(int(i), 1)[1][0, 6]
+                assert np.abs(a.get_joint_state(int(envs[1]), 1)[1][0, 6]) < 0.05
+            for x in (a, b): x.step2()
+        # small ranges (staging) against the whole batch (copies), on either engine
+        k = int(envs[s % len(envs)]); k = min(k, nenv - 3)
+        q3, v3, f3 = a.get_joint_state(k, 3); qw, vw, fw = b.get_joint_state()
+        assert np.array_equal(q3, qw[k:k+3]) and np.array_equal(v3, vw[k:k+3]) and np.array_equal(f3, fw[k:k+3])
+        q1, v1, f1 = b.get_joint_state(k, 1)
+        assert np.array_equal(q1, qw[k:k+1]) and np.array_equal(f1, fw[k:k+1])
+    qa, va, fa = a.get_joint_state(); qb, vb, fb = b.get_joint_state()
+    assert np.array_equal(qa, qb) and np.array_equal(va, vb) and np.array_equal(fa, fb)
+    moved = np.abs(qa[envs] - q0[envs]).max(1)
+    assert moved.min() > 1e-3 and np.isfinite(qa).all()          # the commanded envs did follow their commands
+    a.close(); b.close()
