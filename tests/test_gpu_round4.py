@@ -432,3 +432,38 @@ def test_per_step_read_write_through_host_mapped_staging_equals_the_copy_path():
     moved = np.abs(qa[envs] - q0[envs]).max(1)
     assert moved.min() > 1e-3 and np.isfinite(qa).all()          # the commanded envs did follow their commands
     a.close(); b.close()
+
+
+_TIER_SCRIPT = r'''
+import sys, os, hashlib
+sys.path.insert(0, os.path.join(sys.argv[1], "tests")); sys.path.insert(0, sys.argv[1])
+import numpy as np
+import test_gpu_round4 as T
+m, e, tab = T._s24d(768)
+e.set_cohorts(3); e.step(260); e.synchronize()
+_, q, v, w = e.get_state(); st = e.get_stats()
+print("TIER", hashlib.sha256(q.tobytes() + v.tobytes() + w.tobytes() + st[:, :3].tobytes()).hexdigest(), int(st[:, 1].max()), int((st[:, 1] > 96).sum()))
+'''
+
+
+def test_window_tiers_hold_the_same_values_wherever_a_window_waits():
+    """mjh_window_kernel keeps six windows of an env in registers; the later ones wait in LDS (as many as the launch was given) or in the
+    env's global slice.  The host picks the LDS tier's size from an UNSYNCHRONISED hint (the cohort's largest row count of some steps
+    ago, engine.hip launch_on) — allowed only because the choice changes where a window waits, never what is computed.  S24D (up to 16
+    windows per env) with the LDS tier forced off (MJH_WN_NL=0: everything beyond the registers in global memory), forced to 3 and to
+    its full size, and chosen by the hint (default): the same bits after 260 steps.  MJH_WN_NL is read once per process: subprocesses."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for nl in ("default", "0", "3", "10"):
+        env = dict(os.environ)
+        env.pop("MJH_WN_NL", None)
+        if nl != "default":
+            env["MJH_WN_NL"] = nl
+        r = subprocess.run([sys.executable, "-c", _TIER_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("TIER ")]
+        assert r.returncode == 0 and lines, r.stderr[-2000:]
+        out[nl] = lines[-1].split()
+    print("WINDOW-TIERS:", {k: (v[1][:12], v[2], v[3]) for k, v in out.items()})
+    assert int(out["default"][2]) > 128 and int(out["default"][3]) > 100        # envs beyond the register-resident windows and the 32-row section
+    assert len({v[1] for v in out.values()}) == 1, out
