@@ -207,6 +207,9 @@ __global__ __launch_bounds__(DN_BUILD_THREADS) void mjh_dense_build_kernel(const
 }
 
 // ------------------------------------------------------------------------------------------------ sweeps
+#ifndef DN_GROUP_ROWS
+#define DN_GROUP_ROWS(K) 16
+#endif
 template <int K> struct DnCol { float v[K]; };
 template <int K> DEV DnCol<K> dn_load(const __amdgpu_buffer_rsrc_t rs, const unsigned voff, const int soff) {
   DnCol<K> c;
@@ -230,12 +233,17 @@ template <int K> DEV DnCol<K> dn_load(const __amdgpu_buffer_rsrc_t rs, const uns
 template <int K>
 DEV int dn_sweeps(const __amdgpu_buffer_rsrc_t rs, const int art_bytes, const int nr32, const int itmax, const float tol, const float scale,
                   float* f, float* s, const float* lo, const float* hi, const float* arr, const int lane) {
-  const int G = nr32 >> 4;
+  // K = 3 (129 - 192 rows, the slowest envs of a C4 launch): groups of 32 rows — twice the bytes in flight per wave.  A sweep over an odd
+  // number of groups gets one idle slot at its end, in which the first group of the next sweep is requested (buffer parity stays static).
+  constexpr int GR = DN_GROUP_ROWS(K);
+  static_assert(GR == 16 || GR == 32, "groups must tile the 32-row padding of the sweep (rows beyond it are not initialised)");
+  constexpr int GPK = 64 / GR;
+  const int G = nr32 / GR, GE = (G + 1) & ~1;
   const unsigned voff = (unsigned)lane * (unsigned)(4 * K);
   constexpr int ROWB = 64 * K * 4;                       // bytes per row of AR'
-  DnCol<K> buf[2][16];
+  DnCol<K> buf[2][GR];
 #pragma unroll
-  for (int r = 0; r < 16; r++) buf[0][r] = dn_load<K>(rs, voff, art_bytes + r * ROWB);
+  for (int r = 0; r < GR; r++) buf[0][r] = dn_load<K>(rs, voff, art_bytes + r * ROWB);
   int niter = 0;
   for (;;) {
     float sv[K];
@@ -247,32 +255,47 @@ DEV int dn_sweeps(const __amdgpu_buffer_rsrc_t rs, const int art_bytes, const in
 #pragma unroll
     for (int k = 0; k < K; k++) {
 #pragma unroll
-      for (int gg = 0; gg < 4; gg++) {
-        const int g = 4 * k + gg;
-        if (g < G) {
-          const int gn = g + 1 < G ? g + 1 : 0;
-          int sb = art_bytes + gn * 16 * ROWB; asm volatile("" : "+s"(sb));
+      for (int gg = 0; gg < GPK; gg++) {
+        const int g = GPK * k + gg;
+        if (g < GE) {
+          const int gn = g + 1 < GE ? g + 1 : 0;
+          if (gn < G) {
+#ifdef DN_PROBE_SAMEGROUP     // timing probe (tools/r04_dense_probe.sh): every fetch aimed at the first group — a near cache; results are garbage
+            int sb = art_bytes; asm volatile("" : "+s"(sb));
+#else
+            int sb = art_bytes + gn * GR * ROWB; asm volatile("" : "+s"(sb));
+#endif
 #pragma unroll
-          for (int r = 0; r < 16; r++) buf[(gg + 1) & 1][r] = dn_load<K>(rs, voff, sb + r * ROWB);
-          unsigned long long mask = m1 << (16 * gg);
+            for (int r = 0; r < GR; r++) buf[(g + 1) & 1][r] = dn_load<K>(rs, voff, sb + r * ROWB);
+          }
+          if (g < G) {
+            unsigned long long mask = m1 << (GR * gg);
 #pragma unroll
-          for (int r = 0; r < 16; r++) {
-            const int l = 16 * gg + r;
-            const float fn = __builtin_amdgcn_fmed3f(s[k], lo[k], hi[k]);
-            const float d = fn - f[k];
-            const float sd = readlane_f(d, l);
-            const bool me = __builtin_amdgcn_inverse_ballot_w64(mask);     // lane l: v_cndmask on a scalar mask, no compare
-            mask <<= 1;
-            sv[k] = me ? s[k] : sv[k];            // (f itself is not touched inside the sweep: a row is visited once, its new force is med3 of sv)
-            // (pairs of the lane's rows in one v_pk_fma_f32: 2 instead of 3 instructions at K = 3)
-            typedef float dn_f2 __attribute__((ext_vector_type(2)));
+            for (int r = 0; r < GR; r++) {
+              const int l = GR * gg + r;
+              const float fn = __builtin_amdgcn_fmed3f(s[k], lo[k], hi[k]);
+              const float d = fn - f[k];
+              const float sd = readlane_f(d, l);
+              const bool me = __builtin_amdgcn_inverse_ballot_w64(mask);     // lane l: v_cndmask on a scalar mask, no compare
+              mask <<= 1;
+              sv[k] = me ? s[k] : sv[k];            // (f itself is not touched inside the sweep: a row is visited once, its new force is med3 of sv)
+              if constexpr (K == 3 && GR == 32) {
+                // (three plain multiply-adds: the pair form wants its operands in aligned register pairs, which a 96-bit fetch does not
+                //  deliver — with 32-row buffers the copies cost 120 registers)
 #pragma unroll
-            for (int j = 0; j + 1 < K; j += 2) {
-              const dn_f2 c2 = {buf[gg & 1][r].v[j], buf[gg & 1][r].v[j + 1]}, d2 = {sd, sd}, s2 = {s[j], s[j + 1]};
-              const dn_f2 o2 = __builtin_elementwise_fma(c2, d2, s2);
-              s[j] = o2.x; s[j + 1] = o2.y;
+                for (int j = 0; j < K; j++) s[j] = __builtin_fmaf(buf[g & 1][r].v[j], sd, s[j]);
+              } else {
+                // (pairs of the lane's rows in one v_pk_fma_f32: 2 instead of 3 instructions at K = 3)
+                typedef float dn_f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int j = 0; j + 1 < K; j += 2) {
+                  const dn_f2 c2 = {buf[g & 1][r].v[j], buf[g & 1][r].v[j + 1]}, d2 = {sd, sd}, s2 = {s[j], s[j + 1]};
+                  const dn_f2 o2 = __builtin_elementwise_fma(c2, d2, s2);
+                  s[j] = o2.x; s[j + 1] = o2.y;
+                }
+                if (K & 1) s[K - 1] = __builtin_fmaf(buf[g & 1][r].v[K - 1], sd, s[K - 1]);
+              }
             }
-            if (K & 1) s[K - 1] = __builtin_fmaf(buf[gg & 1][r].v[K - 1], sd, s[K - 1]);
           }
         }
       }
@@ -281,6 +304,81 @@ DEV int dn_sweeps(const __amdgpu_buffer_rsrc_t rs, const int art_bytes, const in
     float imp = 0;
 #pragma unroll
     for (int k = 0; k < K; k++) {      // -delta (res + AR delta / 2), res = -t AR, t = s - f at the row's visit
+      const float fn = __builtin_amdgcn_fmed3f(sv[k], lo[k], hi[k]), dc = fn - f[k];
+      imp += dc * arr[k] * ((sv[k] - f[k]) - 0.5f * dc);
+      f[k] = fn;
+    }
+    const float improvement = wave_sum<4>(imp);
+    if (improvement * scale < tol || niter >= itmax) break;
+  }
+  return niter;
+}
+
+// The same sweeps with the lane's part of AR' RESIDENT in registers (K <= 2: up to 128 rows, 64 K floats per lane): fetched once,
+// no memory operand inside the sweeps.  What the streamed form above waits for is its column fetch (768 B per row and wave through the
+// CU's vector-memory path, every sweep again — tools/r04_dense_probe.sh), so the envs that fit (the mean env: 107 rows) stop competing
+// for that path with the ones that do not (129+ rows: the launch's slowest).  Same rows, same order, same arithmetic: bitwise the
+// streamed form's iterates.
+#ifndef DN_RESIDENT_MAXK
+#define DN_RESIDENT_MAXK 2
+#endif
+template <int K>
+DEV int dn_sweeps_resident(const __amdgpu_buffer_rsrc_t rs, const int art_bytes, const int nr32, const int itmax, const float tol, const float scale,
+                           float* f, float* s, const float* lo, const float* hi, const float* arr, const int lane) {
+  const int G = nr32 >> 4;
+  const unsigned voff = (unsigned)lane * (unsigned)(4 * K);
+  constexpr int ROWB = 64 * K * 4;                       // bytes per row of AR'
+  DnCol<K> A[64 * K];
+#pragma unroll
+  for (int g = 0; g < 4 * K; g++) {
+    if (g < G) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) A[16 * g + r] = dn_load<K>(rs, voff, art_bytes + (16 * g + r) * ROWB);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+#pragma unroll
+        for (int j = 0; j < K; j++) A[16 * g + r].v[j] = 0.0f;
+    }
+  }
+  int niter = 0;
+  for (;;) {
+    float sv[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) sv[k] = s[k];
+    unsigned long long m1 = 1ull; asm volatile("" : "+s"(m1));
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+#pragma unroll
+      for (int gg = 0; gg < 4; gg++) {
+        const int g = 4 * k + gg;
+        if (g < G) {
+          unsigned long long mask = m1 << (16 * gg);
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int l = 16 * gg + r;
+            const float fn = __builtin_amdgcn_fmed3f(s[k], lo[k], hi[k]);
+            const float d = fn - f[k];
+            const float sd = readlane_f(d, l);
+            const bool me = __builtin_amdgcn_inverse_ballot_w64(mask);
+            mask <<= 1;
+            sv[k] = me ? s[k] : sv[k];
+            typedef float dn_f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int j = 0; j + 1 < K; j += 2) {
+              const dn_f2 c2 = {A[16 * g + r].v[j], A[16 * g + r].v[j + 1]}, d2 = {sd, sd}, s2 = {s[j], s[j + 1]};
+              const dn_f2 o2 = __builtin_elementwise_fma(c2, d2, s2);
+              s[j] = o2.x; s[j + 1] = o2.y;
+            }
+            if (K & 1) s[K - 1] = __builtin_fmaf(A[16 * g + r].v[K - 1], sd, s[K - 1]);
+          }
+        }
+      }
+    }
+    niter++;
+    float imp = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
       const float fn = __builtin_amdgcn_fmed3f(sv[k], lo[k], hi[k]), dc = fn - f[k];
       imp += dc * arr[k] * ((sv[k] - f[k]) - 0.5f * dc);
       f[k] = fn;
@@ -303,7 +401,9 @@ DEV void dn_solve_env(const DModel& M, const Lay& L, float* gs, const __amdgpu_b
   const float scale = 1.0f / (M.meaninertia * (float)(M.nv > 1 ? M.nv : 1));
 #pragma unroll
   for (int k = 0; k < K; k++) t[k] += f[k];                  // s = f + t
-  const int niter = dn_sweeps<K>(rs, 4 * o.art, nr32, M.iterations, M.tolerance, scale, f, t, lo, hi, arr, lane);
+  int niter;
+  if constexpr (K <= DN_RESIDENT_MAXK) niter = dn_sweeps_resident<K>(rs, 4 * o.art, nr32, M.iterations, M.tolerance, scale, f, t, lo, hi, arr, lane);
+  else niter = dn_sweeps<K>(rs, 4 * o.art, nr32, M.iterations, M.tolerance, scale, f, t, lo, hi, arr, lane);
   // forces back into the block records (the integrate launch forms qfrc_constraint from them), force changes to LDS
   const int* rmap = (const int*)(gs + o.rmap);
   float* g_bf = gs + (-1 - L.blkf);
@@ -318,12 +418,32 @@ DEV void dn_solve_env(const DModel& M, const Lay& L, float* gs, const __amdgpu_b
   const int nv = M.nv, nvs = M.dense_nvs;
   const float* g_yd = gs + o.yd;
   float q0 = 0.0f, q1 = 0.0f;
+  // (eight rows per round, their fetches issued together: one row per round with a branch on df was a chain of nefc dependent
+  //  round trips to L2 / HBM — 100+ us per env, every env; a zero df adds an exact zero, rows are summed in the same order)
+#ifdef DN_TAIL_SERIAL
   for (int p = 0; p < nefc; p++) {
     const float df = s_df[p];
     if (df == 0.0f) continue;
     if (lane < nvs) q0 += g_yd[p * nvs + lane] * df;
     if (lane + 64 < nvs) q1 += g_yd[p * nvs + lane + 64] * df;
   }
+#else
+  const bool c0 = lane < nvs, c1 = lane + 64 < nvs;
+  for (int p0 = 0; p0 < nefc; p0 += 8) {
+    float y0[8], y1[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int p = p0 + j < nefc ? p0 + j : nefc - 1;
+      y0[j] = c0 ? g_yd[p * nvs + lane] : 0.0f;
+      y1[j] = c1 ? g_yd[p * nvs + lane + 64] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const float df = p0 + j < nefc ? s_df[p0 + j] : 0.0f;
+      q0 += y0[j] * df; q1 += y1[j] * df;
+    }
+  }
+#endif
   if (lane < nv) s_x[lane] = q0 * gs[L.g_minv + lane];
   if (lane + 64 < nv) s_x[lane + 64] = q1 * gs[L.g_minv + lane + 64];
   __syncthreads();
