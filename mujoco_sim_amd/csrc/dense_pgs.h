@@ -208,7 +208,7 @@ __global__ __launch_bounds__(DN_BUILD_THREADS) void mjh_dense_build_kernel(const
 
 // ------------------------------------------------------------------------------------------------ sweeps
 #ifndef DN_GROUP_ROWS
-#define DN_GROUP_ROWS(K) 16
+#define DN_GROUP_ROWS(K) ((K) == 3 ? 32 : 16)     // rows per fetch group of the streamed sweeps (dn_sweeps)
 #endif
 template <int K> struct DnCol { float v[K]; };
 template <int K> DEV DnCol<K> dn_load(const __amdgpu_buffer_rsrc_t rs, const unsigned voff, const int soff) {
