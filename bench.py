@@ -640,7 +640,7 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} under a launcher with WORLD_SIZE={world}: start it with --nproc-per-node {args.gpus}, or plainly")
     if args.rank_probe:
-        print(f"RANKPROBE {rank} {world} {local_rank}", flush=True)
+        os.write(1, f"RANKPROBE {rank} {world} {local_rank}\n".encode())      # (one write: two ranks share the pipe)
         return
 
     import torch

@@ -1,6 +1,7 @@
 """CPU tests of bench.py's host logic: the plain `--gpus N` invocation becomes an N-rank launch, the usable-core count, and the
 cpu_baseline leg (oracle timed on a team of spinning threads: thread-scaling table, >= 256 env-steps behind the 1-thread figure)."""
 import os
+import re
 import subprocess
 import sys
 
@@ -25,7 +26,7 @@ def test_plain_multi_gpu_invocation_spawns_one_rank_per_gpu():
         if r.returncode == 0:
             break
     assert r.returncode == 0, r.stderr[-2000:]
-    probes = sorted(l.split()[1:] for l in r.stdout.splitlines() if l.startswith("RANKPROBE"))
+    probes = sorted(list(t) for t in re.findall(r"RANKPROBE (\d+) (\d+) (\d+)", r.stdout))
     assert probes == [["0", "2", "0"], ["1", "2", "1"]], r.stdout
 
 
