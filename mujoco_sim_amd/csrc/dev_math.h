@@ -152,14 +152,19 @@ DEV int wave_sum_dpp_i(int v) {
 // terms sum to less than 1), clamped to +-2 (a single term of 2 decides the test) and counted in units of 2^-MJH_IMP_BITS.  Integer
 // addition is associative: the total does not depend on the order in which a schedule visits independent blocks, which float
 // addition would (a sequential sweep and a side-by-side schedule of the same Gauss-Seidel order must stop after the same sweep).
-#define MJH_IMP_BITS 18     // 2048 blocks x 2 x 2^18 < 2^31
-DEV int imp_fixed(const float decrease, const float qscale) {   // qscale = scale / tolerance * 2^MJH_IMP_BITS
-  return (int)__builtin_amdgcn_fmed3f(decrease * qscale, -(float)(2 << MJH_IMP_BITS), (float)(2 << MJH_IMP_BITS));
+#define MJH_IMP_BITS 18     // 2048 terms x 2 x 2^18 < 2^31; sweeps over more terms count in coarser units (imp_quantum: nterms)
+DEV int imp_fixed(const float decrease, const float qscale, const float clampv = (float)(2 << MJH_IMP_BITS)) {   // qscale = scale / tolerance * 2^bits
+  return (int)__builtin_amdgcn_fmed3f(decrease * qscale, -clampv, clampv);
 }
-struct ImpQ { float qs; int thr; };     // thr: the sweep has converged when the fixed-point total is below it
-DEV ImpQ imp_quantum(const float scale, const float tol) {      // tolerance 0: never converged (the float test improvement * scale < 0 never holds either)
+struct ImpQ { float qs; int thr; float cl; };     // thr: the sweep has converged when the fixed-point total is below it; cl: the clamp of one term (2 units)
+// nterms: an upper bound of the terms one sweep adds up (blocks of the env).  Up to 2047 the unit is 2^-18, beyond it the unit grows so
+// that nterms terms, every one at the clamp, still fit 31 bits (a many-body model with thousands of active blocks: the int32 total must
+// not wrap in the first sweeps, when every term sits at the clamp)
+DEV ImpQ imp_quantum(const float scale, const float tol, const int nterms = 0) {      // tolerance 0: never converged (the float test improvement * scale < 0 never holds either)
   ImpQ q; const bool on = tol > 0.0f;
-  q.qs = on ? scale / tol * (float)(1 << MJH_IMP_BITS) : 0.0f; q.thr = on ? (1 << MJH_IMP_BITS) : (int)0x80000000;
+  int bits = MJH_IMP_BITS;
+  if (nterms >= 2048) { bits = 29 - (32 - __builtin_clz((unsigned)nterms)); if (bits < 2) bits = 2; }
+  q.qs = on ? scale / tol * (float)(1 << bits) : 0.0f; q.thr = on ? (1 << bits) : (int)0x80000000; q.cl = (float)(2 << bits);
   return q;
 }
 DEV bool wave_any(bool p) { return __ballot(p) != 0ull; }

@@ -121,6 +121,7 @@ enum { PH_STEP1 = 1, PH_INV = 2, PH_STEP2 = 4, PH_NOINT = 8, PH_FKONLY = 16, PH_
 enum { XF_BODY = 1, XF_GEOM = 2, XF_CON = 4, XF_FORCE = 8, XF_PROF = 16,
        XF_NOSTORE = 32,     // read-only launch: nothing of the env's state, statistics or time is written back
        XF_DENSE = 64,
+       XF_SPLIT2 = 256,     // window kernel behind a step2-only launch (split API): what mj_checkAcc's reset clears besides the state (qfrc_applied) is cleared as the fused kernel's step2 does
        XF_DEFER = 128 };    // window chain, assemble launch of the split API (mjh_step1 [+ mjh_inverse]): EVERY env is handed over to the window kernel (unconstrained ones too: nothing is integrated in this launch); qpos / qvel / qvel_ref / qfrc_applied are stored as mj_step1 leaves them     // assemble launch of a cohort whose solve runs the dense row-space solver (dense_pgs.h): no per-block solver matrices
 
 #define CON_STRIDE 16  // dist, pos3, frame9, [13] geom1 | geom2 << 12 | dim << 24, [14] includemargin, [15] pad

@@ -18,6 +18,7 @@
 #include "dense_pgs.h"
 
 void mjh_set_error(const std::string& s);  // model_builder.cpp
+hipError_t mjh_launch_window(hipStream_t st, int nvt, int grid, size_t lds, const DConst* dC, const DState& S, int env0, int n, int nl, int wxf, int n32);   // window.hip
 
 #define HIPCHK(call)                                                                             \
   do {                                                                                           \
@@ -167,10 +168,8 @@ static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps,
     // 24-dof models: a first section of wavefronts sweeps the envs with many rows in 32-row windows, two per wavefront (they scan the
     // same launch order and take the envs the assemble launch marked; almost all of them exit at once)
     const int n32 = (e->S.win32 && e->M.win_nvt == 24) ? (n + 1) / 2 : 0;
-    const int wxf = xflags & ~XF_DEFER;
-    if (e->M.win_nvt == 24) hipLaunchKernelGGL((mjh_window_kernel<24, WN_NW24>), dim3(n32 + (n + 3) / 4), dim3(64), lds, st, e->dC, e->S, env0, n, nl, wxf, n32);
-    else hipLaunchKernelGGL((mjh_window_kernel<32, WN_NW32>), dim3((n + 3) / 4), dim3(64), lds, st, e->dC, e->S, env0, n, nl, wxf, 0);
-    HIPCHK(hipGetLastError());
+    const int wxf = (xflags & ~XF_DEFER) | ((ph & PH_STEP1) ? 0 : XF_SPLIT2);
+    HIPCHK(mjh_launch_window(st, e->M.win_nvt, (e->M.win_nvt == 24 ? n32 : 0) + (n + 3) / 4, lds, e->dC, e->S, env0, n, nl, wxf, n32));
   }
   return MJH_OK;
 }
@@ -449,6 +448,8 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     } else L.zero = put(4);
     L.site = m->nsite > 0 ? put(12 * m->nsite) : 0;        // world frame of every site: pos(3) + rotation(9)
     L.fext = m->nsensor > 0 ? put(6 * nb) : 0;             // external spatial force per body (mj_rnePostConstraint)
+    // (the site frames / external forces sit behind the patch pool: an assemble-only launch of a model that has them gets the whole layout)
+    if (m->nsite > 0 || m->nsensor > 0) hp.lds_bytes_pre = off * (int)sizeof(float);
     if (big) {   // hand-over vectors of the three-launch step (non-negative offsets into the scratch slice)
       auto graw = [&](int n) { long long o = goff; goff += ((std::max(n, 1) + 3) / 4) * 4; return (int)o; };
       L.g_a0 = graw(nv); L.g_minv = graw(nv); L.g_qvel = graw(nv); L.g_smooth = graw(nv); L.g_qacc = graw(nv); L.g_meta = graw(8); L.g_qM = graw(m->nM);

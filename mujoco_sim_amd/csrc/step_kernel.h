@@ -529,7 +529,7 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
   if (mode == 1) { ns = true; nmain = niter; niter = 0; itmax = c.noslip_iterations; tol = c.noslip_tolerance; if (!solo) __syncthreads(); }
   // (the side-by-side forms below sum a sweep's cost decrease as fixed-point integers: the total must not depend on which lane
   //  carried which block — dev_math.h: imp_fixed)
-  const ImpQ iq = imp_quantum(c.scale, tol);
+  const ImpQ iq = imp_quantum(c.scale, tol, c.nblk);
   // operands of one block; every address follows from the block index alone (contact blocks are laid out
   // regularly behind the c.nfixblk non-contact ones), so all loads of block k+1 are in flight while block k is solved
   struct MOp { int4 hd; int b; float4 J, B, p0, r0, r1, r2, A0, A1, A2, A3, X0, X1, X2; };
@@ -680,7 +680,7 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
         *(float4*)(c.a4 + t4) = an;                                           // (the group's blocks touch disjoint bodies)
       }
       const bool head = actb && h == 0;
-      impl += imp_fixed(head ? imp : 0.0f, iq.qs);
+      impl += imp_fixed(head ? imp : 0.0f, iq.qs, iq.cl);
       const unsigned of = head ? (unsigned)op.b * 64u + (unsigned)(BF_F * 4) : MJH_BUF_OOB;
       mjh_v4u f4; mjh_v2u f2;
       __builtin_memcpy(&f4, f, 16); __builtin_memcpy(&f2, f + 4, 8);
@@ -804,7 +804,7 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
 #undef MJH_ROWSUM
       ak += (Bp[0] * dphi[0] + Bp[1] * dphi[1] + Bp[2] * dphi[2] + Bp[3] * dphi[3]) * bs;
       if (on) c.qacc[d] = ak;                                                 // scatter (the group's blocks touch disjoint dofs)
-      impl += imp_fixed(op.act * imp, iq.qs);
+      impl += imp_fixed(op.act * imp, iq.qs, iq.cl);
       if constexpr (BUF) {
         const unsigned of = (l == 0 && op.act > 0.0f) ? (unsigned)op.b * 64u + (unsigned)(BF_F * 4) : MJH_BUF_OOB;
         mjh_v4u f4; mjh_v2u f2;
@@ -2419,8 +2419,9 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
               //      the sweeps in constraint-row order, mj_checkAcc and mj_Euler, and stores the state.  Handed over: the rows (J^ dense over
               //      the dofs, aref, R), M^1/2 qacc_smooth, M^1/2 qacc_warmstart, M^-1/2, qvel after the controller, the normalised qpos.
               float* wb = S.wbuf + (size_t)env * (size_t)S.wstride;
-              const int nrow = window_emit(wb, M.win_nvt, s_blki_i, s_blkf, s_J, s_bias, nblk, lane, WPRE);
-              if (WPRE && nefc > nrow) flags |= 2;          // (rows beyond the window kernel's capacity were dropped)
+              // (the split API's hand-over has no sweep to fall back to either: rows beyond the capacity are dropped with the flag, never the whole set)
+              const int nrow = window_emit(wb, M.win_nvt, s_blki_i, s_blkf, s_J, s_bias, nblk, lane, WPRE || wdefer);
+              if ((WPRE || wdefer) && nefc > nrow) flags |= 2;          // (rows beyond the window kernel's capacity were dropped)
               if (nrow > 0 || wdefer) {
                 for (int d = lane; d < nv; d += 64) { wb[WN_AS + d] = s_qacc[d]; wb[WN_AWS + d] = s_tmpv2[d]; wb[WN_SINV + d] = s_bias[d]; wb[WN_QVEL + d] = s_qvel[d]; }
                 for (int i = lane; i < nq; i += 64) wb[WN_QPOS + i] = s_qpos[i];
@@ -2429,6 +2430,8 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
                   for (int d = lane; d < nv; d += 64) { S.qvel[vrow + d] = s_qvel[d]; S.qvel_ref[vrow + d] = s_qvref[d]; S.qfrc_applied[vrow + d] = s_applied[d]; }
                 }
                 // [4]: the form the window kernel sweeps this env in — 32-row windows for many rows (window_pgs.h: wn_run32), a function of the env's own row count
+                // (split API: the counts of THIS step are what mjh_get_stats / mjh_get_field see between the two halves, as after a plain mj_step1)
+                if (lane == 0 && wdefer) { S.stats[4*env] = ncon; S.stats[4*env+1] = nefc; S.stats[4*env+2] = 0; S.stats[4*env+3] |= flags & 0xff; }
                 if (lane == 0) { int* wh = (int*)wb; wh[0] = nrow; wh[1] = ncon; wh[2] = nefc; wh[3] = flags; wh[4] = (S.win32 > 0 && M.win_nvt == 24 && nrow > S.win32 && nrow <= 32 * WN32_NW) ? 1 : 0; wh[5] = (wdefer && nrow == 0) ? 1 : 0; }   // [5]: an env without rows that the window kernel integrates (split API)
                 return;
               }
@@ -3019,6 +3022,7 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
   if ((xflags & XF_PROF) && lane == 0) S.x_prof[(size_t)blockIdx.x * PROF_STRIDE + 17] = (long long)__builtin_amdgcn_s_memrealtime();
 }
 
+#ifndef MJH_WINDOW_TU
 // pack time + qpos + qvel per env into one contiguous fp32 buffer (feeds the RCCL all-gather)
 __global__ void mjh_export_kernel(const DState S, float* out, int env0, int nenv, int nq, int nv, int nqp, int nvp) {
   const int stride = 1 + nq + nv;
@@ -3056,6 +3060,8 @@ __global__ __launch_bounds__(1024) void mjh_order_kernel(const int* __restrict__
   __syncthreads();
   for (int e = t; e < nenv; e += 1024) order[atomicAdd(&base[255 - bucket(e)], 1)] = env0 + e;
 }
+
+#endif   // MJH_WINDOW_TU
 
 // Stand-alone solver of the many-body layout's three-launch step: everything it needs is in the env's scratch slice
 // (pools + hand-over vectors), its LDS footprint is two dof vectors, so many environments are resident per CU while the

@@ -1,0 +1,618 @@
+// window_kernel.h — mjh_window_kernel: the sweeps, mj_checkAcc and mj_Euler of the window chain (see window_pgs.h for the design and the
+// hand-over layout).  Included by window.hip only: the kernel is a translation unit of its own (seconds to compile, against minutes
+// for the step kernel's instances), launched from engine.hip through mjh_launch_window.
+#pragma once
+#include "step_kernel.h"
+
+#define WN_BC8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+template <int NV> struct WnWin { float J[NV]; float4 A0, A1, A2, A3; float aref, R, nw, half; };   // one window row: J^, tile row (-AR_qr / AR_qq, r < q), constants
+
+// transpose-reduce: x[k](lane q) -> lane q of the 16-lane row receives sum over the row's lanes of x[q]   (16 values, 33 instructions)
+#define WN_ROR2(d, s0, s1, r0, m0, r1, m1) "v_add_f32_dpp " d ", " s0 ", " s0 " row_ror:" #r0 " row_mask:0xf bank_mask:" #m0 "\n\tv_add_f32_dpp " d ", " s1 ", " s1 " row_ror:" #r1 " row_mask:0xf bank_mask:" #m1 "\n\t"
+DEV float wn_fold_tail(const float* z) {     // four values over the quads (lane bit 1 and bit 0 pick the value)
+  const int q = threadIdx.x & 15;
+  const bool b1 = (q & 2) != 0, b0 = (q & 1) != 0;
+  float w[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const float s = b1 ? z[k + 2] : z[k], o = b1 ? z[k] : z[k + 2];
+    w[k] = s + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, o), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  }
+  const float s = b0 ? w[1] : w[0], o = b0 ? w[0] : w[1];
+  return s + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, o), 0xB1, 0xf, 0xf, true));       // quad_perm [1,0,3,2]
+}
+DEV void wn_fold_8to4(const float* y, float* z) {   // lanes with bit 2 clear keep values 0..3, the others 4..7 (partner: 4 lanes away, same half of the row)
+  asm volatile(WN_ROR2("%0", "%4", "%8", 12, 0x5, 4, 0xa) WN_ROR2("%1", "%5", "%9", 12, 0x5, 4, 0xa) WN_ROR2("%2", "%6", "%10", 12, 0x5, 4, 0xa) WN_ROR2("%3", "%7", "%11", 12, 0x5, 4, 0xa)
+               : "=&v"(z[0]), "=&v"(z[1]), "=&v"(z[2]), "=&v"(z[3]) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]));
+}
+DEV float wn_fold16(const float* x) {
+  float y[8], z[4];
+  // lanes 0..7 keep values 0..7, lanes 8..15 values 8..15 (partner: 8 lanes away)
+  asm volatile("s_nop 1\n\t"
+               WN_ROR2("%0", "%8", "%16", 8, 0x3, 8, 0xc) WN_ROR2("%1", "%9", "%17", 8, 0x3, 8, 0xc) WN_ROR2("%2", "%10", "%18", 8, 0x3, 8, 0xc) WN_ROR2("%3", "%11", "%19", 8, 0x3, 8, 0xc)
+               WN_ROR2("%4", "%12", "%20", 8, 0x3, 8, 0xc) WN_ROR2("%5", "%13", "%21", 8, 0x3, 8, 0xc) WN_ROR2("%6", "%14", "%22", 8, 0x3, 8, 0xc) WN_ROR2("%7", "%15", "%23", 8, 0x3, 8, 0xc)
+               : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]), "=&v"(y[4]), "=&v"(y[5]), "=&v"(y[6]), "=&v"(y[7])
+               : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]),
+                 "v"(x[8]), "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]), "v"(x[13]), "v"(x[14]), "v"(x[15]));
+  wn_fold_8to4(y, z);
+  return wn_fold_tail(z);
+}
+// 8 values: lanes 2j and 2j + 1 both receive the sum of x[j]   (16 instructions: every stage halves the values a lane keeps)
+DEV float wn_fold8(const float* x) {
+  float y[4], z[2];
+  asm volatile("s_nop 1\n\t" WN_ROR2("%0", "%4", "%8", 8, 0x3, 8, 0xc) WN_ROR2("%1", "%5", "%9", 8, 0x3, 8, 0xc) WN_ROR2("%2", "%6", "%10", 8, 0x3, 8, 0xc) WN_ROR2("%3", "%7", "%11", 8, 0x3, 8, 0xc)
+               : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));   // lanes 0..7: values 0..3, lanes 8..15: values 4..7
+  asm volatile(WN_ROR2("%0", "%2", "%4", 12, 0x5, 4, 0xa) WN_ROR2("%1", "%3", "%5", 12, 0x5, 4, 0xa)
+               : "=&v"(z[0]), "=&v"(z[1]) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]));                                  // lane bit 2 clear: values 0, 1 of the half; set: 2, 3
+  const bool b1 = (threadIdx.x & 2) != 0;
+  const float s = b1 ? z[1] : z[0], o = b1 ? z[0] : z[1];
+  float r = s + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, o), 0x4E, 0xf, 0xf, true));   // value index = 4 bit3 + 2 bit2 + bit1 of the lane = lane >> 1
+  MJH_DPP_ADD(r, 0xB1, 0xf, true);                                                                                             // + the neighbour lane (bit 0): both keep the value
+  return r;
+}
+// sum over the 16 lanes of a row, result in every lane of the row (integers: order-independent)
+DEV int wn_rowsum_i(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true); v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  return __builtin_amdgcn_update_dpp(0, v, 0x15F, 0xf, 0xf, false);     // row_newbcast:15
+}
+DEV float wn_rowsum_f(float v) {
+  MJH_DPP_ADD(v, 0x111, 0xf, true); MJH_DPP_ADD(v, 0x112, 0xf, true); MJH_DPP_ADD(v, 0x114, 0xf, true); MJH_DPP_ADD(v, 0x118, 0xf, true);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x15F, 0xf, 0xf, false));
+}
+
+// u = J^ . a^ : a_lo / a_hi hold the dof vector (lane q of the row: dofs q and 16 + q); two independent chains
+#define WN_FM(acc, x, y, R) "v_fmac_f32_dpp " acc ", " x ", " y " row_newbcast:" #R " row_mask:0xf bank_mask:0xf\n\t"
+template <int NV> DEV float wn_dot(const float* J, const float a_lo, const float a_hi) {
+  static_assert(NV == 24 || NV == 32, "window kernel instances: 24 or 32 dof slots");
+  float u0, u1;
+  asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+               WN_FM("%0", "%1", "%3", 1) WN_FM("%0", "%1", "%4", 2) WN_FM("%0", "%1", "%5", 3) WN_FM("%0", "%1", "%6", 4) WN_FM("%0", "%1", "%7", 5)
+               WN_FM("%0", "%1", "%8", 6) WN_FM("%0", "%1", "%9", 7) WN_FM("%0", "%1", "%10", 8) WN_FM("%0", "%1", "%11", 9) WN_FM("%0", "%1", "%12", 10)
+               WN_FM("%0", "%1", "%13", 11) WN_FM("%0", "%1", "%14", 12) WN_FM("%0", "%1", "%15", 13) WN_FM("%0", "%1", "%16", 14) WN_FM("%0", "%1", "%17", 15)
+               : "=&v"(u0) : "v"(a_lo), "v"(J[0]), "v"(J[1]), "v"(J[2]), "v"(J[3]), "v"(J[4]), "v"(J[5]), "v"(J[6]), "v"(J[7]),
+                 "v"(J[8]), "v"(J[9]), "v"(J[10]), "v"(J[11]), "v"(J[12]), "v"(J[13]), "v"(J[14]), "v"(J[15]));
+  if constexpr (NV == 24)      // (a_hi: lane 2j carries dof 16 + j — wn_fold8)
+    asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 WN_FM("%0", "%1", "%3", 2) WN_FM("%0", "%1", "%4", 4) WN_FM("%0", "%1", "%5", 6) WN_FM("%0", "%1", "%6", 8) WN_FM("%0", "%1", "%7", 10)
+                 WN_FM("%0", "%1", "%8", 12) WN_FM("%0", "%1", "%9", 14)
+                 : "=&v"(u1) : "v"(a_hi), "v"(J[16]), "v"(J[17]), "v"(J[18]), "v"(J[19]), "v"(J[20]), "v"(J[21]), "v"(J[22]), "v"(J[23]));
+  else
+    asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 WN_FM("%0", "%1", "%3", 1) WN_FM("%0", "%1", "%4", 2) WN_FM("%0", "%1", "%5", 3) WN_FM("%0", "%1", "%6", 4) WN_FM("%0", "%1", "%7", 5)
+                 WN_FM("%0", "%1", "%8", 6) WN_FM("%0", "%1", "%9", 7)
+                 : "=&v"(u1) : "v"(a_hi), "v"(J[16]), "v"(J[17]), "v"(J[18]), "v"(J[19]), "v"(J[20]), "v"(J[21]), "v"(J[22]), "v"(J[23]));
+  if constexpr (NV == 32)
+    asm volatile("s_nop 1\n\t" WN_FM("%0", "%1", "%2", 8) WN_FM("%0", "%1", "%3", 9) WN_FM("%0", "%1", "%4", 10) WN_FM("%0", "%1", "%5", 11)
+                 WN_FM("%0", "%1", "%6", 12) WN_FM("%0", "%1", "%7", 13) WN_FM("%0", "%1", "%8", 14) WN_FM("%0", "%1", "%9", 15)
+                 : "+v"(u1) : "v"(a_hi), "v"(J[NV == 32 ? 24 : 0]), "v"(J[NV == 32 ? 25 : 0]), "v"(J[NV == 32 ? 26 : 0]), "v"(J[NV == 32 ? 27 : 0]),
+                   "v"(J[NV == 32 ? 28 : 0]), "v"(J[NV == 32 ? 29 : 0]), "v"(J[NV == 32 ? 30 : 0]), "v"(J[NV == 32 ? 31 : 0]));
+  return u0 + u1;
+}
+// a^ += J^T x over the row's 16 lanes
+template <int NV> DEV void wn_jt(const float* J, const float x, float& a_lo, float& a_hi) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f x2 = {x, x};
+  float p[NV];
+#pragma unroll
+  for (int k = 0; k < NV; k += 2) { const v2f pr = v2f{J[k], J[k + 1]} * x2; p[k] = pr.x; p[k + 1] = pr.y; }     // v_pk_mul_f32
+  a_lo += wn_fold16(p);
+  if constexpr (NV == 32) a_hi += wn_fold16(p + 16); else a_hi += wn_fold8(p + 16);
+}
+
+
+// ---- 32-row windows: TWO environments per wavefront (a 32-lane half each), for the environments with many rows.  A cohort's step waits
+// for its slowest wavefront, and that one carries an env at the sweep cap with 7 or 8 windows of 16 (S24: 3.5 % of the envs have more
+// than 96 rows — tools/s24_critical_path.py, tools/s24_hybrid_model.py).  Per 32 rows one dot and one transpose-reduce instead of two:
+// ~186 instead of 260 instructions on that env's chain.  Lanes: env slot es = lane >> 5, half hq = (lane >> 4) & 1 (rows 0..15 / 16..31
+// of the window), q = lane & 15.  Gauss-Seidel stays row by row: the lower half's 16 rows (DPP row mask 0x5), then the upper half
+// receives the lower deltas through the cross tile (C: -AR_{16+q, r} / AR_qq, r < 16 — the lower deltas come over by ds_swizzle),
+// then its own 16 rows (row mask 0xa).  Both halves carry the same a^ (dof q / 16 + q / 2), their partial J^T sums are exchanged by
+// ds_swizzle.  The MODE of an env is a function of its own row count alone (96 < rows <= 128, set by the assemble launch): results do
+// not depend on which envs share a wavefront.  Same row math, same order, same stopping rule as the 16-row form; the grouping of
+// the arithmetic differs (fp32 rounding).
+#define WN_SWZ16(x) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, (x)), 0x401F))   // lane ^ 16 within 32 lanes
+#define WN_ROWM(r, ar, m) "v_max_f32 %[d], %[t], %[nf]\n\ts_nop 1\n\tv_fmac_f32_dpp %[t], %[d], " ar " row_newbcast:" #r " row_mask:" #m " bank_mask:0xf\n\t"
+#define WN_ROWS4M(r0, r1, r2, r3, T, m) asm volatile(WN_ROWM(r0, "%[a0]", m) WN_ROWM(r1, "%[a1]", m) WN_ROWM(r2, "%[a2]", m) WN_ROWM(r3, "%[a3]", m) \
+    : [t] "+v"(tt), [d] "=&v"(dl) : [nf] "v"(nf), [a0] "v"(T.x), [a1] "v"(T.y), [a2] "v"(T.z), [a3] "v"(T.w))
+#define WN_XFM(r, ar) "v_fmac_f32_dpp %[t], %[x], " ar " row_newbcast:" #r " row_mask:0xa bank_mask:0xf\n\t"
+#define WN_CROSS4(r0, r1, r2, r3, T) asm volatile(WN_XFM(r0, "%[a0]") WN_XFM(r1, "%[a1]") WN_XFM(r2, "%[a2]") WN_XFM(r3, "%[a3]") \
+    : [t] "+v"(tt) : [x] "v"(dx), [a0] "v"(T.x), [a1] "v"(T.y), [a2] "v"(T.z), [a3] "v"(T.w))
+struct WnWin32 { float J[24]; float4 A0, A1, A2, A3, C0, C1, C2, C3; float aref, R, nw, half; };
+
+DEV void wn_jt32(const float* J, const float x, float& a_lo, float& a_hi) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f x2 = {x, x};
+  float p[24];
+#pragma unroll
+  for (int k = 0; k < 24; k += 2) { const v2f pr = v2f{J[k], J[k + 1]} * x2; p[k] = pr.x; p[k + 1] = pr.y; }
+  float s_lo = wn_fold16(p), s_hi = wn_fold8(p + 16);
+  // + the other half's 16 rows: v_permlane16_swap exchanges the odd 16-lane rows of the first register with the even rows of the second,
+  // so (x, y) = (lower half's sum, upper half's sum) in EVERY lane afterwards: the same sum, in the same order, in both halves
+  // (a VALU instruction: the LDS crossbar's round trip — ds_swizzle — sat three times in every window-sweep's chain)
+  float y_lo = s_lo, y_hi = s_hi;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1" : "+v"(s_lo), "+v"(s_hi), "+v"(y_lo), "+v"(y_hi));
+  a_lo += s_lo + y_lo; a_hi += s_hi + y_hi;
+}
+
+// MjSim::set_odom_vels (/root/reference/src/mujoco_sim/mj_sim.cpp:1079-1153) behind mj_Euler, as in the fused kernel (step_kernel.h): the commanded
+// twist, rotated by the odom angles of the INTEGRATED qpos, overwrites the odom dofs' velocities for the next step.  One lane per env;
+// qp: the env's integrated qpos (LDS), qv: its row of S.qvel.
+DEV void wn_odom(const DModel& M, const DState& S, const int env, const float* qp, float* qv) {
+  const Tab<int> odom{M.I, M.o_odom};
+  const float* v = S.odom_vel + (size_t)env * 6;
+  const float ax = odom[6] >= 0 ? qp[odom[6]] : 0.0f, ay = odom[7] >= 0 ? qp[odom[7]] : 0.0f, az = odom[8] >= 0 ? qp[odom[8]] : 0.0f;
+  const float sx = sinf(ax), cx = cosf(ax), sy = sinf(ay), cy = cosf(ay), sz = sinf(az), cz = cosf(az);
+  if (odom[0] >= 0) qv[odom[0]] = v[0]*cy*cz + v[1]*(sx*sy*cz - cx*sz) + v[2]*(cx*sy*cz + sx*sz);
+  if (odom[1] >= 0) qv[odom[1]] = v[0]*cy*sz + v[1]*(sx*sy*sz + cx*cz) + v[2]*(cx*sy*sz - sx*cz);
+  if (odom[2] >= 0) qv[odom[2]] = -v[0]*sy + v[1]*sx*cy + v[2]*cx*cy;
+  for (int k = 0; k < 3; k++) if (odom[3+k] >= 0) qv[odom[3+k]] = v[3+k];
+}
+
+DEV void wn_run32(const DConst* __restrict__ C, const DState& S, const int env0, const int nenv, const int xflags, const int blk) {
+  const DModel& M = C->M;
+  constexpr int NV = 24, NK = NV + 2;
+  const int lane = threadIdx.x, es = lane >> 5, hq = (lane >> 4) & 1, q = lane & 15;
+  const int slot = blk * 2 + es;
+  const bool have = slot < nenv;
+  const int env = have ? (S.env_order ? S.env_order[env0 + slot] : env0 + slot) : 0;
+  float* const wb = S.wbuf + (size_t)env * (size_t)S.wstride;
+  const int* const wh = (const int*)wb;
+  const int nrow = (have && wh[4] == 1) ? wh[0] : 0;          // (envs of the 16-row form are not this section's)
+  if (__ballot(nrow > 0) == 0ull) return;
+  const bool mine = nrow > 0;
+  const int nwin16 = (nrow + 15) >> 4, nwin = (nrow + 31) >> 5;
+  const int nwmax = max(__builtin_amdgcn_readlane(nwin, 0), __builtin_amdgcn_readlane(nwin, 32));
+  const int nv = M.nv;
+  const int dhi = 16 + (q >> 1);
+  const bool lo_on = q < nv, hi_on = dhi < nv;
+  const float as_lo = lo_on ? wb[WN_AS + q] : 0.0f, as_hi = hi_on ? wb[WN_AS + dhi] : 0.0f;
+  const float ws_lo = lo_on ? wb[WN_AWS + q] : 0.0f, ws_hi = hi_on ? wb[WN_AWS + dhi] : 0.0f;
+  WnWin32 win[WN32_NW];
+  float f[WN32_NW];
+  const float* rows = wb + WN_ROWS + q;
+#pragma unroll
+  for (int w = 0; w < WN32_NW; w++) if (w < nwmax) {
+    WnWin32& W = win[w];
+    const bool ok = (2 * w + hq) < nwin16;                  // (the assemble launch pads the last 16-row block with zero rows; a missing upper block is all zeros)
+    const float* p = rows + (2 * w + hq) * NK * 16;
+#pragma unroll
+    for (int k = 0; k < NV; k++) W.J[k] = ok ? p[16 * k] : 0.0f;
+    W.aref = ok ? p[16 * NV] : 0.0f; W.R = ok ? p[16 * (NV + 1)] : 0.0f;
+    float acc[16], acx[16], Jx[NV];
+#pragma unroll
+    for (int sidx = 0; sidx < 16; sidx++) { acc[sidx] = 0.0f; acx[sidx] = 0.0f; }
+#pragma unroll
+    for (int k = 0; k < NV; k++) Jx[k] = WN_SWZ16(W.J[k]);   // the other half's row q: upper lanes see the lower rows
+#pragma unroll
+    for (int k = 0; k < NV; k++) asm volatile("" : "+v"(W.J[k]), "+v"(Jx[k]));
+    asm volatile("s_nop 1");
+#define WN_ACC(sidx) _Pragma("unroll") for (int k = 0; k < NV; k++) { PP_FMAC_BC(acc[sidx], W.J[k], W.J[k], sidx); PP_FMAC_BC(acx[sidx], Jx[k], W.J[k], sidx); }
+    PP_BC16(WN_ACC)
+#undef WN_ACC
+    float diag = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) diag += W.J[k] * W.J[k];
+    const float ARqq = diag + W.R;
+    const float inv = ARqq < MJ_MINVAL ? 0.0f : 1.0f / ARqq, ninv = -inv, cinv = hq ? ninv : 0.0f;
+    W.nw = ninv; W.half = 0.5f * ARqq;
+    W.A0 = make_float4(0 < q ? ninv * acc[0] : 0.0f, 1 < q ? ninv * acc[1] : 0.0f, 2 < q ? ninv * acc[2] : 0.0f, 3 < q ? ninv * acc[3] : 0.0f);
+    W.A1 = make_float4(4 < q ? ninv * acc[4] : 0.0f, 5 < q ? ninv * acc[5] : 0.0f, 6 < q ? ninv * acc[6] : 0.0f, 7 < q ? ninv * acc[7] : 0.0f);
+    W.A2 = make_float4(8 < q ? ninv * acc[8] : 0.0f, 9 < q ? ninv * acc[9] : 0.0f, 10 < q ? ninv * acc[10] : 0.0f, 11 < q ? ninv * acc[11] : 0.0f);
+    W.A3 = make_float4(12 < q ? ninv * acc[12] : 0.0f, 13 < q ? ninv * acc[13] : 0.0f, 14 < q ? ninv * acc[14] : 0.0f, 0.0f);
+    W.C0 = make_float4(cinv * acx[0], cinv * acx[1], cinv * acx[2], cinv * acx[3]);
+    W.C1 = make_float4(cinv * acx[4], cinv * acx[5], cinv * acx[6], cinv * acx[7]);
+    W.C2 = make_float4(cinv * acx[8], cinv * acx[9], cinv * acx[10], cinv * acx[11]);
+    W.C3 = make_float4(cinv * acx[12], cinv * acx[13], cinv * acx[14], cinv * acx[15]);
+  }
+  auto rowsum_i32 = [&](int v) __attribute__((always_inline)) { v = wn_rowsum_i(v); return v + __builtin_amdgcn_ds_swizzle(v, 0x401F); };
+  auto rowsum_f32 = [&](float v) __attribute__((always_inline)) { v = wn_rowsum_f(v); return v + WN_SWZ16(v); };
+#define WN32_FOR_WINDOWS(...) do { _Pragma("unroll") for (int w = 0; w < WN32_NW; w++) if (w < nwmax) { WnWin32& W = win[w]; float& fw = f[w]; __VA_ARGS__ } } while (0)
+  // ---- warm start
+  float a_lo = as_lo, a_hi = as_hi;
+#pragma unroll
+  for (int w = 0; w < WN32_NW; w++) f[w] = 0.0f;
+  if (!(M.disableflags & MJH_DSBL_WARMSTART)) {
+    float da_lo = 0.0f, da_hi = 0.0f;
+    WN32_FOR_WINDOWS({
+      const float jar = wn_dot<NV>(W.J, ws_lo, ws_hi) - W.aref;
+      fw = (jar < 0.0f && W.R > 0.0f) ? -jar / W.R : 0.0f;
+      wn_jt32(W.J, fw, da_lo, da_hi);
+    });
+    float cost = 0.0f;
+    WN32_FOR_WINDOWS({
+      const float jda = wn_dot<NV>(W.J, da_lo, da_hi), bb = wn_dot<NV>(W.J, as_lo, as_hi) - W.aref;
+      cost += fw * (0.5f * (jda + W.R * fw) + bb);
+    });
+    cost = rowsum_f32(cost);
+    if (cost > 0.0f) {
+#pragma unroll
+      for (int w = 0; w < WN32_NW; w++) f[w] = 0.0f;
+    } else { a_lo += da_lo; a_hi += da_hi; }
+  }
+  // ---- sweeps
+  const ImpQ iq = imp_quantum(1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1)), M.tolerance);
+  const int itmax = M.iterations;
+  int niter = 0;
+  bool act = nrow > 0;
+  while (__ballot(act) != 0ull) {
+    if (act) {
+      int impl = 0;
+      WN32_FOR_WINDOWS({
+        const float u = wn_dot<NV>(W.J, a_lo, a_hi);
+        const float fo = fw;
+        float tt = ((u - W.aref) + W.R * fo) * W.nw;
+        const float nf = -fo;
+        float dl;
+        // rows 0..15 (lower half) ...
+        WN_ROWS4M(0, 1, 2, 3, W.A0, 0x5); WN_ROWS4M(4, 5, 6, 7, W.A1, 0x5); WN_ROWS4M(8, 9, 10, 11, W.A2, 0x5); WN_ROWS4M(12, 13, 14, 15, W.A3, 0x5);
+        asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));
+        // ... their deltas reach the upper half through the cross tile ...
+        float dx = dl, dy = dl;                                         // (dx: the lower half's deltas in the upper half's lanes)
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(dx), "+v"(dy));
+        WN_CROSS4(0, 1, 2, 3, W.C0); WN_CROSS4(4, 5, 6, 7, W.C1); WN_CROSS4(8, 9, 10, 11, W.C2); WN_CROSS4(12, 13, 14, 15, W.C3);
+        // ... rows 16..31 (upper half)
+        WN_ROWS4M(0, 1, 2, 3, W.A0, 0xa); WN_ROWS4M(4, 5, 6, 7, W.A1, 0xa); WN_ROWS4M(8, 9, 10, 11, W.A2, 0xa); WN_ROWS4M(12, 13, 14, 15, W.A3, 0xa);
+        asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));
+        impl += imp_fixed((W.half * dl) * (2.0f * tt - dl), iq.qs);
+        fw = fo + dl;
+        wn_jt32(W.J, dl, a_lo, a_hi);
+      });
+      niter++;
+      if (rowsum_i32(impl) < iq.thr || niter >= itmax) act = false;
+    }
+  }
+  // ---- qacc, mj_checkAcc, semi-implicit Euler, state and statistics (the lower half's lanes carry the dofs)
+  const bool dl_lane = mine && hq == 0;
+  const float sv_lo = (dl_lane && lo_on) ? wb[WN_SINV + q] : 0.0f, sv_hi = (dl_lane && hi_on) ? wb[WN_SINV + dhi] : 0.0f;
+  float qa_lo = a_lo * sv_lo, qa_hi = a_hi * sv_hi;
+  float qv_lo = (dl_lane && lo_on) ? wb[WN_QVEL + q] : 0.0f, qv_hi = (dl_lane && hi_on) ? wb[WN_QVEL + dhi] : 0.0f;
+  int flags = mine ? wh[3] : 0;
+  if (dl_lane && (xflags & XF_FORCE)) {
+    const size_t xe = (size_t)(env - env0) * M.nvp;
+    if (lo_on) { if (S.x_smooth) S.x_smooth[xe + q] = as_lo * sv_lo; if (S.x_constraint) S.x_constraint[xe + q] = (a_lo - as_lo) / sv_lo; }
+    if (hi_on && !(q & 1)) { if (S.x_smooth) S.x_smooth[xe + dhi] = as_hi * sv_hi; if (S.x_constraint) S.x_constraint[xe + dhi] = (a_hi - as_hi) / sv_hi; }
+  }
+  const bool badl = !(qa_lo == qa_lo) || fabsf(qa_lo) > MJ_MAXVAL || !(qa_hi == qa_hi) || fabsf(qa_hi) > MJ_MAXVAL;
+  const bool bad = ((__ballot(badl) >> (32 * es)) & 0xffffffffull) != 0ull;
+  const size_t qrow = (size_t)env * M.nqp, vrow = (size_t)env * M.nvp;
+  if (bad) { qa_lo = qa_hi = 0.0f; qv_lo = qv_hi = 0.0f; flags |= 4; }
+  const float h = M.timestep;
+  const Tab<int> dof_bodyid{M.I, M.o_dof_bodyid}, jnt_qposadr{M.I, M.o_jnt_qposadr}, jnt_dofadr{M.I, M.o_jnt_dofadr};
+  const Tab<float> dof_damping{M.F, M.o_dof_damping};
+  const unsigned slotmask = S.slot_mask ? S.slot_mask[env] : 0u;
+  const int sbase = M.nbody > 32 ? M.nbody - 32 : 0;
+  __shared__ float s_v32[2][32];
+  __shared__ float s_qp32[2][40];
+  const bool has_odom = M.I[M.o_odom + 9] != 0;
+  auto advance = [&](const int d, float& qa, float& qv) __attribute__((always_inline)) {
+    float qint = qa;
+    if (M.has_damping && !(M.disableflags & MJH_DSBL_EULERDAMP)) {
+      const float sv = wb[WN_SINV + d], Mdd = 1.0f / (sv * sv), D = dof_damping[d];
+      qint = qa - h * (D * qa) / (Mdd + h * D);
+    }
+    const unsigned rb = (unsigned)(dof_bodyid[d] - sbase);
+    const bool parked = rb < 32u && ((slotmask >> rb) & 1u);
+    qv = parked ? 0.0f : qv + h * qint;
+    if (parked) qa = 0.0f;
+    S.qvel[vrow + d] = qv; S.qacc_ws[vrow + d] = qa;
+    if (bad && (xflags & XF_SPLIT2)) S.qfrc_applied[vrow + d] = 0.0f;
+    s_v32[es][d] = qv;
+  };
+  if (dl_lane && lo_on) advance(q, qa_lo, qv_lo);
+  if (dl_lane && hi_on && !(q & 1)) advance(dhi, qa_hi, qv_hi);
+  __syncthreads();
+  if (dl_lane && q < M.njnt) {
+    const int qadr = jnt_qposadr[q], da = jnt_dofadr[q];
+    float p[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) p[k] = bad ? S.initial_qpos[qrow + qadr + k] : wb[WN_QPOS + qadr + k];
+    const float* v = s_v32[es] + da;
+    p[0] += h * v[0]; p[1] += h * v[1]; p[2] += h * v[2];
+    float w3[3] = {v[3], v[4], v[5]};
+    quat_integrate(p + 3, w3, h);
+#pragma unroll
+    for (int k = 0; k < 7; k++) { S.qpos[qrow + qadr + k] = p[k]; s_qp32[es][qadr + k] = p[k]; }
+  }
+  if (has_odom) {       // (the qvel rows above are this wave's own stores: the overwrite follows them in program order)
+    __syncthreads();
+    if (dl_lane && q == 0) wn_odom(M, S, env, s_qp32[es], S.qvel + vrow);
+  }
+  if (dl_lane && q == 0) {
+    S.time[env] += M.timestep_d;
+    const int cost_hint = min(niter * nwin16 * 20 + 1, 1 << 22);
+    S.stats[4 * env] = wh[1]; S.stats[4 * env + 1] = wh[2]; S.stats[4 * env + 2] = niter;
+    S.stats[4 * env + 3] = ((S.stats[4 * env + 3] | flags) & 0xff) | (cost_hint << 8);
+  }
+#undef WN32_FOR_WINDOWS
+}
+
+// a^ += J_a^T x_a + J_b^T x_b : two windows of the same 16 lanes, one transpose-reduce
+template <int NV> DEV void wn_jt2(const float* JA, const float xa, const float* JB, const float xb, float& a_lo, float& a_hi) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f xa2 = {xa, xa}, xb2 = {xb, xb};
+  float p[NV];
+#pragma unroll
+  for (int k = 0; k < NV; k += 2) {
+    const v2f pr = __builtin_elementwise_fma(v2f{JB[k], JB[k + 1]}, xb2, v2f{JA[k], JA[k + 1]} * xa2);     // v_pk_mul_f32, v_pk_fma_f32
+    p[k] = pr.x; p[k + 1] = pr.y;
+  }
+  a_lo += wn_fold16(p);
+  if constexpr (NV == 32) a_hi += wn_fold16(p + 16); else a_hi += wn_fold8(p + 16);
+}
+#define WN_XFMA(r, ar) "v_fmac_f32_dpp %[t], %[x], " ar " row_newbcast:" #r " row_mask:0xf bank_mask:0xf\n\t"
+#define WN_CROSS4A(r0, r1, r2, r3, T) asm volatile(WN_XFMA(r0, "%[a0]") WN_XFMA(r1, "%[a1]") WN_XFMA(r2, "%[a2]") WN_XFMA(r3, "%[a3]") \
+    : [t] "+v"(tt) : [x] "v"(dx), [a0] "v"(T.x), [a1] "v"(T.y), [a2] "v"(T.z), [a3] "v"(T.w))
+
+template <int NV, int NW>
+__global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restrict__ C, const DState S, const int env0, const int nenv, const int nl, const int xflags, const int n32waves) {
+  // the first n32waves wavefronts: the section of the envs with many rows (two per wavefront, 32-row windows); dispatched first
+  if constexpr (NV == 24) { if ((int)blockIdx.x < n32waves) { wn_run32(C, S, env0, nenv, xflags, (int)blockIdx.x); return; } }
+  const DModel& M = C->M;
+  const int lane = threadIdx.x, rho = lane >> 4, q = lane & 15;
+  const int slot = ((int)blockIdx.x - n32waves) * 4 + rho;
+  const bool have = slot < nenv;
+  const int env = have ? (S.env_order ? S.env_order[env0 + slot] : env0 + slot) : 0;
+  float* const wb = S.wbuf + (size_t)env * (size_t)S.wstride;
+  const int* const wh = (const int*)wb;
+  const int nrow = (have && !(n32waves > 0 && wh[4] == 1)) ? wh[0] : 0;
+  const bool mine = nrow > 0 || (have && wh[5] == 1);      // (else: a row without an environment, or one that finished in the assemble launch — it must not write anything; [5]: an env without rows handed over by the split API: integrated here)
+  if (__ballot(mine) == 0ull) return;
+  const int nwin = (nrow + 15) >> 4;
+  const int nwmax = max(max(__builtin_amdgcn_readlane(nwin, 0), __builtin_amdgcn_readlane(nwin, 16)), max(__builtin_amdgcn_readlane(nwin, 32), __builtin_amdgcn_readlane(nwin, 48)));
+  const int nv = M.nv;
+  constexpr int NK = NV + 2;
+  // dof vectors: lane q of the row carries dof q (lo) and dof 16 + q (hi; the 24-slot instance: dof 16 + (q >> 1), wn_fold8)
+  const int dhi = NV == 24 ? 16 + (q >> 1) : 16 + q;
+  const bool lo_on = q < nv, hi_on = dhi < nv;
+  const float as_lo = lo_on ? wb[WN_AS + q] : 0.0f, as_hi = hi_on ? wb[WN_AS + dhi] : 0.0f;
+  const float ws_lo = lo_on ? wb[WN_AWS + q] : 0.0f, ws_hi = hi_on ? wb[WN_AWS + dhi] : 0.0f;
+
+  WnWin<NV> win[NW];
+  float f[NW];                                                 // forces of the register-resident windows
+  const float* rows = wb + WN_ROWS + q;
+  auto load_rows = [&](WnWin<NV>& W, const int w) __attribute__((always_inline)) {
+    const bool ok = w < nwin;
+    const float* p = rows + w * NK * 16;
+#pragma unroll
+    for (int k = 0; k < NV; k++) W.J[k] = ok ? p[16 * k] : 0.0f;
+    W.aref = ok ? p[16 * NV] : 0.0f; W.R = ok ? p[16 * (NV + 1)] : 0.0f;
+  };
+  // tile row of a window: acc_r = J^_q . J^_r for the 16 rows r of the window (every lane of the row at once), then -AR_qr / AR_qq, r < q
+  auto make_tile = [&](WnWin<NV>& W) __attribute__((always_inline)) {
+    float acc[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) acc[s] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) asm volatile("" : "+v"(W.J[k]));     // (materialised before the DPP reads below: no VALU write within two instructions of them)
+    asm volatile("s_nop 1");
+#define WN_ACC(s) _Pragma("unroll") for (int k = 0; k < NV; k++) PP_FMAC_BC(acc[s], W.J[k], W.J[k], s);
+    PP_BC16(WN_ACC)
+#undef WN_ACC
+    float diag = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) diag += W.J[k] * W.J[k];
+    const float ARqq = diag + W.R;
+    const float inv = ARqq < MJ_MINVAL ? 0.0f : 1.0f / ARqq, ninv = -inv;
+    W.nw = ninv; W.half = 0.5f * ARqq;
+    W.A0 = make_float4(0 < q ? ninv * acc[0] : 0.0f, 1 < q ? ninv * acc[1] : 0.0f, 2 < q ? ninv * acc[2] : 0.0f, 3 < q ? ninv * acc[3] : 0.0f);
+    W.A1 = make_float4(4 < q ? ninv * acc[4] : 0.0f, 5 < q ? ninv * acc[5] : 0.0f, 6 < q ? ninv * acc[6] : 0.0f, 7 < q ? ninv * acc[7] : 0.0f);
+    W.A2 = make_float4(8 < q ? ninv * acc[8] : 0.0f, 9 < q ? ninv * acc[9] : 0.0f, 10 < q ? ninv * acc[10] : 0.0f, 11 < q ? ninv * acc[11] : 0.0f);
+    W.A3 = make_float4(12 < q ? ninv * acc[12] : 0.0f, 13 < q ? ninv * acc[13] : 0.0f, 14 < q ? ninv * acc[14] : 0.0f, 0.0f);
+  };
+  // windows beyond the register-resident ones: the whole record (J^, aref, R, tile row, -1 / AR_qq, AR_qq / 2, force) [NX][16] — the
+  // next NL windows of every env in LDS (the kernel has no other use for it: 40 KB per wave at four waves per CU), the rest in the env's
+  // slice of global memory (read every sweep: slow, and rare — S24D's 140-row piles reach the LDS tier only)
+  constexpr int NX = NV + 21;
+  extern __shared__ float wn_lds[];
+  auto store_ext = [&](float* t, const WnWin<NV>& W, const float fw) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) t[16 * k] = W.J[k];
+    t[16 * NV] = W.aref; t[16 * (NV + 1)] = W.R;
+    float* u = t + 16 * (NV + 2);
+    u[0] = W.A0.x; u[16] = W.A0.y; u[32] = W.A0.z; u[48] = W.A0.w; u[64] = W.A1.x; u[80] = W.A1.y; u[96] = W.A1.z; u[112] = W.A1.w;
+    u[128] = W.A2.x; u[144] = W.A2.y; u[160] = W.A2.z; u[176] = W.A2.w; u[192] = W.A3.x; u[208] = W.A3.y; u[224] = W.A3.z; u[240] = W.A3.w;
+    u[256] = W.nw; u[272] = W.half; u[288] = fw;
+  };
+  auto load_ext = [&](const float* t, WnWin<NV>& W) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) W.J[k] = t[16 * k];
+    W.aref = t[16 * NV]; W.R = t[16 * (NV + 1)];
+    const float* u = t + 16 * (NV + 2);
+    W.A0 = make_float4(u[0], u[16], u[32], u[48]); W.A1 = make_float4(u[64], u[80], u[96], u[112]);
+    W.A2 = make_float4(u[128], u[144], u[160], u[176]); W.A3 = make_float4(u[192], u[208], u[224], u[240]);
+    W.nw = u[256]; W.half = u[272];
+  };
+  float* const xl = wn_lds + (rho * nl * NX) * 16 + q;                               // LDS tier: window NW + j at xl + j * NX * 16
+  float* const xg = wb + WN_ROWS + WN_MAXW * NK * 16 + q;                            // global tier: window w at xg + w * NX * 16
+  const int nwl = min(nwmax, NW + nl);
+#pragma unroll
+  for (int w = 0; w < NW; w++) if (w < nwmax) { load_rows(win[w], w); make_tile(win[w]); }
+  // The register-resident windows are swept two at a time: window 2j + 1 takes its residual from the acceleration BEFORE window 2j's
+  // deltas plus the cross tile X_j[r] = (-1 / AR_qq) J^_{2j+1,q} . J^_{2j,r} times those deltas (16 broadcast multiply-adds), so that both
+  // windows' J^T delta go through ONE transpose-reduce: ~255 instead of 300 issue slots per 32 rows on every env's chain.  Same rows, same
+  // order, same row math; the grouping of the arithmetic differs (fp32 rounding).
+  static_assert(NW % 2 == 0, "register-resident windows are swept in pairs");
+  float4 X[NW / 2][4];
+#pragma unroll
+  for (int j = 0; j < NW / 2; j++) if (2 * j + 1 < nwmax) {
+    WnWin<NV>& A = win[2 * j]; WnWin<NV>& B = win[2 * j + 1];
+    float acx[16];
+#pragma unroll
+    for (int sidx = 0; sidx < 16; sidx++) acx[sidx] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) asm volatile("" : "+v"(A.J[k]), "+v"(B.J[k]));
+    asm volatile("s_nop 1");
+#define WN_ACX(sidx) _Pragma("unroll") for (int k = 0; k < NV; k++) PP_FMAC_BC(acx[sidx], A.J[k], B.J[k], sidx);
+    PP_BC16(WN_ACX)
+#undef WN_ACX
+    X[j][0] = make_float4(B.nw * acx[0], B.nw * acx[1], B.nw * acx[2], B.nw * acx[3]);
+    X[j][1] = make_float4(B.nw * acx[4], B.nw * acx[5], B.nw * acx[6], B.nw * acx[7]);
+    X[j][2] = make_float4(B.nw * acx[8], B.nw * acx[9], B.nw * acx[10], B.nw * acx[11]);
+    X[j][3] = make_float4(B.nw * acx[12], B.nw * acx[13], B.nw * acx[14], B.nw * acx[15]);
+  }
+  for (int w = NW; w < nwl; w++) { WnWin<NV> W; load_rows(W, w); make_tile(W); store_ext(xl + (w - NW) * NX * 16, W, 0.0f); }
+  for (int w = nwl; w < nwmax; w++) { WnWin<NV> W; load_rows(W, w); make_tile(W); if (mine) store_ext(xg + w * NX * 16, W, 0.0f); }
+  // every window of the wave, register-resident ones first; the body sees the window W and its force fw
+#define WN_FOR_WINDOWS(...) do { \
+    _Pragma("unroll") for (int w = 0; w < NW; w++) if (w < nwmax) { WnWin<NV>& W = win[w]; float& fw = f[w]; __VA_ARGS__ } \
+    for (int w = NW; w < nwl; w++) { WnWin<NV> W; float* t = xl + (w - NW) * NX * 16; load_ext(t, W); float fw = t[16 * (NV + 20)]; __VA_ARGS__ t[16 * (NV + 20)] = fw; } \
+    for (int w = nwl; w < nwmax; w++) { WnWin<NV> W; float* t = xg + w * NX * 16; float fw = 0.0f; if (mine) { load_ext(t, W); fw = t[16 * (NV + 20)]; } else { load_rows(W, WN_MAXW); W.A0 = W.A1 = W.A2 = W.A3 = make_float4(0, 0, 0, 0); W.nw = 0; W.half = 0; } \
+                                          __VA_ARGS__ if (mine) t[16 * (NV + 20)] = fw; } } while (0)
+#define WN_ZERO_EXT_FORCES() do { for (int w = NW; w < nwl; w++) xl[(w - NW) * NX * 16 + 16 * (NV + 20)] = 0.0f; \
+                                  if (mine) for (int w = nwl; w < nwmax; w++) xg[w * NX * 16 + 16 * (NV + 20)] = 0.0f; } while (0)
+
+  // ---- warm start (mj_fwdConstraint): f = max(0, -(J a_ws - aref) / R), kept if the dual cost is not positive
+  float a_lo = as_lo, a_hi = as_hi;
+#pragma unroll
+  for (int w = 0; w < NW; w++) f[w] = 0.0f;
+  if (!(M.disableflags & MJH_DSBL_WARMSTART)) {
+    float da_lo = 0.0f, da_hi = 0.0f;
+    WN_FOR_WINDOWS({
+      const float jar = wn_dot<NV>(W.J, ws_lo, ws_hi) - W.aref;
+      fw = (jar < 0.0f && W.R > 0.0f) ? -jar / W.R : 0.0f;
+      wn_jt<NV>(W.J, fw, da_lo, da_hi);
+    });
+    float cost = 0.0f;
+    WN_FOR_WINDOWS({
+      const float jda = wn_dot<NV>(W.J, da_lo, da_hi), bb = wn_dot<NV>(W.J, as_lo, as_hi) - W.aref;
+      cost += fw * (0.5f * (jda + W.R * fw) + bb);
+    });
+    cost = wn_rowsum_f(cost);
+    if (cost > 0.0f) {
+#pragma unroll
+      for (int w = 0; w < NW; w++) f[w] = 0.0f;
+      WN_ZERO_EXT_FORCES();
+    } else { a_lo += da_lo; a_hi += da_hi; }
+  }
+  // ---- sweeps: every env (16-lane row) until ITS improvement falls below the tolerance
+  const ImpQ iq = imp_quantum(1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1)), M.tolerance);
+  const int itmax = M.iterations;
+  int niter = 0;
+  bool act = nrow > 0;
+  while (__ballot(act) != 0ull) {
+    if (act) {
+      int impl = 0;
+#define WN_SWEEP_ONE(W, fw) do { \
+        const float u = wn_dot<NV>(W.J, a_lo, a_hi); \
+        const float fo = fw; \
+        float tt = ((u - W.aref) + W.R * fo) * W.nw; \
+        const float nf = -fo; \
+        float dl; \
+        PP_ROWS4(0, 1, 2, 3, W.A0); PP_ROWS4(4, 5, 6, 7, W.A1); PP_ROWS4(8, 9, 10, 11, W.A2); PP_ROWS4(12, 13, 14, 15, W.A3); \
+        asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf)); \
+        impl += imp_fixed((W.half * dl) * (2.0f * tt - dl), iq.qs); \
+        fw = fo + dl; \
+        wn_jt<NV>(W.J, dl, a_lo, a_hi); } while (0)
+      // register-resident windows: pairs (see the cross tiles above), a last odd one alone
+#pragma unroll
+      for (int j = 0; j < NW / 2; j++) if (2 * j < nwmax) {
+        if (2 * j + 1 < nwmax) {
+          WnWin<NV>& A = win[2 * j]; WnWin<NV>& B = win[2 * j + 1];
+          const float ua = wn_dot<NV>(A.J, a_lo, a_hi), ub = wn_dot<NV>(B.J, a_lo, a_hi);
+          float dla, dlb;
+          {
+            const float fo = f[2 * j];
+            float tt = ((ua - A.aref) + A.R * fo) * A.nw;
+            const float nf = -fo;
+            float dl;
+            PP_ROWS4(0, 1, 2, 3, A.A0); PP_ROWS4(4, 5, 6, 7, A.A1); PP_ROWS4(8, 9, 10, 11, A.A2); PP_ROWS4(12, 13, 14, 15, A.A3);
+            asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));
+            impl += imp_fixed((A.half * dl) * (2.0f * tt - dl), iq.qs);
+            f[2 * j] = fo + dl; dla = dl;
+          }
+          {
+            const float fo = f[2 * j + 1];
+            float tt = ((ub - B.aref) + B.R * fo) * B.nw;
+            float dx = dla;
+            asm volatile("s_nop 1" : "+v"(dx));
+            WN_CROSS4A(0, 1, 2, 3, X[j][0]); WN_CROSS4A(4, 5, 6, 7, X[j][1]); WN_CROSS4A(8, 9, 10, 11, X[j][2]); WN_CROSS4A(12, 13, 14, 15, X[j][3]);
+            const float nf = -fo;
+            float dl;
+            PP_ROWS4(0, 1, 2, 3, B.A0); PP_ROWS4(4, 5, 6, 7, B.A1); PP_ROWS4(8, 9, 10, 11, B.A2); PP_ROWS4(12, 13, 14, 15, B.A3);
+            asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));
+            impl += imp_fixed((B.half * dl) * (2.0f * tt - dl), iq.qs);
+            f[2 * j + 1] = fo + dl; dlb = dl;
+          }
+          wn_jt2<NV>(A.J, dla, B.J, dlb, a_lo, a_hi);
+        } else { WnWin<NV>& W = win[2 * j]; WN_SWEEP_ONE(W, f[2 * j]); }
+      }
+      // the tiers beyond them: one window at a time
+      for (int w = NW; w < nwl; w++) { WnWin<NV> W; float* t = xl + (w - NW) * NX * 16; load_ext(t, W); float fw = t[16 * (NV + 20)]; WN_SWEEP_ONE(W, fw); t[16 * (NV + 20)] = fw; }
+      for (int w = nwl; w < nwmax; w++) {
+        WnWin<NV> W; float* t = xg + w * NX * 16; float fw = 0.0f;
+        if (mine) { load_ext(t, W); fw = t[16 * (NV + 20)]; } else { load_rows(W, WN_MAXW); W.A0 = W.A1 = W.A2 = W.A3 = make_float4(0, 0, 0, 0); W.nw = 0; W.half = 0; }
+        WN_SWEEP_ONE(W, fw);
+        if (mine) t[16 * (NV + 20)] = fw;
+      }
+#undef WN_SWEEP_ONE
+      niter++;
+      if (wn_rowsum_i(impl) < iq.thr || niter >= itmax) act = false;
+    }
+  }
+  // ---- qacc, mj_checkAcc, semi-implicit Euler (mj_Euler; free joints only), state and statistics
+  const float sv_lo = (mine && lo_on) ? wb[WN_SINV + q] : 0.0f, sv_hi = (mine && hi_on) ? wb[WN_SINV + dhi] : 0.0f;
+  float qa_lo = a_lo * sv_lo, qa_hi = a_hi * sv_hi;
+  float qv_lo = (mine && lo_on) ? wb[WN_QVEL + q] : 0.0f, qv_hi = (mine && hi_on) ? wb[WN_QVEL + dhi] : 0.0f;
+  int flags = mine ? wh[3] : 0;
+  if (mine && (xflags & XF_FORCE)) {   // the split API's exports (mjh_step2): qacc_smooth and qfrc_constraint = M (qacc - qacc_smooth), indexed by the row inside the launch's range
+    const size_t xe = (size_t)(env - env0) * M.nvp;
+    if (lo_on) { if (S.x_smooth) S.x_smooth[xe + q] = as_lo * sv_lo; if (S.x_constraint) S.x_constraint[xe + q] = (a_lo - as_lo) / sv_lo; }
+    if (hi_on && (NV != 24 || !(q & 1))) { if (S.x_smooth) S.x_smooth[xe + dhi] = as_hi * sv_hi; if (S.x_constraint) S.x_constraint[xe + dhi] = (a_hi - as_hi) / sv_hi; }
+  }
+  const bool badl = !(qa_lo == qa_lo) || fabsf(qa_lo) > MJ_MAXVAL || !(qa_hi == qa_hi) || fabsf(qa_hi) > MJ_MAXVAL;
+  const bool bad = ((__ballot(badl) >> (16 * rho)) & 0xffffull) != 0ull;
+  const size_t qrow = (size_t)env * M.nqp, vrow = (size_t)env * M.nvp;
+  if (bad) { qa_lo = qa_hi = 0.0f; qv_lo = qv_hi = 0.0f; flags |= 4; }
+  const float h = M.timestep;
+  const Tab<int> dof_bodyid{M.I, M.o_dof_bodyid}, jnt_qposadr{M.I, M.o_jnt_qposadr}, jnt_dofadr{M.I, M.o_jnt_dofadr};
+  const Tab<float> dof_damping{M.F, M.o_dof_damping};
+  const unsigned slotmask = S.slot_mask ? S.slot_mask[env] : 0u;
+  const int sbase = M.nbody > 32 ? M.nbody - 32 : 0;
+  __shared__ float s_v[4][32];
+  __shared__ float s_qp[4][40];
+  const bool has_odom = M.I[M.o_odom + 9] != 0;
+  auto advance = [&](const int d, float& qa, float& qv) __attribute__((always_inline)) {
+    float qint = qa;
+    if (M.has_damping && !(M.disableflags & MJH_DSBL_EULERDAMP)) {
+      // (M + h D) qacc' = M qacc, M diagonal: qacc' = qacc - h D qacc / (M_dd + h D)
+      const float sv = wb[WN_SINV + d], Mdd = 1.0f / (sv * sv), D = dof_damping[d];
+      qint = qa - h * (D * qa) / (Mdd + h * D);
+    }
+    const unsigned rb = (unsigned)(dof_bodyid[d] - sbase);
+    const bool parked = rb < 32u && ((slotmask >> rb) & 1u);
+    qv = parked ? 0.0f : qv + h * qint;
+    if (parked) qa = 0.0f;
+    S.qvel[vrow + d] = qv; S.qacc_ws[vrow + d] = qa;
+    if (bad && (xflags & XF_SPLIT2)) S.qfrc_applied[vrow + d] = 0.0f;
+    s_v[rho][d] = qv;
+  };
+  if (mine && lo_on) advance(q, qa_lo, qv_lo);
+  if (mine && hi_on && (NV != 24 || !(q & 1))) advance(dhi, qa_hi, qv_hi);
+  __syncthreads();
+  if (mine && q < M.njnt) {
+    const int qadr = jnt_qposadr[q], da = jnt_dofadr[q];
+    float p[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) p[k] = bad ? S.initial_qpos[qrow + qadr + k] : wb[WN_QPOS + qadr + k];
+    const float* v = s_v[rho] + da;
+    p[0] += h * v[0]; p[1] += h * v[1]; p[2] += h * v[2];
+    float w3[3] = {v[3], v[4], v[5]};
+    quat_integrate(p + 3, w3, h);
+#pragma unroll
+    for (int k = 0; k < 7; k++) { S.qpos[qrow + qadr + k] = p[k]; s_qp[rho][qadr + k] = p[k]; }
+  }
+  if (has_odom) {
+    __syncthreads();
+    if (mine && q == 0) wn_odom(M, S, env, s_qp[rho], S.qvel + vrow);
+  }
+  if (mine && q == 0) {
+    S.time[env] += M.timestep_d;
+    // launch-order hint: sweeps x windows in units of the fused kernel's hint (patch_pgs.h: about four instructions)
+    const int cost_hint = min(niter * nwin * 20 + 1, 1 << 22);
+    S.stats[4 * env] = wh[1]; S.stats[4 * env + 1] = wh[2]; S.stats[4 * env + 2] = niter;
+    S.stats[4 * env + 3] = ((S.stats[4 * env + 3] | flags) & 0xff) | (cost_hint << 8);
+  }
+#undef WN_FOR_WINDOWS
+#undef WN_ZERO_EXT_FORCES
+}
