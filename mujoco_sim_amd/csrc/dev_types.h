@@ -47,7 +47,7 @@ struct DModel {
   int patch, pool, pool_floats, pdesc, pslot;
   // window sweep (window_pgs.h): the fused step of a patch-eligible model in row order as two launches, assemble (PH_PRE) -> mjh_window_kernel
   // (four envs per wavefront, rows in registers); win_nvt: dof slots of a row record (24 or 32)
-  int window, win_nvt;
+  int window, win_nvt, win_maxw;     // win_maxw: windows of 16 rows an env can hand over (min(WN_MAXW, ceil(maxefc / 16)); rows beyond are dropped with the capacity flag)
   int pgs_row_order;   // 1: Gauss-Seidel visits the constraint rows in their own order, one block after the other (mj_solPGS's order; mjh_set_pgs_row_order)
   // dense row-space solver of the many-body layout (dense_pgs.h): on / off, row capacity (a multiple of 64, <= 256), nv padded to 16
   int dense, dense_cap, dense_nvs;

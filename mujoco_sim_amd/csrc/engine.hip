@@ -221,6 +221,7 @@ static int pair_cap(int t1, int t2) {
 // layout.  Needs no HIP device (mjh_query_lds_bytes uses it for capacity planning and in the CPU tests).
 struct HostPack { DModel M{}; Lay L{}; std::vector<int> I; std::vector<float> F; int o_controlled = 0, o_odom = 0, lds_bytes = 0, lds_bytes_pre = 0; long long gstride = 0; };
 // Gauss-Seidel order of engines created afterwards (mjhip.h): 1 = mj_solPGS's own row order
+#define MJH_WINDOW_MAXCON 128    // contact capacity up to which a small free-body model steps through the window chain
 static int g_window_solver = getenv("MJH_WINDOW") ? (atoi(getenv("MJH_WINDOW")) != 0) : 1;
 extern "C" void mjh_set_window_solver(int on) { g_window_solver = on ? 1 : 0; }
 static int g_pgs_row_order = 1;
@@ -363,12 +364,17 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     // same rules as the oracle's (oracle/mjh_oracle.c: m_row_order)
     M.pgs_row_order = g_pgs_row_order;
     if (!M.pgs_row_order && nv > 32) for (int t = 0; t < m->ntree; t++) if (m->tree_dofnum[t] > 16) M.pgs_row_order = 1;
-    const bool patch = allow_patch && diagM && !big && nv <= 32 && M.noslip_iterations == 0 && M.maxcon <= 64 && !keep;
+    const bool small_free = allow_patch && diagM && !big && nv <= 32 && M.noslip_iterations == 0 && !keep;
+    const bool patch = small_free && M.maxcon <= 64;
     M.patch = patch ? 1 : 0;
-    // window sweep (window_pgs.h): mjh_step of a patch-eligible model in row order = assemble launch + mjh_window_kernel (MJH_WINDOW=0 /
-    // mjh_set_window_solver(0): the fused kernel's patch sweep instead — same order, same iterates up to fp32 rounding)
-    M.window = (patch && M.pgs_row_order != 0 && g_window_solver && nv <= 32 && m->njnt <= 16 && m->nq <= 40) ? 1 : 0;
+    // window sweep (window_pgs.h): mjh_step of a small free-body model in row order = assemble launch + mjh_window_kernel (MJH_WINDOW=0 /
+    // mjh_set_window_solver(0): the fused kernel's sweep instead — same order, same iterates up to fp32 rounding).  The window chain
+    // has no tie to one contact per lane: models of this class with a contact capacity of 65 .. MJH_WINDOW_MAXCON keep the LDS-resident
+    // layout WITHOUT the patch sweep (the fused kernel's dual-block sweep, list-scheduled in the same row order, serves the launches
+    // that are not whole steps) and step through the window chain (mj_collision itself has no cap: mj_main.cpp:83)
+    M.window = (small_free && M.maxcon <= MJH_WINDOW_MAXCON && M.pgs_row_order != 0 && g_window_solver && nv <= 32 && m->njnt <= 16 && m->nq <= 40) ? 1 : 0;
     M.win_nvt = nv <= 24 ? 24 : 32;
+    M.win_maxw = std::max(1, std::min(WN_MAXW, (M.maxefc + 15) / 16));
     L.qpos = put(m->nq);
     L.qvel = put(nv); L.qvref = put(nv); L.ws = put(nv); L.qacc = put(nv); L.smooth = put(nv); L.asmooth = put(nv); L.passive = put(nv);
     L.bias = put(nv); L.applied = put(nv); L.tmpv = put(nv); L.tmpv2 = put(nv);
@@ -489,7 +495,7 @@ static void derive_fitting(const mjh_model* m, HostPack& hp) {
   const int limit = policy == 1 ? 160 * 1024 : (policy == 2 ? 0 : MJH_LDS_RESIDENT_MAX);
   // (models on the contact-patch sweep stay LDS-resident under the default policy: their visiting order is the patch order,
   //  which the many-body layout does not have; mjh_solver_order() tells which one an engine runs)
-  if (hp.M.patch && policy == 0 && hp.lds_bytes <= 64 * 1024) return;
+  if ((hp.M.patch || hp.M.window) && policy == 0 && hp.lds_bytes <= 64 * 1024) return;
   // The patch sweep packs two LDS byte addresses into one 32-bit word (patch_pgs.h: laddr(x) | laddr(y) << 16), which holds
   // only while the workgroup's LDS stays within 64 KiB.  A patch model that would stay LDS-resident beyond that (policy 1 /
   // MJH_FORCE_BIG=0 with a large user-set maxefc) is re-derived WITHOUT the patch sweep (pair order, mjh_solver_order() = 0).
@@ -596,8 +602,8 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   if (M.big) rc |= dev_alloc(e, &S.gscratch, (size_t)nenv * (size_t)hp.gstride, false);   // many-body models: contact / block / Jacobian pools
   S.wbuf = nullptr; S.wstride = 0;
   S.win32 = getenv("MJH_WINDOW32") ? std::max(0, atoi(getenv("MJH_WINDOW32"))) : WN32_MIN_ROWS;     // (0: off; experiments: another row threshold)
-  if (M.window) {   // window sweep: header + vectors + WN_MAXW windows of rows + tiles of the streamed windows, per env
-    S.wstride = ((WN_ROWS + WN_MAXW * (M.win_nvt + 2) * 16 + WN_MAXW * WN_XREC(M.win_nvt) * 16 + 63) / 64) * 64;
+  if (M.window) {   // window sweep: header + vectors + win_maxw windows of rows + tiles of the streamed windows, per env
+    S.wstride = ((WN_ROWS + M.win_maxw * (M.win_nvt + 2) * 16 + M.win_maxw * WN_XREC(M.win_nvt) * 16 + 63) / 64) * 64;
     rc |= dev_alloc(e, &S.wbuf, (size_t)nenv * (size_t)S.wstride, true);
   }
   if (M.window && e->lpt && nenv >= 1024) {

@@ -988,7 +988,7 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
   // window sweep (window_pgs.h): assemble launch of a patch-eligible free-body model; an env WITHOUT constraint rows (or with more than
   // the window kernel takes) finishes the step in this launch and leaves 0 in its hand-over header
   bool wpre = false;
-  if constexpr (DIAGM && NROW <= 2) wpre = M.window != 0 && M.patch != 0 && (ph & PH_PRE) && S.wbuf != nullptr;
+  if constexpr (DIAGM && NROW <= 2) wpre = M.window != 0 && (ph & PH_PRE) && S.wbuf != nullptr;
   if (wpre && lane == 0) { int* wh0 = (int*)(S.wbuf + (size_t)env * (size_t)S.wstride); wh0[0] = 0; wh0[4] = 0; wh0[5] = 0; }
   if (post) for (int i = lane; i < nv; i += 64) s_qvel[i] = gs[L.g_qvel + i];     // (the controller may have overridden velocities)
   double time = S.time[env];
@@ -2362,8 +2362,8 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
         // ---- warm start (mj_fwdConstraint): forces implied by qacc_warmstart, kept if their dual cost < 0
         const bool warm = !(M.disableflags & MJH_DSBL_WARMSTART);
         bool zero_f = !warm;
-        bool patch_ws = false;   // contact-patch sweep: the warm start runs in patch form, after the patches are built
-        if constexpr (DIAGM && NROW <= 2) patch_ws = M.patch != 0;
+        bool patch_ws = false;   // contact-patch sweep: the warm start runs in patch form, after the patches are built (window hand-over: in the window kernel)
+        if constexpr (DIAGM && NROW <= 2) patch_ws = M.patch != 0 || wpre;
         if (warm && !patch_ws) {
           base_dots(s_ws, s_bv);
           forces_from(s_bv, true);
@@ -2400,7 +2400,7 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
         WSYNC();
         bool patched = false;
         if constexpr (DIAGM && NROW <= 2) {
-          if (M.patch) {
+          if (M.patch || wpre) {
             // ---- contact-patch sweep (patch_pgs.h): the blocks are regrouped into patches of up to 16 rows between the same
             //      bodies; the running acceleration lives in LDS in the scaled coordinates a^ = M^1/2 a
             patched = true;
@@ -2420,8 +2420,8 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
               //      the dofs, aref, R), M^1/2 qacc_smooth, M^1/2 qacc_warmstart, M^-1/2, qvel after the controller, the normalised qpos.
               float* wb = S.wbuf + (size_t)env * (size_t)S.wstride;
               // (the split API's hand-over has no sweep to fall back to either: rows beyond the capacity are dropped with the flag, never the whole set)
-              const int nrow = window_emit(wb, M.win_nvt, s_blki_i, s_blkf, s_J, s_bias, nblk, lane, WPRE || wdefer);
-              if ((WPRE || wdefer) && nefc > nrow) flags |= 2;          // (rows beyond the window kernel's capacity were dropped)
+              const int nrow = window_emit(wb, M.win_nvt, M.win_maxw, s_blki_i, s_blkf, s_J, s_bias, nblk, lane, WPRE || wdefer || !M.patch);
+              if ((WPRE || wdefer || !M.patch) && nefc > nrow) flags |= 2;          // (rows beyond the window kernel's capacity were dropped)
               if (nrow > 0 || wdefer) {
                 for (int d = lane; d < nv; d += 64) { wb[WN_AS + d] = s_qacc[d]; wb[WN_AWS + d] = s_tmpv2[d]; wb[WN_SINV + d] = s_bias[d]; wb[WN_QVEL + d] = s_qvel[d]; }
                 for (int i = lane; i < nq; i += 64) wb[WN_QPOS + i] = s_qpos[i];
@@ -2437,7 +2437,7 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
               }
               // (more rows than the window kernel takes: this env finishes the step here, in patch form)
             }
-            if constexpr (!WPRE) {
+            if constexpr (!WPRE) if (M.patch) {      // (window-only models — more than 64 contacts — never get here: their hand-over clamps)
             int swork = 0, npatch = 0;
             const int nstep = patch_build(pa, lane, flags, swork, npatch);
             if (warm) patch_warmstart(pa, lane, nstep, npatch, L.tmpv2, L.qacc, L.tmpv);

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
     W.nw = u[256]; W.half = u[272];
   };
   float* const xl = wn_lds + (rho * nl * NX) * 16 + q;                               // LDS tier: window NW + j at xl + j * NX * 16
-  float* const xg = wb + WN_ROWS + WN_MAXW * NK * 16 + q;                            // global tier: window w at xg + w * NX * 16
+  float* const xg = wb + WN_ROWS + M.win_maxw * NK * 16 + q;                            // global tier: window w at xg + w * NX * 16
   const int nwl = min(nwmax, NW + nl);
 #pragma unroll
   for (int w = 0; w < NW; w++) if (w < nwmax) { load_rows(win[w], w); make_tile(win[w]); }

@@ -29,7 +29,7 @@
 #define WN_QPOS 144     // qpos after mj_kinematics' quaternion normalisation [40]
 #define WN_ROWS 192     // window w at WN_ROWS + w * NK * 16: [k][16 rows], k < NK = NVT + 2: J^[NVT], aref, R
 #define WN32_MIN_ROWS 96   // rows above which an env is swept in 32-row windows (3.5 % of S24's envs: the ones a cohort's step waits for)
-#define WN_MAXW 16      // windows per env (256 rows: the capacity of the patch sweep as well)
+#define WN_MAXW 24      // most windows per env any model gets (384 rows); a model's own capacity: DModel::win_maxw = min(WN_MAXW, ceil(maxefc / 16))
 #define WN_XREC(nvt) ((nvt) + 21)   // record of a window beyond the register-resident ones, per row: J^[nvt], aref, R, 16 tile entries, -1 / AR_qq, AR_qq / 2, force
 #ifndef WN_NW24
 #define WN_NW24 6       // register-resident windows of the 24-dof instance (96 rows: what the 16-row form meets with the 32-row section on; S24 has 72 on average), the rest is streamed
@@ -41,49 +41,61 @@
 
 // Assemble launch (mjh_step_kernel with PH_PRE, free-body instance): the constraint blocks of this env -> window rows in global memory.
 // blki / blkf / J: the block tables in LDS (step_kernel.h); sinv = M^-1/2 per dof.  Returns the number of rows (0: too many, not written).
-// `clamp` (the assemble-only kernel instance, which has no sweep of its own to fall back to): rows beyond the window kernel's 256 are dropped,
+// `clamp` (the assemble-only kernel instance, which has no sweep of its own to fall back to): rows beyond the model's window capacity (16 maxw) are dropped,
 // like contacts beyond maxcon (the caller raises the capacity flag), instead of handing nothing over.
-DEV int window_emit(float* __restrict__ wb, const int nvt, const int* blki, const float* blkf, const float* J, const float* sinv, const int nblk, const int lane, const bool clamp = false) {
+DEV int window_emit(float* __restrict__ wb, const int nvt, const int maxw, const int* blki, const float* blkf, const float* J, const float* sinv, const int nblk, const int lane, const bool clamp = false) {
   const int4* blki4 = (const int4*)blki;
   const int nk = nvt + 2;
-  int4 hd = make_int4(0, 0, 0, 0);
-  if (lane < nblk) hd = blki4[lane];
-  const int myn = lane < nblk ? (hd.x >> 4) & 15 : 0;
-  const int incl = wave_incl_scan_i(myn, lane);
-  int nrow = __shfl(incl, 63);
-  if (nrow > 16 * WN_MAXW) { if (!clamp) return 0; nrow = 16 * WN_MAXW; }
+  // rows of every block: blocks in chunks of 64 (one per lane), the running row count carried from chunk to chunk
+  int total = 0;
+  for (int b0 = 0; b0 < nblk; b0 += 64) {
+    const int b = b0 + lane;
+    const int myn = b < nblk ? (blki4[b].x >> 4) & 15 : 0;
+    total += __shfl(wave_incl_scan_i(myn, lane), 63);
+  }
+  int nrow = total;
+  if (nrow > 16 * maxw) { if (!clamp) return 0; nrow = 16 * maxw; }
   const int nwin = (nrow + 15) >> 4;
   // padding rows of the last window: zeros (inert: AR_qq = 0 -> -1 / AR_qq stored as 0)
   for (int t = lane; t < (16 * nwin - nrow) * nk; t += 64) {
     const int r = nrow + t / nk, k = t - (t / nk) * nk;
     wb[WN_ROWS + ((r >> 4) * nk + k) * 16 + (r & 15)] = 0.0f;
   }
-  if (lane < nblk) {
-    const int a1 = hd.z & 0xffff, a2 = hd.w & 0xffff; const bool two = (hd.w >> 16) != 0, single = myn == 1;
-    const float* Jb = J + BLK_JOFF(hd.x);
-    float4 jb[12];
+  int base = 0;
+  for (int b0 = 0; b0 < nblk && base < nrow; b0 += 64) {
+    const int b = b0 + lane;
+    int4 hd = make_int4(0, 0, 0, 0);
+    if (b < nblk) hd = blki4[b];
+    const int myn = b < nblk ? (hd.x >> 4) & 15 : 0;
+    const int incl = wave_incl_scan_i(myn, lane);
+    if (b < nblk) {
+      const int a1 = hd.z & 0xffff, a2 = hd.w & 0xffff; const bool two = (hd.w >> 16) != 0, single = myn == 1;
+      const float* Jb = J + BLK_JOFF(hd.x);
+      float4 jb[12];
 #pragma unroll
-    for (int k = 0; k < 12; k++) jb[k] = (k < 6 || two) ? *(const float4*)(Jb + 4 * k) : make_float4(0, 0, 0, 0);
-    float sc[12];
+      for (int k = 0; k < 12; k++) jb[k] = (k < 6 || two) ? *(const float4*)(Jb + 4 * k) : make_float4(0, 0, 0, 0);
+      float sc[12];
 #pragma unroll
-    for (int k = 0; k < 12; k++) sc[k] = (k < 6 || two) ? sinv[k < 6 ? a1 + k : a2 + k - 6] : 0.0f;
-    const float* bf = blkf + lane * BLKF_STRIDE;
-    const int row0 = incl - myn;
-    for (int r = 0; r < myn; r++) {
-      const int g = row0 + r;
-      if (g >= nrow) break;
-      float* o = wb + WN_ROWS + (g >> 4) * nk * 16 + (g & 15);
-      const int kk = 1 + (r >> 1); const float c = (r & 1) ? -1.0f : 1.0f;
-      for (int k = 0; k < nvt; k++) o[16 * k] = 0.0f;
+      for (int k = 0; k < 12; k++) sc[k] = (k < 6 || two) ? sinv[k < 6 ? a1 + k : a2 + k - 6] : 0.0f;
+      const float* bf = blkf + b * BLKF_STRIDE;
+      const int row0 = base + incl - myn;
+      for (int r = 0; r < myn; r++) {
+        const int g = row0 + r;
+        if (g >= nrow) break;
+        float* o = wb + WN_ROWS + (g >> 4) * nk * 16 + (g & 15);
+        const int kk = 1 + (r >> 1); const float c = (r & 1) ? -1.0f : 1.0f;
+        for (int k = 0; k < nvt; k++) o[16 * k] = 0.0f;
 #pragma unroll
-      for (int k = 0; k < 12; k++) {
-        if (k >= 6 && !two) continue;
-        const float v = single ? jb[k].x : jb[k].x + c * (kk == 1 ? jb[k].y : (kk == 2 ? jb[k].z : jb[k].w));
-        o[16 * (k < 6 ? a1 + k : a2 + k - 6)] = v * sc[k];
+        for (int k = 0; k < 12; k++) {
+          if (k >= 6 && !two) continue;
+          const float v = single ? jb[k].x : jb[k].x + c * (kk == 1 ? jb[k].y : (kk == 2 ? jb[k].z : jb[k].w));
+          o[16 * (k < 6 ? a1 + k : a2 + k - 6)] = v * sc[k];
+        }
+        o[16 * nvt] = single ? bf[BF_AREF] : bf[BF_AREF] + c * bf[BF_AREF + kk];
+        o[16 * (nvt + 1)] = bf[0];
       }
-      o[16 * nvt] = single ? bf[BF_AREF] : bf[BF_AREF] + c * bf[BF_AREF + kk];
-      o[16 * (nvt + 1)] = bf[0];
     }
+    base += __shfl(incl, 63);
   }
   return nrow;
 }

@@ -89,3 +89,81 @@ def test_split_api_statistics_between_the_two_halves_are_this_steps():
     e.step2(); f.step2()
     assert np.array_equal(e.get_stats()[:, :2], f.get_stats()[:, :2])
     e.close(); f.close()
+
+
+# ---------------------------------------------------------------- S24D beyond 64 contacts (the "30-contact" scene without a capacity flag)
+# bench.py's s24d seeds whose piles exceeded 64 contacts between steps 400 and 1400 of the r04 code (tools/r05_hist.py; 66 .. 68 contacts,
+# 276 .. 300 rows) — the envs the 64-contact capacity of rounds 3 / 4 flagged and dropped contacts in
+S24D_HEAVY_SEEDS = [1956, 2548, 2422, 375, 3623, 1290, 1556, 2278, 2967, 3149, 3445, 3669, 4044]
+S24D_CAPACITY = 96
+
+
+def _s24d_seeds(seeds, capacity=S24D_CAPACITY, window=True):
+    """bench.py's S24D for the given env ids (per-env sizes / masses from the S24 seed of that id, released flat 2 x 2 with the id's yaws)"""
+    pen = 0.175
+    m = ms.scene("s24pen", pen, capacity)
+    e = _engine(m, len(seeds), window)
+    parts = [m.s24_randomize(int(s), 1) for s in seeds]
+    tab = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    q = tab["qpos"].reshape(len(seeds), 4, 7)
+    for i, s in enumerate(seeds):
+        rng = np.random.default_rng(0x524D0000 + int(s))
+        for k in range(4):
+            yaw = rng.uniform(-0.3, 0.3)
+            q[i, k] = [(-1 if k & 1 else 1) * pen / 2, (-1 if k & 2 else 1) * pen / 2, 0.16 + 0.02 * k, np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)]
+    e.load_tables(tab)
+    return m, e, tab
+
+
+def test_s24d_capacity_above_64_contacts_takes_the_window_chain():
+    """a small free-body model with a contact capacity of 65 .. 128 keeps the window chain (no contact-patch sweep: that one is tied to
+    one contact per lane); its row capacity follows maxefc up to 24 windows"""
+    m = ms.scene("s24pen", 0.175, S24D_CAPACITY)
+    e = _engine(m, 8, True)
+    assert e.window_solver() == 1 and e.patch_sweep() == 0 and e.solver_order() == 2
+    e.close()
+    m64 = ms.scene("s24pen", 0.175, 64)
+    e = _engine(m64, 8, True)
+    assert e.window_solver() == 1 and e.patch_sweep() == 1
+    e.close()
+
+
+def test_s24d_teacher_forced_including_the_envs_above_64_contacts():
+    """the S24D envs that exceeded the 64-contact capacity, teacher-forced against the oracle.  64 envs — the 13 seeds
+    above and the first 51 — settle 450 steps on the device (where the heavy seeds carry 60+ contacts), the oracles take the device's
+    state over, then 100 steps teacher-forced at S24's tolerances with no capacity flag anywhere; the sample must contain env-steps
+    with more than 64 contacts and with more than 256 rows (beyond the old row capacity as well)."""
+    from test_gpu_teacher_forced import teacher_forced, summarize, S24_TOL_Q, S24_TOL_V
+    seeds = S24D_HEAVY_SEEDS + list(range(51))
+    m, e, tab = _s24d_seeds(seeds)
+    e.step(450)
+    t, q, v, w = e.get_state()
+    st0 = e.get_stats()
+    assert (st0[:, 3] & 3 == 0).all(), "no capacity flag while settling"
+    ds = [oracle_s24(m, tab, i) for i in range(len(seeds))]
+    for i, d in enumerate(ds):
+        d.f("qpos")[:] = q[i]; d.f("qvel")[:] = v[i]; d.f("qacc_warmstart")[:] = w[i]; d.f("time")[0] = t[i]
+    r = teacher_forced(e, ds, 100)
+    s = summarize("s24d-capacity96/default=mj_solPGS-row-order(window sweep), 13 seeds beyond 64 contacts + 51", r)
+    a = r["agree"].astype(bool)
+    heavy = r["ncon"] > 64
+    print(f"S24D-HEAVY env-steps with > 64 contacts: {int(heavy.sum())} (agreeing {int((heavy & a).sum())}), max ncon {int(r['ncon'].max())}, max rows {int(r['nefc'].max())}, "
+          f"env-steps with > 256 rows {int((r['nefc'] > 256).sum())}")
+    for lo, hi in ((0, 128), (129, 192), (193, 256), (257, 400)):
+        mk = a & (r["nefc"] >= lo) & (r["nefc"] <= hi)
+        if mk.any():
+            print(f"S24D-HEAVY rows {lo}-{hi}: {int(mk.sum())} env-steps, qpos max {r['eq'][mk].max():.2e}, qvel 99% {np.quantile(r['ev'][mk], 0.99):.2e} max {r['ev'][mk].max():.2e}, "
+                  f"sweeps dev/oracle differ in {int((r['iter'][mk] != r['diter'][mk]).sum()) if 'diter' in r else -1}")
+    worst = np.unravel_index(np.argmax(np.where(a, r["ev"], 0)), r["ev"].shape)
+    print(f"S24D-HEAVY worst qvel env-step: step {worst[0]} env {worst[1]} (seed {seeds[worst[1]]}): ncon {int(r['ncon'][worst])} rows {int(r['nefc'][worst])} sweeps {int(r['iter'][worst])} ev {r['ev'][worst]:.2e} eq {r['eq'][worst]:.2e} ea {r['ea'][worst]:.2e}")
+    assert heavy.sum() >= 20 and (heavy & a).sum() >= 10, "the sample must cover env-steps beyond the old contact capacity"
+    assert r["nefc"].max() > 256
+    assert s["agree_fraction"] >= 0.95, s
+    # qpos at S24's tolerance; qvel: fp32 round-off at the 100-sweep cap grows with the row count (measured: max 1.3e-5 up to 128 rows,
+    # 2.8e-5 up to 192, 8.6e-5 up to 256, 3.7e-5 beyond; 99 % 2.3e-5 in the worst class) — S24's 2e-5 for the 99 % quantile of the
+    # whole sample, 2e-4 for its maximum, the same bound for the env-steps beyond 64 contacts
+    assert r["eq"][a].max() <= S24_TOL_Q and np.quantile(r["ev"][a], 0.99) <= S24_TOL_V and r["ev"][a].max() <= 2e-4, s
+    assert r["eq"][heavy & a].max() <= S24_TOL_Q and r["ev"][heavy & a].max() <= 2e-4
+    st = e.get_stats()
+    assert (st[:, 3] & 3 == 0).all(), "no capacity flag"
+    e.close()

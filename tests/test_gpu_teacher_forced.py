@@ -50,7 +50,7 @@ def teacher_forced(e, ds, nsteps, with_inverse=False):
     agree: same ncon / nefc, no capacity flag, AND the same contact records (device snapshot at the state just set, before the step,
     against the oracle's contacts of that step: _same_contacts)"""
     n = len(ds)
-    out = {k: np.zeros((nsteps, n)) for k in ("eq", "ev", "ea", "agree", "ncon", "nefc", "iter", "samecon")}
+    out = {k: np.zeros((nsteps, n)) for k in ("eq", "ev", "ea", "agree", "ncon", "nefc", "iter", "diter", "samecon")}
     for k in range(nsteps):
         e.set_state(qpos=np.array([d.f("qpos") for d in ds]), qvel=np.array([d.f("qvel") for d in ds]),
                     time=np.array([d.f("time")[0] for d in ds]), warmstart=np.array([d.f("qacc_warmstart") for d in ds]))
@@ -65,7 +65,7 @@ def teacher_forced(e, ds, nsteps, with_inverse=False):
         same = np.array([_same_contacts(dcs[i], ds[i].contacts()) for i in range(n)])
         out["samecon"][k] = same
         out["agree"][k] = (st[:, 0] == on) & (st[:, 1] == oe) & (st[:, 3] & 7 == 0) & same
-        out["ncon"][k] = on; out["nefc"][k] = oe; out["iter"][k] = [d.i("solver_iter") for d in ds]
+        out["ncon"][k] = on; out["nefc"][k] = oe; out["iter"][k] = [d.i("solver_iter") for d in ds]; out["diter"][k] = st[:, 2]
     return out
 
 
