@@ -132,7 +132,7 @@ class S24D(S24):
     together (16 floor contacts of condim 4) and are wedged against each other and the walls — ~30 contacts, ~130 rows per env, what
     SURVEY.md §8-d D2 expected of the scene.  Reported beside the D2-exact S24 line, never instead of it."""
     name = "s24d"; settle_steps = 400; min_ncon = 20.0
-    pen_half = 0.175; capacity = 64
+    pen_half = 0.175; capacity = 96      # (piles reach 68 contacts / 300 rows: tools/r05_hist.py; up to 64 the model keeps the contact-patch sweep as well)
     label = ("S24D: S24's pen and 4 free boxes (same sizes / seeds), released flat in a 2 x 2 layout with random yaw: ~30 contacts, ~130 rows per env, "
              "PGS 100 it / tol 1e-8")
 

@@ -24,6 +24,9 @@ SOURCES = {
     "mjcf_loader.cpp": ["hmath.h", API],
 }
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-Wno-unused-result"]
+# per-source flags.  window.hip: its window forms are written as fully unrolled loops over register-resident windows; past clang's default
+# budget for `#pragma unroll` (16 k instructions) a window loop stays a loop and its operand arrays land in scratch memory
+SOURCE_FLAGS = {"window.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
 FLAGS += os.environ.get("MJH_EXTRA_FLAGS", "").split()      # A/B builds (e.g. -DPP_NRC=0 -DMJH_STEP_WAVES=3), together with MJH_BUILD_DIR / MJHIP_LIB
 if os.environ.get("MJH_BUILD_DIR"):
     OBJ = os.environ["MJH_BUILD_DIR"]; LIB = os.path.join(OBJ, "libmjhip.so")
@@ -51,11 +54,12 @@ def build(force=False, verbose=False):
         if not os.path.exists(sp):
             continue
         op = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
-        dg = _digest([sp] + [os.path.join(CSRC, d) for d in deps], " ".join(FLAGS))
+        sflags = FLAGS + SOURCE_FLAGS.get(src, [])
+        dg = _digest([sp] + [os.path.join(CSRC, d) for d in deps], " ".join(sflags))
         stamp = op + ".sha256"
         have = open(stamp).read().strip() if os.path.exists(stamp) else ""
         if force or not os.path.exists(op) or have != dg:
-            cmd = [hipcc] + FLAGS + ["-c", sp, "-o", op]
+            cmd = [hipcc] + sflags + ["-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)

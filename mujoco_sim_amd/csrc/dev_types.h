@@ -47,7 +47,7 @@ struct DModel {
   int patch, pool, pool_floats, pdesc, pslot;
   // window sweep (window_pgs.h): the fused step of a patch-eligible model in row order as two launches, assemble (PH_PRE) -> mjh_window_kernel
   // (four envs per wavefront, rows in registers); win_nvt: dof slots of a row record (24 or 32)
-  int window, win_nvt, win_maxw;     // win_maxw: windows of 16 rows an env can hand over (min(WN_MAXW, ceil(maxefc / 16)); rows beyond are dropped with the capacity flag)
+  int window, win_nvt, win_maxw, win_jsz;     // win_jsz: floats of the base-row (J) pool, which the assemble-only launch keeps in the env's window slice instead of LDS;     // win_maxw: windows of 16 rows an env can hand over (min(WN_MAXW, ceil(maxefc / 16)); rows beyond are dropped with the capacity flag)
   int pgs_row_order;   // 1: Gauss-Seidel visits the constraint rows in their own order, one block after the other (mj_solPGS's order; mjh_set_pgs_row_order)
   // dense row-space solver of the many-body layout (dense_pgs.h): on / off, row capacity (a multiple of 64, <= 256), nv padded to 16
   int dense, dense_cap, dense_nvs;
@@ -82,9 +82,10 @@ struct DState {
   // Lay offset -1-k addresses float k of the env's slice
   float* gscratch; long long gstride;
   int win32;             // window kernel: envs with more than this many rows (default WN32_MIN_ROWS) are swept in 32-row windows, two per wavefront (0: every env in the 16-row form)
+  int win64;             // ... with more than this many rows (default WN64_MIN_ROWS, at most 64 WN64_NW) in 64-row windows, one env per wavefront (0: off)
   int probe_slices;      // debug (mjh_debug_solve_probe): mjh_solve_kernel reads the block operands of env0 + blockIdx % probe_slices instead of its own (0: off)
   // window sweep (window_pgs.h): per-env hand-over slice (header, scaled dof vectors, state, window rows, tiles of streamed windows)
-  float* wbuf; long long wstride;
+  float* wbuf; long long wstride; long long wj_off;     // wj_off: where the assemble-only launch's base-row pool starts inside the env's slice
 };
 
 // LDS layout (float offsets into the dynamic shared array; negative: offset into the env's global scratch slice)

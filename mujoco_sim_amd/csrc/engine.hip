@@ -18,7 +18,7 @@
 #include "dense_pgs.h"
 
 void mjh_set_error(const std::string& s);  // model_builder.cpp
-hipError_t mjh_launch_window(hipStream_t st, int nvt, int grid, size_t lds, const DConst* dC, const DState& S, int env0, int n, int nl, int wxf, int n32);   // window.hip
+hipError_t mjh_launch_window(hipStream_t st, int nvt, int grid, size_t lds, const DConst* dC, const DState& S, int env0, int n, int nl, int wxf, int n32, int n64);   // window.hip
 
 #define HIPCHK(call)                                                                             \
   do {                                                                                           \
@@ -163,13 +163,16 @@ static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps,
     // (with the 32-row section on, the 16-row form only meets envs of at most WN32_MIN_ROWS rows — or more than 128, the tier's clients)
     const bool sec32 = e->S.win32 > 0 && e->M.win_nvt == 24 && e->S.win32 <= 16 * nwreg;
     const bool tier = sec32 ? seen > 32 * WN32_NW : seen + 16 > 16 * nwreg;
-    const int nl = nl_env >= 0 ? nl_env : (tier ? nl_full : 0);
+    // (models whose rows can exceed 256 — win_maxw > 16 — always get the tier: the 64-row section keeps the tile of its fifth window there,
+    //  and which envs take that section is decided on the device)
+    const int nl = nl_env >= 0 ? nl_env : ((tier || e->M.win_maxw > 16) ? nl_full : 0);
     const size_t lds = (size_t)4 * nl * WN_XREC(e->M.win_nvt) * 16 * sizeof(float);
     // 24-dof models: a first section of wavefronts sweeps the envs with many rows in 32-row windows, two per wavefront (they scan the
     // same launch order and take the envs the assemble launch marked; almost all of them exit at once)
     const int n32 = (e->S.win32 && e->M.win_nvt == 24) ? (n + 1) / 2 : 0;
     const int wxf = (xflags & ~XF_DEFER) | ((ph & PH_STEP1) ? 0 : XF_SPLIT2);
-    HIPCHK(mjh_launch_window(st, e->M.win_nvt, (e->M.win_nvt == 24 ? n32 : 0) + (n + 3) / 4, lds, e->dC, e->S, env0, n, nl, wxf, n32));
+    const int n64 = (e->S.win64 && e->M.win_nvt == 24 && e->M.win_maxw > 16) ? n : 0;      // the 64-row section: one wavefront per env of the launch order, almost all of them exit at once
+    HIPCHK(mjh_launch_window(st, e->M.win_nvt, n64 + (e->M.win_nvt == 24 ? n32 : 0) + (n + 3) / 4, lds, e->dC, e->S, env0, n, nl, wxf, n32, n64));
   }
   return MJH_OK;
 }
@@ -431,9 +434,12 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       // the dual-block sweep (nv <= 32) reads the pair schedule only; `order` is then just scratch of the schedule builder
       L.order = (nv <= 32 && nblkcap <= k1_size && !keep) ? L.bv : put(nblkcap);
       L.ext = (extsz <= k2_size && !keep) ? k1 : put(extsz);
+      // (window models: the base-row pool comes last, an assemble-only launch keeps it in global memory and allocates the LDS in front of it)
+      hp.lds_bytes_pre = off * (int)sizeof(float);
       L.J = put((int)jsz); L.B = diagM ? L.J : put((int)jsz);
     }
-    hp.lds_bytes_pre = off * (int)sizeof(float);    // everything but the patch pool's own tail: what an assemble-only launch (window chain) touches
+    M.win_jsz = (int)jsz;
+    if (!(M.window && !big)) hp.lds_bytes_pre = off * (int)sizeof(float);    // everything but the patch pool's own tail: what an assemble-only launch (window chain) touches
     if (patch) {
       // the pool: per patch of nr4 rows (a multiple of 4, at most 16) a record per row (20 floats between two bodies, 12 on one
       // body) + 16 floats per 4x4 tile of the lower triangle of AR: 16 .. 30 floats per row.  It takes the span of everything that
@@ -602,8 +608,12 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   if (M.big) rc |= dev_alloc(e, &S.gscratch, (size_t)nenv * (size_t)hp.gstride, false);   // many-body models: contact / block / Jacobian pools
   S.wbuf = nullptr; S.wstride = 0;
   S.win32 = getenv("MJH_WINDOW32") ? std::max(0, atoi(getenv("MJH_WINDOW32"))) : WN32_MIN_ROWS;     // (0: off; experiments: another row threshold)
+  S.win64 = getenv("MJH_WINDOW64") ? std::max(0, atoi(getenv("MJH_WINDOW64"))) : WN64_MIN_ROWS;   // (0: off)
+  if (S.win64 > 0 && S.win64 < S.win32) S.win64 = S.win32;
+  if (getenv("MJH_WN_NL") && atoi(getenv("MJH_WN_NL")) < 3) S.win64 = 0;      // (experiments that take the LDS tier away: the 64-row section keeps two 16 KB tiles there)
   if (M.window) {   // window sweep: header + vectors + win_maxw windows of rows + tiles of the streamed windows, per env
-    S.wstride = ((WN_ROWS + M.win_maxw * (M.win_nvt + 2) * 16 + M.win_maxw * WN_XREC(M.win_nvt) * 16 + 63) / 64) * 64;
+    S.wj_off = ((WN_ROWS + M.win_maxw * (M.win_nvt + 2) * 16 + M.win_maxw * WN_XREC(M.win_nvt) * 16 + 63) / 64) * 64;
+    S.wstride = S.wj_off + ((M.win_jsz + 63) / 64) * 64;
     rc |= dev_alloc(e, &S.wbuf, (size_t)nenv * (size_t)S.wstride, true);
   }
   if (M.window && e->lpt && nenv >= 1024) {

@@ -945,6 +945,10 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
   const bool short_rows = level_solves && M.ntree <= 4;
   // M after the factorisation: articulated models in the many-body layout keep only the factor in LDS (it is built in M's place)
   const float* qM_ro = (NROW == 8 && !DIAGM) ? gs + L.g_qM : s_qM;
+  // assemble-only launches of the window chain: the base-row pool (and the raw-contact staging that aliases it) — the largest array by far,
+  // 192 B per contact — lives in the env's slice of the window buffer (global memory, L2-resident) instead of LDS: the launch is bound by
+  // the latency of one wave per env, and its LDS sets how many envs a CU holds (S24D at 96 contacts: 44 KB -> 25 KB, 3 -> 6 per CU)
+  if constexpr (WPRE) { s_J = S.wbuf + (size_t)env * (size_t)S.wstride + S.wj_off; s_B = s_J; }
   float* s_stage = s_J;  // raw-contact staging aliases the (not yet built) base-row storage
   const int rowW = M.rowW;
 
@@ -2429,10 +2433,10 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
                   for (int i = lane; i < nq; i += 64) S.qpos[qrow + i] = s_qpos[i];
                   for (int d = lane; d < nv; d += 64) { S.qvel[vrow + d] = s_qvel[d]; S.qvel_ref[vrow + d] = s_qvref[d]; S.qfrc_applied[vrow + d] = s_applied[d]; }
                 }
-                // [4]: the form the window kernel sweeps this env in — 32-row windows for many rows (window_pgs.h: wn_run32), a function of the env's own row count
+                // [4]: the form the window kernel sweeps this env in — 1: 32-row windows for many rows (window_kernel.h: wn_run32), 2: 64-row windows for the most (wn_run64); a function of the env's own row count
                 // (split API: the counts of THIS step are what mjh_get_stats / mjh_get_field see between the two halves, as after a plain mj_step1)
                 if (lane == 0 && wdefer) { S.stats[4*env] = ncon; S.stats[4*env+1] = nefc; S.stats[4*env+2] = 0; S.stats[4*env+3] |= flags & 0xff; }
-                if (lane == 0) { int* wh = (int*)wb; wh[0] = nrow; wh[1] = ncon; wh[2] = nefc; wh[3] = flags; wh[4] = (S.win32 > 0 && M.win_nvt == 24 && nrow > S.win32 && nrow <= 32 * WN32_NW) ? 1 : 0; wh[5] = (wdefer && nrow == 0) ? 1 : 0; }   // [5]: an env without rows that the window kernel integrates (split API)
+                if (lane == 0) { int* wh = (int*)wb; wh[0] = nrow; wh[1] = ncon; wh[2] = nefc; wh[3] = flags; wh[4] = (S.win64 > 0 && M.win_nvt == 24 && nrow > S.win64 && nrow <= (M.win_maxw > 16 ? 64 * (WN64_NW + WN64_NT) : 0)) ? 2 : ((S.win32 > 0 && M.win_nvt == 24 && nrow > S.win32 && nrow <= 32 * WN32_NW) ? 1 : 0); wh[5] = (wdefer && nrow == 0) ? 1 : 0; }   // [5]: an env without rows that the window kernel integrates (split API)
                 return;
               }
               // (more rows than the window kernel takes: this env finishes the step here, in patch form)

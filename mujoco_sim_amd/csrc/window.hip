@@ -6,8 +6,8 @@
 #include "window_kernel.h"
 
 // nvt: dof slots of the instance (24 / 32); grid: wavefronts (the 32-row section's first); lds: bytes of the LDS tier
-hipError_t mjh_launch_window(hipStream_t st, int nvt, int grid, size_t lds, const DConst* dC, const DState& S, int env0, int n, int nl, int wxf, int n32) {
-  if (nvt == 24) hipLaunchKernelGGL((mjh_window_kernel<24, WN_NW24>), dim3(grid), dim3(64), lds, st, dC, S, env0, n, nl, wxf, n32);
-  else hipLaunchKernelGGL((mjh_window_kernel<32, WN_NW32>), dim3(grid), dim3(64), lds, st, dC, S, env0, n, nl, wxf, 0);
+hipError_t mjh_launch_window(hipStream_t st, int nvt, int grid, size_t lds, const DConst* dC, const DState& S, int env0, int n, int nl, int wxf, int n32, int n64) {
+  if (nvt == 24) hipLaunchKernelGGL((mjh_window_kernel<24, WN_NW24>), dim3(grid), dim3(64), lds, st, dC, S, env0, n, nl, wxf, n32, n64);
+  else hipLaunchKernelGGL((mjh_window_kernel<32, WN_NW32>), dim3(grid), dim3(64), lds, st, dC, S, env0, n, nl, wxf, 0, 0);
   return hipGetLastError();
 }

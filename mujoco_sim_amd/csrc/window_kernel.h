@@ -4,6 +4,16 @@
 #pragma once
 #include "step_kernel.h"
 
+#ifdef WN_PROF_CLK
+#define WN_STAT0(x) cost_hint       // (probe build: the wave's clocks where the contact count goes)
+#else
+#define WN_STAT0(x) (x)
+#endif
+
+#ifdef WN_PROF_CLK
+__shared__ long long wn_t0;      // (probe build: the wavefront's start clock)
+#endif
+
 #define WN_BC8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
 template <int NV> struct WnWin { float J[NV]; float4 A0, A1, A2, A3; float aref, R, nw, half; };   // one window row: J^, tile row (-AR_qr / AR_qq, r < q), constants
 
@@ -149,6 +159,80 @@ DEV void wn_odom(const DModel& M, const DState& S, const int env, const float* q
   for (int k = 0; k < 3; k++) if (odom[3+k] >= 0) qv[odom[3+k]] = v[3+k];
 }
 
+// ---- qacc, mj_checkAcc, semi-implicit Euler, state and statistics of the wide forms (32-row: two envs per wavefront, es = 0 / 1; 64-row: one,
+// es = 0).  dl_lane: the 16 lanes of the env that carry its dofs (lane q: dofs q and 16 + q / 2); envmask: the env's lanes (mj_checkAcc's vote)
+DEV void wn_finish_wide(const DModel& M, const DState& S, float* const wb, const int* const wh, const int env, const int env0, const int xflags,
+                        const bool mine, const bool dl_lane, const int es, const unsigned long long envmask, const int q,
+                        const float a_lo, const float a_hi, const float as_lo, const float as_hi, const int niter, const int nwin16) {
+  const int nv = M.nv;
+  const int dhi = 16 + (q >> 1);
+  const bool lo_on = q < nv, hi_on = dhi < nv;
+  const float sv_lo = (dl_lane && lo_on) ? wb[WN_SINV + q] : 0.0f, sv_hi = (dl_lane && hi_on) ? wb[WN_SINV + dhi] : 0.0f;
+  float qa_lo = a_lo * sv_lo, qa_hi = a_hi * sv_hi;
+  float qv_lo = (dl_lane && lo_on) ? wb[WN_QVEL + q] : 0.0f, qv_hi = (dl_lane && hi_on) ? wb[WN_QVEL + dhi] : 0.0f;
+  int flags = mine ? wh[3] : 0;
+  if (dl_lane && (xflags & XF_FORCE)) {
+    const size_t xe = (size_t)(env - env0) * M.nvp;
+    if (lo_on) { if (S.x_smooth) S.x_smooth[xe + q] = as_lo * sv_lo; if (S.x_constraint) S.x_constraint[xe + q] = (a_lo - as_lo) / sv_lo; }
+    if (hi_on && !(q & 1)) { if (S.x_smooth) S.x_smooth[xe + dhi] = as_hi * sv_hi; if (S.x_constraint) S.x_constraint[xe + dhi] = (a_hi - as_hi) / sv_hi; }
+  }
+  const bool badl = !(qa_lo == qa_lo) || fabsf(qa_lo) > MJ_MAXVAL || !(qa_hi == qa_hi) || fabsf(qa_hi) > MJ_MAXVAL;
+  const bool bad = (__ballot(badl) & envmask) != 0ull;
+  const size_t qrow = (size_t)env * M.nqp, vrow = (size_t)env * M.nvp;
+  if (bad) { qa_lo = qa_hi = 0.0f; qv_lo = qv_hi = 0.0f; flags |= 4; }
+  const float h = M.timestep;
+  const Tab<int> dof_bodyid{M.I, M.o_dof_bodyid}, jnt_qposadr{M.I, M.o_jnt_qposadr}, jnt_dofadr{M.I, M.o_jnt_dofadr};
+  const Tab<float> dof_damping{M.F, M.o_dof_damping};
+  const unsigned slotmask = S.slot_mask ? S.slot_mask[env] : 0u;
+  const int sbase = M.nbody > 32 ? M.nbody - 32 : 0;
+  __shared__ float s_v32[2][32];
+  __shared__ float s_qp32[2][40];
+  const bool has_odom = M.I[M.o_odom + 9] != 0;
+  auto advance = [&](const int d, float& qa, float& qv) __attribute__((always_inline)) {
+    float qint = qa;
+    if (M.has_damping && !(M.disableflags & MJH_DSBL_EULERDAMP)) {
+      const float sv = wb[WN_SINV + d], Mdd = 1.0f / (sv * sv), D = dof_damping[d];
+      qint = qa - h * (D * qa) / (Mdd + h * D);
+    }
+    const unsigned rb = (unsigned)(dof_bodyid[d] - sbase);
+    const bool parked = rb < 32u && ((slotmask >> rb) & 1u);
+    qv = parked ? 0.0f : qv + h * qint;
+    if (parked) qa = 0.0f;
+    S.qvel[vrow + d] = qv; S.qacc_ws[vrow + d] = qa;
+    if (bad && (xflags & XF_SPLIT2)) S.qfrc_applied[vrow + d] = 0.0f;
+    s_v32[es][d] = qv;
+  };
+  if (dl_lane && lo_on) advance(q, qa_lo, qv_lo);
+  if (dl_lane && hi_on && !(q & 1)) advance(dhi, qa_hi, qv_hi);
+  __syncthreads();
+  if (dl_lane && q < M.njnt) {
+    const int qadr = jnt_qposadr[q], da = jnt_dofadr[q];
+    float p[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) p[k] = bad ? S.initial_qpos[qrow + qadr + k] : wb[WN_QPOS + qadr + k];
+    const float* v = s_v32[es] + da;
+    p[0] += h * v[0]; p[1] += h * v[1]; p[2] += h * v[2];
+    float w3[3] = {v[3], v[4], v[5]};
+    quat_integrate(p + 3, w3, h);
+#pragma unroll
+    for (int k = 0; k < 7; k++) { S.qpos[qrow + qadr + k] = p[k]; s_qp32[es][qadr + k] = p[k]; }
+  }
+  if (has_odom) {       // (the qvel rows above are this wave's own stores: the overwrite follows them in program order)
+    __syncthreads();
+    if (dl_lane && q == 0) wn_odom(M, S, env, s_qp32[es], S.qvel + vrow);
+  }
+  if (dl_lane && q == 0) {
+    S.time[env] += M.timestep_d;
+#ifdef WN_PROF_CLK
+    const int cost_hint = min((int)(((long long)__builtin_amdgcn_s_memtime() - wn_t0) >> 5) + 1, (1 << 22) - 1);   // (probe build: the wave's own clocks in the hint field)
+#else
+    const int cost_hint = min(niter * nwin16 * 20 + 1, 1 << 22);
+#endif
+    S.stats[4 * env] = WN_STAT0(wh[1]); S.stats[4 * env + 1] = wh[2]; S.stats[4 * env + 2] = niter;
+    S.stats[4 * env + 3] = ((S.stats[4 * env + 3] | flags) & 0xff) | (cost_hint << 8);
+  }
+}
+
 DEV void wn_run32(const DConst* __restrict__ C, const DState& S, const int env0, const int nenv, const int xflags, const int blk) {
   const DModel& M = C->M;
   constexpr int NV = 24, NK = NV + 2;
@@ -262,69 +346,247 @@ DEV void wn_run32(const DConst* __restrict__ C, const DState& S, const int env0,
       if (rowsum_i32(impl) < iq.thr || niter >= itmax) act = false;
     }
   }
-  // ---- qacc, mj_checkAcc, semi-implicit Euler, state and statistics (the lower half's lanes carry the dofs)
-  const bool dl_lane = mine && hq == 0;
-  const float sv_lo = (dl_lane && lo_on) ? wb[WN_SINV + q] : 0.0f, sv_hi = (dl_lane && hi_on) ? wb[WN_SINV + dhi] : 0.0f;
-  float qa_lo = a_lo * sv_lo, qa_hi = a_hi * sv_hi;
-  float qv_lo = (dl_lane && lo_on) ? wb[WN_QVEL + q] : 0.0f, qv_hi = (dl_lane && hi_on) ? wb[WN_QVEL + dhi] : 0.0f;
-  int flags = mine ? wh[3] : 0;
-  if (dl_lane && (xflags & XF_FORCE)) {
-    const size_t xe = (size_t)(env - env0) * M.nvp;
-    if (lo_on) { if (S.x_smooth) S.x_smooth[xe + q] = as_lo * sv_lo; if (S.x_constraint) S.x_constraint[xe + q] = (a_lo - as_lo) / sv_lo; }
-    if (hi_on && !(q & 1)) { if (S.x_smooth) S.x_smooth[xe + dhi] = as_hi * sv_hi; if (S.x_constraint) S.x_constraint[xe + dhi] = (a_hi - as_hi) / sv_hi; }
-  }
-  const bool badl = !(qa_lo == qa_lo) || fabsf(qa_lo) > MJ_MAXVAL || !(qa_hi == qa_hi) || fabsf(qa_hi) > MJ_MAXVAL;
-  const bool bad = ((__ballot(badl) >> (32 * es)) & 0xffffffffull) != 0ull;
-  const size_t qrow = (size_t)env * M.nqp, vrow = (size_t)env * M.nvp;
-  if (bad) { qa_lo = qa_hi = 0.0f; qv_lo = qv_hi = 0.0f; flags |= 4; }
-  const float h = M.timestep;
-  const Tab<int> dof_bodyid{M.I, M.o_dof_bodyid}, jnt_qposadr{M.I, M.o_jnt_qposadr}, jnt_dofadr{M.I, M.o_jnt_dofadr};
-  const Tab<float> dof_damping{M.F, M.o_dof_damping};
-  const unsigned slotmask = S.slot_mask ? S.slot_mask[env] : 0u;
-  const int sbase = M.nbody > 32 ? M.nbody - 32 : 0;
-  __shared__ float s_v32[2][32];
-  __shared__ float s_qp32[2][40];
-  const bool has_odom = M.I[M.o_odom + 9] != 0;
-  auto advance = [&](const int d, float& qa, float& qv) __attribute__((always_inline)) {
-    float qint = qa;
-    if (M.has_damping && !(M.disableflags & MJH_DSBL_EULERDAMP)) {
-      const float sv = wb[WN_SINV + d], Mdd = 1.0f / (sv * sv), D = dof_damping[d];
-      qint = qa - h * (D * qa) / (Mdd + h * D);
-    }
-    const unsigned rb = (unsigned)(dof_bodyid[d] - sbase);
-    const bool parked = rb < 32u && ((slotmask >> rb) & 1u);
-    qv = parked ? 0.0f : qv + h * qint;
-    if (parked) qa = 0.0f;
-    S.qvel[vrow + d] = qv; S.qacc_ws[vrow + d] = qa;
-    if (bad && (xflags & XF_SPLIT2)) S.qfrc_applied[vrow + d] = 0.0f;
-    s_v32[es][d] = qv;
-  };
-  if (dl_lane && lo_on) advance(q, qa_lo, qv_lo);
-  if (dl_lane && hi_on && !(q & 1)) advance(dhi, qa_hi, qv_hi);
-  __syncthreads();
-  if (dl_lane && q < M.njnt) {
-    const int qadr = jnt_qposadr[q], da = jnt_dofadr[q];
-    float p[7];
-#pragma unroll
-    for (int k = 0; k < 7; k++) p[k] = bad ? S.initial_qpos[qrow + qadr + k] : wb[WN_QPOS + qadr + k];
-    const float* v = s_v32[es] + da;
-    p[0] += h * v[0]; p[1] += h * v[1]; p[2] += h * v[2];
-    float w3[3] = {v[3], v[4], v[5]};
-    quat_integrate(p + 3, w3, h);
-#pragma unroll
-    for (int k = 0; k < 7; k++) { S.qpos[qrow + qadr + k] = p[k]; s_qp32[es][qadr + k] = p[k]; }
-  }
-  if (has_odom) {       // (the qvel rows above are this wave's own stores: the overwrite follows them in program order)
-    __syncthreads();
-    if (dl_lane && q == 0) wn_odom(M, S, env, s_qp32[es], S.qvel + vrow);
-  }
-  if (dl_lane && q == 0) {
-    S.time[env] += M.timestep_d;
-    const int cost_hint = min(niter * nwin16 * 20 + 1, 1 << 22);
-    S.stats[4 * env] = wh[1]; S.stats[4 * env + 1] = wh[2]; S.stats[4 * env + 2] = niter;
-    S.stats[4 * env + 3] = ((S.stats[4 * env + 3] | flags) & 0xff) | (cost_hint << 8);
-  }
+  wn_finish_wide(M, S, wb, wh, env, env0, xflags, mine, mine && hq == 0, es, 0xffffffffull << (32 * es), q, a_lo, a_hi, as_lo, as_hi, niter, nwin16);
 #undef WN32_FOR_WINDOWS
+}
+
+// ---- 64-row windows: ONE environment per wavefront, for the environments a cohort's step waits for (S24D: more than WN64_MIN_ROWS rows —
+// 11 % of the envs, every one of them at the 100-sweep cap; in the 16-row form 13 .. 19 windows a sweep, most of them streamed).  A window
+// = 64 consecutive rows = one row per lane; inside it Gauss-Seidel stays row by row on the strictly lower triangle of the window's AR
+// (64 tile entries per lane; the wavefront's four 16-lane rows one after the other, each by the 16-row form's chain, a finished row's
+// deltas carried to the rows behind it through the cross entries), between windows the acceleration a^ moves
+// through ONE dot and ONE transpose-reduce per 64 rows: ~4.8 issue slots per row against 8 in the 16-row form (which serves four envs
+// with them: the wide form buys the shorter chain of the slowest envs with the SIMDs the window kernel leaves idle).  Every 16-lane row
+// of the wavefront carries the same a^ (lane q: dofs q and 16 + q / 2): the rows' partial J^T sums are exchanged by v_permlane16_swap /
+// v_permlane32_swap, the same sum in the same order in every lane.  WN64_NW windows (192 rows) register-resident, WN64_NT more (320 rows) with their tiles in LDS.  The form is a
+// function of the env's own row count (set by the assemble launch); same rows, same order, same row math and stopping rule as the
+// other forms, another grouping of the arithmetic (fp32 rounding).
+extern __shared__ float wn_lds[];
+DEV float* wn_lds_base() { return wn_lds; }
+struct WnWin64 { float J[24]; float A[64]; float aref, R, nw, half; };
+
+// sum over the four 16-lane rows of a wavefront, the same value (same order of additions) in every lane
+DEV void wn_rows4_sum2(float& x, float& y) {
+  float x2 = x, y2 = y;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1" : "+v"(x), "+v"(y), "+v"(x2), "+v"(y2));
+  x += x2; y += y2;                       // rows 0, 1: r0 + r1; rows 2, 3: r2 + r3
+  x2 = x; y2 = y;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1" : "+v"(x), "+v"(y), "+v"(x2), "+v"(y2));
+  x += x2; y += y2;                       // (r0 + r1) + (r2 + r3) everywhere
+}
+DEV void wn_jt64(const float* J, const float x, float& a_lo, float& a_hi) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f x2 = {x, x};
+  float p[24];
+#pragma unroll
+  for (int k = 0; k < 24; k += 2) { const v2f pr = v2f{J[k], J[k + 1]} * x2; p[k] = pr.x; p[k + 1] = pr.y; }
+  float s_lo = wn_fold16(p), s_hi = wn_fold8(p + 16);
+  wn_rows4_sum2(s_lo, s_hi);
+  a_lo += s_lo; a_hi += s_hi;
+}
+// one 16-lane row's 16 constraint rows (lanes of DPP row mask m): per row  v_max, two wait states, v_fmac ... row_newbcast — the 16-row form's chain
+#define WN64_R4(r0, r1, r2, r3, a0_, a1_, a2_, a3_, m) asm volatile(WN_ROWM(r0, "%[a0]", m) WN_ROWM(r1, "%[a1]", m) WN_ROWM(r2, "%[a2]", m) WN_ROWM(r3, "%[a3]", m) \
+    : [t] "+v"(tt), [d] "=&v"(dl) : [nf] "v"(nf), [a0] "v"(a0_), [a1] "v"(a1_), [a2] "v"(a2_), [a3] "v"(a3_))
+#define WN64_CHAIN16(A, b, m) do { WN64_R4(0, 1, 2, 3, A[b], A[b + 1], A[b + 2], A[b + 3], m); WN64_R4(4, 5, 6, 7, A[b + 4], A[b + 5], A[b + 6], A[b + 7], m); \
+    WN64_R4(8, 9, 10, 11, A[b + 8], A[b + 9], A[b + 10], A[b + 11], m); WN64_R4(12, 13, 14, 15, A[b + 12], A[b + 13], A[b + 14], A[b + 15], m); \
+    asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf)); } while (0)
+// the deltas dx of a finished 16-lane row (replicated into every row) reach the rows behind it (mask m) through their cross entries
+#define WN64_XF(r, ar, m) "v_fmac_f32_dpp %[t], %[x], " ar " row_newbcast:" #r " row_mask:" #m " bank_mask:0xf\n\t"
+#define WN64_X4(r0, r1, r2, r3, a0_, a1_, a2_, a3_, m) asm volatile(WN64_XF(r0, "%[a0]", m) WN64_XF(r1, "%[a1]", m) WN64_XF(r2, "%[a2]", m) WN64_XF(r3, "%[a3]", m) \
+    : [t] "+v"(tt) : [x] "v"(dx), [a0] "v"(a0_), [a1] "v"(a1_), [a2] "v"(a2_), [a3] "v"(a3_))
+#define WN64_CROSS16(A, b, m) do { WN64_X4(0, 1, 2, 3, A[b], A[b + 1], A[b + 2], A[b + 3], m); WN64_X4(4, 5, 6, 7, A[b + 4], A[b + 5], A[b + 6], A[b + 7], m); \
+    WN64_X4(8, 9, 10, 11, A[b + 8], A[b + 9], A[b + 10], A[b + 11], m); WN64_X4(12, 13, 14, 15, A[b + 12], A[b + 13], A[b + 14], A[b + 15], m); } while (0)
+// one sweep over a 64-row window: u = J^ a^, then the four 16-lane rows one after the other (Gauss-Seidel row by row inside each: DPP row
+// masks 0x1 .. 0x8), the deltas of a finished row carried to every later row by two lane swaps and 16 broadcast multiply-adds
+// (A: the tile array, Bg: index of the 16 entries of lane row g in it, Lg: statement in front of row g — the register-resident windows read
+//  W.A[16 g ..], the LDS window loads the 16 entries of row g first)
+#define WN64_SWEEP_X(W, fw, A, B0, B1, B2, B3, L0, L1, L2, L3) do { \
+    const float u = wn_dot<NV>(W.J, a_lo, a_hi); \
+    const float fo = fw; \
+    float tt = ((u - W.aref) + W.R * fo) * W.nw; \
+    const float nf = -fo; \
+    float dl, dx, dy; \
+    L0; \
+    WN64_CHAIN16(A, B0, 0x1); \
+    dx = dl; dy = dl; \
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(dx), "+v"(dy));        /* dx = (d0, d0, ., .) */ \
+    dy = dx; \
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(dx), "+v"(dy));        /* dx = (d0, d0, d0, d0) */ \
+    WN64_CROSS16(A, B0, 0xe); \
+    L1; \
+    WN64_CHAIN16(A, B1, 0x2); \
+    dx = dl; dy = dl; \
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(dx), "+v"(dy));        /* dy = (d1, d1, ., .) */ \
+    dx = dy; \
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(dy), "+v"(dx));        /* dy = (d1, d1, d1, d1) */ \
+    dx = dy; \
+    WN64_CROSS16(A, B1, 0xc); \
+    L2; \
+    WN64_CHAIN16(A, B2, 0x4); \
+    dx = dl; dy = dl; \
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(dx), "+v"(dy));        /* dx = (., ., d2, d2) */ \
+    WN64_CROSS16(A, B2, 0x8); \
+    L3; \
+    WN64_CHAIN16(A, B3, 0x8); \
+    impl += imp_fixed((W.half * dl) * (2.0f * tt - dl), iq.qs); \
+    fw = fo + dl; \
+    wn_jt64(W.J, dl, a_lo, a_hi); } while (0)
+#define WN64_SWEEP(W, fw) WN64_SWEEP_X(W, fw, W.A, 0, 16, 32, 48, (void)0, (void)0, (void)0, (void)0)
+
+DEV void wn_run64(const DConst* __restrict__ C, const DState& S, const int env0, const int nenv, const int xflags, const int blk, float* const lds64) {
+  const DModel& M = C->M;
+  constexpr int NV = 24, NK = NV + 2;
+  const int lane = threadIdx.x, g = lane >> 4, q = lane & 15;
+  const bool have = blk < nenv;
+  const int env = have ? (S.env_order ? S.env_order[env0 + blk] : env0 + blk) : 0;
+  float* const wb = S.wbuf + (size_t)env * (size_t)S.wstride;
+  const int* const wh = (const int*)wb;
+  const int nrow = (have && wh[4] == 2) ? wh[0] : 0;            // (uniform: one env per wavefront)
+  if (nrow <= 0) return;
+  const int nwin16 = (nrow + 15) >> 4, nwin = (nrow + 63) >> 6;
+  const int nv = M.nv;
+  const int dhi = 16 + (q >> 1);
+  const bool lo_on = q < nv, hi_on = dhi < nv;
+  const float as_lo = lo_on ? wb[WN_AS + q] : 0.0f, as_hi = hi_on ? wb[WN_AS + dhi] : 0.0f;
+  const float ws_lo = lo_on ? wb[WN_AWS + q] : 0.0f, ws_hi = hi_on ? wb[WN_AWS + dhi] : 0.0f;
+  WnWin64 win[WN64_NW];
+  float f[WN64_NW];
+  const float* rows = wb + WN_ROWS + q;
+#pragma unroll
+  for (int w = 0; w < WN64_NW; w++) if (w < nwin) {
+    WnWin64& W = win[w];
+    const bool ok = (4 * w + g) < nwin16;                      // (the assemble launch pads the last 16-row block with zero rows; a missing block is all zeros)
+    const float* p = rows + (4 * w + g) * NK * 16;
+#pragma unroll
+    for (int k = 0; k < NV; k++) W.J[k] = ok ? p[16 * k] : 0.0f;
+    W.aref = ok ? p[16 * NV] : 0.0f; W.R = ok ? p[16 * (NV + 1)] : 0.0f;
+    float diag = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) diag += W.J[k] * W.J[k];
+    const float ARqq = diag + W.R;
+    const float inv = ARqq < MJ_MINVAL ? 0.0f : 1.0f / ARqq, ninv = -inv;
+    W.nw = ninv; W.half = 0.5f * ARqq;
+    // tile row: acc_r = J^_lane . J^_r for the 64 rows r of the window.  The rows of 16-lane group G come over through the LDS crossbar
+    // (ds_bpermute: lane (G, q) to every group's lane q), then sixteen broadcast multiply-add chains as in the 16-row form
+#pragma unroll
+    for (int G = 0; G < 4; G++) {
+      float Jg[NV], acc[16];
+#pragma unroll
+      for (int k = 0; k < NV; k++) Jg[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((16 * G + q) << 2, __builtin_bit_cast(int, W.J[k])));
+#pragma unroll
+      for (int sidx = 0; sidx < 16; sidx++) acc[sidx] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < NV; k++) asm volatile("" : "+v"(W.J[k]), "+v"(Jg[k]));
+      asm volatile("s_nop 1");
+#define WN_ACC(sidx) _Pragma("unroll") for (int k = 0; k < NV; k++) PP_FMAC_BC(acc[sidx], Jg[k], W.J[k], sidx);
+      PP_BC16(WN_ACC)
+#undef WN_ACC
+#pragma unroll
+      for (int sidx = 0; sidx < 16; sidx++) W.A[16 * G + sidx] = (16 * G + sidx) < lane ? ninv * acc[sidx] : 0.0f;
+    }
+  }
+  // the WN64_NT windows behind the register-resident ones (rows 193 .. 320): J^ and the constants in registers, their 64 x 64 tiles in LDS
+  // (16 KB each of the launch's LDS tier; [r / 4][lane][4]: the 16 entries of a lane row are four 16-byte reads), read again every sweep.
+  // (All five windows in registers would take 500 of them — and a window kernel beyond 448 registers costs the 16-row form 10 % on S24,
+  // measured: the forms share one kernel.)
+  struct WnTail { float J[NV]; float aref, R, nw, half; };
+  WnTail TLS[WN64_NT];
+  float ftl[WN64_NT];
+  float* const tile = lds64 + lane * 4;
+#pragma unroll
+  for (int t = 0; t < WN64_NT; t++) {
+    ftl[t] = 0.0f;
+    if (WN64_NW + t < nwin) {
+    WnTail& TL = TLS[t];
+    const bool ok = (4 * (WN64_NW + t) + g) < nwin16;
+    const float* p = rows + (4 * (WN64_NW + t) + g) * NK * 16;
+#pragma unroll
+    for (int k = 0; k < NV; k++) TL.J[k] = ok ? p[16 * k] : 0.0f;
+    TL.aref = ok ? p[16 * NV] : 0.0f; TL.R = ok ? p[16 * (NV + 1)] : 0.0f;
+    float diag = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) diag += TL.J[k] * TL.J[k];
+    const float ARqq = diag + TL.R;
+    const float inv = ARqq < MJ_MINVAL ? 0.0f : 1.0f / ARqq, ninv = -inv;
+    TL.nw = ninv; TL.half = 0.5f * ARqq;
+#pragma unroll
+    for (int G = 0; G < 4; G++) {
+      float Jg[NV], acc[16];
+#pragma unroll
+      for (int k = 0; k < NV; k++) Jg[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((16 * G + q) << 2, __builtin_bit_cast(int, TL.J[k])));
+#pragma unroll
+      for (int sidx = 0; sidx < 16; sidx++) acc[sidx] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < NV; k++) asm volatile("" : "+v"(TL.J[k]), "+v"(Jg[k]));
+      asm volatile("s_nop 1");
+#define WN_ACC(sidx) _Pragma("unroll") for (int k = 0; k < NV; k++) PP_FMAC_BC(acc[sidx], Jg[k], TL.J[k], sidx);
+      PP_BC16(WN_ACC)
+#undef WN_ACC
+#pragma unroll
+      for (int c4 = 0; c4 < 4; c4++) {
+        const int r0 = 16 * G + 4 * c4;
+        *(float4*)(tile + t * 4096 + (r0 >> 2) * 256) = make_float4(r0 < lane ? ninv * acc[4 * c4] : 0.0f, r0 + 1 < lane ? ninv * acc[4 * c4 + 1] : 0.0f,
+                                                                    r0 + 2 < lane ? ninv * acc[4 * c4 + 2] : 0.0f, r0 + 3 < lane ? ninv * acc[4 * c4 + 3] : 0.0f);
+      }
+    }
+    }
+  }
+  float T[16];
+#define WN64_TLOAD(t, gb) do { const float* tp_ = tile + (t) * 4096 + (4 * (gb)) * 256; \
+    const float4 t0_ = *(const float4*)(tp_), t1_ = *(const float4*)(tp_ + 256), t2_ = *(const float4*)(tp_ + 512), t3_ = *(const float4*)(tp_ + 768); \
+    T[0] = t0_.x; T[1] = t0_.y; T[2] = t0_.z; T[3] = t0_.w; T[4] = t1_.x; T[5] = t1_.y; T[6] = t1_.z; T[7] = t1_.w; \
+    T[8] = t2_.x; T[9] = t2_.y; T[10] = t2_.z; T[11] = t2_.w; T[12] = t3_.x; T[13] = t3_.y; T[14] = t3_.z; T[15] = t3_.w; } while (0)
+#define WN64_FOR_TAILS(...) do { _Pragma("unroll") for (int t = 0; t < WN64_NT; t++) if (WN64_NW + t < nwin) { WnTail& TL = TLS[t]; float& ft = ftl[t]; __VA_ARGS__ } } while (0)
+  // ---- warm start
+  float a_lo = as_lo, a_hi = as_hi;
+#pragma unroll
+  for (int w = 0; w < WN64_NW; w++) f[w] = 0.0f;
+#define WN64_FOR_WINDOWS(...) do { _Pragma("unroll") for (int w = 0; w < WN64_NW; w++) if (w < nwin) { WnWin64& W = win[w]; float& fw = f[w]; __VA_ARGS__ } } while (0)
+  if (!(M.disableflags & MJH_DSBL_WARMSTART)) {
+    float da_lo = 0.0f, da_hi = 0.0f;
+    WN64_FOR_WINDOWS({
+      const float jar = wn_dot<NV>(W.J, ws_lo, ws_hi) - W.aref;
+      fw = (jar < 0.0f && W.R > 0.0f) ? -jar / W.R : 0.0f;
+      wn_jt64(W.J, fw, da_lo, da_hi);
+    });
+    WN64_FOR_TAILS({
+      const float jar = wn_dot<NV>(TL.J, ws_lo, ws_hi) - TL.aref;
+      ft = (jar < 0.0f && TL.R > 0.0f) ? -jar / TL.R : 0.0f;
+      wn_jt64(TL.J, ft, da_lo, da_hi);
+    });
+    float cost = 0.0f;
+    WN64_FOR_WINDOWS({
+      const float jda = wn_dot<NV>(W.J, da_lo, da_hi), bb = wn_dot<NV>(W.J, as_lo, as_hi) - W.aref;
+      cost += fw * (0.5f * (jda + W.R * fw) + bb);
+    });
+    WN64_FOR_TAILS({
+      const float jda = wn_dot<NV>(TL.J, da_lo, da_hi), bb = wn_dot<NV>(TL.J, as_lo, as_hi) - TL.aref;
+      cost += ft * (0.5f * (jda + TL.R * ft) + bb);
+    });
+    float dummy = 0.0f;
+    cost = wn_rowsum_f(cost); wn_rows4_sum2(cost, dummy);
+    if (cost > 0.0f) {
+#pragma unroll
+      for (int w = 0; w < WN64_NW; w++) f[w] = 0.0f;
+#pragma unroll
+      for (int t = 0; t < WN64_NT; t++) ftl[t] = 0.0f;
+    } else { a_lo += da_lo; a_hi += da_hi; }
+  }
+  // ---- sweeps
+  const ImpQ iq = imp_quantum(1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1)), M.tolerance);
+  const int itmax = M.iterations;
+  int niter = 0;
+  while (true) {
+    int impl = 0;
+    WN64_FOR_WINDOWS({ WN64_SWEEP(W, fw); });
+    WN64_FOR_TAILS({ WN64_SWEEP_X(TL, ft, T, 0, 0, 0, 0, WN64_TLOAD(t, 0), WN64_TLOAD(t, 1), WN64_TLOAD(t, 2), WN64_TLOAD(t, 3)); });
+    niter++;
+    if (wave_sum_dpp_i(impl) < iq.thr || niter >= itmax) break;
+  }
+#undef WN64_FOR_WINDOWS
+#undef WN64_TLOAD
+#undef WN64_FOR_TAILS
+  wn_finish_wide(M, S, wb, wh, env, env0, xflags, true, g == 0, 0, ~0ull, q, a_lo, a_hi, as_lo, as_hi, niter, nwin16);
 }
 
 // a^ += J_a^T x_a + J_b^T x_b : two windows of the same 16 lanes, one transpose-reduce
@@ -345,17 +607,27 @@ template <int NV> DEV void wn_jt2(const float* JA, const float xa, const float* 
     : [t] "+v"(tt) : [x] "v"(dx), [a0] "v"(T.x), [a1] "v"(T.y), [a2] "v"(T.z), [a3] "v"(T.w))
 
 template <int NV, int NW>
-__global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restrict__ C, const DState S, const int env0, const int nenv, const int nl, const int xflags, const int n32waves) {
-  // the first n32waves wavefronts: the section of the envs with many rows (two per wavefront, 32-row windows); dispatched first
-  if constexpr (NV == 24) { if ((int)blockIdx.x < n32waves) { wn_run32(C, S, env0, nenv, xflags, (int)blockIdx.x); return; } }
+__global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restrict__ C, const DState S, const int env0, const int nenv, const int nl, const int xflags, const int n32waves, const int n64waves) {
+  // the first n64waves wavefronts: the section of the envs with the most rows (one per wavefront, 64-row windows); the next n32waves: the
+  // section of the envs with many rows (two per wavefront, 32-row windows); dispatched first — they are the launch's longest jobs
+#ifdef WN_PROF_CLK
+  if (threadIdx.x == 0) wn_t0 = (long long)__builtin_amdgcn_s_memtime();
+  __syncthreads();
+#endif
+  if constexpr (NV == 24) {
+#ifndef WN_NO_F64
+    if ((int)blockIdx.x < n64waves) { wn_run64(C, S, env0, nenv, xflags, (int)blockIdx.x, wn_lds_base()); return; }
+#endif
+    if ((int)blockIdx.x < n64waves + n32waves) { wn_run32(C, S, env0, nenv, xflags, (int)blockIdx.x - n64waves); return; }
+  }
   const DModel& M = C->M;
   const int lane = threadIdx.x, rho = lane >> 4, q = lane & 15;
-  const int slot = ((int)blockIdx.x - n32waves) * 4 + rho;
+  const int slot = ((int)blockIdx.x - n32waves - n64waves) * 4 + rho;
   const bool have = slot < nenv;
   const int env = have ? (S.env_order ? S.env_order[env0 + slot] : env0 + slot) : 0;
   float* const wb = S.wbuf + (size_t)env * (size_t)S.wstride;
   const int* const wh = (const int*)wb;
-  const int nrow = (have && !(n32waves > 0 && wh[4] == 1)) ? wh[0] : 0;
+  const int nrow = (have && !(n32waves > 0 && wh[4] == 1) && !(n64waves > 0 && wh[4] == 2)) ? wh[0] : 0;
   const bool mine = nrow > 0 || (have && wh[5] == 1);      // (else: a row without an environment, or one that finished in the assemble launch — it must not write anything; [5]: an env without rows handed over by the split API: integrated here)
   if (__ballot(mine) == 0ull) return;
   const int nwin = (nrow + 15) >> 4;
@@ -404,7 +676,6 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
   // next NL windows of every env in LDS (the kernel has no other use for it: 40 KB per wave at four waves per CU), the rest in the env's
   // slice of global memory (read every sweep: slow, and rare — S24D's 140-row piles reach the LDS tier only)
   constexpr int NX = NV + 21;
-  extern __shared__ float wn_lds[];
   auto store_ext = [&](float* t, const WnWin<NV>& W, const float fw) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < NV; k++) t[16 * k] = W.J[k];
@@ -609,8 +880,12 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
   if (mine && q == 0) {
     S.time[env] += M.timestep_d;
     // launch-order hint: sweeps x windows in units of the fused kernel's hint (patch_pgs.h: about four instructions)
+#ifdef WN_PROF_CLK
+    const int cost_hint = min((int)(((long long)__builtin_amdgcn_s_memtime() - wn_t0) >> 5) + 1, (1 << 22) - 1);
+#else
     const int cost_hint = min(niter * nwin * 20 + 1, 1 << 22);
-    S.stats[4 * env] = wh[1]; S.stats[4 * env + 1] = wh[2]; S.stats[4 * env + 2] = niter;
+#endif
+    S.stats[4 * env] = WN_STAT0(wh[1]); S.stats[4 * env + 1] = wh[2]; S.stats[4 * env + 2] = niter;
     S.stats[4 * env + 3] = ((S.stats[4 * env + 3] | flags) & 0xff) | (cost_hint << 8);
   }
 #undef WN_FOR_WINDOWS

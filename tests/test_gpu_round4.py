@@ -458,6 +458,7 @@ def test_window_tiers_hold_the_same_values_wherever_a_window_waits():
     for nl in ("default", "0", "3", "10"):
         env = dict(os.environ)
         env.pop("MJH_WN_NL", None)
+        env["MJH_WINDOW64"] = "0"          # (the 64-row section keeps tiles in the LDS tier and is switched off with it: this test is about the 16-row form's tiers)
         if nl != "default":
             env["MJH_WN_NL"] = nl
         r = subprocess.run([sys.executable, "-c", _TIER_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)

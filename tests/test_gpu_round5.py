@@ -167,3 +167,54 @@ def test_s24d_teacher_forced_including_the_envs_above_64_contacts():
     st = e.get_stats()
     assert (st[:, 3] & 3 == 0).all(), "no capacity flag"
     e.close()
+
+
+def test_64_row_windows_for_the_envs_with_the_most_rows_equal_the_16_row_form_up_to_rounding(monkeypatch):
+    """window_kernel.h wn_run64: S24D envs with more than 192 constraint rows (the ones a cohort's step waits for: 13 .. 19 windows of 16,
+    every one at the 100-sweep cap) are swept in 64-row windows, one env per wavefront — same rows, same order, same stopping rule.
+    Against the same engine with the section switched off (MJH_WINDOW64=0): the other envs are bitwise equal (their form did not
+    change), the 64-row ones agree to fp32 rounding; and against the oracle one step from the device's state."""
+    from test_gpu_teacher_forced import S24_TOL_Q
+    nenv = 1024
+    seeds = list(range(nenv))
+    m, a, tab = _s24d_seeds(seeds)
+    monkeypatch.setenv("MJH_WINDOW64", "0")
+    _, b, _ = _s24d_seeds(seeds)
+    monkeypatch.delenv("MJH_WINDOW64")
+    a.step(420); a.synchronize()
+    heavy_seen = 0; worst_q = worst_v = 0.0; same_it = []
+    for k in range(30):
+        t, q, v, w = a.get_state()
+        b.set_state(qpos=q, qvel=v, time=t, warmstart=w)
+        a.step(1); b.step(1)
+        _, qa, va, _ = a.get_state(); _, qb, vb, _ = b.get_state()
+        sa, sb = a.get_stats(), b.get_stats()
+        assert np.array_equal(sa[:, :2], sb[:, :2]) and (sa[:, 3] & 3 == 0).all()
+        heavy = (sa[:, 1] > 192) & (sa[:, 1] <= 320)
+        assert np.array_equal(qa[~heavy], qb[~heavy]) and np.array_equal(va[~heavy], vb[~heavy]) and np.array_equal(sa[~heavy, 2], sb[~heavy, 2])
+        if heavy.any():
+            heavy_seen += int(heavy.sum())
+            worst_q = max(worst_q, float((np.abs(qa[heavy] - qb[heavy]).max(1) / np.maximum(1, np.abs(qb[heavy]).max(1))).max()))
+            worst_v = max(worst_v, float((np.abs(va[heavy] - vb[heavy]).max(1) / np.maximum(1, np.abs(vb[heavy]).max(1))).max()))
+            same_it.append(float((sa[heavy, 2] == sb[heavy, 2]).mean()))
+    tail_seen = int(((sa[:, 1] > 256) & (sa[:, 1] <= 320)).sum())
+    print(f"WINDOW64: {heavy_seen} env-steps in 64-row windows of {30 * nenv}: qpos {worst_q:.2e} qvel {worst_v:.2e} against the 16-row form, same sweep count {np.mean(same_it):.3f}; envs beyond 256 rows (fifth window: tile in LDS) in the last step: {tail_seen}")
+    assert heavy_seen >= 500 and worst_q <= S24_TOL_Q and worst_v <= 2e-4 and np.mean(same_it) >= 0.9
+    # against the oracle: one step from the device's state, the envs in 64-row windows
+    t, q, v, w = a.get_state()
+    a.step(1); _, q1, v1, _ = a.get_state(); st = a.get_stats()
+    tailed = np.nonzero((st[:, 1] > 256) & (st[:, 1] <= 320))[0][:8]
+    heavy = np.concatenate([tailed, np.nonzero((st[:, 1] > 192) & (st[:, 1] <= 256))[0][:16 - len(tailed)]])
+    assert len(heavy) >= 8
+    eq = ev = 0.0
+    for i in heavy:
+        d = oracle_s24(m, tab, int(i))
+        d.f("qpos")[:] = q[i]; d.f("qvel")[:] = v[i]; d.f("qacc_warmstart")[:] = w[i]; d.f("qacc")[:] = w[i]; d.f("time")[0] = t[i]
+        d.step(1)
+        if d.i("ncon") != st[i, 0] or d.i("nefc") != st[i, 1]:
+            continue
+        eq = max(eq, float(np.abs(q1[i] - d.f("qpos")).max() / max(1, np.abs(d.f("qpos")).max())))
+        ev = max(ev, float(np.abs(v1[i] - d.f("qvel")).max() / max(1, np.abs(d.f("qvel")).max())))
+    print(f"WINDOW64 vs oracle, {len(heavy)} envs one step: qpos {eq:.2e} qvel {ev:.2e}")
+    assert eq <= S24_TOL_Q and ev <= 2e-4
+    a.close(); b.close()
