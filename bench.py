@@ -744,7 +744,7 @@ def main():
         other = {"value": total_envs * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3, "kernel_ms": k2}
 
     # committed rocprofv3 PMC measurement of this config (profiles/), per launch: provenance stated, never re-measured here
-    traffic = traffic_src = valu_busy = valu_frac = valu_lanes = valu_instr = None
+    traffic = traffic_src = valu_busy = valu_frac = valu_lanes = valu_instr = valu_fracs = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
@@ -754,8 +754,15 @@ def main():
                 traffic = tj["bytes_per_launch"] * envs_per_launch / tj["envs_per_launch"]
                 valu_busy = tj.get("valu_issue_busy")
                 valu_instr = tj.get("valu_instr_per_env_step"); valu_lanes = tj.get("valu_lane_util")
-                if valu_instr:      # wave-instructions per second at THIS run's rate, of the chip's 1024 SIMDs x one VALU instruction per 4 clocks at 2.4 GHz
-                    valu_frac = valu_instr * (value / world) / (1024 * 2.4e9 / 4)
+                if valu_instr:
+                    # wave-instructions per second at THIS run's rate over the chip's 1024 SIMDs, against (i) the guide's issue peak — a
+                    # wave64 fp32 VALU instruction every 2 clocks per SIMD (MI355X_MICROARCH.md) — which is `valu_issue_frac`, (ii) what this
+                    # repo's micro-benchmark reaches with four resident waves per SIMD (one per 2.5 clocks: profiles/r02m_valu_issue_bench.txt)
+                    # and (iii) the rate of a LONE wave (one per 8 clocks) — the window kernel's 446 registers leave one wave per SIMD, so (iii)
+                    # is the ceiling of the structure and the number that says how full the SIMDs' only wave keeps its own issue slots
+                    vrate = valu_instr * (value / world) / 1024 / 2.4e9          # VALU instructions per SIMD and clock
+                    valu_frac = vrate * 2.0
+                    valu_fracs = {"per_2_clocks_guide_peak": vrate * 2.0, "per_2.5_clocks_measured_4_waves": vrate * 2.5, "per_8_clocks_lone_wave": vrate * 8.0}
                 traffic_src = f"profiles/{tj.get('tag', '?')} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this config, scaled to this run's envs per launch; not measured in this run)"
         except Exception:
             traffic = None
@@ -781,7 +788,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": ("mjh_step_kernel (assemble: position / velocity stages, collision, constraint rows) + mjh_window_kernel (PGS sweeps in mj_solPGS row order, four "
-                                "envs per wavefront in 16-row windows — two in 32-row windows above 96 rows —, rows in registers; mj_Euler): the two-launch chain of one cohort's step, timed as one" if eng.window_solver() else "mjh_step_kernel") + ((" (+ mjh_dense_build_kernel [MFMA] + mjh_dense_solve_kernel: assemble -> build -> solve -> integrate chain of the many-body layout)" if eng.dense_solver() else
+                                "envs per wavefront in 16-row windows — two in 32-row windows above 96 rows, one in 64-row windows above 208 (models with more than 256 rows) —, rows in registers; mj_Euler): the two-launch chain of one cohort's step, timed as one" if eng.window_solver() else "mjh_step_kernel") + ((" (+ mjh_dense_build_kernel [MFMA] + mjh_dense_solve_kernel: assemble -> build -> solve -> integrate chain of the many-body layout)" if eng.dense_solver() else
                                                      " (+ mjh_solve_kernel: three-launch step of the many-body layout)") if eng.lds_bytes > 24 * 1024 or model.nv > 64 else ""),
                      "kernel_ms": kernel_ms, "launches": n_launches, "launches_timed": n_timed, "envs_per_launch": envs_per_launch, "concurrent_launches": cohorts,
                      # `achieved` / `frac` are per launch (one cohort's step), as the contract defines them; the cohorts' launches overlap, so the
@@ -789,9 +796,10 @@ def main():
                      "achieved_whole_chip": bytes_step * nenv / (elapsed / args.steps) / 1e9, "frac_whole_chip": bytes_step * nenv / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_env_step": bytes_step,
                      # the second fraction (say which binds): VALU issue — committed SQ-counter passes of this config x this run's rate
-                     "valu_issue_frac": valu_frac, "valu_lane_util": valu_lanes, "valu_instr_per_env_step": valu_instr,
+                     "valu_issue_frac": valu_frac, "valu_issue_frac_by_denominator": valu_fracs, "valu_lane_util": valu_lanes, "valu_instr_per_env_step": valu_instr,
                      "valu_source": traffic_src.replace("FETCH_SIZE / WRITE_SIZE", "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_THREAD_CYCLES_VALU") if (traffic_src and valu_instr) else None,
-                     "binds": "VALU issue of the resident waves (valu_issue_frac), not HBM (frac)" if valu_frac else None,
+                     "binds": ("the dependent instruction chain of ONE resident wave per SIMD (window kernel: 446 registers): a lone wave issues at most one VALU instruction per 8 clocks — "
+                               "valu_issue_frac_by_denominator.per_8_clocks_lone_wave says how much of THAT the chip uses; against the SIMD's issue peak it is valu_issue_frac; HBM (frac) does not bind") if valu_frac else None,
                      "timed_window_note": f"{args.steps} steps = {elapsed * 1e3:.1f} ms; kernel_ms is the mean of {n_timed} event-timed launches in it",
                      "note": "fused per-env pipeline keeps intermediates in LDS / registers: the path is issue/latency bound, far below the HBM roofline by design (DESIGN.md §4, §5)"},
     }

@@ -48,6 +48,7 @@ def test_driver_line_has_everything_the_contract_names():
     for name, line in r["configs"].items():
         assert "error" not in line, (name, line)
         assert line["value"] > 0 and line["steps"] >= 6 and line["roofline_frac"] > 0 and line["overflow_envs"] <= 0.02 * line["envs"], (name, line)
+    assert r["configs"]["s24d"]["overflow_envs"] == 0, "S24D: no env over the contact / row capacity (VERDICT r04 next #1)"
     assert r["configs"]["s24d"]["mean_ncon"] >= 20 and r["configs"]["c2"]["mean_ncon"] >= 100 and r["configs"]["c4"]["mean_nefc"] >= 50
 
 
