@@ -247,6 +247,11 @@ void mjh_load_set_robot_gravcomp(int mode);
  * (lin x y z, ang x y z), with the reference's rule that a planar linear axis comes along when the other one and the yaw
  * (or, for z, the pitch) are selected.  Resolve their dofs with mjh_name2id and pass them to mjh_set_odom_dofs. */
 void mjh_load_set_odom_joints(unsigned mask);
+/* launch argument disable_parent_child_collision_level of the reference (mujoco_sim.launch:7, default 1): its mujoco_compile writes
+ * <exclude> pairs between every body and its first `level` ancestors into the compiled robot file (mujoco_compile.cpp:250-290).
+ * Per-thread setting for all later loads; 0 (default) adds nothing (adjacent bodies are filtered by the model compiler anyway,
+ * as MuJoCo's filterparent does). */
+void mjh_load_set_parent_child_exclude(int level);
 /* rosparam ~pose_init (mj_sim.cpp:312-335): position and roll / pitch / yaw (radians, tf2 setRPY) written onto the root body
  * of a robot file, by body name; pose NULL removes the entry, root_body NULL removes all */
 void mjh_load_set_robot_pose(const char* root_body, const double pose[6]);

@@ -148,6 +148,7 @@ SYMBOLS = [
     ("mjh_load_set_mesh_mode", None, [C.c_int]),
     ("mjh_load_set_robot_gravcomp", None, [C.c_int]),
     ("mjh_load_set_odom_joints", None, [C.c_uint]),
+    ("mjh_load_set_parent_child_exclude", None, [C.c_int]),
     ("mjh_load_set_robot_pose", None, [C.c_char_p, c_double_p]),
     ("mjh_scene_s24", Model_p, []),
     ("mjh_scene_s24_pen", Model_p, [C.c_double, C.c_int]),

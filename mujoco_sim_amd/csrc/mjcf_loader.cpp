@@ -106,6 +106,7 @@ static thread_local double g_boundmass = 0, g_boundinertia = 0;
 static thread_local int g_robot_gravcomp = -1;   // mjh_load_set_robot_gravcomp: -1 keep the files' values, 0 / 1 force it on every robot body
 static thread_local std::map<std::string, std::array<double, 6>> g_robot_pose;   // mjh_load_set_robot_pose: root body name -> x y z roll pitch yaw
 static thread_local unsigned g_odom_mask = 0;      // mjh_load_set_odom_joints: bits 0..5 = lin x y z, ang x y z
+static thread_local int g_pc_exclude_level = 0;   // mjh_load_set_parent_child_exclude: a body does not collide with its first k ancestors (mujoco_compile.cpp:250-290)
 static thread_local int g_load_meshes = 1;   // mjh_load_set_mesh_mode: 0 = skip mesh assets (their geoms are reported and dropped)
 
 struct Loader {
@@ -114,6 +115,7 @@ struct Loader {
   double bmass = 0, binertia = 0;   // <compiler boundmass boundinertia>, raised to the process-wide floor of mjh_load_set_bounds
   Defaults def;
   std::map<std::string, int> body_id, joint_id, mesh_id, site_id;
+  std::vector<int> body_parent;      // parent body of every body added so far
   // <default class="..."> tables: class -> element tag -> attributes (a nested class starts from its parent's); the
   // unnamed top-level <default> is class "main".  An element takes the attributes it does not set itself from its class
   // (its own class="" attribute, else the nearest enclosing body's childclass, else "main").
@@ -252,6 +254,8 @@ struct Loader {
     int id = mjh_builder_add_body(b, name.c_str(), parent, pos, quat, gc);
     if (id < 0) return false;
     body_id[name] = id;
+    if ((int)body_parent.size() <= id) body_parent.resize(id + 1, 0);
+    body_parent[id] = parent;
     const bool is_mocap = n.get("mocap") && std::string(n.get("mocap")) == "true";   // MjSim::init_references: the *_ref clones (mj_sim.cpp:903)
     const std::string saved = childclass;
     if (n.get("childclass")) childclass = n.get("childclass");
@@ -377,6 +381,14 @@ struct Loader {
       mesh_id[name] = id;
     }
     for (auto& c : root.kids) if (c->tag == "worldbody") if (!children(*c, 0)) return false;
+    // the wrapper's mujoco_compile writes <exclude> pairs between every body and its first `level` ancestors into the compiled robot file
+    // (disable_parent_child_collision, /root/reference/src/mujoco_compile.cpp:250-290; launch argument disable_parent_child_collision_level,
+    // default 1): the same rule as a load option, for robot files that come without their own exclude list
+    if (g_pc_exclude_level > 0)
+      for (int id = 1; id < (int)body_parent.size(); id++) {
+        int p = id;
+        for (int k = 0; k < g_pc_exclude_level; k++) { p = body_parent[p]; if (p <= 0) break; mjh_builder_add_exclude(b, p, id); }
+      }
     for (auto& c : root.kids) {
       if (c->tag == "contact") {
         for (auto& e : c->kids) if (e->tag == "exclude") {
@@ -532,4 +544,5 @@ extern "C" void mjh_load_set_robot_pose(const char* root_body, const double pose
   g_robot_pose[root_body] = a;
 }
 extern "C" void mjh_load_set_odom_joints(unsigned mask) { g_odom_mask = mask & 63u; }
+extern "C" void mjh_load_set_parent_child_exclude(int level) { g_pc_exclude_level = level < 0 ? 0 : level; }
 extern "C" void mjh_load_set_robot_gravcomp(int mode) { g_robot_gravcomp = mode < 0 ? -1 : (mode ? 1 : 0); }

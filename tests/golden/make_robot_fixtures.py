@@ -35,6 +35,16 @@ ROBOTS = {"pr2": ("pr2/pr2.xml", 16), "tiago": ("tiago/tiago.xml", 40), "hsrb4s"
           # ill-conditioned portal-refinement contacts): a short horizon, compared segment by segment with a loose tolerance.
           # (ridgeback_panda's worst pair overlaps by 18 cm: fp32 and fp64 portal refinement leave through different faces)
           "tiago_mesh": ("tiago/tiago.xml", 40), "hsrb4s_mesh": ("hsrb4s/hsrb4s.xml", 32),
+          # armar6 (model/test/armar/armar6.xml: a free-floating torso with 19 joints, every geom a mesh, no <exclude> list either: short
+          # horizon, loose tolerance, like tiago_mesh / hsrb4s_mesh).  Only WITH its meshes: two of its bodies carry neither an <inertial>
+          # nor a primitive geom, so with the mesh assets switched off they are left at boundmass = 1e-6 and the commanded accelerations
+          # blow the mass matrix's conditioning (the oracle resets at step 3)
+          "armar6_mesh": ("armar/armar6.xml", 48),
+          # ridgeback_panda with its meshes: at the wrapper's default the arm's links overlap their grandparents by up to 18 cm for good
+          # (fp32 and fp64 portal refinement leave such an overlap through different faces); with the launch argument
+          # disable_parent_child_collision_level = 2 (mujoco_sim.launch:7, mujoco_compile.cpp:250-290: a body does not collide with its
+          # first two ancestors) the deepest contact at rest is 0.15 mm and the model is well-posed
+          "ridgeback_panda_mesh": ("ridgeback_panda/ridgeback_panda.xml", 32),
           # C5, literally: launch/multi_mujoco_sim.launch:3-4 = world pendulum.xml (three bodies on ball joints, damping 0.5,
           # gravity -0.1) + "robot" bowl.xml (37 static mesh geoms); started with a spin so that the bodies meet
           "c5_pendulum_bowl_mesh": ("pendulum.xml+bowl.xml", 16),
@@ -47,6 +57,7 @@ OBJECT_POOL = """<mujoco><worldbody>
     f'<body name="object_{k}" pos="{4 + 0.6 * k} 4 0.3"><freejoint/><geom type="{t}" size="{sz}"/></body>\n'
     for k, (t, sz) in enumerate([("box", "0.10 0.10 0.10"), ("sphere", "0.15"), ("cylinder", "0.12 0.12"), ("box", "0.20 0.20 0.20"),
                                  ("sphere", "0.25"), ("cylinder", "0.20 0.20"), ("box", "0.15 0.15 0.15"), ("sphere", "0.10")])) + """</worldbody></mujoco>"""
+PC_EXCLUDE = {"ridgeback_panda_mesh": 2}     # mjh_load_set_parent_child_exclude level per fixture (default 0)
 QVEL0 = {"c5_pendulum_bowl_mesh": [0.0, 0.1, 2.0, 0.1, 0.0, -2.0, 0.2, -0.1, 0.3]}   # sphere and cube circle towards each other
 STEPS = 300
 KEEP = (1, 10, 50, 100, 200, 300)
@@ -68,7 +79,10 @@ def command(m, k):
 def main():
     # the reference writes boundmass = boundinertia = 1e-6 into every file before mj_loadXML (mj_sim.cpp:584-590)
     ms.capi.load().mjh_load_set_bounds(1e-6, 1e-6)
+    only = set(sys.argv[1:])          # python make_robot_fixtures.py [name ...]: only these fixtures
     for name, (rel, cap) in ROBOTS.items():
+        if only and name not in only:
+            continue
         mesh = name.endswith("_mesh")
         ms.capi.load().mjh_load_set_mesh_mode(1 if mesh else 0)
         paths = []
@@ -79,11 +93,12 @@ def main():
                 paths.append(tf.name)
             else:
                 paths.append(os.path.join(REF, r))
+        ms.capi.load().mjh_load_set_parent_child_exclude(PC_EXCLUDE.get(name, 0))
         m = ms.load_mjcf(paths=paths)
-        ms.capi.load().mjh_load_set_mesh_mode(1)
+        ms.capi.load().mjh_load_set_mesh_mode(1); ms.capi.load().mjh_load_set_parent_child_exclude(0)
         assert (m.c.nmesh > 0) == mesh
         steps, keep = (MESH_STEPS, MESH_KEEP) if mesh else (STEPS, KEEP)
-        if name in ("tiago_mesh", "hsrb4s_mesh"):
+        if name in ("tiago_mesh", "hsrb4s_mesh", "armar6_mesh"):
             steps, keep = 20, (1, 5, 10, 20)
         m.c.maxcon = cap; m.c.maxefc = 6 * cap + m.neq + 2 * m.njnt + m.nv
         d = orc.OrcData(m.ptr)

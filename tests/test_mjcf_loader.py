@@ -298,3 +298,24 @@ def test_per_call_load_options_do_not_leak_into_later_loads(tmp_path):
     assert m.name2id(1, "base_ang_odom_z_joint") >= 0
     m2 = ms.load_mjcf(paths=[str(world), str(robot)])                         # the thread's settings were left alone
     assert m2.array("body_mass")[1] == 1e-3 and m2.array("body_gravcomp")[1] == 0 and m2.njnt == 1
+
+
+def test_parent_child_exclude_level(lib):
+    """launch argument disable_parent_child_collision_level (mujoco_sim.launch:7; mujoco_compile.cpp:250-290): every body is excluded from
+    colliding with its first `level` ancestors.  A chain of four overlapping spheres: level 0 keeps MuJoCo's own parent filter only
+    (grandparent and great-grandparent pairs collide), level 2 leaves the pair three links apart, level 3 none."""
+    import mujoco_sim_amd as ms
+    xml = ('<mujoco><worldbody><body name="a" pos="0 0 1"><joint type="hinge" axis="0 1 0"/><geom type="sphere" size="0.2"/>'
+           '<body name="b" pos="0.1 0 0"><joint type="hinge" axis="0 1 0"/><geom type="sphere" size="0.2"/>'
+           '<body name="c" pos="0.1 0 0"><joint type="hinge" axis="0 1 0"/><geom type="sphere" size="0.2"/>'
+           '<body name="d" pos="0.1 0 0"><joint type="hinge" axis="0 1 0"/><geom type="sphere" size="0.2"/>'
+           '</body></body></body></body></worldbody></mujoco>')
+    npair = {}
+    try:
+        for level in (0, 1, 2, 3):
+            lib.mjh_load_set_parent_child_exclude(level)
+            npair[level] = ms.load_mjcf(xml=xml).c.npair
+    finally:
+        lib.mjh_load_set_parent_child_exclude(0)
+    assert npair == {0: 3, 1: 3, 2: 1, 3: 0}, npair           # 6 pairs, 3 adjacent ones always filtered; level 2 also a-c, b-d; level 3 also a-d
+    assert ms.load_mjcf(xml=xml).c.npair == 3                   # (the setting was put back)

@@ -12,7 +12,7 @@ from conftest import ROOT
 from helpers import load_model_tables
 
 ROBOTS = ["pr2", "tiago", "hsrb4s", "ridgeback_panda", "pr2_world", "hsrb4s_world", "pr2_mesh", "pr2_world_mesh", "c5_pendulum_bowl_mesh",
-          "c4_pr2_world_objects_mesh", "tiago_mesh", "hsrb4s_mesh"]
+          "c4_pr2_world_objects_mesh", "tiago_mesh", "hsrb4s_mesh", "armar6_mesh", "ridgeback_panda_mesh"]
 FILES = {"pr2": "pr2/pr2.xml", "tiago": "tiago/tiago.xml", "hsrb4s": "hsrb4s/hsrb4s.xml",
          "ridgeback_panda": "ridgeback_panda/ridgeback_panda.xml",
          "pr2_world": "../world/empty.xml+pr2/pr2.xml", "hsrb4s_world": "../world/empty.xml+hsrb4s/hsrb4s.xml",
@@ -22,7 +22,10 @@ FILES = {"pr2": "pr2/pr2.xml", "tiago": "tiago/tiago.xml", "hsrb4s": "hsrb4s/hsr
          "c5_pendulum_bowl_mesh": "pendulum.xml+bowl.xml",
          # C4: PR2 on the world floor + 8 spawnable objects (cubes / spheres / cylinders; the pool text lives in the generator)
          "c4_pr2_world_objects_mesh": None,
-         "tiago_mesh": "tiago/tiago.xml", "hsrb4s_mesh": "hsrb4s/hsrb4s.xml"}
+         "tiago_mesh": "tiago/tiago.xml", "hsrb4s_mesh": "hsrb4s/hsrb4s.xml", "armar6_mesh": "armar/armar6.xml",
+         # (loaded with mjh_load_set_parent_child_exclude(2): the wrapper's disable_parent_child_collision_level, mujoco_compile.cpp:250-290)
+         "ridgeback_panda_mesh": "ridgeback_panda/ridgeback_panda.xml"}
+PC_EXCLUDE = {"ridgeback_panda_mesh": 2}
 REF = "/root/reference/model/test"
 
 
@@ -73,10 +76,11 @@ def test_loader_still_produces_the_fixture_tables(lib, name):
     from mujoco_sim_amd import capi
     lib.mjh_load_set_bounds(1e-6, 1e-6)      # as the reference does before mj_loadXML (mj_sim.cpp:584-590)
     lib.mjh_load_set_mesh_mode(1 if name.endswith("_mesh") else 0)
+    lib.mjh_load_set_parent_child_exclude(PC_EXCLUDE.get(name, 0))
     try:
         m = ms.load_mjcf(paths=[os.path.join(REF, r) for r in FILES[name].split("+")])
     finally:
-        lib.mjh_load_set_bounds(0.0, 0.0); lib.mjh_load_set_mesh_mode(1)
+        lib.mjh_load_set_bounds(0.0, 0.0); lib.mjh_load_set_mesh_mode(1); lib.mjh_load_set_parent_child_exclude(0)
     f, z = load_model_tables(os.path.join(ROOT, "tests", "golden", f"robot_{name}.npz"))
     for k in ("nq", "nv", "nbody", "njnt", "ngeom", "neq", "npair", "nM", "ntree", "nmesh", "nmeshvert"):
         assert getattr(m, k) == getattr(f, k), k
