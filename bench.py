@@ -492,8 +492,8 @@ def run_group_host(args):
                    "mean_solver_iter": float(st[:, 2].mean())},
         "host": {"kind": "group", "api": "mjh_group_create / mjh_group_step / mjh_group_publish (csrc/group.hip)", "devices": devices,
                  "ranks": [{"rank": k, "device": devices[k], "env0": lo, "nenv": n} for k, (lo, n) in enumerate(g.ranges)],
-                 "host_issue": host_issue, "rccl": bool(g.uses_rccl), "rccl_ranks": ndev if g.uses_rccl else 0,
-                 "transport": "RCCL ncclAllGather (ncclCommInitAll, one group call)" if g.uses_rccl else "peer copies (hipMemcpyPeerAsync)",
+                 "host_issue": host_issue, "host_threads": int(ms.capi.load().mjh_group_host_threads(g.h)), "rccl": bool(g.uses_rccl), "rccl_ranks": ndev if g.uses_rccl else 0,
+                 "transport": "RCCL ncclAllGather (ncclCommInitAll; every device's host thread enqueues its own rank)" if g.uses_rccl else "peer copies (hipMemcpyPeerAsync)",
                  "all_gather": {"ms_mean": ag_ms, "count": ag_n, "bytes_per_rank": int(g.ranges[0][1] * g.stride * 4), "publish_every_steps": publish_every}},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "mjh_step_kernel", "kernel_ms": kernel_ms, "launches_timed": n_timed, "envs_per_launch": envs_per_launch,

@@ -526,6 +526,14 @@ int mjh_group_uses_rccl(const mjh_group*);
 int mjh_group_set_publish_timing(mjh_group*, int on);
 int mjh_group_get_publish_timing(mjh_group*, double* mean_ms, int* count);
 void mjh_group_set_transport(int mode);   /* groups created afterwards: 0 = RCCL when available (default), 1 = peer copies */
+/* Host threads of a group (groups created afterwards; default 1, environment MJH_GROUP_THREADS): 1 = one persistent host thread per device
+ * issues that device's launches, exports and its rank of the all-gather, every mjh_group_* call posts one job per device and waits for
+ * them — the host time of a call is that of ONE device (the reference steps on one thread, mj_main.cpp:203: with eight devices behind
+ * it that thread's launch calls alone would be as long as a light scene's step); 0 = the caller's thread issues everything, one device
+ * after the other.  Same launches in the same per-device order either way: results are bitwise the same.  mjh_group_host_threads:
+ * the number of such threads of a group (0: none). */
+void mjh_group_set_host_threads(int on);
+int mjh_group_host_threads(const mjh_group* g);
 
 /* ROS-free harness of the host loop (csrc/host_sim.cpp: simulate() + MjhHWInterface, mirrors of
  * mj_main.cpp:76-164 and mj_hw_interface.cpp:59-110) with an in-process PD effort controller on

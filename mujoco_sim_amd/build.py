@@ -17,7 +17,7 @@ WINDOW_HEADERS = ["window_kernel.h", "step_kernel.h", "patch_pgs.h", "window_pgs
 SOURCES = {
     "engine.hip": KERNEL_HEADERS + [API],
     "window.hip": WINDOW_HEADERS + [API],
-    "group.hip": [API],
+    "group.hip": ["host_pool.h", API],
     "model_builder.cpp": ["hmath.h", API],
     "scenes.cpp": ["hmath.h", API],
     "host_sim.cpp": ["host_sim.h", API],

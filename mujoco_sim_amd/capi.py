@@ -234,6 +234,8 @@ SYMBOLS = [
     ("mjh_group_state_stride", C.c_int, [_vp]),
     ("mjh_group_uses_rccl", C.c_int, [_vp]),
     ("mjh_group_set_transport", None, [C.c_int]),
+    ("mjh_group_set_host_threads", None, [C.c_int]),
+    ("mjh_group_host_threads", C.c_int, [C.c_void_p]),
     ("mjh_group_wait_publish", C.c_int, [_vp, C.c_int, _vp]),
     ("mjh_group_release_publish", C.c_int, [_vp, C.c_int, _vp]),
     ("mjh_group_set_publish_timing", C.c_int, [_vp, C.c_int]),

@@ -1,4 +1,5 @@
-// group.hip — the environments of ONE simulation sharded over the GPUs of a node, driven by ONE host thread through the C ABI
+// group.hip — the environments of ONE simulation sharded over the GPUs of a node, driven by ONE caller thread through the C ABI (behind it: a
+// host thread per device issues that device's launches — host_pool.h)
 // (include/mjhip.h "multi-GPU").  The reference is one C++ node with one publisher set (src/mj_main.cpp:167-236,
 // src/mujoco_sim/mj_ros.cpp:554-564); with many environments the stepper shards them — contiguous env ranges, one engine and one
 // stream per device, model tables replicated, NO collective in the step (environments are independent) — and the only exchange
@@ -10,11 +11,15 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "../../include/mjhip.h"
+#include "host_pool.h"
 
 void mjh_set_error(const std::string& s);  // model_builder.cpp
 
@@ -84,12 +89,31 @@ struct mjh_group {
   float* host = nullptr;                             // pinned staging of the gathered state (rank 0's copy)
   Rccl* rccl = nullptr; std::vector<ncclComm_t> ncomm;
   bool padded = false;
+  // one host thread per device (ndev > 1; MJH_GROUP_THREADS=0 / mjh_group_set_host_threads(0): the caller's thread issues everything, one
+  // device after the other): every entry point posts one job per device and waits for them
+  std::unique_ptr<HostPool> pool;
+  bool rccl_per_thread = true;     // threaded host: every device's thread enqueues its own ncclAllGather (NCCL's one-thread-per-device use) instead of one grouped call
 };
 
 extern "C" void mjh_group_set_transport(int mode) { g_transport = mode == 1 ? 1 : 0; }
+static int g_host_threads = getenv("MJH_GROUP_THREADS") ? atoi(getenv("MJH_GROUP_THREADS")) : 1;
+extern "C" void mjh_group_set_host_threads(int on) { g_host_threads = on ? 1 : 0; }      // groups created afterwards
+extern "C" int mjh_group_host_threads(const mjh_group* g) { return g && g->pool ? g->pool->size() : 0; }
+// fn(k) for every device: on the device's own host thread when the group has them, else one after the other on the caller's
+static int for_devices(mjh_group* g, const std::function<int(int)>& fn) {
+  if (g->pool) {
+    std::string err;
+    const int rc = g->pool->run(fn, &err);
+    if (rc) mjh_set_error(err);
+    return rc;
+  }
+  for (int k = 0; k < g->ndev; k++) { const int rc = fn(k); if (rc) return rc; }
+  return MJH_OK;
+}
 
 extern "C" void mjh_group_destroy(mjh_group* g) {
   if (!g) return;
+  g->pool.reset();
   for (int k = 0; k < (int)g->eng.size(); k++) {
     (void)hipSetDevice(g->dev[k]);
     if (g->eng[k]) mjh_destroy(g->eng[k]);
@@ -167,6 +191,11 @@ extern "C" int mjh_group_create(const mjh_model* model, int nenv_total, const in
       }
     }
   }
+  if (ndev > 1 && g_host_threads) {
+    std::vector<int> devs = g->dev;
+    g->pool.reset(new HostPool(ndev, [devs](int k) { (void)hipSetDevice(devs[k]); }, mjh_last_error));
+    if (const char* v = getenv("MJH_GROUP_RCCL_PER_THREAD")) g->rccl_per_thread = atoi(v) != 0;
+  }
   *out = g;
   return MJH_OK;
 }
@@ -188,7 +217,7 @@ extern "C" int mjh_group_locate(const mjh_group* g, int env, int* rank, int* loc
 }
 
 // one call per device, all asynchronous: the devices step concurrently, the host thread never waits here
-#define FOR_ALL(expr) do { for (int k = 0; k < g->ndev; k++) { mjh_engine* e = g->eng[k]; const int rc_ = (expr); if (rc_) return rc_; } return MJH_OK; } while (0)
+#define FOR_ALL(expr) return for_devices(g, [&](int k) -> int { mjh_engine* e = g->eng[k]; return (expr); })
 extern "C" int mjh_group_step(mjh_group* g, int nsteps, int with_inverse) { if (!g) return MJH_ERR_ARG; FOR_ALL(mjh_step(e, nsteps, with_inverse)); }
 extern "C" int mjh_group_step1(mjh_group* g) { if (!g) return MJH_ERR_ARG; FOR_ALL(mjh_step1(e)); }
 extern "C" int mjh_group_step2(mjh_group* g) { if (!g) return MJH_ERR_ARG; FOR_ALL(mjh_step2(e)); }
@@ -196,11 +225,11 @@ extern "C" int mjh_group_inverse(mjh_group* g) { if (!g) return MJH_ERR_ARG; FOR
 extern "C" int mjh_group_reset(mjh_group* g) { if (!g) return MJH_ERR_ARG; FOR_ALL(mjh_reset(e, nullptr, 0)); }
 extern "C" int mjh_group_synchronize(mjh_group* g) {
   if (!g) return MJH_ERR_ARG;
-  for (int k = 0; k < g->ndev; k++) {
+  return for_devices(g, [&](int k) -> int {
     const int rc = mjh_synchronize(g->eng[k]); if (rc) return rc;
     GCHK(hipStreamSynchronize(g->comm[k]));                            // (the last publish's exchange as well)
-  }
-  return MJH_OK;
+    return MJH_OK;
+  });
 }
 #undef FOR_ALL
 
@@ -220,7 +249,8 @@ extern "C" int mjh_group_publish(mjh_group* g, float* host_out) {
   // publish before it overwrites the send buffer (three steps later at 60 Hz: long done), and never for the current one — a
   // collective on the stepping stream would sit between two steps of every cohort and drain the pipeline (measured on one
   // device: 7.0 M against 9.1 M env-steps/s on S24).
-  for (int k = 0; k < g->ndev; k++) {
+  // stage A, per device: the engine's stream waits for the previous publish, packs the send buffer, hands over to the communication stream
+  int rc = for_devices(g, [&](int k) -> int {
     GCHK(hipSetDevice(g->dev[k]));
     if (g->published) {
       GCHK(hipStreamWaitEvent(g->stream[k], g->gathered[k], 0));          // (own collective has read send[k] / written recv[k])
@@ -228,16 +258,37 @@ extern "C" int mjh_group_publish(mjh_group* g, float* host_out) {
       // gather a torn slice, or one from a later step)
       if (!g->rccl) for (int r = 0; r < g->ndev; r++) if (r != k) GCHK(hipStreamWaitEvent(g->stream[k], g->consumed[r], 0));
     }
-    const int rc = mjh_export_state_device(g->eng[k], g->send[k]);      // (re-selects device k)
-    if (rc) return rc;
+    const int rce = mjh_export_state_device(g->eng[k], g->send[k]);      // (re-selects device k)
+    if (rce) return rce;
     GCHK(hipEventRecord(g->ready[k], g->stream[k]));
     GCHK(hipStreamWaitEvent(g->comm[k], g->ready[k], 0));
     // a consumer that is still reading the previous gathered state of this device (mjh_group_release_publish): the exchange below
     // overwrites that buffer
     if (g->has_release[k]) { GCHK(hipStreamWaitEvent(g->comm[k], g->released[k], 0)); g->has_release[k] = 0; }
-  }
-  if (g->timing) { GCHK(hipSetDevice(g->dev[0])); GCHK(hipEventRecord(g->t0, g->comm[0])); }
-  if (g->rccl) {
+    if (g->timing && k == 0) GCHK(hipEventRecord(g->t0, g->comm[0]));
+    return MJH_OK;
+  });
+  if (rc) return rc;
+  // stage B: the exchange (every ready[] event has been recorded: stage A is complete on every device), then the compaction
+  auto finish = [&](int k) -> int {
+    if (g->timing && k == 0) { GCHK(hipEventRecord(g->t1, g->comm[0])); g->t_pending = true; }
+    if (g->padded)     // uneven shares: the ranks' slots carry padding behind the smaller shares; close the gaps
+      for (int r = 0; r < g->ndev; r++)
+        GCHK(hipMemcpyAsync(g->packed[k] + (size_t)g->env0[r] * g->stride, g->recv[k] + (size_t)r * g->slot, (size_t)g->n[r] * g->stride * sizeof(float),
+                            hipMemcpyDeviceToDevice, g->comm[k]));
+    GCHK(hipEventRecord(g->gathered[k], g->comm[k]));
+    return MJH_OK;
+  };
+  if (g->rccl && g->pool && g->rccl_per_thread) {
+    // one thread per device, each enqueues its own rank's all-gather on its communication stream (the library's one-thread-per-device use)
+    rc = for_devices(g, [&](int k) -> int {
+      GCHK(hipSetDevice(g->dev[k]));
+      const ncclResult_t r = g->rccl->AllGather(g->send[k], g->recv[k], g->slot, ncclFloat, g->ncomm[k], g->comm[k]);
+      if (r != ncclSuccess) { mjh_set_error(std::string("ncclAllGather: ") + (g->rccl->GetErrorString ? g->rccl->GetErrorString(r) : "failed")); return MJH_ERR_NO_DEVICE; }
+      return finish(k);
+    });
+    if (rc) return rc;
+  } else if (g->rccl) {
     // every exit path passes ncclGroupEnd: a failure inside the group is remembered, not returned from
     ncclResult_t r = g->rccl->GroupStart();
     hipError_t he = hipSuccess;
@@ -254,24 +305,19 @@ extern "C" int mjh_group_publish(mjh_group* g, float* host_out) {
       mjh_set_error(std::string("ncclAllGather: ") + (g->rccl->GetErrorString ? g->rccl->GetErrorString(r) : "failed"));
       return MJH_ERR_NO_DEVICE;
     }
+    rc = for_devices(g, [&](int k) -> int { GCHK(hipSetDevice(g->dev[k])); return finish(k); });
+    if (rc) return rc;
   } else {
-    for (int k = 0; k < g->ndev; k++) {
+    rc = for_devices(g, [&](int k) -> int {
       GCHK(hipSetDevice(g->dev[k]));
       for (int r = 0; r < g->ndev; r++) {
         GCHK(hipStreamWaitEvent(g->comm[k], g->ready[r], 0));
         GCHK(hipMemcpyPeerAsync(g->recv[k] + (size_t)r * g->slot, g->dev[k], g->send[r], g->dev[r], slot_bytes, g->comm[k]));
       }
       GCHK(hipEventRecord(g->consumed[k], g->comm[k]));
-    }
-  }
-  if (g->timing) { GCHK(hipSetDevice(g->dev[0])); GCHK(hipEventRecord(g->t1, g->comm[0])); g->t_pending = true; }
-  for (int k = 0; k < g->ndev; k++) {
-    GCHK(hipSetDevice(g->dev[k]));
-    if (g->padded)     // uneven shares: the ranks' slots carry padding behind the smaller shares; close the gaps
-      for (int r = 0; r < g->ndev; r++)
-        GCHK(hipMemcpyAsync(g->packed[k] + (size_t)g->env0[r] * g->stride, g->recv[k] + (size_t)r * g->slot, (size_t)g->n[r] * g->stride * sizeof(float),
-                            hipMemcpyDeviceToDevice, g->comm[k]));
-    GCHK(hipEventRecord(g->gathered[k], g->comm[k]));
+      return finish(k);
+    });
+    if (rc) return rc;
   }
   g->published = true;
   if (host_out) {

@@ -260,7 +260,8 @@ def test_in_kernel_step_loop_equals_one_launch_per_step(with_inverse):
     e.close()
 
 
-def test_c5_as_eight_shards_on_one_device_equals_the_plain_engine():
+@pytest.mark.parametrize("host_threads", [1, 0], ids=["thread-per-shard", "one-host-thread"])
+def test_c5_as_eight_shards_on_one_device_equals_the_plain_engine(host_threads):
     """the multi-GPU config (multi_mujoco_sim.launch: C5) through the C host's group — 4096 envs as EIGHT shards
     of 512, all on device 0 (the one device there is; peer-copy transport: RCCL refuses duplicate devices), per-env spin, the state
     slice published every 3 steps and the consumer releasing it — against ONE engine over all 4096 envs: env order and bitwise state"""
@@ -270,11 +271,13 @@ def test_c5_as_eight_shards_on_one_device_equals_the_plain_engine():
     m, z = load_model_tables(os.path.join(os.path.dirname(__file__), "golden", "robot_c5_pendulum_bowl_mesh.npz"))
     nenv, nshard = 4096, 8
     spin = z["qvel0"][None, :] * np.random.default_rng(0xC5).uniform(0.5, 1.5, size=(nenv, 1))
-    lib.mjh_group_set_transport(1)
+    lib.mjh_group_set_transport(1); lib.mjh_group_set_host_threads(host_threads)
     try:
         g = ms.Group(m, nenv, [0] * nshard)
     finally:
-        lib.mjh_group_set_transport(0)
+        lib.mjh_group_set_transport(0); lib.mjh_group_set_host_threads(1)
+    # (round 5: a host thread per shard issues that shard's launches, exports and peer copies; the caller's thread only posts and waits)
+    assert lib.mjh_group_host_threads(g.h) == (nshard if host_threads else 0)
     single = ms.Engine(m, nenv)
     single.set_controlled_dofs(z["controlled"].astype(np.int32)); single.set_state(qvel=spin)
     assert [n for _, n in g.ranges] == [nenv // nshard] * nshard
