@@ -126,7 +126,7 @@ class S24(Workload):
 
 
 class S24D(S24):
-    cohorts = 3       # 4.20 / 4.37 M env-steps/s on 2 / 3 cohorts (tools/r04_final_s24.sh)
+    cohorts = 2       # round 5 (64-row form, window-count-major launch order): 4.82 / 4.65 / 4.51 M env-steps/s on 2 / 3 / 4 cohorts
     """the "30-contact" reading of the metric's name: S24's pen and S24's four boxes (same per-env sizes, masses, seeds), but released
     flat and side by side (2 x 2, random yaw) instead of as a staggered column of random orientations: the boxes land on the floor
     together (16 floor contacts of condim 4) and are wedged against each other and the walls — ~30 contacts, ~130 rows per env, what

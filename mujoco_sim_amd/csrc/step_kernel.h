@@ -948,7 +948,9 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
   // assemble-only launches of the window chain: the base-row pool (and the raw-contact staging that aliases it) — the largest array by far,
   // 192 B per contact — lives in the env's slice of the window buffer (global memory, L2-resident) instead of LDS: the launch is bound by
   // the latency of one wave per env, and its LDS sets how many envs a CU holds (S24D at 96 contacts: 44 KB -> 25 KB, 3 -> 6 per CU)
+#ifndef MJH_WPRE_LDS_J       // (A/B builds: the pool back in LDS; the launch then needs the whole layout: MJH_WINDOW_SLIM_LDS=0)
   if constexpr (WPRE) { s_J = S.wbuf + (size_t)env * (size_t)S.wstride + S.wj_off; s_B = s_J; }
+#endif
   float* s_stage = s_J;  // raw-contact staging aliases the (not yet built) base-row storage
   const int rowW = M.rowW;
 

@@ -145,6 +145,19 @@ DEV void wn_jt32(const float* J, const float x, float& a_lo, float& a_hi) {
   a_lo += s_lo + y_lo; a_hi += s_hi + y_hi;
 }
 
+// launch-order hint of an env (mjh_order_kernel sorts by hint >> 6 into 256 buckets, longest job first): the number of its 16-row windows
+// first, its sweeps second — a wavefront of the 16-row form sweeps max(windows) x max(sweeps) over its four envs, so envs of EQUAL window
+// count belong together (sorted by the product alone, a wave of {3 windows x 100 sweeps, 6 x 50, ...} ran 6 x 100: S24's mean wave ran
+// 12 % more window-sweeps than its mean env; S24 11.24 -> 11.76 M env-steps/s).  Scaled so that the model's largest env fills the buckets.
+DEV int wn_cost_hint(const DModel& M, const int nwin16, const int niter) {
+#ifdef WN_HINT_PRODUCT
+  return min(niter * nwin16 * 20 + 1, 1 << 22);
+#else
+  const int scale = max(1, 16320 / ((M.win_maxw + 1) * 104));
+  return (nwin16 * 104 + min(niter, 103)) * scale + 1;
+#endif
+}
+
 // MjSim::set_odom_vels (/root/reference/src/mujoco_sim/mj_sim.cpp:1079-1153) behind mj_Euler, as in the fused kernel (step_kernel.h): the commanded
 // twist, rotated by the odom angles of the INTEGRATED qpos, overwrites the odom dofs' velocities for the next step.  One lane per env;
 // qp: the env's integrated qpos (LDS), qv: its row of S.qvel.
@@ -226,7 +239,7 @@ DEV void wn_finish_wide(const DModel& M, const DState& S, float* const wb, const
 #ifdef WN_PROF_CLK
     const int cost_hint = min((int)(((long long)__builtin_amdgcn_s_memtime() - wn_t0) >> 5) + 1, (1 << 22) - 1);   // (probe build: the wave's own clocks in the hint field)
 #else
-    const int cost_hint = min(niter * nwin16 * 20 + 1, 1 << 22);
+    const int cost_hint = wn_cost_hint(M, nwin16, niter);
 #endif
     S.stats[4 * env] = WN_STAT0(wh[1]); S.stats[4 * env + 1] = wh[2]; S.stats[4 * env + 2] = niter;
     S.stats[4 * env + 3] = ((S.stats[4 * env + 3] | flags) & 0xff) | (cost_hint << 8);
@@ -883,7 +896,7 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
 #ifdef WN_PROF_CLK
     const int cost_hint = min((int)(((long long)__builtin_amdgcn_s_memtime() - wn_t0) >> 5) + 1, (1 << 22) - 1);
 #else
-    const int cost_hint = min(niter * nwin * 20 + 1, 1 << 22);
+    const int cost_hint = wn_cost_hint(M, nwin, niter);
 #endif
     S.stats[4 * env] = WN_STAT0(wh[1]); S.stats[4 * env + 1] = wh[2]; S.stats[4 * env + 2] = niter;
     S.stats[4 * env + 3] = ((S.stats[4 * env + 3] | flags) & 0xff) | (cost_hint << 8);
