@@ -171,7 +171,7 @@ static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps,
     // same launch order and take the envs the assemble launch marked; almost all of them exit at once)
     const int n32 = (e->S.win32 && e->M.win_nvt == 24) ? (n + 1) / 2 : 0;
     const int wxf = (xflags & ~XF_DEFER) | ((ph & PH_STEP1) ? 0 : XF_SPLIT2);
-    const int n64 = (e->S.win64 && e->M.win_nvt == 24 && e->M.win_maxw > 16) ? n : 0;      // the 64-row section: one wavefront per env of the launch order, almost all of them exit at once
+    const int n64 = (e->S.win64 && e->M.win_nvt == 24 && e->S.win64 < 16 * e->M.win_maxw) ? n : 0;      // the 64-row section: one wavefront per env of the launch order, almost all of them exit at once
     HIPCHK(mjh_launch_window(st, e->M.win_nvt, n64 + (e->M.win_nvt == 24 ? n32 : 0) + (n + 3) / 4, lds, e->dC, e->S, env0, n, nl, wxf, n32, n64));
   }
   return MJH_OK;

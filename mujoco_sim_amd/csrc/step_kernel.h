@@ -2438,7 +2438,7 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
                 // [4]: the form the window kernel sweeps this env in — 1: 32-row windows for many rows (window_kernel.h: wn_run32), 2: 64-row windows for the most (wn_run64); a function of the env's own row count
                 // (split API: the counts of THIS step are what mjh_get_stats / mjh_get_field see between the two halves, as after a plain mj_step1)
                 if (lane == 0 && wdefer) { S.stats[4*env] = ncon; S.stats[4*env+1] = nefc; S.stats[4*env+2] = 0; S.stats[4*env+3] |= flags & 0xff; }
-                if (lane == 0) { int* wh = (int*)wb; wh[0] = nrow; wh[1] = ncon; wh[2] = nefc; wh[3] = flags; wh[4] = (S.win64 > 0 && M.win_nvt == 24 && nrow > S.win64 && nrow <= (M.win_maxw > 16 ? 64 * (WN64_NW + WN64_NT) : 0)) ? 2 : ((S.win32 > 0 && M.win_nvt == 24 && nrow > S.win32 && nrow <= 32 * WN32_NW) ? 1 : 0); wh[5] = (wdefer && nrow == 0) ? 1 : 0; }   // [5]: an env without rows that the window kernel integrates (split API)
+                if (lane == 0) { int* wh = (int*)wb; wh[0] = nrow; wh[1] = ncon; wh[2] = nefc; wh[3] = flags; wh[4] = (S.win64 > 0 && M.win_nvt == 24 && nrow > S.win64 && nrow <= (M.win_maxw > 16 ? 64 * (WN64_NW + WN64_NT) : 64 * WN64_NW)) ? 2 : ((S.win32 > 0 && M.win_nvt == 24 && nrow > S.win32 && nrow <= 32 * WN32_NW) ? 1 : 0); wh[5] = (wdefer && nrow == 0) ? 1 : 0; }   // [5]: an env without rows that the window kernel integrates (split API)
                 return;
               }
               // (more rows than the window kernel takes: this env finishes the step here, in patch form)
