@@ -775,7 +775,7 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": w.label, "name": w.name, "settle_steps": w.settle_steps, "envs_per_gpu": nenv, "envs_total": total_envs,
-                   "steps_per_launch": spl, "cohorts": cohorts, "with_inverse": bool(main_inverse), "parallelism": f"env-sharded x{world}",
+                   "steps_per_launch": spl, "launches_per_cohort_step": int(eng.launches_per_step), "cohorts": cohorts, "with_inverse": bool(main_inverse), "parallelism": f"env-sharded x{world}",
                    "envs_per_wavefront": w.pack, "nq": int(w.base_model.nq), "nv": int(w.base_model.nv),
                    "mean_ncon": mean_ncon, "max_ncon": int(st[:, 0].max()), "mean_nefc": float(st[:, 1].mean()) / w.pack,
                    "max_nefc": int(st[:, 1].max()), "mean_solver_iter": float(st[:, 2].mean()),

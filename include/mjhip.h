@@ -479,6 +479,15 @@ int mjh_get_cohorts(const mjh_engine*);
  * chains of launches (src/mj_main.cpp:83-108 is one step of ONE world; the batch steps n times before the host looks again). */
 int mjh_set_steps_per_launch(mjh_engine*, int n);
 int mjh_get_steps_per_launch(const mjh_engine*);
+/* Launch chains as graphs.  Where a step is a chain of launches per cohort — the window chain of small free-body models (assemble ->
+ * window kernel) and the many-body layout (assemble -> [dense build -> dense solve] -> solve -> integrate) — mjh_step captures the
+ * chain once per cohort and variant (hipStreamBeginCapture on the cohort's stream) and queues every further cohort-step with ONE
+ * hipGraphLaunch; the graph is captured again whenever something its kernels take by value changes.  Same kernels, same arguments, same
+ * order: results are bitwise those of the separate launches.  mode (also MJH_CHAIN_GRAPH): 1 (default) the many-body chain only, 2 the
+ * window chain as well (measured slower on S24: two plain launches stay the default there), 0 every launch on its own.
+ * mjh_launches_per_step: host-side launches mjh_step issues per cohort-step (1 with the graph; 2 / 3 / 5 without). */
+void mjh_set_chain_graph(int mode);
+int mjh_launches_per_step(const mjh_engine*);
 /* HIP-event timing of the step-kernel launches on the stream they run on: enable (on = 1: every launch, on = N > 1: every
  * N-th launch — the event pairs cost stream time of their own, visible in launch-bound configs), step, then read the mean
  * duration [ms] and the number of launches timed since the last read (bench.py's roofline leg). */

@@ -214,6 +214,8 @@ SYMBOLS = [
     ("mjh_get_cohorts", C.c_int, [_vp]),
     ("mjh_set_steps_per_launch", C.c_int, [_vp, C.c_int]),
     ("mjh_get_steps_per_launch", C.c_int, [_vp]),
+    ("mjh_set_chain_graph", None, [C.c_int]),
+    ("mjh_launches_per_step", C.c_int, [C.c_void_p]),
     ("mjh_set_launch_timing", C.c_int, [_vp, C.c_int]),
     ("mjh_get_launch_timing", C.c_int, [_vp, c_double_p, C.POINTER(C.c_int)]),
     ("mjh_group_create", C.c_int, [Model_p, C.c_int, c_int_p, C.c_int, C.POINTER(_vp)]),

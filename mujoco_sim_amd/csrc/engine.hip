@@ -78,6 +78,10 @@ struct mjh_engine {
   bool lpt = true;
   bool split3 = true;         // many-body layout: three-launch step (MJH_SPLIT3=0: fused kernel)
   bool order_valid = false;   // d_order holds a full-range permutation (split API); mjh_step sorts per cohort
+  // one captured graph per cohort and variant of its step chain (mjh_step: assemble -> [dense build -> dense solve] -> solve -> integrate of the
+  // many-body layout; assemble -> window kernel of the window chain): the chain is queued with ONE hipGraphLaunch per cohort-step
+  struct ChainGraph { hipGraphExec_t exec = nullptr; unsigned char S[sizeof(DState)]; int g0 = -1, n = -1, key = -1; };
+  ChainGraph cgraph[MJH_MAX_COHORTS][8];
   int steps_per_launch = 8;   // mjh_step(n): steps one launch of a loop-capable kernel instance runs (mjh_set_steps_per_launch; 1: one launch per step)
   long order_age = 0; int order_G = 0; int last_chunk = 1;   // last_chunk: steps of the previous launch (the sort is renewed when a multiple of MJH_ORDER_EVERY was crossed)   // mjh_step renews its per-cohort sorts every MJH_ORDER_EVERY-th step; order_G: cohort count they were made for (-1: none)
   // Cohorts: mjh_step() splits the envs into ncohort contiguous groups, each stepped on its own stream, so that the
@@ -108,6 +112,11 @@ template <class T> static int dev_alloc(mjh_engine* e, T** p, size_t n, bool zer
   return MJH_OK;
 }
 
+// 1 (default): mjh_step queues the many-body layout's launch chain of a cohort-step as one captured graph; 2: the window chain as well (S24:
+// 11.42 against 11.63 M env-steps/s with two plain launches — the graph's own launch costs more than it saves there); 0: never
+static int g_chain_graph = getenv("MJH_CHAIN_GRAPH") ? atoi(getenv("MJH_CHAIN_GRAPH")) : 1;
+extern "C" void mjh_set_chain_graph(int mode) { g_chain_graph = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
+
 static int ensure_scratch(mjh_engine* e, size_t floats) {
   if (floats <= e->scratch_floats) return MJH_OK;
   if (e->scratch) { HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipFree(e->scratch)); }
@@ -120,9 +129,25 @@ static int ensure_scratch(mjh_engine* e, size_t floats) {
 // ... or sites / sensors / mocap bodies / connect-weld equalities; and (engine state) Cartesian forces on bodies in use
 static bool extra_instance(const DModel& M) { return M.has_convex || M.noslip_iterations > 0 || M.nsensor > 0 || M.nmocap > 0 || M.has_weld; }
 
+// windows of the window kernel's LDS tier for the next launch of cohort e->cur_cohort
+static int window_tier(const mjh_engine* e) {
+  static const int nl_env = getenv("MJH_WN_NL") ? atoi(getenv("MJH_WN_NL")) : -1;      // (experiments: force the number of LDS-tier windows)
+  // ... and none at all while no env of the cohort comes near the register-resident windows' rows: mjh_order_kernel leaves the cohort's
+  // largest row count in a host-mapped word whenever it renews the launch order; read unsynchronised — the tiers hold the same values,
+  // the choice changes where a window waits, not what is computed (S24: 9.13 -> 9.35 M env-steps/s; S24D needs the tier)
+  const int nwreg = e->M.win_nvt == 24 ? WN_NW24 : WN_NW32;
+  const int seen = (e->h_wn && e->cur_cohort >= 0) ? *(volatile int*)(e->h_wn + e->cur_cohort) : (1 << 20);
+  const int nl_full = std::min(WN_MAXW, (int)((40 * 1024 - 1024) / (4 * WN_XREC(e->M.win_nvt) * 16 * sizeof(float))));
+  // (with the 32-row section on, the 16-row form only meets envs of at most WN32_MIN_ROWS rows — or more than 128, the tier's clients)
+  const bool sec32 = e->S.win32 > 0 && e->M.win_nvt == 24 && e->S.win32 <= 16 * nwreg;
+  const bool tier = sec32 ? seen > 32 * WN32_NW : seen + 16 > 16 * nwreg;
+  // (models whose rows can exceed 256 — win_maxw > 16 — always get the tier: the 64-row section keeps the tiles of its last windows there,
+  //  and which envs take that section is decided on the device)
+  return nl_env >= 0 ? nl_env : ((tier || e->M.win_maxw > 16) ? nl_full : 0);
+}
 // wmode (window chain of small free-body models): 0 the whole step; 1 the assemble launch only, every env handed over — the split API's
 // mjh_step1 [+ mjh_inverse] doing the work mjh_step2 would otherwise repeat (the rows only exist in LDS); 2 the window kernel only
-static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps, int ph, int xflags, int wmode = 0) {
+static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps, int ph, int xflags, int wmode = 0, int tier_nl = -1) {
   if (n <= 0) return MJH_OK;
   // window sweep (window_pgs.h): every launch that runs mj_step2 to the end (the fused step and the split API's step2) of a small
   // free-body model = assemble launch (PH_PRE), then four envs per wavefront through the sweeps and the integration
@@ -153,19 +178,7 @@ static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps,
   }
   if (window && wmode != 1) {
     // LDS tier: windows beyond the register-resident ones, as many as leave four waves per CU (40 KB per wave)
-    static const int nl_env = getenv("MJH_WN_NL") ? atoi(getenv("MJH_WN_NL")) : -1;      // (experiments: force the number of LDS-tier windows)
-    // ... and none at all while no env of the cohort comes near the register-resident windows' rows: mjh_order_kernel leaves the cohort's
-    // largest row count in a host-mapped word whenever it renews the launch order; read unsynchronised — the tiers hold the same values,
-    // the choice changes where a window waits, not what is computed (S24: 9.13 -> 9.35 M env-steps/s; S24D needs the tier)
-    const int nwreg = e->M.win_nvt == 24 ? WN_NW24 : WN_NW32;
-    const int seen = (e->h_wn && e->cur_cohort >= 0) ? *(volatile int*)(e->h_wn + e->cur_cohort) : (1 << 20);
-    const int nl_full = std::min(WN_MAXW, (int)((40 * 1024 - 1024) / (4 * WN_XREC(e->M.win_nvt) * 16 * sizeof(float))));
-    // (with the 32-row section on, the 16-row form only meets envs of at most WN32_MIN_ROWS rows — or more than 128, the tier's clients)
-    const bool sec32 = e->S.win32 > 0 && e->M.win_nvt == 24 && e->S.win32 <= 16 * nwreg;
-    const bool tier = sec32 ? seen > 32 * WN32_NW : seen + 16 > 16 * nwreg;
-    // (models whose rows can exceed 256 — win_maxw > 16 — always get the tier: the 64-row section keeps the tile of its fifth window there,
-    //  and which envs take that section is decided on the device)
-    const int nl = nl_env >= 0 ? nl_env : ((tier || e->M.win_maxw > 16) ? nl_full : 0);
+    const int nl = tier_nl >= 0 ? tier_nl : window_tier(e);
     const size_t lds = (size_t)4 * nl * WN_XREC(e->M.win_nvt) * 16 * sizeof(float);
     // 24-dof models: a first section of wavefronts sweeps the envs with many rows in 32-row windows, two per wavefront (they scan the
     // same launch order and take the envs the assemble launch marked; almost all of them exit at once)
@@ -674,6 +687,7 @@ extern "C" void mjh_destroy(mjh_engine* e) {
   (void)hipStreamSynchronize(e->stream);
   for (int g = 0; g < MJH_MAX_COHORTS; g++) { if (e->cstream[g]) (void)hipStreamDestroy(e->cstream[g]); if (e->ev_join[g]) (void)hipEventDestroy(e->ev_join[g]); }
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  for (int g = 0; g < MJH_MAX_COHORTS; g++) for (int k = 0; k < 8; k++) if (e->cgraph[g][k].exec) (void)hipGraphExecDestroy(e->cgraph[g][k].exec);
   for (auto& p : e->tev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->scratch) (void)hipFree(e->scratch);
@@ -838,37 +852,65 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
         ta = e->tev[e->tev_used].first; tb = e->tev[e->tev_used].second; e->tev_used++;
         HIPCHK(hipEventRecord(ta, st));
       }
-      if (e->M.big && e->split3) {
-        // many-body layout: assemble -> solve (3 KB of LDS per env instead of ~70 KB: many more resident envs during the
-        // sweeps, which are > 90 % of such a step) -> integrate
-        // dense row-space solver for this cohort's step?  (the word mjh_order_kernel left two rebuilds of the launch order ago; the
-        // assemble launch is TOLD the decision, nothing on the device reads the word)
-        const bool dn = e->M.dense && (!e->h_dense || e->dense_now[g]);
-        rc = launch_on(e, st, g0, g1 - g0, 1, ph | PH_PRE, dn ? XF_DENSE : 0);
-        if (!rc && dn) {
-          // dense row-space solver (dense_pgs.h): AR = J M^-1 J^T on the matrix cores, then column sweeps, for every env of the
-          // launch whose row count fits; the block solver below skips those envs (meta[7])
-          hipLaunchKernelGGL(mjh_dense_build_kernel, dim3(g1 - g0), dim3(DN_BUILD_THREADS), e->dense_lds, st, e->dC, e->S, g0);
-          hipLaunchKernelGGL(mjh_dense_solve_kernel, dim3(g1 - g0), dim3(64), e->dense_solve_lds, st, e->dC, e->S, g0);
-          HIPCHK(hipGetLastError());
+      // the chain of launches of this cohort-step.  dn: dense row-space solver for this cohort's step (the word mjh_order_kernel left two
+      // rebuilds of the launch order ago; the assemble launch is TOLD the decision, nothing on the device reads the word); nl: windows of the
+      // window kernel's LDS tier (window models: window_tier — an unsynchronised hint read HERE, once per cohort-step)
+      const bool chain_big = e->M.big && e->split3;
+      const bool chain_win = !chain_big && e->M.window && e->S.wbuf;
+      const bool dn = chain_big && e->M.dense && (!e->h_dense || e->dense_now[g]);
+      e->cur_cohort = g; const int nl = chain_win ? window_tier(e) : -1; e->cur_cohort = -1;
+      auto issue_chain = [&]() -> int {
+        int rc = MJH_OK;
+        if (e->M.big && e->split3) {
+          // many-body layout: assemble -> solve (3 KB of LDS per env instead of ~70 KB: many more resident envs during the
+          // sweeps, which are > 90 % of such a step) -> integrate
+          // dense row-space solver for this cohort's step?  (the word mjh_order_kernel left two rebuilds of the launch order ago; the
+          // assemble launch is TOLD the decision, nothing on the device reads the word)
+          rc = launch_on(e, st, g0, g1 - g0, 1, ph | PH_PRE, dn ? XF_DENSE : 0);
+          if (!rc && dn) {
+            // dense row-space solver (dense_pgs.h): AR = J M^-1 J^T on the matrix cores, then column sweeps, for every env of the
+            // launch whose row count fits; the block solver below skips those envs (meta[7])
+            hipLaunchKernelGGL(mjh_dense_build_kernel, dim3(g1 - g0), dim3(DN_BUILD_THREADS), e->dense_lds, st, e->dC, e->S, g0);
+            hipLaunchKernelGGL(mjh_dense_solve_kernel, dim3(g1 - g0), dim3(64), e->dense_solve_lds, st, e->dC, e->S, g0);
+            HIPCHK(hipGetLastError());
+          }
+          if (!rc) {
+            const size_t lds = (2 * (size_t)(((e->M.nv + 3) / 4) * 4) + 2 * (size_t)std::max(e->M.maxblk, 1) + 4 + 8 + 8 + 8 * (size_t)((e->M.nv + 2) / 3)) * sizeof(float);   // ... + the quad sweep's padded copies (four floats per 3 dofs, twice)   // 2 dof vectors + visiting order + group starts + per-wave partial sums
+            const bool xs = e->M.noslip_iterations > 0;      // (the convex narrow phase is not part of the solve launch)
+            // wide groups (up to 16 independent blocks) can be shared by several waves per environment (MJH_SOLVE_WAVES = 2, 4: chunk
+            // c4 of a group goes to wave c4 % n, a workgroup barrier ends the group).  Measured on C2 (4096 envs, 215 contacts per
+            // env): 288 k / 282 k / 259 k env-steps/s with 1 / 2 / 4 waves — the sweep streams 0.4 MB of block operands per env and
+            // sweep from L2 / HBM and is bound by that stream, not by the length of the dependent chain; so the default stays 1
+            static const int nwave_env = getenv("MJH_SOLVE_WAVES") ? std::max(1, std::min(4, atoi(getenv("MJH_SOLVE_WAVES")))) : 1;
+            const dim3 thr(e->M.group_max == 16 && e->M.rowW <= 16 ? 64 * nwave_env : 64);
+            if (e->M.diagM) { if (xs) hipLaunchKernelGGL((mjh_solve_kernel<true, true>), dim3(g1 - g0), thr, lds, st, e->dC, e->S, g0);
+                              else hipLaunchKernelGGL((mjh_solve_kernel<true, false>), dim3(g1 - g0), thr, lds, st, e->dC, e->S, g0); }
+            else { if (xs) hipLaunchKernelGGL((mjh_solve_kernel<false, true>), dim3(g1 - g0), thr, lds, st, e->dC, e->S, g0);
+                   else hipLaunchKernelGGL((mjh_solve_kernel<false, false>), dim3(g1 - g0), thr, lds, st, e->dC, e->S, g0); }
+            HIPCHK(hipGetLastError());
+            rc = launch_on(e, st, g0, g1 - g0, 1, PH_STEP2 | PH_POST, 0);
+          }
+        } else { e->cur_cohort = g; rc = launch_on(e, st, g0, g1 - g0, k, ph, 0, 0, nl); e->cur_cohort = -1; }
+        return rc;
+      };
+      // One hipGraphLaunch per cohort-step instead of 2 .. 5 kernel launches: the chain is captured once per (cohort, variant) and replayed
+      // while nothing its kernels take by value changes (the device-state descriptor, the env range, the phase / tier / dense choice)
+      if (((chain_big && g_chain_graph >= 1) || (chain_win && g_chain_graph >= 2)) && k == 1) {
+        const int key = (dn ? 1 : 0) | (with_inverse ? 2 : 0) | ((nl > 0 ? 1 : 0) << 2);
+        mjh_engine::ChainGraph& cg = e->cgraph[g][key & 7];
+        if (!cg.exec || cg.g0 != g0 || cg.n != g1 - g0 || cg.key != (key | (nl << 8)) || std::memcmp(cg.S, &e->S, sizeof(DState)) != 0) {
+          if (cg.exec) { (void)hipGraphExecDestroy(cg.exec); cg.exec = nullptr; }
+          hipGraph_t gr = nullptr;
+          HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+          rc = issue_chain();
+          const hipError_t ce = hipStreamEndCapture(st, &gr);
+          if (!rc && ce != hipSuccess) { mjh_set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce)); rc = MJH_ERR_NO_DEVICE; }
+          if (!rc) HIPCHK(hipGraphInstantiate(&cg.exec, gr, nullptr, nullptr, 0));
+          if (gr) (void)hipGraphDestroy(gr);
+          if (!rc) { std::memcpy(cg.S, &e->S, sizeof(DState)); cg.g0 = g0; cg.n = g1 - g0; cg.key = key | (nl << 8); }
         }
-        if (!rc) {
-          const size_t lds = (2 * (size_t)(((e->M.nv + 3) / 4) * 4) + 2 * (size_t)std::max(e->M.maxblk, 1) + 4 + 8 + 8 + 8 * (size_t)((e->M.nv + 2) / 3)) * sizeof(float);   // ... + the quad sweep's padded copies (four floats per 3 dofs, twice)   // 2 dof vectors + visiting order + group starts + per-wave partial sums
-          const bool xs = e->M.noslip_iterations > 0;      // (the convex narrow phase is not part of the solve launch)
-          // wide groups (up to 16 independent blocks) can be shared by several waves per environment (MJH_SOLVE_WAVES = 2, 4: chunk
-          // c4 of a group goes to wave c4 % n, a workgroup barrier ends the group).  Measured on C2 (4096 envs, 215 contacts per
-          // env): 288 k / 282 k / 259 k env-steps/s with 1 / 2 / 4 waves — the sweep streams 0.4 MB of block operands per env and
-          // sweep from L2 / HBM and is bound by that stream, not by the length of the dependent chain; so the default stays 1
-          static const int nwave_env = getenv("MJH_SOLVE_WAVES") ? std::max(1, std::min(4, atoi(getenv("MJH_SOLVE_WAVES")))) : 1;
-          const dim3 thr(e->M.group_max == 16 && e->M.rowW <= 16 ? 64 * nwave_env : 64);
-          if (e->M.diagM) { if (xs) hipLaunchKernelGGL((mjh_solve_kernel<true, true>), dim3(g1 - g0), thr, lds, st, e->dC, e->S, g0);
-                            else hipLaunchKernelGGL((mjh_solve_kernel<true, false>), dim3(g1 - g0), thr, lds, st, e->dC, e->S, g0); }
-          else { if (xs) hipLaunchKernelGGL((mjh_solve_kernel<false, true>), dim3(g1 - g0), thr, lds, st, e->dC, e->S, g0);
-                 else hipLaunchKernelGGL((mjh_solve_kernel<false, false>), dim3(g1 - g0), thr, lds, st, e->dC, e->S, g0); }
-          HIPCHK(hipGetLastError());
-          rc = launch_on(e, st, g0, g1 - g0, 1, PH_STEP2 | PH_POST, 0);
-        }
-      } else { e->cur_cohort = g; rc = launch_on(e, st, g0, g1 - g0, k, ph, 0); e->cur_cohort = -1; }
+        if (!rc) HIPCHK(hipGraphLaunch(cg.exec, st));
+      } else rc = issue_chain();
       if (ta && !rc) HIPCHK(hipEventRecord(tb, st));
     }
     e->last_chunk = k;
@@ -905,6 +947,12 @@ extern "C" double mjh_get_timestep(const mjh_engine* e) { return e ? e->M.timest
 static int reset_dense_choice(mjh_engine* e);
 extern "C" int mjh_set_cohorts(mjh_engine* e, int n) { ENG(e); int rc = set_cohorts(e, n); return rc ? rc : reset_dense_choice(e); }
 extern "C" int mjh_get_cohorts(const mjh_engine* e) { return e ? e->ncohort : 0; }
+extern "C" int mjh_launches_per_step(const mjh_engine* e) {
+  if (!e) return 0;
+  const bool big = e->M.big && e->split3, win = !big && e->M.window && e->S.wbuf;
+  const int chain = big ? (e->M.dense ? 5 : 3) : (win ? 2 : 1);
+  return ((big && g_chain_graph >= 1) || (win && g_chain_graph >= 2)) ? 1 : chain;
+}
 extern "C" int mjh_set_steps_per_launch(mjh_engine* e, int n) { ENG(e); e->steps_per_launch = std::max(1, std::min(n, 64)); return MJH_OK; }
 extern "C" int mjh_get_steps_per_launch(const mjh_engine* e) { return !e ? 0 : ((!e->M.big && !e->M.diagM) ? e->steps_per_launch : 1); }
 extern "C" int mjh_synchronize(mjh_engine* e) { ENG(e); KEEP_HANDOVER(e); HIPCHK(hipStreamSynchronize(e->stream)); return MJH_OK; }

@@ -145,6 +145,11 @@ class Engine:
     def set_steps_per_launch(self, n): _chk(self.lib, self.lib.mjh_set_steps_per_launch(self.h, int(n)), "mjh_set_steps_per_launch")
     @property
     def steps_per_launch(self): return self.lib.mjh_get_steps_per_launch(self.h)
+    @property
+    def launches_per_step(self):
+        """host-side launches mjh_step issues per cohort-step (1: fused kernel, or a launch chain queued as one captured graph)"""
+        return self.lib.mjh_launches_per_step(self.h)
+
     def set_launch_timing(self, on=True): _chk(self.lib, self.lib.mjh_set_launch_timing(self.h, int(on)), "mjh_set_launch_timing")   # N > 1: every N-th launch
     def get_launch_timing(self):
         """-> (mean step-kernel duration [ms], launches) since the last call"""

@@ -293,3 +293,40 @@ def test_window_sweeps_converge_to_the_qp_solution_of_an_independent_solver():
     errs = np.concatenate([e1, e2])
     assert len(errs) >= 200
     assert np.median(errs) <= 1e-3 and errs.max() <= 1e-2          # measured: median 1.3e-4 (S24) / 4.0e-4 (S24D), max 1.8e-3 / 3.1e-3
+
+
+@pytest.mark.parametrize("config", ["s24", "c2"])
+def test_launch_chain_as_a_captured_graph_equals_the_separate_launches(config):
+    """B2 (one launch per step): where a cohort-step is a chain of launches — the window chain (assemble -> window kernel) and
+    the many-body layout (assemble -> solve -> integrate) — mjh_step queues it as ONE captured graph per cohort-step
+    (mjh_launches_per_step == 1; default for the many-body chain, opt-in — mode 2 — for the window chain, where it measures 2 % slower).  Same kernels, same arguments: bitwise the state of the separate launches, over order renewals, a
+    state change between calls (set_state: nothing the graph holds by value) and a change of what it does hold (the cohort count)."""
+    lib = ms.capi.load()
+    outs = []
+    for graph in (2, 0):
+        lib.mjh_set_chain_graph(graph)
+        try:
+            if config == "s24":
+                m = ms.scene("s24"); nenv = 1536
+                e = ms.Engine(m, nenv); e.load_s24()
+            else:
+                m = ms.scene("boxpile", 64); m.c.maxcon = 600; m.c.maxefc = 2400          # bench.py's C2
+                nenv = 1536
+                e = ms.Engine(m, nenv)
+                e.load_tables(ms.boxes_randomize(m, 0, nenv, jitter=0.01))
+            e.set_cohorts(3)
+            assert e.launches_per_step == (1 if graph else (2 if config == "s24" else 3))
+            e.step(40)
+            t, q, v, w = e.get_state()
+            e.set_state(qvel=v * 0.5)                # (the graphs stay valid: the state lives behind pointers)
+            e.step(37, True)
+            e.set_cohorts(2)                         # (env ranges of the cohorts change: captured again)
+            e.step(10)
+            outs.append((e.get_state(), e.get_stats()[:, :3].copy()))
+            e.close()
+        finally:
+            lib.mjh_set_chain_graph(1)
+    (sa, sta), (sb, stb) = outs
+    for x, y in zip(sa, sb):
+        assert np.array_equal(x, y)
+    assert np.array_equal(sta, stb) and sta[:, 0].mean() > 4
