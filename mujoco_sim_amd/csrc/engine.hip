@@ -895,21 +895,23 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
       };
       // One hipGraphLaunch per cohort-step instead of 2 .. 5 kernel launches: the chain is captured once per (cohort, variant) and replayed
       // while nothing its kernels take by value changes (the device-state descriptor, the env range, the phase / tier / dense choice)
-      if (((chain_big && g_chain_graph >= 1) || (chain_win && g_chain_graph >= 2)) && k == 1) {
+      // (not on the NULL stream — it cannot be captured —: small engines without cohort streams on the caller's default stream keep the plain launches)
+      if (((chain_big && g_chain_graph >= 1) || (chain_win && g_chain_graph >= 2)) && k == 1 && st != nullptr) {
         const int key = (dn ? 1 : 0) | (with_inverse ? 2 : 0) | ((nl > 0 ? 1 : 0) << 2);
         mjh_engine::ChainGraph& cg = e->cgraph[g][key & 7];
         if (!cg.exec || cg.g0 != g0 || cg.n != g1 - g0 || cg.key != (key | (nl << 8)) || std::memcmp(cg.S, &e->S, sizeof(DState)) != 0) {
           if (cg.exec) { (void)hipGraphExecDestroy(cg.exec); cg.exec = nullptr; }
           hipGraph_t gr = nullptr;
-          HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-          rc = issue_chain();
-          const hipError_t ce = hipStreamEndCapture(st, &gr);
-          if (!rc && ce != hipSuccess) { mjh_set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce)); rc = MJH_ERR_NO_DEVICE; }
-          if (!rc) HIPCHK(hipGraphInstantiate(&cg.exec, gr, nullptr, nullptr, 0));
-          if (gr) (void)hipGraphDestroy(gr);
-          if (!rc) { std::memcpy(cg.S, &e->S, sizeof(DState)); cg.g0 = g0; cg.n = g1 - g0; cg.key = key | (nl << 8); }
+          if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            rc = issue_chain();
+            const hipError_t ce = hipStreamEndCapture(st, &gr);        // (always ended, also when a launch inside failed)
+            if (!rc && ce != hipSuccess) { mjh_set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce)); rc = MJH_ERR_NO_DEVICE; }
+            if (!rc && hipGraphInstantiate(&cg.exec, gr, nullptr, nullptr, 0) != hipSuccess) { cg.exec = nullptr; (void)hipGetLastError(); }
+            if (gr) (void)hipGraphDestroy(gr);
+            if (!rc && cg.exec) { std::memcpy(cg.S, &e->S, sizeof(DState)); cg.g0 = g0; cg.n = g1 - g0; cg.key = key | (nl << 8); }
+          } else (void)hipGetLastError();                                // (a stream that cannot be captured: plain launches below)
         }
-        if (!rc) HIPCHK(hipGraphLaunch(cg.exec, st));
+        if (!rc) { if (cg.exec) HIPCHK(hipGraphLaunch(cg.exec, st)); else rc = issue_chain(); }
       } else rc = issue_chain();
       if (ta && !rc) HIPCHK(hipEventRecord(tb, st));
     }
