@@ -145,6 +145,22 @@ DEV void wn_jt32(const float* J, const float x, float& a_lo, float& a_hi) {
   a_lo += s_lo + y_lo; a_hi += s_hi + y_hi;
 }
 
+// one hand-over row (window_pgs.h: WN_NK floats, sparse — a contact row touches at most two free bodies) expanded into the dense J^ over the
+// NV dof slots the sweeps use: slot 6 b + j = entry j of the first body's six if b is it, of the second's if b is that one, else 0
+template <int NV> DEV void wn_load_row(const float* p, const bool ok, float* J, float& aref, float& R) {
+  float v[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) v[k] = ok ? p[16 * k] : 0.0f;
+  const int b1 = ok ? __float_as_int(p[16 * 12]) : -1, b2 = ok ? __float_as_int(p[16 * 13]) : -1;
+  aref = ok ? p[16 * 14] : 0.0f; R = ok ? p[16 * 15] : 0.0f;
+#pragma unroll
+  for (int b = 0; 6 * b < NV; b++) {
+    const bool i1 = b == b1, i2 = b == b2;
+#pragma unroll
+    for (int j = 0; j < 6; j++) if (6 * b + j < NV) J[6 * b + j] = i1 ? v[j] : (i2 ? v[6 + j] : 0.0f);
+  }
+}
+
 // launch-order hint of an env (mjh_order_kernel sorts by hint >> 6 into 256 buckets, longest job first): the number of its 16-row windows
 // first, its sweeps second — a wavefront of the 16-row form sweeps max(windows) x max(sweeps) over its four envs, so envs of EQUAL window
 // count belong together (sorted by the product alone, a wave of {3 windows x 100 sweeps, 6 x 50, ...} ran 6 x 100: S24's mean wave ran
@@ -248,7 +264,7 @@ DEV void wn_finish_wide(const DModel& M, const DState& S, float* const wb, const
 
 DEV void wn_run32(const DConst* __restrict__ C, const DState& S, const int env0, const int nenv, const int xflags, const int blk) {
   const DModel& M = C->M;
-  constexpr int NV = 24, NK = NV + 2;
+  constexpr int NV = 24;
   const int lane = threadIdx.x, es = lane >> 5, hq = (lane >> 4) & 1, q = lane & 15;
   const int slot = blk * 2 + es;
   const bool have = slot < nenv;
@@ -272,10 +288,7 @@ DEV void wn_run32(const DConst* __restrict__ C, const DState& S, const int env0,
   for (int w = 0; w < WN32_NW; w++) if (w < nwmax) {
     WnWin32& W = win[w];
     const bool ok = (2 * w + hq) < nwin16;                  // (the assemble launch pads the last 16-row block with zero rows; a missing upper block is all zeros)
-    const float* p = rows + (2 * w + hq) * NK * 16;
-#pragma unroll
-    for (int k = 0; k < NV; k++) W.J[k] = ok ? p[16 * k] : 0.0f;
-    W.aref = ok ? p[16 * NV] : 0.0f; W.R = ok ? p[16 * (NV + 1)] : 0.0f;
+    wn_load_row<NV>(rows + (2 * w + hq) * WN_NK * 16, ok, W.J, W.aref, W.R);
     float acc[16], acx[16], Jx[NV];
 #pragma unroll
     for (int sidx = 0; sidx < 16; sidx++) { acc[sidx] = 0.0f; acx[sidx] = 0.0f; }
@@ -448,7 +461,7 @@ DEV void wn_jt64(const float* J, const float x, float& a_lo, float& a_hi) {
 
 DEV void wn_run64(const DConst* __restrict__ C, const DState& S, const int env0, const int nenv, const int xflags, const int blk, float* const lds64) {
   const DModel& M = C->M;
-  constexpr int NV = 24, NK = NV + 2;
+  constexpr int NV = 24;
   const int lane = threadIdx.x, g = lane >> 4, q = lane & 15;
   const bool have = blk < nenv;
   const int env = have ? (S.env_order ? S.env_order[env0 + blk] : env0 + blk) : 0;
@@ -469,10 +482,7 @@ DEV void wn_run64(const DConst* __restrict__ C, const DState& S, const int env0,
   for (int w = 0; w < WN64_NW; w++) if (w < nwin) {
     WnWin64& W = win[w];
     const bool ok = (4 * w + g) < nwin16;                      // (the assemble launch pads the last 16-row block with zero rows; a missing block is all zeros)
-    const float* p = rows + (4 * w + g) * NK * 16;
-#pragma unroll
-    for (int k = 0; k < NV; k++) W.J[k] = ok ? p[16 * k] : 0.0f;
-    W.aref = ok ? p[16 * NV] : 0.0f; W.R = ok ? p[16 * (NV + 1)] : 0.0f;
+    wn_load_row<NV>(rows + (4 * w + g) * WN_NK * 16, ok, W.J, W.aref, W.R);
     float diag = 0.0f;
 #pragma unroll
     for (int k = 0; k < NV; k++) diag += W.J[k] * W.J[k];
@@ -512,10 +522,7 @@ DEV void wn_run64(const DConst* __restrict__ C, const DState& S, const int env0,
     if (WN64_NW + t < nwin) {
     WnTail& TL = TLS[t];
     const bool ok = (4 * (WN64_NW + t) + g) < nwin16;
-    const float* p = rows + (4 * (WN64_NW + t) + g) * NK * 16;
-#pragma unroll
-    for (int k = 0; k < NV; k++) TL.J[k] = ok ? p[16 * k] : 0.0f;
-    TL.aref = ok ? p[16 * NV] : 0.0f; TL.R = ok ? p[16 * (NV + 1)] : 0.0f;
+    wn_load_row<NV>(rows + (4 * (WN64_NW + t) + g) * WN_NK * 16, ok, TL.J, TL.aref, TL.R);
     float diag = 0.0f;
 #pragma unroll
     for (int k = 0; k < NV; k++) diag += TL.J[k] * TL.J[k];
@@ -646,7 +653,6 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
   const int nwin = (nrow + 15) >> 4;
   const int nwmax = max(max(__builtin_amdgcn_readlane(nwin, 0), __builtin_amdgcn_readlane(nwin, 16)), max(__builtin_amdgcn_readlane(nwin, 32), __builtin_amdgcn_readlane(nwin, 48)));
   const int nv = M.nv;
-  constexpr int NK = NV + 2;
   // dof vectors: lane q of the row carries dof q (lo) and dof 16 + q (hi; the 24-slot instance: dof 16 + (q >> 1), wn_fold8)
   const int dhi = NV == 24 ? 16 + (q >> 1) : 16 + q;
   const bool lo_on = q < nv, hi_on = dhi < nv;
@@ -658,10 +664,7 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
   const float* rows = wb + WN_ROWS + q;
   auto load_rows = [&](WnWin<NV>& W, const int w) __attribute__((always_inline)) {
     const bool ok = w < nwin;
-    const float* p = rows + w * NK * 16;
-#pragma unroll
-    for (int k = 0; k < NV; k++) W.J[k] = ok ? p[16 * k] : 0.0f;
-    W.aref = ok ? p[16 * NV] : 0.0f; W.R = ok ? p[16 * (NV + 1)] : 0.0f;
+    wn_load_row<NV>(rows + w * WN_NK * 16, ok, W.J, W.aref, W.R);
   };
   // tile row of a window: acc_r = J^_q . J^_r for the 16 rows r of the window (every lane of the row at once), then -AR_qr / AR_qq, r < q
   auto make_tile = [&](WnWin<NV>& W) __attribute__((always_inline)) {
@@ -708,7 +711,7 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
     W.nw = u[256]; W.half = u[272];
   };
   float* const xl = wn_lds + (rho * nl * NX) * 16 + q;                               // LDS tier: window NW + j at xl + j * NX * 16
-  float* const xg = wb + WN_ROWS + M.win_maxw * NK * 16 + q;                            // global tier: window w at xg + w * NX * 16
+  float* const xg = wb + WN_ROWS + M.win_maxw * WN_NK * 16 + q;                            // global tier: window w at xg + w * NX * 16
   const int nwl = min(nwmax, NW + nl);
 #pragma unroll
   for (int w = 0; w < NW; w++) if (w < nwmax) { load_rows(win[w], w); make_tile(win[w]); }

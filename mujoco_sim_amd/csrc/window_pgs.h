@@ -27,7 +27,9 @@
 #define WN_SINV 80      // M^-1/2 per dof [32]
 #define WN_QVEL 112     // qvel after the controller [32]
 #define WN_QPOS 144     // qpos after mj_kinematics' quaternion normalisation [40]
-#define WN_ROWS 192     // window w at WN_ROWS + w * NK * 16: [k][16 rows], k < NK = NVT + 2: J^[NVT], aref, R
+#define WN_ROWS 192     // window w at WN_ROWS + w * WN_NK * 16: [k][16 rows], k < WN_NK
+#define WN_NK 16        // floats of a handed-over row: a contact row touches at most two free bodies — J^ over the first one's six dofs [0..5], over the second's [6..11],
+                        // the two body slots (dof address / 6; -1: none) as integers [12], [13], aref [14], R [15]; the window kernel expands it over its dof slots
 #define WN32_MIN_ROWS 96   // rows above which an env is swept in 32-row windows (3.5 % of S24's envs: the ones a cohort's step waits for)
 #define WN_MAXW 24      // most windows per env any model gets (384 rows); a model's own capacity: DModel::win_maxw = min(WN_MAXW, ceil(maxefc / 16))
 #define WN_XREC(nvt) ((nvt) + 21)   // record of a window beyond the register-resident ones, per row: J^[nvt], aref, R, 16 tile entries, -1 / AR_qq, AR_qq / 2, force
@@ -48,7 +50,7 @@
 // like contacts beyond maxcon (the caller raises the capacity flag), instead of handing nothing over.
 DEV int window_emit(float* __restrict__ wb, const int nvt, const int maxw, const int* blki, const float* blkf, const float* J, const float* sinv, const int nblk, const int lane, const bool clamp = false) {
   const int4* blki4 = (const int4*)blki;
-  const int nk = nvt + 2;
+  constexpr int nk = WN_NK; (void)nvt;
   // rows of every block: blocks in chunks of 64 (one per lane), the running row count carried from chunk to chunk
   int total = 0;
   for (int b0 = 0; b0 < nblk; b0 += 64) {
@@ -87,15 +89,14 @@ DEV int window_emit(float* __restrict__ wb, const int nvt, const int maxw, const
         if (g >= nrow) break;
         float* o = wb + WN_ROWS + (g >> 4) * nk * 16 + (g & 15);
         const int kk = 1 + (r >> 1); const float c = (r & 1) ? -1.0f : 1.0f;
-        for (int k = 0; k < nvt; k++) o[16 * k] = 0.0f;
 #pragma unroll
         for (int k = 0; k < 12; k++) {
-          if (k >= 6 && !two) continue;
           const float v = single ? jb[k].x : jb[k].x + c * (kk == 1 ? jb[k].y : (kk == 2 ? jb[k].z : jb[k].w));
-          o[16 * (k < 6 ? a1 + k : a2 + k - 6)] = v * sc[k];
+          o[16 * k] = (k < 6 || two) ? v * sc[k] : 0.0f;
         }
-        o[16 * nvt] = single ? bf[BF_AREF] : bf[BF_AREF] + c * bf[BF_AREF + kk];
-        o[16 * (nvt + 1)] = bf[0];
+        o[16 * 12] = __int_as_float(a1 / 6); o[16 * 13] = __int_as_float(two ? a2 / 6 : -1);
+        o[16 * 14] = single ? bf[BF_AREF] : bf[BF_AREF] + c * bf[BF_AREF + kk];
+        o[16 * 15] = bf[0];
       }
     }
     base += __shfl(incl, 63);
