@@ -166,8 +166,11 @@ static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps,
     const bool cx = extra_instance(e->M) || e->S.xfrc_applied;
     static const bool slim_lds = !(getenv("MJH_WINDOW_SLIM_LDS") && atoi(getenv("MJH_WINDOW_SLIM_LDS")) == 0);
     const size_t wlds = (size_t)((slim_lds && e->lds_bytes_pre > 0) ? e->lds_bytes_pre : e->lds_bytes);
-#define MJH_LAUNCHW(NR, CX) hipLaunchKernelGGL((mjh_step_kernel<NR, true, CX, true>), dim3(n), dim3(64), wlds, st, e->dC, e->S, env0, nsteps, ph, xflags)
-    if (nr == 1) { if (cx) MJH_LAUNCHW(1, true); else MJH_LAUNCHW(1, false); } else { if (cx) MJH_LAUNCHW(2, true); else MJH_LAUNCHW(2, false); }
+    // (models of up to 64 contacts keep the base-row pool in LDS — instance 1 —, larger ones in the env's window slice — instance 2: derive_device_model)
+#define MJH_LAUNCHW(NR, CX, GJ) hipLaunchKernelGGL((mjh_step_kernel<NR, true, CX, GJ>), dim3(n), dim3(64), wlds, st, e->dC, e->S, env0, nsteps, ph, xflags)
+#define MJH_LAUNCHW2(NR, CX) do { if (e->M.patch) MJH_LAUNCHW(NR, CX, 1); else MJH_LAUNCHW(NR, CX, 2); } while (0)
+    if (nr == 1) { if (cx) MJH_LAUNCHW2(1, true); else MJH_LAUNCHW2(1, false); } else { if (cx) MJH_LAUNCHW2(2, true); else MJH_LAUNCHW2(2, false); }
+#undef MJH_LAUNCHW2
 #undef MJH_LAUNCHW
   } else
   if (e->M.diagM) { if (nr == 1) MJH_LAUNCH(1, true); else if (nr == 2) MJH_LAUNCH(2, true); else if (nr == 4) MJH_LAUNCH(4, true); else MJH_LAUNCH(8, true); }
@@ -447,12 +450,12 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       // the dual-block sweep (nv <= 32) reads the pair schedule only; `order` is then just scratch of the schedule builder
       L.order = (nv <= 32 && nblkcap <= k1_size && !keep) ? L.bv : put(nblkcap);
       L.ext = (extsz <= k2_size && !keep) ? k1 : put(extsz);
-      // (window models: the base-row pool comes last, an assemble-only launch keeps it in global memory and allocates the LDS in front of it)
+      // (window models beyond 64 contacts: the base-row pool comes last, their assemble-only launch keeps it in global memory and allocates the LDS in front of it)
       hp.lds_bytes_pre = off * (int)sizeof(float);
       L.J = put((int)jsz); L.B = diagM ? L.J : put((int)jsz);
     }
     M.win_jsz = (int)jsz;
-    if (!(M.window && !big)) hp.lds_bytes_pre = off * (int)sizeof(float);    // everything but the patch pool's own tail: what an assemble-only launch (window chain) touches
+    if (!(M.window && !big && !patch)) hp.lds_bytes_pre = off * (int)sizeof(float);    // everything but the patch pool's own tail: what an assemble-only launch (window chain) touches
     if (patch) {
       // the pool: per patch of nr4 rows (a multiple of 4, at most 16) a record per row (20 floats between two bodies, 12 on one
       // body) + 16 floats per 4x4 tile of the lower triangle of AR: 16 .. 30 floats per row.  It takes the span of everything that
@@ -599,10 +602,10 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   MJH_ATTR(1, true); MJH_ATTR(2, true); MJH_ATTR(4, true); MJH_ATTR(8, true); MJH_ATTR(1, false); MJH_ATTR(2, false); MJH_ATTR(4, false); MJH_ATTR(8, false);
 #undef MJH_ATTR
   if (e->M.window) {
-    HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<1, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
-    HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<1, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
-    HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<2, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
-    HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<2, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+#define MJH_ATTRW(NR, CX, GJ) HIPCHK(hipFuncSetAttribute((const void*)mjh_step_kernel<NR, true, CX, GJ>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes))
+    MJH_ATTRW(1, false, 1); MJH_ATTRW(1, true, 1); MJH_ATTRW(2, false, 1); MJH_ATTRW(2, true, 1);
+    MJH_ATTRW(1, false, 2); MJH_ATTRW(1, true, 2); MJH_ATTRW(2, false, 2); MJH_ATTRW(2, true, 2);
+#undef MJH_ATTRW
   }
 
   // ---- per-env state

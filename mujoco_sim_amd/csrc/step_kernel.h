@@ -898,7 +898,9 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
 #include "patch_pgs.h"
 #include "window_pgs.h"
 
-template <int NROW, bool DIAGM, bool EXTRA, bool WPRE = false>
+// WPRE: 0 the whole kernel; assemble-only instances of the window chain (no sweep code): 1 with the base-row pool in LDS, 2 with the pool in the
+// env's window slice (models beyond 64 contacts: the pool is what decides how many envs a CU holds)
+template <int NROW, bool DIAGM, bool EXTRA, int WPRE = 0>
 #ifndef MJH_STEP_WAVES
 // resident waves per SIMD the register allocation aims at: two for the instances that keep sweep records in registers (free-body
 // patch sweep) or long dense stages (many-body chain), three for the small articulated models (C3, C5: latency-bound, every extra
@@ -945,12 +947,10 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
   const bool short_rows = level_solves && M.ntree <= 4;
   // M after the factorisation: articulated models in the many-body layout keep only the factor in LDS (it is built in M's place)
   const float* qM_ro = (NROW == 8 && !DIAGM) ? gs + L.g_qM : s_qM;
-  // assemble-only launches of the window chain: the base-row pool (and the raw-contact staging that aliases it) — the largest array by far,
+  // assemble-only launches of the window chain of models beyond 64 contacts: the base-row pool (and the raw-contact staging that aliases it) — the largest array by far,
   // 192 B per contact — lives in the env's slice of the window buffer (global memory, L2-resident) instead of LDS: the launch is bound by
   // the latency of one wave per env, and its LDS sets how many envs a CU holds (S24D at 96 contacts: 44 KB -> 25 KB, 3 -> 6 per CU)
-#ifndef MJH_WPRE_LDS_J       // (A/B builds: the pool back in LDS; the launch then needs the whole layout: MJH_WINDOW_SLIM_LDS=0)
-  if constexpr (WPRE) { s_J = S.wbuf + (size_t)env * (size_t)S.wstride + S.wj_off; s_B = s_J; }
-#endif
+  if constexpr (WPRE == 2) { s_J = S.wbuf + (size_t)env * (size_t)S.wstride + S.wj_off; s_B = s_J; }
   float* s_stage = s_J;  // raw-contact staging aliases the (not yet built) base-row storage
   const int rowW = M.rowW;
 

@@ -18,7 +18,7 @@
 #define ONE_EXTRA false
 #endif
 #ifndef ONE_WPRE
-#define ONE_WPRE false
+#define ONE_WPRE 0
 #endif
 template __global__ void mjh_step_kernel<ONE_NROW, ONE_DIAGM, ONE_EXTRA, ONE_WPRE>(const DConst*, const DState, int, int, int, int);
 #ifdef ONE_NW
