@@ -330,3 +330,25 @@ def test_launch_chain_as_a_captured_graph_equals_the_separate_launches(config):
     for x, y in zip(sa, sb):
         assert np.array_equal(x, y)
     assert np.array_equal(sta, stb) and sta[:, 0].mean() > 4
+
+
+def test_s24d_results_do_not_depend_on_cohorts_launch_order_or_batch_size():
+    """every env's arithmetic stays inside its own lanes in all three window forms (16-row: a 16-lane row of a four-env wavefront; 32-row: half
+    a wavefront; 64-row: a wavefront of its own, tiles of the last windows in that workgroup's LDS), and the form is a function of the env's
+    own row count: S24D (all three forms, tiers, up to ~280 rows) gives the same bits on 1 / 3 / 2 cohorts (the launch order — window count
+    first, sweeps second — is sorted per cohort: which envs share a wavefront changes with them), another batch size and other call lengths"""
+    outs = []
+    for nenv, nc, chunk in ((1280, 1, 430), (1280, 3, 7), (1283, 2, 43)):
+        m, e, tab = _s24d_seeds(list(range(nenv)))
+        e.set_cohorts(nc)
+        for _ in range(0, 430, chunk):
+            e.step(min(chunk, 430 - _))
+        t, q, v, w = e.get_state(); st = e.get_stats()
+        outs.append((q[:1280], v[:1280], w[:1280], st[:1280, :3]))
+        assert (st[:, 3] & 7 == 0).all()
+        e.close()
+    rows = outs[0][3][:, 1]
+    assert (rows > 208).sum() >= 10 and ((rows > 96) & (rows <= 128)).sum() >= 50 and (rows <= 96).sum() >= 20, "all three forms present"
+    for k in (1, 2):
+        for x, y in zip(outs[0], outs[k]):
+            assert np.array_equal(x, y)
