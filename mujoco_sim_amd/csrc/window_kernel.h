@@ -626,6 +626,36 @@ template <int NV> DEV void wn_jt2(const float* JA, const float xa, const float* 
 #define WN_CROSS4A(r0, r1, r2, r3, T) asm volatile(WN_XFMA(r0, "%[a0]") WN_XFMA(r1, "%[a1]") WN_XFMA(r2, "%[a2]") WN_XFMA(r3, "%[a3]") \
     : [t] "+v"(tt) : [x] "v"(dx), [a0] "v"(T.x), [a1] "v"(T.y), [a2] "v"(T.z), [a3] "v"(T.w))
 
+// ---- the row chain with its wait states put to work (16-row form, register-resident window pairs).  `v_max -> v_fmac ... row_newbcast` needs
+// two wait states between the VALU write and the DPP read; as `s_nop 1` that is a third issue slot per row (11.5 of 27.5 clocks) in which
+// nothing happens — 32 per window pair.  This kernel's wavefront is ALONE on its SIMD (425 registers), and a lone wave issues one
+// instruction per 8 clocks (profiles/r02m_valu_issue_bench.txt: every instruction kind, never less): ONE independent VALU instruction
+// between the two puts 16 clocks between their issues — more than the 12 the two wait states stand for (no instruction between them: 8 clocks,
+// measurably too few — HISTORY.md Round 4 "the row chain without its two wait states").  Independent work exists in a PAIR of windows:
+// window 2j's chain carries the first 16 multiply-adds of window 2j+1's dot u = J^ a^ (both dots start from the same a^), window 2j+1's
+// chain carries window 2j's products J^ delta (12 packed multiplies) and the float part of its cost decrease (4).  Same instructions, same
+// operands, same order of every sum: bitwise the chain with the nops (state hash against a -DWN_FILL=0 build).  Kept to this kernel.
+#ifndef WN_FILL
+#define WN_FILL 1
+#endif
+#define WN_ROWF(r, ar, fill) "v_max_f32 %[d], %[t], %[nf]\n\t" fill "\n\tv_fmac_f32_dpp %[t], %[d], " ar " row_newbcast:" #r " row_mask:0xf bank_mask:0xf\n\t"
+#define WN_FDOT(r, jb) "v_fmac_f32_dpp %[ub], %[al], " jb " row_newbcast:" #r " row_mask:0xf bank_mask:0xf"
+// window A's rows r0 .. r0 + 3 (tile entries a0 .. a3), filler: window B's dot over dofs r0 .. r0 + 3 (b0 .. b3 = B.J[r0 ..])
+#define WN_ROWS4_FA(r0, r1, r2, r3, T, b0_, b1_, b2_, b3_) asm volatile( \
+    WN_ROWF(r0, "%[a0]", WN_FDOT(r0, "%[b0]")) WN_ROWF(r1, "%[a1]", WN_FDOT(r1, "%[b1]")) WN_ROWF(r2, "%[a2]", WN_FDOT(r2, "%[b2]")) WN_ROWF(r3, "%[a3]", WN_FDOT(r3, "%[b3]")) \
+    : [t] "+v"(tt), [d] "=&v"(dl), [ub] "+v"(ub0) : [nf] "v"(nf), [a0] "v"(T.x), [a1] "v"(T.y), [a2] "v"(T.z), [a3] "v"(T.w), [al] "v"(a_lo), [b0] "v"(b0_), [b1] "v"(b1_), [b2] "v"(b2_), [b3] "v"(b3_))
+// window B's rows, filler: window A's products p_k = J^_A[2k .. 2k + 1] * delta_A (packed)
+#define WN_FPK(pk, ja) "v_pk_mul_f32 " pk ", " ja ", %[x2]"
+#define WN_ROWS4_FB(r0, r1, r2, r3, T, p0_, p1_, p2_, p3_, j0_, j1_, j2_, j3_) asm volatile( \
+    WN_ROWF(r0, "%[a0]", WN_FPK("%[p0]", "%[j0]")) WN_ROWF(r1, "%[a1]", WN_FPK("%[p1]", "%[j1]")) WN_ROWF(r2, "%[a2]", WN_FPK("%[p2]", "%[j2]")) WN_ROWF(r3, "%[a3]", WN_FPK("%[p3]", "%[j3]")) \
+    : [t] "+v"(tt), [d] "=&v"(dl), [p0] "=&v"(p0_), [p1] "=&v"(p1_), [p2] "=&v"(p2_), [p3] "=&v"(p3_) \
+    : [nf] "v"(nf), [a0] "v"(T.x), [a1] "v"(T.y), [a2] "v"(T.z), [a3] "v"(T.w), [x2] "v"(xa2), [j0] "v"(j0_), [j1] "v"(j1_), [j2] "v"(j2_), [j3] "v"(j3_))
+// ... and the float part of A's cost decrease: e = ((half_A delta_A) (2 t_A - delta_A)) qs
+#define WN_ROWS4_FC(r0, r1, r2, r3, T) asm volatile( \
+    WN_ROWF(r0, "%[a0]", "v_mul_f32 %[e1], %[hf], %[da]") WN_ROWF(r1, "%[a1]", "v_fma_f32 %[e2], 2.0, %[ta], -%[da]") WN_ROWF(r2, "%[a2]", "v_mul_f32 %[e1], %[e1], %[e2]") WN_ROWF(r3, "%[a3]", "v_mul_f32 %[e1], %[e1], %[qs]") \
+    : [t] "+v"(tt), [d] "=&v"(dl), [e1] "=&v"(e1), [e2] "=&v"(e2) \
+    : [nf] "v"(nf), [a0] "v"(T.x), [a1] "v"(T.y), [a2] "v"(T.z), [a3] "v"(T.w), [hf] "v"(A.half), [da] "v"(dla), [ta] "v"(tta), [qs] "v"(iq.qs))
+
 template <int NV, int NW>
 __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restrict__ C, const DState S, const int env0, const int nenv, const int nl, const int xflags, const int n32waves, const int n64waves) {
   // the first n64waves wavefronts: the section of the envs with the most rows (one per wavefront, 64-row windows); the next n32waves: the
@@ -796,6 +826,58 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
       for (int j = 0; j < NW / 2; j++) if (2 * j < nwmax) {
         if (2 * j + 1 < nwmax) {
           WnWin<NV>& A = win[2 * j]; WnWin<NV>& B = win[2 * j + 1];
+          if constexpr (NV == 24 && WN_FILL) {
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const float ua = wn_dot<NV>(A.J, a_lo, a_hi);
+            float ub1;                                   // window B's dot over dofs 16 .. 23 (a_hi: lane 2j carries dof 16 + j)
+            asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                         WN_FM("%0", "%1", "%3", 2) WN_FM("%0", "%1", "%4", 4) WN_FM("%0", "%1", "%5", 6) WN_FM("%0", "%1", "%6", 8) WN_FM("%0", "%1", "%7", 10)
+                         WN_FM("%0", "%1", "%8", 12) WN_FM("%0", "%1", "%9", 14)
+                         : "=&v"(ub1) : "v"(a_hi), "v"(B.J[16]), "v"(B.J[17]), "v"(B.J[18]), "v"(B.J[19]), "v"(B.J[20]), "v"(B.J[21]), "v"(B.J[22]), "v"(B.J[23]));
+            const float foa = f[2 * j], fob = f[2 * j + 1];
+            float tta, dla, dlb, ub0;
+            {
+              float tt = ((ua - A.aref) + A.R * foa) * A.nw;
+              const float nf = -foa;
+              float dl;
+              // (row 0's filler opens window B's dot: a product, not a multiply-add)
+              asm volatile(WN_ROWF(0, "%[a0]", "v_mul_f32_dpp %[ub], %[al], %[b0] row_newbcast:0 row_mask:0xf bank_mask:0xf") WN_ROWF(1, "%[a1]", WN_FDOT(1, "%[b1]")) WN_ROWF(2, "%[a2]", WN_FDOT(2, "%[b2]")) WN_ROWF(3, "%[a3]", WN_FDOT(3, "%[b3]"))
+                           : [t] "+v"(tt), [d] "=&v"(dl), [ub] "=&v"(ub0) : [nf] "v"(nf), [a0] "v"(A.A0.x), [a1] "v"(A.A0.y), [a2] "v"(A.A0.z), [a3] "v"(A.A0.w), [al] "v"(a_lo), [b0] "v"(B.J[0]), [b1] "v"(B.J[1]), [b2] "v"(B.J[2]), [b3] "v"(B.J[3]));
+              WN_ROWS4_FA(4, 5, 6, 7, A.A1, B.J[4], B.J[5], B.J[6], B.J[7]); WN_ROWS4_FA(8, 9, 10, 11, A.A2, B.J[8], B.J[9], B.J[10], B.J[11]); WN_ROWS4_FA(12, 13, 14, 15, A.A3, B.J[12], B.J[13], B.J[14], B.J[15]);
+              asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));
+              f[2 * j] = foa + dl; dla = dl; tta = tt;
+            }
+            v2f p[NV / 2];
+            float e1, e2;
+            {
+              const float ub = ub0 + ub1;
+              float tt = ((ub - B.aref) + B.R * fob) * B.nw;
+              float dx = dla;
+              asm volatile("s_nop 1" : "+v"(dx));
+              WN_CROSS4A(0, 1, 2, 3, X[j][0]); WN_CROSS4A(4, 5, 6, 7, X[j][1]); WN_CROSS4A(8, 9, 10, 11, X[j][2]); WN_CROSS4A(12, 13, 14, 15, X[j][3]);
+              const float nf = -fob;
+              float dl;
+              const v2f xa2 = {dla, dla};
+#define WN_J2(W, k) v2f{W.J[2 * (k)], W.J[2 * (k) + 1]}
+              WN_ROWS4_FB(0, 1, 2, 3, B.A0, p[0], p[1], p[2], p[3], WN_J2(A, 0), WN_J2(A, 1), WN_J2(A, 2), WN_J2(A, 3));
+              WN_ROWS4_FB(4, 5, 6, 7, B.A1, p[4], p[5], p[6], p[7], WN_J2(A, 4), WN_J2(A, 5), WN_J2(A, 6), WN_J2(A, 7));
+              WN_ROWS4_FB(8, 9, 10, 11, B.A2, p[8], p[9], p[10], p[11], WN_J2(A, 8), WN_J2(A, 9), WN_J2(A, 10), WN_J2(A, 11));
+              WN_ROWS4_FC(12, 13, 14, 15, B.A3);
+              asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));
+              impl += (int)__builtin_amdgcn_fmed3f(e1, -(float)(2 << MJH_IMP_BITS), (float)(2 << MJH_IMP_BITS));
+              impl += imp_fixed((B.half * dl) * (2.0f * tt - dl), iq.qs);
+              f[2 * j + 1] = fob + dl; dlb = dl;
+            }
+            {   // a^ += J_A^T delta_A + J_B^T delta_B: A's products are there, B's join them, one transpose-reduce (wn_jt2)
+              const v2f xb2 = {dlb, dlb};
+              float pp[NV];
+#pragma unroll
+              for (int k = 0; k < NV / 2; k++) { const v2f pr = __builtin_elementwise_fma(WN_J2(B, k), xb2, p[k]); pp[2 * k] = pr.x; pp[2 * k + 1] = pr.y; }
+#undef WN_J2
+              a_lo += wn_fold16(pp);
+              a_hi += wn_fold8(pp + 16);
+            }
+          } else {
           const float ua = wn_dot<NV>(A.J, a_lo, a_hi), ub = wn_dot<NV>(B.J, a_lo, a_hi);
           float dla, dlb;
           {
@@ -822,6 +904,7 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
             f[2 * j + 1] = fo + dl; dlb = dl;
           }
           wn_jt2<NV>(A.J, dla, B.J, dlb, a_lo, a_hi);
+          }
         } else { WnWin<NV>& W = win[2 * j]; WN_SWEEP_ONE(W, f[2 * j]); }
       }
       // the tiers beyond them: one window at a time
