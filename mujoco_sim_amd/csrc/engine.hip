@@ -624,7 +624,10 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   if (M.big) rc |= dev_alloc(e, &S.gscratch, (size_t)nenv * (size_t)hp.gstride, false);   // many-body models: contact / block / Jacobian pools
   S.wbuf = nullptr; S.wstride = 0;
   S.win32 = getenv("MJH_WINDOW32") ? std::max(0, atoi(getenv("MJH_WINDOW32"))) : WN32_MIN_ROWS;     // (0: off; experiments: another row threshold)
-  S.win64 = getenv("MJH_WINDOW64") ? std::max(0, atoi(getenv("MJH_WINDOW64"))) : WN64_MIN_ROWS;   // (0: off)
+  // 64-row form above ... rows: models whose envs stay within 256 rows (S24: 9 % of the envs beyond 96 rows) give it every env beyond the 16-row
+  // form's register-resident windows — 2 x 64 rows with the chains' wait states filled beat 4 x 32 (S24 12.3 -> 13.3 M); models with more rows
+  // (S24D: 30 % of the envs between 97 and 128 rows, 60 % beyond) only the envs a cohort's step waits for (176 / 192 / 208 rows: 4.65 / 4.97 / 5.26 M)
+  S.win64 = getenv("MJH_WINDOW64") ? std::max(0, atoi(getenv("MJH_WINDOW64"))) : (M.win_maxw > 16 ? WN64_MIN_ROWS : WN32_MIN_ROWS);   // (0: off)
   if (S.win64 > 0 && S.win64 < S.win32) S.win64 = S.win32;
   if (getenv("MJH_WN_NL") && atoi(getenv("MJH_WN_NL")) < 3) S.win64 = 0;      // (experiments that take the LDS tier away: the 64-row section keeps two 16 KB tiles there)
   if (M.window) {   // window sweep: header + vectors + win_maxw windows of rows + tiles of the streamed windows, per env

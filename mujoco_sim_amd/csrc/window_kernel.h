@@ -457,7 +457,57 @@ DEV void wn_jt64(const float* J, const float x, float& a_lo, float& a_hi) {
     impl += imp_fixed((W.half * dl) * (2.0f * tt - dl), iq.qs); \
     fw = fo + dl; \
     wn_jt64(W.J, dl, a_lo, a_hi); } while (0)
+// The same sweep with the chains' wait states put to work (register-resident windows; see WN_FILL below: one independent VALU instruction between
+// v_max and the DPP read is enough for a wavefront that is alone on its SIMD).  A finished row's deltas are applied to the NEXT row at once (it
+// needs them before its chain starts) and to the rows behind that one inside the next row's chain, one multiply-add per wait slot: rows 1 and 2
+// of the wavefront run without nops; every lane still receives the rows' contributions in the same order (bitwise the sweep above).
+#define WN64_RF(r, ar, cr, m, mc) "v_max_f32 %[d], %[t], %[nf]\n\tv_fmac_f32_dpp %[t], %[xp], " cr " row_newbcast:" #r " row_mask:" #mc " bank_mask:0xf\n\t" \
+                                  "v_fmac_f32_dpp %[t], %[d], " ar " row_newbcast:" #r " row_mask:" #m " bank_mask:0xf\n\t"
+#define WN64_R4F(r0, r1, r2, r3, a0_, a1_, a2_, a3_, c0_, c1_, c2_, c3_, m, mc, xp_) asm volatile( \
+    WN64_RF(r0, "%[a0]", "%[c0]", m, mc) WN64_RF(r1, "%[a1]", "%[c1]", m, mc) WN64_RF(r2, "%[a2]", "%[c2]", m, mc) WN64_RF(r3, "%[a3]", "%[c3]", m, mc) \
+    : [t] "+v"(tt), [d] "=&v"(dl) : [nf] "v"(nf), [xp] "v"(xp_), [a0] "v"(a0_), [a1] "v"(a1_), [a2] "v"(a2_), [a3] "v"(a3_), [c0] "v"(c0_), [c1] "v"(c1_), [c2] "v"(c2_), [c3] "v"(c3_))
+#define WN64_CHAIN16F(A, b, m, bc, mc, xp_) do { \
+    WN64_R4F(0, 1, 2, 3, A[b], A[b + 1], A[b + 2], A[b + 3], A[bc], A[bc + 1], A[bc + 2], A[bc + 3], m, mc, xp_); \
+    WN64_R4F(4, 5, 6, 7, A[b + 4], A[b + 5], A[b + 6], A[b + 7], A[bc + 4], A[bc + 5], A[bc + 6], A[bc + 7], m, mc, xp_); \
+    WN64_R4F(8, 9, 10, 11, A[b + 8], A[b + 9], A[b + 10], A[b + 11], A[bc + 8], A[bc + 9], A[bc + 10], A[bc + 11], m, mc, xp_); \
+    WN64_R4F(12, 13, 14, 15, A[b + 12], A[b + 13], A[b + 14], A[b + 15], A[bc + 12], A[bc + 13], A[bc + 14], A[bc + 15], m, mc, xp_); \
+    asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf)); } while (0)
+#define WN64_SWEEP_F(W, fw) do { \
+    const float u = wn_dot<NV>(W.J, a_lo, a_hi); \
+    const float fo = fw; \
+    float tt = ((u - W.aref) + W.R * fo) * W.nw; \
+    const float nf = -fo; \
+    float dl, dx, dy, dx0, dx1; \
+    WN64_CHAIN16(W.A, 0, 0x1); \
+    dx = dl; dy = dl; \
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(dx), "+v"(dy));        /* dx = (d0, d0, ., .) */ \
+    dy = dx; \
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(dx), "+v"(dy));        /* dx = (d0, d0, d0, d0) */ \
+    dx0 = dx; \
+    WN64_CROSS16(W.A, 0, 0x2);                                  /* row 0's deltas -> row 1 (now) */ \
+    WN64_CHAIN16F(W.A, 16, 0x2, 0, 0xc, dx0);                   /* row 1's chain; in its wait slots: row 0's deltas -> rows 2, 3 */ \
+    dx = dl; dy = dl; \
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(dx), "+v"(dy));        /* dy = (d1, d1, ., .) */ \
+    dx = dy; \
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(dy), "+v"(dx));        /* dy = (d1, d1, d1, d1) */ \
+    dx = dy; dx1 = dy; \
+    WN64_CROSS16(W.A, 16, 0x4);                                 /* row 1's deltas -> row 2 (now) */ \
+    WN64_CHAIN16F(W.A, 32, 0x4, 16, 0x8, dx1);                  /* row 2's chain; in its wait slots: row 1's deltas -> row 3 */ \
+    dx = dl; dy = dl; \
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(dx), "+v"(dy));        /* dx = (., ., d2, d2) */ \
+    WN64_CROSS16(W.A, 32, 0x8); \
+    WN64_CHAIN16(W.A, 48, 0x8); \
+    impl += imp_fixed((W.half * dl) * (2.0f * tt - dl), iq.qs); \
+    fw = fo + dl; \
+    wn_jt64(W.J, dl, a_lo, a_hi); } while (0)
+#ifndef WN_FILL64
+#define WN_FILL64 1
+#endif
+#if WN_FILL64
+#define WN64_SWEEP(W, fw) WN64_SWEEP_F(W, fw)
+#else
 #define WN64_SWEEP(W, fw) WN64_SWEEP_X(W, fw, W.A, 0, 16, 32, 48, (void)0, (void)0, (void)0, (void)0)
+#endif
 
 DEV void wn_run64(const DConst* __restrict__ C, const DState& S, const int env0, const int nenv, const int xflags, const int blk, float* const lds64) {
   const DModel& M = C->M;

@@ -352,3 +352,51 @@ def test_s24d_results_do_not_depend_on_cohorts_launch_order_or_batch_size():
     for k in (1, 2):
         for x, y in zip(outs[0], outs[k]):
             assert np.array_equal(x, y)
+
+
+def test_s24_64_row_windows_for_the_envs_beyond_96_rows_equal_the_16_row_form_up_to_rounding(monkeypatch):
+    """S24's default since round 5: envs with more than 96 rows (9 % — the ones a cohort's step waits for) are swept in 64-row windows, one env
+    per wavefront, both windows register-resident, the chains' wait states filled.  Against the same engine with both wide sections off
+    (every env in the 16-row form): the others bitwise equal, the 64-row envs equal to fp32 rounding with the same sweep counts; and
+    against the oracle one step from the device's state."""
+    from test_gpu_teacher_forced import S24_TOL_Q, S24_TOL_V
+    m = ms.scene("s24")
+    nenv = 2048
+    a = ms.Engine(m, nenv); tab = a.load_s24()
+    monkeypatch.setenv("MJH_WINDOW64", "0"); monkeypatch.setenv("MJH_WINDOW32", "0")
+    b = ms.Engine(m, nenv); b.load_s24()
+    monkeypatch.delenv("MJH_WINDOW64"); monkeypatch.delenv("MJH_WINDOW32")
+    a.step(300); a.synchronize()
+    heavy_seen = 0; worst_q = worst_v = 0.0; same_it = []
+    for k in range(40):
+        t, q, v, w = a.get_state()
+        b.set_state(qpos=q, qvel=v, time=t, warmstart=w)
+        a.step(1); b.step(1)
+        _, qa, va, _ = a.get_state(); _, qb, vb, _ = b.get_state()
+        sa, sb = a.get_stats(), b.get_stats()
+        assert np.array_equal(sa[:, :2], sb[:, :2])
+        heavy = sa[:, 1] > 96
+        assert np.array_equal(qa[~heavy], qb[~heavy]) and np.array_equal(va[~heavy], vb[~heavy]) and np.array_equal(sa[~heavy, 2], sb[~heavy, 2])
+        if heavy.any():
+            heavy_seen += int(heavy.sum())
+            worst_q = max(worst_q, float((np.abs(qa[heavy] - qb[heavy]).max(1) / np.maximum(1, np.abs(qb[heavy]).max(1))).max()))
+            worst_v = max(worst_v, float((np.abs(va[heavy] - vb[heavy]).max(1) / np.maximum(1, np.abs(vb[heavy]).max(1))).max()))
+            same_it.append(float((sa[heavy, 2] == sb[heavy, 2]).mean()))
+    print(f"S24-WINDOW64: {heavy_seen} env-steps in 64-row windows of {40 * nenv}: qpos {worst_q:.2e} qvel {worst_v:.2e} against the 16-row form, same sweep count {np.mean(same_it):.3f}")
+    assert heavy_seen >= 400 and worst_q <= S24_TOL_Q and worst_v <= S24_TOL_V and np.mean(same_it) >= 0.9
+    t, q, v, w = a.get_state()
+    a.step(1); _, q1, v1, _ = a.get_state(); st = a.get_stats()
+    heavy = np.nonzero(st[:, 1] > 96)[0][:24]
+    assert len(heavy) >= 8
+    checked = 0
+    for i in heavy:
+        d = oracle_s24(m, tab, int(i))
+        d.f("qpos")[:] = q[i]; d.f("qvel")[:] = v[i]; d.f("qacc_warmstart")[:] = w[i]; d.f("qacc")[:] = w[i]; d.f("time")[0] = t[i]
+        d.step(1)
+        if d.i("ncon") != st[i, 0] or d.i("nefc") != st[i, 1]:
+            continue
+        checked += 1
+        assert np.abs(q1[i] - d.f("qpos")).max() / max(1, np.abs(d.f("qpos")).max()) <= S24_TOL_Q
+        assert np.abs(v1[i] - d.f("qvel")).max() / max(1, np.abs(d.f("qvel")).max()) <= S24_TOL_V
+    assert checked >= 6
+    a.close(); b.close()
