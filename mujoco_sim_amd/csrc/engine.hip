@@ -631,7 +631,7 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   if (S.win64 > 0 && S.win64 < S.win32) S.win64 = S.win32;
   if (getenv("MJH_WN_NL") && atoi(getenv("MJH_WN_NL")) < 3) S.win64 = 0;      // (experiments that take the LDS tier away: the 64-row section keeps two 16 KB tiles there)
   if (M.window) {   // window sweep: header + vectors + win_maxw windows of rows + tiles of the streamed windows, per env
-    S.wj_off = ((WN_ROWS + M.win_maxw * WN_NK * 16 + M.win_maxw * WN_XREC(M.win_nvt) * 16 + 63) / 64) * 64;
+    S.wj_off = ((WN_ROWS + M.win_maxw * WN_NK * 16 + M.win_maxw * WN_XREC(M.win_nvt) * 16 + (M.win_maxw / 2 + 1) * WN_XPAIR * 16 + 63) / 64) * 64;
     S.wstride = S.wj_off + ((M.win_jsz + 63) / 64) * 64;
     if (((S.wstride / 64) & 1) == 0) S.wstride += 64;      // an odd number of 256-byte lines per env: the same offset of consecutive envs' slices does not fall on the same memory channel
     rc |= dev_alloc(e, &S.wbuf, (size_t)nenv * (size_t)S.wstride, true);

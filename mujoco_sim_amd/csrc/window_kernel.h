@@ -5,7 +5,7 @@
 #include "step_kernel.h"
 
 #ifdef WN_PROF_CLK
-#define WN_STAT0(x) cost_hint       // (probe build: the wave's clocks where the contact count goes)
+#define WN_STAT0(x) min((int)(((long long)__builtin_amdgcn_s_memtime() - wn_t0) >> 5) + 1, (1 << 22) - 1)       // (probe build: the wave's clocks where the contact count goes; the launch order keeps its own hint)
 #else
 #define WN_STAT0(x) (x)
 #endif
@@ -252,11 +252,7 @@ DEV void wn_finish_wide(const DModel& M, const DState& S, float* const wb, const
   }
   if (dl_lane && q == 0) {
     S.time[env] += M.timestep_d;
-#ifdef WN_PROF_CLK
-    const int cost_hint = min((int)(((long long)__builtin_amdgcn_s_memtime() - wn_t0) >> 5) + 1, (1 << 22) - 1);   // (probe build: the wave's own clocks in the hint field)
-#else
     const int cost_hint = wn_cost_hint(M, nwin16, niter);
-#endif
     S.stats[4 * env] = WN_STAT0(wh[1]); S.stats[4 * env + 1] = wh[2]; S.stats[4 * env + 2] = niter;
     S.stats[4 * env + 3] = ((S.stats[4 * env + 3] | flags) & 0xff) | (cost_hint << 8);
   }
@@ -387,7 +383,7 @@ DEV void wn_run32(const DConst* __restrict__ C, const DState& S, const int env0,
 // v_permlane32_swap, the same sum in the same order in every lane.  WN64_NW windows (192 rows) register-resident, WN64_NT more (320 rows) with their tiles in LDS.  The form is a
 // function of the env's own row count (set by the assemble launch); same rows, same order, same row math and stopping rule as the
 // other forms, another grouping of the arithmetic (fp32 rounding).
-extern __shared__ float wn_lds[];
+extern __shared__ __attribute__((aligned(16))) float wn_lds[];
 DEV float* wn_lds_base() { return wn_lds; }
 struct WnWin64 { float J[24]; float A[64]; float aref, R, nw, half; };
 
@@ -768,30 +764,31 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
     W.A2 = make_float4(8 < q ? ninv * acc[8] : 0.0f, 9 < q ? ninv * acc[9] : 0.0f, 10 < q ? ninv * acc[10] : 0.0f, 11 < q ? ninv * acc[11] : 0.0f);
     W.A3 = make_float4(12 < q ? ninv * acc[12] : 0.0f, 13 < q ? ninv * acc[13] : 0.0f, 14 < q ? ninv * acc[14] : 0.0f, 0.0f);
   };
-  // windows beyond the register-resident ones: the whole record (J^, aref, R, tile row, -1 / AR_qq, AR_qq / 2, force) [NX][16] — the
+  // windows beyond the register-resident ones: the whole record — the
   // next NL windows of every env in LDS (the kernel has no other use for it: 40 KB per wave at four waves per CU), the rest in the env's
   // slice of global memory (read every sweep: slow, and rare — S24D's 140-row piles reach the LDS tier only)
-  constexpr int NX = NV + 21;
-  auto store_ext = [&](float* t, const WnWin<NV>& W, const float fw) __attribute__((always_inline)) {
+  // record of such a window, float4 [NX4][16 lanes]: J^ (NV / 4), the tile row (4), {aref, R, -1 / AR_qq, AR_qq / 2}, {force, -, -, -} — read
+  // with NX4 - 1 sixteen-byte loads and one four-byte load per sweep (45 four-byte loads of the [k][16] layout cost the lone wave 33 more
+  // issue slots per window and sweep)
+  constexpr int NX4 = WN_XREC(NV) / 4, NJ4 = NV / 4;
+  static_assert(NV % 4 == 0 && NX4 == NJ4 + 6, "window record layout");
+  auto store_ext = [&](float4* t, const WnWin<NV>& W, const float fw) __attribute__((always_inline)) {
 #pragma unroll
-    for (int k = 0; k < NV; k++) t[16 * k] = W.J[k];
-    t[16 * NV] = W.aref; t[16 * (NV + 1)] = W.R;
-    float* u = t + 16 * (NV + 2);
-    u[0] = W.A0.x; u[16] = W.A0.y; u[32] = W.A0.z; u[48] = W.A0.w; u[64] = W.A1.x; u[80] = W.A1.y; u[96] = W.A1.z; u[112] = W.A1.w;
-    u[128] = W.A2.x; u[144] = W.A2.y; u[160] = W.A2.z; u[176] = W.A2.w; u[192] = W.A3.x; u[208] = W.A3.y; u[224] = W.A3.z; u[240] = W.A3.w;
-    u[256] = W.nw; u[272] = W.half; u[288] = fw;
+    for (int k = 0; k < NJ4; k++) t[16 * k] = make_float4(W.J[4 * k], W.J[4 * k + 1], W.J[4 * k + 2], W.J[4 * k + 3]);
+    t[16 * NJ4] = W.A0; t[16 * (NJ4 + 1)] = W.A1; t[16 * (NJ4 + 2)] = W.A2; t[16 * (NJ4 + 3)] = W.A3;
+    t[16 * (NJ4 + 4)] = make_float4(W.aref, W.R, W.nw, W.half);
+    *(float*)(t + 16 * (NJ4 + 5)) = fw;
   };
-  auto load_ext = [&](const float* t, WnWin<NV>& W) __attribute__((always_inline)) {
+  auto load_ext = [&](const float4* t, WnWin<NV>& W) __attribute__((always_inline)) {
 #pragma unroll
-    for (int k = 0; k < NV; k++) W.J[k] = t[16 * k];
-    W.aref = t[16 * NV]; W.R = t[16 * (NV + 1)];
-    const float* u = t + 16 * (NV + 2);
-    W.A0 = make_float4(u[0], u[16], u[32], u[48]); W.A1 = make_float4(u[64], u[80], u[96], u[112]);
-    W.A2 = make_float4(u[128], u[144], u[160], u[176]); W.A3 = make_float4(u[192], u[208], u[224], u[240]);
-    W.nw = u[256]; W.half = u[272];
+    for (int k = 0; k < NJ4; k++) { const float4 j = t[16 * k]; W.J[4 * k] = j.x; W.J[4 * k + 1] = j.y; W.J[4 * k + 2] = j.z; W.J[4 * k + 3] = j.w; }
+    W.A0 = t[16 * NJ4]; W.A1 = t[16 * (NJ4 + 1)]; W.A2 = t[16 * (NJ4 + 2)]; W.A3 = t[16 * (NJ4 + 3)];
+    const float4 c = t[16 * (NJ4 + 4)];
+    W.aref = c.x; W.R = c.y; W.nw = c.z; W.half = c.w;
   };
-  float* const xl = wn_lds + (rho * nl * NX) * 16 + q;                               // LDS tier: window NW + j at xl + j * NX * 16
-  float* const xg = wb + WN_ROWS + M.win_maxw * WN_NK * 16 + q;                            // global tier: window w at xg + w * NX * 16
+#define WN_XF(t) (*(float*)((t) + 16 * (NJ4 + 5)))       /* the record's force */
+  float4* const xl = (float4*)wn_lds + (rho * nl * NX4) * 16 + q;                                   // LDS tier: window NW + j at xl + j * NX4 * 16
+  float4* const xg = (float4*)(wb + WN_ROWS + M.win_maxw * WN_NK * 16) + q;                         // global tier: window w at xg + w * NX4 * 16
   const int nwl = min(nwmax, NW + nl);
 #pragma unroll
   for (int w = 0; w < NW; w++) if (w < nwmax) { load_rows(win[w], w); make_tile(win[w]); }
@@ -801,9 +798,7 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
   // order, same row math; the grouping of the arithmetic differs (fp32 rounding).
   static_assert(NW % 2 == 0, "register-resident windows are swept in pairs");
   float4 X[NW / 2][4];
-#pragma unroll
-  for (int j = 0; j < NW / 2; j++) if (2 * j + 1 < nwmax) {
-    WnWin<NV>& A = win[2 * j]; WnWin<NV>& B = win[2 * j + 1];
+  auto make_cross = [&](WnWin<NV>& A, WnWin<NV>& B, float4 (&Xo)[4]) __attribute__((always_inline)) {
     float acx[16];
 #pragma unroll
     for (int sidx = 0; sidx < 16; sidx++) acx[sidx] = 0.0f;
@@ -813,21 +808,44 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
 #define WN_ACX(sidx) _Pragma("unroll") for (int k = 0; k < NV; k++) PP_FMAC_BC(acx[sidx], A.J[k], B.J[k], sidx);
     PP_BC16(WN_ACX)
 #undef WN_ACX
-    X[j][0] = make_float4(B.nw * acx[0], B.nw * acx[1], B.nw * acx[2], B.nw * acx[3]);
-    X[j][1] = make_float4(B.nw * acx[4], B.nw * acx[5], B.nw * acx[6], B.nw * acx[7]);
-    X[j][2] = make_float4(B.nw * acx[8], B.nw * acx[9], B.nw * acx[10], B.nw * acx[11]);
-    X[j][3] = make_float4(B.nw * acx[12], B.nw * acx[13], B.nw * acx[14], B.nw * acx[15]);
+    Xo[0] = make_float4(B.nw * acx[0], B.nw * acx[1], B.nw * acx[2], B.nw * acx[3]);
+    Xo[1] = make_float4(B.nw * acx[4], B.nw * acx[5], B.nw * acx[6], B.nw * acx[7]);
+    Xo[2] = make_float4(B.nw * acx[8], B.nw * acx[9], B.nw * acx[10], B.nw * acx[11]);
+    Xo[3] = make_float4(B.nw * acx[12], B.nw * acx[13], B.nw * acx[14], B.nw * acx[15]);
+  };
+#pragma unroll
+  for (int j = 0; j < NW / 2; j++) if (2 * j + 1 < nwmax) make_cross(win[2 * j], win[2 * j + 1], X[j]);
+  for (int w = NW; w < nwl; w++) { WnWin<NV> W; load_rows(W, w); make_tile(W); store_ext(xl + (w - NW) * NX4 * 16, W, 0.0f); }
+  for (int w = nwl; w < nwmax; w++) { WnWin<NV> W; load_rows(W, w); make_tile(W); if (mine) store_ext(xg + w * NX4 * 16, W, 0.0f); }
+  // a tier window for a sweep: record and force (a lane without an env, or with one that finished in the assemble launch, sweeps zero rows)
+  auto load_tier = [&](const int w, WnWin<NV>& W, float& fw) __attribute__((always_inline)) {
+    if (w < nwl) { const float4* t = xl + (w - NW) * NX4 * 16; load_ext(t, W); fw = WN_XF(t); }
+    else {
+      const float4* t = xg + w * NX4 * 16; fw = 0.0f;
+      if (mine) { load_ext(t, W); fw = WN_XF(t); } else { load_rows(W, WN_MAXW); W.A0 = W.A1 = W.A2 = W.A3 = make_float4(0, 0, 0, 0); W.nw = 0; W.half = 0; }
+    }
+  };
+  auto store_tier_force = [&](const int w, const float fw) __attribute__((always_inline)) {
+    if (w < nwl) WN_XF(xl + (w - NW) * NX4 * 16) = fw; else if (mine) WN_XF(xg + w * NX4 * 16) = fw;
+  };
+  // the tiers' windows are swept in pairs too (the filled chain, 24-slot instance): cross tile of pair (NW + 2 j, NW + 2 j + 1) at xx + j * 64,
+  // in the env's slice behind the records
+  constexpr bool TIER_PAIRS = NV == 24 && WN_FILL && WN_TIER_PAIRS;
+  float4* const xx = xg + M.win_maxw * NX4 * 16;
+  if constexpr (TIER_PAIRS) for (int w = NW; w + 1 < nwmax; w += 2) {
+    WnWin<NV> A, B; float fdum; float4 Xo[4];
+    load_tier(w, A, fdum); load_tier(w + 1, B, fdum);
+    make_cross(A, B, Xo);
+    if (mine) { float4* tx = xx + ((w - NW) >> 1) * 64; tx[0] = Xo[0]; tx[16] = Xo[1]; tx[32] = Xo[2]; tx[48] = Xo[3]; }
   }
-  for (int w = NW; w < nwl; w++) { WnWin<NV> W; load_rows(W, w); make_tile(W); store_ext(xl + (w - NW) * NX * 16, W, 0.0f); }
-  for (int w = nwl; w < nwmax; w++) { WnWin<NV> W; load_rows(W, w); make_tile(W); if (mine) store_ext(xg + w * NX * 16, W, 0.0f); }
   // every window of the wave, register-resident ones first; the body sees the window W and its force fw
 #define WN_FOR_WINDOWS(...) do { \
     _Pragma("unroll") for (int w = 0; w < NW; w++) if (w < nwmax) { WnWin<NV>& W = win[w]; float& fw = f[w]; __VA_ARGS__ } \
-    for (int w = NW; w < nwl; w++) { WnWin<NV> W; float* t = xl + (w - NW) * NX * 16; load_ext(t, W); float fw = t[16 * (NV + 20)]; __VA_ARGS__ t[16 * (NV + 20)] = fw; } \
-    for (int w = nwl; w < nwmax; w++) { WnWin<NV> W; float* t = xg + w * NX * 16; float fw = 0.0f; if (mine) { load_ext(t, W); fw = t[16 * (NV + 20)]; } else { load_rows(W, WN_MAXW); W.A0 = W.A1 = W.A2 = W.A3 = make_float4(0, 0, 0, 0); W.nw = 0; W.half = 0; } \
-                                          __VA_ARGS__ if (mine) t[16 * (NV + 20)] = fw; } } while (0)
-#define WN_ZERO_EXT_FORCES() do { for (int w = NW; w < nwl; w++) xl[(w - NW) * NX * 16 + 16 * (NV + 20)] = 0.0f; \
-                                  if (mine) for (int w = nwl; w < nwmax; w++) xg[w * NX * 16 + 16 * (NV + 20)] = 0.0f; } while (0)
+    for (int w = NW; w < nwl; w++) { WnWin<NV> W; float4* t = xl + (w - NW) * NX4 * 16; load_ext(t, W); float fw = WN_XF(t); __VA_ARGS__ WN_XF(t) = fw; } \
+    for (int w = nwl; w < nwmax; w++) { WnWin<NV> W; float4* t = xg + w * NX4 * 16; float fw = 0.0f; if (mine) { load_ext(t, W); fw = WN_XF(t); } else { load_rows(W, WN_MAXW); W.A0 = W.A1 = W.A2 = W.A3 = make_float4(0, 0, 0, 0); W.nw = 0; W.half = 0; } \
+                                          __VA_ARGS__ if (mine) WN_XF(t) = fw; } } while (0)
+#define WN_ZERO_EXT_FORCES() do { for (int w = NW; w < nwl; w++) WN_XF(xl + (w - NW) * NX4 * 16) = 0.0f; \
+                                  if (mine) for (int w = nwl; w < nwmax; w++) WN_XF(xg + w * NX4 * 16) = 0.0f; } while (0)
 
   // ---- warm start (mj_fwdConstraint): f = max(0, -(J a_ws - aref) / R), kept if the dual cost is not positive
   float a_lo = as_lo, a_hi = as_hi;
@@ -856,10 +874,67 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
   const ImpQ iq = imp_quantum(1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1)), M.tolerance);
   const int itmax = M.iterations;
   int niter = 0;
+  // one sweep of a PAIR of windows with the chains' wait states filled (see WN_ROWF above): the register-resident pairs, and the pairs of the
+  // tiers beyond them (records and cross tile loaded for the sweep)
+  int impl = 0;
+  auto sweep_pair_fill = [&](WnWin<NV>& A, WnWin<NV>& B, const float4& X0, const float4& X1, const float4& X2, const float4& X3, float& fa, float& fb) __attribute__((always_inline)) {
+    if constexpr (NV == 24) {
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      const float ua = wn_dot<NV>(A.J, a_lo, a_hi);
+      float ub1;                                   // window B's dot over dofs 16 .. 23 (a_hi: lane 2j carries dof 16 + j)
+      asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                   WN_FM("%0", "%1", "%3", 2) WN_FM("%0", "%1", "%4", 4) WN_FM("%0", "%1", "%5", 6) WN_FM("%0", "%1", "%6", 8) WN_FM("%0", "%1", "%7", 10)
+                   WN_FM("%0", "%1", "%8", 12) WN_FM("%0", "%1", "%9", 14)
+                   : "=&v"(ub1) : "v"(a_hi), "v"(B.J[16]), "v"(B.J[17]), "v"(B.J[18]), "v"(B.J[19]), "v"(B.J[20]), "v"(B.J[21]), "v"(B.J[22]), "v"(B.J[23]));
+      const float foa = fa, fob = fb;
+      float tta, dla, dlb, ub0;
+      {
+        float tt = ((ua - A.aref) + A.R * foa) * A.nw;
+        const float nf = -foa;
+        float dl;
+        // (row 0's filler opens window B's dot: a product, not a multiply-add)
+        asm volatile(WN_ROWF(0, "%[a0]", "v_mul_f32_dpp %[ub], %[al], %[b0] row_newbcast:0 row_mask:0xf bank_mask:0xf") WN_ROWF(1, "%[a1]", WN_FDOT(1, "%[b1]")) WN_ROWF(2, "%[a2]", WN_FDOT(2, "%[b2]")) WN_ROWF(3, "%[a3]", WN_FDOT(3, "%[b3]"))
+                     : [t] "+v"(tt), [d] "=&v"(dl), [ub] "=&v"(ub0) : [nf] "v"(nf), [a0] "v"(A.A0.x), [a1] "v"(A.A0.y), [a2] "v"(A.A0.z), [a3] "v"(A.A0.w), [al] "v"(a_lo), [b0] "v"(B.J[0]), [b1] "v"(B.J[1]), [b2] "v"(B.J[2]), [b3] "v"(B.J[3]));
+        WN_ROWS4_FA(4, 5, 6, 7, A.A1, B.J[4], B.J[5], B.J[6], B.J[7]); WN_ROWS4_FA(8, 9, 10, 11, A.A2, B.J[8], B.J[9], B.J[10], B.J[11]); WN_ROWS4_FA(12, 13, 14, 15, A.A3, B.J[12], B.J[13], B.J[14], B.J[15]);
+        asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));
+        fa = foa + dl; dla = dl; tta = tt;
+      }
+      v2f p[NV / 2];
+      float e1, e2;
+      {
+        const float ub = ub0 + ub1;
+        float tt = ((ub - B.aref) + B.R * fob) * B.nw;
+        float dx = dla;
+        asm volatile("s_nop 1" : "+v"(dx));
+        WN_CROSS4A(0, 1, 2, 3, X0); WN_CROSS4A(4, 5, 6, 7, X1); WN_CROSS4A(8, 9, 10, 11, X2); WN_CROSS4A(12, 13, 14, 15, X3);
+        const float nf = -fob;
+        float dl;
+        const v2f xa2 = {dla, dla};
+#define WN_J2(W, k) v2f{W.J[2 * (k)], W.J[2 * (k) + 1]}
+        WN_ROWS4_FB(0, 1, 2, 3, B.A0, p[0], p[1], p[2], p[3], WN_J2(A, 0), WN_J2(A, 1), WN_J2(A, 2), WN_J2(A, 3));
+        WN_ROWS4_FB(4, 5, 6, 7, B.A1, p[4], p[5], p[6], p[7], WN_J2(A, 4), WN_J2(A, 5), WN_J2(A, 6), WN_J2(A, 7));
+        WN_ROWS4_FB(8, 9, 10, 11, B.A2, p[8], p[9], p[10], p[11], WN_J2(A, 8), WN_J2(A, 9), WN_J2(A, 10), WN_J2(A, 11));
+        WN_ROWS4_FC(12, 13, 14, 15, B.A3);
+        asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));
+        impl += (int)__builtin_amdgcn_fmed3f(e1, -(float)(2 << MJH_IMP_BITS), (float)(2 << MJH_IMP_BITS));
+        impl += imp_fixed((B.half * dl) * (2.0f * tt - dl), iq.qs);
+        fb = fob + dl; dlb = dl;
+      }
+      {   // a^ += J_A^T delta_A + J_B^T delta_B: A's products are there, B's join them, one transpose-reduce (wn_jt2)
+        const v2f xb2 = {dlb, dlb};
+        float pp[NV];
+#pragma unroll
+        for (int k = 0; k < NV / 2; k++) { const v2f pr = __builtin_elementwise_fma(WN_J2(B, k), xb2, p[k]); pp[2 * k] = pr.x; pp[2 * k + 1] = pr.y; }
+#undef WN_J2
+        a_lo += wn_fold16(pp);
+        a_hi += wn_fold8(pp + 16);
+      }
+    }
+  };
   bool act = nrow > 0;
   while (__ballot(act) != 0ull) {
     if (act) {
-      int impl = 0;
+      impl = 0;
 #define WN_SWEEP_ONE(W, fw) do { \
         const float u = wn_dot<NV>(W.J, a_lo, a_hi); \
         const float fo = fw; \
@@ -877,56 +952,7 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
         if (2 * j + 1 < nwmax) {
           WnWin<NV>& A = win[2 * j]; WnWin<NV>& B = win[2 * j + 1];
           if constexpr (NV == 24 && WN_FILL) {
-            typedef float v2f __attribute__((ext_vector_type(2)));
-            const float ua = wn_dot<NV>(A.J, a_lo, a_hi);
-            float ub1;                                   // window B's dot over dofs 16 .. 23 (a_hi: lane 2j carries dof 16 + j)
-            asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-                         WN_FM("%0", "%1", "%3", 2) WN_FM("%0", "%1", "%4", 4) WN_FM("%0", "%1", "%5", 6) WN_FM("%0", "%1", "%6", 8) WN_FM("%0", "%1", "%7", 10)
-                         WN_FM("%0", "%1", "%8", 12) WN_FM("%0", "%1", "%9", 14)
-                         : "=&v"(ub1) : "v"(a_hi), "v"(B.J[16]), "v"(B.J[17]), "v"(B.J[18]), "v"(B.J[19]), "v"(B.J[20]), "v"(B.J[21]), "v"(B.J[22]), "v"(B.J[23]));
-            const float foa = f[2 * j], fob = f[2 * j + 1];
-            float tta, dla, dlb, ub0;
-            {
-              float tt = ((ua - A.aref) + A.R * foa) * A.nw;
-              const float nf = -foa;
-              float dl;
-              // (row 0's filler opens window B's dot: a product, not a multiply-add)
-              asm volatile(WN_ROWF(0, "%[a0]", "v_mul_f32_dpp %[ub], %[al], %[b0] row_newbcast:0 row_mask:0xf bank_mask:0xf") WN_ROWF(1, "%[a1]", WN_FDOT(1, "%[b1]")) WN_ROWF(2, "%[a2]", WN_FDOT(2, "%[b2]")) WN_ROWF(3, "%[a3]", WN_FDOT(3, "%[b3]"))
-                           : [t] "+v"(tt), [d] "=&v"(dl), [ub] "=&v"(ub0) : [nf] "v"(nf), [a0] "v"(A.A0.x), [a1] "v"(A.A0.y), [a2] "v"(A.A0.z), [a3] "v"(A.A0.w), [al] "v"(a_lo), [b0] "v"(B.J[0]), [b1] "v"(B.J[1]), [b2] "v"(B.J[2]), [b3] "v"(B.J[3]));
-              WN_ROWS4_FA(4, 5, 6, 7, A.A1, B.J[4], B.J[5], B.J[6], B.J[7]); WN_ROWS4_FA(8, 9, 10, 11, A.A2, B.J[8], B.J[9], B.J[10], B.J[11]); WN_ROWS4_FA(12, 13, 14, 15, A.A3, B.J[12], B.J[13], B.J[14], B.J[15]);
-              asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));
-              f[2 * j] = foa + dl; dla = dl; tta = tt;
-            }
-            v2f p[NV / 2];
-            float e1, e2;
-            {
-              const float ub = ub0 + ub1;
-              float tt = ((ub - B.aref) + B.R * fob) * B.nw;
-              float dx = dla;
-              asm volatile("s_nop 1" : "+v"(dx));
-              WN_CROSS4A(0, 1, 2, 3, X[j][0]); WN_CROSS4A(4, 5, 6, 7, X[j][1]); WN_CROSS4A(8, 9, 10, 11, X[j][2]); WN_CROSS4A(12, 13, 14, 15, X[j][3]);
-              const float nf = -fob;
-              float dl;
-              const v2f xa2 = {dla, dla};
-#define WN_J2(W, k) v2f{W.J[2 * (k)], W.J[2 * (k) + 1]}
-              WN_ROWS4_FB(0, 1, 2, 3, B.A0, p[0], p[1], p[2], p[3], WN_J2(A, 0), WN_J2(A, 1), WN_J2(A, 2), WN_J2(A, 3));
-              WN_ROWS4_FB(4, 5, 6, 7, B.A1, p[4], p[5], p[6], p[7], WN_J2(A, 4), WN_J2(A, 5), WN_J2(A, 6), WN_J2(A, 7));
-              WN_ROWS4_FB(8, 9, 10, 11, B.A2, p[8], p[9], p[10], p[11], WN_J2(A, 8), WN_J2(A, 9), WN_J2(A, 10), WN_J2(A, 11));
-              WN_ROWS4_FC(12, 13, 14, 15, B.A3);
-              asm volatile("v_max_f32 %0, %1, %2" : "=v"(dl) : "v"(tt), "v"(nf));
-              impl += (int)__builtin_amdgcn_fmed3f(e1, -(float)(2 << MJH_IMP_BITS), (float)(2 << MJH_IMP_BITS));
-              impl += imp_fixed((B.half * dl) * (2.0f * tt - dl), iq.qs);
-              f[2 * j + 1] = fob + dl; dlb = dl;
-            }
-            {   // a^ += J_A^T delta_A + J_B^T delta_B: A's products are there, B's join them, one transpose-reduce (wn_jt2)
-              const v2f xb2 = {dlb, dlb};
-              float pp[NV];
-#pragma unroll
-              for (int k = 0; k < NV / 2; k++) { const v2f pr = __builtin_elementwise_fma(WN_J2(B, k), xb2, p[k]); pp[2 * k] = pr.x; pp[2 * k + 1] = pr.y; }
-#undef WN_J2
-              a_lo += wn_fold16(pp);
-              a_hi += wn_fold8(pp + 16);
-            }
+            sweep_pair_fill(A, B, X[j][0], X[j][1], X[j][2], X[j][3], f[2 * j], f[2 * j + 1]);
           } else {
           const float ua = wn_dot<NV>(A.J, a_lo, a_hi), ub = wn_dot<NV>(B.J, a_lo, a_hi);
           float dla, dlb;
@@ -957,13 +983,24 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
           }
         } else { WnWin<NV>& W = win[2 * j]; WN_SWEEP_ONE(W, f[2 * j]); }
       }
-      // the tiers beyond them: one window at a time
-      for (int w = NW; w < nwl; w++) { WnWin<NV> W; float* t = xl + (w - NW) * NX * 16; load_ext(t, W); float fw = t[16 * (NV + 20)]; WN_SWEEP_ONE(W, fw); t[16 * (NV + 20)] = fw; }
-      for (int w = nwl; w < nwmax; w++) {
-        WnWin<NV> W; float* t = xg + w * NX * 16; float fw = 0.0f;
-        if (mine) { load_ext(t, W); fw = t[16 * (NV + 20)]; } else { load_rows(W, WN_MAXW); W.A0 = W.A1 = W.A2 = W.A3 = make_float4(0, 0, 0, 0); W.nw = 0; W.half = 0; }
+      // the tiers beyond them: in pairs as well (a last odd one alone), or one window at a time
+      int wt = NW;
+      if constexpr (TIER_PAIRS) for (; wt + 1 < nwmax; wt += 2) {
+        WnWin<NV> A, B; float fa, fb;
+        load_tier(wt, A, fa); load_tier(wt + 1, B, fb);
+        const float4* tx = xx + ((wt - NW) >> 1) * 64;
+        float4 X0 = make_float4(0, 0, 0, 0), X1 = X0, X2 = X0, X3 = X0;
+        if (mine) { X0 = tx[0]; X1 = tx[16]; X2 = tx[32]; X3 = tx[48]; }
+        sweep_pair_fill(A, B, X0, X1, X2, X3, fa, fb);
+        store_tier_force(wt, fa); store_tier_force(wt + 1, fb);
+      }
+      // (two loops: the LDS tier's sweep waits on the LDS counter only, the global tier's on the memory counter only — one loop over both: S24D 5.32 -> 5.06 M)
+      for (; wt < nwl; wt++) { WnWin<NV> W; float4* t = xl + (wt - NW) * NX4 * 16; load_ext(t, W); float fw = WN_XF(t); WN_SWEEP_ONE(W, fw); WN_XF(t) = fw; }
+      for (; wt < nwmax; wt++) {
+        WnWin<NV> W; float4* t = xg + wt * NX4 * 16; float fw = 0.0f;
+        if (mine) { load_ext(t, W); fw = WN_XF(t); } else { load_rows(W, WN_MAXW); W.A0 = W.A1 = W.A2 = W.A3 = make_float4(0, 0, 0, 0); W.nw = 0; W.half = 0; }
         WN_SWEEP_ONE(W, fw);
-        if (mine) t[16 * (NV + 20)] = fw;
+        if (mine) WN_XF(t) = fw;
       }
 #undef WN_SWEEP_ONE
       niter++;
@@ -1029,14 +1066,11 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
   if (mine && q == 0) {
     S.time[env] += M.timestep_d;
     // launch-order hint: sweeps x windows in units of the fused kernel's hint (patch_pgs.h: about four instructions)
-#ifdef WN_PROF_CLK
-    const int cost_hint = min((int)(((long long)__builtin_amdgcn_s_memtime() - wn_t0) >> 5) + 1, (1 << 22) - 1);
-#else
     const int cost_hint = wn_cost_hint(M, nwin, niter);
-#endif
     S.stats[4 * env] = WN_STAT0(wh[1]); S.stats[4 * env + 1] = wh[2]; S.stats[4 * env + 2] = niter;
     S.stats[4 * env + 3] = ((S.stats[4 * env + 3] | flags) & 0xff) | (cost_hint << 8);
   }
 #undef WN_FOR_WINDOWS
 #undef WN_ZERO_EXT_FORCES
+#undef WN_XF
 }

@@ -32,7 +32,15 @@
                         // the two body slots (dof address / 6; -1: none) as integers [12], [13], aref [14], R [15]; the window kernel expands it over its dof slots
 #define WN32_MIN_ROWS 96   // rows above which an env is swept in 32-row windows (3.5 % of S24's envs: the ones a cohort's step waits for)
 #define WN_MAXW 24      // most windows per env any model gets (384 rows); a model's own capacity: DModel::win_maxw = min(WN_MAXW, ceil(maxefc / 16))
-#define WN_XREC(nvt) ((nvt) + 21)   // record of a window beyond the register-resident ones, per row: J^[nvt], aref, R, 16 tile entries, -1 / AR_qq, AR_qq / 2, force
+// Sweeping the tiers' windows in pairs as well (-DWN_TIER_PAIRS=1: the filled chain on two loaded records and their cross tile) was measured
+// and is off: with six register-resident windows the kernel grows to 490 registers (S24 13.3 -> 11.5 M, S24D 5.3 -> 4.7 M), with four
+// resident windows and the pairs S24D runs at 4.65 M against 5.03 M — a tier window's sweep waits for its record's loads (a lone
+// wavefront hides no latency), and a pair waits for twice as many before its first instruction (HISTORY.md Round 5).
+#ifndef WN_TIER_PAIRS
+#define WN_TIER_PAIRS 0
+#endif
+#define WN_XPAIR (WN_TIER_PAIRS ? 16 : 0)     // cross tile of a PAIR of such windows, per row
+#define WN_XREC(nvt) (((nvt) + 24) / 4 * 4)   // (floats, a multiple of four: the record is read in 16-byte pieces) record of a window beyond the register-resident ones, per row: J^[nvt], aref, R, 16 tile entries, -1 / AR_qq, AR_qq / 2, force
 #ifndef WN_NW24
 #define WN_NW24 6       // register-resident windows of the 24-dof instance (96 rows: what the 16-row form meets with the 32-row section on; S24 has 72 on average), the rest is streamed
 #endif

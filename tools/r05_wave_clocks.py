@@ -14,15 +14,19 @@ args = types.SimpleNamespace(envs_per_gpu=4096, pack=0, maxcon=0, pen_half=0.0)
 w = bench.WORKLOADS[name](ms, args, 0, 0, None)
 e = w.eng; e.set_cohorts(nc)
 e.step(w.settle_steps + 40); e.synchronize()
-w64 = int(os.environ.get("MJH_WINDOW64", "208")); w32 = 96
+w64 = int(os.environ.get("MJH_WINDOW64", "208" if name == "s24d" else "96")); w32 = 96
 for rep in range(3):
     e.step(1); e.synchronize()
     st = e.get_stats()
     rows, it, clk = st[:, 1], st[:, 2], st[:, 0] * 32.0
-    us = clk / 100.0        # s_memtime ticks at 100 MHz
+    us = clk / 2400.0       # s_memtime counts shader clocks here (2.4 GHz: a 258 us kernel reads 620 k ticks)
     if rep < 2: continue
-    print(f"{name}: per-env clocks of its wavefront (s_memtime ticks x 32 granularity; 100 MHz -> us): max {us.max():.0f} us")
-    for lo, hi, form in ((1, 64, "16-row"), (65, 96, "16-row"), (97, 128, "32-row"), (129, 160, "16-row + tiers"), (161, 192, "16-row + tiers"), (193, w64, "16-row + tiers"), (w64 + 1, 256, "64-row"), (257, 320, "64-row"), (321, 400, "16-row + tiers")):
+    print(f"{name}: per-env clocks of its wavefront (s_memtime ticks, 32-tick granularity, 2.4 GHz -> us): max {us.max():.0f} us")
+    classes = [(1, 32, "16-row"), (33, 64, "16-row"), (65, 80, "16-row"), (81, 96, "16-row")] + ([(97, 128, "64-row"), (129, 192, "64-row")] if w64 <= 96 else [(97, 128, "32-row"), (129, 160, "16-row + tiers"), (161, 192, "16-row + tiers"), (193, w64, "16-row + tiers"), (w64 + 1, 256, "64-row"), (257, 320, "64-row"), (321, 400, "16-row + tiers")])
+    simd_us = 0.0
+    for lo, hi, form in classes:
         m = (rows >= lo) & (rows <= hi)
         if m.any():
+            simd_us += us[m].sum() / {"16": 4, "32": 2, "64": 1}[form[:2]]
             print(f"  rows {lo:3d}-{hi:3d} ({form:15s}): {int(m.sum()):5d} envs, sweeps mean {it[m].mean():5.1f}, wave time mean {us[m].mean():7.1f} max {us[m].max():7.1f} us; at the sweep cap: mean {us[m & (it >= 100)].mean() if (m & (it >= 100)).any() else 0:7.1f} us")
+    print(f"  window wavefronts hold {simd_us / 1e3:.1f} SIMD-ms per step of all cohorts: {simd_us / 1024:.0f} us of every one of the chip's 1024 SIMDs (one such wavefront per SIMD: 424 registers)")
