@@ -165,7 +165,8 @@ static int launch_on(mjh_engine* e, hipStream_t st, int env0, int n, int nsteps,
     // fit beside the window kernel's on a SIMD
     const bool cx = extra_instance(e->M) || e->S.xfrc_applied;
     static const bool slim_lds = !(getenv("MJH_WINDOW_SLIM_LDS") && atoi(getenv("MJH_WINDOW_SLIM_LDS")) == 0);
-    const size_t wlds = (size_t)((slim_lds && e->lds_bytes_pre > 0) ? e->lds_bytes_pre : e->lds_bytes);
+    static const int wpad = getenv("MJH_WPRE_LDS_PAD") ? std::max(0, atoi(getenv("MJH_WPRE_LDS_PAD"))) : 0;      // (occupancy experiments: bytes of unused LDS per assemble-only workgroup)
+    const size_t wlds = (size_t)((slim_lds && e->lds_bytes_pre > 0) ? e->lds_bytes_pre : e->lds_bytes) + (size_t)wpad;
     // (models of up to 64 contacts keep the base-row pool in LDS — instance 1 —, larger ones in the env's window slice — instance 2: derive_device_model)
 #define MJH_LAUNCHW(NR, CX, GJ) hipLaunchKernelGGL((mjh_step_kernel<NR, true, CX, GJ>), dim3(n), dim3(64), wlds, st, e->dC, e->S, env0, nsteps, ph, xflags)
 #define MJH_LAUNCHW2(NR, CX) do { if (e->M.patch) MJH_LAUNCHW(NR, CX, 1); else MJH_LAUNCHW(NR, CX, 2); } while (0)
@@ -444,6 +445,14 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       L.ext = gput(extsz); L.J = gput(jsz); L.B = diagM ? L.J : gput(jsz);
     } else {
       L.blki = put(nblkcap * BLKI_STRIDE); L.blkf = put(nblkcap * BLKF_STRIDE);
+      // window-only models (65 .. 128 contacts): their assemble-only launch (WPRE instance 2) builds no block schedule and no condim-4
+      // extension — both belong to the fused kernel's sweep — and keeps the per-base scratch vectors bv / phi (first written by the
+      // velocity stage) in the contact records, which are dead by then (step_kernel.h; the fused instance cannot: its A_c / Q matrices
+      // take that span while phi is live).  Its LDS ends in front of all of them: S24D at capacity 96 25.3 -> 16.9 KB, 6 -> 9
+      // environments per CU (5.30 -> 5.6 M env-steps/s, bitwise).  MJH_WPRE_SLIM2=0: the former extent
+      static const bool slim2 = !(getenv("MJH_WPRE_SLIM2") && atoi(getenv("MJH_WPRE_SLIM2")) == 0);
+      const bool wonly = M.window && !patch && slim2 && 8 * nblkcap <= M.maxcon * CON_STRIDE;
+      if (wonly) hp.lds_bytes_pre = off * (int)sizeof(float);
       if (2 * nblkcap * 4 <= k1_size && !keep) { L.bv = k1; L.phi = k1 + nblkcap * 4; }
       else { L.bv = put(nblkcap * 4); L.phi = put(nblkcap * 4); }
       L.sched = put(nblkcap * 2);
@@ -451,7 +460,7 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       L.order = (nv <= 32 && nblkcap <= k1_size && !keep) ? L.bv : put(nblkcap);
       L.ext = (extsz <= k2_size && !keep) ? k1 : put(extsz);
       // (window models beyond 64 contacts: the base-row pool comes last, their assemble-only launch keeps it in global memory and allocates the LDS in front of it)
-      hp.lds_bytes_pre = off * (int)sizeof(float);
+      if (!wonly) hp.lds_bytes_pre = off * (int)sizeof(float);
       L.J = put((int)jsz); L.B = diagM ? L.J : put((int)jsz);
     }
     M.win_jsz = (int)jsz;

@@ -951,6 +951,9 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DCon
   // 192 B per contact — lives in the env's slice of the window buffer (global memory, L2-resident) instead of LDS: the launch is bound by
   // the latency of one wave per env, and its LDS sets how many envs a CU holds (S24D at 96 contacts: 44 KB -> 25 KB, 3 -> 6 per CU)
   if constexpr (WPRE == 2) { s_J = S.wbuf + (size_t)env * (size_t)S.wstride + S.wj_off; s_B = s_J; }
+  // ... and the per-base scratch vectors bv / phi (velocity stage: J qvel; mj_inverse: J qacc and the base forces) in the contact records, which
+  // nothing reads once the rows are made (the last reader is the row-parameter stage): this instance's LDS ends in front of their own slots (engine.hip)
+  if constexpr (WPRE == 2) if (8 * max(M.maxblk, 1) <= M.maxcon * CON_STRIDE) { s_bv = s_con; s_phi = s_con + 4 * max(M.maxblk, 1); }
   float* s_stage = s_J;  // raw-contact staging aliases the (not yet built) base-row storage
   const int rowW = M.rowW;
 
@@ -1724,6 +1727,7 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
     int ngrp = 0;
     bool patch_order = false;    // contact-patch sweep (patch_pgs.h): it builds its own schedule
     if constexpr (DIAGM && NROW <= 2) patch_order = M.patch != 0;
+    if constexpr (WPRE != 0) patch_order = true;      // (assemble-only instances: the window kernel sweeps in row order and needs no schedule — nothing of it is built, its LDS is not even allocated: engine.hip)
     if (!patch_order && M.pgs_row_order) {
       // mj_solPGS's own order: block after block as the rows were made.  Blocks without a common kinematic tree touch disjoint dofs, so
       // their updates commute exactly; pgs_row_order 1 list-schedules the sequence — block i goes to the first group (with a free place)

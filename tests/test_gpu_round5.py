@@ -400,3 +400,35 @@ def test_s24_64_row_windows_for_the_envs_beyond_96_rows_equal_the_16_row_form_up
         assert np.abs(v1[i] - d.f("qvel")).max() / max(1, np.abs(d.f("qvel")).max()) <= S24_TOL_V
     assert checked >= 6
     a.close(); b.close()
+
+
+def test_s24d_assemble_only_launch_with_its_scratch_in_the_dead_contact_records():
+    """The assemble-only instance of window-only models (65 .. 128 contacts) allocates no LDS for the block schedule, the condim-4 extension and
+    the per-base scratch vectors bv / phi: no schedule is built, and bv / phi (velocity stage: J qvel -> aref; mj_inverse: J qacc, base forces)
+    live in the contact records, dead once the rows are made (engine.hip: lds_bytes_pre; step_kernel.h: WPRE == 2).  Against the fused kernel
+    (own slots for all of them, MJH_WINDOW off) on the same states: mj_inverse's output after one step and the split API's hand-over."""
+    lib = ms.capi.load()
+    m = ms.scene("s24pen", 0.175, S24D_CAPACITY)
+    full, pre = lib.mjh_query_lds_bytes(m.ptr), lib.mjh_query_lds_bytes_assemble(m.ptr)
+    assert 0 < pre <= 17 * 1024 < full, (pre, full)           # (25.3 KB before: six environments per CU; now nine)
+    seeds = list(range(48))
+    _, a, _ = _s24d_seeds(seeds, window=True)
+    _, b, _ = _s24d_seeds(seeds, window=False)
+    a.step(300); t, q, v, w = a.get_state()
+    b.set_state(qpos=q, qvel=v, time=t, warmstart=w)
+    st = a.get_stats()
+    assert st[:, 0].max() > 24 and (st[:, 3] & 7 == 0).all()
+    a.step(1, True); b.step(1, True)
+    fa, fb = a.get_field("qfrc_inverse"), b.get_field("qfrc_inverse")
+    scale = np.abs(fb).max()
+    assert scale > 1.0 and np.abs(fa - fb).max() <= 2e-3 * scale, (np.abs(fa - fb).max(), scale)
+    # split API: mjh_step1 + mjh_inverse is the assemble-only launch with the hand-over; mjh_step2 the window kernel
+    t, q, v, w = a.get_state()
+    b.set_state(qpos=q, qvel=v, time=t, warmstart=w)
+    a.step1(); a.inverse(); b.step1(); b.inverse()
+    fa, fb = a.get_field("qfrc_inverse"), b.get_field("qfrc_inverse")
+    assert np.abs(fa - fb).max() <= 2e-3 * max(np.abs(fb).max(), 1.0)
+    a.step2(); b.step2()
+    _, q1, v1, _ = a.get_state(); _, q2, v2, _ = b.get_state()
+    assert np.abs(q1 - q2).max() <= 5e-6 and np.abs(v1 - v2).max() <= 2e-3
+    a.close(); b.close()
