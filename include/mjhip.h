@@ -591,6 +591,7 @@ void mjh_set_pgs_row_order(int mode);
  * to fp32 rounding as the block solver (MJH_DENSE=0 turns it off) */
 int mjh_dense_solver(const mjh_engine*);
 int mjh_query_lds_bytes(const mjh_model*); /* same figure without a device: capacity planning (160 KiB per CU) */
+int mjh_debug_lds_layout(const mjh_model*, char* out, int cap);   /* the LDS layout as text ("name offset" per array, float units; then totals): capacity planning, tools/lds_layout.py */
 int mjh_query_lds_bytes_assemble(const mjh_model*);   /* LDS per env of the assemble-only launch of the window chain (small free-body models; 0: not taken) */
 const char* mjh_last_error(void);
 const char* mjh_version(void);

@@ -251,6 +251,7 @@ SYMBOLS = [
     ("mjh_dense_solver", C.c_int, [_vp]),
     ("mjh_query_lds_bytes", C.c_int, [Model_p]),
     ("mjh_query_lds_bytes_assemble", C.c_int, [Model_p]),
+    ("mjh_debug_lds_layout", C.c_int, [Model_p, C.c_char_p, C.c_int]),
     ("mjh_host_run_pd", C.c_int, [_vp, C.c_int, c_double_p, C.c_double, C.c_double, C.c_long, c_double_p, c_double_p, c_double_p]),
     ("mjh_host_run_pd_group", C.c_int, [_vp, C.c_int, c_double_p, C.c_double, C.c_double, C.c_long, C.c_int, c_double_p, c_double_p, C.POINTER(C.c_float)]),
     ("mjh_host_run_realtime", C.c_int, [_vp, C.c_int, c_double_p, C.c_double, C.c_double, C.c_long, C.c_double, c_double_p]),

@@ -421,7 +421,10 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
       L.qM = put(m->nM); L.qLD = (diagM || big) ? L.qM : put(m->nM); L.qLDinv = put(nv);
       if (diagM) { L.dofpar = 0; L.dofMadr = 0; L.anc = 0; }   // free-body models read the shared chain-walk tables (step_kernel.h)
       else { L.dofpar = put(nv); L.dofMadr = put(nv); L.anc = put(m->nM); }
-      L.p_gsize = put(3*ng); L.p_rbound = put(ng); L.p_mass = put(nb); L.p_inertia = put(3*nb);
+      // (models without a collision pair never read the per-env geom sizes / bounding radii: their copies land in the geom poses' span instead of
+      //  taking their own — C3, four arms per wavefront: 20816 -> 20336 B, 17 -> 16 LDS granules, 7 -> 8 workgroups per CU = all 2048 resident)
+      const bool nopairs = m->npair == 0;
+      L.p_gsize = nopairs ? L.gpos : put(3*ng); L.p_rbound = nopairs ? L.gmat : put(ng); L.p_mass = put(nb); L.p_inertia = put(3*nb);
     }
     {  // the contact records die once the blocks are built; the velocity-stage spatial vectors reuse their space
       const int a4 = [](int n) { return ((std::max(n, 1) + 3) / 4) * 4; }(6*nb);
@@ -538,6 +541,22 @@ extern "C" int mjh_query_lds_bytes(const mjh_model* m) {
   if (!m) return MJH_ERR_ARG;
   HostPack hp; derive_fitting(m, hp);
   return hp.lds_bytes;
+}
+// the LDS layout of a model as text: "name offset" per array in float units (negative: the env's global slice), then the totals —
+// capacity planning (which array costs a granule: tools/lds_layout.py).  Returns the number of bytes written (without the terminator)
+extern "C" int mjh_debug_lds_layout(const mjh_model* m, char* out, int cap) {
+  if (!m || !out || cap <= 0) return MJH_ERR_ARG;
+  HostPack hp; derive_fitting(m, hp);
+  std::string t;
+#define X(n) t += std::string(#n) + " " + std::to_string(hp.L.n) + "\n";
+  MJH_LDS_ARRAYS(X)
+#undef X
+  t += "total " + std::to_string(hp.L.total) + "\nlds_bytes " + std::to_string(hp.lds_bytes) + "\nlds_bytes_pre " + std::to_string(hp.lds_bytes_pre) +
+       "\nk1_floats " + std::to_string(hp.M.k1_floats) + "\nmaxcon " + std::to_string(hp.M.maxcon) + "\nmaxblk " + std::to_string(hp.M.maxblk) +
+       "\nrowW " + std::to_string(hp.M.rowW) + "\nnstage " + std::to_string(hp.M.nstage) + "\nbig " + std::to_string((int)hp.M.big) + "\n";
+  const int n = std::min((int)t.size(), cap - 1);
+  std::memcpy(out, t.data(), (size_t)n); out[n] = 0;
+  return n;
 }
 extern "C" int mjh_query_lds_bytes_assemble(const mjh_model* m) {   // ... of the assemble-only instance of the window chain (0: the model does not take it)
   if (!m) return MJH_ERR_ARG;
