@@ -126,7 +126,7 @@ class S24(Workload):
 
 
 class S24D(S24):
-    cohorts = 2       # round 5 (64-row form, window-count-major launch order): 4.82 / 4.65 / 4.51 M env-steps/s on 2 / 3 / 4 cohorts
+    cohorts = 2       # round 5 (64-row form, window-count-major launch order): 4.82 / 4.65 / 4.51 M env-steps/s on 2 / 3 / 4 cohorts; with the slim assemble-only launch 5.75 / 5.56 M on 2 / 3
     """the "30-contact" reading of the metric's name: S24's pen and S24's four boxes (same per-env sizes, masses, seeds), but released
     flat and side by side (2 x 2, random yaw) instead of as a staggered column of random orientations: the boxes land on the floor
     together (16 floor contacts of condim 4) and are wedged against each other and the walls — ~30 contacts, ~130 rows per env, what
@@ -759,7 +759,7 @@ def main():
                     # wave-instructions per second at THIS run's rate over the chip's 1024 SIMDs, against (i) the guide's issue peak — a
                     # wave64 fp32 VALU instruction every 2 clocks per SIMD (MI355X_MICROARCH.md) — which is `valu_issue_frac`, (ii) what this
                     # repo's micro-benchmark reaches with four resident waves per SIMD (one per 2.5 clocks: profiles/r02m_valu_issue_bench.txt)
-                    # and (iii) the rate of a LONE wave (one per 8 clocks) — the window kernel's 446 registers leave one wave per SIMD, so (iii)
+                    # and (iii) the rate of a LONE wave (one per 8 clocks) — the window kernel's 424 registers leave one wave per SIMD, so (iii)
                     # is the ceiling of the structure and the number that says how full the SIMDs' only wave keeps its own issue slots
                     vrate = valu_instr * (value / world) / 1024 / 2.4e9          # VALU instructions per SIMD and clock
                     valu_frac = vrate * 2.0
@@ -799,8 +799,10 @@ def main():
                      # the second fraction (say which binds): VALU issue — committed SQ-counter passes of this config x this run's rate
                      "valu_issue_frac": valu_frac, "valu_issue_frac_by_denominator": valu_fracs, "valu_lane_util": valu_lanes, "valu_instr_per_env_step": valu_instr,
                      "valu_source": traffic_src.replace("FETCH_SIZE / WRITE_SIZE", "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_THREAD_CYCLES_VALU") if (traffic_src and valu_instr) else None,
-                     "binds": ("the dependent instruction chain of ONE resident wave per SIMD (window kernel: 446 registers): a lone wave issues at most one VALU instruction per 8 clocks — "
-                               "valu_issue_frac_by_denominator.per_8_clocks_lone_wave says how much of THAT the chip uses; against the SIMD's issue peak it is valu_issue_frac; HBM (frac) does not bind") if valu_frac else None,
+                     "binds": ((("the dependent instruction chain of ONE resident wave per SIMD (window kernel: 424 registers): " if w.name in ("s24", "s24d") else
+                                 "the dependent instruction chain of the one wavefront an environment (or a pack of them) is stepped by, few of them per SIMD: ") +
+                                "a lone wave issues at most one VALU instruction per 8 clocks — valu_issue_frac_by_denominator.per_8_clocks_lone_wave says how much of THAT the chip uses; "
+                                "against the SIMD's issue peak it is valu_issue_frac; HBM (frac) does not bind")) if valu_frac else None,
                      "timed_window_note": f"{args.steps} steps = {elapsed * 1e3:.1f} ms; kernel_ms is the mean of {n_timed} event-timed launches in it",
                      "note": "fused per-env pipeline keeps intermediates in LDS / registers: the path is issue/latency bound, far below the HBM roofline by design (DESIGN.md §4, §5)"},
     }

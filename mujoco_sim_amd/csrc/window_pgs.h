@@ -47,10 +47,16 @@
 #ifndef WN_NW32
 #define WN_NW32 6
 #endif
+#ifndef WN32_NW
 #define WN32_NW 4       // 32-row windows of an env (128 rows), all register-resident
+#endif
 #define WN64_MIN_ROWS 208  // rows above which an env is swept in 64-row windows, one env per wavefront (S24D: 11 % of the envs, the ones a cohort's step waits for)
+#ifndef WN64_NW
 #define WN64_NW 3       // 64-row windows of an env that are register-resident (192 rows) ...
+#endif
+#ifndef WN64_NT
 #define WN64_NT 2       // ... and the ones behind them whose tiles live in LDS (320 rows in all; they need the launch's LDS tier: 2 x 16 KB)
+#endif
 
 // Assemble launch (mjh_step_kernel with PH_PRE, free-body instance): the constraint blocks of this env -> window rows in global memory.
 // blki / blkf / J: the block tables in LDS (step_kernel.h); sinv = M^-1/2 per dof.  Returns the number of rows (0: too many, not written).
