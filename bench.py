@@ -363,7 +363,7 @@ def cpu_baseline(w, sample_envs, budget_s, with_inverse):
         ncal = min(sample_envs, T)
         arr = ensure(ncal)
         L.orc_step_many(arr, ncal, 1, int(with_inverse))                 # (creates the team's threads, faults the data in)
-        cal = max(L.orc_step_many_timed(arr, ncal, 1, 1, int(with_inverse)), 1e-6)   # one env-step per thread
+        cal = max(min(L.orc_step_many_timed(arr, ncal, 1, 1, int(with_inverse)) for _ in range(3)), 1e-6)   # one env-step per thread (the fastest of three: one slow sample on a shared host would shrink the whole point's sample)
         afford = per_point * T / cal                  # env-steps this point can afford
         n_envs = min(sample_envs, max(T, min(max(4 * T, 64), int(afford // 4))))
         n_steps = max(1, min(200, int(afford // n_envs)))
