@@ -49,7 +49,9 @@ typedef float mjh_f4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------ build
 // LDS: s_minv[NVS] | s_inv[CAP] | s_row[CAP] int4 | s_start[maxblk + 1]  (a few KB: several workgroups per CU)
+#ifndef DN_BUILD_THREADS
 #define DN_BUILD_THREADS 512
+#endif
 __global__ __launch_bounds__(DN_BUILD_THREADS) void mjh_dense_build_kernel(const DConst* __restrict__ C, const DState S, int env0) {
   const DModel& M = C->M; const Lay& L = C->L;
   extern __shared__ float lds[];
@@ -245,10 +247,13 @@ DEV int dn_sweeps(const __amdgpu_buffer_rsrc_t rs, const int art_bytes, const in
 #pragma unroll
   for (int r = 0; r < GR; r++) buf[0][r] = dn_load<K>(rs, voff, art_bytes + r * ROWB);
   int niter = 0;
-  for (;;) {
-    float sv[K];
+  // (the sweep carries r = s - f and the interval relative to f: a row's delta is ONE med3 — see dn_sweeps_resident)
 #pragma unroll
-    for (int k = 0; k < K; k++) sv[k] = s[k];      // sv: s of the lane's row at ITS visit (rows never visited are inert: lo = hi = f = 0)
+  for (int k = 0; k < K; k++) s[k] -= f[k];
+  for (;;) {
+    float sv[K], lor[K], hir[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { sv[k] = s[k]; lor[k] = lo[k] - f[k]; hir[k] = hi[k] - f[k]; }      // sv: r of the lane's row at ITS visit (rows never visited are inert: lo = hi = f = 0)
     // (opaque per sweep: otherwise the 64 lane masks and the row offsets are hoisted out of the sweep loop as loop invariants and
     //  spilled — v_writelane / v_readlane around every use)
     unsigned long long m1 = 1ull; asm volatile("" : "+s"(m1));
@@ -273,8 +278,7 @@ DEV int dn_sweeps(const __amdgpu_buffer_rsrc_t rs, const int art_bytes, const in
 #pragma unroll
             for (int r = 0; r < GR; r++) {
               const int l = GR * gg + r;
-              const float fn = __builtin_amdgcn_fmed3f(s[k], lo[k], hi[k]);
-              const float d = fn - f[k];
+              const float d = __builtin_amdgcn_fmed3f(s[k], lor[k], hir[k]);
               const float sd = readlane_f(d, l);
               const bool me = __builtin_amdgcn_inverse_ballot_w64(mask);     // lane l: v_cndmask on a scalar mask, no compare
               mask <<= 1;
@@ -303,10 +307,10 @@ DEV int dn_sweeps(const __amdgpu_buffer_rsrc_t rs, const int art_bytes, const in
     niter++;
     float imp = 0;
 #pragma unroll
-    for (int k = 0; k < K; k++) {      // -delta (res + AR delta / 2), res = -t AR, t = s - f at the row's visit
-      const float fn = __builtin_amdgcn_fmed3f(sv[k], lo[k], hi[k]), dc = fn - f[k];
-      imp += dc * arr[k] * ((sv[k] - f[k]) - 0.5f * dc);
-      f[k] = fn;
+    for (int k = 0; k < K; k++) {      // -delta (res + AR delta / 2), res = -t AR, t = s - f = r at the row's visit
+      const float dc = __builtin_amdgcn_fmed3f(sv[k], lor[k], hir[k]);
+      imp += dc * arr[k] * (sv[k] - 0.5f * dc);
+      f[k] += dc; s[k] -= dc;          // (r = s - f: the row's own update leaves s where it was)
     }
     const float improvement = wave_sum<4>(imp);
     if (improvement * scale < tol || niter >= itmax) break;
@@ -342,10 +346,17 @@ DEV int dn_sweeps_resident(const __amdgpu_buffer_rsrc_t rs, const int art_bytes,
     }
   }
   int niter = 0;
-  for (;;) {
-    float sv[K];
+  // The sweep carries  r = s - f  and the projection interval relative to the force,  [lo - f, hi - f]  (f does not move inside a sweep: a row
+  // is visited once), so that a row's delta  med3(s, lo, hi) - f  is ONE instruction,  med3(r, lo - f, hi - f): six instead of seven
+  // VALU instructions per row at K = 3, and one less on the row-to-row chain (round 5: C4's dense solve launch 501 -> ~440 us).  Same
+  // iteration in exact arithmetic; in fp32 the iterates differ from the s-form by rounding (the new force is f + delta instead of the
+  // clamped s: identical at an active bound lo = 0, where lo - f = -f exactly).
 #pragma unroll
-    for (int k = 0; k < K; k++) sv[k] = s[k];
+  for (int k = 0; k < K; k++) s[k] -= f[k];
+  for (;;) {
+    float sv[K], lor[K], hir[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { sv[k] = s[k]; lor[k] = lo[k] - f[k]; hir[k] = hi[k] - f[k]; }
     unsigned long long m1 = 1ull; asm volatile("" : "+s"(m1));
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -357,8 +368,7 @@ DEV int dn_sweeps_resident(const __amdgpu_buffer_rsrc_t rs, const int art_bytes,
 #pragma unroll
           for (int r = 0; r < 16; r++) {
             const int l = 16 * gg + r;
-            const float fn = __builtin_amdgcn_fmed3f(s[k], lo[k], hi[k]);
-            const float d = fn - f[k];
+            const float d = __builtin_amdgcn_fmed3f(s[k], lor[k], hir[k]);
             const float sd = readlane_f(d, l);
             const bool me = __builtin_amdgcn_inverse_ballot_w64(mask);
             mask <<= 1;
@@ -379,9 +389,9 @@ DEV int dn_sweeps_resident(const __amdgpu_buffer_rsrc_t rs, const int art_bytes,
     float imp = 0;
 #pragma unroll
     for (int k = 0; k < K; k++) {
-      const float fn = __builtin_amdgcn_fmed3f(sv[k], lo[k], hi[k]), dc = fn - f[k];
-      imp += dc * arr[k] * ((sv[k] - f[k]) - 0.5f * dc);
-      f[k] = fn;
+      const float dc = __builtin_amdgcn_fmed3f(sv[k], lor[k], hir[k]);
+      imp += dc * arr[k] * (sv[k] - 0.5f * dc);
+      f[k] += dc; s[k] -= dc;
     }
     const float improvement = wave_sum<4>(imp);
     if (improvement * scale < tol || niter >= itmax) break;
