@@ -849,7 +849,7 @@ DEV int pgs_many_body(const ManyCtx& c, const int lane) {
       impl = 0;
       done = improvement < iq.thr || niter >= itmax;
     };
-    if (c.ngrp >= 3) {
+    if (MJH_QUAD_DEPTH >= 3 && c.ngrp >= 3) {
       QOp o0 = nextFetch(), o1 = nextFetch(), o2;
       while (true) {
         o2 = nextFetch(); processQ(o0, impl); stepDone(); if (done) break;
