@@ -137,6 +137,29 @@ def test_s24_working_set_fits_eight_envs_per_cu(lib):
     assert 0 < nbytes <= 16 * 1280, nbytes
 
 
+def test_lds_layout_of_the_launches_that_wait_for_lds(lib):
+    """Capacity planning without a device (mjh_debug_lds_layout, tools/lds_layout.py).  Two budgets found by measurement in round 5: the assemble-only
+    launch of the window chain for S24D (contact capacity 96) fits 13.2 granules of 1280 B — nine environments per CU beside the window wavefronts
+    (25.3 KB, six per CU: S24D 5.28 instead of 5.75 M env-steps/s) —, and C3's four arms per wavefront fit 16 granules (eight workgroups per CU = all
+    2048 resident; pair-less models keep no LDS for per-env geom sizes)."""
+    import ctypes as C
+    def layout(m):
+        buf = C.create_string_buffer(8192)
+        n = lib.mjh_debug_lds_layout(m.ptr, buf, 8192)
+        assert n > 0
+        return dict((k, int(v)) for k, v in (ln.split() for ln in buf.value.decode().strip().splitlines()))
+    s24d = ms.scene("s24pen", 0.175, 96)
+    L = layout(s24d)
+    assert L["lds_bytes_pre"] == lib.mjh_query_lds_bytes_assemble(s24d.ptr) <= 14 * 1280 and L["lds_bytes"] == lib.mjh_query_lds_bytes(s24d.ptr)
+    # what that launch does not use lies behind its extent: the pair schedule, the condim-4 extension, the per-base scratch vectors
+    assert min(L["sched"], L["ext"], L["bv"], L["phi"]) * 4 >= L["lds_bytes_pre"] and max(L["con"], L["blki"], L["blkf"]) * 4 < L["lds_bytes_pre"]
+    s24 = ms.scene("s24")
+    assert lib.mjh_query_lds_bytes_assemble(s24.ptr) == 18192          # (the headline's assemble-only launch: unchanged, its waves wait for SIMDs, not LDS)
+    c3 = ms.scene("arm7", 1).replicate(4)
+    L3 = layout(c3)
+    assert L3["lds_bytes"] <= 16 * 1280 and L3["p_gsize"] == L3["gpos"] and L3["p_rbound"] == L3["gmat"], L3["lds_bytes"]
+
+
 def test_model_replicate_keeps_instances_apart(lib):
     """mjh_model_replicate (sub-wave packing): moving trees are copied, static geometry is shared, no pair joins two instances"""
     import mujoco_sim_amd as ms
