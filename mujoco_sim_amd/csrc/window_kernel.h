@@ -293,8 +293,12 @@ DEV void wn_run32(const DConst* __restrict__ C, const DState& S, const int env0,
 #pragma unroll
     for (int k = 0; k < NV; k++) asm volatile("" : "+v"(W.J[k]), "+v"(Jx[k]));
     asm volatile("s_nop 1");
-#define WN_ACC(sidx) _Pragma("unroll") for (int k = 0; k < NV; k++) { PP_FMAC_BC(acc[sidx], W.J[k], W.J[k], sidx); PP_FMAC_BC(acx[sidx], Jx[k], W.J[k], sidx); }
-    PP_BC16(WN_ACC)
+    // (dof k outermost, the 16 tile entries inside: consecutive multiply-adds go to DIFFERENT accumulators.  Entry after entry the compiler put an
+    //  `s_nop` between every two of them — its hazard model counts the accumulator of a DPP multiply-add as a DPP source of the next one — and a lone
+    //  wave pays an issue slot for each: half of the tile build's slots.  Every accumulator still sums its dofs in the same order: bitwise.)
+#define WN_ACC(sidx) PP_FMAC_BC(acc[sidx], W.J[k], W.J[k], sidx); PP_FMAC_BC(acx[sidx], Jx[k], W.J[k], sidx);
+#pragma unroll
+    for (int k = 0; k < NV; k++) { PP_BC16(WN_ACC) }
 #undef WN_ACC
     float diag = 0.0f;
 #pragma unroll
@@ -547,8 +551,9 @@ DEV void wn_run64(const DConst* __restrict__ C, const DState& S, const int env0,
 #pragma unroll
       for (int k = 0; k < NV; k++) asm volatile("" : "+v"(W.J[k]), "+v"(Jg[k]));
       asm volatile("s_nop 1");
-#define WN_ACC(sidx) _Pragma("unroll") for (int k = 0; k < NV; k++) PP_FMAC_BC(acc[sidx], Jg[k], W.J[k], sidx);
-      PP_BC16(WN_ACC)
+#define WN_ACC(sidx) PP_FMAC_BC(acc[sidx], Jg[k], W.J[k], sidx);
+#pragma unroll
+      for (int k = 0; k < NV; k++) { PP_BC16(WN_ACC) }
 #undef WN_ACC
 #pragma unroll
       for (int sidx = 0; sidx < 16; sidx++) W.A[16 * G + sidx] = (16 * G + sidx) < lane ? ninv * acc[sidx] : 0.0f;
@@ -585,8 +590,9 @@ DEV void wn_run64(const DConst* __restrict__ C, const DState& S, const int env0,
 #pragma unroll
       for (int k = 0; k < NV; k++) asm volatile("" : "+v"(TL.J[k]), "+v"(Jg[k]));
       asm volatile("s_nop 1");
-#define WN_ACC(sidx) _Pragma("unroll") for (int k = 0; k < NV; k++) PP_FMAC_BC(acc[sidx], Jg[k], TL.J[k], sidx);
-      PP_BC16(WN_ACC)
+#define WN_ACC(sidx) PP_FMAC_BC(acc[sidx], Jg[k], TL.J[k], sidx);
+#pragma unroll
+      for (int k = 0; k < NV; k++) { PP_BC16(WN_ACC) }
 #undef WN_ACC
 #pragma unroll
       for (int c4 = 0; c4 < 4; c4++) {
@@ -750,8 +756,10 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
 #pragma unroll
     for (int k = 0; k < NV; k++) asm volatile("" : "+v"(W.J[k]));     // (materialised before the DPP reads below: no VALU write within two instructions of them)
     asm volatile("s_nop 1");
-#define WN_ACC(s) _Pragma("unroll") for (int k = 0; k < NV; k++) PP_FMAC_BC(acc[s], W.J[k], W.J[k], s);
-    PP_BC16(WN_ACC)
+    // (dof k outermost: consecutive multiply-adds go to different accumulators, no `s_nop` between them — see wn_run32's tile build)
+#define WN_ACC(s) PP_FMAC_BC(acc[s], W.J[k], W.J[k], s);
+#pragma unroll
+    for (int k = 0; k < NV; k++) { PP_BC16(WN_ACC) }
 #undef WN_ACC
     float diag = 0.0f;
 #pragma unroll
@@ -805,8 +813,9 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
 #pragma unroll
     for (int k = 0; k < NV; k++) asm volatile("" : "+v"(A.J[k]), "+v"(B.J[k]));
     asm volatile("s_nop 1");
-#define WN_ACX(sidx) _Pragma("unroll") for (int k = 0; k < NV; k++) PP_FMAC_BC(acx[sidx], A.J[k], B.J[k], sidx);
-    PP_BC16(WN_ACX)
+#define WN_ACX(sidx) PP_FMAC_BC(acx[sidx], A.J[k], B.J[k], sidx);
+#pragma unroll
+    for (int k = 0; k < NV; k++) { PP_BC16(WN_ACX) }
 #undef WN_ACX
     Xo[0] = make_float4(B.nw * acx[0], B.nw * acx[1], B.nw * acx[2], B.nw * acx[3]);
     Xo[1] = make_float4(B.nw * acx[4], B.nw * acx[5], B.nw * acx[6], B.nw * acx[7]);
