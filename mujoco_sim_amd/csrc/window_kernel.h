@@ -708,7 +708,17 @@ template <int NV> DEV void wn_jt2(const float* JA, const float xa, const float* 
     : [t] "+v"(tt), [d] "=&v"(dl), [e1] "=&v"(e1), [e2] "=&v"(e2) \
     : [nf] "v"(nf), [a0] "v"(T.x), [a1] "v"(T.y), [a2] "v"(T.z), [a3] "v"(T.w), [hf] "v"(A.half), [da] "v"(dla), [ta] "v"(tta), [qs] "v"(iq.qs))
 
-template <int NV, int NW>
+// Cross tiles of the register-resident pairs in LDS instead of registers (the 24-slot instance): 16 values per pair and lane that the sweep uses once,
+// in four `ds_read_b128` instead of sixteen copies out of the accumulation half of the register file (a VALU instruction takes its operands from
+// the architectural half only; the kernel holds 422 registers) — 48 registers fewer, 12 KB of LDS per wavefront behind the tier.  Same values,
+// same arithmetic: bitwise.
+#ifndef WN_X_LDS
+#define WN_X_LDS 1
+#endif
+// Only launches WITHOUT the LDS tier take it (instance XL; S24's default): beside the tier's 36 KB the 12 KB would cost the fourth window wavefront
+// of a CU its place (S24D: 5.83 -> 4.67 M, measured).
+#define WN_XLDS_BYTES(nvt, nw) (((nvt) == 24 && WN_FILL && WN_X_LDS) ? ((nw) / 2) * 4 * 64 * 16 : 0)
+template <int NV, int NW, bool XL = false>
 __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restrict__ C, const DState S, const int env0, const int nenv, const int nl, const int xflags, const int n32waves, const int n64waves) {
   // the first n64waves wavefronts: the section of the envs with the most rows (one per wavefront, 64-row windows); the next n32waves: the
   // section of the envs with many rows (two per wavefront, 32-row windows); dispatched first — they are the launch's longest jobs
@@ -822,8 +832,16 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
     Xo[2] = make_float4(B.nw * acx[8], B.nw * acx[9], B.nw * acx[10], B.nw * acx[11]);
     Xo[3] = make_float4(B.nw * acx[12], B.nw * acx[13], B.nw * acx[14], B.nw * acx[15]);
   };
+  constexpr bool X_LDS = XL && NV == 24 && WN_FILL && WN_X_LDS;
+  float4* const xs = (float4*)wn_lds + (4 * nl * NX4) * 16 + lane;                              // (behind the tier) pair j, quarter c of the lane at xs[(4 j + c) * 64]
 #pragma unroll
-  for (int j = 0; j < NW / 2; j++) if (2 * j + 1 < nwmax) make_cross(win[2 * j], win[2 * j + 1], X[j]);
+  for (int j = 0; j < NW / 2; j++) if (2 * j + 1 < nwmax) {
+    make_cross(win[2 * j], win[2 * j + 1], X[j]);
+    if constexpr (X_LDS) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) xs[(4 * j + c) * 64] = X[j][c];
+    }
+  }
   for (int w = NW; w < nwl; w++) { WnWin<NV> W; load_rows(W, w); make_tile(W); store_ext(xl + (w - NW) * NX4 * 16, W, 0.0f); }
   for (int w = nwl; w < nwmax; w++) { WnWin<NV> W; load_rows(W, w); make_tile(W); if (mine) store_ext(xg + w * NX4 * 16, W, 0.0f); }
   // a tier window for a sweep: record and force (a lane without an env, or with one that finished in the assemble launch, sweeps zero rows)
@@ -961,6 +979,10 @@ __global__ __launch_bounds__(64, 1) void mjh_window_kernel(const DConst* __restr
         if (2 * j + 1 < nwmax) {
           WnWin<NV>& A = win[2 * j]; WnWin<NV>& B = win[2 * j + 1];
           if constexpr (NV == 24 && WN_FILL) {
+            if constexpr (X_LDS) {
+              const float4 x0 = xs[(4 * j) * 64], x1 = xs[(4 * j + 1) * 64], x2 = xs[(4 * j + 2) * 64], x3 = xs[(4 * j + 3) * 64];      // (requested here: they arrive during window A's chain)
+              sweep_pair_fill(A, B, x0, x1, x2, x3, f[2 * j], f[2 * j + 1]);
+            } else
             sweep_pair_fill(A, B, X[j][0], X[j][1], X[j][2], X[j][3], f[2 * j], f[2 * j + 1]);
           } else {
           const float ua = wn_dot<NV>(A.J, a_lo, a_hi), ub = wn_dot<NV>(B.J, a_lo, a_hi);
