@@ -1,6 +1,6 @@
 # window kernel (XL instance): tiles of the windows from WN_TILE_LDS0 on in LDS as well — A/B against the committed build (cross tiles only)
 set -u; cd ${GRAFT_REPO_ROOT:-/root/repo}; mkdir -p gpurun_out/r05s6
-H=build_exp/xonly/libmjhip.so
+H=build_exp/head/libmjhip.so
 {
 python tools/state_hash.py s24 1024 450 2>&1 | grep STATEHASH
 MJHIP_LIB=$H python tools/state_hash.py s24 1024 450 2>&1 | grep STATEHASH
