@@ -169,8 +169,11 @@ if sq:
     json.dump(sqsum, open(os.path.join(dst, f"{tag}_{cfg}_sq.json"), "w"), indent=1)
     # whole step launch: VALU wave-instructions per env-step and the fraction of lanes live in them, into the traffic record (bench.py
     # turns the first into an issue fraction with the rate IT measures: x env-steps/s / (1024 SIMDs x 2.4 GHz / 4 clocks))
-    vi = sum(m.get("SQ_INSTS_VALU", 0.0) for m in sqsum.values()); va = sum(m.get("SQ_ACTIVE_INST_VALU", 0.0) for m in sqsum.values())
-    vt = sum(m.get("SQ_THREAD_CYCLES_VALU", 0.0) for m in sqsum.values())
+    # (only the kernels that run in EVERY step launch of the timed region: an instance met a few times while the scene settles — the window kernel's
+    #  tier variant of S24's first steps — is listed above but is not part of a step)
+    every = {kn for kn, cs in sq.items() if max(len(v) for v in cs.values()) >= timed}
+    vi = sum(m.get("SQ_INSTS_VALU", 0.0) for kn, m in sqsum.items() if kn in every); va = sum(m.get("SQ_ACTIVE_INST_VALU", 0.0) for kn, m in sqsum.items() if kn in every)
+    vt = sum(m.get("SQ_THREAD_CYCLES_VALU", 0.0) for kn, m in sqsum.items() if kn in every)
     tp = os.path.join(dst, f"{tag}_{cfg}_traffic.json")
     if vi > 0 and os.path.exists(tp):
         tj = json.load(open(tp))
