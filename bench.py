@@ -157,6 +157,7 @@ class S24D(S24):
 
 class C2(S24):
     name = "c2"; settle_steps = 200; min_ncon = None
+    cohorts = 4       # round 5: 0.477 - 0.478 M on four cohorts against 0.470 - 0.472 M on three (two same-call A/Bs)
     label = ("C2: 64 free boxes (nv 384), half-extents U[0.05,0.125]^3, 4x4x4 lattice (pitch 0.3 m, z0 0.5..1.4) with +-0.01 m jitter and "
              "random orientation, on the empty.xml floor")
 
@@ -179,7 +180,7 @@ class C3(Workload):
              "PD ddq = 200 (q* - q) - 50 qd in the engine, targets U[limits] re-drawn every 200 steps; four arms per wavefront (mjh_model_replicate)")
 
     pack = 4          # four arms per wavefront (7 of 64 lanes busy otherwise): mjh_model_replicate, HISTORY.md §9
-    cohorts = 3       # a 0.10 ms launch of 1024 wavefronts leaves the chip half empty: 74 / 79 M env-steps/s with 2 / 3 cohorts (four: 54 M, the per-step join for the publish copy costs more than the overlap gives; tools/c3_sweep.sh)
+    cohorts = 2       # round 5, with all 2048 workgroups resident (16 LDS granules): 101.4 - 101.7 M on two cohorts against 99.7 - 99.9 M on three, three same-call A/Bs (round 4: 74 / 79 M with 2 / 3 cohorts; four: 54 M, the per-step join for the publish copy costs more than the overlap gives; tools/c3_sweep.sh)
 
     def build(self, device, stream):
         self.model = self.packed(self.ms.scene("arm7", 1))
