@@ -232,6 +232,7 @@ typedef struct mjh_load_options {
   unsigned odom_joints;             /* ~add_odom_joints mask: bits 0..5 = lin x y z, ang x y z (mj_sim.cpp:337-415) */
   int nrobot_pose;                  /* ~pose_init entries (mj_sim.cpp:312-335): root body names and x y z roll pitch yaw each */
   const char* const* robot_pose_body; const double* robot_pose;
+  int parent_child_exclude;         /* disable_parent_child_collision_level (mujoco_sim.launch:7; mujoco_compile.cpp:250-290): see mjh_load_set_parent_child_exclude; 0 adds nothing */
 } mjh_load_options;
 void mjh_load_default_options(mjh_load_options*);
 mjh_model* mjh_load_mjcf_files_opt(const char* const* paths, int n, const mjh_load_options* options);
@@ -250,7 +251,9 @@ void mjh_load_set_odom_joints(unsigned mask);
 /* launch argument disable_parent_child_collision_level of the reference (mujoco_sim.launch:7, default 1): its mujoco_compile writes
  * <exclude> pairs between every body and its first `level` ancestors into the compiled robot file (mujoco_compile.cpp:250-290).
  * Per-thread setting for all later loads; 0 (default) adds nothing (adjacent bodies are filtered by the model compiler anyway,
- * as MuJoCo's filterparent does). */
+ * as MuJoCo's filterparent does).  Applied to robot files only — the files after the first of mjh_load_mjcf_files, or the one file of a
+ * single-file load —, to the bodies that file adds; the walk ends at the file's top level (the reference names the robot's geom-less
+ * wrapper body there, mujoco_compile.cpp:272-276: no collision is excluded by that pair). */
 void mjh_load_set_parent_child_exclude(int level);
 /* rosparam ~pose_init (mj_sim.cpp:312-335): position and roll / pitch / yaw (radians, tf2 setRPY) written onto the root body
  * of a robot file, by body name; pose NULL removes the entry, root_body NULL removes all */
@@ -485,7 +488,11 @@ int mjh_get_steps_per_launch(const mjh_engine*);
  * hipGraphLaunch; the graph is captured again whenever something its kernels take by value changes.  Same kernels, same arguments, same
  * order: results are bitwise those of the separate launches.  mode (also MJH_CHAIN_GRAPH): 1 (default) the many-body chain only, 2 the
  * window chain as well (measured slower on S24: two plain launches stay the default there), 0 every launch on its own.
- * mjh_launches_per_step: host-side launches mjh_step issues per cohort-step (1 with the graph; 2 / 3 / 5 without). */
+ * mjh_launches_per_step: queue entries the LAST mjh_step issued per cohort-step — 1 when it replayed a captured graph, else the chain's
+ * kernel launches (2 window chain, 3 / 5 many-body block / dense chain, 1 fused kernel): plain launches are also what a step falls back to
+ * on the NULL stream, on a stream that is already being captured and after a failed capture / instantiate (latched per cohort and variant).
+ * Before the first step (and after mjh_set_cohorts): what the next step intends.  A retired graph exec is destroyed only after the
+ * stream it was last launched on has drained. */
 void mjh_set_chain_graph(int mode);
 int mjh_launches_per_step(const mjh_engine*);
 /* HIP-event timing of the step-kernel launches on the stream they run on: enable (on = 1: every launch, on = N > 1: every
@@ -534,7 +541,14 @@ int mjh_group_uses_rccl(const mjh_group*);
  * milliseconds and the number of publishes since the last call */
 int mjh_group_set_publish_timing(mjh_group*, int on);
 int mjh_group_get_publish_timing(mjh_group*, double* mean_ms, int* count);
-void mjh_group_set_transport(int mode);   /* groups created afterwards: 0 = RCCL when available (default), 1 = peer copies */
+void mjh_group_set_transport(int mode);   /* groups created afterwards: 0 = RCCL when available and the devices are distinct (default), 1 = peer copies,
+                                             2 = RCCL also when a device is listed twice (a real RCCL refuses that at ncclCommInitAll and the group falls back to peer
+                                             copies; the recording stand-in of tests/nccl_stub, named by MJH_RCCL_LIB, accepts it: N ranks on one device) */
+/* Test hook, no device needed: the RCCL call sequence of `publishes` exchanges with `ndev` ranks exactly as mjh_group_publish issues it
+ * (per_thread != 0: a host thread per rank enqueues its own ncclAllGather; 0: one grouped call inside ncclGroupStart / ncclGroupEnd), between
+ * ncclCommInitAll and ncclCommDestroy, against the library MJH_RCCL_LIB names (default: the process's RCCL); buffers and streams are
+ * made-up addresses that are only passed through. */
+int mjh_debug_rccl_exchange(int ndev, int per_thread, unsigned long slot_floats, int publishes);
 /* Host threads of a group (groups created afterwards; default 1, environment MJH_GROUP_THREADS): 1 = one persistent host thread per device
  * issues that device's launches, exports and its rank of the all-gather, every mjh_group_* call posts one job per device and waits for
  * them — the host time of a call is that of ONE device (the reference steps on one thread, mj_main.cpp:203: with eight devices behind

@@ -103,7 +103,7 @@ Model_p = C.POINTER(Model)
 
 class LoadOptions(C.Structure):
     _fields_ = [("boundmass", C.c_double), ("boundinertia", C.c_double), ("robot_gravcomp", C.c_int), ("load_meshes", C.c_int),
-                ("odom_joints", C.c_uint), ("nrobot_pose", C.c_int), ("robot_pose_body", C.POINTER(C.c_char_p)), ("robot_pose", c_double_p)]
+                ("odom_joints", C.c_uint), ("nrobot_pose", C.c_int), ("robot_pose_body", C.POINTER(C.c_char_p)), ("robot_pose", c_double_p), ("parent_child_exclude", C.c_int)]
 
 
 # every symbol include/mjhip.h declares: (name, restype, argtypes)
@@ -236,6 +236,7 @@ SYMBOLS = [
     ("mjh_group_state_stride", C.c_int, [_vp]),
     ("mjh_group_uses_rccl", C.c_int, [_vp]),
     ("mjh_group_set_transport", None, [C.c_int]),
+    ("mjh_debug_rccl_exchange", C.c_int, [C.c_int, C.c_int, C.c_ulong, C.c_int]),
     ("mjh_group_set_host_threads", None, [C.c_int]),
     ("mjh_group_host_threads", C.c_int, [C.c_void_p]),
     ("mjh_group_wait_publish", C.c_int, [_vp, C.c_int, _vp]),

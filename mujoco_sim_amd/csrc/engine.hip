@@ -80,7 +80,8 @@ struct mjh_engine {
   bool order_valid = false;   // d_order holds a full-range permutation (split API); mjh_step sorts per cohort
   // one captured graph per cohort and variant of its step chain (mjh_step: assemble -> [dense build -> dense solve] -> solve -> integrate of the
   // many-body layout; assemble -> window kernel of the window chain): the chain is queued with ONE hipGraphLaunch per cohort-step
-  struct ChainGraph { hipGraphExec_t exec = nullptr; unsigned char S[sizeof(DState)]; int g0 = -1, n = -1, key = -1; };
+  struct ChainGraph { hipGraphExec_t exec = nullptr; unsigned char S[sizeof(DState)]; int g0 = -1, n = -1, key = -1; bool nocap = false; };   // nocap: capture / instantiate failed once for this slot — plain launches from then on
+  int last_launches = 0;      // queue entries the last mjh_step issued per cohort-step (1: a captured graph; else the chain's kernel launches)
   ChainGraph cgraph[MJH_MAX_COHORTS][8];
   int steps_per_launch = 8;   // mjh_step(n): steps one launch of a loop-capable kernel instance runs (mjh_set_steps_per_launch; 1: one launch per step)
   long order_age = 0; int order_G = 0; int last_chunk = 1;   // last_chunk: steps of the previous launch (the sort is renewed when a multiple of MJH_ORDER_EVERY was crossed)   // mjh_step renews its per-cohort sorts every MJH_ORDER_EVERY-th step; order_G: cohort count they were made for (-1: none)
@@ -395,6 +396,9 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
     M.window = (small_free && M.maxcon <= MJH_WINDOW_MAXCON && M.pgs_row_order != 0 && g_window_solver && nv <= 32 && m->njnt <= 16 && m->nq <= 40) ? 1 : 0;
     M.win_nvt = nv <= 24 ? 24 : 32;
     M.win_maxw = std::max(1, std::min(WN_MAXW, (M.maxefc + 15) / 16));
+    // (tests: MJH_WINDOW_MAXW lowers a model's window capacity below its row capacity, so that the hand-over's own capacity rule — whole blocks
+    //  dropped behind the last one that fits, window_emit — can be met with a few dozen rows instead of more than 16 WN_MAXW = 384)
+    if (const char* v = getenv("MJH_WINDOW_MAXW")) M.win_maxw = std::max(1, std::min(M.win_maxw, atoi(v)));
     L.qpos = put(m->nq);
     L.qvel = put(nv); L.qvref = put(nv); L.ws = put(nv); L.qacc = put(nv); L.smooth = put(nv); L.asmooth = put(nv); L.passive = put(nv);
     L.bias = put(nv); L.applied = put(nv); L.tmpv = put(nv); L.tmpv2 = put(nv);
@@ -933,20 +937,25 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
       if (((chain_big && g_chain_graph >= 1) || (chain_win && g_chain_graph >= 2)) && k == 1 && st != nullptr) {
         const int key = (dn ? 1 : 0) | (with_inverse ? 2 : 0) | ((nl > 0 ? 1 : 0) << 2);
         mjh_engine::ChainGraph& cg = e->cgraph[g][key & 7];
-        if (!cg.exec || cg.g0 != g0 || cg.n != g1 - g0 || cg.key != (key | (nl << 8)) || std::memcmp(cg.S, &e->S, sizeof(DState)) != 0) {
-          if (cg.exec) { (void)hipGraphExecDestroy(cg.exec); cg.exec = nullptr; }
+        if (!cg.nocap && (!cg.exec || cg.g0 != g0 || cg.n != g1 - g0 || cg.key != (key | (nl << 8)) || std::memcmp(cg.S, &e->S, sizeof(DState)) != 0)) {
+          if (cg.exec) {
+            // the retired exec owns the kernel arguments of its launches and mjh_step is asynchronous: its last hipGraphLaunch may still be
+            // running on this stream — wait for it before the exec goes (re-capture is rare: a descriptor / range / variant change)
+            HIPCHK(hipStreamSynchronize(st));
+            (void)hipGraphExecDestroy(cg.exec); cg.exec = nullptr;
+          }
           hipGraph_t gr = nullptr;
           if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             rc = issue_chain();
             const hipError_t ce = hipStreamEndCapture(st, &gr);        // (always ended, also when a launch inside failed)
             if (!rc && ce != hipSuccess) { mjh_set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce)); rc = MJH_ERR_NO_DEVICE; }
-            if (!rc && hipGraphInstantiate(&cg.exec, gr, nullptr, nullptr, 0) != hipSuccess) { cg.exec = nullptr; (void)hipGetLastError(); }
+            if (!rc && hipGraphInstantiate(&cg.exec, gr, nullptr, nullptr, 0) != hipSuccess) { cg.exec = nullptr; cg.nocap = true; (void)hipGetLastError(); }   // (latched: no capture attempt per step from here on)
             if (gr) (void)hipGraphDestroy(gr);
             if (!rc && cg.exec) { std::memcpy(cg.S, &e->S, sizeof(DState)); cg.g0 = g0; cg.n = g1 - g0; cg.key = key | (nl << 8); }
           } else (void)hipGetLastError();                                // (a stream that cannot be captured: plain launches below)
         }
-        if (!rc) { if (cg.exec) HIPCHK(hipGraphLaunch(cg.exec, st)); else rc = issue_chain(); }
-      } else rc = issue_chain();
+        if (!rc) { if (cg.exec) { HIPCHK(hipGraphLaunch(cg.exec, st)); e->last_launches = 1; } else { rc = issue_chain(); e->last_launches = chain_big ? (dn ? 5 : 3) : (chain_win ? 2 : 1); } }
+      } else { rc = issue_chain(); e->last_launches = chain_big ? (dn ? 5 : 3) : (chain_win ? 2 : 1); }
       if (ta && !rc) HIPCHK(hipEventRecord(tb, st));
     }
     e->last_chunk = k;
@@ -981,10 +990,13 @@ extern "C" int mjh_set_timestep(mjh_engine* e, double dt) {
 }
 extern "C" double mjh_get_timestep(const mjh_engine* e) { return e ? e->M.timestep_d : 0.0; }
 static int reset_dense_choice(mjh_engine* e);
-extern "C" int mjh_set_cohorts(mjh_engine* e, int n) { ENG(e); int rc = set_cohorts(e, n); return rc ? rc : reset_dense_choice(e); }
+extern "C" int mjh_set_cohorts(mjh_engine* e, int n) { ENG(e); e->last_launches = 0; int rc = set_cohorts(e, n); return rc ? rc : reset_dense_choice(e); }
 extern "C" int mjh_get_cohorts(const mjh_engine* e) { return e ? e->ncohort : 0; }
 extern "C" int mjh_launches_per_step(const mjh_engine* e) {
   if (!e) return 0;
+  // what the last mjh_step actually queued per cohort-step (1: one captured graph; else the kernel launches of the chain it issued — 3 / 5
+  // for the many-body layout's block / dense chain, 2 for the window chain); before the first step: what the next one intends
+  if (e->last_launches > 0) return e->last_launches;
   const bool big = e->M.big && e->split3, win = !big && e->M.window && e->S.wbuf;
   const int chain = big ? (e->M.dense ? 5 : 3) : (win ? 2 : 1);
   return ((big && g_chain_graph >= 1) || (win && g_chain_graph >= 2)) ? 1 : chain;

@@ -43,6 +43,7 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;      // optional: after a partial failure of a per-thread exchange
   bool ok() const { return lib && CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd; }
 };
 Rccl* load_rccl() {
@@ -50,8 +51,12 @@ Rccl* load_rccl() {
   if (tried) return r.ok() ? &r : nullptr;
   tried = true;
   // a process that already holds RCCL (torch bundles its own) must not get a second copy: look the symbols up globally first
-  const char* names[] = {nullptr, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-  for (const char* n : names) {
+  // MJH_RCCL_LIB names the library instead (tests: tests/nccl_stub — a recording stand-in that lets the grouped-call and the
+  // per-thread sequence run with N ranks where there is one device or none)
+  const char* forced = getenv("MJH_RCCL_LIB");
+  const char* names[] = {forced && *forced ? forced : nullptr, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (int ni = 0; ni < (forced && *forced ? 1 : 4); ni++) {
+    const char* n = names[ni];
     void* h = n ? dlopen(n, RTLD_NOW | RTLD_GLOBAL) : dlopen(nullptr, RTLD_NOW);
     if (!h) continue;
     if (!dlsym(h, "ncclAllGather")) { if (n) dlclose(h); continue; }
@@ -62,11 +67,12 @@ Rccl* load_rccl() {
     r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    r.CommAbort = (decltype(r.CommAbort))dlsym(h, "ncclCommAbort");
     if (r.ok()) return &r;
   }
   return nullptr;
 }
-int g_transport = 0;   // 0: RCCL when it can be loaded (and the devices are distinct), 1: peer copies
+int g_transport = 0;   // 0: RCCL when it can be loaded (and the devices are distinct), 1: peer copies, 2: RCCL also for repeated devices (only a stand-in library accepts that: tests)
 }  // namespace
 
 struct mjh_group {
@@ -95,7 +101,7 @@ struct mjh_group {
   bool rccl_per_thread = true;     // threaded host: every device's thread enqueues its own ncclAllGather (NCCL's one-thread-per-device use) instead of one grouped call
 };
 
-extern "C" void mjh_group_set_transport(int mode) { g_transport = mode == 1 ? 1 : 0; }
+extern "C" void mjh_group_set_transport(int mode) { g_transport = mode == 1 ? 1 : (mode == 2 ? 2 : 0); }
 static int g_host_threads = getenv("MJH_GROUP_THREADS") ? atoi(getenv("MJH_GROUP_THREADS")) : 1;
 extern "C" void mjh_group_set_host_threads(int on) { g_host_threads = on ? 1 : 0; }      // groups created afterwards
 extern "C" int mjh_group_host_threads(const mjh_group* g) { return g && g->pool ? g->pool->size() : 0; }
@@ -109,6 +115,77 @@ static int for_devices(mjh_group* g, const std::function<int(int)>& fn) {
   }
   for (int k = 0; k < g->ndev; k++) { const int rc = fn(k); if (rc) return rc; }
   return MJH_OK;
+}
+
+
+// The exchange of one publish over RCCL: every rank's all-gather of `slot` floats on its communication stream, then after(k) per device.
+//  * pool != nullptr (a host thread per device): every device's thread enqueues its own rank (the library's one-thread-per-device use).
+//    Nothing that can fail stands between a thread and its ncclAllGather — the device was selected by the thread's init job and by stage A —,
+//    so no rank is left waiting for a partner that returned early; if a rank's call itself fails, the communicators are aborted (the other
+//    ranks' collectives would otherwise stay enqueued without a partner) and the error is returned.
+//  * pool == nullptr: ONE grouped call on the caller's thread, ncclGroupStart .. ncclGroupEnd around the ranks; every exit path passes GroupEnd.
+// set_device = false and after = nullptr: the call sequence alone (mjh_debug_rccl_exchange: no HIP call at all).
+static int rccl_exchange(Rccl* R, int ndev, const int* dev, float* const* send, float* const* recv, size_t slot, ncclComm_t* ncomm, hipStream_t* comm,
+                         HostPool* pool, bool set_device, const std::function<int(int)>& after) {
+  auto errtext = [&](ncclResult_t r) { return std::string("ncclAllGather: ") + (R->GetErrorString ? R->GetErrorString(r) : "failed"); };
+  if (pool) {
+    std::vector<ncclResult_t> res((size_t)ndev, ncclSuccess);
+    std::string err;
+    int rc = pool->run([&](int k) -> int {
+      if (set_device) (void)hipSetDevice(dev[k]);
+      res[(size_t)k] = R->AllGather(send[k], recv[k], slot, ncclFloat, ncomm[k], comm[k]);
+      if (res[(size_t)k] != ncclSuccess) { mjh_set_error(errtext(res[(size_t)k])); return MJH_ERR_NO_DEVICE; }
+      return after ? after(k) : MJH_OK;
+    }, &err);
+    if (rc) {
+      bool partial = false;
+      for (int k = 0; k < ndev; k++) if (res[(size_t)k] != ncclSuccess) partial = true;
+      if (partial && R->CommAbort) for (int k = 0; k < ndev; k++) if (ncomm[k]) { (void)R->CommAbort(ncomm[k]); ncomm[k] = nullptr; }
+      mjh_set_error(err);
+    }
+    return rc;
+  }
+  ncclResult_t r = R->GroupStart();
+  hipError_t he = hipSuccess;
+  if (r == ncclSuccess) {
+    for (int k = 0; k < ndev && r == ncclSuccess && he == hipSuccess; k++) {
+      if (set_device) he = hipSetDevice(dev[k]);
+      if (he == hipSuccess) r = R->AllGather(send[k], recv[k], slot, ncclFloat, ncomm[k], comm[k]);
+    }
+    const ncclResult_t r2 = R->GroupEnd();
+    if (r == ncclSuccess) r = r2;
+  }
+  if (he != hipSuccess) { mjh_set_error(std::string("hipSetDevice (all-gather): ") + hipGetErrorString(he)); return MJH_ERR_NO_DEVICE; }
+  if (r != ncclSuccess) { mjh_set_error(errtext(r)); return MJH_ERR_NO_DEVICE; }
+  for (int k = 0; k < ndev && after; k++) {
+    if (set_device) { const hipError_t e2 = hipSetDevice(dev[k]); if (e2 != hipSuccess) { mjh_set_error(std::string("hipSetDevice: ") + hipGetErrorString(e2)); return MJH_ERR_NO_DEVICE; } }
+    const int rc = after(k); if (rc) return rc;
+  }
+  return MJH_OK;
+}
+// The RCCL call sequence of one publish with `ndev` ranks and no device at all (tests on the CPU box, with MJH_RCCL_LIB = a recording
+// stand-in): ncclCommInitAll, `publishes` exchanges of `slot` floats per rank exactly as mjh_group_publish issues them — per_thread != 0: a
+// host thread per rank, else one grouped call —, ncclCommDestroy.  Buffers and streams are distinct made-up addresses, never dereferenced here.
+extern "C" int mjh_debug_rccl_exchange(int ndev, int per_thread, unsigned long slot, int publishes) {
+  if (ndev <= 0 || ndev > 64) { mjh_set_error("mjh_debug_rccl_exchange: bad rank count"); return MJH_ERR_ARG; }
+  Rccl* R = load_rccl();
+  if (!R) { mjh_set_error("mjh_debug_rccl_exchange: no RCCL library (MJH_RCCL_LIB)"); return MJH_ERR_NO_DEVICE; }
+  std::vector<int> dev((size_t)ndev); std::vector<ncclComm_t> nc((size_t)ndev, nullptr);
+  std::vector<float*> send((size_t)ndev), recv((size_t)ndev); std::vector<hipStream_t> st((size_t)ndev);
+  for (int k = 0; k < ndev; k++) {
+    dev[(size_t)k] = k; send[(size_t)k] = (float*)(uintptr_t)(0x10000000ull + 0x100000ull * (unsigned)k); recv[(size_t)k] = (float*)(uintptr_t)(0x20000000ull + 0x100000ull * (unsigned)k);
+    st[(size_t)k] = (hipStream_t)(uintptr_t)(0x1000u + (unsigned)k);
+  }
+  ncclResult_t r = R->CommInitAll(nc.data(), ndev, dev.data());
+  if (r != ncclSuccess) { mjh_set_error(std::string("ncclCommInitAll: ") + (R->GetErrorString ? R->GetErrorString(r) : "failed")); return MJH_ERR_NO_DEVICE; }
+  std::unique_ptr<HostPool> pool;
+  if (per_thread) pool.reset(new HostPool(ndev, nullptr, mjh_last_error));
+  int rc = MJH_OK;
+  for (int p = 0; p < publishes && !rc; p++)
+    rc = rccl_exchange(R, ndev, dev.data(), send.data(), recv.data(), (size_t)slot, nc.data(), st.data(), pool.get(), false, nullptr);
+  pool.reset();
+  for (int k = 0; k < ndev; k++) if (nc[(size_t)k]) (void)R->CommDestroy(nc[(size_t)k]);
+  return rc;
 }
 
 extern "C" void mjh_group_destroy(mjh_group* g) {
@@ -180,7 +257,7 @@ extern "C" int mjh_group_create(const mjh_model* model, int nenv_total, const in
   GFAIL(hipSetDevice(g->dev[0]));
   GFAIL(hipEventCreate(&g->t0)); GFAIL(hipEventCreate(&g->t1));
 #undef GFAIL
-  if (g_transport == 0 && distinct) {
+  if ((g_transport == 0 && distinct) || g_transport == 2) {
     g->rccl = load_rccl();
     if (g->rccl) {
       g->ncomm.assign(ndev, nullptr);
@@ -279,33 +356,9 @@ extern "C" int mjh_group_publish(mjh_group* g, float* host_out) {
     GCHK(hipEventRecord(g->gathered[k], g->comm[k]));
     return MJH_OK;
   };
-  if (g->rccl && g->pool && g->rccl_per_thread) {
-    // one thread per device, each enqueues its own rank's all-gather on its communication stream (the library's one-thread-per-device use)
-    rc = for_devices(g, [&](int k) -> int {
-      GCHK(hipSetDevice(g->dev[k]));
-      const ncclResult_t r = g->rccl->AllGather(g->send[k], g->recv[k], g->slot, ncclFloat, g->ncomm[k], g->comm[k]);
-      if (r != ncclSuccess) { mjh_set_error(std::string("ncclAllGather: ") + (g->rccl->GetErrorString ? g->rccl->GetErrorString(r) : "failed")); return MJH_ERR_NO_DEVICE; }
-      return finish(k);
-    });
-    if (rc) return rc;
-  } else if (g->rccl) {
-    // every exit path passes ncclGroupEnd: a failure inside the group is remembered, not returned from
-    ncclResult_t r = g->rccl->GroupStart();
-    hipError_t he = hipSuccess;
-    if (r == ncclSuccess) {
-      for (int k = 0; k < g->ndev && r == ncclSuccess && he == hipSuccess; k++) {
-        he = hipSetDevice(g->dev[k]);
-        if (he == hipSuccess) r = g->rccl->AllGather(g->send[k], g->recv[k], g->slot, ncclFloat, g->ncomm[k], g->comm[k]);
-      }
-      const ncclResult_t r2 = g->rccl->GroupEnd();
-      if (r == ncclSuccess) r = r2;
-    }
-    if (he != hipSuccess) { mjh_set_error(std::string("hipSetDevice (all-gather): ") + hipGetErrorString(he)); return MJH_ERR_NO_DEVICE; }
-    if (r != ncclSuccess) {
-      mjh_set_error(std::string("ncclAllGather: ") + (g->rccl->GetErrorString ? g->rccl->GetErrorString(r) : "failed"));
-      return MJH_ERR_NO_DEVICE;
-    }
-    rc = for_devices(g, [&](int k) -> int { GCHK(hipSetDevice(g->dev[k])); return finish(k); });
+  if (g->rccl) {
+    rc = rccl_exchange(g->rccl, g->ndev, g->dev.data(), g->send.data(), g->recv.data(), g->slot, g->ncomm.data(), g->comm.data(),
+                       g->rccl_per_thread ? g->pool.get() : nullptr, true, [&](int k) -> int { return finish(k); });
     if (rc) return rc;
   } else {
     rc = for_devices(g, [&](int k) -> int {

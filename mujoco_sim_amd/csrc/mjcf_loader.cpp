@@ -112,6 +112,7 @@ static thread_local int g_load_meshes = 1;   // mjh_load_set_mesh_mode: 0 = skip
 struct Loader {
   mjh_builder* b = nullptr;
   bool degree = true, autolimits = false, balance = false, robot_file = false;
+  int nfiles = 1;                    // files of this load (mjh_load_mjcf_files): a single file is treated as the robot file by the per-robot rules that say so
   double bmass = 0, binertia = 0;   // <compiler boundmass boundinertia>, raised to the process-wide floor of mjh_load_set_bounds
   Defaults def;
   std::map<std::string, int> body_id, joint_id, mesh_id, site_id;
@@ -380,12 +381,17 @@ struct Loader {
       if (id < 0) { note += "mesh " + name + " not loaded (" + mjh_last_error() + "); "; continue; }
       mesh_id[name] = id;
     }
+    const int body_first = std::max(1, (int)body_parent.size());      // first body this file adds
     for (auto& c : root.kids) if (c->tag == "worldbody") if (!children(*c, 0)) return false;
-    // the wrapper's mujoco_compile writes <exclude> pairs between every body and its first `level` ancestors into the compiled robot file
+    // the wrapper's mujoco_compile writes <exclude> pairs between every body and its first `level` ancestors into the compiled ROBOT file
     // (disable_parent_child_collision, /root/reference/src/mujoco_compile.cpp:250-290; launch argument disable_parent_child_collision_level,
-    // default 1): the same rule as a load option, for robot files that come without their own exclude list
-    if (g_pc_exclude_level > 0)
-      for (int id = 1; id < (int)body_parent.size(); id++) {
+    // default 1): the same rule as a load option, for robot files that come without their own exclude list.  Applied to the bodies THIS
+    // file adds, and only to robot files — the files after the world file, or the one file of a single-file load (what mujoco_compile itself
+    // works on).  Where the reference's walk reaches the world it names the robot's wrapper body (`body1 = model name`,
+    // mujoco_compile.cpp:272-276; add_robot_body :195-216 creates it around the file's top-level bodies): that body has no geom of its own,
+    // so the pair excludes no collision and the walk simply ends here.
+    if (g_pc_exclude_level > 0 && (robot_file || nfiles == 1))
+      for (int id = body_first; id < (int)body_parent.size(); id++) {
         int p = id;
         for (int k = 0; k < g_pc_exclude_level; k++) { p = body_parent[p]; if (p <= 0) break; mjh_builder_add_exclude(b, p, id); }
       }
@@ -497,7 +503,7 @@ extern "C" mjh_model* mjh_load_mjcf_file(const char* path) { return mjh_load_mjc
 extern "C" mjh_model* mjh_load_mjcf_files(const char* const* paths, int n) {
   g_note.clear();
   if (!paths || n <= 0) { mjh_set_error("mjh_load_mjcf_files: no files"); return nullptr; }
-  Loader L;
+  Loader L; L.nfiles = n;
   for (int i = 0; i < n; i++) {
     std::ifstream f(paths[i] ? paths[i] : "");
     if (!f) { mjh_set_error(std::string("cannot open ") + (paths[i] ? paths[i] : "(null)")); L.abort(); return nullptr; }
@@ -518,7 +524,8 @@ extern "C" mjh_model* mjh_load_mjcf_files(const char* const* paths, int n) {
 extern "C" mjh_model* mjh_load_mjcf_files_opt(const char* const* paths, int n, const mjh_load_options* o) {
   if (!o) return mjh_load_mjcf_files(paths, n);
   const double sb = g_boundmass, si = g_boundinertia; const int sg = g_robot_gravcomp, sm = g_load_meshes; const unsigned so = g_odom_mask;
-  const auto sp = g_robot_pose;
+  const auto sp = g_robot_pose; const int sx = g_pc_exclude_level;
+  g_pc_exclude_level = o->parent_child_exclude < 0 ? 0 : o->parent_child_exclude;
   g_boundmass = o->boundmass; g_boundinertia = o->boundinertia; g_robot_gravcomp = o->robot_gravcomp < 0 ? -1 : (o->robot_gravcomp ? 1 : 0);
   g_load_meshes = o->load_meshes != 0; g_odom_mask = o->odom_joints & 63u;
   g_robot_pose.clear();
@@ -527,12 +534,12 @@ extern "C" mjh_model* mjh_load_mjcf_files_opt(const char* const* paths, int n, c
     g_robot_pose[o->robot_pose_body[k]] = a;
   }
   mjh_model* m = mjh_load_mjcf_files(paths, n);
-  g_boundmass = sb; g_boundinertia = si; g_robot_gravcomp = sg; g_load_meshes = sm; g_odom_mask = so; g_robot_pose = sp;
+  g_boundmass = sb; g_boundinertia = si; g_robot_gravcomp = sg; g_load_meshes = sm; g_odom_mask = so; g_robot_pose = sp; g_pc_exclude_level = sx;
   return m;
 }
 extern "C" void mjh_load_default_options(mjh_load_options* o) {
   if (!o) return;
-  o->boundmass = 0; o->boundinertia = 0; o->robot_gravcomp = -1; o->load_meshes = 1; o->odom_joints = 0; o->nrobot_pose = 0; o->robot_pose_body = nullptr; o->robot_pose = nullptr;
+  o->boundmass = 0; o->boundinertia = 0; o->robot_gravcomp = -1; o->load_meshes = 1; o->odom_joints = 0; o->nrobot_pose = 0; o->robot_pose_body = nullptr; o->robot_pose = nullptr; o->parent_child_exclude = 0;
 }
 extern "C" const char* mjh_load_note(void) { return g_note.c_str(); }
 extern "C" void mjh_load_set_bounds(double boundmass, double boundinertia) { g_boundmass = boundmass; g_boundinertia = boundinertia; }

@@ -60,7 +60,7 @@
 
 // Assemble launch (mjh_step_kernel with PH_PRE, free-body instance): the constraint blocks of this env -> window rows in global memory.
 // blki / blkf / J: the block tables in LDS (step_kernel.h); sinv = M^-1/2 per dof.  Returns the number of rows (0: too many, not written).
-// `clamp` (the assemble-only kernel instance, which has no sweep of its own to fall back to): rows beyond the model's window capacity (16 maxw) are dropped,
+// `clamp` (the assemble-only kernel instance, which has no sweep of its own to fall back to): blocks whose rows do not fit the model's window capacity (16 maxw) are dropped whole,
 // like contacts beyond maxcon (the caller raises the capacity flag), instead of handing nothing over.
 DEV int window_emit(float* __restrict__ wb, const int nvt, const int maxw, const int* blki, const float* blkf, const float* J, const float* sinv, const int nblk, const int lane, const bool clamp = false) {
   const int4* blki4 = (const int4*)blki;
@@ -73,7 +73,23 @@ DEV int window_emit(float* __restrict__ wb, const int nvt, const int maxw, const
     total += __shfl(wave_incl_scan_i(myn, lane), 63);
   }
   int nrow = total;
-  if (nrow > 16 * maxw) { if (!clamp) return 0; nrow = 16 * maxw; }
+  if (nrow > 16 * maxw) {
+    if (!clamp) return 0;
+    // keep whole blocks only: the longest prefix of blocks whose rows fit (a friction pyramid cut in the middle would leave a net
+    // tangential force — ADVICE r05); the rows behind it are dropped like contacts beyond maxcon
+    int kept = 0, cum0 = 0;
+    for (int b0 = 0; b0 < nblk; b0 += 64) {
+      const int b = b0 + lane;
+      const int myn = b < nblk ? (blki4[b].x >> 4) & 15 : 0;
+      const int incl = wave_incl_scan_i(myn, lane);
+      int cand = (cum0 + incl <= 16 * maxw) ? cum0 + incl : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) cand = max(cand, __shfl_xor(cand, o));
+      kept = max(kept, cand);
+      cum0 += __shfl(incl, 63);
+    }
+    nrow = kept;
+  }
   const int nwin = (nrow + 15) >> 4;
   // padding rows of the last window: zeros (inert: AR_qq = 0 -> -1 / AR_qq stored as 0)
   for (int t = lane; t < (16 * nwin - nrow) * nk; t += 64) {

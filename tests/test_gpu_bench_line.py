@@ -49,6 +49,17 @@ def test_driver_line_has_everything_the_contract_names():
         assert "error" not in line, (name, line)
         assert line["value"] > 0 and line["steps"] >= 6 and line["roofline_frac"] > 0 and line["overflow_envs"] <= 0.02 * line["envs"], (name, line)
     assert r["configs"]["s24d"]["overflow_envs"] == 0, "S24D: no env over the contact / row capacity (VERDICT r04 next #1)"
+    # VERDICT r05 #1a / #5: every extra runs as a process of its own (the stand-alone run's streams) and carries its whole roofline block;
+    # the 30-contact scene sits at the top level of the line, with its own roofline block and the measured contact / row histograms
+    for name, line in r["configs"].items():
+        rf2 = line["roofline"]
+        assert line["process"].startswith("own") and rf2["kernel_ms"] > 0 and abs(rf2["frac"] - line["roofline_frac"]) < 1e-15, name
+        assert rf2["traffic"] is None or rf2["traffic"] > rf2["algorithmic_bytes_per_env_step"] * rf2["envs_per_launch"], name
+        assert rf2["traffic"] is None or (rf2["valu_issue_frac"] and 0 < rf2["valu_issue_frac"] < 1 and 0 < rf2["valu_lane_util"] <= 1), name
+    assert r["value_30_contact"] == r["configs"]["s24d"]["value"] and r["roofline_30_contact"] == r["configs"]["s24d"]["roofline"]
+    c30 = r["config_30_contact"]
+    assert c30["overflow_envs"] == 0 and 24 <= c30["mean_ncon"] <= 40 and sum(c30["ncon_histogram"].values()) == 4096 and sum(c30["nefc_histogram"].values()) == 4096
+    assert sum(r["configs"]["c2"]["ncon_histogram"].values()) == 4096
     assert r["configs"]["s24d"]["mean_ncon"] >= 20 and r["configs"]["c2"]["mean_ncon"] >= 100 and r["configs"]["c4"]["mean_nefc"] >= 50
 
 

@@ -1,0 +1,141 @@
+"""Round 6 GPU tests: the window hand-over's own capacity rule, graph re-capture while steps are in flight, and
+the N-rank RCCL publish path executed on ONE device through the recording stand-in of tests/nccl_stub."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import mujoco_sim_amd as ms
+import orc
+from conftest import ROOT
+from helpers import oracle_s24
+from test_gpu_round5 import _s24d_seeds, S24D_HEAVY_SEEDS
+
+pytestmark = pytest.mark.gpu
+
+
+def test_window_hand_over_drops_whole_contacts_beyond_its_capacity(monkeypatch):
+    """ADVICE r05 (engine.hip:395 / window_emit): a window model whose rows can exceed the window capacity (16 rows x win_maxw; maxefc of a
+    128-contact model is 512 .. 768, the capacity 384) used to have its rows cut at the capacity — in the middle of a friction pyramid, which
+    leaves a net tangential force.  Now the hand-over keeps the longest prefix of whole blocks that fits: the oracle's own rule for maxefc
+    (a contact whose rows do not fit drops it and every later one).  Checked with the capacity lowered to 6 windows = 96 rows
+    (MJH_WINDOW_MAXW; S24D's settled piles carry 100 - 250 rows) against the oracle built with maxefc = 96: one teacher-forced step agrees to
+    round-off on every env, the capacity flag is raised exactly where rows were dropped, and the kept rows are a multiple of whole contacts."""
+    seeds = S24D_HEAVY_SEEDS[:6] + list(range(26))
+    m, e, tab = _s24d_seeds(seeds)
+    e.step(450)
+    t, q, v, w = e.get_state(); st0 = e.get_stats()
+    assert (st0[:, 3] & 3 == 0).all() and (st0[:, 1] > 96).sum() >= 16, "the sample must hold envs beyond 96 rows"
+    e.close()
+    monkeypatch.setenv("MJH_WINDOW_MAXW", "6")
+    m2, e2, _ = _s24d_seeds(seeds)
+    monkeypatch.delenv("MJH_WINDOW_MAXW")
+    mo = ms.scene("s24pen", 0.175, 96); mo.c.maxefc = 96           # the oracle's row capacity = the hand-over's
+    ds = [oracle_s24(mo, tab, i) for i in range(len(seeds))]
+    for i, d in enumerate(ds):
+        d.set_qpos(q[i]); d.f("qvel")[:] = v[i]; d.f("qacc_warmstart")[:] = w[i]; d.f("time")[0] = t[i]
+    e2.set_state(qpos=q, qvel=v, time=t, warmstart=w)
+    e2.step(1)
+    for d in ds:
+        d.step(1)
+    _, q2, v2, w2 = e2.get_state(); st = e2.get_stats()
+    over = st0[:, 1] > 96
+    onefc = np.array([d.i("nefc") for d in ds]); owarn = np.array([d.i("warn") for d in ds])
+    assert ((st[:, 3] & 2) != 0).tolist() == over.tolist(), "capacity flag exactly on the envs whose rows were dropped"
+    assert ((owarn & 2) != 0).tolist() == over.tolist()
+    assert (onefc <= 96).all() and (onefc[over] >= 96 - 5).all(), "the oracle kept whole contacts up to its capacity"
+    vo = np.array([d.f("qvel") for d in ds]); qo = np.array([d.f("qpos") for d in ds])
+    ev = np.abs(v2 - vo).max(1) / np.maximum(1.0, np.abs(vo).max(1)); eq = np.abs(q2 - qo).max(1)
+    print(f"WINDOW-CLAMP envs over capacity {int(over.sum())} of {len(seeds)}: qvel err over / within capacity {ev[over].max():.2e} / {ev[~over].max():.2e}, qpos {eq.max():.2e}")
+    # (a row set cut inside a pyramid differs from the oracle's by the force of the half-kept contact: 1e-2 .. 1e-1 in qvel on these piles)
+    assert ev.max() <= 5e-4 and eq.max() <= 1e-6, (ev.max(), eq.max())
+    e2.close()
+
+
+def test_graph_recapture_while_the_previous_graph_is_still_running():
+    """ADVICE r05 (engine.hip:937): a change of what a captured chain holds by value (here: xfrc_applied allocated, then the cohort count)
+    re-captures the graph while the launches of the old one may still be running on the cohort streams — the retired exec is destroyed only
+    after its stream has drained.  Same results as the plain launches, bitwise, with re-captures forced every few steps and no synchronisation
+    in between."""
+    lib = ms.capi.load()
+    outs = []
+    for graph in (2, 0):
+        lib.mjh_set_chain_graph(graph)
+        try:
+            m = ms.scene("s24"); nenv = 1536
+            e = ms.Engine(m, nenv); e.load_s24(); e.set_cohorts(3)
+            for k in range(24):
+                e.step(5)                                   # asynchronous: nothing waits for these launches ...
+                e.set_cohorts(2 + k % 3)                    # ... before the env ranges change and every slot is captured again
+            assert e.launches_per_step == (1 if graph else 2), "what the LAST step issued per cohort-step"
+            outs.append(e.get_state())
+            e.close()
+        finally:
+            lib.mjh_set_chain_graph(1)
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
+
+
+def _stub():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_rccl_sequence import build_stub
+    return build_stub()
+
+
+_GROUP_SCRIPT = r"""
+import ctypes as C, json, os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import mujoco_sim_amd as ms
+from mujoco_sim_amd.tables import load_model_tables
+lib = ms.capi.load()
+stub = C.CDLL(os.environ["MJH_RCCL_LIB"])
+m, z = load_model_tables(os.path.join({root!r}, "tests", "golden", "robot_c5_pendulum_bowl_mesh.npz"))
+nenv, nshard = 4096, 8
+spin = z["qvel0"][None, :] * np.random.default_rng(0xC5).uniform(0.5, 1.5, size=(nenv, 1))
+res = {{}}
+pubs = {{}}
+for label, transport, threads in (("rccl-stub/thread-per-rank", 2, 1), ("rccl-stub/grouped", 2, 0), ("peer-copies", 1, 1)):
+    stub.stub_reset()
+    lib.mjh_group_set_transport(transport); lib.mjh_group_set_host_threads(threads)
+    g = ms.Group(m, nenv, [0] * nshard)
+    lib.mjh_group_set_transport(0); lib.mjh_group_set_host_threads(1)
+    for (e0, n), e in zip(g.ranges, g.engines):
+        e.set_controlled_dofs(z["controlled"].astype(np.int32)); e.set_state(qvel=spin[e0:e0 + n])
+    for k in range(12):
+        g.step(3, True); g.publish_device()
+        for r in range(nshard):
+            g.wait_publish(r); g.release_publish(r)
+    pubs[label] = g.publish()
+    cnt = (C.c_int * 8)(); stub.stub_counters(cnt)
+    res[label] = {{"uses_rccl": bool(g.uses_rccl), "threads": int(lib.mjh_group_host_threads(g.h)), "allgathers": int(stub.stub_nlog()), "counters": list(cnt)}}
+    g.close()
+ref = pubs["peer-copies"]
+res["equal"] = {{k: bool(np.array_equal(v, ref)) for k, v in pubs.items()}}
+res["spread"] = float(np.abs(ref[:, -9:]).max())
+print(json.dumps(res))
+"""
+
+
+def test_eight_ranks_through_the_rccl_code_path_on_one_device_equal_the_peer_copy_transport():
+    """the RCCL path of mjh_group_publish has only ever run with ONE rank (RCCL refuses the same device twice and no
+    multi-GPU node is available).  With tests/nccl_stub as the library (MJH_RCCL_LIB; NCCL_STUB_COPY=1: the stand-in performs the
+    all-gather as device copies with the call's stream semantics) the group runs C5 as EIGHT ranks on device 0 through exactly the code an
+    8-GPU node runs — ncclCommInitAll over 8 devices, then per publish either 8 per-thread ncclAllGather calls or one grouped call — and
+    the gathered state equals the peer-copy transport's bit for bit, consumers waiting for and releasing every publish."""
+    env = dict(os.environ); env["MJH_RCCL_LIB"] = _stub(); env["NCCL_STUB_COPY"] = "1"
+    r = subprocess.run([sys.executable, "-c", _GROUP_SCRIPT.format(root=ROOT)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    a, b, c = res["rccl-stub/thread-per-rank"], res["rccl-stub/grouped"], res["peer-copies"]
+    assert a["uses_rccl"] and b["uses_rccl"] and not c["uses_rccl"]
+    assert a["threads"] == 8 and b["threads"] == 0
+    assert a["counters"][6] == 1, "the stand-in performed the copies"
+    assert a["allgathers"] == b["allgathers"] == 8 * 13 and c["allgathers"] == 0          # 12 publish_device + the final publish, 8 ranks each
+    assert (a["counters"][3], a["counters"][4]) == (0, 0) and (b["counters"][3], b["counters"][4]) == (13, 13), "per-thread: no group; one thread: one group per publish"
+    assert a["counters"][0] == b["counters"][0] == 1 and a["counters"][5] == 8 and a["counters"][1] == 8, "one ncclCommInitAll over 8 ranks, 8 ncclCommDestroy"
+    assert res["equal"] == {"rccl-stub/thread-per-rank": True, "rccl-stub/grouped": True, "peer-copies": True}
+    assert res["spread"] > 0.1
