@@ -43,31 +43,39 @@ static int (*p_hipEventRecord)(void*, void*);
 static int (*p_hipStreamWaitEvent)(void*, void*, unsigned);
 static int (*p_hipMemcpyAsync)(void*, const void*, size_t, int, void*);
 static void* ev[MAXR];
+static int hip_err, hip_where;     /* first failing HIP call of the copy mode: its code and which one (1 event create, 2 record, 3 wait, 4 copy, 5 barrier timeout) */
+#define HIPTRY(w, call) do { int e_ = (call); if (e_) { if (!hip_err) { hip_err = e_; hip_where = (w); } return 1; } } while (0)
 static struct { const void* send; size_t count; } pend[MAXR];
 static int arrived, epoch;
 
-static int copying(void) {
-  if (copy_mode < 0) {
-    const char* e = getenv("NCCL_STUB_COPY");
-    copy_mode = 0;
-    if (e && atoi(e)) {
-      p_hipEventCreateWithFlags = (int (*)(void**, unsigned))dlsym(RTLD_DEFAULT, "hipEventCreateWithFlags");
-      p_hipEventRecord = (int (*)(void*, void*))dlsym(RTLD_DEFAULT, "hipEventRecord");
-      p_hipStreamWaitEvent = (int (*)(void*, void*, unsigned))dlsym(RTLD_DEFAULT, "hipStreamWaitEvent");
-      p_hipMemcpyAsync = (int (*)(void*, const void*, size_t, int, void*))dlsym(RTLD_DEFAULT, "hipMemcpyAsync");
-      if (p_hipEventCreateWithFlags && p_hipEventRecord && p_hipStreamWaitEvent && p_hipMemcpyAsync) copy_mode = 1;
-    }
+static pthread_once_t copy_once = PTHREAD_ONCE_INIT;
+static void copy_init(void) {
+  const char* e = getenv("NCCL_STUB_COPY");
+  int mode = 0;
+  if (e && atoi(e)) {
+    /* the HIP runtime the process already holds (libmjhip.so's): never a second copy */
+    void* h = dlopen("libamdhip64.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("libamdhip64.so.7", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("libamdhip64.so.6", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = RTLD_DEFAULT;
+    p_hipEventCreateWithFlags = (int (*)(void**, unsigned))dlsym(h, "hipEventCreateWithFlags");
+    p_hipEventRecord = (int (*)(void*, void*))dlsym(h, "hipEventRecord");
+    p_hipStreamWaitEvent = (int (*)(void*, void*, unsigned))dlsym(h, "hipStreamWaitEvent");
+    p_hipMemcpyAsync = (int (*)(void*, const void*, size_t, int, void*))dlsym(h, "hipMemcpyAsync");
+    if (p_hipEventCreateWithFlags && p_hipEventRecord && p_hipStreamWaitEvent && p_hipMemcpyAsync) mode = 1;
   }
-  return copy_mode;
+  copy_mode = mode;
 }
+static int copying(void) { pthread_once(&copy_once, copy_init); return copy_mode; }     /* (eight threads ask at once) */
 static int ready_event(int rank, void* stream) {
-  if (!ev[rank] && p_hipEventCreateWithFlags(&ev[rank], 2u /* hipEventDisableTiming */)) return 1;
-  return p_hipEventRecord(ev[rank], stream);
+  if (!ev[rank]) HIPTRY(1, p_hipEventCreateWithFlags(&ev[rank], 2u /* hipEventDisableTiming */));
+  HIPTRY(2, p_hipEventRecord(ev[rank], stream));
+  return 0;
 }
 static int gather_into(int nranks, void* recv, size_t count, void* stream, const void* const* sends) {
   for (int r = 0; r < nranks; r++) {
-    if (p_hipStreamWaitEvent(stream, ev[r], 0)) return 1;
-    if (p_hipMemcpyAsync((char*)recv + (size_t)r * count * 4, sends[r], count * 4, 3 /* hipMemcpyDeviceToDevice */, stream)) return 1;
+    HIPTRY(3, p_hipStreamWaitEvent(stream, ev[r], 0));
+    HIPTRY(4, p_hipMemcpyAsync((char*)recv + (size_t)r * count * 4, sends[r], count * 4, 3 /* hipMemcpyDeviceToDevice */, stream));
   }
   return 0;
 }
@@ -143,7 +151,7 @@ int ncclAllGather(const void* send, void* recv, size_t count, int dtype, stub_co
   if (++arrived == c->nranks) { arrived = 0; epoch++; pthread_cond_broadcast(&cv); }
   else {
     struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); ts.tv_sec += 10;
-    while (epoch == my_epoch && !rc) if (pthread_cond_timedwait(&cv, &mu, &ts)) rc = 1;
+    while (epoch == my_epoch && !rc) if (pthread_cond_timedwait(&cv, &mu, &ts)) { rc = 1; if (!hip_err) { hip_err = -1; hip_where = 5; } }
   }
   for (int r = 0; r < c->nranks; r++) sends[r] = pend[r].send;
   pthread_mutex_unlock(&mu);
@@ -157,4 +165,5 @@ void stub_fail_rank(int rank) { pthread_mutex_lock(&mu); fail_rank = rank; pthre
 int stub_nlog(void) { return nlog; }
 int stub_get(int i, stub_rec* out) { if (i < 0 || i >= nlog) return 1; *out = logv[i]; return 0; }
 void stub_counters(int* out) { out[0] = n_init; out[1] = n_destroy; out[2] = n_abort; out[3] = n_gstart; out[4] = n_gend; out[5] = init_ndev; out[6] = copying(); out[7] = epoch; }
+void stub_hip_error(int* out) { out[0] = hip_err; out[1] = hip_where; }
 int stub_init_dev(int k) { return k >= 0 && k < MAXR ? init_devs[k] : -1; }
