@@ -907,7 +907,14 @@ template <int NROW, bool DIAGM, bool EXTRA, int WPRE = 0>
 // resident wave counts) (A/B builds: -DMJH_STEP_WAVES=3 with -DPP_NRC=0)
 #define MJH_STEP_WAVES ((!DIAGM && NROW <= 4) ? 3 : 2)
 #endif
-__global__ __launch_bounds__(64, MJH_STEP_WAVES) void mjh_step_kernel(const DConst* __restrict__ C, const DState S, int env0, int nsteps, int ph, int xflags) {
+// the assemble-only instances of the window chain: waves per SIMD their register allocation aims at.  6 = 80 registers: such a wave fits on a
+// SIMD BESIDE a window wavefront (422 of the 512 registers), i.e. on every SIMD of the chip instead of only on those the other cohorts'
+// window waves have left
+#ifndef MJH_WPRE_WAVES
+#define MJH_WPRE_WAVES 2
+#endif
+#define MJH_STEP_WAVES_T (WPRE ? MJH_WPRE_WAVES : MJH_STEP_WAVES)
+__global__ __launch_bounds__(64, MJH_STEP_WAVES_T) void mjh_step_kernel(const DConst* __restrict__ C, const DState S, int env0, int nsteps, int ph, int xflags) {
   // model descriptor + LDS layout live in device memory (uploaded once): uniform scalar loads on demand instead
   // of a by-value kernarg struct that the lambdas below would force into a private (scratch) copy
   const DModel& M = C->M;
