@@ -72,7 +72,7 @@ Rccl* load_rccl() {
   }
   return nullptr;
 }
-int g_transport = 0;   // 0: RCCL when it can be loaded (and the devices are distinct), 1: peer copies, 2: RCCL also for repeated devices (only a stand-in library accepts that: tests)
+int g_transport = getenv("MJH_GROUP_TRANSPORT") ? atoi(getenv("MJH_GROUP_TRANSPORT")) : 0;   // 0: RCCL when it can be loaded (and the devices are distinct), 1: peer copies, 2: RCCL also for repeated devices (only a stand-in library accepts that: tests)
 }  // namespace
 
 struct mjh_group {

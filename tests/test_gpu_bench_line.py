@@ -73,6 +73,25 @@ def test_group_host_runs_in_one_process_without_a_launcher():
     assert r1["host"]["rccl"] is True and r1["host"]["rccl_ranks"] == 1, "one device: the publish goes through ncclAllGather (the 8-GPU code path)"
 
 
+def test_group_host_bench_with_eight_ranks_through_the_rccl_code_path():
+    """`bench.py --gpus 8 --host group` as an 8-GPU node runs it — eight engines, a host thread per rank, ncclCommInitAll over eight ranks, one
+    ncclAllGather per rank and publish — on the ONE device there is: the recording stand-in of tests/nccl_stub performs the collective
+    (MJH_RCCL_LIB, NCCL_STUB_COPY=1; MJH_GROUP_TRANSPORT=2 lets the group take the RCCL path although the device repeats)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_rccl_sequence import build_stub
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MJH_RCCL_LIB=build_stub(), NCCL_STUB_COPY="1", MJH_GROUP_TRANSPORT="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--host", "group", "--group-devices", "0,0,0,0,0,0,0,0", "--config", "c5",
+                        "--envs-per-gpu", "512", "--steps", "60", "--warmup", "6"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    h = j["host"]
+    assert j["n_gpus"] == 8 and h["kind"] == "group" and h["rccl"] is True and h["rccl_ranks"] == 8 and h["host_threads"] == 8
+    assert [x["nenv"] for x in h["ranks"]] == [512] * 8 and [x["env0"] for x in h["ranks"]] == [512 * k for k in range(8)]
+    assert h["all_gather"]["count"] >= 3 and h["all_gather"]["ms_mean"] > 0 and h["all_gather"]["bytes_per_rank"] == 512 * (1 + 12 + 9) * 4
+    assert j["value"] > 1e6 and j["config"]["envs_total"] == 4096
+
+
 def test_the_drivers_multi_gpu_invocation_runs_the_rccl_publish_path():
     """The driver launches N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
     bench.py --gpus N ...`, one rank per GPU.  With the one GPU there is, the same launcher form with N = 1 (process group of one rank
