@@ -524,8 +524,16 @@ static void derive_device_model(const mjh_model* m, HostPack& hp, bool force_big
 // chip, 74 us (S24) to 200 us (C2) beside the other cohorts' resident waves; an env's cost drifts slowly.  8 / 16 / 32 / 64 steps: S24
 // 11.29 / 11.46 / 11.52 / 11.40 M, C4 1.41 / 1.43 / 1.45 / 1.39 M, C2 0.541 / 0.545 / 0.546 / 0.544 M env-steps/s (tools/r04_order_every.sh)
 #define MJH_ORDER_EVERY 32
+// ... 16 for the window models whose envs reach the 64-row form's row counts (S24D: the slowest wavefront is a function of which envs share it,
+// and the piles' row counts drift faster than the sweep counts of S24): 8 / 16 / 32 / 64 steps S24D 5.92 / 5.91 / 5.84 / 5.73 M, S24 13.60 /
+// 13.75 / 13.82 / 13.75 M (round 6, tools/r06_knobs.sh).  Results do not depend on the launch order (bitwise: tests).
+static int order_every_of(const mjh_engine* e);
 static int g_layout_policy = 0;
 extern "C" void mjh_set_layout_policy(int policy) { g_layout_policy = policy < 0 || policy > 2 ? 0 : policy; }
+static int order_every_of(const mjh_engine* e) {
+  static const int env = getenv("MJH_ORDER_EVERY") ? std::max(1, atoi(getenv("MJH_ORDER_EVERY"))) : 0;
+  return env ? env : ((e->M.window && e->M.win_maxw > 16) ? 16 : MJH_ORDER_EVERY);
+}
 static void derive_fitting(const mjh_model* m, HostPack& hp) {
   derive_device_model(m, hp);
   int policy = g_layout_policy;
@@ -765,7 +773,7 @@ static int launch_lpt(mjh_engine* e, int ph, int xflags, bool resort, int wmode 
     StateGuard guard(&e->S);
     const bool lpt = e->lpt && e->d_order && e->nenv >= 1024;
     if (lpt) e->S.env_order = e->d_order;
-    static const int order_every = getenv("MJH_ORDER_EVERY") ? std::max(1, atoi(getenv("MJH_ORDER_EVERY"))) : MJH_ORDER_EVERY;
+    const int order_every = order_every_of(e);
     const bool sort = lpt && (e->order_G != G || !e->order_valid || (resort && e->order_age % order_every == 0));
     // (the XF_FORCE exports are engine-sized arrays indexed by the row inside the launch's range: shifted to the cohort's first row)
     float* const xb = e->S.x_bias; float* const xp = e->S.x_passive; float* const xs = e->S.x_smooth; float* const xc = e->S.x_constraint; float* const xe = e->S.x_energy;
@@ -871,7 +879,7 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
       // dispatch the envs with the most solver work first (shorter kernel tail).  An env's cost drifts slowly, so the sort is
       // renewed every MJH_ORDER_EVERY-th step only: its 10 us sit in front of every step launch of the cohort's stream, which
       // is 9 % of a step of the small configs (C3, C5: 0.10 ms kernels)
-      static const int order_every = getenv("MJH_ORDER_EVERY") ? std::max(1, atoi(getenv("MJH_ORDER_EVERY"))) : MJH_ORDER_EVERY;
+      const int order_every = order_every_of(e);
       if (e->S.env_order && (e->order_G != G || e->order_age / order_every != (e->order_age - e->last_chunk) / order_every || e->order_age == 0)) {
         const bool dsel = e->M.big && e->split3 && e->M.dense && e->d_dense;
         const unsigned ep = e->dense_epoch[g];
