@@ -128,13 +128,13 @@ class S24(Workload):
         # "the harness must print the measured ncon / nefc so the ~30 claim is checked, not assumed"
         st = self.eng.get_stats()
         hc, _ = np.histogram(st[:, 0], bins=[0, 8, 16, 24, 32, 40, 48, 64, 100000])
-        hr, _ = np.histogram(st[:, 1], bins=[0, 32, 64, 96, 128, 160, 192, 208, 256, 320, 100000])
+        hr, _ = np.histogram(st[:, 1], bins=[0, 33, 65, 97, 129, 161, 193, 209, 257, 321, 100000])
         return {"ncon_histogram": dict(zip(["0-7", "8-15", "16-23", "24-31", "32-39", "40-47", "48-63", "64+"], map(int, hc))),
-                "nefc_histogram": dict(zip(["0-31", "32-63", "64-95", "96-127", "128-159", "160-191", "192-207", "208-255", "256-319", "320+"], map(int, hr)))}
+                "nefc_histogram": dict(zip(["0-32", "33-64", "65-96", "97-128", "129-160", "161-192", "193-208", "209-256", "257-320", "321+"], map(int, hr)))}
 
 
 class S24D(S24):
-    cohorts = 2       # round 5 (64-row form, window-count-major launch order): 4.82 / 4.65 / 4.51 M env-steps/s on 2 / 3 / 4 cohorts; with the slim assemble-only launch 5.75 / 5.56 M on 2 / 3
+    cohorts = 3       # round 6 (32-row section off, 64-row form above 192 rows): 6.19 / 6.28 / 5.83 M env-steps/s on 2 / 3 / 4 cohorts (round 5, section on, threshold 208: 5.75 / 5.56 M on 2 / 3)
     """the "30-contact" reading of the metric's name: S24's pen and S24's four boxes (same per-env sizes, masses, seeds), but released
     flat and side by side (2 x 2, random yaw) instead of as a staggered column of random orientations: the boxes land on the floor
     together (16 floor contacts of condim 4) and are wedged against each other and the walls — ~30 contacts, ~130 rows per env, what
@@ -811,7 +811,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": ("mjh_step_kernel (assemble: position / velocity stages, collision, constraint rows) + mjh_window_kernel (PGS sweeps in mj_solPGS row order, four "
-                                "envs per wavefront in 16-row windows — two in 32-row windows above 96 rows, one in 64-row windows above 208 (models with more than 256 rows) —, rows in registers; mj_Euler): the two-launch chain of one cohort's step, timed as one" if eng.window_solver() else "mjh_step_kernel") + ((" (+ mjh_dense_build_kernel [MFMA] + mjh_dense_solve_kernel: assemble -> build -> solve -> integrate chain of the many-body layout)" if eng.dense_solver() else
+                                "envs per wavefront in 16-row windows, one env per wavefront in 64-row windows above 96 rows (S24) / above 192 rows (models whose rows can exceed 256: S24D) —, rows in registers; mj_Euler): the two-launch chain of one cohort's step, timed as one" if eng.window_solver() else "mjh_step_kernel") + ((" (+ mjh_dense_build_kernel [MFMA] + mjh_dense_solve_kernel: assemble -> build -> solve -> integrate chain of the many-body layout)" if eng.dense_solver() else
                                                      " (+ mjh_solve_kernel: three-launch step of the many-body layout)") if eng.lds_bytes > 24 * 1024 or model.nv > 64 else ""),
                      "kernel_ms": kernel_ms, "launches": n_launches, "launches_timed": n_timed, "envs_per_launch": envs_per_launch, "concurrent_launches": cohorts,
                      # `achieved` / `frac` are per launch (one cohort's step), as the contract defines them; the cohorts' launches overlap, so the

@@ -663,7 +663,9 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
   S.gscratch = nullptr; S.gstride = hp.gstride;
   if (M.big) rc |= dev_alloc(e, &S.gscratch, (size_t)nenv * (size_t)hp.gstride, false);   // many-body models: contact / block / Jacobian pools
   S.wbuf = nullptr; S.wstride = 0;
-  S.win32 = getenv("MJH_WINDOW32") ? std::max(0, atoi(getenv("MJH_WINDOW32"))) : WN32_MIN_ROWS;     // (0: off; experiments: another row threshold)
+  // (0: off; experiments: another row threshold.  Models whose rows can exceed 256 — S24D — keep every env below the 64-row threshold in the 16-row form:
+  //  four envs per wavefront; the two-env wavefronts of the 32-row form cost the SIMD time the one-env wavefronts of the slowest envs need — round 6)
+  S.win32 = getenv("MJH_WINDOW32") ? std::max(0, atoi(getenv("MJH_WINDOW32"))) : (M.win_maxw > 16 ? 0 : WN32_MIN_ROWS);
   // 64-row form above ... rows: models whose envs stay within 256 rows (S24: 9 % of the envs beyond 96 rows) give it every env beyond the 16-row
   // form's register-resident windows — 2 x 64 rows with the chains' wait states filled beat 4 x 32 (S24 12.3 -> 13.3 M); models with more rows
   // (S24D: 30 % of the envs between 97 and 128 rows, 60 % beyond) only the envs a cohort's step waits for (176 / 192 / 208 rows: 4.65 / 4.97 / 5.26 M)

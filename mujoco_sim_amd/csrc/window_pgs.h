@@ -50,7 +50,11 @@
 #ifndef WN32_NW
 #define WN32_NW 4       // 32-row windows of an env (128 rows), all register-resident
 #endif
-#define WN64_MIN_ROWS 208  // rows above which an env is swept in 64-row windows, one env per wavefront (S24D: 11 % of the envs, the ones a cohort's step waits for)
+#define WN64_MIN_ROWS 192  // rows above which an env of a model whose rows can exceed 256 is swept in 64-row windows, one env per wavefront (S24D: 9 % of the envs, the ones
+                           // a cohort's step waits for).  A multiple of 16: the threshold must not split a window count of the 16-row form (193 - 208 rows = 13 windows —
+                           // at 200 half of that class stays the slowest wavefront AND the other half holds SIMDs of its own).  Round 6, with the 32-row section off for
+                           // these models (it held 593 two-env wavefronts of 97 - 128-row envs: SIMD time the 64-row form of the slowest envs can use better): 176 / 184 /
+                           // 192 / 200 / 208 rows 5.86 / 5.98 / 6.18 / 5.88 / 6.00 M on two cohorts, 192 on three cohorts 6.28 M (round 5, section on: 208 rows, 5.85 M)
 #ifndef WN64_NW
 #define WN64_NW 3       // 64-row windows of an env that are register-resident (192 rows) ...
 #endif
