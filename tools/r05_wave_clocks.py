@@ -14,7 +14,7 @@ args = types.SimpleNamespace(envs_per_gpu=4096, pack=0, maxcon=0, pen_half=0.0)
 w = bench.WORKLOADS[name](ms, args, 0, 0, None)
 e = w.eng; e.set_cohorts(nc)
 e.step(w.settle_steps + 40); e.synchronize()
-w64 = int(os.environ.get("MJH_WINDOW64", "208" if name == "s24d" else "96")); w32 = 96
+w64 = int(os.environ.get("MJH_WINDOW64", "192" if name == "s24d" else "96")); w32 = int(os.environ.get("MJH_WINDOW32", "0" if name == "s24d" else "96"))
 for rep in range(3):
     e.step(1); e.synchronize()
     st = e.get_stats()
@@ -22,7 +22,12 @@ for rep in range(3):
     us = clk / 2400.0       # s_memtime counts shader clocks here (2.4 GHz: a 258 us kernel reads 620 k ticks)
     if rep < 2: continue
     print(f"{name}: per-env clocks of its wavefront (s_memtime ticks, 32-tick granularity, 2.4 GHz -> us): max {us.max():.0f} us")
-    classes = [(1, 32, "16-row"), (33, 64, "16-row"), (65, 80, "16-row"), (81, 96, "16-row")] + ([(97, 128, "64-row"), (129, 192, "64-row")] if w64 <= 96 else [(97, 128, "32-row"), (129, 160, "16-row + tiers"), (161, 192, "16-row + tiers"), (193, w64, "16-row + tiers"), (w64 + 1, 256, "64-row"), (257, 320, "64-row"), (321, 400, "16-row + tiers")])
+    def form_of(lo):          # the form an env of lo.. rows takes under the thresholds in force (engine.hip: S.win32 / S.win64; step_kernel.h: wh[4])
+        if w64 and lo > w64: return "64-row"
+        if w32 and lo > w32 and lo <= 128: return "32-row"
+        return "16-row" if lo <= 96 else "16-row + tiers"
+    edges = [(1, 32), (33, 64), (65, 80), (81, 96), (97, 112), (113, 128), (129, 144), (145, 160), (161, 176), (177, 192), (193, 208), (209, 256), (257, 320)]
+    classes = [(lo, hi, form_of(lo)) for lo, hi in edges]
     simd_us = 0.0
     for lo, hi, form in classes:
         m = (rows >= lo) & (rows <= hi)
