@@ -184,3 +184,81 @@ def test_device_against_the_oracle_built_on_the_independent_model():
     print(f"INDEP-MODEL-GPU arm7: 8 envs x 200 steps, max |HIP fp32 - oracle fp64 on the independent model| = {worst:.2e}")
     assert worst < 2e-3
     e.close()
+
+
+@pytest.mark.parametrize("name", ["s24", "s24d"])
+def test_every_env_of_the_metrics_batch_one_step_against_the_oracle(name):
+    """BASELINE size, not a sample: ALL 4096 envs of the metric's scene (S24, and S24D in its round-6 window forms), settled 400 steps on the
+    device on three cohorts exactly as bench.py times them, then at three points of the timed regime every env's state goes to the oracle and
+    both advance one step (the oracle on the host's thread team, 512 envs at a time): 12 288 env-steps each.  Contact sets must agree on >= 97 %
+    of the env-steps (counts; where the counts agree and the result does not, the contact RECORDS are compared as well: fp32 and fp64 geometry
+    keep different points of a manifold on a handful of env-steps); on those, qpos / qvel within the teacher-forced tolerances (qvel: 99 % quantile and maximum, the maximum by row class as in
+    test_s24d_teacher_forced...: fp32 round-off at the 100-sweep cap grows with the row count)."""
+    import ctypes as C
+    from mujoco_sim_amd.engine import EP
+    L = orc.lib()
+    nenv = 4096
+    if name == "s24":
+        m = ms.scene("s24"); e = ms.Engine(m, nenv); tab = e.load_s24()
+    else:
+        m, e, tab = _s24d_seeds(list(range(nenv)))
+    e.set_cohorts(3)
+    e.step(400)
+    B = 512
+    ds = [orc.OrcData(m.ptr) for _ in range(B)]
+    arr = (C.c_void_p * B)(*[d.d for d in ds])
+    L.orc_set_threads(min(16, os.cpu_count() or 1))
+    from test_gpu_teacher_forced import _same_contacts
+    eq_all, ev_all, ag_all, rows_all = [], [], [], []
+    rechecked = differ = 0
+    for rep in range(3):
+        t, q, v, w = e.get_state()
+        e.step(1)
+        _, q1, v1, _ = e.get_state(); st = e.get_stats()
+        for b0 in range(0, nenv, B):
+            for k, d in enumerate(ds):
+                i = b0 + k
+                for key, wh in EP.items():
+                    d.set_env_param(wh, tab[key][i])
+                d.f("qpos")[:] = q[i]; d.f("qvel")[:] = v[i]; d.f("qacc_warmstart")[:] = w[i]; d.f("qacc")[:] = w[i]; d.f("time")[0] = t[i]
+            L.orc_step_many(arr, B, 1, 0)
+            for k, d in enumerate(ds):
+                i = b0 + k
+                same = bool(st[i, 0] == d.i("ncon") and st[i, 1] == d.i("nefc") and (st[i, 3] & 7) == 0)
+                eqi = np.abs(q1[i] - d.f("qpos")).max() / max(1.0, np.abs(d.f("qpos")).max())
+                evi = np.abs(v1[i] - d.f("qvel")).max() / max(1.0, np.abs(d.f("qvel")).max())
+                if same and (evi > 1e-4 or eqi > 1e-6):
+                    # equal COUNTS do not make equal contact SETS (fp32 and fp64 geometry can keep different points of one manifold): the device's
+                    # contact records at the state both started from, read from a one-env engine, against the oracle's (as teacher_forced does for
+                    # every env-step of its smaller samples)
+                    if name == "s24":
+                        e1 = ms.Engine(m, 1); e1.load_tables({kk: tab[kk][i:i + 1] for kk in tab})
+                    else:
+                        _, e1, _ = _s24d_seeds([i])
+                    e1.set_state(qpos=q[i:i + 1], qvel=v[i:i + 1], time=t[i:i + 1], warmstart=w[i:i + 1])
+                    same = _same_contacts(e1.get_contacts(0), d.contacts()); rechecked += 1; differ += int(not same)
+                    e1.close()
+                ag_all.append(same); eq_all.append(eqi); ev_all.append(evi)
+                rows_all.append(d.i("nefc"))
+        e.step(29)
+    eq, ev, ag, rows = np.array(eq_all), np.array(ev_all), np.array(ag_all, bool), np.array(rows_all)
+    line = {"scene": name, "env_steps": int(len(ag)), "agree_fraction": float(ag.mean()), "qpos_max": float(eq[ag].max()), "qvel_q50_q99_max": [float(x) for x in np.quantile(ev[ag], [0.5, 0.99, 1.0])],
+            "qvel_max_by_rows": {f"{lo}-{hi}": float(ev[ag & (rows >= lo) & (rows <= hi)].max()) for lo, hi in ((0, 96), (97, 128), (129, 192), (193, 256), (257, 400)) if (ag & (rows >= lo) & (rows <= hi)).any()},
+            "qvel_q99_by_rows": {f"{lo}-{hi}": float(np.quantile(ev[ag & (rows >= lo) & (rows <= hi)], 0.99)) for lo, hi in ((0, 96), (97, 128), (129, 192), (193, 256), (257, 400)) if (ag & (rows >= lo) & (rows <= hi)).any()},
+            "rows_mean_max": [float(rows.mean()), int(rows.max())], "count_agreeing_env_steps_rechecked_by_contact_records": rechecked, "of_them_with_other_records": differ}
+    print("FULL-BATCH", json.dumps(line))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "full_batch_parity.jsonl"), "a") as f:
+            f.write(json.dumps(line) + "\n")
+    except OSError:
+        pass
+    assert ag.mean() >= 0.97, line
+    # measured (round 6, 12 288 env-steps each): S24 agree 99.7 %, qpos 3.0e-7, qvel 50 % / 99 % / max 2.0e-6 / 9.0e-6 / 7.6e-5; S24D agree 98.9 %, qpos 9.9e-7,
+    # qvel 2.0e-6 / 2.8e-5 / 3.6e-4 — the 99 % quantile by row class 8e-6 (<= 96 rows) / 2.5e-5 (<= 128) / 3.2e-5 (<= 192) / 4.2e-5 (<= 256): fp32 round-off of an
+    # iteration that the 100-sweep cap ends before it has converged grows with the row count, whichever window form sweeps the env (32-row section on and
+    # threshold 208: 2.7e-5; 16-row form only: 2.8e-5).  The 64-env sample of test_s24d_teacher_forced... reads 7.9e-6 at its 99 % quantile: the whole batch is
+    # the figure to quote.
+    tol_q, tol_v99 = (1e-6, 2e-5) if name == "s24" else (2e-6, 5e-5)
+    assert eq[ag].max() <= tol_q and np.quantile(ev[ag], 0.99) <= tol_v99 and ev[ag].max() <= 5e-4, line
+    e.close()
