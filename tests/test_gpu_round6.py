@@ -262,3 +262,144 @@ def test_every_env_of_the_metrics_batch_one_step_against_the_oracle(name):
     tol_q, tol_v99 = (1e-6, 2e-5) if name == "s24" else (2e-6, 5e-5)
     assert eq[ag].max() <= tol_q and np.quantile(ev[ag], 0.99) <= tol_v99 and ev[ag].max() <= 5e-4, line
     e.close()
+
+
+def test_every_env_of_the_c4_batch_one_step_against_the_oracle():
+    """C4 (PR2 + world + object pool, mj_inverse every step, per-env commands) at BASELINE size, every one of the 2048 envs handed to the oracle for
+    one step — round 3's test of the same set-up sampled 32 of them"""
+    from test_gpu_round3 import _one_step_on_samples, _robot
+    from test_robot_fixtures import robot_command
+    m, z = _robot("c4_pr2_world_objects_mesh")
+    nenv = 2048
+    e = ms.Engine(m, nenv)
+    assert e.dense_solver() == 1
+    e.set_controlled_dofs(z["controlled"].astype(np.int32))
+    lib = m.lib
+    names = [lib.mjh_id2name(m.ptr, 0, b).decode() for b in range(m.c.nbody)]
+    slots = [b for b, n in enumerate(names) if n.startswith("object_")]
+    for b in slots:
+        e.set_slot_active(b, False)
+    sbase = m.c.nbody - 32 if m.c.nbody > 32 else 0
+    mask = 0
+    for b in slots:
+        mask |= 1 << (b - sbase)
+    rng = np.random.default_rng(4)
+    for k in range(1, 121):
+        if k % 10 == 1:
+            e.set_cmd(ddq=np.tile(robot_command(m, k), (nenv, 1)) * rng.uniform(0.5, 1.5, size=(nenv, 1)))
+        e.step(1, True)
+
+    def make(i):
+        d = orc.OrcData(m.ptr); d.ifield("controlled")[:] = z["controlled"]
+        orc.lib().orc_set_slot_mask(d.d, mask)
+        return d
+    eq, ev, ag, ds = _one_step_on_samples(e, make, list(range(nenv)), with_inverse=True)
+    line = {"scene": "c4", "env_steps": nenv, "agree_fraction": float(ag.mean()), "qpos_max": float(eq[ag].max()), "qvel_q50_q99_max": [float(x) for x in np.quantile(ev[ag], [0.5, 0.99, 1.0])],
+            "rows_min_max": [min(d.i("nefc") for d in ds), max(d.i("nefc") for d in ds)], "not_agreeing_qpos_max": float(eq[~ag].max()) if (~ag).any() else 0.0}
+    print("FULL-BATCH", json.dumps(line))
+    try:
+        with open(os.path.join(ROOT, "gpurun_out", "full_batch_parity.jsonl"), "a") as f:
+            f.write(json.dumps(line) + "\n")
+    except OSError:
+        pass
+    assert ag.mean() >= 0.9 and eq[ag].max() <= 2e-6 and ev[ag].max() <= 1e-4, line
+    assert eq.max() < 1e-3
+    e.close()
+
+
+@pytest.mark.parametrize("name", ["c3", "c5"])
+def test_every_env_of_the_small_model_batches_one_step_against_the_oracle(name):
+    """C3 (8192 arms, four per wavefront, in-engine PD law + computed-torque wrapper + mj_inverse) and C5 (4096 pendulum worlds over the bowl) exactly as
+    bench.py builds and settles them, then EVERY env one step against the oracle (the existing full-size tests of these configs check invariants)."""
+    import ctypes as C
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    args = types.SimpleNamespace(envs_per_gpu=0, pack=0, maxcon=0, pen_half=0.0)
+    w = bench.WORKLOADS[name](ms, args, 0, 0, None)
+    if w.cohorts > 0:
+        w.eng.set_cohorts(w.cohorts)
+    w.step(w.settle_steps + 21, w.inverse)
+    nenv = w.nenv
+    q, v, ws, st = w.env_state(nenv)
+    tt = np.repeat(w.eng.get_state(0, w.rows)[0], w.pack)[:nenv]
+    L = orc.lib(); L.orc_set_threads(min(16, os.cpu_count() or 1))
+    B = 1024
+    ds = [w.oracle_data(orc, i, None) for i in range(B)]
+    arr = (C.c_void_p * B)(*[d.d for d in ds])
+    w.step(1, w.inverse)
+    q1, v1, _, st1 = w.env_state(nenv)
+    eq, ev, ag = np.zeros(nenv), np.zeros(nenv), np.zeros(nenv, bool)
+    for b0 in range(0, nenv, B):
+        for k, d in enumerate(ds):
+            i = b0 + k
+            if name == "c3":
+                d.set_pd(w.target[i], 200.0, 50.0)
+            d.f("qpos")[:] = q[i]; d.f("qvel")[:] = v[i]; d.f("qacc_warmstart")[:] = ws[i]; d.f("qacc")[:] = ws[i]; d.f("time")[0] = tt[i]
+        L.orc_step_many(arr, B, 1, int(w.inverse))
+        for k, d in enumerate(ds):
+            i = b0 + k
+            eq[i] = np.abs(q1[i] - d.f("qpos")).max() / max(1.0, np.abs(d.f("qpos")).max()); ev[i] = np.abs(v1[i] - d.f("qvel")).max() / max(1.0, np.abs(d.f("qvel")).max())
+            ag[i] = w.pack > 1 or (st1[i, 0] == d.i("ncon") and st1[i, 1] == d.i("nefc"))
+    line = {"scene": name, "env_steps": int(nenv), "agree_fraction": float(ag.mean()), "qpos_max": float(eq[ag].max()), "qvel_q50_q99_max": [float(x) for x in np.quantile(ev[ag], [0.5, 0.99, 1.0])],
+            "envs_in_contact": int((st1[:, 0] > 0).sum())}
+    print("FULL-BATCH", json.dumps(line))
+    try:
+        with open(os.path.join(ROOT, "gpurun_out", "full_batch_parity.jsonl"), "a") as f:
+            f.write(json.dumps(line) + "\n")
+    except OSError:
+        pass
+    assert ag.mean() >= 0.99 and eq[ag].max() <= 1e-6 and ev[ag].max() <= 5e-5, line
+    w.eng.close()
+
+
+def test_c2_on_d3s_window_256_envs_one_step_against_the_oracle():
+    """C2 where bench.py times it since round 6 — behind 200 settle + 500 steps, 262 contacts / 1338 rows per env instead of the 185 / 907 of the
+    200-step state the older tests meet — 256 envs spread over the 4096-env batch, one step against the oracle (16 host threads)."""
+    import ctypes as C
+    from mujoco_sim_amd.engine import EP
+    m = ms.scene("boxpile", 64); m.c.maxcon = 600; m.c.maxefc = 2400
+    nenv = 4096
+    e = ms.Engine(m, nenv); e.set_cohorts(4)
+    tab = e.load_tables(ms.boxes_randomize(m, 0, nenv, jitter=0.01))
+    e.step(700)
+    sample = list(range(7, nenv, 16))
+    t, q, v, w = e.get_state()
+    e.step(1)
+    _, q1, v1, _ = e.get_state(); st = e.get_stats()
+    L = orc.lib(); L.orc_set_threads(min(16, os.cpu_count() or 1))
+    B = 32
+    ds = [orc.OrcData(m.ptr) for _ in range(B)]
+    arr = (C.c_void_p * B)(*[d.d for d in ds])
+    from test_gpu_teacher_forced import _same_contacts
+    eq, ev, ag, rows = [], [], [], []
+    rechecked = differ = 0
+    for b0 in range(0, len(sample), B):
+        for k, d in enumerate(ds):
+            i = sample[b0 + k]
+            for key, wh in EP.items():
+                d.set_env_param(wh, tab[key][i])
+            d.f("qpos")[:] = q[i]; d.f("qvel")[:] = v[i]; d.f("qacc_warmstart")[:] = w[i]; d.f("qacc")[:] = w[i]; d.f("time")[0] = t[i]
+        L.orc_step_many(arr, B, 1, 0)
+        for k, d in enumerate(ds):
+            i = sample[b0 + k]
+            same = bool(st[i, 0] == d.i("ncon") and st[i, 1] == d.i("nefc") and (st[i, 3] & 7) == 0); rows.append(d.i("nefc"))
+            eqi = np.abs(q1[i] - d.f("qpos")).max() / max(1.0, np.abs(d.f("qpos")).max()); evi = np.abs(v1[i] - d.f("qvel")).max() / max(1.0, np.abs(d.f("qvel")).max())
+            if same and (evi > 5e-5 or eqi > 1e-6):       # equal counts, other result: are the ~260 contact RECORDS the same?  (one-env engine at the state both started from)
+                e1 = ms.Engine(m, 1); e1.load_tables({kk: tab[kk][i:i + 1] for kk in tab})
+                e1.set_state(qpos=q[i:i + 1], qvel=v[i:i + 1], time=t[i:i + 1], warmstart=w[i:i + 1])
+                same = _same_contacts(e1.get_contacts(0), d.contacts()); rechecked += 1; differ += int(not same)
+                e1.close()
+            ag.append(same); eq.append(eqi); ev.append(evi)
+    eq, ev, ag, rows = np.array(eq), np.array(ev), np.array(ag), np.array(rows)
+    line = {"scene": "c2 (D3 window: 700 steps)", "env_steps": int(len(ag)), "agree_fraction": float(ag.mean()), "qpos_max": float(eq[ag].max()), "qvel_q50_q99_max": [float(x) for x in np.quantile(ev[ag], [0.5, 0.99, 1.0])],
+            "rows_mean_max": [float(rows.mean()), int(rows.max())], "not_agreeing_qpos_max": float(eq[~ag].max()) if (~ag).any() else 0.0,
+            "count_agreeing_env_steps_rechecked_by_contact_records": rechecked, "of_them_with_other_records": differ}
+    print("FULL-BATCH", json.dumps(line))
+    try:
+        with open(os.path.join(ROOT, "gpurun_out", "full_batch_parity.jsonl"), "a") as f:
+            f.write(json.dumps(line) + "\n")
+    except OSError:
+        pass
+    assert rows.mean() > 1100 and ag.mean() >= 0.85 and eq[ag].max() <= 1e-6 and np.quantile(ev[ag], 0.99) <= 2e-5 and ev[ag].max() <= 2e-4, line
+    e.close()
