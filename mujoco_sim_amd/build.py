@@ -11,12 +11,14 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libmjhip.so")
 API = os.path.join("..", "..", "include", "mjhip.h")
-KERNEL_HEADERS = ["step_kernel.h", "patch_pgs.h", "window_pgs.h", "dense_pgs.h", "dev_math.h", "dev_collide.h", "dev_convex.h", "dev_types.h"]
+KERNEL_HEADERS = ["step_kernel.h", "patch_pgs.h", "window_pgs.h", "dev_math.h", "dev_collide.h", "dev_convex.h", "dev_types.h"]
+DENSE_HEADERS = ["dense_pgs.h"] + KERNEL_HEADERS
 WINDOW_HEADERS = ["window_kernel.h", "step_kernel.h", "patch_pgs.h", "window_pgs.h", "dev_math.h", "dev_collide.h", "dev_convex.h", "dev_types.h"]
 # source -> headers it includes (besides itself)
 SOURCES = {
     "engine.hip": KERNEL_HEADERS + [API],
     "window.hip": WINDOW_HEADERS + [API],
+    "dense.hip": DENSE_HEADERS + [API],
     "group.hip": ["host_pool.h", API],
     "model_builder.cpp": ["hmath.h", API],
     "scenes.cpp": ["hmath.h", API],

@@ -33,7 +33,9 @@
 #pragma once
 #include "step_kernel.h"
 
+#ifndef DN_CAP_MAX
 #define DN_CAP_MAX 256          // rows: four per lane
+#endif
 #define DN_META_DENSE 7         // meta[7] = 1: this step of this env is solved by the dense kernels
 
 // float offsets of the dense region inside the env's scratch slice (L.g_dense .. ), CAP = M.dense_cap rows, NVS = M.dense_nvs
@@ -213,6 +215,37 @@ __global__ __launch_bounds__(DN_BUILD_THREADS) void mjh_dense_build_kernel(const
 #define DN_GROUP_ROWS(K) ((K) == 3 ? 32 : 16)     // rows per fetch group of the streamed sweeps (dn_sweeps)
 #endif
 template <int K> struct DnCol { float v[K]; };
+// The value a lane's row has at ITS visit is kept by ONE data-parallel move: v_mov_b32_dpp under a row mask and a bank mask writes the
+// four consecutive lanes of the visited lane's bank — so a set of 64 rows carries four capture registers, one per position inside a
+// bank: the visit of lane l writes register l % 4 in the four lanes of its bank, and a lane only ever reads the register of its own
+// position (the other three hold its neighbours' leftovers).  Replaces `s_lshl_b64` on a scalar lane mask + `v_cndmask_b32` (9.5 + 19.3
+// clocks of a lone wave's issue, profiles/r02m_valu_issue_bench.txt) by one 9-clock instruction per row; same values, bitwise.
+#ifndef DN_RES_PLAIN
+#define DN_RES_PLAIN 1
+#endif
+#ifndef DN_LOAD_BURST
+#define DN_LOAD_BURST 0
+#endif
+#ifndef DN_STRAIGHT
+#define DN_STRAIGHT 0
+#endif
+#ifndef DN_K3_PAIR
+#define DN_K3_PAIR 1
+#endif
+#ifndef DN_DPP_CAPTURE
+#define DN_DPP_CAPTURE 1
+#endif
+// (l is a constant once the row loops are unrolled: the switch folds to its one case — the builtin wants literal masks)
+DEV void dn_capture(float (&q)[4], const float v, const int l) {
+  float& d = q[l & 3];
+#define DN_CC(c) case c: d = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, d), __builtin_bit_cast(int, v), 0xE4, 1 << ((c) >> 2), 1 << ((c) & 3), false)); break;
+  switch (l >> 2) { DN_CC(0) DN_CC(1) DN_CC(2) DN_CC(3) DN_CC(4) DN_CC(5) DN_CC(6) DN_CC(7) DN_CC(8) DN_CC(9) DN_CC(10) DN_CC(11) DN_CC(12) DN_CC(13) DN_CC(14) DN_CC(15) default: break; }
+#undef DN_CC
+}
+DEV float dn_captured(const float (&q)[4], const int lane) {
+  const int i = lane & 3;
+  return i == 0 ? q[0] : (i == 1 ? q[1] : (i == 2 ? q[2] : q[3]));
+}
 template <int K> DEV DnCol<K> dn_load(const __amdgpu_buffer_rsrc_t rs, const unsigned voff, const int soff) {
   DnCol<K> c;
   if constexpr (K == 1) { c.v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, soff, 0)); }
@@ -254,6 +287,13 @@ DEV int dn_sweeps(const __amdgpu_buffer_rsrc_t rs, const int art_bytes, const in
     float sv[K], lor[K], hir[K];
 #pragma unroll
     for (int k = 0; k < K; k++) { sv[k] = s[k]; lor[k] = lo[k] - f[k]; hir[k] = hi[k] - f[k]; }      // sv: r of the lane's row at ITS visit (rows never visited are inert: lo = hi = f = 0)
+#if DN_DPP_CAPTURE
+    float svq[K][4];
+#pragma unroll
+    for (int k = 0; k < K; k++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) svq[k][i] = s[k];
+#endif
     // (opaque per sweep: otherwise the 64 lane masks and the row offsets are hoisted out of the sweep loop as loop invariants and
     //  spilled — v_writelane / v_readlane around every use)
     unsigned long long m1 = 1ull; asm volatile("" : "+s"(m1));
@@ -262,9 +302,27 @@ DEV int dn_sweeps(const __amdgpu_buffer_rsrc_t rs, const int art_bytes, const in
 #pragma unroll
       for (int gg = 0; gg < GPK; gg++) {
         const int g = GPK * k + gg;
+#if DN_STRAIGHT
+        // Straight-line fetch schedule: EVERY one of the K * GPK static slots requests its successor's group (an idle slot behind the env's
+        // last group, or a group that does not exist: the first group once more, never used) — with the request under a branch (`gn < G`) the
+        // compiler's wait-count pass merges the path without it and makes row r of THIS group wait for the r-th fetch of the burst just
+        // issued (s_waitcnt vmcnt(31 - r) instead of vmcnt(63 - r)): the group-ahead buffers bought no look-ahead at all, every group
+        // started with a full memory round trip.  The row offsets go into the instruction's immediate field (voffset + constant: the backend
+        // splits it into six loop-invariant bases + 12 bits) instead of one scalar add per fetch.
+        {
+          constexpr int NS = GPK * K;
+          const int gn = g + 1 < NS ? g + 1 : 0;
+          {
+            int sb = art_bytes + (gn < G ? gn : 0) * GR * ROWB; asm volatile("" : "+s"(sb));
+#pragma unroll
+            for (int r = 0; r < GR; r++) buf[(g + 1) & 1][r] = dn_load<K>(rs, voff + (unsigned)(r * ROWB), sb);
+          }
+          if (false) {
+#else
         if (g < GE) {
           const int gn = g + 1 < GE ? g + 1 : 0;
           if (gn < G) {
+#endif
 #ifdef DN_PROBE_SAMEGROUP     // timing probe (tools/r04_dense_probe.sh): every fetch aimed at the first group — a near cache; results are garbage
             int sb = art_bytes; asm volatile("" : "+s"(sb));
 #else
@@ -272,18 +330,32 @@ DEV int dn_sweeps(const __amdgpu_buffer_rsrc_t rs, const int art_bytes, const in
 #endif
 #pragma unroll
             for (int r = 0; r < GR; r++) buf[(g + 1) & 1][r] = dn_load<K>(rs, voff, sb + r * ROWB);
+#if DN_LOAD_BURST
+            // (the next group's fetches as one burst in front of this group's rows: interleaved with the rows, every row waits on its own
+            //  fetch counter value — an s_waitcnt per row is an issue slot per row of a lone wave)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
           }
           if (g < G) {
-            unsigned long long mask = m1 << (GR * gg);
+            [[maybe_unused]] unsigned long long mask = m1 << (GR * gg);
 #pragma unroll
             for (int r = 0; r < GR; r++) {
               const int l = GR * gg + r;
               const float d = __builtin_amdgcn_fmed3f(s[k], lor[k], hir[k]);
               const float sd = readlane_f(d, l);
+#if DN_DPP_CAPTURE
+              dn_capture(svq[k], s[k], l);          // (f itself is not touched inside the sweep: a row is visited once, its new force is med3 of the captured value)
+#else
               const bool me = __builtin_amdgcn_inverse_ballot_w64(mask);     // lane l: v_cndmask on a scalar mask, no compare
               mask <<= 1;
               sv[k] = me ? s[k] : sv[k];            // (f itself is not touched inside the sweep: a row is visited once, its new force is med3 of sv)
-              if constexpr (K == 3 && GR == 32) {
+#endif
+#ifdef DN_WAIT4
+              // (one s_waitcnt per four rows: touching the fourth row's operands here makes the compiler wait for that fetch — the fetches complete in
+              //  order —, and the three rows in between need none)
+              if constexpr (DN_WAIT4 > 1) if (r % DN_WAIT4 == 0 && r + DN_WAIT4 - 1 < GR) asm volatile("" :: "v"(buf[g & 1][r + DN_WAIT4 - 1].v[0]));
+#endif
+              if constexpr (K == 3 && GR == 32 && !DN_K3_PAIR) {
                 // (three plain multiply-adds: the pair form wants its operands in aligned register pairs, which a 96-bit fetch does not
                 //  deliver — with 32-row buffers the copies cost 120 registers)
 #pragma unroll
@@ -308,6 +380,9 @@ DEV int dn_sweeps(const __amdgpu_buffer_rsrc_t rs, const int art_bytes, const in
     float imp = 0;
 #pragma unroll
     for (int k = 0; k < K; k++) {      // -delta (res + AR delta / 2), res = -t AR, t = s - f = r at the row's visit
+#if DN_DPP_CAPTURE
+      sv[k] = dn_captured(svq[k], lane);
+#endif
       const float dc = __builtin_amdgcn_fmed3f(sv[k], lor[k], hir[k]);
       imp += dc * arr[k] * (sv[k] - 0.5f * dc);
       f[k] += dc; s[k] -= dc;          // (r = s - f: the row's own update leaves s where it was)
@@ -357,6 +432,13 @@ DEV int dn_sweeps_resident(const __amdgpu_buffer_rsrc_t rs, const int art_bytes,
     float sv[K], lor[K], hir[K];
 #pragma unroll
     for (int k = 0; k < K; k++) { sv[k] = s[k]; lor[k] = lo[k] - f[k]; hir[k] = hi[k] - f[k]; }
+#if DN_DPP_CAPTURE
+    float svq[K][4];
+#pragma unroll
+    for (int k = 0; k < K; k++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) svq[k][i] = s[k];
+#endif
     unsigned long long m1 = 1ull; asm volatile("" : "+s"(m1));
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -364,15 +446,25 @@ DEV int dn_sweeps_resident(const __amdgpu_buffer_rsrc_t rs, const int art_bytes,
       for (int gg = 0; gg < 4; gg++) {
         const int g = 4 * k + gg;
         if (g < G) {
-          unsigned long long mask = m1 << (16 * gg);
+          [[maybe_unused]] unsigned long long mask = m1 << (16 * gg);
 #pragma unroll
           for (int r = 0; r < 16; r++) {
             const int l = 16 * gg + r;
             const float d = __builtin_amdgcn_fmed3f(s[k], lor[k], hir[k]);
             const float sd = readlane_f(d, l);
+#if DN_DPP_CAPTURE
+            dn_capture(svq[k], s[k], l);
+#else
             const bool me = __builtin_amdgcn_inverse_ballot_w64(mask);
             mask <<= 1;
             sv[k] = me ? s[k] : sv[k];
+#endif
+#if DN_RES_PLAIN
+            // (plain multiply-adds: the pair form needs a wait state in front of the med3 that reads its result and two behind the v_readlane
+            //  whose scalar it reads — as s_nops they are issue slots of a lone wave like any instruction; the off-chain multiply-add fills one)
+#pragma unroll
+            for (int j = 0; j < K; j++) s[j] = __builtin_fmaf(A[16 * g + r].v[j], sd, s[j]);
+#else
             typedef float dn_f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int j = 0; j + 1 < K; j += 2) {
@@ -381,6 +473,7 @@ DEV int dn_sweeps_resident(const __amdgpu_buffer_rsrc_t rs, const int art_bytes,
               s[j] = o2.x; s[j + 1] = o2.y;
             }
             if (K & 1) s[K - 1] = __builtin_fmaf(A[16 * g + r].v[K - 1], sd, s[K - 1]);
+#endif
           }
         }
       }
@@ -389,6 +482,9 @@ DEV int dn_sweeps_resident(const __amdgpu_buffer_rsrc_t rs, const int art_bytes,
     float imp = 0;
 #pragma unroll
     for (int k = 0; k < K; k++) {
+#if DN_DPP_CAPTURE
+      sv[k] = dn_captured(svq[k], lane);
+#endif
       const float dc = __builtin_amdgcn_fmed3f(sv[k], lor[k], hir[k]);
       imp += dc * arr[k] * (sv[k] - 0.5f * dc);
       f[k] += dc; s[k] -= dc;

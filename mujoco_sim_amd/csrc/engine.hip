@@ -15,10 +15,12 @@
 
 #include "../../include/mjhip.h"
 #include "step_kernel.h"
-#include "dense_pgs.h"
 
 void mjh_set_error(const std::string& s);  // model_builder.cpp
 hipError_t mjh_launch_window(hipStream_t st, int nvt, int grid, size_t lds, const DConst* dC, const DState& S, int env0, int n, int nl, int wxf, int n32, int n64);   // window.hip
+hipError_t mjh_dense_attributes(size_t build_lds, size_t solve_lds);   // dense.hip (kernels of dense_pgs.h)
+hipError_t mjh_launch_dense(hipStream_t st, int n, size_t build_lds, size_t solve_lds, const DConst* dC, const DState& S, int env0);
+#define DN_CAP_MAX 256          // row capacity of the dense solver (dense_pgs.h)
 
 #define HIPCHK(call)                                                                             \
   do {                                                                                           \
@@ -635,8 +637,7 @@ extern "C" int mjh_create(const mjh_model* m, int nenv, int device, void* stream
     e->dense_solve_lds = (DN_CAP_MAX + 128 + 2 * (size_t)e->M.nM) * sizeof(float);
     if (e->dense_lds > 160 * 1024 || e->dense_solve_lds > 160 * 1024) { e->M.dense = 0; }
     else {
-      HIPCHK(hipFuncSetAttribute((const void*)mjh_dense_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->dense_lds));
-      HIPCHK(hipFuncSetAttribute((const void*)mjh_dense_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->dense_solve_lds));
+      HIPCHK(mjh_dense_attributes(e->dense_lds, e->dense_solve_lds));
     }
   }
   MJH_ATTR(1, true); MJH_ATTR(2, true); MJH_ATTR(4, true); MJH_ATTR(8, true); MJH_ATTR(1, false); MJH_ATTR(2, false); MJH_ATTR(4, false); MJH_ATTR(8, false);
@@ -918,9 +919,7 @@ extern "C" int mjh_step(mjh_engine* e, int nsteps, int with_inverse) {
           if (!rc && dn) {
             // dense row-space solver (dense_pgs.h): AR = J M^-1 J^T on the matrix cores, then column sweeps, for every env of the
             // launch whose row count fits; the block solver below skips those envs (meta[7])
-            hipLaunchKernelGGL(mjh_dense_build_kernel, dim3(g1 - g0), dim3(DN_BUILD_THREADS), e->dense_lds, st, e->dC, e->S, g0);
-            hipLaunchKernelGGL(mjh_dense_solve_kernel, dim3(g1 - g0), dim3(64), e->dense_solve_lds, st, e->dC, e->S, g0);
-            HIPCHK(hipGetLastError());
+            HIPCHK(mjh_launch_dense(st, g1 - g0, e->dense_lds, e->dense_solve_lds, e->dC, e->S, g0));
           }
           if (!rc) {
             const size_t lds = (2 * (size_t)(((e->M.nv + 3) / 4) * 4) + 2 * (size_t)std::max(e->M.maxblk, 1) + 4 + 8 + 8 + 8 * (size_t)((e->M.nv + 2) / 3)) * sizeof(float);   // ... + the quad sweep's padded copies (four floats per 3 dofs, twice)   // 2 dof vectors + visiting order + group starts + per-wave partial sums
@@ -1708,9 +1707,7 @@ extern "C" int mjh_debug_stage_cycles(mjh_engine* e, int with_inverse, double* o
       const bool dn = e->M.dense != 0;
       rc = launch(e, 0, e->nenv, 1, ph | PH_PRE, (dn ? XF_DENSE : 0) | ((with_inverse & 2) ? XF_PROF : 0));
       if (!rc && dn) {
-        hipLaunchKernelGGL(mjh_dense_build_kernel, dim3(e->nenv), dim3(DN_BUILD_THREADS), e->dense_lds, e->stream, e->dC, e->S, 0);
-        hipLaunchKernelGGL(mjh_dense_solve_kernel, dim3(e->nenv), dim3(64), e->dense_solve_lds, e->stream, e->dC, e->S, 0);
-        HIPCHK(hipGetLastError());
+        HIPCHK(mjh_launch_dense(e->stream, e->nenv, e->dense_lds, e->dense_solve_lds, e->dC, e->S, 0));
       }
       if (!rc) {
         const size_t lds = (2 * (size_t)(((e->M.nv + 3) / 4) * 4) + 2 * (size_t)std::max(e->M.maxblk, 1) + 4 + 8 + 8 + 8 * (size_t)((e->M.nv + 2) / 3)) * sizeof(float);

@@ -6,6 +6,6 @@ N=$1; shift
 R=/root/repo; B=$R/mujoco_sim_amd/build; O=$R/build_exp/$N
 mkdir -p $O
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fno-slp-vectorize -Wno-unused-result -mllvm -pragma-unroll-threshold=200000 "$@" -c $R/mujoco_sim_amd/csrc/window.hip -o $O/window.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $B/engine.o $O/window.o $B/group.o $B/model_builder.o $B/scenes.o $B/host_sim.o $B/mjcf_loader.o -ldl -o $O/libmjhip.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $B/engine.o $O/window.o $B/dense.o $B/group.o $B/model_builder.o $B/scenes.o $B/host_sim.o $B/mjcf_loader.o -ldl -o $O/libmjhip.so
 rm -f $O/window.o
 bash $R/tools/kernel_resources.sh build_exp/$N/libmjhip.so 2>/dev/null | grep -i "window_kernelILi24"
