@@ -806,7 +806,9 @@ def main():
                    "lds_bytes_per_env": eng.lds_bytes, "contact_capacity": int(model.maxcon),
                    "pgs_order": ["legacy: independent pairs / groups of blocks (first fit)", "legacy: contact patches sorted by body pair (first fit)", "mj_solPGS row order"][eng.solver_order()],
                    "pgs_schedule": ["legacy reordering schedule", "precedence-preserving list schedule (bit-identical to the sequential sweep)", "sequential, one block after the other"][eng.pgs_schedule()],
-                   "solver_form": "contact patches (<= 16 rows of one body pair, <= 4 side by side)" if eng.patch_sweep() else "constraint blocks",
+                   "solver_form": ("window sweep: assemble launch + mjh_window_kernel (16 consecutive rows per window, four envs per wavefront; 64-row windows, one env per wavefront, for the envs with the most rows)" if eng.window_solver()
+                                   else "dense row-space sweeps (AR on the matrix cores) for cohorts with a long-sweeping env, constraint blocks elsewhere" if eng.dense_solver()
+                                   else "contact patches (<= 16 rows of one body pair, <= 4 side by side)" if eng.patch_sweep() else "constraint blocks"),
                    "timed_window_ms": elapsed * 1e3, **w.extra_config()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
