@@ -421,6 +421,11 @@ DEV int dn_sweeps_resident(const __amdgpu_buffer_rsrc_t rs, const int art_bytes,
     }
   }
   int niter = 0;
+#ifdef DN_REFRESH
+  float s0[K], f0[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) { s0[k] = s[k]; f0[k] = f[k]; }
+#endif
   // The sweep carries  r = s - f  and the projection interval relative to the force,  [lo - f, hi - f]  (f does not move inside a sweep: a row
   // is visited once), so that a row's delta  med3(s, lo, hi) - f  is ONE instruction,  med3(r, lo - f, hi - f): six instead of seven
   // VALU instructions per row at K = 3, and one less on the row-to-row chain (round 5: C4's dense solve launch 501 -> ~440 us).  Same
@@ -491,6 +496,30 @@ DEV int dn_sweeps_resident(const __amdgpu_buffer_rsrc_t rs, const int art_bytes,
     }
     const float improvement = wave_sum<4>(imp);
     if (improvement * scale < tol || niter >= itmax) break;
+#ifdef DN_REFRESH
+    // (accuracy probe: every DN_REFRESH sweeps the carried residual is formed anew from the start values and the force changes — what it drifts by)
+    if (niter % DN_REFRESH == 0) {
+      float acc[K], df[K];
+#pragma unroll
+      for (int k = 0; k < K; k++) { acc[k] = s0[k]; df[k] = f[k] - f0[k]; }
+#pragma unroll
+      for (int k = 0; k < K; k++)
+#pragma unroll
+        for (int gg = 0; gg < 4; gg++) {
+          const int g = 4 * k + gg;
+          if (g < G) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+              const float sd = readlane_f(df[k], 16 * gg + r);
+#pragma unroll
+              for (int j = 0; j < K; j++) acc[j] = __builtin_fmaf(A[16 * g + r].v[j], sd, acc[j]);
+            }
+          }
+        }
+#pragma unroll
+      for (int k = 0; k < K; k++) s[k] = acc[k] - f[k];
+    }
+#endif
   }
   return niter;
 }
