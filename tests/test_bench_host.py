@@ -80,7 +80,9 @@ def test_cpu_baseline_reports_a_thread_scaling_table():
     assert r["kind"] == "port" and r["cores"] == n == r["scaling"][-1]["threads"] and r["scaling"][0]["threads"] == 1
     assert r["env_steps_1thread"] >= 256, "the 1-thread figure must rest on a real sample"
     assert all(p["value"] > 0 and p["envs"] >= p["threads"] or p["envs"] == 32 for p in r["scaling"])
-    assert abs(r["mean_ncon"] - r["gpu_mean_ncon_same_envs"]) < 3, "the CPU leg starts from the state it was handed"
+    # (the leg steps its 32 envs for a time budget, so how far they have moved on depends on the host's speed: measured 1 .. 3.1 contacts of drift — a leg that
+    #  started from the reset state instead, boxes in the air, would be ~16 contacts off)
+    assert abs(r["mean_ncon"] - r["gpu_mean_ncon_same_envs"]) < 6, "the CPU leg starts from the state it was handed"
     # (no bound on the speed-up here: 32 envs on a shared CI host are too noisy a sample — the table is what the bench line carries)
     assert all("speedup_vs_1thread" in p for p in r["scaling"])
 
