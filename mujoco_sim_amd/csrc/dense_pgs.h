@@ -82,7 +82,7 @@ __global__ __launch_bounds__(DN_BUILD_THREADS) void mjh_dense_build_kernel(const
       const int nr = i < nblk ? (g_hd[g_ord[i]].x >> 4) & 15 : 0;
       const int incl = wave_incl_scan_i(nr, lane);
       if (i < nblk) s_start[i] = run + incl - nr;
-      run += __shfl(incl, 63);
+      run += wave_last_i(incl);
     }
   }
   __syncthreads();

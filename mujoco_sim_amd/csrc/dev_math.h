@@ -129,11 +129,27 @@ template <int NROW, int N> DEV void wave_sum4(float* v) {
 #pragma unroll
   for (int j = 0; j < N; j++) v[j] = readlane_f(v[j], src);
 }
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside every 16-lane row by four row shifts (lanes without a source add 0), then the rows'
+// totals handed on (lane 15 -> the next odd row, lane 31 -> rows 2 and 3).  Six data-parallel adds instead of six ds_bpermute round trips with a
+// select each (integers: the same sums in any order).  Every lane of the wave must be active.
+#ifndef MJH_DPP_SCAN
+#define MJH_DPP_SCAN 1
+#endif
 DEV int wave_incl_scan_i(int v, int lane) {
+#if MJH_DPP_SCAN
+  (void)lane;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true); v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return v;
+#else
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o); if (lane >= o) v += t; }
   return v;
+#endif
 }
+DEV int wave_last_i(int v) { return __builtin_amdgcn_readlane(v, 63); }      // lane 63's value in every lane (the total of an inclusive scan)
 DEV int wave_sum_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -118,7 +118,7 @@ DEV int patch_build(const PatchArgs& A, const int lane, int& flags, int& swork, 
   const int desc = lane < npatch ? (((pend - psize) >> 2) | (pn4 << 13) | (pdA << 16) | (pdB << 21)) : 0;
   const int tmask = lane < npatch ? ((1 << (pdA / 6)) | (pdB != 63 ? (1 << (pdB / 6)) : 0)) : 0;
   const int prow0 = prowend - 4 * pn4;
-  const int tot4 = min(__shfl(prowend, 63), 256);
+  const int tot4 = min(wave_last_i(prowend), 256);
   for (int g = lane; g < tot4; g += 64) s_rowmap[g] = -1;     // (rows of dropped patches stay unmapped)
   WSYNC();
   if (lane < npatch) { s_pdesc[lane] = desc; s_pinfo[lane] = prow0; }

@@ -1337,7 +1337,7 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
         // generic convex pairs (dev_convex.h): the lanes run the portal algorithm on their pairs, the wave serves their mesh scans
         if constexpr (EXTRA) { if (wave_any(cvx)) { const int nc = c_convex_wave(G1, G2, margin, st, cvx, lane); if (cvx) n = nc; } }
         const int incl = wave_incl_scan_i(n, lane);
-        const int total = __shfl(incl, 63);
+        const int total = wave_last_i(incl);
         const int first = conbase + incl - n;
         for (int q = 0; q < n; q++) {
           const int idx = first + q;
@@ -1447,7 +1447,7 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
           int r = incl - n;
           if (lo) { put_block(nblk + r, BK_SINGLE, 1, 1, 1, (nblk + r) * w4, j, RT_LIMIT, 0); r++; }
           if (hi) put_block(nblk + r, BK_SINGLE, 1, 1, 1, (nblk + r) * w4, j, RT_LIMIT, 1);
-          const int tot = __shfl(incl, 63);
+          const int tot = wave_last_i(incl);
           nblk += tot; nbrow += tot; nefc += tot;
         }
       }
@@ -1469,7 +1469,7 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
           put_block(nblk + sc - 1, dim == 1 ? BK_SINGLE : (dim == 3 ? BK_PYR3 : BK_PYR4), nr, nb, 1, (nfix + 4 * (nblk + sc - 1 - nfix)) * w4, ic, RT_CONTACT, 0);
         int last = 63;
         if (over) { flags |= 2; stop = true; last = firstover - 1; }
-        if (last >= 0) { nefc += __shfl(sr, last); nbrow += __shfl(sb, last); nblk += __shfl(sc, last); }
+        if (last >= 0) { const int ul = __builtin_amdgcn_readfirstlane(last); nefc += __builtin_amdgcn_readlane(sr, ul); nbrow += __builtin_amdgcn_readlane(sb, ul); nblk += __builtin_amdgcn_readlane(sc, ul); }   // (last is uniform: a v_readlane each instead of a ds_bpermute round trip)
       }
     }
     nefc = __builtin_amdgcn_readfirstlane(nefc); nblk = __builtin_amdgcn_readfirstlane(nblk); nbrow = __builtin_amdgcn_readfirstlane(nbrow);
@@ -1813,7 +1813,7 @@ step_again:      // (a backward goto instead of a `for`: the instances without t
             const int cnt = g < ngrp ? gcnt[g] : 0;
             const int incl = wave_incl_scan_i(cnt, lane);
             if (g < ngrp) s_sched_i[g] = carry + incl - cnt;
-            carry += __shfl(incl, 63);
+            carry += wave_last_i(incl);
           }
           if (lane == 0) s_sched_i[ngrp] = nblk;
           WSYNC();

@@ -74,7 +74,7 @@ DEV int window_emit(float* __restrict__ wb, const int nvt, const int maxw, const
   for (int b0 = 0; b0 < nblk; b0 += 64) {
     const int b = b0 + lane;
     const int myn = b < nblk ? (blki4[b].x >> 4) & 15 : 0;
-    total += __shfl(wave_incl_scan_i(myn, lane), 63);
+    total += wave_last_i(wave_incl_scan_i(myn, lane));
   }
   int nrow = total;
   if (nrow > 16 * maxw) {
@@ -90,7 +90,7 @@ DEV int window_emit(float* __restrict__ wb, const int nvt, const int maxw, const
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) cand = max(cand, __shfl_xor(cand, o));
       kept = max(kept, cand);
-      cum0 += __shfl(incl, 63);
+      cum0 += wave_last_i(incl);
     }
     nrow = kept;
   }
@@ -133,7 +133,7 @@ DEV int window_emit(float* __restrict__ wb, const int nvt, const int maxw, const
         o[16 * 15] = bf[0];
       }
     }
-    base += __shfl(incl, 63);
+    base += wave_last_i(incl);
   }
   return nrow;
 }
