@@ -42,6 +42,17 @@ template <class T> struct Tab {
   DEV T operator[](int i) const { return base[off + i]; }
   DEV const T* operator+(int k) const { return base + off + k; }
 };
+// ... or read through the model descriptor at the place of use (LAZY): the table's offset is a scalar load where the table is read instead of one of ~70 scalars
+// loaded at the kernel's entry and kept — spilled to vector-register lanes and reloaded by v_readlane — until their last use.  Per instance of the kernel: the
+// assemble-only instances of the window chain take it (S24's: 29.9 k -> 28.0 k instructions, 3 967 -> 2 274 v_readlane, 88 -> 264 scalar loads; states bitwise);
+// the other instances keep the eager form and their code (the many-body instances' rounding moves with it, C3 loses 2 %: HISTORY.md Round 6)
+template <bool LAZY, class T, int DModel::*OFF> struct XTab {
+  const DModel* m; const T* base; int off;
+  DEV explicit XTab(const DModel& M) : m(&M), base(nullptr), off(0) { if constexpr (!LAZY) { base = tb(); off = M.*OFF; } }
+  DEV const T* tb() const { if constexpr (T(1.5) == T(1)) return (const T*)m->I; else return (const T*)m->F; }
+  DEV T operator[](int i) const { if constexpr (LAZY) return tb()[m->*OFF + i]; else return base[off + i]; }
+  DEV const T* operator+(int k) const { if constexpr (LAZY) return tb() + (m->*OFF + k); else return base + off + k; }
+};
 
 // in-place x <- M^-1 x over one tree's contiguous dof range, x addressed by absolute dof index
 DEV void solve_tree(float* x, const float* qLD, const float* qLDinv, const int* dof_parentid, const int* dof_Madr, int adr, int num, const int STRIDE = 1) {
@@ -205,7 +216,8 @@ DEV void factor_short_step(float* qLD, float* qLDinv, const int* anc, const int*
   if (on && q <= d) qLD[Mk + q] = aq * inv;
   if (on && q == 1) qLDinv[k] = inv;
 }
-DEV void factor_trees_short(float* qLD, float* qLDinv, const int* anc, const int* dof_Madr, const Tab<int>& tree_dofadr, const Tab<int>& tree_dofnum,
+template <class TA, class TN>
+DEV void factor_trees_short(float* qLD, float* qLDinv, const int* anc, const int* dof_Madr, const TA& tree_dofadr, const TN& tree_dofnum,
                             const int ntree, const int nM, const int nv, const int lane) {
   const int q = 1 + (lane & 15), row = lane >> 4;
   for (int t0 = 0; t0 < ntree; t0 += 4) {
@@ -929,10 +941,13 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES_T) void mjh_step_kernel(const DC
 
   // model tables: one base pointer per element type + a kernarg-resident offset per table (kept as
   // (base, offset) pairs so that ~70 table addresses do not each pin an SGPR pair for the whole kernel)
-#define IT(n) const Tab<int> n{M.I, M.o_##n};
+#ifndef MJH_LAZY_TABLES
+#define MJH_LAZY_TABLES (WPRE != 0)
+#endif
+#define IT(n) const XTab<MJH_LAZY_TABLES, int, &DModel::o_##n> n(M);
   MJH_INT_TABLES(IT)
 #undef IT
-#define FT(n) const Tab<float> n{M.F, M.o_##n};
+#define FT(n) const XTab<MJH_LAZY_TABLES, float, &DModel::o_##n> n(M);
   MJH_FLT_TABLES(FT)
 #undef FT
   float* const gs = NROW == 8 ? S.gscratch + (size_t)env * (size_t)S.gstride : nullptr;   // many-body models: big pools in global memory
