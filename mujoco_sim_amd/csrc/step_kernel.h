@@ -54,6 +54,15 @@ template <bool LAZY, class T, int DModel::*OFF> struct XTab {
   DEV const T* operator+(int k) const { if constexpr (LAZY) return tb() + (m->*OFF + k); else return base + off + k; }
 };
 
+// the per-env LDS arrays the same way: `lds + L.n` formed where the array is used (LAZY) instead of 43 LDS addresses formed at the kernel's entry and kept
+template <bool LAZY, int Lay::*OFF> struct XArr {
+  float* p; const Lay* l; float* b;
+  DEV XArr(float* lds, const Lay& L) : p(nullptr), l(&L), b(lds) { if constexpr (!LAZY) p = lds + L.*OFF; }
+  DEV float* get() const { if constexpr (LAZY) return b + l->*OFF; else return p; }
+  DEV operator float*() const { return get(); }
+  template <class U> DEV explicit operator U*() const { return (U*)get(); }
+};
+
 // in-place x <- M^-1 x over one tree's contiguous dof range, x addressed by absolute dof index
 DEV void solve_tree(float* x, const float* qLD, const float* qLDinv, const int* dof_parentid, const int* dof_Madr, int adr, int num, const int STRIDE = 1) {
   for (int k = adr + num - 1; k >= adr; k--) {
@@ -952,7 +961,10 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES_T) void mjh_step_kernel(const DC
 #undef FT
   float* const gs = NROW == 8 ? S.gscratch + (size_t)env * (size_t)S.gstride : nullptr;   // many-body models: big pools in global memory
   // (compile-time choice per instantiation: the address space of every array is known to the compiler)
-#define LA(n) float* s_##n = lds + L.n;
+#ifndef MJH_LAZY_LDS
+#define MJH_LAZY_LDS (WPRE != 0)
+#endif
+#define LA(n) const XArr<MJH_LAZY_LDS, &Lay::n> s_##n(lds, L);
   MJH_LDS_SMALL(LA)
 #undef LA
 #define LA(n) float* s_##n = NROW == 8 ? gs + (-1 - L.n) : lds + L.n;
