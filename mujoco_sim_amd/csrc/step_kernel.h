@@ -935,7 +935,14 @@ template <int NROW, bool DIAGM, bool EXTRA, int WPRE = 0>
 #define MJH_WPRE_WAVES 2
 #endif
 #define MJH_STEP_WAVES_T (WPRE ? MJH_WPRE_WAVES : MJH_STEP_WAVES)
-__global__ __launch_bounds__(64, MJH_STEP_WAVES_T) void mjh_step_kernel(const DConst* __restrict__ C, const DState S, int env0, int nsteps, int ph, int xflags) {
+__global__ __launch_bounds__(64, MJH_STEP_WAVES_T) void mjh_step_kernel(const DConst* __restrict__ C, const DState S_arg, int env0, int nsteps, int ph, int xflags) {
+  // the device-state descriptor (32 scalars: the pointers of the per-env arrays): by value in the kernel-argument segment.  As a plain argument all of it is
+  // loaded at the kernel's entry, and what the LAST stage stores through is spilled across the whole kernel; the assemble-only instances of the window chain
+  // read it through the segment pointer where a field is used (same segment, same values)
+#ifndef MJH_LAZY_STATE
+#define MJH_LAZY_STATE (WPRE != 0)
+#endif
+  const DState& S = MJH_LAZY_STATE ? *(const DState*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(const DConst*)) : S_arg;
   // model descriptor + LDS layout live in device memory (uploaded once): uniform scalar loads on demand instead
   // of a by-value kernarg struct that the lambdas below would force into a private (scratch) copy
   const DModel& M = C->M;
