@@ -940,7 +940,7 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES_T) void mjh_step_kernel(const DC
   // loaded at the kernel's entry, and what the LAST stage stores through is spilled across the whole kernel; the assemble-only instances of the window chain
   // read it through the segment pointer where a field is used (same segment, same values)
 #ifndef MJH_LAZY_STATE
-#define MJH_LAZY_STATE (WPRE != 0)
+#define MJH_LAZY_STATE true
 #endif
   const DState& S = MJH_LAZY_STATE ? *(const DState*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(const DConst*)) : S_arg;
   // model descriptor + LDS layout live in device memory (uploaded once): uniform scalar loads on demand instead
@@ -958,7 +958,7 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES_T) void mjh_step_kernel(const DC
   // model tables: one base pointer per element type + a kernarg-resident offset per table (kept as
   // (base, offset) pairs so that ~70 table addresses do not each pin an SGPR pair for the whole kernel)
 #ifndef MJH_LAZY_TABLES
-#define MJH_LAZY_TABLES (WPRE != 0)
+#define MJH_LAZY_TABLES (WPRE != 0 || (!DIAGM && NROW <= 4 && EXTRA))
 #endif
 #define IT(n) const XTab<MJH_LAZY_TABLES, int, &DModel::o_##n> n(M);
   MJH_INT_TABLES(IT)
