@@ -664,7 +664,8 @@ def main():
 
     # the other configs first, each in a process of its own, while this process has not created a stream yet (child_config_line)
     with_extras = rank == 0 and world == 1 and args.config == "s24" and not args.no_extra_configs and not args.force_dist
-    extras = extra_config_lines(args) if with_extras else None
+    extras_last = os.environ.get("BENCH_EXTRAS_LAST", "0") == "1"
+    extras = extra_config_lines(args) if (with_extras and not extras_last) else None
 
     import torch
     import torch.distributed as dist
@@ -854,6 +855,8 @@ def main():
     if use_dist:
         dist.barrier()
     eng.close()
+    if with_extras and extras_last:
+        extras = extra_config_lines(args)
     if extras is not None:
         out["configs"] = extras
         d = extras.get("s24d", {})
