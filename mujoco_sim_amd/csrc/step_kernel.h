@@ -50,7 +50,11 @@ template <bool LAZY, class T, int DModel::*OFF> struct XTab {
   const DModel* m; const T* base; int off;
   DEV explicit XTab(const DModel& M) : m(&M), base(nullptr), off(0) { if constexpr (!LAZY) { base = tb(); off = M.*OFF; } }
   DEV const T* tb() const { if constexpr (T(1.5) == T(1)) return (const T*)m->I; else return (const T*)m->F; }
+#ifdef MJH_TAB_PROBE_L2     // probe: every table read of the lazy instances past the L1 (volatile: glc) — what a table read's latency is worth to the assemble launch
+  DEV T operator[](int i) const { if constexpr (LAZY) return *(volatile const T*)(tb() + (m->*OFF + i)); else return base[off + i]; }
+#else
   DEV T operator[](int i) const { if constexpr (LAZY) return tb()[m->*OFF + i]; else return base[off + i]; }
+#endif
   DEV const T* operator+(int k) const { if constexpr (LAZY) return tb() + (m->*OFF + k); else return base + off + k; }
 };
 
