@@ -946,6 +946,7 @@ __global__ __launch_bounds__(64, MJH_STEP_WAVES_T) void mjh_step_kernel(const DC
 #ifndef MJH_LAZY_STATE
 #define MJH_LAZY_STATE true
 #endif
+  static_assert(alignof(DState) <= alignof(const DConst*), "the descriptor follows the first argument in the kernel-argument segment without padding");
   const DState& S = MJH_LAZY_STATE ? *(const DState*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(const DConst*)) : S_arg;
   // model descriptor + LDS layout live in device memory (uploaded once): uniform scalar loads on demand instead
   // of a by-value kernarg struct that the lambdas below would force into a private (scratch) copy
